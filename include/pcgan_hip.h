@@ -1,0 +1,147 @@
+/*
+ * pcgan_hip.h — C ABI of libpcgan_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * Generator/Discriminator training step of flash4242/Promptable-Counterfactual-GAN.
+ *
+ * The reference has no FFI of its own: every FLOP of its hot path is a torch.nn / torch.optim call
+ * (SURVEY.md §8b).  Each entry point below therefore cites the reference call site whose ATen
+ * operator it replaces; the Python shim (promptable-counterfactual-gan_amd/) binds them with ctypes
+ * and hands over `tensor.data_ptr()` of PyTorch-ROCm tensors.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types; no exceptions.  Every function returns PCG_OK (0)
+ *    or a negative pcg_status; pcg_last_error() gives the text for the calling thread.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises, nothing
+ *    allocates: every buffer, including workspaces, is owned by the caller and only borrowed until
+ *    the enqueued work has run.  All launches are hipGraph-capturable.
+ *  - Activations are fp32 NHWC  [B][H][W][C]  (PyTorch: torch.channels_last tensors of shape [B,C,H,W]).
+ *    Conv2d weights are fp32 OHWI [Cout][KH][KW][Cin] (PyTorch: channels_last tensor [Cout,Cin,KH,KW]);
+ *    ConvTranspose2d weights [Cin][KH][KW][Cout] (channels_last tensor [Cin,Cout,KH,KW]) — which is
+ *    the OHWI weight of the adjoint convolution, so one geometry struct serves both layer kinds:
+ *        Conv2d           forward = pcg_conv2d_fwd,   grad-input = pcg_conv2d_dgrad, grad-weight = pcg_conv2d_wgrad
+ *        ConvTranspose2d  forward = pcg_conv2d_dgrad, grad-input = pcg_conv2d_fwd,   grad-weight = pcg_conv2d_wgrad
+ *    (for the transposed layer, `x` of the geometry is the layer's OUTPUT side and `y` its INPUT side).
+ *  - Labels / class indices are int64 (torch.long), as in the reference.
+ */
+#ifndef PCGAN_HIP_H
+#define PCGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pcg_stream_t; /* hipStream_t */
+
+typedef enum pcg_status {
+  PCG_OK = 0,
+  PCG_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  PCG_ERR_WORKSPACE = -2,   /* workspace too small */
+  PCG_ERR_LAUNCH = -3,      /* HIP launch error */
+  PCG_ERR_UNSUPPORTED = -4
+} pcg_status;
+
+typedef enum pcg_act {
+  PCG_ACT_NONE = 0,
+  PCG_ACT_RELU = 1,
+  PCG_ACT_LRELU = 2,   /* slope given separately */
+  PCG_ACT_TANH = 3,
+  PCG_ACT_SIGMOID = 4
+} pcg_act;
+
+/* y[b,oh,ow,co] = bias[co] + sum_{kh,kw,ci} x[b, oh*stride-pad+kh, ow*stride-pad+kw, ci] * w[co,kh,kw,ci] */
+typedef struct pcg_conv_geom {
+  int32_t B;
+  int32_t IH, IW, Cin;   /* x: [B][IH][IW][Cin]  */
+  int32_t OH, OW, Cout;  /* y: [B][OH][OW][Cout] */
+  int32_t KH, KW, stride, pad;
+} pcg_conv_geom;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int pcg_abi_version(void);
+const char* pcg_last_error(void);
+/* "gfx950" — the only code object in the library */
+const char* pcg_target_arch(void);
+
+/* ---- convolution family (MFMA f32 implicit GEMM; thin Cin==1 / Cout==1 layers on the vector ALU) -
+ * replaces nn.Conv2d / nn.ConvTranspose2d forward + autograd:
+ *   dconv_gan/mnist/mnist_dcgan.py:76-88 (G ConvT stack), :100-111 (D Conv stack);
+ *   conditional_counteRGAN/mnist/models/generator.py:11-14,39,49-50; models/discriminator.py:14-24;
+ *   models/classifier.py:7-12.                                                                    */
+int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias /*nullable*/,
+                   float* y, pcg_stream_t stream);
+int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x /*nullable: added per Cin channel (ConvTranspose2d bias)*/,
+                     float* dx, pcg_stream_t stream);
+size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g);
+/* dw[co,kh,kw,ci] (+)= sum_{b,oh,ow} dy[b,oh,ow,co] * x[b,oh*s-p+kh,ow*s-p+kw,ci];  accumulate!=0 adds into dw
+ * (the reference accumulates .grad over two backward() calls: mnist_dcgan.py:153,161).             */
+int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
+                     void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */
+size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C);
+int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate,
+               void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
+/* ---- BatchNorm (training mode) + activation --------------------------------------------------
+ * replaces nn.BatchNorm2d(train) + nn.ReLU / nn.LeakyReLU(0.2): mnist_dcgan.py:77-87,103-110;
+ * models/generator.py:12-15,18-20 (counteRGAN _ResBlock).  [torch] semantics: normalise with the
+ * biased batch variance, eps inside the sqrt, running_var updated with the unbiased variance,
+ * running = (1-momentum)*running + momentum*batch.                                                 */
+size_t pcg_bn_workspace_bytes(int64_t rows, int32_t C);
+/* stats over rows = B*H*W of x[rows][C]: writes save_mean[C], save_invstd[C]; updates running_* if non-null */
+int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float eps, float momentum,
+                       float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked /*nullable: += 1*/,
+                       void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* y = act( (x-mean)*invstd*gamma + beta ).  var_eps < 0: `invstd_or_var` holds invstd (training: save_invstd);
+ * var_eps >= 0: it holds a variance and invstd = rsqrt(var + var_eps) (eval mode: running_var, eps).   */
+int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd_or_var,
+                     float var_eps, const float* gamma, const float* beta, int act, float slope, float* y,
+                     pcg_stream_t stream);
+/* backward of y = act(bn(x)):  given dy (grad wrt y), x (pre-BN), y (post-activation: the sign mask)
+ *   dgamma (+)= sum dz*xhat ; dbeta (+)= sum dz ; dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
+ *   dz = dy*act'(.)     ([torch] LeakyReLU/ReLU sub-gradient at 0 is the negative-side one: uses y>0) */
+int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C,
+                   const float* mean, const float* invstd, const float* gamma,
+                   int act, float slope, float* dx, float* dgamma, float* dbeta, int accumulate,
+                   void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
+/* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
+ * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */
+int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream);
+/* dx = dy * act'(.) expressed through the OUTPUT y (relu/lrelu: y>0; tanh: 1-y^2; sigmoid: y(1-y)) */
+int pcg_act_bwd(const float* dy, const float* y, int64_t n, int act, float slope, float* dx, pcg_stream_t stream);
+
+/* ---- losses ----------------------------------------------------------------------------------
+ * nn.BCELoss (mean): mnist_dcgan.py:125,152,160,172  ([torch]: log clamped at -100; backward
+ * (p-t)/max(p(1-p),1e-12)/n).  loss is one float on the device; dp may be null (forward only).     */
+int pcg_bce_fwd_bwd(const float* p, const float* target /*nullable → target_const*/, float target_const,
+                    int64_t n, float grad_scale, float* loss, float* dp, pcg_stream_t stream);
+/* nn.BCEWithLogitsLoss (mean): conditional_counteRGAN/mnist/trainer.py:79,106-107,117              */
+int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale,
+                           float* loss, float* dz, pcg_stream_t stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------
+ * torch.optim.Adam over one flat fp32 parameter buffer: mnist_dcgan.py:126-127,164,175;
+ * mnist/trainer.py:77-78,112,123.  [torch] non-amsgrad, eps outside the sqrt of the bias-corrected
+ * second moment: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step` is the 1-based step count.   */
+int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                  int64_t step, pcg_stream_t stream);
+
+/* hipGraph-capturable form: the step count lives on the device (*step_counter_dev is incremented by the
+ * call) and the bias corrections are computed there in fp64; hyper_scratch2_dev is 2 floats of scratch. */
+int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                             int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream);
+
+/* ---- helpers ---------------------------------------------------------------------------------- */
+int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);
+/* out[0] (+)= sum p[i]^2   (grad_norm diagnostic: mnist/trainer.py:41-42) */
+int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGAN_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libpcgan_hip.so (the C ABI declared in include/pcgan_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this module raises.  `import torch`
+happens first on purpose — PyTorch-ROCm ships its own libamdhip64.so.7, and the dynamic linker must
+resolve our library's HIP runtime to that already-loaded copy so that streams and device pointers are
+shared with PyTorch.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime this process will use)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcgan_hip.so")
+
+PCG_OK = 0
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+
+
+class PcgError(RuntimeError):
+    pass
+
+
+class ConvGeom(ctypes.Structure):
+    """pcg_conv_geom (include/pcgan_hip.h)."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "IH", "IW", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad")]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_c = ctypes
+_vp, _f, _i, _i64, _sz = _c.c_void_p, _c.c_float, _c.c_int, _c.c_int64, _c.c_size_t
+_gp = _c.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); every symbol include/pcgan_hip.h declares
+PROTOTYPES = {
+    "pcg_abi_version": (_i, []),
+    "pcg_last_error": (_c.c_char_p, []),
+    "pcg_target_arch": (_c.c_char_p, []),
+    "pcg_conv2d_fwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_conv2d_dgrad": (_i, [_gp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
+    "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_colsum_workspace_bytes": (_sz, [_i64, _c.c_int32]),
+    "pcg_colsum": (_i, [_vp, _i64, _c.c_int32, _vp, _i, _vp, _sz, _vp]),
+    "pcg_bn_workspace_bytes": (_sz, [_i64, _c.c_int32]),
+    "pcg_bn_train_stats": (_i, [_vp, _i64, _c.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_bn_apply_act": (_i, [_vp, _i64, _c.c_int32, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp]),
+    "pcg_bn_act_bwd": (_i, [_vp, _vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_act_fwd": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
+    "pcg_act_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
+    "pcg_bce_fwd_bwd": (_i, [_vp, _vp, _f, _i64, _f, _vp, _vp, _vp]),
+    "pcg_bce_logits_fwd_bwd": (_i, [_vp, _f, _i64, _f, _vp, _vp, _vp]),
+    "pcg_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _vp]),
+    "pcg_adam_step_capturable": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
+    "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once) and attach prototypes.  Raises PcgError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PcgError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {os.path.join(_HERE, 'csrc')}` — there is no CPU/PyTorch fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != PCG_OK:
+        msg = load().pcg_last_error().decode("utf-8", "replace")
+        raise PcgError(f"{what or 'libpcgan_hip'} failed (status {rc}): {msg}")

@@ -1,0 +1,348 @@
+// batchnorm.hip — training-mode BatchNorm (+ fused ReLU / LeakyReLU) forward and backward, and the
+// per-channel column sums they are built from.  All HBM-bound: x[rows][C] (NHWC flattened) is streamed
+// with 16-byte lane accesses; per-channel sums are reduced per thread -> through LDS per block -> as
+// per-block partial rows that a finalize kernel adds in a fixed order in fp64 (bitwise reproducible, no
+// float atomics).  Replaces nn.BatchNorm2d + nn.ReLU/nn.LeakyReLU at mnist_dcgan.py:77-87,103-110 and
+// conditional_counteRGAN/mnist/models/generator.py:12-20; [torch] semantics cited in pcgan_hip.h.
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+constexpr int CR_THREADS = 256;
+constexpr int CR_MAX_BLOCKS = 1024;
+
+struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
+
+ColPlan plan_cols(int64_t rows, int C, bool aligned16) {
+  ColPlan p;
+  p.vec = (C % 4 == 0 && aligned16) ? 4 : 1;
+  p.CG = C / p.vec;
+  int tx = 1;
+  while (tx * 2 <= p.CG && tx * 2 <= CR_THREADS) tx *= 2;
+  p.TX = tx;
+  p.TY = CR_THREADS / tx;
+  // >= 4 rows per thread, <= CR_MAX_BLOCKS blocks
+  int64_t rpb = ceil_div64(rows, CR_MAX_BLOCKS);
+  const int64_t min_rpb = (int64_t)p.TY * 4;
+  if (rpb < min_rpb) rpb = min_rpb;
+  p.rows_per_block = (int)rpb;
+  p.nblocks = (int)ceil_div64(rows, rpb);
+  if (p.nblocks < 1) p.nblocks = 1;
+  return p;
+}
+
+// ---- element functors: NVAL per-channel quantities for VEC consecutive channels of one row --------
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, size_t idx, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p + idx);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    v[0] = p[idx];
+  }
+}
+struct FnStats {  // sum x, sum x^2
+  static constexpr int NVAL = 2;
+  const float* x;
+  template <int VEC>
+  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
+    (void)c0;
+    float v[VEC];
+    ldv<VEC>(x, idx, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { o[0][e] = v[e]; o[1][e] = v[e] * v[e]; }
+  }
+};
+struct FnSum {  // sum dy
+  static constexpr int NVAL = 1;
+  const float* x;
+  template <int VEC>
+  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[1][VEC]) const {
+    (void)c0;
+    ldv<VEC>(x, idx, o[0]);
+  }
+};
+struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy*act'(y)
+  static constexpr int NVAL = 2;
+  const float* dy; const float* x; const float* y; const float* mean; const float* invstd;
+  int act; float slope;
+  template <int VEC>
+  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
+    float g[VEC], xv[VEC], yv[VEC];
+    ldv<VEC>(dy, idx, g); ldv<VEC>(x, idx, xv); ldv<VEC>(y, idx, yv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float dz = g[e] * act_grad_from_out(yv[e], act, slope);
+      const float xh = (xv[e] - mean[c0 + e]) * invstd[c0 + e];
+      o[0][e] = dz; o[1][e] = dz * xh;
+    }
+  }
+};
+
+// partial[blk][k][C]
+template <int VEC, class Fn>
+__global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t rows, int C, int CG, int TX, int TY,
+                                                               int rows_per_block, float* __restrict__ partial) {
+  constexpr int NVAL = Fn::NVAL;
+  __shared__ float red[NVAL * VEC * CR_THREADS];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  const int passes = (CG + TX - 1) / TX;
+  for (int ps = 0; ps < passes; ++ps) {
+    const int cg = ps * TX + tx;
+    const bool cok = cg < CG;
+    float acc[NVAL][VEC];
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
+    if (cok) {
+      for (int64_t r = r0 + ty; r < r1; r += TY) {
+        float o[NVAL][VEC];
+        fn.template eval<VEC>((size_t)r * C + (size_t)cg * VEC, cg * VEC, o);
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[k][e] += o[k][e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[(k * VEC + e) * CR_THREADS + threadIdx.x] = acc[k][e];
+    __syncthreads();
+    if (ty == 0 && cok) {
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s = 0.f;
+          for (int j = 0; j < TY; ++j) s += red[(k * VEC + e) * CR_THREADS + j * TX + tx];
+          partial[((size_t)blockIdx.x * NVAL + k) * C + cg * VEC + e] = s;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double inv_rows,
+                                         double unbias, float eps, float momentum, float* save_mean, float* save_invstd,
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s += (double)partial[((size_t)b * 2 + 0) * C + c];
+    q += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const double mean = s * inv_rows;
+  double var = q * inv_rows - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+// coef[0][c] = gamma*invstd ; coef[1][c] = mean(dz) ; coef[2][c] = mean(dz*xhat)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double inv_rows,
+                                       const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s1 += (double)partial[((size_t)b * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+  coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+  coef[C + c] = (float)(s1 * inv_rows);
+  coef[2 * C + c] = (float)(s2 * inv_rows);
+}
+
+// ---- elementwise passes (float4 when C % 4 == 0) -------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_apply_act_kernel(const float* __restrict__ x, size_t n, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float var_eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int act, float slope, float* __restrict__ y) {
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * VEC) % (size_t)C);
+    float v[VEC];
+    if constexpr (VEC == 4) {
+      const float4 q = reinterpret_cast<const float4*>(x)[i];
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = x[i];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = c0 + e;
+      const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[c] + var_eps) : invstd[c];
+      const float sc = (gamma ? gamma[c] : 1.f) * is;
+      const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+      v[e] = act_apply(fmaf(v[e], sc, sh), act, slope);
+    }
+    if constexpr (VEC == 4) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    else y[i] = v[0];
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, size_t n, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, int act, float slope,
+                                                           float* __restrict__ dx) {
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * VEC) % (size_t)C);
+    float g[VEC], xv[VEC], yv[VEC];
+    if constexpr (VEC == 4) {
+      const float4 a = reinterpret_cast<const float4*>(dy)[i];
+      const float4 b = reinterpret_cast<const float4*>(x)[i];
+      const float4 c = reinterpret_cast<const float4*>(y)[i];
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
+      xv[0] = b.x; xv[1] = b.y; xv[2] = b.z; xv[3] = b.w;
+      yv[0] = c.x; yv[1] = c.y; yv[2] = c.z; yv[3] = c.w;
+    } else {
+      g[0] = dy[i]; xv[0] = x[i]; yv[0] = y[i];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = c0 + e;
+      const float dz = g[e] * act_grad_from_out(yv[e], act, slope);
+      const float xh = (xv[e] - mean[c]) * invstd[c];
+      g[e] = coef[c] * (dz - coef[C + c] - xh * coef[2 * C + c]);
+    }
+    if constexpr (VEC == 4) reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    else dx[i] = g[0];
+  }
+}
+
+template <class Fn>
+int launch_colreduce(const Fn& fn, int64_t rows, int C, const ColPlan& cp, float* partial, hipStream_t s) {
+  if (cp.vec == 4)
+    hipLaunchKernelGGL((colreduce_kernel<4, Fn>), dim3(cp.nblocks), dim3(CR_THREADS), 0, s, fn, rows, C, cp.CG, cp.TX, cp.TY,
+                       cp.rows_per_block, partial);
+  else
+    hipLaunchKernelGGL((colreduce_kernel<1, Fn>), dim3(cp.nblocks), dim3(CR_THREADS), 0, s, fn, rows, C, cp.CG, cp.TX, cp.TY,
+                       cp.rows_per_block, partial);
+  return launch_status("colreduce_kernel");
+}
+
+unsigned ew_blocks(size_t nv) {
+  size_t b = (nv + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" size_t pcg_bn_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  // partial[nblocks][2][C] + coef[3][C]; the plan with vec=1 never has more blocks than vec=4
+  const ColPlan a = plan_cols(rows, C, true), b = plan_cols(rows, C, false);
+  const int nb = a.nblocks > b.nblocks ? a.nblocks : b.nblocks;
+  return ((size_t)nb * 2 * C + 3 * (size_t)C) * sizeof(float);
+}
+extern "C" size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C) { return pcg_bn_workspace_bytes(rows, C); }
+
+extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float eps, float momentum, float* save_mean,
+                                  float* save_invstd, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                                  pcg_stream_t stream) {
+  PCG_REQUIRE(x && save_mean && save_invstd && rows > 0 && C > 0, "pcg_bn_train_stats: bad arguments");
+  if (!workspace || workspace_bytes < pcg_bn_workspace_bytes(rows, C)) {
+    set_error("pcg_bn_train_stats: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_workspace_bytes(rows, C));
+    return PCG_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const ColPlan cp = plan_cols(rows, C, al16(x));
+  float* partial = (float*)workspace;
+  FnStats fn{x};
+  if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C,
+                     1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                     num_batches_tracked);
+  return launch_status("bn_stats_finalize_kernel");
+}
+
+extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                float var_eps, const float* gamma, const float* beta, int act, float slope, float* y,
+                                pcg_stream_t stream) {
+  PCG_REQUIRE(x && y && mean && invstd && rows > 0 && C > 0, "pcg_bn_apply_act: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)rows * C;
+  if (C % 4 == 0 && al16(x) && al16(y))
+    hipLaunchKernelGGL(bn_apply_act_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, y);
+  else
+    hipLaunchKernelGGL(bn_apply_act_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, y);
+  return launch_status("bn_apply_act_kernel");
+}
+
+extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
+                              const float* invstd, const float* gamma, int act, float slope, float* dx, float* dgamma,
+                              float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && y && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
+  if (!workspace || workspace_bytes < pcg_bn_workspace_bytes(rows, C)) {
+    set_error("pcg_bn_act_bwd: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_workspace_bytes(rows, C));
+    return PCG_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const bool aligned = al16(dy) && al16(x) && al16(y) && al16(dx);
+  const ColPlan cp = plan_cols(rows, C, aligned);
+  float* partial = (float*)workspace;
+  float* coef = partial + (size_t)cp.nblocks * 2 * C;
+  FnBnBwd fn{dy, x, y, mean, invstd, act, slope};
+  if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C,
+                     1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
+  const size_t n = (size_t)rows * C;
+  if (C % 4 == 0 && aligned)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
+                       (const float*)coef, act, slope, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
+                       (const float*)coef, act, slope, dx);
+  return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate, void* workspace,
+                          size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && db && rows > 0 && C > 0, "pcg_colsum: bad arguments");
+  if (!workspace || workspace_bytes < pcg_colsum_workspace_bytes(rows, C)) {
+    set_error("pcg_colsum: workspace %zu B < required %zu B", workspace_bytes, pcg_colsum_workspace_bytes(rows, C));
+    return PCG_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const ColPlan cp = plan_cols(rows, C, al16(dy));
+  float* partial = (float*)workspace;
+  FnSum fn{dy};
+  if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
+  return launch_status("colsum_finalize_kernel");
+}

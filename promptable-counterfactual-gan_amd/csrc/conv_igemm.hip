@@ -1,0 +1,584 @@
+// conv_igemm.hip — Conv2d / ConvTranspose2d forward, grad-input and grad-weight as fp32-MFMA implicit
+// GEMMs over NHWC activations and OHWI weights (see include/pcgan_hip.h for the layer <-> op mapping).
+//
+//   fwd   : M = B*OH*OW        N = Cout          K = (kh,kw,ci)     A = im2col(x) gathered, B = w rows
+//   dgrad : per sub-pixel phase (ih%s, iw%s):  M = B*PHh*PHw  N = Cin  K = (taps of the phase, co)
+//           A = dy gathered, B = w^T slices.  For k4 s2 p1 every phase sees exactly 2x2 taps: no MAC is
+//           spent on the zeros a "dilate then convolve" formulation would insert.
+//   wgrad : M = Cout  N = (kh,kw,ci)  K = B*OH*OW split over gridDim.y; partial slabs reduced in a
+//           fixed order by a second kernel (deterministic; also implements .grad accumulation).
+//
+// Replaces ATen conv forward/backward behind nn.Conv2d / nn.ConvTranspose2d at
+// dconv_gan/mnist/mnist_dcgan.py:76-88,100-111 and conditional_counteRGAN/mnist/models/*.py.
+#include "igemm_core.h"
+#include "thin_conv.h"
+
+namespace pcg {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// parameter blocks (passed by value as kernel arguments)
+// ------------------------------------------------------------------------------------------------
+struct ConvP {
+  const float* x;    // fwd: input          dgrad: dx (output, written)   wgrad: input
+  const float* w;
+  const float* bias; // fwd: per-Cout       dgrad: per-Cin (nullable)
+  float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
+  const float* dy;   // dgrad / wgrad
+  int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int M, N;          // GEMM extents of this launch (fwd: B*OH*OW, Cout)
+  int tilesN;
+  int ktiles;        // fwd: KH*KW*ceil(Cin/32)
+  FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition
+};
+
+struct PhaseInfo {
+  int ph, pw;          // phase offsets (ih % s, iw % s)
+  int PHh, PHw;        // phase grid
+  int Mp;              // B*PHh*PHw
+  int kh0, kw0;        // first tap of the phase
+  int nth, ntw;        // taps per axis
+  int dh0, dw0;        // oh = a + dh0 - jh ; ow = c + dw0 - jw
+  FastDiv dPHw, dPHh;
+};
+struct DgradPhases { PhaseInfo p[4]; };
+
+// ------------------------------------------------------------------------------------------------
+// loaders
+// ------------------------------------------------------------------------------------------------
+template <int ROWS_>
+struct FwdALoader {  // im2col rows of x, k-contiguous (NHWC): K-major
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  const float* x;
+  int IH, IW, Cin, KW;
+  int pix0[NV], ih0[NV], iw0[NV];
+  int kh, kw, ci0, kq;
+
+  __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block) {
+    x = p.x; IH = p.IH; IW = p.IW; Cin = p.Cin; KW = p.KW;
+    kq = threadIdx.x & 7;
+    const int r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m_block + r0 + 32 * i;
+      if (m < p.M) {
+        uint32_t t, ow, b, oh;
+        p.dOW.divmod((uint32_t)m, t, ow);
+        p.dOH.divmod(t, b, oh);
+        pix0[i] = (int)b * IH * IW;
+        ih0[i] = (int)oh * p.stride - p.pad;
+        iw0[i] = (int)ow * p.stride - p.pad;
+      } else {
+        pix0[i] = 0; ih0[i] = -(1 << 28); iw0[i] = 0;
+      }
+    }
+    kh = 0; kw = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const bool kok = ci0 + 4 * kq < Cin;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int ih = ih0[i] + kh, iw = iw0[i] + kw;
+      const bool ok = kok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+      if (ok) {
+        const size_t off = (size_t)(pix0[i] + ih * IW + iw) * (size_t)Cin + (size_t)(ci0 + 4 * kq);
+        v[i] = *reinterpret_cast<const float4*>(x + off);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    ci0 += IG_BK;
+    if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+  }
+};
+
+template <int ROWS_>
+struct FwdBLoader {  // OHWI weight rows, k-contiguous: K-major
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  const float* wrow[NV];  // nullptr if n >= N
+  int Cin, tapoff, ci0, kq;
+
+  __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block) {
+    Cin = p.Cin; kq = threadIdx.x & 7;
+    const int r0 = threadIdx.x >> 3;
+    const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int n = n_block + r0 + 32 * i;
+      wrow[i] = n < p.N ? p.w + (size_t)n * Ktot : nullptr;
+    }
+    tapoff = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const bool kok = ci0 + 4 * kq < Cin;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (kok && wrow[i]) v[i] = *reinterpret_cast<const float4*>(wrow[i] + tapoff + ci0 + 4 * kq);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    ci0 += IG_BK;
+    if (ci0 >= Cin) { ci0 = 0; tapoff += Cin; }
+  }
+};
+
+// tap iterator shared by the two dgrad loaders: k-tiles run over (jh, jw, co-chunk)
+struct DgradTapIter {
+  int Cout, ntw, jw, co0;
+  int jh;
+  __device__ __forceinline__ void init(int Cout_, int ntw_) { Cout = Cout_; ntw = ntw_; jh = 0; jw = 0; co0 = 0; }
+  __device__ __forceinline__ void advance() {
+    co0 += IG_BK;
+    if (co0 >= Cout) { co0 = 0; if (++jw == ntw) { jw = 0; ++jh; } }
+  }
+};
+
+template <int ROWS_>
+struct DgradALoader {  // dy rows gathered for one sub-pixel phase, k = co contiguous: K-major
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  const float* dy;
+  int OH, OW, Cout, dh0, dw0, kq;
+  int pix0[NV], a[NV], c[NV];
+  DgradTapIter it;
+
+  __device__ __forceinline__ DgradALoader(const ConvP& p, const PhaseInfo& f, int m_block) {
+    dy = p.dy; OH = p.OH; OW = p.OW; Cout = p.Cout; dh0 = f.dh0; dw0 = f.dw0;
+    kq = threadIdx.x & 7;
+    const int r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m_block + r0 + 32 * i;
+      if (m < f.Mp) {
+        uint32_t t, cc, b, aa;
+        f.dPHw.divmod((uint32_t)m, t, cc);
+        f.dPHh.divmod(t, b, aa);
+        pix0[i] = (int)b * OH * OW; a[i] = (int)aa; c[i] = (int)cc;
+      } else {
+        pix0[i] = 0; a[i] = -(1 << 28); c[i] = 0;
+      }
+    }
+    it.init(Cout, f.ntw);
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const bool kok = it.co0 + 4 * kq < Cout;
+    const int dh = dh0 - it.jh, dw = dw0 - it.jw;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int oh = a[i] + dh, ow = c[i] + dw;
+      const bool ok = kok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+      if (ok) {
+        const size_t off = (size_t)(pix0[i] + oh * OW + ow) * (size_t)Cout + (size_t)(it.co0 + 4 * kq);
+        v[i] = *reinterpret_cast<const float4*>(dy + off);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    it.advance();
+  }
+};
+
+template <int ROWS_>
+struct DgradBLoader {  // w[co][kh][kw][ci]: for a fixed tap, k = co rows, n = ci contiguous: MN-major
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
+  const float* w;
+  int Cin, KHKW, KW, stride, kh0, kw0, kr0;
+  bool nok;
+  DgradTapIter it;
+
+  __device__ __forceinline__ DgradBLoader(const ConvP& p, const PhaseInfo& f, int n_block) {
+    Cin = p.Cin; KHKW = p.KH * p.KW; KW = p.KW; stride = p.stride; kh0 = f.kh0; kw0 = f.kw0;
+    const int c4 = threadIdx.x % C4;
+    kr0 = threadIdx.x / C4;
+    const int n = n_block + 4 * c4;
+    nok = n < p.N;
+    w = p.w + n;
+    it.init(p.Cout, f.ntw);
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const int kh = kh0 + stride * it.jh, kw = kw0 + stride * it.jw;
+    const int tap = kh * KW + kw;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int co = it.co0 + kr0 + KR * i;
+      if (nok && co < it.Cout) v[i] = *reinterpret_cast<const float4*>(w + ((size_t)co * KHKW + tap) * (size_t)Cin);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    it.advance();
+  }
+};
+
+template <int ROWS_>
+struct WgradALoader {  // dy[pixel][co]: k = pixel rows, m = co contiguous: MN-major
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
+  const float* dy;
+  int Cout, K, q0;
+  bool mok;
+
+  __device__ __forceinline__ WgradALoader(const ConvP& p, int m_block, int kt_begin) {
+    Cout = p.Cout; K = p.B * p.OH * p.OW;
+    const int c4 = threadIdx.x % C4;
+    const int m = m_block + 4 * c4;
+    mok = m < p.M;
+    dy = p.dy + m;
+    q0 = kt_begin * IG_BK + threadIdx.x / C4;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = q0 + KR * i;
+      if (mok && q < K) v[i] = *reinterpret_cast<const float4*>(dy + (size_t)q * (size_t)Cout);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    q0 += IG_BK;
+  }
+};
+
+template <int ROWS_>
+struct WgradBLoader {  // x gathered at (oh*s-p+kh, ow*s-p+kw): k = pixel rows, n = (tap,ci) contiguous in ci: MN-major
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
+  const float* x;
+  int IH, IW, Cin, stride, K, q0, dh, dw;  // dh = kh - pad
+  bool nok;
+  FastDiv dOW, dOH;
+
+  __device__ __forceinline__ WgradBLoader(const ConvP& p, int n_block, int kt_begin) {
+    IH = p.IH; IW = p.IW; Cin = p.Cin; stride = p.stride; K = p.B * p.OH * p.OW;
+    dOW = p.dOW; dOH = p.dOH;
+    const int c4 = threadIdx.x % C4;
+    const int n = n_block + 4 * c4;
+    nok = n < p.N;
+    const int tap = nok ? n / Cin : 0;
+    const int ci = nok ? n - tap * Cin : 0;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    dh = kh - p.pad; dw = kw - p.pad;
+    x = p.x + ci;
+    q0 = kt_begin * IG_BK + threadIdx.x / C4;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = q0 + KR * i;
+      bool ok = nok && q < K;
+      uint32_t t, ow, b, oh;
+      dOW.divmod((uint32_t)q, t, ow);
+      dOH.divmod(t, b, oh);
+      const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
+      ok = ok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+      if (ok) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(((int)b * IH + ih) * IW + iw) * (size_t)Cin);
+      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    q0 += IG_BK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <class Cfg>
+__global__ void __launch_bounds__(IG_THREADS) conv_fwd_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / p.tilesN, nt = tile % p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+
+  FwdALoader<Cfg::BM> la(p, m_block);
+  FwdBLoader<Cfg::BN> lb(p, n_block);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_mainloop<Cfg>(la, lb, p.ktiles, acc, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int mbase = m_block + wm * Cfg::WTM + 32 * i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + acc_row(r, lh);
+        if (m < p.M) p.out[(size_t)m * p.N + n] = acc[i][j][r] + bv;
+      }
+    }
+  }
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(IG_THREADS) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int rowpix[Cfg::BM];
+  const PhaseInfo& f = phases.p[blockIdx.y];
+  const int tilesM = (f.Mp + Cfg::BM - 1) / Cfg::BM;
+  const uint32_t ntiles = (uint32_t)tilesM * p.tilesN;
+  if (blockIdx.x >= ntiles) return;  // phases can differ in size (odd IH/IW); uniform per block
+  const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
+  const int mt = tile / p.tilesN, nt = tile % p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+
+  // output pixel of every tile row (dx is written at (a*s+ph, c*s+pw))
+  for (int r = threadIdx.x; r < Cfg::BM; r += IG_THREADS) {
+    const int m = m_block + r;
+    int pix = -1;
+    if (m < f.Mp) {
+      uint32_t t, cc, b, aa;
+      f.dPHw.divmod((uint32_t)m, t, cc);
+      f.dPHh.divmod(t, b, aa);
+      pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
+    }
+    rowpix[r] = pix;
+  }
+
+  DgradALoader<Cfg::BM> la(p, f, m_block);
+  DgradBLoader<Cfg::BN> lb(p, f, n_block);
+  const int ktiles = f.nth * f.ntw * ((p.Cout + IG_BK - 1) / IG_BK);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_mainloop<Cfg>(la, lb, ktiles, acc, smem);
+  __syncthreads();  // rowpix visible (also covers ktiles == 0)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int rbase = wm * Cfg::WTM + 32 * i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pix = rowpix[rbase + acc_row(r, lh)];
+        if (pix >= 0) p.out[(size_t)pix * p.Cin + n] = acc[i][j][r] + bv;
+      }
+    }
+  }
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(IG_THREADS) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / p.tilesN, nt = tile % p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  const int kt_begin = blockIdx.y * ktiles_per_split;
+  int ktiles = ktiles_total - kt_begin;
+  if (ktiles > ktiles_per_split) ktiles = ktiles_per_split;
+
+  WgradALoader<Cfg::BM> la(p, m_block, kt_begin);
+  WgradBLoader<Cfg::BN> lb(p, n_block, kt_begin);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_mainloop<Cfg>(la, lb, ktiles, acc, smem);
+
+  float* slab = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int mbase = m_block + wm * Cfg::WTM + 32 * i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + acc_row(r, lh);
+        if (m < p.M) slab[(size_t)m * p.N + n] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+using Cfg128x128 = TileCfg<128, 128, 2, 2>;
+using Cfg128x64 = TileCfg<128, 64, 2, 2>;
+
+int check_geom(const pcg_conv_geom* g) {
+  PCG_REQUIRE(g != nullptr, "conv geometry is null");
+  PCG_REQUIRE(g->B > 0 && g->IH > 0 && g->IW > 0 && g->Cin > 0 && g->OH > 0 && g->OW > 0 && g->Cout > 0,
+              "conv geometry: non-positive extent");
+  PCG_REQUIRE(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->pad >= 0, "conv geometry: bad kernel/stride/pad");
+  PCG_REQUIRE(g->OH == (g->IH + 2 * g->pad - g->KH) / g->stride + 1 && g->OW == (g->IW + 2 * g->pad - g->KW) / g->stride + 1,
+              "conv geometry: OH/OW inconsistent with IH/IW, kernel %dx%d stride %d pad %d", g->KH, g->KW, g->stride, g->pad);
+  PCG_REQUIRE((int64_t)g->B * g->IH * g->IW < (1ll << 31) / 2 && (int64_t)g->B * g->OH * g->OW < (1ll << 31) / 2,
+              "conv geometry: pixel count exceeds 2^30");
+  return PCG_OK;
+}
+
+ConvP make_params(const pcg_conv_geom* g) {
+  ConvP p{};
+  p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.Cin = g->Cin; p.OH = g->OH; p.OW = g->OW; p.Cout = g->Cout;
+  p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
+  p.dOW = FastDiv((uint32_t)g->OW);
+  p.dOH = FastDiv((uint32_t)g->OH);
+  return p;
+}
+
+template <class Cfg, class LA, class LB>
+constexpr size_t smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, LA, LB>(); }
+
+template <class K>
+int set_smem(K kernel, size_t bytes) {
+  // > 64 KB of dynamic LDS needs the opt-in attribute; harmless otherwise
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e)); return PCG_ERR_LAUNCH; }
+  return PCG_OK;
+}
+
+template <class Cfg>
+int launch_fwd(ConvP p, hipStream_t s) {
+  p.tilesN = ceil_div(p.N, Cfg::BN);
+  const int tilesM = ceil_div(p.M, Cfg::BM);
+  constexpr size_t smem = smem_bytes<Cfg, FwdALoader<Cfg::BM>, FwdBLoader<Cfg::BN>>();
+  static int once = set_smem(conv_fwd_kernel<Cfg>, smem);
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN), dim3(IG_THREADS), smem, s, p);
+  return launch_status("conv_fwd_kernel");
+}
+
+template <class Cfg>
+int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
+  p.tilesN = ceil_div(p.N, Cfg::BN);
+  const int tilesM = ceil_div(maxMp, Cfg::BM);
+  constexpr size_t smem = smem_bytes<Cfg, DgradALoader<Cfg::BM>, DgradBLoader<Cfg::BN>>();
+  static int once = set_smem(conv_dgrad_kernel<Cfg>, smem);
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, ph);
+  return launch_status("conv_dgrad_kernel");
+}
+
+struct WgradPlan { int splits, ktiles_total, ktiles_per_split, tiles; bool narrow; };
+
+WgradPlan plan_wgrad(const pcg_conv_geom* g) {
+  WgradPlan w{};
+  const int M = g->Cout, N = g->KH * g->KW * g->Cin;
+  w.narrow = (M <= 64);
+  const int BM = w.narrow ? 64 : 128;
+  w.tiles = ceil_div(M, BM) * ceil_div(N, 128);
+  const int64_t K = (int64_t)g->B * g->OH * g->OW;
+  w.ktiles_total = (int)ceil_div64(K, IG_BK);
+  // aim for >= 2 blocks per CU (512 blocks) but keep >= 8 k-tiles (256 pixels) per slice
+  int splits = ceil_div(512, w.tiles);
+  const int max_splits = w.ktiles_total / 8 > 0 ? w.ktiles_total / 8 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  w.ktiles_per_split = ceil_div(w.ktiles_total, splits);
+  w.splits = ceil_div(w.ktiles_total, w.ktiles_per_split);
+  return w;
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                              pcg_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd(g, x, w, bias, y, (hipStream_t)stream);
+  PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
+  ConvP p = make_params(g);
+  p.x = x; p.w = w; p.bias = bias; p.out = y;
+  p.M = g->B * g->OH * g->OW; p.N = g->Cout;
+  p.ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
+  hipStream_t s = (hipStream_t)stream;
+  if (p.N > 64) return launch_fwd<Cfg128x128>(p, s);
+  return launch_fwd<Cfg128x64>(p, s);
+}
+
+extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
+                                pcg_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad(g, dy, w, bias_x, dx, (hipStream_t)stream);
+  PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
+  PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
+  ConvP p = make_params(g);
+  p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx;
+  p.N = g->Cin;
+  DgradPhases ph{};
+  int nph = 0, maxMp = 0;
+  const int s = g->stride;
+  for (int a = 0; a < s; ++a)
+    for (int b = 0; b < s; ++b) {
+      PhaseInfo& f = ph.p[nph];
+      f.ph = a; f.pw = b;
+      f.PHh = a < g->IH ? (g->IH - a + s - 1) / s : 0;
+      f.PHw = b < g->IW ? (g->IW - b + s - 1) / s : 0;
+      f.Mp = g->B * f.PHh * f.PHw;
+      if (f.Mp == 0) continue;
+      f.kh0 = (a + g->pad) % s; f.kw0 = (b + g->pad) % s;
+      f.nth = f.kh0 < g->KH ? (g->KH - f.kh0 + s - 1) / s : 0;
+      f.ntw = f.kw0 < g->KW ? (g->KW - f.kw0 + s - 1) / s : 0;
+      if (f.nth == 0 || f.ntw == 0) { f.nth = 0; f.ntw = 1; }
+      f.dh0 = (a + g->pad - f.kh0) / s; f.dw0 = (b + g->pad - f.kw0) / s;
+      f.dPHw = FastDiv((uint32_t)f.PHw); f.dPHh = FastDiv((uint32_t)f.PHh);
+      if (f.Mp > maxMp) maxMp = f.Mp;
+      ++nph;
+    }
+  PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
+  hipStream_t st = (hipStream_t)stream;
+  if (p.N > 64) return launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st);
+  return launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st);
+}
+
+extern "C" size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK) return 0;
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_wgrad_workspace_bytes(g);
+  const WgradPlan w = plan_wgrad(g);
+  return (size_t)w.splits * (size_t)g->Cout * (size_t)g->KH * g->KW * g->Cin * sizeof(float);
+}
+
+extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(x && dy && dw, "pcg_conv2d_wgrad: null pointer");
+  if (thin_is_cin(g) || thin_is_cout(g))
+    return thin_conv_wgrad(g, x, dy, dw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+  PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
+  const WgradPlan wp = plan_wgrad(g);
+  const size_t need = pcg_conv2d_wgrad_workspace_bytes(g);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("pcg_conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
+    return PCG_ERR_WORKSPACE;
+  }
+  PCG_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)dw & 15) == 0, "pcg_conv2d_wgrad: workspace/dw must be 16-byte aligned");
+  ConvP p = make_params(g);
+  p.x = x; p.dy = dy; p.out = (float*)workspace;
+  p.M = g->Cout; p.N = g->KH * g->KW * g->Cin;
+  p.tilesN = ceil_div(p.N, 128);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (wp.narrow) {
+    using Cfg = TileCfg<64, 128, 1, 4>;
+    constexpr size_t smem = smem_bytes<Cfg, WgradALoader<64>, WgradBLoader<128>>();
+    static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
+    if (once != PCG_OK) return once;
+    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
+                       wp.ktiles_total, wp.ktiles_per_split);
+    rc = launch_status("conv_wgrad_kernel<64x128>");
+  } else {
+    using Cfg = Cfg128x128;
+    constexpr size_t smem = smem_bytes<Cfg, WgradALoader<128>, WgradBLoader<128>>();
+    static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
+    if (once != PCG_OK) return once;
+    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
+                       wp.ktiles_total, wp.ktiles_per_split);
+    rc = launch_status("conv_wgrad_kernel<128x128>");
+  }
+  if (rc != PCG_OK) return rc;
+  const size_t n = (size_t)p.M * p.N;
+  return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s);
+}

@@ -1,0 +1,253 @@
+// pointwise.hip — activations without BatchNorm, the two BCE losses, fused flat Adam, and small helpers.
+// All HBM-bound streaming kernels (float4 lane accesses, grid-stride).  Reference call sites are listed
+// next to each prototype in include/pcgan_hip.h.
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+unsigned ew_blocks(size_t nv) {
+  size_t b = (nv + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int VEC>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const float* __restrict__ x, size_t n, int act, float slope,
+                                                      float* __restrict__ y) {
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (VEC == 4) {
+      float4 q = reinterpret_cast<const float4*>(x)[i];
+      q.x = act_apply(q.x, act, slope); q.y = act_apply(q.y, act, slope);
+      q.z = act_apply(q.z, act, slope); q.w = act_apply(q.w, act, slope);
+      reinterpret_cast<float4*>(y)[i] = q;
+    } else {
+      y[i] = act_apply(x[i], act, slope);
+    }
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n,
+                                                      int act, float slope, float* __restrict__ dx) {
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (VEC == 4) {
+      float4 g = reinterpret_cast<const float4*>(dy)[i];
+      const float4 o = reinterpret_cast<const float4*>(y)[i];
+      g.x *= act_grad_from_out(o.x, act, slope); g.y *= act_grad_from_out(o.y, act, slope);
+      g.z *= act_grad_from_out(o.z, act, slope); g.w *= act_grad_from_out(o.w, act, slope);
+      reinterpret_cast<float4*>(dx)[i] = g;
+    } else {
+      dx[i] = dy[i] * act_grad_from_out(y[i], act, slope);
+    }
+  }
+}
+
+// one block: n is a batch size (hundreds..thousands); fixed-order tree => reproducible loss
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const float s = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return s;
+}
+
+__global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ p, const float* __restrict__ target, float tconst,
+                                                  int64_t n, float grad_scale, float* loss, float* __restrict__ dp) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float pi = p[i], t = target ? target[i] : tconst;
+    // [torch] binary_cross_entropy: log terms clamped at -100
+    const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+    acc += (t - 1.f) * lq - t * lp;
+    if (dp) dp[i] = grad_scale * inv_n * (pi - t) / fmaxf((1.f - pi) * pi, 1e-12f);
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && loss) loss[0] = s * inv_n;
+}
+
+__global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ z, float t, int64_t n, float grad_scale,
+                                                         float* loss, float* __restrict__ dz) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv_n = 1.f / (float)n;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float x = z[i];
+    // [torch] binary_cross_entropy_with_logits: (1-t)*x + max(-x,0) + log(exp(-max) + exp(-x-max))
+    const float mx = fmaxf(-x, 0.f);
+    acc += (1.f - t) * x + mx + logf(expf(-mx) + expf(-x - mx));
+    if (dz) dz[i] = grad_scale * inv_n * (1.f / (1.f + expf(-x)) - t);
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && loss) loss[0] = s * inv_n;
+}
+
+// hyper[0] = lr / (1 - beta1^step) ; hyper[1] = sqrt(1 - beta2^step)
+struct AdamHyper { float step_size, bc2_sqrt; };
+
+__global__ void adam_tick_kernel(int64_t* step_counter, float lr, float beta1, float beta2, AdamHyper* out) {
+  const int64_t t = step_counter[0] + 1;
+  step_counter[0] = t;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  out->step_size = (float)((double)lr / bc1);
+  out->bc2_sqrt = (float)sqrt(bc2);
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float beta1, float beta2,
+                                         float eps, float wd, int decoupled, float step_size, float bc2_sqrt) {
+  if (wd != 0.f) {
+    if (decoupled) p *= (1.f - lr * wd);   // AdamW
+    else g = fmaf(wd, p, g);               // Adam L2
+  }
+  // [torch] exp_avg.lerp_(grad, 1-beta1): weight < 0.5 ? a + w(b-a) : b - (b-a)(1-w)
+  const float w1 = 1.f - beta1;
+  m = (w1 < 0.5f) ? fmaf(w1, g - m, m) : g - (g - m) * (1.f - w1);
+  v = fmaf(v, beta2, (1.f - beta2) * g * g);
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                   float beta1, float beta2, float eps, float wd, int decoupled,
+                                                   AdamHyper hy, const AdamHyper* hy_dev) {
+  if (hy_dev) hy = *hy_dev;
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (VEC == 4) {
+      float4 p4 = reinterpret_cast<float4*>(param)[i];
+      const float4 g4 = reinterpret_cast<const float4*>(grad)[i];
+      float4 m4 = reinterpret_cast<float4*>(m)[i];
+      float4 v4 = reinterpret_cast<float4*>(v)[i];
+      adam_one(p4.x, g4.x, m4.x, v4.x, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.y, g4.y, m4.y, v4.y, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.z, g4.z, m4.z, v4.z, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.w, g4.w, m4.w, v4.w, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      reinterpret_cast<float4*>(param)[i] = p4;
+      reinterpret_cast<float4*>(m)[i] = m4;
+      reinterpret_cast<float4*>(v)[i] = v4;
+    } else {
+      float p = param[i], mm = m[i], vv = v[i];
+      adam_one(p, grad[i], mm, vv, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      param[i] = p; m[i] = mm; v[i] = vv;
+    }
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, size_t n, float value) {
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (VEC == 4) reinterpret_cast<float4*>(p)[i] = make_float4(value, value, value, value);
+    else p[i] = value;
+  }
+}
+
+// single block, fixed order: diagnostic only (mnist/trainer.py:41-42)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p, int64_t n, float* out, int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc = fmaf(p[i], p[i], acc);
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s;
+}
+
+int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                float wd, int decoupled, AdamHyper hy, const AdamHyper* hy_dev, hipStream_t s) {
+  const bool vec = (n % 4 == 0) && al16(param) && al16(grad) && al16(m) && al16(v);
+  if (vec)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)n, lr, beta1,
+                       beta2, eps, wd, decoupled, hy, hy_dev);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, param, grad, m, v, (size_t)n, lr, beta1,
+                       beta2, eps, wd, decoupled, hy, hy_dev);
+  return launch_status("adam_kernel");
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream) {
+  PCG_REQUIRE(x && y && n > 0, "pcg_act_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && al16(x) && al16(y))
+    hipLaunchKernelGGL(act_fwd_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, x, (size_t)n, act, slope, y);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, x, (size_t)n, act, slope, y);
+  return launch_status("act_fwd_kernel");
+}
+
+extern "C" int pcg_act_bwd(const float* dy, const float* y, int64_t n, int act, float slope, float* dx, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && y && dx && n > 0, "pcg_act_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && al16(dy) && al16(y) && al16(dx))
+    hipLaunchKernelGGL(act_bwd_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, dy, y, (size_t)n, act, slope, dx);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, dy, y, (size_t)n, act, slope, dx);
+  return launch_status("act_bwd_kernel");
+}
+
+extern "C" int pcg_bce_fwd_bwd(const float* p, const float* target, float target_const, int64_t n, float grad_scale,
+                               float* loss, float* dp, pcg_stream_t stream) {
+  PCG_REQUIRE(p && n > 0 && (loss || dp), "pcg_bce_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, target_const, n, grad_scale, loss, dp);
+  return launch_status("bce_kernel");
+}
+
+extern "C" int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale, float* loss, float* dz,
+                                      pcg_stream_t stream) {
+  PCG_REQUIRE(z && n > 0 && (loss || dz), "pcg_bce_logits_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, z, target_const, n, grad_scale, loss, dz);
+  return launch_status("bce_logits_kernel");
+}
+
+extern "C" int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int64_t step,
+                             pcg_stream_t stream) {
+  PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "pcg_adam_step: bad arguments");
+  AdamHyper hy;
+  hy.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+  hy.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, nullptr,
+                     (hipStream_t)stream);
+}
+
+extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                        float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                                        int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream) {
+  PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_counter_dev && hyper_scratch2_dev,
+              "pcg_adam_step_capturable: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  AdamHyper* hd = reinterpret_cast<AdamHyper*>(hyper_scratch2_dev);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_counter_dev, lr, beta1, beta2, hd);
+  if (int e = launch_status("adam_tick_kernel")) return e;
+  AdamHyper hy{0.f, 1.f};
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, hd, s);
+}
+
+extern "C" int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream) {
+  PCG_REQUIRE(p && n > 0, "pcg_fill: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && al16(p)) hipLaunchKernelGGL(fill_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, p, (size_t)n, value);
+  else hipLaunchKernelGGL(fill_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, p, (size_t)n, value);
+  return launch_status("fill_kernel");
+}
+
+extern "C" int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(p && out && n > 0, "pcg_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, out, accumulate);
+  return launch_status("sumsq_kernel");
+}

@@ -1,0 +1,28 @@
+// runtime.hip — library-level entry points: ABI version, target, thread-local error text.
+#include "pcg_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace pcg {
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_status(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return PCG_OK;
+  set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return PCG_ERR_LAUNCH;
+}
+}  // namespace pcg
+
+extern "C" int pcg_abi_version(void) { return 1; }
+extern "C" const char* pcg_last_error(void) { return pcg::g_err; }
+extern "C" const char* pcg_target_arch(void) { return "gfx950"; }

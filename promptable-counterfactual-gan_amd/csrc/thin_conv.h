@@ -1,0 +1,20 @@
+// thin_conv.h — internal entry points for convolutions with a 1..4-channel side (HBM-bound; vector ALU).
+#pragma once
+#include "pcg_common.h"
+
+namespace pcg {
+
+// true if the geometry is served by the thin kernels rather than the MFMA implicit GEMM
+inline bool thin_is_cin(const pcg_conv_geom* g) { return g->Cin <= 3; }
+inline bool thin_is_cout(const pcg_conv_geom* g) { return g->Cout <= 3 && !thin_is_cin(g); }
+
+int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, hipStream_t s);
+size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g);
+int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+
+// shared with conv_igemm.hip: dw[i] = (acc ? dw[i] : 0) + sum_z slab[z*stride + i]
+int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s);
+
+}  // namespace pcg

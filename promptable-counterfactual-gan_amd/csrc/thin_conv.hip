@@ -1,0 +1,348 @@
+// thin_conv.hip — convolutions with a 1..3-channel side: DCGAN D's first conv (1->64, mnist_dcgan.py:100),
+// D's last conv (512->1, :111) and G's last ConvTranspose (64->1, :88); counteRGAN conv_in (3->64),
+// conv_out (64->1) and the 2-channel discriminator entry (models/generator.py:39,50; discriminator.py:14).
+// With N (or K) of 1..3 these are HBM-bound streaming kernels, not MFMA work: one "wide" NHWC tensor
+// [B][WH][WW][C] is read or written exactly once with 16-byte lane accesses, the "thin" tensor
+// [B][TH][TW][Cs] and the weights come from L1/LDS.
+//
+// Three access patterns, each usable on the conv's output grid (direct tap map  q = p*s - pad + k) or its
+// input grid (transposed tap map  q = (p + pad - k)/s when divisible):
+//   expand : wide[P][c]  = bias[c] + sum_{tap,cs} thin[map(P,tap)][cs] * W[tap,cs][c]
+//   reduce : thin[P][cs] = bias[cs] + sum_{tap} sum_c wide[map(P,tap)][c] * W[tap,cs][c]
+//   wgrad  : dW[tap,cs][c] = sum_P wide[P][c] * thin[map(P,tap)][cs]
+#include "thin_conv.h"
+
+namespace pcg {
+namespace {
+
+struct ThinP {
+  const float* thin;
+  const float* wide;
+  const float* w;
+  const float* bias;
+  float* out;
+  int B, TH, TW, Cs, WH, WW, C;
+  int KH, KW, stride, pad, transposed;
+  int wsS, wsT, wsC;       // weight element (cs, tap, c) lives at cs*wsS + tap*wsT + c*wsC
+  int IH_, IW_;            // iteration grid
+  int QH, QW;              // other grid
+  int npix;                // B * IH_ * IW_
+  FastDiv dIW, dIH, dCQ;
+};
+
+__device__ __forceinline__ bool tap_map(const ThinP& p, int ph, int pw, int kh, int kw, int& qh, int& qw) {
+  if (!p.transposed) {
+    qh = ph * p.stride - p.pad + kh;
+    qw = pw * p.stride - p.pad + kw;
+  } else {
+    const int th = ph + p.pad - kh, tw = pw + p.pad - kw;
+    if (th < 0 || tw < 0) return false;
+    if (p.stride == 1) { qh = th; qw = tw; }
+    else if (p.stride == 2) { if ((th | tw) & 1) return false; qh = th >> 1; qw = tw >> 1; }
+    else { if (th % p.stride || tw % p.stride) return false; qh = th / p.stride; qw = tw / p.stride; }
+  }
+  return (unsigned)qh < (unsigned)p.QH && (unsigned)qw < (unsigned)p.QW;
+}
+
+// LDS weight image Wl[(tap*Cs+cs)][C]
+__device__ __forceinline__ void stage_weights(const ThinP& p, float* Wl) {
+  const int TT = p.KH * p.KW * p.Cs;
+  for (int i = threadIdx.x; i < TT * p.C; i += blockDim.x) {
+    const int t = i / p.C, c = i - t * p.C;
+    const int tap = t / p.Cs, cs = t - tap * p.Cs;
+    Wl[i] = p.w[(size_t)cs * p.wsS + (size_t)tap * p.wsT + (size_t)c * p.wsC];
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) thin_expand_kernel(ThinP p) {
+  extern __shared__ __attribute__((aligned(16))) float Wl[];
+  stage_weights(p, Wl);
+  const int CQ = p.C >> 2;
+  const uint32_t total = (uint32_t)p.npix * (uint32_t)CQ;
+  const float4* bias4 = reinterpret_cast<const float4*>(p.bias);
+  float4* out4 = reinterpret_cast<float4*>(p.out);
+  for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    uint32_t pix, cq, t, pw, b, ph;
+    p.dCQ.divmod(idx, pix, cq);
+    p.dIW.divmod(pix, t, pw);
+    p.dIH.divmod(t, b, ph);
+    float4 acc = p.bias ? bias4[cq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int qh, qw;
+        if (!tap_map(p, (int)ph, (int)pw, kh, kw, qh, qw)) continue;
+        const float* sp = p.thin + (size_t)(((int)b * p.TH + qh) * p.TW + qw) * p.Cs;
+        const float* wl = Wl + (size_t)((kh * p.KW + kw) * p.Cs) * p.C + 4 * cq;
+        for (int cs = 0; cs < p.Cs; ++cs) {
+          const float sv = sp[cs];
+          const float4 w4 = *reinterpret_cast<const float4*>(wl + (size_t)cs * p.C);
+          acc.x = fmaf(sv, w4.x, acc.x); acc.y = fmaf(sv, w4.y, acc.y);
+          acc.z = fmaf(sv, w4.z, acc.z); acc.w = fmaf(sv, w4.w, acc.w);
+        }
+      }
+    out4[idx] = acc;
+  }
+}
+
+// 16 lanes per output pixel, each lane strides over the channel quads; xor-shuffle tree inside the 16-lane group
+__global__ void __launch_bounds__(256) thin_reduce_kernel(ThinP p) {
+  extern __shared__ __attribute__((aligned(16))) float Wl[];
+  stage_weights(p, Wl);
+  const int CQ = p.C >> 2;
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (uint32_t pix = blockIdx.x * 16u + grp; pix < (uint32_t)p.npix; pix += gridDim.x * 16u) {
+    uint32_t t, pw, b, ph;
+    p.dIW.divmod(pix, t, pw);
+    p.dIH.divmod(t, b, ph);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int qh, qw;
+        if (!tap_map(p, (int)ph, (int)pw, kh, kw, qh, qw)) continue;
+        const float4* vp = reinterpret_cast<const float4*>(p.wide + (size_t)(((int)b * p.WH + qh) * p.WW + qw) * p.C);
+        const float* wl = Wl + (size_t)((kh * p.KW + kw) * p.Cs) * p.C;
+        for (int cq = l16; cq < CQ; cq += 16) {
+          const float4 v = vp[cq];
+          {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + 4 * cq);
+            a0 = fmaf(v.x, w4.x, a0); a0 = fmaf(v.y, w4.y, a0); a0 = fmaf(v.z, w4.z, a0); a0 = fmaf(v.w, w4.w, a0);
+          }
+          if (p.Cs > 1) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + p.C + 4 * cq);
+            a1 = fmaf(v.x, w4.x, a1); a1 = fmaf(v.y, w4.y, a1); a1 = fmaf(v.z, w4.z, a1); a1 = fmaf(v.w, w4.w, a1);
+          }
+          if (p.Cs > 2) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wl + 2 * p.C + 4 * cq);
+            a2 = fmaf(v.x, w4.x, a2); a2 = fmaf(v.y, w4.y, a2); a2 = fmaf(v.z, w4.z, a2); a2 = fmaf(v.w, w4.w, a2);
+          }
+        }
+      }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      a0 += __shfl_xor(a0, off);
+      a1 += __shfl_xor(a1, off);
+      a2 += __shfl_xor(a2, off);
+    }
+    if (l16 == 0) {
+      float* o = p.out + (size_t)pix * p.Cs;
+      o[0] = a0 + (p.bias ? p.bias[0] : 0.f);
+      if (p.Cs > 1) o[1] = a1 + (p.bias ? p.bias[1] : 0.f);
+      if (p.Cs > 2) o[2] = a2 + (p.bias ? p.bias[2] : 0.f);
+    }
+  }
+}
+
+// Each block owns `ppb` iteration pixels; thread (cq, pl) accumulates NT float4 sums over pixels pl, pl+PL, ...
+// then the PL pixel-lanes are summed through LDS in a fixed order and the block writes its slab in dw layout.
+template <int KH, int KW, int CS>
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinP p, float* slab, int ppb, int wn) {
+  constexpr int NT = KH * KW * CS;
+  __shared__ float4 red[256];
+  const int CQ = p.C >> 2;           // power of two <= 256 (checked on the host)
+  const int PL = 256 / CQ;
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
+  float4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int p0 = blockIdx.x * ppb;
+  int p1 = p0 + ppb; if (p1 > p.npix) p1 = p.npix;
+  for (int pix = p0 + pl; pix < p1; pix += PL) {
+    uint32_t t, pw, b, ph;
+    p.dIW.divmod((uint32_t)pix, t, pw);
+    p.dIH.divmod(t, b, ph);
+    const float4 v = *reinterpret_cast<const float4*>(p.wide + (size_t)pix * p.C + 4 * cq);
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        int qh, qw;
+        if (!tap_map(p, (int)ph, (int)pw, kh, kw, qh, qw)) continue;
+        const float* sp = p.thin + (size_t)(((int)b * p.TH + qh) * p.TW + qw) * CS;
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          const float sv = sp[cs];
+          float4& a = acc[(kh * KW + kw) * CS + cs];
+          a.x = fmaf(sv, v.x, a.x); a.y = fmaf(sv, v.y, a.y); a.z = fmaf(sv, v.z, a.z); a.w = fmaf(sv, v.w, a.w);
+        }
+      }
+  }
+  float* myslab = slab + (size_t)blockIdx.x * wn;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    red[threadIdx.x] = acc[t];
+    __syncthreads();
+    if (pl == 0) {
+      float4 s = red[cq];
+      for (int j = 1; j < PL; ++j) {
+        const float4 o = red[j * CQ + cq];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      const int tap = t / CS, cs = t % CS;
+      float* d = myslab + (size_t)cs * p.wsS + (size_t)tap * p.wsT + (size_t)(4 * cq) * p.wsC;
+      d[0] = s.x; d[p.wsC] = s.y; d[2 * p.wsC] = s.z; d[3 * p.wsC] = s.w;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) slab_reduce4_kernel(const float4* __restrict__ s, float4* __restrict__ o, size_t n4,
+                                                           size_t stride4, int nslabs, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = accumulate ? o[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nslabs; ++z) {
+      const float4 v = s[(size_t)z * stride4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    o[i] = a;
+  }
+}
+__global__ void __launch_bounds__(256) slab_reduce1_kernel(const float* __restrict__ s, float* __restrict__ o, size_t n,
+                                                           size_t stride, int nslabs, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float a = accumulate ? o[i] : 0.f;
+    for (int z = 0; z < nslabs; ++z) a += s[(size_t)z * stride + i];
+    o[i] = a;
+  }
+}
+
+// geometry -> ThinP for the two thin families
+int fill_common(ThinP& p, const pcg_conv_geom* g, bool cin_thin, bool iter_on_output) {
+  p.B = g->B; p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
+  const int T = g->KH * g->KW;
+  if (cin_thin) {  // thin = x side (input grid), wide = y side (output grid)
+    p.TH = g->IH; p.TW = g->IW; p.Cs = g->Cin; p.WH = g->OH; p.WW = g->OW; p.C = g->Cout;
+    p.wsS = 1; p.wsT = g->Cin; p.wsC = T * g->Cin;
+  } else {         // thin = y side (output grid), wide = x side (input grid)
+    p.TH = g->OH; p.TW = g->OW; p.Cs = g->Cout; p.WH = g->IH; p.WW = g->IW; p.C = g->Cin;
+    p.wsS = T * g->Cin; p.wsT = g->Cin; p.wsC = 1;
+  }
+  p.transposed = iter_on_output ? 0 : 1;
+  if (iter_on_output) { p.IH_ = g->OH; p.IW_ = g->OW; p.QH = g->IH; p.QW = g->IW; }
+  else { p.IH_ = g->IH; p.IW_ = g->IW; p.QH = g->OH; p.QW = g->OW; }
+  p.npix = g->B * p.IH_ * p.IW_;
+  p.dIW = FastDiv((uint32_t)p.IW_); p.dIH = FastDiv((uint32_t)p.IH_); p.dCQ = FastDiv((uint32_t)(p.C / 4));
+  PCG_REQUIRE(p.C % 4 == 0, "thin conv: wide channel count %d must be a multiple of 4", p.C);
+  PCG_REQUIRE(p.Cs >= 1 && p.Cs <= 3, "thin conv: thin channel count %d not in 1..3", p.Cs);
+  PCG_REQUIRE((int64_t)p.npix * (p.C / 4) < (1ll << 31), "thin conv: problem too large for 32-bit indexing");
+  return PCG_OK;
+}
+
+size_t lds_weight_bytes(const ThinP& p) { return (size_t)p.KH * p.KW * p.Cs * p.C * sizeof(float); }
+
+int launch_expand(ThinP& p, hipStream_t s) {
+  const size_t smem = lds_weight_bytes(p);
+  PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
+  const uint64_t total = (uint64_t)p.npix * (p.C / 4);
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(thin_expand_kernel, dim3(blocks), dim3(256), smem, s, p);
+  return launch_status("thin_expand_kernel");
+}
+int launch_reduce(ThinP& p, hipStream_t s) {
+  const size_t smem = lds_weight_bytes(p);
+  PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
+  unsigned blocks = (unsigned)((p.npix + 15) / 16);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(thin_reduce_kernel, dim3(blocks), dim3(256), smem, s, p);
+  return launch_status("thin_reduce_kernel");
+}
+
+struct ThinWgradPlan { int ppb, nblocks; };
+ThinWgradPlan plan_thin_wgrad(int npix, int C) {
+  ThinWgradPlan w;
+  const int PL = 256 / (C / 4);
+  int ppb = (npix + 1023) / 1024;           // ~1024 blocks
+  const int min_ppb = PL * 8;               // at least 8 pixels per thread
+  if (ppb < min_ppb) ppb = min_ppb;
+  w.ppb = ppb;
+  w.nblocks = (npix + ppb - 1) / ppb;
+  return w;
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s) {
+  const bool vec = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)slab | (uintptr_t)dw) & 15) == 0;
+  if (vec) {
+    const size_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(slab),
+                       reinterpret_cast<float4*>(dw), n4, slab_stride / 4, nslabs, accumulate);
+  } else {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(slab_reduce1_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, n, slab_stride, nslabs, accumulate);
+  }
+  return launch_status("slab_reduce_kernel");
+}
+
+int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+  ThinP p{};
+  const bool cin_thin = thin_is_cin(g);
+  if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/true)) return e;
+  p.w = w; p.bias = bias; p.out = y;
+  if (cin_thin) { p.thin = x; return launch_expand(p, s); }   // y wide
+  p.wide = x;                                                 // y thin
+  return launch_reduce(p, s);
+}
+
+int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, hipStream_t s) {
+  ThinP p{};
+  const bool cin_thin = thin_is_cin(g);
+  if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/false)) return e;
+  p.w = w; p.bias = bias_x; p.out = dx;
+  if (cin_thin) { p.wide = dy; return launch_reduce(p, s); }  // dx thin
+  p.thin = dy;                                                // dx wide
+  return launch_expand(p, s);
+}
+
+size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
+  const bool cin_thin = thin_is_cin(g);
+  const int C = cin_thin ? g->Cout : g->Cin;
+  if (C % 4 != 0 || C / 4 > 256 || !is_pow2(C / 4)) return 0;
+  const int npix = cin_thin ? g->B * g->OH * g->OW : g->B * g->IH * g->IW;
+  const ThinWgradPlan wp = plan_thin_wgrad(npix, C);
+  return (size_t)wp.nblocks * (size_t)g->Cout * g->KH * g->KW * g->Cin * sizeof(float);
+}
+
+int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+  ThinP p{};
+  const bool cin_thin = thin_is_cin(g);
+  // iterate over the wide tensor's pixels: dy (output grid) when Cin is thin, x (input grid) when Cout is thin
+  if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/cin_thin)) return e;
+  PCG_REQUIRE(p.C / 4 <= 256 && is_pow2(p.C / 4), "thin conv wgrad: wide channel count %d must be 4*2^k <= 1024", p.C);
+  if (cin_thin) { p.wide = dy; p.thin = x; } else { p.wide = x; p.thin = dy; }
+  const ThinWgradPlan wp = plan_thin_wgrad(p.npix, p.C);
+  const int wn = g->Cout * g->KH * g->KW * g->Cin;
+  const size_t need = (size_t)wp.nblocks * wn * sizeof(float);
+  if (ws == nullptr || ws_bytes < need) {
+    set_error("thin conv wgrad: workspace %zu B < required %zu B", ws_bytes, need);
+    return PCG_ERR_WORKSPACE;
+  }
+  float* slab = (float*)ws;
+#define PCG_THIN_WGRAD_CASE(KH_, KW_, CS_)                                                                          \
+  if (g->KH == KH_ && g->KW == KW_ && p.Cs == CS_) {                                                                 \
+    hipLaunchKernelGGL((thin_wgrad_kernel<KH_, KW_, CS_>), dim3(wp.nblocks), dim3(256), 0, s, p, slab, wp.ppb, wn); \
+  } else
+  PCG_THIN_WGRAD_CASE(4, 4, 1)
+  PCG_THIN_WGRAD_CASE(3, 3, 1)
+  PCG_THIN_WGRAD_CASE(3, 3, 2)
+  PCG_THIN_WGRAD_CASE(3, 3, 3)
+  PCG_THIN_WGRAD_CASE(1, 1, 1)
+  {
+    set_error("thin conv wgrad: kernel %dx%d with %d thin channels has no instantiation", g->KH, g->KW, p.Cs);
+    return PCG_ERR_UNSUPPORTED;
+  }
+#undef PCG_THIN_WGRAD_CASE
+  if (int e = launch_status("thin_wgrad_kernel")) return e;
+  return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, wp.nblocks, accumulate, s);
+}
+
+}  // namespace pcg

@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C ABI: PyTorch-ROCm tensors in, raw pointers across the boundary.
+
+Activations are *physically* NHWC: tensors of shape [B, H, W, C], contiguous.  Conv weights are physically
+OHWI [Cout, KH, KW, Cin] (ConvTranspose2d: [Cin, KH, KW, Cout]); `ohwi(p)` gives that view of a PyTorch
+parameter of logical shape [Cout, Cin, KH, KW] kept in channels_last memory format.  Nothing here computes
+on the CPU and nothing falls back to ATen kernels: every function launches kernels of libpcgan_hip.so on
+torch's current HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ConvGeom, check  # noqa: F401
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.PcgError(f"{name}: expected a tensor on the GPU (libpcgan_hip has no CPU path), got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.PcgError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.PcgError(f"{name}: expected a contiguous tensor, got strides {t.stride()} for shape {tuple(t.shape)}")
+    return t
+
+
+def workspace(nbytes, device):
+    """A cached scratch buffer on `device`, grown on demand.  Stream-ordered use on the current stream only."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        nbytes = max(int(nbytes), 1 << 20)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def ohwi(w):
+    """Physical [O, KH, KW, I] view of a conv parameter of logical shape [O, I, KH, KW] (channels_last memory)."""
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise _lib.PcgError("conv weight is not in channels_last (OHWI) memory layout; FlatModule keeps it that way")
+    return v
+
+
+def conv_geom(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
+    OH = (IH + 2 * pad - KH) // stride + 1
+    OW = (IW + 2 * pad - KW) // stride + 1
+    return ConvGeom(B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad)
+
+
+# ---- convolution family --------------------------------------------------------------------------
+def conv2d_fwd(g, x, w, bias=None, out=None):
+    """y[B,OH,OW,Cout] = conv(x[B,IH,IW,Cin], w OHWI) (+ bias)."""
+    _chk(x, "x"); _chk(w, "w")
+    assert x.numel() == g.B * g.IH * g.IW * g.Cin and w.numel() == g.Cout * g.KH * g.KW * g.Cin
+    y = out if out is not None else torch.empty((g.B, g.OH, g.OW, g.Cout), dtype=torch.float32, device=x.device)
+    check(_lib.load().pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _stream()), "pcg_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
+    """dx[B,IH,IW,Cin] = conv_transpose(dy[B,OH,OW,Cout], w OHWI) (+ bias_x per Cin)."""
+    _chk(dy, "dy"); _chk(w, "w")
+    assert dy.numel() == g.B * g.OH * g.OW * g.Cout and w.numel() == g.Cout * g.KH * g.KW * g.Cin
+    dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
+    check(_lib.load().pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _stream()), "pcg_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(g, x, dy, dw, accumulate):
+    """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x."""
+    _chk(x, "x"); _chk(dy, "dy"); _chk(dw, "dw")
+    assert dw.numel() == g.Cout * g.KH * g.KW * g.Cin
+    lib = _lib.load()
+    need = lib.pcg_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
+    ws = workspace(need, x.device)
+    check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
+          "pcg_conv2d_wgrad")
+    return dw
+
+
+def colsum(dy2d_rows, C, dy, db, accumulate):
+    lib = _lib.load()
+    need = lib.pcg_colsum_workspace_bytes(dy2d_rows, C)
+    ws = workspace(need, dy.device)
+    check(lib.pcg_colsum(_p(dy), dy2d_rows, C, _p(db), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_colsum")
+    return db
+
+
+# ---- BatchNorm + activation -------------------------------------------------------------------------
+def bn_train_stats(x, C, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    _chk(x, "x")
+    rows = x.numel() // C
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
+    check(lib.pcg_bn_train_stats(_p(x), rows, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                                 _p(num_batches_tracked), _p(ws), ws.numel(), _stream()), "pcg_bn_train_stats")
+    return mean, invstd
+
+
+def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps=-1.0, out=None):
+    _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.load().pcg_bn_apply_act(_p(x), x.numel() // C, C, _p(mean), _p(invstd_or_var), var_eps, _p(gamma), _p(beta),
+                                       act, slope, _p(y), _stream()), "pcg_bn_apply_act")
+    return y
+
+
+def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None):
+    _chk(dy, "dy"); _chk(x, "x"); _chk(y, "y")
+    rows = x.numel() // C
+    dx = out if out is not None else torch.empty_like(x)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
+    check(lib.pcg_bn_act_bwd(_p(dy), _p(x), _p(y), rows, C, _p(mean), _p(invstd), _p(gamma), act, slope, _p(dx), _p(dgamma),
+                             _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_act_bwd")
+    return dx
+
+
+def act_fwd(x, act, slope=0.0, out=None):
+    _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.load().pcg_act_fwd(_p(x), x.numel(), act, slope, _p(y), _stream()), "pcg_act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act, slope=0.0, out=None):
+    _chk(dy, "dy"); _chk(y, "y")
+    dx = out if out is not None else torch.empty_like(dy)
+    check(_lib.load().pcg_act_bwd(_p(dy), _p(y), dy.numel(), act, slope, _p(dx), _stream()), "pcg_act_bwd")
+    return dx
+
+
+# ---- losses -------------------------------------------------------------------------------------------
+def bce_fwd_bwd(p, target, target_const, grad_scale=1.0, need_grad=True):
+    """nn.BCELoss(mean).  Returns (loss[1], dp or None).  `target` tensor or None (=> constant)."""
+    _chk(p, "p")
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    dp = torch.empty_like(p) if need_grad else None
+    check(_lib.load().pcg_bce_fwd_bwd(_p(p), _p(target), float(target_const), p.numel(), grad_scale, _p(loss), _p(dp), _stream()),
+          "pcg_bce_fwd_bwd")
+    return loss, dp
+
+
+def bce_logits_fwd_bwd(z, target_const, grad_scale=1.0, need_grad=True):
+    _chk(z, "z")
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if need_grad else None
+    check(_lib.load().pcg_bce_logits_fwd_bwd(_p(z), float(target_const), z.numel(), grad_scale, _p(loss), _p(dz), _stream()),
+          "pcg_bce_logits_fwd_bwd")
+    return loss, dz
+
+
+# ---- optimizer / helpers ------------------------------------------------------------------------------
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, decoupled, step):
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, n)
+    check(_lib.load().pcg_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+                                    weight_decay, int(bool(decoupled)), int(step), _stream()), "pcg_adam_step")
+
+
+def adam_step_capturable(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, decoupled, step_dev, hyper_dev):
+    check(_lib.load().pcg_adam_step_capturable(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                               eps, weight_decay, int(bool(decoupled)), _p(step_dev), _p(hyper_dev), _stream()),
+          "pcg_adam_step_capturable")
+
+
+def fill(t, value):
+    _chk(t, "t")
+    if t.numel():
+        check(_lib.load().pcg_fill(_p(t), t.numel(), float(value), _stream()), "pcg_fill")
+    return t
+
+
+def sumsq(t, out, accumulate=False):
+    _chk(t, "t")
+    check(_lib.load().pcg_sumsq(_p(t), t.numel(), _p(out), int(bool(accumulate)), _stream()), "pcg_sumsq")
+    return out

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own code on the CPU (this container only: /root/reference
+does not travel to the GPU box; the .npz files written next to this script do).
+
+DCGAN (`dconv_gan/mnist/mnist_dcgan.py`) cannot be imported (torchvision, /mnt/data, trains at import), so the
+pure-torch pieces are lifted out of its syntax tree and executed unmodified:
+  * `weights_init`, `Generator`, `Discriminator`                 (lines 63-116)
+  * the construction of nets / loss / optimizers                  (lines 119-127)
+  * the body of the inner training loop up to optimizerG.step()   (lines 147-175)
+Nothing of the reference's text is stored in this repo — only the numbers it produces.
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/dcgan_ref_small.npz)
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PCG_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _lift_dcgan(config):
+    path = os.path.join(REF, "dconv_gan/mnist/mnist_dcgan.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    defs, setup, body = [], [], []
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in ("weights_init", "Generator", "Discriminator"):
+            defs.append(node)
+        elif isinstance(node, (ast.Assign, ast.Expr)) and 119 <= node.lineno <= 127:
+            setup.append(node)  # netG/netD creation + .apply(weights_init), criterion, optimizerD/G
+        elif isinstance(node, ast.For) and node.lineno == 140:
+            inner = [n for n in node.body if isinstance(n, ast.For)]
+            assert len(inner) == 1 and inner[0].lineno == 143, "reference layout changed"
+            body = [n for n in inner[0].body if 147 <= n.lineno <= 175]
+    assert len(defs) == 3 and len(setup) == 7 and body and body[-1].lineno == 175, (len(defs), len(setup), len(body))
+    ns = {"torch": torch, "nn": torch.nn, "optim": torch.optim, "config": config, "device": torch.device("cpu")}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), ns)
+    setup_code = compile(ast.Module(body=setup, type_ignores=[]), path, "exec")
+    step_code = compile(ast.Module(body=body, type_ignores=[]), path, "exec")
+    return ns, setup_code, step_code
+
+
+def _sd(prefix, module, out):
+    for k, v in module.state_dict().items():
+        out[f"{prefix}.{k}"] = v.detach().cpu().numpy().copy()
+
+
+def make_dcgan_small(path, g_hidden=8, d_hidden=8, z_dim=16, batch=4, steps=3):
+    config = {"image_channel": 1, "z_dim": z_dim, "g_hidden": g_hidden, "d_hidden": d_hidden, "real_label": 1.0,
+              "fake_label": 0.0, "lr": 2e-4, "seed": 1, "batch_size": batch}
+    ns, setup_code, step_code = _lift_dcgan(config)
+    torch.manual_seed(config["seed"])  # mnist_dcgan.py:33
+    exec(setup_code, ns)
+    netG, netD = ns["netG"], ns["netD"]
+    out = {"meta.g_hidden": np.int64(g_hidden), "meta.d_hidden": np.int64(d_hidden), "meta.z_dim": np.int64(z_dim),
+           "meta.batch": np.int64(batch), "meta.steps": np.int64(steps)}
+    _sd("init.G", netG, out)
+    _sd("init.D", netD, out)
+
+    # single forward passes at init (train mode, but on copies so running stats of the trained nets are untouched)
+    import copy
+    gen = torch.Generator().manual_seed(7)
+    real0 = torch.rand(batch, 1, 64, 64, generator=gen) * 2 - 1
+    z0 = torch.randn(batch, z_dim, 1, 1, generator=gen)
+    g0, d0 = copy.deepcopy(netG), copy.deepcopy(netD)
+    out["fwd.real"], out["fwd.z"] = real0.numpy(), z0.numpy()
+    out["fwd.G_out"] = g0(z0).detach().numpy()
+    out["fwd.D_out"] = d0(real0).detach().numpy()
+    g0.eval(); d0.eval()
+    out["fwd.G_out_eval"] = g0(z0).detach().numpy()
+    out["fwd.D_out_eval"] = d0(real0).detach().numpy()
+
+    for k in range(steps):
+        gen = torch.Generator().manual_seed(100 + k)
+        real = torch.rand(batch, 1, 64, 64, generator=gen) * 2 - 1
+        # the loop body draws its noise from the global RNG (:156); replay that draw to record it
+        torch.manual_seed(1000 + k)
+        noise = torch.randn(batch, z_dim, 1, 1)
+        torch.manual_seed(1000 + k)
+        ns["data"] = (real,)
+        exec(step_code, ns)
+        out[f"step{k}.real"], out[f"step{k}.noise"] = real.numpy(), noise.numpy()
+        for name in ("errD_real", "errD_fake", "errD", "errG"):
+            out[f"step{k}.{name}"] = np.float32(ns[name].item())
+        for name in ("D_x", "D_G_z1", "D_G_z2"):
+            out[f"step{k}.{name}"] = np.float32(ns[name])
+        assert torch.equal(ns["noise"], noise)
+    _sd("final.G", netG, out)
+    _sd("final.D", netD, out)
+    for n, p in netG.named_parameters():
+        out[f"final.G.grad.{n}"] = p.grad.detach().numpy().copy()
+    for n, p in netD.named_parameters():   # = D-step grads + the G-step's D wgrad? no: zeroed at :147, so last D-step + G-step
+        out[f"final.D.grad.{n}"] = p.grad.detach().numpy().copy()
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
+    make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))

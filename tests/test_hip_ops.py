@@ -1,0 +1,230 @@
+"""GPU parity, op level: every C-ABI entry point against the oracle (torch-CPU float64 for the conv family — the same
+operators the reference calls — and oracle/ops_np.py for the rest) on identical seeded inputs.
+
+Stated tolerance (SURVEY.md §8c noise floor): the MFMA path is a k-ordered fp32 fma chain, so for a length-K dot product
+of O(1) terms we allow |err| <= 2e-6 * sqrt(K) * max|terms| + 1e-6 (random-walk bound with ample margin); elementwise
+ops must agree to 2e-6 relative.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pcg():
+    import pcgan_amd
+    pcgan_amd.load()
+    return pcgan_amd
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+# B, Cin, Cout, H, W, k, s, p
+CONV_CASES = [
+    # DCGAN-64 discriminator / generator layers at full width, small batch
+    (4, 64, 128, 32, 32, 4, 2, 1),     # D2 / G4 adjoint
+    (4, 128, 256, 16, 16, 4, 2, 1),    # D3 / G3 adjoint
+    (4, 256, 512, 8, 8, 4, 2, 1),      # D4 / G2 adjoint
+    (8, 1, 64, 64, 64, 4, 2, 1),       # D1 (thin Cin) / G5 adjoint
+    (8, 512, 1, 4, 4, 4, 1, 0),        # D5 (thin Cout)
+    (8, 8192, 100, 1, 1, 1, 1, 0),     # G1 adjoint as a 1x1 conv (K tail: Cout=100)
+    # counteRGAN shapes
+    (3, 64, 64, 28, 28, 3, 1, 1),      # resblock conv
+    (3, 64, 128, 14, 14, 3, 2, 1),     # D conv 14->7
+    (3, 128, 256, 7, 7, 3, 2, 1),      # D conv 7->4 (odd extent: unequal phases)
+    (3, 3, 64, 28, 28, 3, 1, 1),       # conv_in (thin Cin=3)
+    (3, 64, 1, 28, 28, 3, 1, 1),       # conv_out (thin Cout)
+    (3, 2, 64, 28, 28, 3, 2, 1),       # D entry (thin Cin=2)
+    # ragged / tiny: partial tiles in M, N and K
+    (1, 4, 4, 5, 5, 3, 1, 1),
+    (2, 36, 20, 6, 10, 3, 2, 1),
+    (5, 8, 8, 64, 64, 4, 2, 1),        # reduced-width golden nets (g_hidden=8)
+]
+
+
+def _conv_ref(B, Cin, Cout, H, W, k, s, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    return x, w, b, y, dy
+
+
+def _tol(K, scale):
+    return 2e-6 * math.sqrt(K) * scale + 1e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(pcg, B, Cin, Cout, H, W, k, s, p):
+    ops = pcg.ops
+    x, w, b, y, dy = _conv_ref(B, Cin, Cout, H, W, k, s, p, seed=B * 131 + Cin)
+    g = ops.conv_geom(B, H, W, Cin, Cout, k, k, s, p)
+    xd = nhwc(x.detach()).float().to(dev())
+    wd = nhwc(w.detach()).float().to(dev())          # OHWI
+    bd = b.float().to(dev())
+    dyd = nhwc(dy).float().to(dev())
+
+    yd = ops.conv2d_fwd(g, xd, wd, bd)
+    err = (yd.cpu().double() - nhwc(y.detach())).abs().max().item()
+    assert err <= _tol(Cin * k * k, 4.0), f"fwd max err {err}"
+
+    dxd = ops.conv2d_dgrad(g, dyd, wd)
+    err = (dxd.cpu().double() - nhwc(x.grad)).abs().max().item()
+    assert err <= _tol(Cout * k * k, 4.0), f"dgrad max err {err}"
+
+    dwd = torch.full((Cout, k, k, Cin), 0.5, dtype=torch.float32, device=dev())
+    ops.conv2d_wgrad(g, xd, dyd, dwd, accumulate=False)
+    ref = nhwc(w.grad)
+    K = B * y.shape[2] * y.shape[3]
+    err = (dwd.cpu().double() - ref).abs().max().item()
+    assert err <= _tol(K, 8.0), f"wgrad max err {err}"
+    # accumulate: second call adds into dw (mnist_dcgan.py:153,161 accumulate .grad over two backward calls)
+    ops.conv2d_wgrad(g, xd, dyd, dwd, accumulate=True)
+    err = (dwd.cpu().double() - 2 * ref).abs().max().item()
+    assert err <= 2 * _tol(K, 8.0), f"wgrad accumulate max err {err}"
+
+
+def test_conv_rejects_bad_geometry(pcg):
+    ops = pcg.ops
+    g = ops.conv_geom(2, 8, 8, 8, 8, 4, 4, 2, 1)
+    g.OH = 5  # inconsistent
+    x = torch.zeros(2, 8, 8, 8, device=dev()); w = torch.zeros(8, 4, 4, 8, device=dev())
+    with pytest.raises(pcg.PcgError, match="inconsistent"):
+        ops.conv2d_fwd(g, x, w, None, out=torch.zeros(2, 5, 5, 8, device=dev()))
+    with pytest.raises(pcg.PcgError, match="GPU"):
+        ops.act_fwd(torch.zeros(4), ops.ACT_RELU)
+
+
+@pytest.mark.parametrize("rows,C", [(4 * 16 * 16, 128), (4 * 8 * 8, 256), (6 * 28 * 28, 64), (37, 10), (1000, 512), (5, 8)])
+@pytest.mark.parametrize("act,slope", [(O.ACT_RELU, 0.0), (O.ACT_LRELU, 0.2)])
+def test_batchnorm_fwd_bwd(pcg, rows, C, act, slope):
+    ops = pcg.ops
+    rng = np.random.default_rng(rows + C)
+    x = (rng.standard_normal((rows, C)) * 1.5 + 0.3).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    dy = rng.standard_normal((rows, C)).astype(np.float32)
+    rm0, rv0 = rng.standard_normal(C).astype(np.float32), (1 + rng.random(C)).astype(np.float32)
+    mean, invstd, nrm, nrv = O.bn_train_stats(x, 1e-5, 0.1, rm0, rv0)
+    y = O.bn_apply_act(x, mean, invstd, gamma, beta, act, slope)
+    dx, dg, db = O.bn_act_bwd(dy, x, y, mean, invstd, gamma, act, slope)
+
+    d = dev()
+    xd, gd, bd, dyd = (torch.from_numpy(a).to(d) for a in (x, gamma, beta, dy))
+    rm, rv = torch.from_numpy(rm0).to(d), torch.from_numpy(rv0).to(d)
+    nbt = torch.zeros(1, dtype=torch.int64, device=d)
+    md, isd = ops.bn_train_stats(xd, C, 1e-5, 0.1, rm, rv, nbt)
+    np.testing.assert_allclose(md.cpu().numpy(), mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(isd.cpu().numpy(), invstd, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rm.cpu().numpy(), nrm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), nrv, rtol=1e-5, atol=1e-6)
+    assert nbt.item() == 1
+    yd = ops.bn_apply_act(xd, C, md, isd, gd, bd, act, slope)
+    np.testing.assert_allclose(yd.cpu().numpy(), y, rtol=2e-5, atol=2e-6)
+    dgd = torch.full((C,), 1.0, device=d); dbd = torch.full((C,), -1.0, device=d)
+    dxd = ops.bn_act_bwd(dyd, xd, yd, C, md, isd, gd, act, slope, dgd, dbd, accumulate=True)
+    scale = math.sqrt(rows)
+    np.testing.assert_allclose(dgd.cpu().numpy() - 1.0, dg, rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(dbd.cpu().numpy() + 1.0, db, rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(dxd.cpu().numpy(), dx, rtol=1e-4, atol=2e-5)
+    # eval mode: running statistics, invstd = rsqrt(var + eps) inside the kernel
+    ye = ops.bn_apply_act(xd, C, rm, rv, gd, bd, act, slope, var_eps=1e-5)
+    ref = O.bn_apply_act(x, nrm, 1.0 / np.sqrt(nrv + 1e-5), gamma, beta, act, slope)
+    np.testing.assert_allclose(ye.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("act,slope", [(O.ACT_RELU, 0.0), (O.ACT_LRELU, 0.2), (O.ACT_TANH, 0.0), (O.ACT_SIGMOID, 0.0)])
+@pytest.mark.parametrize("n", [4096 * 64, 1001])
+def test_activations(pcg, act, slope, n):
+    ops = pcg.ops
+    rng = np.random.default_rng(n + act)
+    x = (rng.standard_normal(n) * 2).astype(np.float32)
+    dy = rng.standard_normal(n).astype(np.float32)
+    y = O.act_fwd(x, act, slope)
+    xd, dyd = torch.from_numpy(x).to(dev()), torch.from_numpy(dy).to(dev())
+    yd = ops.act_fwd(xd, act, slope)
+    np.testing.assert_allclose(yd.cpu().numpy(), y, rtol=2e-6, atol=2e-7)
+    dxd = ops.act_bwd(dyd, yd, act, slope)
+    np.testing.assert_allclose(dxd.cpu().numpy(), dy * O.act_grad_from_out(yd.cpu().numpy(), act, slope), rtol=2e-6, atol=2e-7)
+    # in place (nn.ReLU(True) / LeakyReLU(inplace=True) in the reference)
+    ops.act_fwd(xd, act, slope, out=xd)
+    assert torch.equal(xd, yd)
+
+
+@pytest.mark.parametrize("n", [512, 1000, 7])
+def test_bce_losses(pcg, n):
+    ops = pcg.ops
+    rng = np.random.default_rng(n)
+    p = rng.random(n).astype(np.float32)
+    p[0] = 0.0; p[-1] = 1.0  # saturated: the -100 clamp and the 1e-12 denominator clamp
+    z = (rng.standard_normal(n) * 5).astype(np.float32)
+    for t in (0.0, 1.0):
+        l, gr = O.bce(p, t)
+        ld, gd = ops.bce_fwd_bwd(torch.from_numpy(p).to(dev()), None, t)
+        np.testing.assert_allclose(ld.item(), l, rtol=2e-6)
+        np.testing.assert_allclose(gd.cpu().numpy(), gr, rtol=2e-5, atol=1e-9)
+        l, gr = O.bce_with_logits(z, t)
+        ld, gd = ops.bce_logits_fwd_bwd(torch.from_numpy(z).to(dev()), t)
+        np.testing.assert_allclose(ld.item(), l, rtol=2e-6)
+        np.testing.assert_allclose(gd.cpu().numpy(), gr, rtol=2e-5, atol=1e-9)
+    tt = (rng.random(n) > 0.5).astype(np.float32)
+    l, gr = O.bce(p, tt)
+    ld, gd = ops.bce_fwd_bwd(torch.from_numpy(p).to(dev()), torch.from_numpy(tt).to(dev()), 0.0)
+    np.testing.assert_allclose(ld.item(), l, rtol=2e-6)
+
+
+@pytest.mark.parametrize("betas,wd,decoupled", [((0.5, 0.999), 0.0, False), ((0.9, 0.999), 0.0, False), ((0.0, 0.9), 0.01, True)])
+@pytest.mark.parametrize("n", [4096, 1003])
+def test_adam(pcg, betas, wd, decoupled, n):
+    ops = pcg.ops
+    rng = np.random.default_rng(n)
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n); v = np.zeros(n); pr = p.astype(np.float64)
+    d = dev()
+    pd = torch.from_numpy(p.copy()).to(d); md = torch.zeros(n, device=d); vd = torch.zeros(n, device=d)
+    pd2 = pd.clone(); md2 = torch.zeros(n, device=d); vd2 = torch.zeros(n, device=d)
+    step_dev = torch.zeros(1, dtype=torch.int64, device=d); hyper = torch.zeros(2, device=d)
+    for step in range(1, 5):
+        g = rng.standard_normal(n).astype(np.float32)
+        gd = torch.from_numpy(g).to(d)
+        pr, m, v = O.adam_step(pr, g, m, v, step, 2e-4, betas[0], betas[1], 1e-8, wd, decoupled)
+        ops.adam_step(pd, gd, md, vd, 2e-4, betas[0], betas[1], 1e-8, wd, decoupled, step)
+        ops.adam_step_capturable(pd2, gd, md2, vd2, 2e-4, betas[0], betas[1], 1e-8, wd, decoupled, step_dev, hyper)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-9)
+    assert step_dev.item() == 4
+    assert torch.equal(pd, pd2) and torch.equal(md, md2) and torch.equal(vd, vd2)
+
+
+def test_fill_sumsq_colsum(pcg):
+    ops = pcg.ops
+    d = dev()
+    t = torch.empty(1003, device=d)
+    ops.fill(t, 0.25)
+    assert torch.equal(t.cpu(), torch.full((1003,), 0.25))
+    out = torch.zeros(1, device=d)
+    ops.sumsq(t, out)
+    np.testing.assert_allclose(out.item(), 1003 * 0.0625, rtol=1e-6)
+    rng = np.random.default_rng(0)
+    for rows, C in [(3 * 28 * 28, 64), (100, 1), (777, 10)]:
+        a = rng.standard_normal((rows, C)).astype(np.float32)
+        db = torch.ones(C, device=d)
+        ops.colsum(rows, C, torch.from_numpy(a).to(d), db, accumulate=True)
+        np.testing.assert_allclose(db.cpu().numpy() - 1.0, a.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4)
