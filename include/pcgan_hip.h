@@ -117,10 +117,12 @@ int pcg_act_bwd(const float* dy, const float* y, int64_t n, int act, float slope
  * nn.BCELoss (mean): mnist_dcgan.py:125,152,160,172  ([torch]: log clamped at -100; backward
  * (p-t)/max(p(1-p),1e-12)/n).  loss is one float on the device; dp may be null (forward only).     */
 int pcg_bce_fwd_bwd(const float* p, const float* target /*nullable → target_const*/, float target_const,
-                    int64_t n, float grad_scale, float* loss, float* dp, pcg_stream_t stream);
+                    int64_t n, float grad_scale, const float* grad_out_dev /*nullable: one float, multiplies dp*/,
+                    float* loss /*nullable*/, float* dp /*nullable*/, pcg_stream_t stream);
 /* nn.BCEWithLogitsLoss (mean): conditional_counteRGAN/mnist/trainer.py:79,106-107,117              */
 int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale,
-                           float* loss, float* dz, pcg_stream_t stream);
+                           const float* grad_out_dev /*nullable*/, float* loss /*nullable*/, float* dz /*nullable*/,
+                           pcg_stream_t stream);
 
 /* ---- optimizer -------------------------------------------------------------------------------
  * torch.optim.Adam over one flat fp32 parameter buffer: mnist_dcgan.py:126-127,164,175;

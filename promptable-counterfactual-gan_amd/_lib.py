@@ -51,8 +51,8 @@ PROTOTYPES = {
     "pcg_bn_act_bwd": (_i, [_vp, _vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_act_fwd": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
     "pcg_act_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
-    "pcg_bce_fwd_bwd": (_i, [_vp, _vp, _f, _i64, _f, _vp, _vp, _vp]),
-    "pcg_bce_logits_fwd_bwd": (_i, [_vp, _f, _i64, _f, _vp, _vp, _vp]),
+    "pcg_bce_fwd_bwd": (_i, [_vp, _vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),
+    "pcg_bce_logits_fwd_bwd": (_i, [_vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),
     "pcg_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _vp]),
     "pcg_adam_step_capturable": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),

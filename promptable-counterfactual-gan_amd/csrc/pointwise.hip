@@ -60,10 +60,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ p, const float* __restrict__ target, float tconst,
-                                                  int64_t n, float grad_scale, float* loss, float* __restrict__ dp) {
+                                                  int64_t n, float grad_scale, const float* grad_out, float* loss,
+                                                  float* __restrict__ dp) {
   __shared__ float red[4];
   float acc = 0.f;
   const float inv_n = 1.f / (float)n;
+  if (grad_out) grad_scale *= grad_out[0];
   for (int64_t i = threadIdx.x; i < n; i += 256) {
     const float pi = p[i], t = target ? target[i] : tconst;
     // [torch] binary_cross_entropy: log terms clamped at -100
@@ -76,10 +78,11 @@ __global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ p, c
 }
 
 __global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ z, float t, int64_t n, float grad_scale,
-                                                         float* loss, float* __restrict__ dz) {
+                                                         const float* grad_out, float* loss, float* __restrict__ dz) {
   __shared__ float red[4];
   float acc = 0.f;
   const float inv_n = 1.f / (float)n;
+  if (grad_out) grad_scale *= grad_out[0];
   for (int64_t i = threadIdx.x; i < n; i += 256) {
     const float x = z[i];
     // [torch] binary_cross_entropy_with_logits: (1-t)*x + max(-x,0) + log(exp(-max) + exp(-x-max))
@@ -201,16 +204,18 @@ extern "C" int pcg_act_bwd(const float* dy, const float* y, int64_t n, int act, 
 }
 
 extern "C" int pcg_bce_fwd_bwd(const float* p, const float* target, float target_const, int64_t n, float grad_scale,
-                               float* loss, float* dp, pcg_stream_t stream) {
+                               const float* grad_out_dev, float* loss, float* dp, pcg_stream_t stream) {
   PCG_REQUIRE(p && n > 0 && (loss || dp), "pcg_bce_fwd_bwd: bad arguments");
-  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, target_const, n, grad_scale, loss, dp);
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, target_const, n, grad_scale, grad_out_dev,
+                     loss, dp);
   return launch_status("bce_kernel");
 }
 
-extern "C" int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale, float* loss, float* dz,
-                                      pcg_stream_t stream) {
+extern "C" int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale,
+                                      const float* grad_out_dev, float* loss, float* dz, pcg_stream_t stream) {
   PCG_REQUIRE(z && n > 0 && (loss || dz), "pcg_bce_logits_fwd_bwd: bad arguments");
-  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, z, target_const, n, grad_scale, loss, dz);
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, z, target_const, n, grad_scale, grad_out_dev,
+                     loss, dz);
   return launch_status("bce_logits_kernel");
 }
 

@@ -1,0 +1,173 @@
+"""Host-side mirror of `dconv_gan/mnist/mnist_dcgan.py` on the HIP kernels: same `config` keys, same class names,
+same `nn.Sequential` layer list (so `state_dict()` keys are `main.0.weight` ... `main.12.weight` exactly as in the
+reference), same loss / optimizer construction and the same D-step / G-step sequence.
+
+    reference (mnist_dcgan.py)                      here
+    --------------------------------------------    ------------------------------------------------
+    weights_init               :63-69               weights_init (unchanged semantics)
+    Generator / Discriminator  :72-116              Generator / Discriminator (SequentialConvNet)
+    criterion, optimizerD/G    :125-127             make_optimizers -> pcgan_amd BCELoss, Adam
+    loop body                  :147-175             train_step (no host sync inside; scalars stay on device)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import BCELoss, SequentialConvNet
+from .optim import Adam
+
+# mnist_dcgan.py:15-30
+config = {
+    "cuda": True,
+    "batch_size": 128,
+    "image_channel": 1,
+    "z_dim": 100,
+    "g_hidden": 64,
+    "d_hidden": 64,
+    "x_dim": 64,
+    "epochs": 20,
+    "real_label": 1.0,
+    "fake_label": 0.0,
+    "lr": 2e-4,
+    "seed": 1,
+}
+
+
+def _cfg(c):
+    return dict(config, **(c or {}))
+
+
+def weights_init(m):
+    """mnist_dcgan.py:63-69 (class-name substring match: 'Conv' also hits ConvTranspose2d)."""
+    classname = m.__class__.__name__
+    if classname.find("Conv") != -1 and hasattr(m, "weight") and isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        nn.init.normal_(m.weight.data, 0.0, 0.02)
+    elif classname.find("BatchNorm") != -1:
+        nn.init.normal_(m.weight.data, 1.0, 0.02)
+        nn.init.constant_(m.bias.data, 0)
+
+
+class Generator(SequentialConvNet):
+    """mnist_dcgan.py:72-93."""
+
+    def __init__(self, cfg=None):
+        c = _cfg(cfg)
+        g, z, ch = c["g_hidden"], c["z_dim"], c["image_channel"]
+        super().__init__(nn.Sequential(
+            nn.ConvTranspose2d(z, g * 8, 4, 1, 0, bias=False), nn.BatchNorm2d(g * 8), nn.ReLU(True),
+            nn.ConvTranspose2d(g * 8, g * 4, 4, 2, 1, bias=False), nn.BatchNorm2d(g * 4), nn.ReLU(True),
+            nn.ConvTranspose2d(g * 4, g * 2, 4, 2, 1, bias=False), nn.BatchNorm2d(g * 2), nn.ReLU(True),
+            nn.ConvTranspose2d(g * 2, g, 4, 2, 1, bias=False), nn.BatchNorm2d(g), nn.ReLU(True),
+            nn.ConvTranspose2d(g, ch, 4, 2, 1, bias=False), nn.Tanh(),
+        ))
+
+
+class Discriminator(SequentialConvNet):
+    """mnist_dcgan.py:96-116."""
+
+    def __init__(self, cfg=None):
+        c = _cfg(cfg)
+        d, ch = c["d_hidden"], c["image_channel"]
+        super().__init__(nn.Sequential(
+            nn.Conv2d(ch, d, 4, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d, d * 2, 4, 2, 1, bias=False), nn.BatchNorm2d(d * 2), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d * 2, d * 4, 4, 2, 1, bias=False), nn.BatchNorm2d(d * 4), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d * 4, d * 8, 4, 2, 1, bias=False), nn.BatchNorm2d(d * 8), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d * 8, 1, 4, 1, 0, bias=False), nn.Sigmoid(),
+        ))
+
+    def forward(self, input):
+        return super().forward(input).view(-1, 1).squeeze(1)  # :116
+
+
+def make_optimizers(netG, netD, cfg=None):
+    """mnist_dcgan.py:125-127."""
+    c = _cfg(cfg)
+    criterion = BCELoss()
+    optimizerD = Adam(netD.parameters(), lr=c["lr"], betas=(0.5, 0.999))
+    optimizerG = Adam(netG.parameters(), lr=c["lr"], betas=(0.5, 0.999))
+    return criterion, optimizerD, optimizerG
+
+
+class _Labels:
+    """The reference refills one `label` tensor per pass (:150,158,170); two constant tensors per batch size do
+    the same job without a fill launch per pass."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, n, value, device):
+        key = (n, float(value), device)
+        t = self._cache.get(key)
+        if t is None:
+            t = ops.fill(torch.empty(n, dtype=torch.float32, device=device), value)
+            self._cache[key] = t
+        return t
+
+
+_labels = _Labels()
+
+
+def train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, cfg=None, dp=None, skip_dead_d_wgrad=True):
+    """One iteration of the reference loop body (mnist_dcgan.py:147-175) for a batch `real` already on the GPU and a
+    noise tensor `noise` ([B, z_dim, 1, 1]; the reference draws it at :156).
+
+    Returns the loss tensors (errD_real, errD_fake, errG) and the three D outputs, all still on the device — the
+    reference's `.item()` calls (:154,162,174) are host syncs for logging and belong to the caller.
+
+    skip_dead_d_wgrad: in the G step the reference's autograd also computes D's weight gradients, which
+    `netD.zero_grad()` (:147) throws away at the next iteration.  With True they are not computed (D's parameters are
+    marked requires_grad=False around that pass); parameters, losses and G gradients are unchanged.
+    dp: optional `parallel.GradSync` — averages D's / G's flat gradient bucket across ranks before each Adam step.
+    """
+    c = _cfg(cfg)
+    b_size = real.size(0)
+    dev = real.device
+    # (1) Update D network
+    netD.zero_grad()                                              # :147
+    label = _labels.get(b_size, c["real_label"], dev)            # :150
+    out_real = netD(real)                                         # :151
+    errD_real = criterion(out_real, label)                        # :152
+    errD_real.backward()                                          # :153
+    if dp is not None:
+        dp.wait(netG)                                             # previous iteration's G all-reduce + Adam(G) done
+    fake = netG(noise)                                            # :157
+    label = _labels.get(b_size, c["fake_label"], dev)            # :158
+    out_fake = netD(fake.detach())                                # :159
+    errD_fake = criterion(out_fake, label)                        # :160
+    errD_fake.backward()                                          # :161
+    if dp is not None:
+        dp.sync_now(netD)
+    optimizerD.step()                                             # :164
+    # (2) Update G network
+    netG.zero_grad()                                              # :169
+    label = _labels.get(b_size, c["real_label"], dev)            # :170
+    if skip_dead_d_wgrad:
+        for p in netD.parameters():
+            p.requires_grad_(False)
+    try:
+        out_g = netD(fake)                                        # :171
+        errG = criterion(out_g, label)                            # :172
+        errG.backward()                                           # :173
+    finally:
+        if skip_dead_d_wgrad:
+            for p in netD.parameters():
+                p.requires_grad_(True)
+    if dp is not None:
+        dp.sync_then(netG, optimizerG.step)                       # overlapped with the next D(real) pass
+    else:
+        optimizerG.step()                                         # :175
+    return {"errD_real": errD_real, "errD_fake": errD_fake, "errG": errG, "out_real": out_real, "out_fake": out_fake,
+            "out_g": out_g}
+
+
+def build(cfg=None, device="cuda", seed=None):
+    """Nets built and initialised as the reference does (:119-122)."""
+    c = _cfg(cfg)
+    if seed is not None:
+        torch.manual_seed(seed)
+    netG = Generator(c).to(device)
+    netG.apply(weights_init)
+    netD = Discriminator(c).to(device)
+    netD.apply(weights_init)
+    return netG, netD

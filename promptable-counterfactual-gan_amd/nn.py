@@ -1,0 +1,335 @@
+"""nn.Module drop-ins backed by libpcgan_hip.so.
+
+`SequentialConvNet` takes the very `nn.Sequential` the reference scripts build (Conv2d / ConvTranspose2d /
+BatchNorm2d / ReLU / LeakyReLU / Tanh / Sigmoid — mnist_dcgan.py:75-90,99-113) and runs it on the HIP kernels:
+the torch layer objects stay as parameter containers, so `state_dict()` keys, `.apply(weights_init)`,
+`parameters()`, `.train()/.eval()` and `load_state_dict()` behave exactly as in the reference, while forward and
+backward are one autograd node that sequences C-ABI calls on NHWC activations.
+
+Parameters live in ONE flat fp32 buffer per net (conv weights physically OHWI = channels_last), gradients in a
+second one: the fused Adam step is a single launch over the flat buffer and the data-parallel all-reduce is a
+single RCCL call on the flat gradient bucket.  Backward accumulates straight into the flat gradient buffer
+(`p.grad` are views of it), which is autograd's `.grad` accumulation contract without extra add kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PcgError
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatModule(nn.Module):
+    """Keeps every parameter of the module tree as a view of one flat buffer (and .grad as views of another)."""
+
+    def __init__(self):
+        super().__init__()
+        self._flat = None
+        self._gflat = None
+        self._seg = None  # list of (param, offset, numel)
+
+    # -- layout ------------------------------------------------------------------------------------
+    def _flatten(self, device=None):
+        params = list(self.parameters())
+        if not params:
+            raise PcgError("FlatModule has no parameters")
+        device = device or params[0].device
+        if device.type != "cuda":
+            raise PcgError(f"parameters are on {device}; libpcgan_hip has no CPU path — move the module to the GPU")
+        total, seg = 0, []
+        for p in params:
+            seg.append((p, total, p.numel()))
+            total += _pad4(p.numel())
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        gflat = torch.empty(total, dtype=torch.float32, device=device)
+        ops.fill(flat, 0.0)
+        ops.fill(gflat, 0.0)
+        with torch.no_grad():
+            for p, off, n in seg:
+                pv, gv = self._views(flat, gflat, p, off, n)
+                pv.copy_(p.data)          # one-time relayout (ATen copy: setup, not the step)
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.data = pv
+                p.grad = gv
+        self._flat, self._gflat, self._seg = flat, gflat, seg
+
+    @staticmethod
+    def _views(flat, gflat, p, off, n):
+        if p.dim() == 4:  # conv weight: physical [d0, KH, KW, d1], logical [d0, d1, KH, KW] (channels_last)
+            o, i, kh, kw = p.shape
+            pv = flat[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+            gv = gflat[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+        else:
+            pv = flat[off:off + n].view(p.shape)
+            gv = gflat[off:off + n].view(p.shape)
+        return pv, gv
+
+    def _ensure_flat(self):
+        if self._flat is None:
+            self._flatten()
+            return
+        p, off, _ = self._seg[0]
+        if p.data_ptr() != self._flat.data_ptr() + 4 * off or not p.is_cuda:
+            self._flatten()  # someone replaced .data (e.g. .to(device)): rebuild the flat image from current values
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._flat = None  # .to()/.cuda()/.float() re-create storages; re-flatten lazily
+        return r
+
+    # -- grads ---------------------------------------------------------------------------------------
+    def _grad_view(self, p):
+        """(view, accumulate): the flat-buffer gradient view of parameter p, and whether it already holds a
+        gradient to add to (autograd semantics: p.grad is None means 'no gradient yet')."""
+        for q, off, n in self._seg:
+            if q is p:
+                gv = self._views(self._flat, self._gflat, p, off, n)[1]
+                acc = p.grad is not None
+                if not acc or p.grad.data_ptr() != gv.data_ptr():
+                    if acc:  # a foreign .grad tensor: adopt its values
+                        with torch.no_grad():
+                            gv.copy_(p.grad)
+                    p.grad = gv
+                return gv, acc
+        raise PcgError("parameter does not belong to this FlatModule")
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the flat gradient buffer in one launch and keep the .grad views (set_to_none is ignored: the
+        views are the gradient storage; values after backward are identical either way)."""
+        self._ensure_flat()
+        ops.fill(self._gflat, 0.0)
+        for p, off, n in self._seg:
+            if p.grad is None or p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
+                p.grad = self._views(self._flat, self._gflat, p, off, n)[1]
+
+    @property
+    def flat_params(self):
+        self._ensure_flat()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self._ensure_flat()
+        return self._gflat
+
+
+# ---------------------------------------------------------------------------------------------------
+class _Block:
+    """conv (or transposed conv) -> [BatchNorm2d] -> [activation]"""
+
+    def __init__(self, conv):
+        self.conv = conv
+        self.transposed = isinstance(conv, nn.ConvTranspose2d)
+        self.bn = None
+        self.act = ACT_NONE
+        self.slope = 0.0
+        k, s, p = conv.kernel_size, conv.stride, conv.padding
+        if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1:
+            raise PcgError(f"unsupported convolution configuration: {conv}")
+        if self.transposed and conv.output_padding != (0, 0):
+            raise PcgError(f"output_padding is not supported: {conv}")
+        self.kh, self.kw, self.stride, self.pad = k[0], k[1], s[0], p[0]
+
+    def geom(self, B, H, W):
+        """Geometry of the (adjoint) convolution and the output spatial size, for an input [B, H, W, C]."""
+        c = self.conv
+        if not self.transposed:
+            g = ops.conv_geom(B, H, W, c.in_channels, c.out_channels, self.kh, self.kw, self.stride, self.pad)
+            return g, g.OH, g.OW
+        OH = (H - 1) * self.stride - 2 * self.pad + self.kh
+        OW = (W - 1) * self.stride - 2 * self.pad + self.kw
+        # adjoint conv: x side = this layer's output (OH x OW x out_channels), y side = its input
+        g = ops.conv_geom(B, OH, OW, c.out_channels, c.in_channels, self.kh, self.kw, self.stride, self.pad)
+        if g.OH != H or g.OW != W:
+            raise PcgError(f"transposed-conv geometry mismatch for input {H}x{W}: {c}")
+        return g, OH, OW
+
+
+def _compile(seq):
+    blocks = []
+    for m in seq:
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            blocks.append(_Block(m))
+            continue
+        if not blocks:
+            raise PcgError(f"{type(m).__name__} before the first convolution is not supported")
+        b = blocks[-1]
+        if isinstance(m, nn.BatchNorm2d):
+            if b.bn is not None or b.act != ACT_NONE:
+                raise PcgError("expected conv -> [BatchNorm2d] -> [activation]")
+            if not m.affine or not m.track_running_stats or m.momentum is None:
+                raise PcgError(f"unsupported BatchNorm2d configuration: {m}")
+            b.bn = m
+        elif isinstance(m, nn.LeakyReLU):
+            b.act, b.slope = ACT_LRELU, float(m.negative_slope)
+        elif isinstance(m, nn.ReLU):
+            b.act = ACT_RELU
+        elif isinstance(m, nn.Tanh):
+            b.act = ACT_TANH
+        elif isinstance(m, nn.Sigmoid):
+            b.act = ACT_SIGMOID
+        else:
+            raise PcgError(f"layer {type(m).__name__} has no libpcgan_hip implementation")
+    if not blocks:
+        raise PcgError("empty network")
+    return blocks
+
+
+class _SeqFn(torch.autograd.Function):
+    """One autograd node for the whole stack.  Parameters are passed only so that autograd knows the output
+    depends on them; their gradients are accumulated into the flat buffer inside backward (returned as None)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        y, saved = net._run_forward(x)
+        ctx.net, ctx.saved = net, saved
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        need_x = ctx.needs_input_grad[1]
+        need_p = any(ctx.needs_input_grad[2:])
+        dx = ctx.net._run_backward(ctx.saved, dy, need_x, need_p)
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class SequentialConvNet(FlatModule):
+    """Runs `self.main` (an nn.Sequential of torch conv / BN / activation layers) on the HIP kernels.
+
+    Input and output follow the reference's NCHW *shape* convention; internally everything is NHWC.  Inputs with
+    one channel (MNIST images, z as [B, z, 1, 1]) are NHWC already, so no relayout happens at the boundary.
+    """
+
+    def __init__(self, main):
+        super().__init__()
+        self.main = main
+        self._blocks = None
+
+    # -- execution -------------------------------------------------------------------------------------
+    def forward(self, input):
+        self._ensure_flat()
+        if self._blocks is None:
+            self._blocks = _compile(self.main)
+        if input.dim() != 4:
+            raise PcgError(f"expected a [B, C, H, W] input, got shape {tuple(input.shape)}")
+        x = input.permute(0, 2, 3, 1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.dtype != torch.float32:
+            raise PcgError(f"expected float32 input, got {x.dtype}")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            y = _SeqFn.apply(self, x, *self.parameters())
+        else:
+            y, _ = self._run_forward(x, keep=False)
+        return y.permute(0, 3, 1, 2)
+
+    def _run_forward(self, x, keep=True):
+        B, H, W, C = x.shape
+        saved = []
+        a = x
+        for b in self._blocks:
+            c = b.conv
+            if C != c.in_channels:
+                raise PcgError(f"channel mismatch: activation has {C}, layer expects {c.in_channels}")
+            g, OH, OW = b.geom(B, H, W)
+            w = ops.ohwi(c.weight.data)
+            bias = c.bias.data if c.bias is not None else None
+            if not b.transposed:
+                z = ops.conv2d_fwd(g, a, w, bias)
+            else:
+                z = ops.conv2d_dgrad(g, a, w, bias)
+            C = c.out_channels
+            mean = invstd = None
+            if b.bn is not None:
+                bn = b.bn
+                if bn.training:
+                    mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                      bn.num_batches_tracked)
+                    y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
+                else:
+                    y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
+                                         var_eps=bn.eps, out=z)
+                    z = None
+            elif b.act != ACT_NONE:
+                y = ops.act_fwd(z, b.act, b.slope, out=z)  # in place, like nn.ReLU(True) / LeakyReLU(inplace=True)
+                z = None
+            else:
+                y, z = z, None
+            if keep:
+                saved.append((g, a, z, mean, invstd, y, b.bn is not None and not b.bn.training))
+            a, H, W = y, OH, OW
+        return a, saved
+
+    def _run_backward(self, saved, dy, need_x, need_p):
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        d = dy
+        own = False  # never write into autograd's incoming grad tensor; deeper gradients are ours to overwrite
+        nblk = len(self._blocks)
+        for idx in range(nblk - 1, -1, -1):
+            b = self._blocks[idx]
+            g, a, z, mean, invstd, y, bn_eval = saved[idx]
+            c = b.conv
+            C = c.out_channels
+            if b.bn is not None:
+                if bn_eval:
+                    raise PcgError("backward through an eval-mode BatchNorm2d is not implemented")
+                bn = b.bn
+                dg = db = None
+                acc = False
+                if need_p and bn.weight.requires_grad:
+                    dg, acc = self._grad_view(bn.weight)
+                    db, acc2 = self._grad_view(bn.bias)
+                    if acc != acc2:
+                        raise PcgError("inconsistent .grad state on BatchNorm weight/bias")
+                dz = ops.bn_act_bwd(d, z, y, C, mean, invstd, bn.weight.data, b.act, b.slope, dg, db, acc)
+            elif b.act != ACT_NONE:
+                dz = ops.act_bwd(d, y, b.act, b.slope, out=d if own else None)
+            else:
+                dz = d
+            own = True
+            if need_p and c.weight.requires_grad:
+                gw, acc = self._grad_view(c.weight)
+                gw = ops.ohwi(gw)
+                if not b.transposed:
+                    ops.conv2d_wgrad(g, a, dz, gw, acc)
+                else:
+                    ops.conv2d_wgrad(g, dz, a, gw, acc)
+                if c.bias is not None and c.bias.requires_grad:
+                    gb, accb = self._grad_view(c.bias)
+                    ops.colsum(dz.numel() // C, C, dz, gb, accb)
+            last = idx == 0
+            if last and not need_x:
+                return None
+            if not b.transposed:
+                d = ops.conv2d_dgrad(g, dz, ops.ohwi(c.weight.data))
+            else:
+                d = ops.conv2d_fwd(g, dz, ops.ohwi(c.weight.data))
+        return d
+
+
+class BCELoss(nn.Module):
+    """nn.BCELoss() (reduction='mean') on the HIP kernel (mnist_dcgan.py:125)."""
+
+    def forward(self, input, target):
+        return _BCEFn.apply(input, target)
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, target):
+        p = p.contiguous()
+        target = target.contiguous()
+        loss, _ = ops.bce_fwd_bwd(p, target, 0.0, need_grad=False)
+        ctx.save_for_backward(p, target)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, target = ctx.saved_tensors
+        _, dp = ops.bce_fwd_bwd(p, target, 0.0, need_loss=False, grad_out=grad_out.contiguous().view(1))
+        return dp, None

@@ -15,6 +15,49 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ConvGeom
 
 _ws_cache = {}
 
+# Optional per-launch timing hook (bench.py): when set, every MFMA-family conv call is bracketed by two
+# torch.cuda.Event records on the current stream and reported as hook(label, flops, start_event, end_event).
+_conv_hook = None
+
+
+def set_conv_hook(hook):
+    global _conv_hook
+    _conv_hook = hook
+
+
+def _conv_label(g, op):
+    """Kernel the C dispatcher picks for this geometry (mirrors conv_igemm.hip / thin_conv.hip)."""
+    if g.Cin <= 3 or g.Cout <= 3:
+        return f"thin_{op}"
+    if op == "wgrad":
+        return "conv_wgrad_kernel<64x128>" if g.Cout <= 64 else "conv_wgrad_kernel<128x128>"
+    n = g.Cout if op == "fwd" else g.Cin
+    return f"conv_{op}_kernel<128x{'128' if n > 64 else '64'}>"
+
+
+def _conv_flops(g):
+    return 2.0 * g.B * g.OH * g.OW * g.Cout * g.KH * g.KW * g.Cin
+
+
+class _Timed:
+    def __init__(self, g, op):
+        self.on = _conv_hook is not None
+        if self.on:
+            self.g, self.op = g, op
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.t1.record()
+            _conv_hook(_conv_label(self.g, self.op), _conv_flops(self.g), self.t0, self.t1)
+        return False
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -65,7 +108,8 @@ def conv2d_fwd(g, x, w, bias=None, out=None):
     _chk(x, "x"); _chk(w, "w")
     assert x.numel() == g.B * g.IH * g.IW * g.Cin and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     y = out if out is not None else torch.empty((g.B, g.OH, g.OW, g.Cout), dtype=torch.float32, device=x.device)
-    check(_lib.load().pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _stream()), "pcg_conv2d_fwd")
+    with _Timed(g, "fwd"):
+        check(_lib.load().pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _stream()), "pcg_conv2d_fwd")
     return y
 
 
@@ -74,7 +118,8 @@ def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
     _chk(dy, "dy"); _chk(w, "w")
     assert dy.numel() == g.B * g.OH * g.OW * g.Cout and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
-    check(_lib.load().pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _stream()), "pcg_conv2d_dgrad")
+    with _Timed(g, "dgrad"):
+        check(_lib.load().pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _stream()), "pcg_conv2d_dgrad")
     return dx
 
 
@@ -85,8 +130,9 @@ def conv2d_wgrad(g, x, dy, dw, accumulate):
     lib = _lib.load()
     need = lib.pcg_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, x.device)
-    check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
-          "pcg_conv2d_wgrad")
+    with _Timed(g, "wgrad"):
+        check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
+              "pcg_conv2d_wgrad")
     return dw
 
 
@@ -145,22 +191,23 @@ def act_bwd(dy, y, act, slope=0.0, out=None):
 
 
 # ---- losses -------------------------------------------------------------------------------------------
-def bce_fwd_bwd(p, target, target_const, grad_scale=1.0, need_grad=True):
-    """nn.BCELoss(mean).  Returns (loss[1], dp or None).  `target` tensor or None (=> constant)."""
+def bce_fwd_bwd(p, target, target_const, grad_scale=1.0, need_loss=True, need_grad=True, grad_out=None):
+    """nn.BCELoss(mean).  Returns (loss[1] or None, dp or None).  `target` tensor or None (=> constant);
+    `grad_out`: optional one-element device tensor multiplied into dp (autograd's grad_output)."""
     _chk(p, "p")
-    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    loss = torch.empty(1, dtype=torch.float32, device=p.device) if need_loss else None
     dp = torch.empty_like(p) if need_grad else None
-    check(_lib.load().pcg_bce_fwd_bwd(_p(p), _p(target), float(target_const), p.numel(), grad_scale, _p(loss), _p(dp), _stream()),
-          "pcg_bce_fwd_bwd")
+    check(_lib.load().pcg_bce_fwd_bwd(_p(p), _p(target), float(target_const), p.numel(), grad_scale, _p(grad_out), _p(loss),
+                                      _p(dp), _stream()), "pcg_bce_fwd_bwd")
     return loss, dp
 
 
-def bce_logits_fwd_bwd(z, target_const, grad_scale=1.0, need_grad=True):
+def bce_logits_fwd_bwd(z, target_const, grad_scale=1.0, need_loss=True, need_grad=True, grad_out=None):
     _chk(z, "z")
-    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    loss = torch.empty(1, dtype=torch.float32, device=z.device) if need_loss else None
     dz = torch.empty_like(z) if need_grad else None
-    check(_lib.load().pcg_bce_logits_fwd_bwd(_p(z), float(target_const), z.numel(), grad_scale, _p(loss), _p(dz), _stream()),
-          "pcg_bce_logits_fwd_bwd")
+    check(_lib.load().pcg_bce_logits_fwd_bwd(_p(z), float(target_const), z.numel(), grad_scale, _p(grad_out), _p(loss), _p(dz),
+                                             _stream()), "pcg_bce_logits_fwd_bwd")
     return loss, dz
 
 
