@@ -10,7 +10,8 @@ namespace pcg {
 namespace {
 
 constexpr int CR_THREADS = 256;
-constexpr int CR_MAX_BLOCKS = 1024;
+constexpr int CR_MAX_BLOCKS = 512;
+constexpr int FIN_CH = 32, FIN_SL = 8;   // finalize: 32 channels x 8 partial-slices per 256-thread block
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
 
@@ -127,19 +128,44 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double inv_rows,
-                                         double unbias, float eps, float momentum, float* save_mean, float* save_invstd,
-                                         float* running_mean, float* running_var, int64_t* num_batches_tracked) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += (double)partial[((size_t)b * 2 + 0) * C + c];
-    q += (double)partial[((size_t)b * 2 + 1) * C + c];
+// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+8, ... and the 8
+// slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/8 dependent loads per thread).
+template <int NVAL>
+__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblocks, int C, int& c_out,
+                                              double (&sum)[NVAL]) {
+  __shared__ double red[NVAL][FIN_SL][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  double acc[NVAL];
+#pragma unroll
+  for (int k = 0; k < NVAL; ++k) acc[k] = 0.0;
+  if (c < C)
+    for (int b = sl; b < nblocks; b += FIN_SL)
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k) acc[k] += (double)partial[((size_t)b * NVAL + k) * C + c];
+#pragma unroll
+  for (int k = 0; k < NVAL; ++k) red[k][sl][cl] = acc[k];
+  __syncthreads();
+  c_out = c;
+  if (sl != 0 || c >= C) return false;
+#pragma unroll
+  for (int k = 0; k < NVAL; ++k) {
+    double s = 0.0;
+    for (int j = 0; j < FIN_SL; ++j) s += red[k][j][cl];
+    sum[k] = s;
   }
-  const double mean = s * inv_rows;
-  double var = q * inv_rows - mean * mean;
+  return true;
+}
+
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int C, double inv_rows, double unbias, float eps, float momentum,
+    float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+  int c;
+  double sm[2];
+  if (!finalize_sums<2>(partial, nblocks, C, c, sm)) return;
+  const double mean = sm[0] * inv_rows;
+  double var = sm[1] * inv_rows - mean * mean;
   if (var < 0.0) var = 0.0;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -147,30 +173,26 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int 
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) colsum_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                                         int C, float* out, int accumulate) {
+  int c;
+  double sm[1];
+  if (!finalize_sums<1>(partial, nblocks, C, c, sm)) return;
+  out[c] = (accumulate ? out[c] : 0.f) + (float)sm[0];
 }
 
 // coef[0][c] = gamma*invstd ; coef[1][c] = mean(dz) ; coef[2][c] = mean(dz*xhat)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double inv_rows,
-                                       const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s1 += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int C, double inv_rows, const float* gamma, const float* invstd,
+    float* coef, float* dgamma, float* dbeta, int accumulate) {
+  int c;
+  double sm[2];
+  if (!finalize_sums<2>(partial, nblocks, C, c, sm)) return;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sm[0];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sm[1];
   coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
-  coef[C + c] = (float)(s1 * inv_rows);
-  coef[2 * C + c] = (float)(s2 * inv_rows);
+  coef[C + c] = (float)(sm[0] * inv_rows);
+  coef[2 * C + c] = (float)(sm[1] * inv_rows);
 }
 
 // ---- elementwise passes (float4 when C % 4 == 0) -------------------------------------------------
@@ -284,7 +306,7 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
   FnStats fn{x};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                      num_batches_tracked);
   return launch_status("bn_stats_finalize_kernel");
@@ -318,7 +340,7 @@ extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, i
   float* coef = partial + (size_t)cp.nblocks * 2 * C;
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
@@ -343,6 +365,6 @@ extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, i
   float* partial = (float*)workspace;
   FnSum fn{dy};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
   return launch_status("colsum_finalize_kernel");
 }

@@ -190,7 +190,15 @@ __global__ void __launch_bounds__(256) slab_reduce4_kernel(const float4* __restr
                                                            size_t stride4, int nslabs, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = accumulate ? o[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < nslabs; ++z) {
+    int z = 0;
+    for (; z + 8 <= nslabs; z += 8) {  // 8 independent 16-byte loads in flight; summed in slab order
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s[(size_t)(z + j) * stride4 + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; z < nslabs; ++z) {
       const float4 v = s[(size_t)z * stride4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
@@ -268,10 +276,10 @@ int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_strid
   const bool vec = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)slab | (uintptr_t)dw) & 15) == 0;
   if (vec) {
     const size_t n4 = n / 4;
-    unsigned blocks = (unsigned)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    unsigned blocks = (unsigned)((n4 + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(slab),
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(blocks), dim3(64), 0, s, reinterpret_cast<const float4*>(slab),
                        reinterpret_cast<float4*>(dw), n4, slab_stride / 4, nslabs, accumulate);
   } else {
     unsigned blocks = (unsigned)((n + 255) / 256);
