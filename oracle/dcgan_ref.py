@@ -96,7 +96,8 @@ def dcgan_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, confi
     # (1) Update D network
     netD.zero_grad()                                                                   # :147
     b_size = real.size(0)
-    label = torch.full((b_size,), c["real_label"], dtype=torch.float, device=real.device)  # :150
+    # :150 (dtype=torch.float there; real.dtype here so the same restatement can be evaluated in float64 as "truth")
+    label = torch.full((b_size,), c["real_label"], dtype=real.dtype, device=real.device)
     output = netD(real)                                                                # :151
     errD_real = criterion(output, label)                                               # :152
     errD_real.backward()                                                               # :153

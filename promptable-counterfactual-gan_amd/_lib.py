@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime this process will use)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcgan_hip.so")
+LIB_PATH = os.environ.get("PCG_LIB") or os.path.join(_HERE, "libpcgan_hip.so")  # PCG_LIB: A/B builds of the same ABI
 
 PCG_OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

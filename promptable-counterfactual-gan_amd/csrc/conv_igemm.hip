@@ -10,289 +10,34 @@
 //
 // Replaces ATen conv forward/backward behind nn.Conv2d / nn.ConvTranspose2d at
 // dconv_gan/mnist/mnist_dcgan.py:76-88,100-111 and conditional_counteRGAN/mnist/models/*.py.
-#include "igemm_core.h"
+#include "conv_loaders.h"
 #include "thin_conv.h"
 
 namespace pcg {
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// parameter blocks (passed by value as kernel arguments)
-// ------------------------------------------------------------------------------------------------
-struct ConvP {
-  const float* x;    // fwd: input          dgrad: dx (output, written)   wgrad: input
-  const float* w;
-  const float* bias; // fwd: per-Cout       dgrad: per-Cin (nullable)
-  float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
-  const float* dy;   // dgrad / wgrad
-  int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
-  int M, N;          // GEMM extents of this launch (fwd: B*OH*OW, Cout)
-  int tilesN;
-  int ktiles;        // fwd: KH*KW*ceil(Cin/32)
-  FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition
-};
-
-struct PhaseInfo {
-  int ph, pw;          // phase offsets (ih % s, iw % s)
-  int PHh, PHw;        // phase grid
-  int Mp;              // B*PHh*PHw
-  int kh0, kw0;        // first tap of the phase
-  int nth, ntw;        // taps per axis
-  int dh0, dw0;        // oh = a + dh0 - jh ; ow = c + dw0 - jw
-  FastDiv dPHw, dPHh;
-};
-struct DgradPhases { PhaseInfo p[4]; };
-
-// ------------------------------------------------------------------------------------------------
-// loaders
-// ------------------------------------------------------------------------------------------------
-template <int ROWS_>
-struct FwdALoader {  // im2col rows of x, k-contiguous (NHWC): K-major
-  static constexpr bool KMAJOR = true;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  const float* x;
-  int IH, IW, Cin, KW;
-  int pix0[NV], ih0[NV], iw0[NV];
-  int kh, kw, ci0, kq;
-
-  __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block) {
-    x = p.x; IH = p.IH; IW = p.IW; Cin = p.Cin; KW = p.KW;
-    kq = threadIdx.x & 7;
-    const int r0 = threadIdx.x >> 3;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int m = m_block + r0 + 32 * i;
-      if (m < p.M) {
-        uint32_t t, ow, b, oh;
-        p.dOW.divmod((uint32_t)m, t, ow);
-        p.dOH.divmod(t, b, oh);
-        pix0[i] = (int)b * IH * IW;
-        ih0[i] = (int)oh * p.stride - p.pad;
-        iw0[i] = (int)ow * p.stride - p.pad;
-      } else {
-        pix0[i] = 0; ih0[i] = -(1 << 28); iw0[i] = 0;
-      }
-    }
-    kh = 0; kw = 0; ci0 = 0;
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-    const bool kok = ci0 + 4 * kq < Cin;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int ih = ih0[i] + kh, iw = iw0[i] + kw;
-      const bool ok = kok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-      if (ok) {
-        const size_t off = (size_t)(pix0[i] + ih * IW + iw) * (size_t)Cin + (size_t)(ci0 + 4 * kq);
-        v[i] = *reinterpret_cast<const float4*>(x + off);
-      } else {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    ci0 += IG_BK;
-    if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
-  }
-};
-
-template <int ROWS_>
-struct FwdBLoader {  // OHWI weight rows, k-contiguous: K-major
-  static constexpr bool KMAJOR = true;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  const float* wrow[NV];  // nullptr if n >= N
-  int Cin, tapoff, ci0, kq;
-
-  __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block) {
-    Cin = p.Cin; kq = threadIdx.x & 7;
-    const int r0 = threadIdx.x >> 3;
-    const size_t Ktot = (size_t)p.KH * p.KW * p.Cin;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int n = n_block + r0 + 32 * i;
-      wrow[i] = n < p.N ? p.w + (size_t)n * Ktot : nullptr;
-    }
-    tapoff = 0; ci0 = 0;
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-    const bool kok = ci0 + 4 * kq < Cin;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (kok && wrow[i]) v[i] = *reinterpret_cast<const float4*>(wrow[i] + tapoff + ci0 + 4 * kq);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    ci0 += IG_BK;
-    if (ci0 >= Cin) { ci0 = 0; tapoff += Cin; }
-  }
-};
-
-// tap iterator shared by the two dgrad loaders: k-tiles run over (jh, jw, co-chunk)
-struct DgradTapIter {
-  int Cout, ntw, jw, co0;
-  int jh;
-  __device__ __forceinline__ void init(int Cout_, int ntw_) { Cout = Cout_; ntw = ntw_; jh = 0; jw = 0; co0 = 0; }
-  __device__ __forceinline__ void advance() {
-    co0 += IG_BK;
-    if (co0 >= Cout) { co0 = 0; if (++jw == ntw) { jw = 0; ++jh; } }
-  }
-};
-
-template <int ROWS_>
-struct DgradALoader {  // dy rows gathered for one sub-pixel phase, k = co contiguous: K-major
-  static constexpr bool KMAJOR = true;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  const float* dy;
-  int OH, OW, Cout, dh0, dw0, kq;
-  int pix0[NV], a[NV], c[NV];
-  DgradTapIter it;
-
-  __device__ __forceinline__ DgradALoader(const ConvP& p, const PhaseInfo& f, int m_block) {
-    dy = p.dy; OH = p.OH; OW = p.OW; Cout = p.Cout; dh0 = f.dh0; dw0 = f.dw0;
-    kq = threadIdx.x & 7;
-    const int r0 = threadIdx.x >> 3;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int m = m_block + r0 + 32 * i;
-      if (m < f.Mp) {
-        uint32_t t, cc, b, aa;
-        f.dPHw.divmod((uint32_t)m, t, cc);
-        f.dPHh.divmod(t, b, aa);
-        pix0[i] = (int)b * OH * OW; a[i] = (int)aa; c[i] = (int)cc;
-      } else {
-        pix0[i] = 0; a[i] = -(1 << 28); c[i] = 0;
-      }
-    }
-    it.init(Cout, f.ntw);
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-    const bool kok = it.co0 + 4 * kq < Cout;
-    const int dh = dh0 - it.jh, dw = dw0 - it.jw;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int oh = a[i] + dh, ow = c[i] + dw;
-      const bool ok = kok && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
-      if (ok) {
-        const size_t off = (size_t)(pix0[i] + oh * OW + ow) * (size_t)Cout + (size_t)(it.co0 + 4 * kq);
-        v[i] = *reinterpret_cast<const float4*>(dy + off);
-      } else {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    it.advance();
-  }
-};
-
-template <int ROWS_>
-struct DgradBLoader {  // w[co][kh][kw][ci]: for a fixed tap, k = co rows, n = ci contiguous: MN-major
-  static constexpr bool KMAJOR = false;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
-  const float* w;
-  int Cin, KHKW, KW, stride, kh0, kw0, kr0;
-  bool nok;
-  DgradTapIter it;
-
-  __device__ __forceinline__ DgradBLoader(const ConvP& p, const PhaseInfo& f, int n_block) {
-    Cin = p.Cin; KHKW = p.KH * p.KW; KW = p.KW; stride = p.stride; kh0 = f.kh0; kw0 = f.kw0;
-    const int c4 = threadIdx.x % C4;
-    kr0 = threadIdx.x / C4;
-    const int n = n_block + 4 * c4;
-    nok = n < p.N;
-    w = p.w + n;
-    it.init(p.Cout, f.ntw);
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-    const int kh = kh0 + stride * it.jh, kw = kw0 + stride * it.jw;
-    const int tap = kh * KW + kw;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int co = it.co0 + kr0 + KR * i;
-      if (nok && co < it.Cout) v[i] = *reinterpret_cast<const float4*>(w + ((size_t)co * KHKW + tap) * (size_t)Cin);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    it.advance();
-  }
-};
-
-template <int ROWS_>
-struct WgradALoader {  // dy[pixel][co]: k = pixel rows, m = co contiguous: MN-major
-  static constexpr bool KMAJOR = false;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
-  const float* dy;
-  int Cout, K, q0;
-  bool mok;
-
-  __device__ __forceinline__ WgradALoader(const ConvP& p, int m_block, int kt_begin) {
-    Cout = p.Cout; K = p.B * p.OH * p.OW;
-    const int c4 = threadIdx.x % C4;
-    const int m = m_block + 4 * c4;
-    mok = m < p.M;
-    dy = p.dy + m;
-    q0 = kt_begin * IG_BK + threadIdx.x / C4;
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int q = q0 + KR * i;
-      if (mok && q < K) v[i] = *reinterpret_cast<const float4*>(dy + (size_t)q * (size_t)Cout);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    q0 += IG_BK;
-  }
-};
-
-template <int ROWS_>
-struct WgradBLoader {  // x gathered at (oh*s-p+kh, ow*s-p+kw): k = pixel rows, n = (tap,ci) contiguous in ci: MN-major
-  static constexpr bool KMAJOR = false;
-  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
-  static constexpr int C4 = ROWS_ / 4, KR = IG_THREADS / C4;
-  const float* x;
-  int IH, IW, Cin, stride, K, q0, dh, dw;  // dh = kh - pad
-  bool nok;
-  FastDiv dOW, dOH;
-
-  __device__ __forceinline__ WgradBLoader(const ConvP& p, int n_block, int kt_begin) {
-    IH = p.IH; IW = p.IW; Cin = p.Cin; stride = p.stride; K = p.B * p.OH * p.OW;
-    dOW = p.dOW; dOH = p.dOH;
-    const int c4 = threadIdx.x % C4;
-    const int n = n_block + 4 * c4;
-    nok = n < p.N;
-    const int tap = nok ? n / Cin : 0;
-    const int ci = nok ? n - tap * Cin : 0;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    dh = kh - p.pad; dw = kw - p.pad;
-    x = p.x + ci;
-    q0 = kt_begin * IG_BK + threadIdx.x / C4;
-  }
-  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int q = q0 + KR * i;
-      bool ok = nok && q < K;
-      uint32_t t, ow, b, oh;
-      dOW.divmod((uint32_t)q, t, ow);
-      dOH.divmod(t, b, oh);
-      const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
-      ok = ok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-      if (ok) v[i] = *reinterpret_cast<const float4*>(x + (size_t)(((int)b * IH + ih) * IW + iw) * (size_t)Cin);
-      else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    q0 += IG_BK;
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// role of this wave, provably wave-uniform for the compiler (scalar branch, no exec masking)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <class Cfg>
-__global__ void __launch_bounds__(IG_THREADS) conv_fwd_kernel(ConvP p) {
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
 
-  FwdALoader<Cfg::BM> la(p, m_block);
-  FwdBLoader<Cfg::BN> lb(p, n_block);
+  if (wave_id() >= 4) {  // producers
+    const int tid = threadIdx.x - IG_LOADERS;
+    FwdALoader<Cfg::BM> la(p, m_block, tid);
+    FwdBLoader<Cfg::BN> lb(p, n_block, tid);
+    igemm_produce<Cfg>(la, lb, p.ktiles, smem, tid);
+    return;
+  }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_mainloop<Cfg>(la, lb, p.ktiles, acc, smem);
+  igemm_consume<Cfg, true, true>(p.ktiles, acc, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
@@ -314,7 +59,7 @@ __global__ void __launch_bounds__(IG_THREADS) conv_fwd_kernel(ConvP p) {
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(IG_THREADS) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
   const PhaseInfo& f = phases.p[blockIdx.y];
@@ -324,26 +69,28 @@ __global__ void __launch_bounds__(IG_THREADS) conv_dgrad_kernel(ConvP p, DgradPh
   const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
-
-  // output pixel of every tile row (dx is written at (a*s+ph, c*s+pw))
-  for (int r = threadIdx.x; r < Cfg::BM; r += IG_THREADS) {
-    const int m = m_block + r;
-    int pix = -1;
-    if (m < f.Mp) {
-      uint32_t t, cc, b, aa;
-      f.dPHw.divmod((uint32_t)m, t, cc);
-      f.dPHh.divmod(t, b, aa);
-      pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
-    }
-    rowpix[r] = pix;
-  }
-
-  DgradALoader<Cfg::BM> la(p, f, m_block);
-  DgradBLoader<Cfg::BN> lb(p, f, n_block);
   const int ktiles = f.nth * f.ntw * ((p.Cout + IG_BK - 1) / IG_BK);
+
+  if (wave_id() >= 4) {  // producers: also publish the output pixel of every tile row (visible after barrier 0)
+    const int tid = threadIdx.x - IG_LOADERS;
+    for (int r = tid; r < Cfg::BM; r += IG_LOADERS) {
+      const int m = m_block + r;
+      int pix = -1;
+      if (m < f.Mp) {
+        uint32_t t, cc, b, aa;
+        f.dPHw.divmod((uint32_t)m, t, cc);
+        f.dPHh.divmod(t, b, aa);
+        pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
+      }
+      rowpix[r] = pix;
+    }
+    DgradALoader<Cfg::BM> la(p, f, m_block, tid);
+    DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    return;
+  }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_mainloop<Cfg>(la, lb, ktiles, acc, smem);
-  __syncthreads();  // rowpix visible (also covers ktiles == 0)
+  igemm_consume<Cfg, true, false>(ktiles, acc, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
@@ -365,7 +112,7 @@ __global__ void __launch_bounds__(IG_THREADS) conv_dgrad_kernel(ConvP p, DgradPh
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(IG_THREADS) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split) {
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
@@ -374,10 +121,15 @@ __global__ void __launch_bounds__(IG_THREADS) conv_wgrad_kernel(ConvP p, int kti
   int ktiles = ktiles_total - kt_begin;
   if (ktiles > ktiles_per_split) ktiles = ktiles_per_split;
 
-  WgradALoader<Cfg::BM> la(p, m_block, kt_begin);
-  WgradBLoader<Cfg::BN> lb(p, n_block, kt_begin);
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    WgradALoader<Cfg::BM> la(p, m_block, kt_begin, tid);
+    WgradBLoader<Cfg::BN> lb(p, n_block, kt_begin, tid);
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    return;
+  }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_mainloop<Cfg>(la, lb, ktiles, acc, smem);
+  igemm_consume<Cfg, false, false>(ktiles, acc, smem);
 
   float* slab = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -411,8 +163,10 @@ int check_geom(const pcg_conv_geom* g) {
   PCG_REQUIRE(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->pad >= 0, "conv geometry: bad kernel/stride/pad");
   PCG_REQUIRE(g->OH == (g->IH + 2 * g->pad - g->KH) / g->stride + 1 && g->OW == (g->IW + 2 * g->pad - g->KW) / g->stride + 1,
               "conv geometry: OH/OW inconsistent with IH/IW, kernel %dx%d stride %d pad %d", g->KH, g->KW, g->stride, g->pad);
-  PCG_REQUIRE((int64_t)g->B * g->IH * g->IW < (1ll << 31) / 2 && (int64_t)g->B * g->OH * g->OW < (1ll << 31) / 2,
-              "conv geometry: pixel count exceeds 2^30");
+  PCG_REQUIRE((int64_t)g->B * g->IH * g->IW * g->Cin * 4 < (1ll << 31) && (int64_t)g->B * g->OH * g->OW * g->Cout * 4 < (1ll << 31) &&
+                  (int64_t)g->Cout * g->KH * g->KW * g->Cin * 4 < (1ll << 31),
+              "conv geometry: an operand tensor reaches 2 GiB (32-bit buffer offsets); split the batch");
+  PCG_REQUIRE(g->KH * g->KW <= 32, "conv geometry: more than 32 taps (%dx%d) unsupported", g->KH, g->KW);
   return PCG_OK;
 }
 
@@ -422,11 +176,14 @@ ConvP make_params(const pcg_conv_geom* g) {
   p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
   p.dOW = FastDiv((uint32_t)g->OW);
   p.dOH = FastDiv((uint32_t)g->OH);
+  p.x_bytes = (uint32_t)((int64_t)g->B * g->IH * g->IW * g->Cin * 4);
+  p.dy_bytes = (uint32_t)((int64_t)g->B * g->OH * g->OW * g->Cout * 4);
+  p.w_bytes = (uint32_t)((int64_t)g->Cout * g->KH * g->KW * g->Cin * 4);
   return p;
 }
 
-template <class Cfg, class LA, class LB>
-constexpr size_t smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, LA, LB>(); }
+template <class Cfg, bool AK, bool BK_>
+constexpr size_t smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, AK, BK_>(); }
 
 template <class K>
 int set_smem(K kernel, size_t bytes) {
@@ -440,7 +197,7 @@ template <class Cfg>
 int launch_fwd(ConvP p, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(p.M, Cfg::BM);
-  constexpr size_t smem = smem_bytes<Cfg, FwdALoader<Cfg::BM>, FwdBLoader<Cfg::BN>>();
+  constexpr size_t smem = smem_bytes<Cfg, true, true>();
   static int once = set_smem(conv_fwd_kernel<Cfg>, smem);
   if (once != PCG_OK) return once;
   hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN), dim3(IG_THREADS), smem, s, p);
@@ -451,7 +208,7 @@ template <class Cfg>
 int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(maxMp, Cfg::BM);
-  constexpr size_t smem = smem_bytes<Cfg, DgradALoader<Cfg::BM>, DgradBLoader<Cfg::BN>>();
+  constexpr size_t smem = smem_bytes<Cfg, true, false>();
   static int once = set_smem(conv_dgrad_kernel<Cfg>, smem);
   if (once != PCG_OK) return once;
   hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, ph);
@@ -563,7 +320,7 @@ extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const fl
   int rc;
   if (wp.narrow) {
     using Cfg = TileCfg<64, 128, 1, 4>;
-    constexpr size_t smem = smem_bytes<Cfg, WgradALoader<64>, WgradBLoader<128>>();
+    constexpr size_t smem = smem_bytes<Cfg, false, false>();
     static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
     if (once != PCG_OK) return once;
     hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
@@ -571,7 +328,7 @@ extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const fl
     rc = launch_status("conv_wgrad_kernel<64x128>");
   } else {
     using Cfg = Cfg128x128;
-    constexpr size_t smem = smem_bytes<Cfg, WgradALoader<128>, WgradBLoader<128>>();
+    constexpr size_t smem = smem_bytes<Cfg, false, false>();
     static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
     if (once != PCG_OK) return once;
     hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
@@ -582,3 +339,4 @@ extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const fl
   const size_t n = (size_t)p.M * p.N;
   return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s);
 }
+

@@ -1,0 +1,284 @@
+// conv_loaders.h — operand gathers of the implicit-GEMM convolutions.
+//
+// Every gather is a branch-free `buffer_load_dwordx4`: the tensor is described by a raw buffer resource whose
+// num_records is its size in bytes, and an out-of-range byte offset makes the hardware return zeros — which is
+// exactly what zero padding, ragged tile edges and K tails need.  Per k-tile a lane therefore spends ~4 VALU
+// instructions per 16-byte load (add the tile's uniform delta to a per-row base offset, test one bit of a
+// per-row tap-validity mask, select the offset or the out-of-range sentinel): the main loop stays one basic block
+// the scheduler can interleave with the MFMA stream.  Offsets are 32-bit with wrap-around arithmetic (a base can
+// be "negative" for a padded row; base + delta of a valid tap is the true offset), so every operand tensor must be
+// smaller than 2 GiB — checked on the host.
+#pragma once
+#include "igemm_core.h"
+
+namespace pcg {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t OOB_OFF = 0x80000000u;  // >= num_records of any accepted tensor
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// ---- parameter blocks (kernel arguments) -----------------------------------------------------------------
+struct ConvP {
+  const float* x;    // fwd / wgrad: input activations
+  const float* w;
+  const float* bias; // fwd: per-Cout       dgrad: per-Cin (nullable)
+  float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
+  const float* dy;   // dgrad / wgrad
+  uint32_t x_bytes, w_bytes, dy_bytes;
+  int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int M, N;          // GEMM extents of this launch
+  int tilesN;
+  int ktiles;        // fwd: KH*KW*ceil(Cin/32)
+  FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition
+};
+
+struct PhaseInfo {
+  int ph, pw;          // phase offsets (ih % s, iw % s)
+  int PHh, PHw;        // phase grid
+  int Mp;              // B*PHh*PHw
+  int kh0, kw0;        // first tap of the phase
+  int nth, ntw;        // taps per axis
+  int dh0, dw0;        // oh = a + dh0 - jh ; ow = c + dw0 - jw
+  FastDiv dPHw, dPHh;
+};
+struct DgradPhases { PhaseInfo p[4]; };
+
+// ---- forward: A = im2col rows of x (K-major), B = OHWI weight rows (K-major) --------------------------------
+template <int ROWS_>
+struct FwdALoader {
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  rsrc_t rs;
+  uint32_t base[NV], mask[NV];
+  int IW, Cin, KW, kh, kw, ci0, kq4;
+
+  __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block, int tid) {
+    rs = make_rsrc(p.x, p.x_bytes);
+    IW = p.IW; Cin = p.Cin; KW = p.KW;
+    kq4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m_block + r0 + 32 * i;
+      uint32_t mk = 0, bs = OOB_OFF;
+      if (m < p.M) {
+        uint32_t t, ow, b, oh;
+        p.dOW.divmod((uint32_t)m, t, ow);
+        p.dOH.divmod(t, b, oh);
+        const int ih0 = (int)oh * p.stride - p.pad, iw0 = (int)ow * p.stride - p.pad;
+        bs = (uint32_t)(((((int)b * p.IH + ih0) * IW + iw0) * Cin + kq4) * 4);
+        for (int a = 0; a < p.KH; ++a)
+          for (int c = 0; c < KW; ++c)
+            if ((unsigned)(ih0 + a) < (unsigned)p.IH && (unsigned)(iw0 + c) < (unsigned)IW) mk |= 1u << (a * KW + c);
+      }
+      base[i] = bs; mask[i] = mk;
+    }
+    kh = 0; kw = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const int tap = kh * KW + kw;
+    const uint32_t delta = (uint32_t)(((kh * IW + kw) * Cin + ci0) * 4);
+    const bool kok = kq4 < Cin - ci0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool ok = kok && ((mask[i] >> tap) & 1u);
+      v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
+    }
+    ci0 += IG_BK;
+    if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+  }
+};
+
+template <int ROWS_>
+struct FwdBLoader {
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  rsrc_t rs;
+  uint32_t base[NV];
+  int Cin, tapoff, ci0, kq4;
+
+  __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block, int tid) {
+    rs = make_rsrc(p.w, p.w_bytes);
+    Cin = p.Cin; kq4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+    const int Ktot = p.KH * p.KW * p.Cin;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int n = n_block + r0 + 32 * i;
+      base[i] = n < p.N ? (uint32_t)((n * Ktot + kq4) * 4) : OOB_OFF;  // OOB_OFF + delta stays out of range
+    }
+    tapoff = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const uint32_t delta = (uint32_t)((tapoff + ci0) * 4);
+    const bool kok = kq4 < Cin - ci0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, kok ? base[i] + delta : OOB_OFF);
+    ci0 += IG_BK;
+    if (ci0 >= Cin) { ci0 = 0; tapoff += Cin; }
+  }
+};
+
+// ---- dgrad: per sub-pixel phase; A = dy rows gathered (K-major, k = co), B = w[co][tap][ci] slices (MN-major) ----
+struct DgradTapIter {  // k-tiles run over (jh, jw, co-chunk)
+  int Cout, ntw, jw, co0, jh;
+  __device__ __forceinline__ void init(int Cout_, int ntw_) { Cout = Cout_; ntw = ntw_; jh = 0; jw = 0; co0 = 0; }
+  __device__ __forceinline__ void advance() {
+    co0 += IG_BK;
+    if (co0 >= Cout) { co0 = 0; if (++jw == ntw) { jw = 0; ++jh; } }
+  }
+};
+
+template <int ROWS_>
+struct DgradALoader {
+  static constexpr bool KMAJOR = true;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  rsrc_t rs;
+  uint32_t base[NV], mask[NV];
+  int OW, Cout, kq4;
+  DgradTapIter it;
+
+  __device__ __forceinline__ DgradALoader(const ConvP& p, const PhaseInfo& f, int m_block, int tid) {
+    rs = make_rsrc(p.dy, p.dy_bytes);
+    OW = p.OW; Cout = p.Cout;
+    kq4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m_block + r0 + 32 * i;
+      uint32_t mk = 0, bs = OOB_OFF;
+      if (m < f.Mp) {
+        uint32_t t, cc, b, aa;
+        f.dPHw.divmod((uint32_t)m, t, cc);
+        f.dPHh.divmod(t, b, aa);
+        const int oh0 = (int)aa + f.dh0, ow0 = (int)cc + f.dw0;  // tap (jh, jw) reads (oh0 - jh, ow0 - jw)
+        bs = (uint32_t)(((((int)b * p.OH + oh0) * OW + ow0) * Cout + kq4) * 4);
+        for (int a = 0; a < f.nth; ++a)
+          for (int c = 0; c < f.ntw; ++c)
+            if ((unsigned)(oh0 - a) < (unsigned)p.OH && (unsigned)(ow0 - c) < (unsigned)OW) mk |= 1u << (a * f.ntw + c);
+      }
+      base[i] = bs; mask[i] = mk;
+    }
+    it.init(Cout, f.ntw);
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const int tap = it.jh * it.ntw + it.jw;
+    const uint32_t delta = (uint32_t)((it.co0 - (it.jh * OW + it.jw) * Cout) * 4);
+    const bool kok = kq4 < Cout - it.co0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool ok = kok && ((mask[i] >> tap) & 1u);
+      v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
+    }
+    it.advance();
+  }
+};
+
+template <int ROWS_>
+struct DgradBLoader {
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
+  rsrc_t rs;
+  uint32_t base[NV];
+  int Cin, KHKW, KW, stride, kh0, kw0, kr0;
+  DgradTapIter it;
+
+  __device__ __forceinline__ DgradBLoader(const ConvP& p, const PhaseInfo& f, int n_block, int tid) {
+    rs = make_rsrc(p.w, p.w_bytes);
+    Cin = p.Cin; KHKW = p.KH * p.KW; KW = p.KW; stride = p.stride; kh0 = f.kh0; kw0 = f.kw0;
+    const int c4 = tid % C4;
+    kr0 = tid / C4;
+    const int n = n_block + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      base[i] = n < p.N ? (uint32_t)((((kr0 + KR * i) * KHKW) * Cin + n) * 4) : OOB_OFF;
+    it.init(p.Cout, f.ntw);
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const int tap = (kh0 + stride * it.jh) * KW + kw0 + stride * it.jw;
+    const uint32_t delta = (uint32_t)(((it.co0 * KHKW + tap) * Cin) * 4);
+    const int krem = it.Cout - it.co0;  // rows kr < krem are real output channels
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, (kr0 + KR * i) < krem ? base[i] + delta : OOB_OFF);
+    it.advance();
+  }
+};
+
+// ---- wgrad: k = output pixel; A = dy[pixel][co] (MN-major), B = x gathered at the tap's shift (MN-major) -------
+template <int ROWS_>
+struct WgradALoader {
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
+  rsrc_t rs;
+  uint32_t base[NV];
+  int Cout, K, q0, kr0;
+
+  __device__ __forceinline__ WgradALoader(const ConvP& p, int m_block, int kt_begin, int tid) {
+    rs = make_rsrc(p.dy, p.dy_bytes);
+    Cout = p.Cout; K = p.B * p.OH * p.OW;
+    const int c4 = tid % C4;
+    kr0 = tid / C4;
+    const int m = m_block + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) base[i] = m < p.M ? (uint32_t)(((kr0 + KR * i) * Cout + m) * 4) : OOB_OFF;
+    q0 = kt_begin * IG_BK;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const uint32_t delta = (uint32_t)(q0 * Cout * 4);
+    const int krem = K - q0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, (kr0 + KR * i) < krem ? base[i] + delta : OOB_OFF);
+    q0 += IG_BK;
+  }
+};
+
+template <int ROWS_>
+struct WgradBLoader {
+  static constexpr bool KMAJOR = false;
+  static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
+  static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
+  rsrc_t rs;
+  int IH, IW, Cin, stride, K, q0, dh, dw, ci;  // dh = kh - pad
+  bool nok;
+  FastDiv dOW, dOH;
+
+  __device__ __forceinline__ WgradBLoader(const ConvP& p, int n_block, int kt_begin, int tid) {
+    rs = make_rsrc(p.x, p.x_bytes);
+    IH = p.IH; IW = p.IW; Cin = p.Cin; stride = p.stride; K = p.B * p.OH * p.OW;
+    dOW = p.dOW; dOH = p.dOH;
+    const int c4 = tid % C4;
+    const int n = n_block + 4 * c4;
+    nok = n < p.N;
+    const int tap = nok ? n / Cin : 0;
+    ci = nok ? n - tap * Cin : 0;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    dh = kh - p.pad; dw = kw - p.pad;
+    q0 = kt_begin * IG_BK + tid / C4;
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = q0 + KR * i;
+      uint32_t t, ow, b, oh;
+      dOW.divmod((uint32_t)q, t, ow);
+      dOH.divmod(t, b, oh);
+      const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
+      const bool ok = nok && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+      const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci) * 4);
+      v[i] = buf_load4(rs, ok ? off : OOB_OFF);
+    }
+    q0 += IG_BK;
+  }
+};
+
+}  // namespace pcg

@@ -1,22 +1,32 @@
 // igemm_core.h — the one MFMA main loop behind every dense contraction of the GAN step.
 //
-// C[M][N] = sum_k A[m][k] * B[k][n] in exact fp32 on v_mfma_f32_32x32x2_f32 (gfx950).  A block of 256
-// threads (4 waves, one per SIMD) owns a BM x BN tile; each wave owns a WTM x WTN sub-tile made of
-// 32x32 MFMA tiles.  Operand tiles of depth BK=32 are gathered global -> registers by "loader"
-// functors (which know the convolution geometry: im2col rows, sub-pixel phases, zero padding), written
-// to LDS, and double-buffered so the gather of k-tile t+1 is in flight while the MFMAs of k-tile t
-// issue.  fp32 MFMA is 64 cycles per instruction, so one ds_read feeds many matrix cycles: LDS
-// bandwidth is never the limiter here; what matters is coalesced 16-byte global loads, conflict-free
-// LDS images and enough independent accumulators (TM*TN >= 2) to keep the matrix pipe issuing.
+// C[M][N] = sum_k A[m][k] * B[k][n] in exact fp32 on v_mfma_f32_32x32x2_f32 (gfx950).  A workgroup owns a BM x BN
+// tile; operand tiles of depth BK=32 are gathered global -> registers by "loader" functors (which know the
+// convolution geometry: im2col rows, sub-pixel phases, zero padding — conv_loaders.h), written to LDS and
+// double-buffered.
+//
+// Wave specialisation.  fp32 MFMA is 64 cycles per instruction and a wave issues in order, so every instruction a
+// wave spends on gathering (address VALU, buffer_load, ds_write, waits) between two MFMAs is a hole in the matrix
+// pipe unless another wave fills it.  Measured on MI355X: a bare MFMA loop sustains 155 TFLOP/s (64.0 cycles per
+// MFMA at 2.4 GHz); the same MFMAs with the gather in the same instruction stream reach 67-75 %.  The workgroup is
+// therefore split by role:
+//   waves 0..3  "consumers": ds_read fragments + MFMA only (one per SIMD, 64x64 of the tile each, 4 accumulators)
+//   waves 4..7  "producers": gather tile t+2 into registers, ds_write tile t+1, nothing else
+// VALU/VMEM/LDS-write work of the producers issues on the same SIMDs in the shadow of the consumers' MFMAs (the
+// matrix and vector pipes are separate).  One s_barrier per k-tile hands stage (t+1)%2 to the consumers and stage
+// t%2 back to the producers:
+//   RAW  consumers read stage (t+1)%2 only after barrier t+1, which every producer reaches after its ds_writes retired
+//   WAR  producers overwrite stage (t+1)%2 during iteration t; its last readers finished before barrier t
+// Two workgroups fit per CU (73.7 KB LDS, <=128 VGPR+AGPR), so each SIMD hosts two consumers whose barrier / first-
+// fragment latencies cover each other.
 //
 // LDS images (floats):
 //   K-major  [rows][BK+4]  : source rows are k-contiguous (NHWC im2col rows, OHWI weight rows).
 //                            Fragment = one ds_read_b128 : lane (i,h) gets k = k0+4h .. k0+4h+3 of row i.
 //   MN-major [BK][rows+4]  : source is contiguous along m/n for a fixed k (transposed operands).
 //                            Fragment = four ds_read_b32 : same (i,h,t) -> k = k0+4h+t mapping.
-// Both give lane (i = lane&31, h = lane>>5) the values a[t] = A[i][k0+4h+t], t=0..3; MFMA number t of
-// a group consumes k-pair {k0+t, k0+4+t} — the order of k inside the sum is free as long as A and B
-// agree, which they do by construction.
+// Both give lane (i = lane&31, h = lane>>5) the values a[t] = A[i][k0+4h+t], t=0..3; MFMA number t of a group
+// consumes k-pair {k0+t, k0+4+t} — the order of k inside the sum is free as long as A and B agree.
 #pragma once
 #include "pcg_common.h"
 
@@ -24,29 +34,28 @@ namespace pcg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int IG_THREADS = 256;
+constexpr int IG_LOADERS = 256;            // threads that gather one k-tile (4 waves)
+constexpr int IG_THREADS = 512;            // 4 consumer + 4 producer waves
 constexpr int IG_BK = 32;
-constexpr int IG_LDK = IG_BK + 4;  // K-major row stride: 144 B = 9*16 (aligned for b128, conflict-free)
+constexpr int IG_LDK = IG_BK + 4;          // K-major row stride: 144 B = 9*16 (aligned for b128, conflict-free)
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
   static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   static constexpr int TM = WTM / 32, TN = WTN / 32;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(WAVES_M * WAVES_N == 4, "4 consumer waves per block");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 };
 
-// floats of LDS one stage of an operand tile needs
 template <int ROWS, bool KMAJOR>
 struct LdsImage {
   static constexpr int LDM = ROWS + 4;
   static constexpr int FLOATS = KMAJOR ? ROWS * IG_LDK : IG_BK * LDM;
-  static constexpr int NV = ROWS / 32;  // float4 per thread per k-tile (256 threads)
+  static constexpr int NV = ROWS / 32;  // float4 per loader thread per k-tile (256 loader threads)
 
-  // thread -> (row, k-quad) for K-major; (k-row, column-quad) for MN-major
-  __device__ static __forceinline__ void store(float* lds, const float4 (&v)[NV]) {
-    const int tid = threadIdx.x;
+  // loader thread tid (0..255) -> (row, k-quad) for K-major; (k-row, column-quad) for MN-major
+  __device__ static __forceinline__ void store(float* lds, const float4 (&v)[NV], int tid) {
     if constexpr (KMAJOR) {
       const int kq = tid & 7, r0 = tid >> 3;
 #pragma unroll
@@ -54,7 +63,7 @@ struct LdsImage {
         *reinterpret_cast<float4*>(lds + (r0 + 32 * p) * IG_LDK + 4 * kq) = v[p];
     } else {
       constexpr int C4 = ROWS / 4;          // float4 per k-row
-      constexpr int KR = IG_THREADS / C4;   // k-rows per pass
+      constexpr int KR = IG_LOADERS / C4;   // k-rows per pass
       const int c4 = tid % C4, kr0 = tid / C4;
 #pragma unroll
       for (int p = 0; p < NV; ++p)
@@ -73,23 +82,73 @@ struct LdsImage {
   }
 };
 
-// Loader concept (per-thread state, constructed once per block):
+// raw barrier behind an explicit lgkmcnt(0): __syncthreads() would also drain vmcnt, i.e. stall the producers on the
+// gathers they have just issued for tile t+2.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <class Cfg, bool AK, bool BK_>
+constexpr int igemm_smem_floats() {
+  return 2 * (LdsImage<Cfg::BM, AK>::FLOATS + LdsImage<Cfg::BN, BK_>::FLOATS);
+}
+
+// Loader concept (per-thread state of a producer thread, constructed with its loader-thread id 0..255):
 //   static constexpr bool KMAJOR; static constexpr int ROWS;
 //   __device__ void load_next(float4 (&v)[ROWS/32]);   // gathers the next k-tile (sequential) into registers
 template <class Cfg, class LA, class LB>
-__device__ __forceinline__ void igemm_mainloop(LA& la, LB& lb, int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN],
-                                               float* smem) {
+__device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float* smem, int tid) {
   using IA = LdsImage<Cfg::BM, LA::KMAJOR>;
   using IB = LdsImage<Cfg::BN, LB::KMAJOR>;
   static_assert(LA::ROWS == Cfg::BM && LB::ROWS == Cfg::BN, "loader/tile mismatch");
   float* As = smem;
   float* Bs = smem + 2 * IA::FLOATS;
-
   float4 ra[IA::NV], rb[IB::NV];
+  if (ktiles > 0) {
+    la.load_next(ra);
+    lb.load_next(rb);
+    IA::store(As, ra, tid);
+    IB::store(Bs, rb, tid);
+    if (ktiles > 1) {
+      la.load_next(ra);
+      lb.load_next(rb);
+    }
+  }
+  lds_barrier();  // barrier 0: stage 0 is ready
+  int nxt = 1;
+  for (int kt = 0; kt < ktiles; ++kt) {
+#ifndef PCG_ABL_PRODUCER_IDLE   // timing-only ablation: producers just keep the barrier protocol
+    if (kt + 1 < ktiles) {
+      IA::store(As + nxt * IA::FLOATS, ra, tid);
+      IB::store(Bs + nxt * IB::FLOATS, rb, tid);
+    }
+    if (kt + 2 < ktiles) {
+      la.load_next(ra);
+      lb.load_next(rb);
+    }
+#endif
+    lds_barrier();  // barrier kt+1: stage nxt handed to the consumers, stage nxt^1 handed back
+    nxt ^= 1;
+  }
+}
+
+// Consumer: fragments are double-buffered in registers so that the LDS read of k-group g+1 is in flight under the
+// 16 MFMAs of k-group g; the hand-over barrier of the k-tile sits BEFORE its last k-group (whose operands are already
+// in registers), and the first fragments of the next tile are fetched right behind it — no LDS latency is exposed at
+// the tile boundary.  s_setprio keeps MFMA issue ahead of the co-resident producers' vector instructions.
+template <class Cfg, bool AK, bool BK_>
+__device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* smem) {
+  using IA = LdsImage<Cfg::BM, AK>;
+  using IB = LdsImage<Cfg::BN, BK_>;
+  constexpr int KG = IG_BK / 8;  // k-groups per tile
+  const float* As = smem;
+  const float* Bs = smem + 2 * IA::FLOATS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
-
+  const int arow = wm * Cfg::WTM, brow = wn * Cfg::WTN;
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -97,49 +156,42 @@ __device__ __forceinline__ void igemm_mainloop(LA& la, LB& lb, int ktiles, f32x1
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (ktiles <= 0) return;
-  la.load_next(ra);
-  lb.load_next(rb);
-  IA::store(As, ra);
-  IB::store(Bs, rb);
-  __syncthreads();
+  float a[2][Cfg::TM][4], b[2][Cfg::TN][4];
+  auto fetch = [&](const float* as, const float* bs, int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) IA::frag(as, arow + 32 * i, ks, li, lh, a[buf][i]);
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) IB::frag(bs, brow + 32 * j, ks, li, lh, b[buf][j]);
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][i][t], b[buf][j][t], acc[i][j], 0, 0, 0);
+  };
 
+  lds_barrier();  // barrier 0: stage 0 is ready
+  if (ktiles <= 0) return;
+  __builtin_amdgcn_s_setprio(2);
+  fetch(As, Bs, 0, 0);
   int cur = 0;
   for (int kt = 0; kt < ktiles; ++kt) {
-    const bool has_next = (kt + 1 < ktiles);
-    if (has_next) {  // issue the next tile's global gathers before touching the matrix pipe
-      la.load_next(ra);
-      lb.load_next(rb);
-    }
     const float* as = As + cur * IA::FLOATS;
     const float* bs = Bs + cur * IB::FLOATS;
 #pragma unroll
-    for (int ks = 0; ks < IG_BK / 8; ++ks) {
-      float a[Cfg::TM][4], b[Cfg::TN][4];
-#pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) IA::frag(as, wm * Cfg::WTM + 32 * i, ks, li, lh, a[i]);
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) IB::frag(bs, wn * Cfg::WTN + 32 * j, ks, li, lh, b[j]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < Cfg::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    for (int ks = 0; ks < KG - 1; ++ks) {
+      fetch(as, bs, ks + 1, (ks + 1) & 1);
+      mma(ks & 1);
     }
-    if (has_next) {
-      IA::store(As + (cur ^ 1) * IA::FLOATS, ra);
-      IB::store(Bs + (cur ^ 1) * IB::FLOATS, rb);
-    }
-    __syncthreads();
+    lds_barrier();  // barrier kt+1: all reads of stage cur have retired (lgkmcnt(0)); stage cur^1 is ready
     cur ^= 1;
+    if (kt + 1 < ktiles) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
+    mma((KG - 1) & 1);
   }
-}
-
-template <class Cfg, class LA, class LB>
-constexpr int igemm_smem_floats() {
-  return 2 * LdsImage<Cfg::BM, LA::KMAJOR>::FLOATS + 2 * LdsImage<Cfg::BN, LB::KMAJOR>::FLOATS;
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // Accumulator element (tile i,j ; register r) of lane (li,lh) sits at

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv family at the DCGAN bs-512 shapes (diagnostic; not the bench contract).
+
+  python scripts/conv_microbench.py [--batch 512] [--iters 20] [--only fwd,dgrad,wgrad] [--layers D2,D3,...]
+Prints one line per (layer, op): average ms over `iters` launches (HIP events on the launch stream) and TFLOP/s.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import pcgan_amd  # noqa: E402
+from pcgan_amd import ops  # noqa: E402
+
+# name: (Cin, Cout, H_in(conv input), k, s, p)  -- geometry of the (adjoint) conv
+LAYERS = {
+    "D1": (1, 64, 64, 4, 2, 1), "D2": (64, 128, 32, 4, 2, 1), "D3": (128, 256, 16, 4, 2, 1), "D4": (256, 512, 8, 4, 2, 1),
+    "D5": (512, 1, 4, 4, 1, 0),
+    "G1": (512, 100, 4, 4, 1, 0), "G2": (256, 512, 8, 4, 2, 1), "G3": (128, 256, 16, 4, 2, 1), "G4": (64, 128, 32, 4, 2, 1),
+    "G5": (1, 64, 64, 4, 2, 1),
+    "R64": (64, 64, 28, 3, 1, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="fwd,dgrad,wgrad")
+    ap.add_argument("--layers", default="D2,D3,D4,G2,G3,G4")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: not a performance number)")
+    args = ap.parse_args()
+    pcgan_amd.load()
+    dev = torch.device("cuda:0")
+    B = args.batch
+    tot_f = tot_t = 0.0
+    for name in args.layers.split(","):
+        Cin, Cout, H, k, s, p = LAYERS[name]
+        g = ops.conv_geom(B, H, H, Cin, Cout, k, k, s, p)
+        x = torch.randn(B, H, H, Cin, device=dev)
+        w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+        dy = torch.randn(B, g.OH, g.OW, Cout, device=dev)
+        if args.zeros:
+            x.zero_(); w.zero_(); dy.zero_()
+        y = torch.empty(B, g.OH, g.OW, Cout, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        flops = 2.0 * B * g.OH * g.OW * Cout * k * k * Cin
+        fns = {"fwd": lambda: ops.conv2d_fwd(g, x, w, None, out=y), "dgrad": lambda: ops.conv2d_dgrad(g, dy, w, None, out=dx),
+               "wgrad": lambda: ops.conv2d_wgrad(g, x, dy, dw, False)}
+        for op in args.only.split(","):
+            fn = fns[op]
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            tot_f += flops; tot_t += ms * 1e-3
+            print(f"{name:4s} {op:6s} M/N/K-ish B={B} {Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p}  {ms:8.4f} ms  {flops / ms / 1e9:7.2f} TFLOP/s", flush=True)
+    print(f"TOTAL {tot_f / tot_t / 1e12:.2f} TFLOP/s over {tot_t * 1e3:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
