@@ -69,10 +69,15 @@ const char* pcg_target_arch(void);
  *   dconv_gan/mnist/mnist_dcgan.py:76-88 (G ConvT stack), :100-111 (D Conv stack);
  *   conditional_counteRGAN/mnist/models/generator.py:11-14,39,49-50; models/discriminator.py:14-24;
  *   models/classifier.py:7-12.                                                                    */
+/* Optional scratch for fwd / dgrad: 0 for MFMA layers; for a layer whose reduced side has ONE channel (Cout==1 fwd,
+ * Cin==1 dgrad) it buys the two-stage "tap dot + col2im" path that reads the wide tensor exactly once.  Passing
+ * workspace == NULL is always valid (a slower single-kernel path is used).                                        */
+size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g);
+size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g);
 int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias /*nullable*/,
-                   float* y, pcg_stream_t stream);
+                   float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x /*nullable: added per Cin channel (ConvTranspose2d bias)*/,
-                     float* dx, pcg_stream_t stream);
+                     float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g);
 /* dw[co,kh,kw,ci] (+)= sum_{b,oh,ow} dy[b,oh,ow,co] * x[b,oh*s-p+kh,ow*s-p+kw,ci];  accumulate!=0 adds into dw
  * (the reference accumulates .grad over two backward() calls: mnist_dcgan.py:153,161).             */

@@ -10,8 +10,8 @@ namespace pcg {
 namespace {
 
 constexpr int CR_THREADS = 256;
-constexpr int CR_MAX_BLOCKS = 512;
-constexpr int FIN_CH = 32, FIN_SL = 8;   // finalize: 32 channels x 8 partial-slices per 256-thread block
+constexpr int CR_MAX_BLOCKS = 256;
+constexpr int FIN_CH = 16, FIN_SL = 16;  // finalize: 16 channels x 16 partial-slices per 256-thread block
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
 
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
   }
 }
 
-// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+8, ... and the 8
+// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+16, ... and the 16
 // slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/8 dependent loads per thread).
 template <int NVAL>
 __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblocks, int C, int& c_out,

@@ -38,24 +38,10 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, true, true>(p.ktiles, acc, smem);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-      const int mbase = m_block + wm * Cfg::WTM + 32 * i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + acc_row(r, lh);
-        if (m < p.M) p.out[(size_t)m * p.N + n] = acc[i][j][r] + bv;
-      }
-    }
-  }
+  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+    const int m = m_block + row;
+    return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
+  });
 }
 
 template <class Cfg>
@@ -91,24 +77,10 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, true, false>(ktiles, acc, smem);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-      const int rbase = wm * Cfg::WTM + 32 * i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pix = rowpix[rbase + acc_row(r, lh)];
-        if (pix >= 0) p.out[(size_t)pix * p.Cin + n] = acc[i][j][r] + bv;
-      }
-    }
-  }
+  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+    const int pix = rowpix[row];
+    return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
+  });
 }
 
 template <class Cfg>
@@ -130,24 +102,11 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, false, false>(ktiles, acc, smem);
-
   float* slab = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
-    if (n >= p.N) continue;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) {
-      const int mbase = m_block + wm * Cfg::WTM + 32 * i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + acc_row(r, lh);
-        if (m < p.M) slab[(size_t)m * p.N + n] = acc[i][j][r];
-      }
-    }
-  }
+  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
+    const int m = m_block + row;
+    return m < p.M ? slab + (size_t)m * p.N + n_block : nullptr;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,7 +142,10 @@ ConvP make_params(const pcg_conv_geom* g) {
 }
 
 template <class Cfg, bool AK, bool BK_>
-constexpr size_t smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, AK, BK_>(); }
+constexpr size_t smem_bytes() {
+  constexpr int a = igemm_smem_floats<Cfg, AK, BK_>(), b = epilogue_smem_floats<Cfg>();
+  return sizeof(float) * (size_t)(a > b ? a : b);
+}
 
 template <class K>
 int set_smem(K kernel, size_t bytes) {
@@ -240,11 +202,20 @@ WgradPlan plan_wgrad(const pcg_conv_geom* g) {
 
 using namespace pcg;
 
+extern "C" size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK) return 0;
+  return (thin_is_cin(g) || thin_is_cout(g)) ? thin_conv_fwd_workspace_bytes(g) : 0;
+}
+extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK) return 0;
+  return (thin_is_cin(g) || thin_is_cout(g)) ? thin_conv_dgrad_workspace_bytes(g) : 0;
+}
+
 extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                              pcg_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
-  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd(g, x, w, bias, y, (hipStream_t)stream);
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd(g, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
   PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
   ConvP p = make_params(g);
   p.x = x; p.w = w; p.bias = bias; p.out = y;
@@ -256,10 +227,10 @@ extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const floa
 }
 
 extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
-                                pcg_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
-  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad(g, dy, w, bias_x, dx, (hipStream_t)stream);
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream);
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
   ConvP p = make_params(g);

@@ -25,6 +25,17 @@ __device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t off) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// bit (a*nw + c) set for lo_h <= a < hi_h (clipped to [0,nh)) and lo_w <= c < hi_w (clipped to [0,nw)); nh*nw <= 32
+__device__ __forceinline__ uint32_t tap_mask(int lo_h, int hi_h, int nh, int lo_w, int hi_w, int nw) {
+  lo_h = lo_h < 0 ? 0 : lo_h; hi_h = hi_h > nh ? nh : hi_h;
+  lo_w = lo_w < 0 ? 0 : lo_w; hi_w = hi_w > nw ? nw : hi_w;
+  if (lo_h >= hi_h || lo_w >= hi_w) return 0u;
+  const uint32_t rowbits = ((1u << (hi_w - lo_w)) - 1u) << lo_w;   // hi_w - lo_w <= nw <= 32; nw == 32 only if nh == 1
+  uint32_t m = 0;
+  for (int a = lo_h; a < hi_h; ++a) m |= rowbits << (a * nw);
+  return (hi_w - lo_w) >= 32 ? 0xFFFFFFFFu : m;
+}
+
 // ---- parameter blocks (kernel arguments) -----------------------------------------------------------------
 struct ConvP {
   const float* x;    // fwd / wgrad: input activations
@@ -75,9 +86,7 @@ struct FwdALoader {
         p.dOH.divmod(t, b, oh);
         const int ih0 = (int)oh * p.stride - p.pad, iw0 = (int)ow * p.stride - p.pad;
         bs = (uint32_t)(((((int)b * p.IH + ih0) * IW + iw0) * Cin + kq4) * 4);
-        for (int a = 0; a < p.KH; ++a)
-          for (int c = 0; c < KW; ++c)
-            if ((unsigned)(ih0 + a) < (unsigned)p.IH && (unsigned)(iw0 + c) < (unsigned)IW) mk |= 1u << (a * KW + c);
+        mk = tap_mask(-ih0, p.IH - ih0, p.KH, -iw0, IW - iw0, KW);
       }
       base[i] = bs; mask[i] = mk;
     }
@@ -161,9 +170,8 @@ struct DgradALoader {
         f.dPHh.divmod(t, b, aa);
         const int oh0 = (int)aa + f.dh0, ow0 = (int)cc + f.dw0;  // tap (jh, jw) reads (oh0 - jh, ow0 - jw)
         bs = (uint32_t)(((((int)b * p.OH + oh0) * OW + ow0) * Cout + kq4) * 4);
-        for (int a = 0; a < f.nth; ++a)
-          for (int c = 0; c < f.ntw; ++c)
-            if ((unsigned)(oh0 - a) < (unsigned)p.OH && (unsigned)(ow0 - c) < (unsigned)OW) mk |= 1u << (a * f.ntw + c);
+        // tap (a, c) reads (oh0 - a, ow0 - c): valid for oh0 - OH < a <= oh0
+        mk = tap_mask(oh0 - p.OH + 1, oh0 + 1, f.nth, ow0 - OW + 1, ow0 + 1, f.ntw);
       }
       base[i] = bs; mask[i] = mk;
     }

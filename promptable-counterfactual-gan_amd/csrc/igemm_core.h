@@ -82,6 +82,8 @@ struct LdsImage {
   }
 };
 
+__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
 // raw barrier behind an explicit lgkmcnt(0): __syncthreads() would also drain vmcnt, i.e. stall the producers on the
 // gathers they have just issued for tile t+2.
 __device__ __forceinline__ void lds_barrier() {
@@ -194,8 +196,49 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
   __builtin_amdgcn_s_setprio(0);
 }
 
+// ---- epilogue: accumulators -> LDS (wave-private region) -> 16-byte row-contiguous global stores ------------------
+// A 32x32 MFMA accumulator has its column on the lane and its rows in the registers, so a direct store is 64 4-byte-
+// per-lane instructions per wave.  Staging the wave's WTM x WTN tile through LDS turns that into WTM*WTN/256 dwordx4
+// stores whose lanes cover whole rows.  Every LDS read of the main loop retired before the final barrier and each
+// wave only touches its own region, so no further barrier is needed.  `row_base(row)` returns the output pointer of
+// tile row `row` (0..BM) at column 0 of the tile's N range, or nullptr for a row outside the problem.
+template <class Cfg>
+constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
+
+template <class Cfg, class RowBase>
+__device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
+                                                 const float* bias, RowBase row_base) {
+  constexpr int LDW = Cfg::WTN + 4;
+  constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
+  constexpr int RPI = 64 / Q;              // rows per store instruction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
+  float* reg = smem + wave * (Cfg::WTM * LDW);
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) reg[(32 * i + acc_row(r, lh)) * LDW + 32 * j + li] = acc[i][j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int cq = lane % Q, r0 = lane / Q;
+  const int n = n_block + wn * Cfg::WTN + 4 * cq;
+  if (n >= N) return;  // N % 4 == 0: a quad is entirely inside or outside
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+  for (int k = 0; k < Cfg::WTM / RPI; ++k) {
+    const int row = r0 + RPI * k;
+    float* dst = row_base(wm * Cfg::WTM + row);
+    if (dst) {
+      float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+    }
+  }
+}
+
 // Accumulator element (tile i,j ; register r) of lane (li,lh) sits at
 //   row = 32*i + (r&3) + 8*(r>>2) + 4*lh   col = 32*j + li      (within the wave tile)
-__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
 }  // namespace pcg

@@ -133,12 +133,15 @@ __global__ void __launch_bounds__(256) thin_reduce_kernel(ThinP p) {
   }
 }
 
+#include "thin_fast.inc"
+
 // Each block owns `ppb` iteration pixels; thread (cq, pl) accumulates NT float4 sums over pixels pl, pl+PL, ...
 // then the PL pixel-lanes are summed through LDS in a fixed order and the block writes its slab in dw layout.
 template <int KH, int KW, int CS>
-__global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinP p, float* slab, int ppb, int wn) {
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinP p, float* slab, int ppb, int wn, uint32_t thin_bytes) {
   constexpr int NT = KH * KW * CS;
   __shared__ float4 red[256];
+  const thin_rsrc_t rs = thin_rsrc(p.thin, thin_bytes);
   const int CQ = p.C >> 2;           // power of two <= 256 (checked on the host)
   const int PL = 256 / CQ;
   const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ;
@@ -152,20 +155,21 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinP p, float* slab, i
     p.dIW.divmod((uint32_t)pix, t, pw);
     p.dIH.divmod(t, b, ph);
     const float4 v = *reinterpret_cast<const float4*>(p.wide + (size_t)pix * p.C + 4 * cq);
+    float sv[NT];  // all tap scalars gathered branch-free first (invalid tap -> out-of-range offset -> 0)
 #pragma unroll
     for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) {
-        int qh, qw;
-        if (!tap_map(p, (int)ph, (int)pw, kh, kw, qh, qw)) continue;
-        const float* sp = p.thin + (size_t)(((int)b * p.TH + qh) * p.TW + qw) * CS;
+        const int q = tap_map_idx(p, (int)b, (int)ph, (int)pw, kh, kw);
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs) {
-          const float sv = sp[cs];
-          float4& a = acc[(kh * KW + kw) * CS + cs];
-          a.x = fmaf(sv, v.x, a.x); a.y = fmaf(sv, v.y, a.y); a.z = fmaf(sv, v.z, a.z); a.w = fmaf(sv, v.w, a.w);
-        }
+        for (int cs = 0; cs < CS; ++cs)
+          sv[(kh * KW + kw) * CS + cs] = thin_load1(rs, q >= 0 ? (uint32_t)((q * CS + cs) * 4) : THIN_OOB);
       }
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+      acc[tp].x = fmaf(sv[tp], v.x, acc[tp].x); acc[tp].y = fmaf(sv[tp], v.y, acc[tp].y);
+      acc[tp].z = fmaf(sv[tp], v.z, acc[tp].z); acc[tp].w = fmaf(sv[tp], v.w, acc[tp].w);
+    }
   }
   float* myslab = slab + (size_t)blockIdx.x * wn;
 #pragma unroll
@@ -238,18 +242,62 @@ int fill_common(ThinP& p, const pcg_conv_geom* g, bool cin_thin, bool iter_on_ou
 
 size_t lds_weight_bytes(const ThinP& p) { return (size_t)p.KH * p.KW * p.Cs * p.C * sizeof(float); }
 
+bool fast_ok(const ThinP& p) {
+  return p.Cs == 1 && p.stride <= 2 && p.KH * p.KW <= 16 && p.C % 16 == 0 && lds_weight_bytes(p) <= 64 * 1024;
+}
+
 int launch_expand(ThinP& p, hipStream_t s) {
   const size_t smem = lds_weight_bytes(p);
   PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
+  const bool k44 = p.KH == 4 && p.KW == 4, k33 = p.KH == 3 && p.KW == 3, k11 = p.KH == 1 && p.KW == 1;
+  if (fast_ok(p) && (k44 || k33 || k11) && (int64_t)p.npix * (p.C / 16) < (1ll << 31)) {
+    ThinP q = p;
+    q.dCQ = FastDiv((uint32_t)(p.C / 16));
+    const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * 4);
+    const uint64_t total = (uint64_t)p.npix * (p.C / 16);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (k44) hipLaunchKernelGGL((thin_expand16_kernel<4, 4>), dim3(blocks), dim3(256), smem, s, q, thin_bytes);
+    else if (k33) hipLaunchKernelGGL((thin_expand16_kernel<3, 3>), dim3(blocks), dim3(256), smem, s, q, thin_bytes);
+    else hipLaunchKernelGGL((thin_expand16_kernel<1, 1>), dim3(blocks), dim3(256), smem, s, q, thin_bytes);
+    return launch_status("thin_expand16_kernel");
+  }
   const uint64_t total = (uint64_t)p.npix * (p.C / 4);
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(thin_expand_kernel, dim3(blocks), dim3(256), smem, s, p);
   return launch_status("thin_expand_kernel");
 }
-int launch_reduce(ThinP& p, hipStream_t s) {
+
+// scratch the two-stage reduce wants: T[wide pixels][16]
+size_t reduce_scratch_bytes(const ThinP& p) {
+  if (!fast_ok(p)) return 0;
+  const int64_t b = (int64_t)p.B * p.WH * p.WW * 16 * 4;
+  return b < (1ll << 31) ? (size_t)b : 0;
+}
+
+int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
   const size_t smem = lds_weight_bytes(p);
   PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
+  const size_t need = reduce_scratch_bytes(p);
+  if (need && ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0) {
+    float* T = (float*)ws;
+    ThinP q = p;
+    q.npix = p.B * p.WH * p.WW;  // stage 1 walks the wide tensor
+    unsigned blocks = (unsigned)((q.npix + 15) / 16);
+    if (blocks > 8192) blocks = 8192;
+    const int nt = p.KH * p.KW;
+    if (nt == 16) hipLaunchKernelGGL(thin_tapdot_kernel<16>, dim3(blocks), dim3(256), smem, s, q, T);
+    else if (nt == 9) hipLaunchKernelGGL(thin_tapdot_kernel<9>, dim3(blocks), dim3(256), smem, s, q, T);
+    else if (nt == 1) hipLaunchKernelGGL(thin_tapdot_kernel<1>, dim3(blocks), dim3(256), smem, s, q, T);
+    else goto generic;
+    if (int e = launch_status("thin_tapdot_kernel")) return e;
+    unsigned b2 = (unsigned)((p.npix + 255) / 256);
+    if (b2 > 8192) b2 = 8192;
+    hipLaunchKernelGGL(thin_col2im_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need);
+    return launch_status("thin_col2im_kernel");
+  }
+generic:
   unsigned blocks = (unsigned)((p.npix + 15) / 16);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(thin_reduce_kernel, dim3(blocks), dim3(256), smem, s, p);
@@ -290,24 +338,39 @@ int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_strid
   return launch_status("slab_reduce_kernel");
 }
 
-int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                  size_t ws_bytes, hipStream_t s) {
   ThinP p{};
   const bool cin_thin = thin_is_cin(g);
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/true)) return e;
   p.w = w; p.bias = bias; p.out = y;
   if (cin_thin) { p.thin = x; return launch_expand(p, s); }   // y wide
   p.wide = x;                                                 // y thin
-  return launch_reduce(p, s);
+  return launch_reduce(p, ws, ws_bytes, s);
 }
 
-int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, hipStream_t s) {
+int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
   ThinP p{};
   const bool cin_thin = thin_is_cin(g);
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/false)) return e;
   p.w = w; p.bias = bias_x; p.out = dx;
-  if (cin_thin) { p.wide = dy; return launch_reduce(p, s); }  // dx thin
-  p.thin = dy;                                                // dx wide
+  if (cin_thin) { p.wide = dy; return launch_reduce(p, ws, ws_bytes, s); }  // dx thin
+  p.thin = dy;                                                              // dx wide
   return launch_expand(p, s);
+}
+
+size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g) {
+  ThinP p{};
+  const bool cin_thin = thin_is_cin(g);
+  if (cin_thin || fill_common(p, g, cin_thin, true) != PCG_OK) return 0;
+  return reduce_scratch_bytes(p);
+}
+size_t thin_conv_dgrad_workspace_bytes(const pcg_conv_geom* g) {
+  ThinP p{};
+  const bool cin_thin = thin_is_cin(g);
+  if (!cin_thin || fill_common(p, g, cin_thin, false) != PCG_OK) return 0;
+  return reduce_scratch_bytes(p);
 }
 
 size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
@@ -335,9 +398,10 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
     return PCG_ERR_WORKSPACE;
   }
   float* slab = (float*)ws;
+  const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
 #define PCG_THIN_WGRAD_CASE(KH_, KW_, CS_)                                                                          \
   if (g->KH == KH_ && g->KW == KW_ && p.Cs == CS_) {                                                                 \
-    hipLaunchKernelGGL((thin_wgrad_kernel<KH_, KW_, CS_>), dim3(wp.nblocks), dim3(256), 0, s, p, slab, wp.ppb, wn); \
+    hipLaunchKernelGGL((thin_wgrad_kernel<KH_, KW_, CS_>), dim3(wp.nblocks), dim3(256), 0, s, p, slab, wp.ppb, wn, thin_bytes); \
   } else
   PCG_THIN_WGRAD_CASE(4, 4, 1)
   PCG_THIN_WGRAD_CASE(3, 3, 1)

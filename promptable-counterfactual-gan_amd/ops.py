@@ -108,8 +108,12 @@ def conv2d_fwd(g, x, w, bias=None, out=None):
     _chk(x, "x"); _chk(w, "w")
     assert x.numel() == g.B * g.IH * g.IW * g.Cin and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     y = out if out is not None else torch.empty((g.B, g.OH, g.OW, g.Cout), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = lib.pcg_conv2d_fwd_workspace_bytes(ctypes.byref(g))
+    ws = workspace(need, x.device) if need else None
     with _Timed(g, "fwd"):
-        check(_lib.load().pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _stream()), "pcg_conv2d_fwd")
+        check(lib.pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _p(ws), ws.numel() if need else 0, _stream()),
+              "pcg_conv2d_fwd")
     return y
 
 
@@ -118,8 +122,12 @@ def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
     _chk(dy, "dy"); _chk(w, "w")
     assert dy.numel() == g.B * g.OH * g.OW * g.Cout and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    need = lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
+    ws = workspace(need, dy.device) if need else None
     with _Timed(g, "dgrad"):
-        check(_lib.load().pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _stream()), "pcg_conv2d_dgrad")
+        check(lib.pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _p(ws), ws.numel() if need else 0, _stream()),
+              "pcg_conv2d_dgrad")
     return dx
 
 

@@ -129,15 +129,15 @@ def test_full_width_step_vs_oracle(pcg, batch, skip):
     # one fused Adam launch per net: all parameters of a net form one contiguous segment
     assert optD.num_segments() == 1 and optG.num_segments() == 1
     # weights after the Adam step: Adam divides by |g|, so a gradient at the noise level moves its weight by up to
-    # 2*lr = 4e-4 whatever its size; require (a) no element beyond that bound, (b) all but 0.5 % within 1e-4 + 5e-6
+    # 2*lr = 4e-4 whatever its size; require (a) no element beyond that bound, (b) all but 0.5 % (at least 2 elements) within 1e-4 + 5e-6
     lr = 2e-4
     for net, r64net, tag in ((netG, r64G, "G"), (netD, r64D, "D")):
         for (k, v), (_, t) in zip(net.state_dict().items(), r64net.state_dict().items()):
             got, truth = v.cpu().double().numpy(), t.double().numpy()
             diff = np.abs(got - truth)
             assert diff.max() <= 2.2 * lr + 1e-4 * np.abs(truth).max(), f"{tag} {k}: max diff {diff.max():.2e}"
-            frac = np.mean(diff > 5e-6 + 1e-4 * np.abs(truth))
-            assert frac <= 5e-3, f"{tag} {k}: {100 * frac:.2f}% of elements beyond tolerance"
+            bad = int(np.sum(diff > 5e-6 + 1e-4 * np.abs(truth)))
+            assert bad <= max(2, int(5e-3 * diff.size)), f"{tag} {k}: {bad} of {diff.size} elements beyond tolerance"
 
 
 def test_skip_dead_d_wgrad_changes_nothing_observable(pcg):
