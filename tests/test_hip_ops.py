@@ -182,7 +182,8 @@ def test_bce_losses(pcg, n):
         l, gr = O.bce_with_logits(z, t)
         ld, gd = ops.bce_logits_fwd_bwd(torch.from_numpy(z).to(dev()), t)
         np.testing.assert_allclose(ld.item(), l, rtol=2e-6)
-        np.testing.assert_allclose(gd.cpu().numpy(), gr, rtol=2e-5, atol=1e-9)
+        # sigmoid(z) - t cancels in fp32 when |z| is large: absolute floor of one fp32 ulp of 1.0, over n
+        np.testing.assert_allclose(gd.cpu().numpy(), gr, rtol=2e-5, atol=1.2e-7 / n)
     tt = (rng.random(n) > 0.5).astype(np.float32)
     l, gr = O.bce(p, tt)
     ld, gd = ops.bce_fwd_bwd(torch.from_numpy(p).to(dev()), torch.from_numpy(tt).to(dev()), 0.0)
