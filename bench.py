@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU (default: the BASELINE config, 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
+    ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL gradient-sync path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,10 +91,11 @@ def main():
     pcgan_amd.load()
 
     dp = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         from pcgan_amd.parallel import GradSync, broadcast_parameters
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dp = GradSync()
 
@@ -116,7 +118,7 @@ def main():
         return D.train_step(netG, netD, crit, optD, optG, reals[i % nbatches], noises[i % nbatches], dp=dp)
 
     def barrier():
-        if world > 1:
+        if dp is not None:
             torch.distributed.barrier()
 
     for i in range(args.warmup):
@@ -141,7 +143,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_conv_hook(None)
 
-    if world > 1:
+    if dp is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -191,7 +193,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp is not None:
         torch.distributed.destroy_process_group()
 
 

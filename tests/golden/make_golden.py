@@ -99,7 +99,91 @@ def make_dcgan_small(path, g_hidden=8, d_hidden=8, z_dim=16, batch=4, steps=3):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def tensor_digest(t, nsamples=64):
+    """[sum, sum|.|, sum of squares] in float64 + `nsamples` strided samples: a compact pin for a large tensor."""
+    a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, num=min(nsamples, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
+
+
+def make_countergan(path, batch=4, seed=0):
+    """CounteRGAN/mnist: the reference's own modules (models/*.py, trainer.py) imported from the mounted checkout.
+    Nets are seeded (torch.manual_seed(seed); classifier, generator, discriminator constructed in main.py's order,
+    :18-20) rather than stored: 3.2 M parameters would not be a small fixture.  Stored: inputs, forward outputs, the
+    scalars of one training step (trainer.py:96-123 executed through the reference's train_countergan), and digests
+    (sums + strided samples) of every initial parameter, every gradient and every updated parameter."""
+    mdir = os.path.join(REF, "conditional_counteRGAN/mnist")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, mdir)
+    import importlib
+    for name in ("config", "models", "models.generator", "models.discriminator", "models.classifier", "trainer"):
+        sys.modules.pop(name, None)
+    cfgmod = importlib.import_module("config")
+    gen_mod = importlib.import_module("models.generator")
+    dis_mod = importlib.import_module("models.discriminator")
+    cls_mod = importlib.import_module("models.classifier")
+    trainer = importlib.import_module("trainer")
+    cfg = cfgmod.Config()
+
+    torch.manual_seed(seed)
+    classifier = cls_mod.CNNClassifier(num_classes=cfg.num_classes)
+    generator = gen_mod.ResidualGenerator(img_shape=cfg.img_shape, num_classes=cfg.num_classes)
+    discriminator = dis_mod.Discriminator(img_shape=cfg.img_shape, num_classes=cfg.num_classes)
+    classifier.eval()
+    for p_ in classifier.parameters():
+        p_.requires_grad = False
+
+    out = {"meta.batch": np.int64(batch), "meta.seed": np.int64(seed)}
+    for tag, net in (("G", generator), ("D", discriminator), ("C", classifier)):
+        for k, v in net.state_dict().items():
+            out[f"init.{tag}.{k}"] = tensor_digest(v.float())
+
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(batch, 1, 28, 28, generator=g) * 2 - 1
+    y = torch.randint(0, 10, (batch,), generator=g)
+    target_y = torch.randint(0, 10, (batch,), generator=g)
+    torch.manual_seed(77)
+    mask = trainer.build_mask(x, cfg.patch_size, "cpu", cfg.num_modifiable_patches)
+    out.update({"in.x": x.numpy(), "in.y": y.numpy(), "in.target_y": target_y.numpy(), "in.mask": mask.numpy()})
+    assert float(mask.sum()) == batch * cfg.num_modifiable_patches * cfg.patch_size ** 2
+
+    # forward-only vectors (train mode, on copies)
+    import copy
+    g0, d0 = copy.deepcopy(generator), copy.deepcopy(discriminator)
+    raw, masked = g0(x, target_y, mask)
+    out["fwd.raw"], out["fwd.masked"] = raw.detach().numpy(), masked.detach().numpy()
+    out["fwd.d_logits"] = d0(x, y).detach().numpy()
+    out["fwd.c_logits"] = classifier(x).detach().numpy()
+
+    # one iteration through the reference's own train_countergan: a one-batch loader, one epoch; the loop draws
+    # target_y (:94) and the mask (:95) from the global RNG -> replay the draws to record them
+    cfg.num_epochs_gan = 1
+    cfg.save_dir = "/tmp/pcg_golden_out"
+    cfg.generator_path = os.path.join(cfg.save_dir, "generator.pt")
+    os.makedirs(cfg.save_dir, exist_ok=True)
+    torch.manual_seed(999)
+    t_rec = torch.randint(0, cfg.num_classes, (batch,))
+    m_rec = trainer.build_mask(x, cfg.patch_size, "cpu", cfg.num_modifiable_patches)
+    torch.manual_seed(999)
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        trainer.train_countergan(generator, discriminator, classifier, [(x, y)], cfg, "cpu")
+    out["step.target_y"], out["step.mask"] = t_rec.numpy(), m_rec.numpy()
+    out["step.log"] = np.array(buf.getvalue())
+    for tag, net in (("G", generator), ("D", discriminator)):
+        for k, v in net.state_dict().items():
+            out[f"final.{tag}.{k}"] = tensor_digest(v.float())
+        for n, p_ in net.named_parameters():
+            out[f"grad.{tag}.{n}"] = tensor_digest(p_.grad)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+    print(buf.getvalue().strip().splitlines()[0])
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
     make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))
+    make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))

@@ -78,3 +78,51 @@ def test_training_steps_match_reference_loop_body(gold):
         np.testing.assert_allclose(p.grad.numpy(), gold[f"final.G.grad.{n}"], rtol=1e-4, atol=1e-6, err_msg=n)
     for n, p in netD.named_parameters():
         np.testing.assert_allclose(p.grad.numpy(), gold[f"final.D.grad.{n}"], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+# ---- CounteRGAN/mnist: oracle/countergan_ref.py against the reference's own modules + train_countergan --------------
+from oracle import countergan_ref as CR  # noqa: E402
+
+
+def _digest(t, nsamples=64):
+    a = np.asarray(t.detach().cpu().numpy(), dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, num=min(nsamples, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
+
+
+@pytest.fixture(scope="module")
+def cgold(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "countergan_ref_b4.npz")))
+
+
+def test_countergan_init_and_forward(cgold):
+    G, D, C = CR.build(seed=int(cgold["meta.seed"]))
+    for tag, net in (("G", G), ("D", D), ("C", C)):
+        keys = [k for k in cgold if k.startswith(f"init.{tag}.")]
+        assert [f"init.{tag}.{k}" for k in net.state_dict()] == keys      # same names, same order as the reference
+        for k, v in net.state_dict().items():
+            np.testing.assert_array_equal(_digest(v.float()), cgold[f"init.{tag}.{k}"], err_msg=f"{tag}.{k}")
+    x, y, t, m = (torch.from_numpy(cgold[f"in.{n}"]) for n in ("x", "y", "target_y", "mask"))
+    raw, masked = G(x, t, m)
+    np.testing.assert_allclose(raw.detach().numpy(), cgold["fwd.raw"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(masked.detach().numpy(), cgold["fwd.masked"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(D(x, y).detach().numpy(), cgold["fwd.d_logits"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(C(x).detach().numpy(), cgold["fwd.c_logits"], rtol=1e-5, atol=1e-7)
+
+
+def test_countergan_step_matches_reference_train_loop(cgold):
+    G, D, C = CR.build(seed=int(cgold["meta.seed"]))
+    opt_g, opt_d, bce, ce = CR.make_optimizers(G, D)
+    x, y = torch.from_numpy(cgold["in.x"]), torch.from_numpy(cgold["in.y"])
+    t, m = torch.from_numpy(cgold["step.target_y"]), torch.from_numpy(cgold["step.mask"])
+    out = CR.countergan_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
+    log = str(cgold["step.log"])
+    # the reference prints D(real), D(fake) with 3 decimals, g_adv / g_cls with 4, reg with 6 (trainer.py:135-137)
+    assert f"D(real)={out['d_real_p']:.3f}" in log and f"D(fake)={out['d_fake_p']:.3f}" in log, log
+    assert f"g_adv={out['g_adv']:.4f}" in log and f"g_cls={out['g_cls']:.4f}" in log and f"reg={out['reg_l1']:.6f}" in log, log
+    assert f"G: {out['g_loss']:.4f}, D: {out['d_loss']:.4f}" in log, log
+    for tag, net in (("G", G), ("D", D)):
+        for n, p in net.named_parameters():
+            np.testing.assert_allclose(_digest(p.grad), cgold[f"grad.{tag}.{n}"], rtol=2e-4, atol=1e-7, err_msg=f"grad {tag}.{n}")
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(_digest(v.float()), cgold[f"final.{tag}.{k}"], rtol=1e-4, atol=5e-6, err_msg=f"final {tag}.{k}")
