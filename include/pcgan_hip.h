@@ -102,14 +102,17 @@ int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float eps, float
 /* y = act( (x-mean)*invstd*gamma + beta ).  var_eps < 0: `invstd_or_var` holds invstd (training: save_invstd);
  * var_eps >= 0: it holds a variance and invstd = rsqrt(var + var_eps) (eval mode: running_var, eps).   */
 int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd_or_var,
-                     float var_eps, const float* gamma, const float* beta, int act, float slope, float* y,
-                     pcg_stream_t stream);
+                     float var_eps, const float* gamma, const float* beta, int act, float slope,
+                     const float* residual /*nullable*/, float alpha /* y = residual + alpha*act(bn(x)) :
+                     counteRGAN _ResBlock `x + 0.1*out`, models/generator.py:20; plain BN: NULL, 1 */,
+                     float* y, pcg_stream_t stream);
 /* backward of y = act(bn(x)):  given dy (grad wrt y), x (pre-BN), y (post-activation: the sign mask)
  *   dgamma (+)= sum dz*xhat ; dbeta (+)= sum dz ; dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)),
  *   dz = dy*act'(.)     ([torch] LeakyReLU/ReLU sub-gradient at 0 is the negative-side one: uses y>0) */
-int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C,
+int pcg_bn_act_bwd(const float* dy, const float* x, const float* y /*nullable when act==NONE*/, int64_t rows, int32_t C,
                    const float* mean, const float* invstd, const float* gamma,
-                   int act, float slope, float* dx, float* dgamma, float* dbeta, int accumulate,
+                   int act, float slope, float dy_scale /* dz = dy_scale*dy*act'(.) : the alpha of the forward */,
+                   float* dx, float* dgamma, float* dbeta, int accumulate,
                    void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
@@ -142,6 +145,37 @@ int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
                              int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream);
+
+/* ---- CounteRGAN step: non-convolution pieces (conditional_counteRGAN/mnist) -------------------------
+ * nn.Embedding(num_classes, H*W) lookup + torch.cat along channels (models/generator.py:73-74,
+ * models/discriminator.py:35-36): out[b][p] = (x[b][p], table[idx[b]][p] [, mask[b][p]]) — exact copies.
+ * bwd: dtable[k][p] (+)= sum_{b: idx[b]==k, ascending b} dinp[b][p][1];  dx[b][p] = dinp[b][p][0] (nullable).   */
+int pcg_embed_concat_fwd(const float* x, const int64_t* idx, const float* table, const float* mask /*C==3*/,
+                         float* out, int32_t B, int32_t HW, int32_t C, int32_t K, pcg_stream_t stream);
+int pcg_embed_concat_bwd(const float* dinp, const int64_t* idx, float* dtable /*nullable*/, float* dx /*nullable*/,
+                         int32_t B, int32_t HW, int32_t C, int32_t K, int accumulate, pcg_stream_t stream);
+/* out = a*x + b*y (y nullable): residual-path gradient sums */
+int pcg_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, pcg_stream_t stream);
+/* raw = scale*c ; masked = raw*mask (generator.py:80-82);  bwd: dc = scale*(d_raw + d_masked*mask) */
+int pcg_scale_mask_fwd(const float* c, const float* mask, float scale, float* raw, float* masked, int64_t n, pcg_stream_t stream);
+int pcg_scale_mask_bwd(const float* d_raw /*nullable*/, const float* d_masked /*nullable*/, const float* mask, float scale,
+                       float* dc, int64_t n, pcg_stream_t stream);
+/* x_cf = clamp(x + r, lo, hi) (trainer.py:97); bwd: dr = dy on lo <= x+r <= hi, else 0 ([torch] clamp) */
+int pcg_clamp_add_fwd(const float* x, const float* r, float lo, float hi, float* y, int64_t n, pcg_stream_t stream);
+int pcg_clamp_add_bwd(const float* dy, const float* x, const float* r, float lo, float hi, float* dr, int64_t n, pcg_stream_t stream);
+/* out[0] = mean |a*w|, w = m, 1-m (one_minus_m) or 1 (m NULL): trainer.py:99,119; bwd da (+)= g*sign(a*w)*w/n */
+size_t pcg_abs_mean_workspace_bytes(void);
+int pcg_abs_mean_fwd(const float* a, const float* m, int one_minus_m, int64_t n, float* out, void* workspace,
+                     size_t workspace_bytes, pcg_stream_t stream);
+int pcg_abs_mean_bwd(const float* a, const float* m, int one_minus_m, int64_t n, const float* grad_out_dev /*nullable*/,
+                     float grad_scale, float* da, int accumulate, pcg_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) (discriminator.py:26): y[b][c] = mean over the HW pixels of x[b][p][c] */
+int pcg_avgpool_fwd(const float* x, float* y, int32_t B, int32_t HW, int32_t C, pcg_stream_t stream);
+int pcg_avgpool_bwd(const float* dy, float* dx, int32_t B, int32_t HW, int32_t C, pcg_stream_t stream);
+/* nn.CrossEntropyLoss (mean) on logits [B][K] with int64 targets: trainer.py:80,118 */
+int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, int32_t B, int32_t K, float grad_scale,
+                              const float* grad_out_dev /*nullable*/, float* loss /*nullable*/, float* dlogits /*nullable*/,
+                              pcg_stream_t stream);
 
 /* ---- helpers ---------------------------------------------------------------------------------- */
 int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);

@@ -49,8 +49,21 @@ PROTOTYPES = {
     "pcg_colsum": (_i, [_vp, _i64, _c.c_int32, _vp, _i, _vp, _sz, _vp]),
     "pcg_bn_workspace_bytes": (_sz, [_i64, _c.c_int32]),
     "pcg_bn_train_stats": (_i, [_vp, _i64, _c.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "pcg_bn_apply_act": (_i, [_vp, _i64, _c.c_int32, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _vp]),
-    "pcg_bn_act_bwd": (_i, [_vp, _vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_bn_apply_act": (_i, [_vp, _i64, _c.c_int32, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _f, _vp, _vp]),
+    "pcg_bn_act_bwd": (_i, [_vp, _vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_embed_concat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _vp]),
+    "pcg_embed_concat_bwd": (_i, [_vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _i, _vp]),
+    "pcg_axpby": (_i, [_vp, _f, _vp, _f, _vp, _i64, _vp]),
+    "pcg_scale_mask_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _i64, _vp]),
+    "pcg_scale_mask_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _i64, _vp]),
+    "pcg_clamp_add_fwd": (_i, [_vp, _vp, _f, _f, _vp, _i64, _vp]),
+    "pcg_clamp_add_bwd": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i64, _vp]),
+    "pcg_abs_mean_workspace_bytes": (_sz, []),
+    "pcg_abs_mean_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _sz, _vp]),
+    "pcg_abs_mean_bwd": (_i, [_vp, _vp, _i, _i64, _vp, _f, _vp, _i, _vp]),
+    "pcg_avgpool_fwd": (_i, [_vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _vp]),
+    "pcg_avgpool_bwd": (_i, [_vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _vp]),
+    "pcg_cross_entropy_fwd_bwd": (_i, [_vp, _vp, _c.c_int32, _c.c_int32, _f, _vp, _vp, _vp, _vp]),
     "pcg_act_fwd": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
     "pcg_act_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "pcg_bce_fwd_bwd": (_i, [_vp, _vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,568 @@
+"""Host-side mirror of `conditional_counteRGAN/mnist/` on the HIP kernels.
+
+    reference                                              here
+    ---------------------------------------------------    -----------------------------------------------------
+    config.py            Config            :3-28            Config (the fields the step reads)
+    models/generator.py  ResidualGenerator :25-86           ResidualGenerator (same ctor args, same state_dict keys)
+    models/discriminator.py Discriminator  :5-38            Discriminator
+    models/classifier.py CNNClassifier     :4-28            CNNClassifier (frozen / eval use: forward + grad-input)
+    trainer.py           build_mask        :45-72           build_mask (same draws from torch's RNG)
+    trainer.py           train_countergan  :76-123          make_optimizers + train_step (+ train_countergan loop)
+
+The torch layer objects are kept as parameter containers (identical `state_dict()` keys: `embed.weight`,
+`conv_in.*`, `resblocks.{0..5}.{conv1,bn1,conv2,bn2}.*`, `conv_mid.*`, `conv_out.*`; `cond_embed.weight`, `main.{0,2,4,6}.weight`,
+`adv_head.*`; `conv.{0,2,4}.*`, `fc.{1,4}.*`), forward/backward are one autograd node per network sequencing C-ABI
+calls on NHWC activations.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
+from .nn import FlatModule
+from .optim import Adam
+
+
+class Config:
+    """config.py:3-28."""
+    batch_size = 128
+    num_epochs_gan = 20
+    d_lr = 1e-5
+    g_lr = 5e-5
+    lambda_adv = 1.0
+    lambda_cls = 1.0
+    lambda_reg = 2.5
+    lambda_mask = 2.0
+    patch_size = 7
+    num_modifiable_patches = 10
+    img_shape = (1, 28, 28)
+    num_classes = 10
+
+
+# ---- conv helpers on NHWC activations ------------------------------------------------------------------------------
+def _geom(conv, B, H, W):
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    return ops.conv_geom(B, H, W, conv.in_channels, conv.out_channels, k[0], k[1], s[0], p[0])
+
+
+def _conv_fwd(conv, a):
+    B, H, W, _ = a.shape
+    g = _geom(conv, B, H, W)
+    z = ops.conv2d_fwd(g, a, ops.ohwi(conv.weight.data), conv.bias.data if conv.bias is not None else None)
+    return g, z
+
+
+def _conv_bwd(net, conv, g, a, dz, need_p, need_x):
+    """Accumulate weight/bias gradients into net's flat buffer; return grad wrt the conv input (or None)."""
+    if need_p and conv.weight.requires_grad:
+        gw, acc = net._grad_view(conv.weight)
+        ops.conv2d_wgrad(g, a, dz, ops.ohwi(gw), acc)
+        if conv.bias is not None:
+            gb, accb = net._grad_view(conv.bias)
+            ops.colsum(dz.numel() // conv.out_channels, conv.out_channels, dz, gb, accb)
+    return ops.conv2d_dgrad(g, dz, ops.ohwi(conv.weight.data)) if need_x else None
+
+
+def _as_rows(t, B):
+    """[B,1,H,W] / [B,H,W] tensor as a contiguous fp32 [B, H*W] view (C == 1: NCHW and NHWC are the same bytes)."""
+    v = t.reshape(B, -1)
+    if not v.is_contiguous():
+        v = v.contiguous()
+    if v.dtype != torch.float32:
+        raise PcgError(f"expected float32, got {v.dtype}")
+    return v
+
+
+# ---- small autograd nodes for the trainer's elementwise glue (trainer.py:97,99,119) ---------------------------------
+class _ClampAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, lo, hi):
+        xc, rc = x.contiguous(), r.contiguous()
+        ctx.save_for_backward(xc, rc)
+        ctx.lo, ctx.hi = lo, hi
+        return ops.clamp_add_fwd(xc, rc, lo, hi)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r = ctx.saved_tensors
+        return None, ops.clamp_add_bwd(dy.contiguous(), x, r, ctx.lo, ctx.hi), None, None
+
+
+def clamp_add(x, r, lo=-1.0, hi=1.0):
+    """torch.clamp(x + r, lo, hi) with gradient to r only (x is data)."""
+    return _ClampAdd.apply(x, r, lo, hi)
+
+
+class _AbsMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, m, one_minus):
+        ac = a.contiguous()
+        mc = m.contiguous() if m is not None else None
+        ctx.save_for_backward(ac, mc)
+        ctx.one_minus = one_minus
+        return ops.abs_mean_fwd(ac, mc, one_minus).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, m = ctx.saved_tensors
+        return ops.abs_mean_bwd(a, m, ctx.one_minus, g.contiguous().view(1)), None, None
+
+
+def abs_mean(a, m=None, one_minus=False):
+    """mean(|a * w|) with w = m, (1 - m) or 1."""
+    return _AbsMean.apply(a, m, one_minus)
+
+
+class _BCELogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, target_const):
+        zc = z.contiguous()
+        ctx.save_for_backward(zc)
+        ctx.t = target_const
+        loss, _ = ops.bce_logits_fwd_bwd(zc, target_const, need_grad=False)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        _, dz = ops.bce_logits_fwd_bwd(z, ctx.t, need_loss=False, grad_out=g.contiguous().view(1))
+        return dz, None
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """nn.BCEWithLogitsLoss() against an all-ones / all-zeros target (trainer.py:106-107,117 use ones_like / zeros_like)."""
+
+    def forward(self, input, target):
+        t = float(target) if not torch.is_tensor(target) else None
+        if t is None:
+            raise PcgError("BCEWithLogitsLoss here takes the constant target 0.0 or 1.0 (ones_like/zeros_like in the reference)")
+        return _BCELogitsFn.apply(input, t)
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        zc = logits.contiguous()
+        ctx.save_for_backward(zc, target)
+        loss, _ = ops.cross_entropy_fwd_bwd(zc, target, need_grad=False)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        z, target = ctx.saved_tensors
+        _, dz = ops.cross_entropy_fwd_bwd(z, target, need_loss=False, grad_out=g.contiguous().view(1))
+        return dz, None
+
+
+class CrossEntropyLoss(nn.Module):
+    def forward(self, input, target):
+        return _CEFn.apply(input, target)
+
+
+# ---- generator -----------------------------------------------------------------------------------------------------
+class _ResBlock(nn.Module):
+    """generator.py:5-22 (parameter container; executed by ResidualGenerator)."""
+
+    def __init__(self, channels, activation):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(channels)
+        self.act = activation
+        self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(channels)
+
+
+class _GFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, target, mask, *params):
+        raw, masked, saved = net._run_forward(x, target, mask)
+        ctx.net, ctx.saved = net, saved
+        return raw, masked
+
+    @staticmethod
+    def backward(ctx, d_raw, d_masked):
+        ctx.net._run_backward(ctx.saved, d_raw, d_masked, any(ctx.needs_input_grad[4:]))
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class ResidualGenerator(FlatModule):
+    """generator.py:25-86 — returns (raw_residual, masked_residual)."""
+
+    def __init__(self, img_shape=(1, 28, 28), num_classes=10, base_ch=64, n_resblocks=6, residual_scaling=0.1):
+        super().__init__()
+        C, H, W = img_shape
+        if C != 1:
+            raise PcgError("ResidualGenerator: single-channel images only (the reference's MNIST configuration)")
+        self.embed = nn.Embedding(num_classes, H * W)
+        self.conv_in = nn.Conv2d(C + 2, base_ch, kernel_size=3, padding=1)
+        self.act = nn.LeakyReLU(0.2, inplace=True)
+        self.resblocks = nn.Sequential(*[_ResBlock(base_ch, self.act) for _ in range(n_resblocks)])
+        self.conv_mid = nn.Conv2d(base_ch, base_ch, kernel_size=3, padding=1)
+        self.conv_out = nn.Conv2d(base_ch, 1, kernel_size=3, padding=1)
+        self.residual_scaling = residual_scaling
+        self._hw = (H, W)
+        self._init_weights()
+
+    def _init_weights(self):
+        """generator.py:58-69."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0.2)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, mean=0.0, std=0.01)
+
+    def forward(self, x, target, mask=None):
+        if mask is None:
+            raise PcgError("ResidualGenerator: a mask is required (the reference only warns and then fails in torch.cat)")
+        self._ensure_flat()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raw, masked = _GFn.apply(self, x, target, mask, *self.parameters())
+        else:
+            raw, masked, _ = self._run_forward(x, target, mask, keep=False)
+        return raw, masked
+
+    def _bn(self, bn, z, act, slope, residual=None, alpha=1.0):
+        C = bn.num_features
+        if bn.training:
+            mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, act, slope, residual=residual, alpha=alpha)
+            return y, mean, invstd
+        y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, act, slope, var_eps=bn.eps,
+                             residual=residual, alpha=alpha)
+        return y, None, None
+
+    def _run_forward(self, x, target, mask, keep=True):
+        B = x.shape[0]
+        H, W = self._hw
+        xr, mr = _as_rows(x, B), _as_rows(mask, B)
+        slope = float(self.act.negative_slope)
+        inp = ops.embed_concat_fwd(xr, target, self.embed.weight.data, mr).view(B, H, W, 3)
+        g_in, h = _conv_fwd(self.conv_in, inp)
+        ops.act_fwd(h, ACT_LRELU, slope, out=h)
+        blocks = []
+        for blk in self.resblocks:
+            g1, z1 = _conv_fwd(blk.conv1, h)
+            a1, m1, s1 = self._bn(blk.bn1, z1, ACT_LRELU, slope)
+            g2, z2 = _conv_fwd(blk.conv2, a1)
+            hn, m2, s2 = self._bn(blk.bn2, z2, ACT_NONE, 0.0, residual=h, alpha=0.1)      # x + 0.1 * out (:20)
+            if keep:
+                blocks.append((g1, h, z1, a1, m1, s1, g2, z2, m2, s2))
+            h = hn
+        g_mid, hm = _conv_fwd(self.conv_mid, h)
+        ops.act_fwd(hm, ACT_LRELU, slope, out=hm)
+        g_out, c = _conv_fwd(self.conv_out, hm)
+        raw, masked = ops.scale_mask_fwd(c, mr, self.residual_scaling)
+        saved = (inp, g_in, blocks, h, g_mid, hm, g_out, mr, target) if keep else None
+        shp = (B, 1, H, W)
+        return raw.view(shp), masked.view(shp), saved
+
+    def _run_backward(self, saved, d_raw, d_masked, need_p):
+        inp, g_in, blocks, h_last, g_mid, hm, g_out, mr, target = saved
+        if not need_p:
+            return
+        if any(blk.bn1.training is False for blk in self.resblocks):
+            raise PcgError("backward through an eval-mode BatchNorm2d is not implemented")
+        slope = float(self.act.negative_slope)
+        B = inp.shape[0]
+        dr = d_raw.contiguous() if d_raw is not None else None
+        dm = d_masked.contiguous() if d_masked is not None else None
+        dc = ops.scale_mask_bwd(dr, dm, mr, self.residual_scaling, like=mr).view(g_out.B, g_out.OH, g_out.OW, 1)
+        d = _conv_bwd(self, self.conv_out, g_out, hm, dc, True, True)
+        ops.act_bwd(d, hm, ACT_LRELU, slope, out=d)
+        dh = _conv_bwd(self, self.conv_mid, g_mid, h_last, d, True, True)
+        for blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2) in zip(reversed(self.resblocks), reversed(blocks)):
+            C = blk.bn2.num_features
+            dg2, acc = self._grad_view(blk.bn2.weight)
+            db2, _ = self._grad_view(blk.bn2.bias)
+            dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1)
+            da1 = _conv_bwd(self, blk.conv2, g2, a1, dz2, True, True)
+            dg1, acc = self._grad_view(blk.bn1.weight)
+            db1, _ = self._grad_view(blk.bn1.bias)
+            dz1 = ops.bn_act_bwd(da1, z1, a1, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc)
+            dconv = _conv_bwd(self, blk.conv1, g1, h, dz1, True, True)
+            dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)          # skip path + block path
+        ops.act_bwd(dh, blocks[0][1] if blocks else h_last, ACT_LRELU, slope, out=dh)   # h0 = LeakyReLU(conv_in(inp))
+        dinp = _conv_bwd(self, self.conv_in, g_in, inp, dh, True, True)
+        ge, acc = self._grad_view(self.embed.weight)
+        ops.embed_concat_bwd(dinp, target, 3, self.embed.num_embeddings, dtable=ge, accumulate=acc)
+
+
+# ---- discriminator ----------------------------------------------------------------------------------------------------
+class _DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, cond_idx, *params):
+        out, saved = net._run_forward(x, cond_idx)
+        ctx.net, ctx.saved = net, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dx = ctx.net._run_backward(ctx.saved, dlogits, ctx.needs_input_grad[1], any(ctx.needs_input_grad[3:]))
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class Discriminator(FlatModule):
+    """discriminator.py:5-38 — logits [B, 1]."""
+
+    def __init__(self, img_shape=(1, 28, 28), num_classes=Config.num_classes):
+        super().__init__()
+        C, H, W = img_shape
+        self.cond_embed = nn.Embedding(num_classes, H * W)
+        self.img_channel = 2
+        self.d_hidden = 64
+        d = self.d_hidden
+        self.main = nn.Sequential(
+            nn.Conv2d(self.img_channel, d, 3, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d, d * 2, 3, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d * 2, d * 4, 3, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(d * 4, d * 4, 3, 2, 1, bias=False), nn.LeakyReLU(0.2, inplace=True),
+            nn.AdaptiveAvgPool2d(1),
+        )
+        self.flatten = nn.Flatten()
+        self.adv_head = nn.Linear(d * 4, 1)
+        self._hw = (H, W)
+
+    def _convs(self):
+        return [m for m in self.main if isinstance(m, nn.Conv2d)]
+
+    def forward(self, x, cond_idx):
+        self._ensure_flat()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DFn.apply(self, x, cond_idx, *self.parameters())
+        return self._run_forward(x, cond_idx, keep=False)[0]
+
+    def _run_forward(self, x, cond_idx, keep=True):
+        B = x.shape[0]
+        H, W = self._hw
+        a = ops.embed_concat_fwd(_as_rows(x, B), cond_idx, self.cond_embed.weight.data, None).view(B, H, W, 2)
+        layers = []
+        for conv in self._convs():
+            g, z = _conv_fwd(conv, a)
+            ops.act_fwd(z, ACT_LRELU, 0.2, out=z)
+            if keep:
+                layers.append((g, a, z))
+            a = z
+        Bq, Hq, Wq, Cq = a.shape
+        pooled = ops.avgpool_fwd(a, B, Hq * Wq, Cq)
+        gl = ops.conv_geom(B, 1, 1, Cq, 1, 1, 1, 1, 0)
+        logits = ops.conv2d_fwd(gl, pooled, self.adv_head.weight.data, self.adv_head.bias.data).view(B, 1)
+        saved = (layers, pooled, gl, (Hq * Wq, Cq), cond_idx) if keep else None
+        return logits, saved
+
+    def _run_backward(self, saved, dlogits, need_x, need_p):
+        layers, pooled, gl, (HWq, Cq), cond_idx = saved
+        B = pooled.shape[0]
+        dl = dlogits.contiguous()
+        head = self.adv_head
+        if need_p and head.weight.requires_grad:
+            gw, acc = self._grad_view(head.weight)
+            ops.conv2d_wgrad(gl, pooled, dl, gw, acc)
+            gb, accb = self._grad_view(head.bias)
+            ops.colsum(B, 1, dl, gb, accb)
+        dpool = ops.conv2d_dgrad(gl, dl, head.weight.data)
+        d = ops.avgpool_bwd(dpool, B, HWq, Cq).view(layers[-1][2].shape)
+        convs = self._convs()
+        for i in range(len(convs) - 1, -1, -1):
+            g, a, y = layers[i]
+            ops.act_bwd(d, y, ACT_LRELU, 0.2, out=d)
+            last = i == 0
+            need_in = (not last) or need_x or (need_p and self.cond_embed.weight.requires_grad)
+            d = _conv_bwd(self, convs[i], g, a, d, need_p, need_in)
+        if d is None:
+            return None
+        ge, acc = (self._grad_view(self.cond_embed.weight) if need_p and self.cond_embed.weight.requires_grad else (None, False))
+        dx = ops.embed_concat_bwd(d, cond_idx, 2, self.cond_embed.num_embeddings, dtable=ge, accumulate=acc, need_dx=need_x)
+        H, W = self._hw
+        return dx.view(B, 1, H, W) if need_x else None
+
+
+# ---- frozen classifier -----------------------------------------------------------------------------------------------
+class _CFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x):
+        logits, saved = net._run_forward(x)
+        ctx.net, ctx.saved = net, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        return None, ctx.net._run_backward(ctx.saved, dlogits)
+
+
+class CNNClassifier(nn.Module):
+    """classifier.py:4-28, as the GAN step uses it: eval mode, parameters frozen (main.py:30-33) — forward and the
+    gradient with respect to the input image.  Training it (trainer.py:8-39) is not part of this path."""
+
+    def __init__(self, num_classes=10):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(1, 32, 3, 1, 1), nn.ReLU(),
+            nn.Conv2d(32, 64, 3, 2, 1), nn.ReLU(),
+            nn.Conv2d(64, 128, 3, 2, 1), nn.ReLU(),
+            nn.Dropout2d(0.25),
+        )
+        self.fc = nn.Sequential(nn.Flatten(), nn.Linear(128 * 7 * 7, 256), nn.ReLU(), nn.Dropout(0.5), nn.Linear(256, num_classes))
+        self.num_classes = num_classes
+        self._packed = None
+
+    def _pack(self):
+        """NHWC / 4-aligned images of the frozen weights (rebuilt if the parameters change): conv weights OHWI; fc1 columns
+        re-ordered from (c,h,w) to (h,w,c) so it consumes the NHWC activation; fc2 padded from 10 to 12 outputs (16-byte
+        rows).  One-time setup copies, not part of the step."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        if self.training:
+            raise PcgError("CNNClassifier: only eval mode is implemented (the GAN step uses the frozen classifier)")
+        convs = [m for m in self.conv if isinstance(m, nn.Conv2d)]
+        fc1, fc2 = self.fc[1], self.fc[4]
+        with torch.no_grad():
+            cw = [(c, c.weight.permute(0, 2, 3, 1).contiguous(), c.bias.contiguous()) for c in convs]
+            w1 = fc1.weight.view(fc1.out_features, 128, 7, 7).permute(0, 2, 3, 1).contiguous().view(fc1.out_features, -1)
+            kp = (self.num_classes + 3) // 4 * 4
+            w2 = torch.zeros(kp, fc2.in_features, device=fc2.weight.device)
+            w2[: self.num_classes] = fc2.weight
+            b2 = torch.zeros(kp, device=fc2.weight.device)
+            b2[: self.num_classes] = fc2.bias
+        packed = (cw, w1, fc1.bias.contiguous(), w2, b2, kp)
+        self._packed = (key, packed)
+        return packed
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise PcgError(f"CNNClassifier: input is on {x.device}; libpcgan_hip has no CPU path")
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _CFn.apply(self, x)
+        return self._run_forward(x, keep=False)[0]
+
+    def _run_forward(self, x, keep=True):
+        cw, w1, b1, w2, b2, kp = self._pack()
+        B = x.shape[0]
+        a = _as_rows(x, B).view(B, 28, 28, 1)
+        layers = []
+        for conv, w, b in cw:
+            Bq, H, W, _ = a.shape
+            g = _geom(conv, B, H, W)
+            z = ops.conv2d_fwd(g, a, w, b)
+            ops.act_fwd(z, ACT_RELU, 0.0, out=z)
+            if keep:
+                layers.append((g, w, z))
+            a = z
+        feat = a.numel() // B
+        g1 = ops.conv_geom(B, 1, 1, feat, w1.shape[0], 1, 1, 1, 0)
+        h = ops.conv2d_fwd(g1, a.view(B, 1, 1, feat), w1, b1)
+        ops.act_fwd(h, ACT_RELU, 0.0, out=h)
+        g2 = ops.conv_geom(B, 1, 1, w1.shape[0], kp, 1, 1, 1, 0)
+        logits = ops.conv2d_fwd(g2, h, w2, b2).view(B, kp)[:, : self.num_classes]
+        saved = (layers, g1, w1, h, g2, w2, kp) if keep else None
+        return logits, saved
+
+    def _run_backward(self, saved, dlogits):
+        layers, g1, w1, h, g2, w2, kp = saved
+        B = dlogits.shape[0]
+        dl = torch.empty((B, kp), dtype=torch.float32, device=dlogits.device)
+        ops.fill(dl, 0.0)
+        dl[:, : self.num_classes].copy_(dlogits)      # pad 10 -> 12 columns (tiny strided copy)
+        d = ops.conv2d_dgrad(g2, dl, w2)
+        ops.act_bwd(d, h, ACT_RELU, 0.0, out=d)
+        d = ops.conv2d_dgrad(g1, d, w1)
+        for g, w, y in reversed(layers):
+            d = d.view(y.shape)
+            ops.act_bwd(d, y, ACT_RELU, 0.0, out=d)
+            d = ops.conv2d_dgrad(g, d, w)
+        return d.view(B, 1, 28, 28)
+
+
+# ---- trainer ------------------------------------------------------------------------------------------------------------
+def build_mask(x, patch_size, device, num_modifiable_patches=None):
+    """trainer.py:45-72 — same draws from torch's RNG as the reference (host loop over the batch; moving this to the
+    device is SURVEY.md §8f item 1)."""
+    bs, c, h, w = x.shape
+    nph, npw = h // patch_size, w // patch_size
+    total = nph * npw
+    patch_mask = torch.zeros((bs, 1, nph, npw), device=device)
+    if num_modifiable_patches is None or num_modifiable_patches >= total:
+        patch_mask = torch.randint(0, 2, patch_mask.shape, device=device).float()
+    else:
+        for b in range(bs):
+            idx = torch.randperm(total, device=device)[:num_modifiable_patches]
+            patch_mask.view(bs, -1)[b, idx] = 1.0
+    return F.interpolate(patch_mask, size=(h, w), mode="nearest").repeat(1, c, 1, 1)
+
+
+def make_optimizers(generator, discriminator, cfg=Config):
+    """trainer.py:77-80."""
+    opt_g = Adam(generator.parameters(), lr=cfg.g_lr)
+    opt_d = Adam(discriminator.parameters(), lr=cfg.d_lr)
+    return opt_g, opt_d, BCEWithLogitsLoss(), CrossEntropyLoss()
+
+
+def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg=Config, dp=None,
+               skip_dead_d_wgrad=True):
+    """One iteration of train_countergan's loop body (trainer.py:89-123) for a batch already on the GPU; `target_y`
+    (:94) and `mask` (:95) are passed in.  Returns device tensors; the reference's `.item()` calls are the caller's."""
+    raw_residual, masked_residual = generator(x, target_y, mask)                       # :96
+    x_cf = clamp_add(x, masked_residual, -1.0, 1.0)                                    # :97
+    mask_penalty_pre = abs_mean(raw_residual, mask, one_minus=True)                    # :99
+    # Discriminator update
+    opt_d.zero_grad()                                                                  # :102
+    d_real_logits = discriminator(x, y)                                                # :103
+    d_fake_logits = discriminator(x_cf.detach(), target_y)                             # :104
+    d_loss = bce(d_real_logits, 1.0) + bce(d_fake_logits, 0.0)                         # :106-107
+    d_loss.backward()                                                                  # :111
+    if dp is not None:
+        dp.sync_now(discriminator)
+    opt_d.step()                                                                       # :112
+    # Generator update
+    if dp is not None:
+        dp.wait(generator)
+    opt_g.zero_grad()                                                                  # :115
+    if skip_dead_d_wgrad:
+        for p in discriminator.parameters():
+            p.requires_grad_(False)
+    try:
+        g_fake_logits = discriminator(x_cf, target_y)                                  # :116
+        g_adv = bce(g_fake_logits, 1.0)                                                # :117
+        g_cls = ce(classifier(x_cf), target_y)                                         # :118
+        reg_l1 = abs_mean(masked_residual)                                             # :119
+        g_loss = cfg.lambda_adv * g_adv + cfg.lambda_cls * g_cls + cfg.lambda_reg * reg_l1 + cfg.lambda_mask * mask_penalty_pre  # :121
+        g_loss.backward()                                                              # :122
+    finally:
+        if skip_dead_d_wgrad:
+            for p in discriminator.parameters():
+                p.requires_grad_(True)
+    if dp is not None:
+        dp.sync_now(generator)
+    opt_g.step()                                                                       # :123
+    return {"d_loss": d_loss, "g_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg_l1": reg_l1, "mask_pen": mask_penalty_pre,
+            "d_real_logits": d_real_logits, "d_fake_logits": d_fake_logits, "x_cf": x_cf}
+
+
+def train_countergan(generator, discriminator, classifier, train_loader, cfg, device, log_every=100):
+    """trainer.py:76-147 without the plotting / checkpoint tail: same loop, same per-epoch means."""
+    opt_g, opt_d, bce, ce = make_optimizers(generator, discriminator, cfg)
+    history = []
+    for epoch in range(cfg.num_epochs_gan):
+        g_epoch = d_epoch = cls_epoch = 0.0
+        n = 0
+        for batch_idx, (x, y) in enumerate(train_loader):
+            x, y = x.to(device), y.to(device)
+            bs = x.size(0)
+            target_y = torch.randint(0, cfg.num_classes, (bs,), device=device)                 # :94
+            mask = build_mask(x, cfg.patch_size, device, cfg.num_modifiable_patches)           # :95
+            out = train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg)
+            g_epoch += out["g_loss"].item(); d_epoch += out["d_loss"].item(); cls_epoch += out["g_cls"].item()
+            n += 1
+            if batch_idx % log_every == 0:
+                print(f"[Epoch {epoch + 1}/{cfg.num_epochs_gan}] batch {batch_idx} :: "
+                      f"D(real)={torch.sigmoid(out['d_real_logits']).mean().item():.3f}, "
+                      f"D(fake)={torch.sigmoid(out['d_fake_logits']).mean().item():.3f}, g_adv={out['g_adv'].item():.4f}, "
+                      f"g_cls={out['g_cls'].item():.4f}, reg={out['reg_l1'].item():.6f}")
+        history.append((g_epoch / n, d_epoch / n, cls_epoch / n))
+    return history

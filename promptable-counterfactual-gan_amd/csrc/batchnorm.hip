@@ -64,17 +64,18 @@ struct FnSum {  // sum dy
     ldv<VEC>(x, idx, o[0]);
   }
 };
-struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy*act'(y)
+struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
   static constexpr int NVAL = 2;
   const float* dy; const float* x; const float* y; const float* mean; const float* invstd;
-  int act; float slope;
+  int act; float slope; float dy_scale;
   template <int VEC>
   __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
     float g[VEC], xv[VEC], yv[VEC];
-    ldv<VEC>(dy, idx, g); ldv<VEC>(x, idx, xv); ldv<VEC>(y, idx, yv);
+    ldv<VEC>(dy, idx, g); ldv<VEC>(x, idx, xv);
+    if (act != PCG_ACT_NONE) ldv<VEC>(y, idx, yv);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float dz = g[e] * act_grad_from_out(yv[e], act, slope);
+      const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
       const float xh = (xv[e] - mean[c0 + e]) * invstd[c0 + e];
       o[0][e] = dz; o[1][e] = dz * xh;
     }
@@ -201,16 +202,20 @@ __global__ void __launch_bounds__(256) bn_apply_act_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float var_eps,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int act, float slope, float* __restrict__ y) {
+                                                           int act, float slope, const float* __restrict__ residual,
+                                                           float alpha, float* __restrict__ y) {
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     const int c0 = (int)((i * VEC) % (size_t)C);
-    float v[VEC];
+    float v[VEC], rs[VEC];
     if constexpr (VEC == 4) {
       const float4 q = reinterpret_cast<const float4*>(x)[i];
       v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      const float4 r = residual ? reinterpret_cast<const float4*>(residual)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rs[0] = r.x; rs[1] = r.y; rs[2] = r.z; rs[3] = r.w;
     } else {
       v[0] = x[i];
+      rs[0] = residual ? residual[i] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(256) bn_apply_act_kernel(const float* __restri
       const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[c] + var_eps) : invstd[c];
       const float sc = (gamma ? gamma[c] : 1.f) * is;
       const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
-      v[e] = act_apply(fmaf(v[e], sc, sh), act, slope);
+      v[e] = fmaf(alpha, act_apply(fmaf(v[e], sc, sh), act, slope), rs[e]);
     }
     if constexpr (VEC == 4) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
     else y[i] = v[0];
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, size_t n, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, int act, float slope,
-                                                           float* __restrict__ dx) {
+                                                           float dy_scale, float* __restrict__ dx) {
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     const int c0 = (int)((i * VEC) % (size_t)C);
@@ -238,17 +243,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     if constexpr (VEC == 4) {
       const float4 a = reinterpret_cast<const float4*>(dy)[i];
       const float4 b = reinterpret_cast<const float4*>(x)[i];
-      const float4 c = reinterpret_cast<const float4*>(y)[i];
+      const float4 c = act != PCG_ACT_NONE ? reinterpret_cast<const float4*>(y)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
       g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
       xv[0] = b.x; xv[1] = b.y; xv[2] = b.z; xv[3] = b.w;
       yv[0] = c.x; yv[1] = c.y; yv[2] = c.z; yv[3] = c.w;
     } else {
-      g[0] = dy[i]; xv[0] = x[i]; yv[0] = y[i];
+      g[0] = dy[i]; xv[0] = x[i]; yv[0] = act != PCG_ACT_NONE ? y[i] : 1.f;
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int c = c0 + e;
-      const float dz = g[e] * act_grad_from_out(yv[e], act, slope);
+      const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
       const float xh = (xv[e] - mean[c]) * invstd[c];
       g[e] = coef[c] * (dz - coef[C + c] - xh * coef[2 * C + c]);
     }
@@ -313,32 +318,33 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
 }
 
 extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                                float var_eps, const float* gamma, const float* beta, int act, float slope, float* y,
-                                pcg_stream_t stream) {
+                                float var_eps, const float* gamma, const float* beta, int act, float slope,
+                                const float* residual, float alpha, float* y, pcg_stream_t stream) {
   PCG_REQUIRE(x && y && mean && invstd && rows > 0 && C > 0, "pcg_bn_apply_act: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)rows * C;
-  if (C % 4 == 0 && al16(x) && al16(y))
-    hipLaunchKernelGGL(bn_apply_act_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, y);
+  if (C % 4 == 0 && al16(x) && al16(y) && al16(residual))
+    hipLaunchKernelGGL(bn_apply_act_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, residual, alpha, y);
   else
-    hipLaunchKernelGGL(bn_apply_act_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, y);
+    hipLaunchKernelGGL(bn_apply_act_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, residual, alpha, y);
   return launch_status("bn_apply_act_kernel");
 }
 
 extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
-                              const float* invstd, const float* gamma, int act, float slope, float* dx, float* dgamma,
-                              float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
-  PCG_REQUIRE(dy && x && y && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
+                              const float* invstd, const float* gamma, int act, float slope, float dy_scale, float* dx,
+                              float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                              pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && (y || act == PCG_ACT_NONE) && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
   if (!workspace || workspace_bytes < pcg_bn_workspace_bytes(rows, C)) {
     set_error("pcg_bn_act_bwd: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_workspace_bytes(rows, C));
     return PCG_ERR_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const bool aligned = al16(dy) && al16(x) && al16(y) && al16(dx);
+  const bool aligned = al16(dy) && al16(x) && al16(y) && al16(dx);  // al16(nullptr) is true
   const ColPlan cp = plan_cols(rows, C, aligned);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)cp.nblocks * 2 * C;
-  FnBnBwd fn{dy, x, y, mean, invstd, act, slope};
+  FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
@@ -346,10 +352,10 @@ extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, i
   const size_t n = (size_t)rows * C;
   if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
-                       (const float*)coef, act, slope, dx);
+                       (const float*)coef, act, slope, dy_scale, dx);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
-                       (const float*)coef, act, slope, dx);
+                       (const float*)coef, act, slope, dy_scale, dx);
   return launch_status("bn_bwd_apply_kernel");
 }
 

@@ -1,0 +1,280 @@
+// cf_ops.hip — the non-convolution pieces of the CounteRGAN step (conditional_counteRGAN/mnist): label-embedding
+// lookup + channel concat (bit-exact row copies), residual composition, clamp, L1 penalties, global average pool,
+// softmax cross-entropy.  All are small HBM-bound streaming kernels; reductions are fixed-order (reproducible).
+// Reference call sites are cited next to each prototype in include/pcgan_hip.h.
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+unsigned ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// out[b][p][0] = x[b][p] ; out[b][p][1] = table[idx[b]][p] ; out[b][p][2] = mask[b][p] (C == 3)
+__global__ void __launch_bounds__(256) embed_concat_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ table, const float* __restrict__ mask,
+                                                               float* __restrict__ out, int B, int HW, int C, int K) {
+  const size_t n = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i / HW), p = (int)(i - (size_t)b * HW);
+    int64_t k = idx[b];
+    k = k < 0 ? 0 : (k >= K ? K - 1 : k);  // host checks the range; never read outside the table
+    float* o = out + i * C;
+    o[0] = x[i];
+    o[1] = table[(size_t)k * HW + p];
+    if (C > 2) o[2] = mask[i];
+  }
+}
+
+// dtable[k][p] (+)= sum over b with idx[b]==k (ascending b) of dinp[b][p][1] ; dx[b][p] = dinp[b][p][0] (optional)
+__global__ void __launch_bounds__(256) embed_concat_bwd_kernel(const float* __restrict__ dinp, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dtable, float* __restrict__ dx, int B, int HW,
+                                                               int C, int K, int accumulate) {
+  const int total = K * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    if (!dtable) break;
+    const int k = i / HW, p = i - k * HW;
+    float s = accumulate ? dtable[i] : 0.f;
+    for (int b = 0; b < B; ++b)
+      if (idx[b] == (int64_t)k) s += dinp[((size_t)b * HW + p) * C + 1];
+    dtable[i] = s;
+  }
+  if (dx) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = dinp[i * C];
+  }
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(float* __restrict__ out, float a, const float* __restrict__ x, float b,
+                                                    const float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// raw = s*c ; masked = raw*mask
+__global__ void __launch_bounds__(256) scale_mask_fwd_kernel(const float* __restrict__ c, const float* __restrict__ mask, float s,
+                                                             float* __restrict__ raw, float* __restrict__ masked, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float r = s * c[i];
+    raw[i] = r;
+    masked[i] = mask ? r * mask[i] : r;
+  }
+}
+// dc = s*(d_raw + d_masked*mask)
+__global__ void __launch_bounds__(256) scale_mask_bwd_kernel(const float* __restrict__ d_raw, const float* __restrict__ d_masked,
+                                                             const float* __restrict__ mask, float s, float* __restrict__ dc, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float g = d_raw ? d_raw[i] : 0.f;
+    if (d_masked) g += d_masked[i] * (mask ? mask[i] : 1.f);
+    dc[i] = s * g;
+  }
+}
+
+// y = clamp(x + r, lo, hi) ; dr = dy * [lo <= x + r <= hi]   ([torch] clamp passes the gradient on the closed interval)
+__global__ void __launch_bounds__(256) clamp_add_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, float lo,
+                                                            float hi, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = fminf(fmaxf(x[i] + r[i], lo), hi);
+}
+__global__ void __launch_bounds__(256) clamp_add_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ r, float lo, float hi,
+                                                            float* __restrict__ dr, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = x[i] + r[i];
+    dr[i] = (v >= lo && v <= hi) ? dy[i] : 0.f;
+  }
+}
+
+// mean |a * w| (w = 1 - m if one_minus, m otherwise, 1 if null): per-block partials, then a fixed-order finish
+constexpr int AM_BLOCKS = 256;
+__device__ __forceinline__ float am_weight(const float* m, size_t i, int one_minus) {
+  return m ? (one_minus ? 1.f - m[i] : m[i]) : 1.f;
+}
+__global__ void __launch_bounds__(256) abs_mean_partial_kernel(const float* __restrict__ a, const float* __restrict__ m,
+                                                               int one_minus, size_t n, float* __restrict__ partial) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    acc += fabsf(a[i] * am_weight(m, i, one_minus));
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void abs_mean_finish_kernel(const float* __restrict__ partial, int nparts, double inv_n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += (double)partial[i];
+    out[0] = (float)(s * inv_n);
+  }
+}
+// da (+)= g * sign(a*w) * w / n      ([torch] abs'(0) = 0)
+__global__ void __launch_bounds__(256) abs_mean_bwd_kernel(const float* __restrict__ a, const float* __restrict__ m, int one_minus,
+                                                           size_t n, const float* __restrict__ gout, float scale,
+                                                           float* __restrict__ da, int accumulate) {
+  const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float w = am_weight(m, i, one_minus), v = a[i] * w;
+    const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+    da[i] = (accumulate ? da[i] : 0.f) + g * sg * w;
+  }
+}
+
+// global average pool over HW: y[b][c] = mean_p x[b][p][c]
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+  const int total = B * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += x[((size_t)b * HW + p) * C + c];
+    y[i] = s / (float)HW;
+  }
+}
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int HW, int C) {
+  const size_t n = (size_t)B * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t b = i / ((size_t)HW * C);
+    dx[i] = dy[b * C + c] * inv;
+  }
+}
+
+// softmax cross-entropy, reduction mean: one thread per row (K is the number of classes: 10)
+__global__ void __launch_bounds__(256) cross_entropy_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, int B,
+                                                            int K, float grad_scale, const float* __restrict__ gout,
+                                                            float* loss, float* __restrict__ dz) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const float g = grad_scale * (gout ? gout[0] : 1.f) / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* r = z + (size_t)b * K;
+    float mx = r[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, r[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(r[k] - mx);
+    const float lse = mx + logf(se);
+    int64_t t = target[b];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    acc += lse - r[t];
+    if (dz)
+      for (int k = 0; k < K; ++k) dz[(size_t)b * K + k] = g * (expf(r[k] - lse) - (k == (int)t ? 1.f : 0.f));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) loss[0] = red[0] / (float)B;
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" int pcg_embed_concat_fwd(const float* x, const int64_t* idx, const float* table, const float* mask, float* out,
+                                    int32_t B, int32_t HW, int32_t C, int32_t K, pcg_stream_t stream) {
+  PCG_REQUIRE(x && idx && table && out && B > 0 && HW > 0 && K > 0 && (C == 2 || (C == 3 && mask)), "pcg_embed_concat_fwd: bad arguments");
+  hipLaunchKernelGGL(embed_concat_fwd_kernel, dim3(ew_blocks((size_t)B * HW)), dim3(256), 0, (hipStream_t)stream, x, idx, table, mask,
+                     out, B, HW, C, K);
+  return launch_status("embed_concat_fwd_kernel");
+}
+
+extern "C" int pcg_embed_concat_bwd(const float* dinp, const int64_t* idx, float* dtable, float* dx, int32_t B, int32_t HW,
+                                    int32_t C, int32_t K, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(dinp && idx && (dtable || dx) && B > 0 && HW > 0 && K > 0 && C >= 2, "pcg_embed_concat_bwd: bad arguments");
+  const size_t work = dx ? (size_t)B * HW : (size_t)K * HW;
+  hipLaunchKernelGGL(embed_concat_bwd_kernel, dim3(ew_blocks(work)), dim3(256), 0, (hipStream_t)stream, dinp, idx, dtable, dx, B, HW,
+                     C, K, accumulate);
+  return launch_status("embed_concat_bwd_kernel");
+}
+
+extern "C" int pcg_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, pcg_stream_t stream) {
+  PCG_REQUIRE(out && x && n > 0, "pcg_axpby: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, out, a, x, b, y, (size_t)n);
+  return launch_status("axpby_kernel");
+}
+
+extern "C" int pcg_scale_mask_fwd(const float* c, const float* mask, float scale, float* raw, float* masked, int64_t n,
+                                  pcg_stream_t stream) {
+  PCG_REQUIRE(c && raw && masked && n > 0, "pcg_scale_mask_fwd: bad arguments");
+  hipLaunchKernelGGL(scale_mask_fwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, c, mask, scale, raw, masked,
+                     (size_t)n);
+  return launch_status("scale_mask_fwd_kernel");
+}
+
+extern "C" int pcg_scale_mask_bwd(const float* d_raw, const float* d_masked, const float* mask, float scale, float* dc, int64_t n,
+                                  pcg_stream_t stream) {
+  PCG_REQUIRE((d_raw || d_masked) && dc && n > 0, "pcg_scale_mask_bwd: bad arguments");
+  hipLaunchKernelGGL(scale_mask_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, d_raw, d_masked, mask,
+                     scale, dc, (size_t)n);
+  return launch_status("scale_mask_bwd_kernel");
+}
+
+extern "C" int pcg_clamp_add_fwd(const float* x, const float* r, float lo, float hi, float* y, int64_t n, pcg_stream_t stream) {
+  PCG_REQUIRE(x && r && y && n > 0, "pcg_clamp_add_fwd: bad arguments");
+  hipLaunchKernelGGL(clamp_add_fwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, r, lo, hi, y, (size_t)n);
+  return launch_status("clamp_add_fwd_kernel");
+}
+
+extern "C" int pcg_clamp_add_bwd(const float* dy, const float* x, const float* r, float lo, float hi, float* dr, int64_t n,
+                                 pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && r && dr && n > 0, "pcg_clamp_add_bwd: bad arguments");
+  hipLaunchKernelGGL(clamp_add_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, x, r, lo, hi, dr,
+                     (size_t)n);
+  return launch_status("clamp_add_bwd_kernel");
+}
+
+extern "C" size_t pcg_abs_mean_workspace_bytes(void) { return AM_BLOCKS * sizeof(float); }
+
+extern "C" int pcg_abs_mean_fwd(const float* a, const float* m, int one_minus_m, int64_t n, float* out, void* workspace,
+                                size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(a && out && n > 0, "pcg_abs_mean_fwd: bad arguments");
+  if (!workspace || workspace_bytes < pcg_abs_mean_workspace_bytes()) {
+    set_error("pcg_abs_mean_fwd: workspace too small");
+    return PCG_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(abs_mean_partial_kernel, dim3(AM_BLOCKS), dim3(256), 0, s, a, m, one_minus_m, (size_t)n, partial);
+  if (int e = launch_status("abs_mean_partial_kernel")) return e;
+  hipLaunchKernelGGL(abs_mean_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, AM_BLOCKS, 1.0 / (double)n, out);
+  return launch_status("abs_mean_finish_kernel");
+}
+
+extern "C" int pcg_abs_mean_bwd(const float* a, const float* m, int one_minus_m, int64_t n, const float* grad_out_dev,
+                                float grad_scale, float* da, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(a && da && n > 0, "pcg_abs_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(abs_mean_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, m, one_minus_m, (size_t)n,
+                     grad_out_dev, grad_scale, da, accumulate);
+  return launch_status("abs_mean_bwd_kernel");
+}
+
+extern "C" int pcg_avgpool_fwd(const float* x, float* y, int32_t B, int32_t HW, int32_t C, pcg_stream_t stream) {
+  PCG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "pcg_avgpool_fwd: bad arguments");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_blocks((size_t)B * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, HW, C);
+  return launch_status("avgpool_fwd_kernel");
+}
+
+extern "C" int pcg_avgpool_bwd(const float* dy, float* dx, int32_t B, int32_t HW, int32_t C, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && dx && B > 0 && HW > 0 && C > 0, "pcg_avgpool_bwd: bad arguments");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((size_t)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, HW, C);
+  return launch_status("avgpool_bwd_kernel");
+}
+
+extern "C" int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, int32_t B, int32_t K, float grad_scale,
+                                         const float* grad_out_dev, float* loss, float* dlogits, pcg_stream_t stream) {
+  PCG_REQUIRE(logits && target && B > 0 && K > 0 && (loss || dlogits), "pcg_cross_entropy_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, K, grad_scale, grad_out_dev,
+                     loss, dlogits);
+  return launch_status("cross_entropy_kernel");
+}

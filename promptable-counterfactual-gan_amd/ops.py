@@ -165,21 +165,24 @@ def bn_train_stats(x, C, eps, momentum, running_mean=None, running_var=None, num
     return mean, invstd
 
 
-def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps=-1.0, out=None):
+def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps=-1.0, out=None, residual=None, alpha=1.0):
+    """y = residual + alpha * act(bn(x))  (residual None, alpha 1: plain BatchNorm + activation)."""
     _chk(x, "x")
     y = out if out is not None else torch.empty_like(x)
     check(_lib.load().pcg_bn_apply_act(_p(x), x.numel() // C, C, _p(mean), _p(invstd_or_var), var_eps, _p(gamma), _p(beta),
-                                       act, slope, _p(y), _stream()), "pcg_bn_apply_act")
+                                       act, slope, _p(residual), alpha, _p(y), _stream()), "pcg_bn_apply_act")
     return y
 
 
-def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None):
-    _chk(dy, "dy"); _chk(x, "x"); _chk(y, "y")
+def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None, dy_scale=1.0):
+    _chk(dy, "dy"); _chk(x, "x")
+    if y is not None:
+        _chk(y, "y")
     rows = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
     lib = _lib.load()
     ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
-    check(lib.pcg_bn_act_bwd(_p(dy), _p(x), _p(y), rows, C, _p(mean), _p(invstd), _p(gamma), act, slope, _p(dx), _p(dgamma),
+    check(lib.pcg_bn_act_bwd(_p(dy), _p(x), _p(y), rows, C, _p(mean), _p(invstd), _p(gamma), act, slope, dy_scale, _p(dx), _p(dgamma),
                              _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_act_bwd")
     return dx
 
@@ -244,3 +247,106 @@ def sumsq(t, out, accumulate=False):
     _chk(t, "t")
     check(_lib.load().pcg_sumsq(_p(t), t.numel(), _p(out), int(bool(accumulate)), _stream()), "pcg_sumsq")
     return out
+
+
+# ---- CounteRGAN pieces ---------------------------------------------------------------------------------------
+def _chk_idx(idx, K, name="idx"):
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise _lib.PcgError(f"{name}: expected a contiguous int64 tensor on the GPU")
+    return idx
+
+
+def embed_concat_fwd(x, idx, table, mask):
+    """[B,H,W,C] with channels (x, table[idx], [mask]); x, mask: [B,1,H,W] or [B,H,W]; table: [K, H*W]."""
+    _chk(x, "x"); _chk(table, "table"); _chk_idx(idx, table.shape[0])
+    B, HW = idx.numel(), table.shape[1]
+    C = 3 if mask is not None else 2
+    out = torch.empty((B, HW, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().pcg_embed_concat_fwd(_p(x), _p(idx), _p(table), _p(mask), _p(out), B, HW, C, table.shape[0], _stream()),
+          "pcg_embed_concat_fwd")
+    return out
+
+
+def embed_concat_bwd(dinp, idx, C, K, dtable=None, accumulate=False, need_dx=False):
+    _chk(dinp, "dinp")
+    B = idx.numel()
+    HW = dinp.numel() // (B * C)
+    dx = torch.empty((B, HW), dtype=torch.float32, device=dinp.device) if need_dx else None
+    check(_lib.load().pcg_embed_concat_bwd(_p(dinp), _p(idx), _p(dtable), _p(dx), B, HW, C, K, int(bool(accumulate)), _stream()),
+          "pcg_embed_concat_bwd")
+    return dx
+
+
+def axpby(a, x, b=0.0, y=None, out=None):
+    _chk(x, "x")
+    out = out if out is not None else torch.empty_like(x)
+    check(_lib.load().pcg_axpby(_p(out), float(a), _p(x), float(b), _p(y), x.numel(), _stream()), "pcg_axpby")
+    return out
+
+
+def scale_mask_fwd(c, mask, scale):
+    _chk(c, "c")
+    raw, masked = torch.empty_like(c), torch.empty_like(c)
+    check(_lib.load().pcg_scale_mask_fwd(_p(c), _p(mask), float(scale), _p(raw), _p(masked), c.numel(), _stream()), "pcg_scale_mask_fwd")
+    return raw, masked
+
+
+def scale_mask_bwd(d_raw, d_masked, mask, scale, like):
+    dc = torch.empty_like(like)
+    check(_lib.load().pcg_scale_mask_bwd(_p(d_raw), _p(d_masked), _p(mask), float(scale), _p(dc), like.numel(), _stream()),
+          "pcg_scale_mask_bwd")
+    return dc
+
+
+def clamp_add_fwd(x, r, lo, hi):
+    _chk(x, "x"); _chk(r, "r")
+    y = torch.empty_like(x)
+    check(_lib.load().pcg_clamp_add_fwd(_p(x), _p(r), float(lo), float(hi), _p(y), x.numel(), _stream()), "pcg_clamp_add_fwd")
+    return y
+
+
+def clamp_add_bwd(dy, x, r, lo, hi):
+    _chk(dy, "dy")
+    dr = torch.empty_like(x)
+    check(_lib.load().pcg_clamp_add_bwd(_p(dy), _p(x), _p(r), float(lo), float(hi), _p(dr), x.numel(), _stream()), "pcg_clamp_add_bwd")
+    return dr
+
+
+def abs_mean_fwd(a, m=None, one_minus=False):
+    _chk(a, "a")
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = workspace(lib.pcg_abs_mean_workspace_bytes(), a.device)
+    check(lib.pcg_abs_mean_fwd(_p(a), _p(m), int(bool(one_minus)), a.numel(), _p(out), _p(ws), ws.numel(), _stream()), "pcg_abs_mean_fwd")
+    return out
+
+
+def abs_mean_bwd(a, m, one_minus, grad_out, scale=1.0, out=None, accumulate=False):
+    da = out if out is not None else torch.empty_like(a)
+    check(_lib.load().pcg_abs_mean_bwd(_p(a), _p(m), int(bool(one_minus)), a.numel(), _p(grad_out), float(scale), _p(da),
+                                       int(bool(accumulate)), _stream()), "pcg_abs_mean_bwd")
+    return da
+
+
+def avgpool_fwd(x, B, HW, C):
+    _chk(x, "x")
+    y = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().pcg_avgpool_fwd(_p(x), _p(y), B, HW, C, _stream()), "pcg_avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, B, HW, C):
+    _chk(dy, "dy")
+    dx = torch.empty((B, HW, C), dtype=torch.float32, device=dy.device)
+    check(_lib.load().pcg_avgpool_bwd(_p(dy), _p(dx), B, HW, C, _stream()), "pcg_avgpool_bwd")
+    return dx
+
+
+def cross_entropy_fwd_bwd(logits, target, need_loss=True, need_grad=True, grad_out=None, grad_scale=1.0):
+    _chk(logits, "logits"); _chk_idx(target, logits.shape[-1], "target")
+    B, K = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device) if need_loss else None
+    dz = torch.empty_like(logits) if need_grad else None
+    check(_lib.load().pcg_cross_entropy_fwd_bwd(_p(logits), _p(target), B, K, float(grad_scale), _p(grad_out), _p(loss), _p(dz),
+                                                _stream()), "pcg_cross_entropy_fwd_bwd")
+    return loss, dz
