@@ -177,6 +177,17 @@ int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, int32_
                               const float* grad_out_dev /*nullable*/, float* loss /*nullable*/, float* dlogits /*nullable*/,
                               pcg_stream_t stream);
 
+/* ---- device-side batch synthesis (counter-based Philox-4x32-10; deterministic in (seed, offset)) ---------------
+ * Replaces the per-iteration host draws of the training loops: build_mask (trainer.py:45-72: per sample choose
+ * `num_selected` of the (H/patch)x(W/patch) patches, nearest-upsample to HxW), torch.randint targets (trainer.py:94;
+ * `exclude` != NULL draws uniformly from the classes other than exclude[i]: house_sales trainer.py:248-249) and
+ * torch.randn latent noise (mnist_dcgan.py:156).  Streams differ from torch's generators by design. */
+int pcg_patch_mask(float* out /*[B][H][W]*/, int32_t B, int32_t H, int32_t W, int32_t patch_size, int32_t num_selected,
+                   uint64_t seed, uint64_t offset, pcg_stream_t stream);
+int pcg_randint(int64_t* out, int64_t n, int32_t low, int32_t high /*exclusive*/, const int64_t* exclude /*nullable*/,
+                uint64_t seed, uint64_t offset, pcg_stream_t stream);
+int pcg_randn(float* out, int64_t n, float mean, float std, uint64_t seed, uint64_t offset, pcg_stream_t stream);
+
 /* ---- helpers ---------------------------------------------------------------------------------- */
 int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);
 /* out[0] (+)= sum p[i]^2   (grad_norm diagnostic: mnist/trainer.py:41-42) */

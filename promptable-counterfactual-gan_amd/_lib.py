@@ -70,6 +70,9 @@ PROTOTYPES = {
     "pcg_bce_logits_fwd_bwd": (_i, [_vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),
     "pcg_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _vp]),
     "pcg_adam_step_capturable": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "pcg_patch_mask": (_i, [_vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_uint64, _c.c_uint64, _vp]),
+    "pcg_randint": (_i, [_vp, _i64, _c.c_int32, _c.c_int32, _vp, _c.c_uint64, _c.c_uint64, _vp]),
+    "pcg_randn": (_i, [_vp, _i64, _f, _f, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
     "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
 }

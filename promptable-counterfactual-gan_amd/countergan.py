@@ -496,6 +496,19 @@ def build_mask(x, patch_size, device, num_modifiable_patches=None):
     return F.interpolate(patch_mask, size=(h, w), mode="nearest").repeat(1, c, 1, 1)
 
 
+def build_mask_device(rng, x, patch_size, num_modifiable_patches):
+    """build_mask on the GPU (one kernel instead of a host loop of B randperm calls): same distribution — every sample
+    gets exactly `num_modifiable_patches` distinct patches, uniformly — from the engine's Philox stream `rng`
+    (ops.DeviceRNG) rather than torch's generator."""
+    bs, c, h, w = x.shape
+    if c != 1:
+        raise PcgError("build_mask_device: single-channel images only")
+    total = (h // patch_size) * (w // patch_size)
+    if num_modifiable_patches is None or num_modifiable_patches >= total:
+        raise PcgError("build_mask_device: the Bernoulli-per-patch branch (trainer.py:58-60) is not implemented")
+    return rng.patch_mask(bs, h, w, patch_size, num_modifiable_patches, x.device)
+
+
 def make_optimizers(generator, discriminator, cfg=Config):
     """trainer.py:77-80."""
     opt_g = Adam(generator.parameters(), lr=cfg.g_lr)
@@ -544,8 +557,9 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
             "d_real_logits": d_real_logits, "d_fake_logits": d_fake_logits, "x_cf": x_cf}
 
 
-def train_countergan(generator, discriminator, classifier, train_loader, cfg, device, log_every=100):
-    """trainer.py:76-147 without the plotting / checkpoint tail: same loop, same per-epoch means."""
+def train_countergan(generator, discriminator, classifier, train_loader, cfg, device, log_every=100, device_rng=None):
+    """trainer.py:76-147 without the plotting / checkpoint tail: same loop, same per-epoch means.
+    device_rng: an ops.DeviceRNG — draw targets and masks on the GPU instead of torch's RNG."""
     opt_g, opt_d, bce, ce = make_optimizers(generator, discriminator, cfg)
     history = []
     for epoch in range(cfg.num_epochs_gan):
@@ -554,8 +568,12 @@ def train_countergan(generator, discriminator, classifier, train_loader, cfg, de
         for batch_idx, (x, y) in enumerate(train_loader):
             x, y = x.to(device), y.to(device)
             bs = x.size(0)
-            target_y = torch.randint(0, cfg.num_classes, (bs,), device=device)                 # :94
-            mask = build_mask(x, cfg.patch_size, device, cfg.num_modifiable_patches)           # :95
+            if device_rng is not None:
+                target_y = device_rng.randint(0, cfg.num_classes, bs, x.device)                # :94
+                mask = build_mask_device(device_rng, x, cfg.patch_size, cfg.num_modifiable_patches)   # :95
+            else:
+                target_y = torch.randint(0, cfg.num_classes, (bs,), device=device)             # :94
+                mask = build_mask(x, cfg.patch_size, device, cfg.num_modifiable_patches)       # :95
             out = train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg)
             g_epoch += out["g_loss"].item(); d_epoch += out["d_loss"].item(); cls_epoch += out["g_cls"].item()
             n += 1

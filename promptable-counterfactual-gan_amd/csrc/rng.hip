@@ -1,0 +1,147 @@
+// rng.hip — device-side batch synthesis: the per-iteration random draws of the training loops,
+// generated on the GPU by a counter-based Philox-4x32-10 stream instead of the reference's host loop / ATen calls:
+//   * patch masks            trainer.py:45-72  (per sample: `num_modifiable_patches` of the patch grid, nearest-upsampled)
+//                            — the reference's Python loop of B randperm calls costs 18-125 ms per batch on the host
+//   * target classes         trainer.py:94     torch.randint(0, num_classes, (bs,))
+//   * latent noise           mnist_dcgan.py:156 torch.randn(b_size, z_dim, 1, 1)
+// The streams differ from torch's generators (RNG parity is by supplied tensors — SURVEY.md §7 "RNG parity"); what is
+// tested is the distribution: exact patch counts, uniform marginals, N(0,1) moments, determinism in (seed, offset).
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = U4{hi1 ^ ctr.y ^ k0, lo1, hi0 ^ ctr.w ^ k1, lo0};
+    k0 += W0; k1 += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ U4 draw(uint64_t seed, uint64_t offset, uint64_t idx) {
+  const uint64_t c = offset + idx;
+  return philox4x32_10(U4{(uint32_t)c, (uint32_t)(c >> 32), 0x5eed5eedu, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+// one thread per sample: partial Fisher-Yates over <= 64 patches held as a 64-bit "taken" set, then the sample's
+// H*W mask is written by the whole block (nearest up-sampling: pixel (h,w) belongs to patch (h/ps, w/ps))
+__global__ void __launch_bounds__(256) patch_mask_kernel(float* __restrict__ out, int B, int H, int W, int ps, int nph, int npw,
+                                                         int nsel, uint64_t seed, uint64_t offset) {
+  __shared__ unsigned long long sel[256];
+  const int b0 = blockIdx.x * 256;
+  const int b = b0 + threadIdx.x;
+  const int total = nph * npw;
+  unsigned long long taken = 0ull;
+  if (b < B) {
+    int remaining = total;
+    uint64_t ctr = 0;
+    U4 r = draw(seed, offset, (uint64_t)b * 16);
+    int have = 4;
+    for (int s = 0; s < nsel && s < total; ++s) {
+      if (have == 0) { r = draw(seed, offset, (uint64_t)b * 16 + (++ctr)); have = 4; }
+      const uint32_t v = have == 4 ? r.x : have == 3 ? r.y : have == 2 ? r.z : r.w;
+      --have;
+      int k = (int)(((uint64_t)v * (uint64_t)remaining) >> 32);   // uniform in [0, remaining)
+      // the k-th patch that is not yet taken
+      int pidx = 0;
+      for (; pidx < total; ++pidx) {
+        if (!((taken >> pidx) & 1ull)) { if (k == 0) break; --k; }
+      }
+      taken |= 1ull << pidx;
+      --remaining;
+    }
+  }
+  sel[threadIdx.x] = taken;
+  __syncthreads();
+  const int nb = (B - b0) < 256 ? (B - b0) : 256;
+  const int HW = H * W;
+  for (int i = threadIdx.x; i < nb * HW; i += 256) {
+    const int s = i / HW, p = i - s * HW;
+    const int h = p / W, w = p - h * W;
+    const int ph = h / ps, pw = w / ps;
+    const bool on = ph < nph && pw < npw && ((sel[s] >> (ph * npw + pw)) & 1ull);
+    out[(size_t)(b0 + s) * HW + p] = on ? 1.f : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) randint_kernel(int64_t* __restrict__ out, int64_t n, int32_t lo, int32_t hi,
+                                                      const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset) {
+  const uint32_t span = (uint32_t)(hi - lo);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+    const U4 r = draw(seed, offset, (uint64_t)i);
+    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j >= n) break;
+      if (exclude) {  // uniform over the span minus exclude[j] (house-sales: target != source class, trainer.py:248-249)
+        const uint32_t k = (uint32_t)(((uint64_t)v[e] * (uint64_t)(span - 1)) >> 32);
+        const int64_t ex = exclude[j] - lo;
+        out[j] = lo + (int64_t)(k >= (uint32_t)ex ? k + 1 : k);
+      } else {
+        out[j] = lo + (int64_t)(((uint64_t)v[e] * (uint64_t)span) >> 32);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, float mean, float std, uint64_t seed,
+                                                    uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+    const U4 r = draw(seed, offset, (uint64_t)i);
+    // Box-Muller on two uniform pairs
+    const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+    sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j < n) out[j] = fmaf(v[e], std, mean);
+    }
+  }
+}
+
+unsigned grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" int pcg_patch_mask(float* out, int32_t B, int32_t H, int32_t W, int32_t patch_size, int32_t num_selected,
+                              uint64_t seed, uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && B > 0 && H > 0 && W > 0 && patch_size > 0 && num_selected >= 0, "pcg_patch_mask: bad arguments");
+  const int nph = H / patch_size, npw = W / patch_size;
+  PCG_REQUIRE(nph * npw >= 1 && nph * npw <= 64, "pcg_patch_mask: patch grid %dx%d must have 1..64 patches", nph, npw);
+  hipLaunchKernelGGL(patch_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, B, H, W, patch_size, nph, npw,
+                     num_selected, seed, offset);
+  return launch_status("patch_mask_kernel");
+}
+
+extern "C" int pcg_randint(int64_t* out, int64_t n, int32_t low, int32_t high, const int64_t* exclude, uint64_t seed,
+                           uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && n > 0 && high > low && (!exclude || high - low > 1), "pcg_randint: bad arguments");
+  hipLaunchKernelGGL(randint_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, low, high, exclude, seed,
+                     offset);
+  return launch_status("randint_kernel");
+}
+
+extern "C" int pcg_randn(float* out, int64_t n, float mean, float std, uint64_t seed, uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && n > 0, "pcg_randn: bad arguments");
+  hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, mean, std, seed, offset);
+  return launch_status("randn_kernel");
+}

@@ -350,3 +350,36 @@ def cross_entropy_fwd_bwd(logits, target, need_loss=True, need_grad=True, grad_o
     check(_lib.load().pcg_cross_entropy_fwd_bwd(_p(logits), _p(target), B, K, float(grad_scale), _p(grad_out), _p(loss), _p(dz),
                                                 _stream()), "pcg_cross_entropy_fwd_bwd")
     return loss, dz
+
+
+# ---- device-side batch synthesis ---------------------------------------------------------------------------------
+class DeviceRNG:
+    """Counter-based stream: every draw advances `offset`, so a (seed, call sequence) pair is reproducible."""
+
+    def __init__(self, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def _advance(self, n):
+        off = self.offset
+        self.offset += int(n)
+        return off
+
+    def patch_mask(self, B, H, W, patch_size, num_selected, device):
+        """build_mask (trainer.py:45-72) on the device: [B, 1, H, W] of {0, 1}."""
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=device)
+        check(_lib.load().pcg_patch_mask(_p(out), B, H, W, patch_size, num_selected, self.seed, self._advance(16 * B), _stream()),
+              "pcg_patch_mask")
+        return out
+
+    def randint(self, low, high, n, device, exclude=None):
+        out = torch.empty((n,), dtype=torch.int64, device=device)
+        check(_lib.load().pcg_randint(_p(out), n, low, high, _p(exclude), self.seed, self._advance((n + 3) // 4), _stream()),
+              "pcg_randint")
+        return out
+
+    def randn(self, shape, device, mean=0.0, std=1.0):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        check(_lib.load().pcg_randn(_p(out), n, mean, std, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_randn")
+        return out

@@ -157,3 +157,31 @@ def test_step_vs_oracle_float64(pcg, batch):
         den = max(np.linalg.norm(t64), 1e-30)
         l2, l2r = np.linalg.norm(got - t64) / den, np.linalg.norm(r32 - t64) / den
         assert l2 <= max(1e-4, 3 * l2r), f"G grad {n}: rel-L2 {l2:.2e} (reference fp32 noise {l2r:.2e})"
+
+
+def test_device_batch_synthesis(pcg):
+    """build_mask / randint / randn on the device: exact structure, uniform marginals, determinism."""
+    ops = pcg.ops
+    rng = ops.DeviceRNG(seed=1234)
+    B = 4096
+    m = rng.patch_mask(B, 28, 28, 7, 10, DEV).cpu()
+    assert m.shape == (B, 1, 28, 28) and set(m.unique().tolist()) == {0.0, 1.0}
+    patches = m.view(B, 4, 7, 4, 7)
+    assert torch.equal(patches, patches[:, :, :1, :, :1].expand_as(patches))          # constant inside every 7x7 patch
+    sel = patches[:, :, 0, :, 0].reshape(B, 16)
+    assert torch.equal(sel.sum(1), torch.full((B,), 10.0))                              # exactly 10 of 16 per sample (trainer.py:63-65)
+    freq = sel.mean(0)                                                                   # each patch chosen w.p. 10/16
+    assert float((freq - 10 / 16).abs().max()) < 4 * (10 / 16 * 6 / 16 / B) ** 0.5 + 1e-3, freq
+    assert len({tuple(r.tolist()) for r in sel[:256]}) > 200                            # samples differ from each other
+    rng2 = ops.DeviceRNG(seed=1234)
+    assert torch.equal(rng2.patch_mask(B, 28, 28, 7, 10, DEV).cpu(), m)                 # deterministic in (seed, offset)
+    assert not torch.equal(rng2.patch_mask(B, 28, 28, 7, 10, DEV).cpu(), m)             # the stream advances
+    t = rng.randint(0, 10, 100000, DEV).cpu()
+    assert t.min() == 0 and t.max() == 9
+    assert float((torch.bincount(t, minlength=10).float() / 1e5 - 0.1).abs().max()) < 5e-3
+    src = torch.randint(0, 4, (50000,), device=DEV)
+    t2 = rng.randint(0, 4, 50000, DEV, exclude=src)
+    assert not bool((t2 == src).any()) and t2.min() == 0 and t2.max() == 3              # house_sales trainer.py:248-249
+    z = rng.randn((512, 100, 1, 1), DEV).cpu()
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1.0) < 0.02
+    assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.15
