@@ -83,6 +83,18 @@ size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g);
  * (the reference accumulates .grad over two backward() calls: mnist_dcgan.py:153,161).             */
 int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
                      void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* Convolution + training-mode BatchNorm statistics of its output in one call (MFMA layers only): the per-channel sum /
+ * sum of squares are taken from the accumulator tile in the conv epilogue (no extra pass over y), partial rows are
+ * finalised in a fixed order.  Same outputs as pcg_conv2d_fwd (resp. _dgrad) followed by pcg_bn_train_stats.
+ * workspace: pcg_conv2d_{fwd,dgrad}_bn_workspace_bytes (0 = layer not eligible: use the two separate calls).          */
+size_t pcg_conv2d_fwd_bn_workspace_bytes(const pcg_conv_geom* g);
+size_t pcg_conv2d_dgrad_bn_workspace_bytes(const pcg_conv_geom* g);
+int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                      float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
+                        float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */
 size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C);
 int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate,

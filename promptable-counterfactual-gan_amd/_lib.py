@@ -43,6 +43,10 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_bn_workspace_bytes": (_sz, [_gp]),
+    "pcg_conv2d_dgrad_bn_workspace_bytes": (_sz, [_gp]),
+    "pcg_conv2d_fwd_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_colsum_workspace_bytes": (_sz, [_i64, _c.c_int32]),

@@ -227,15 +227,21 @@ class ResidualGenerator(FlatModule):
             raw, masked, _ = self._run_forward(x, target, mask, keep=False)
         return raw, masked
 
-    def _bn(self, bn, z, act, slope, residual=None, alpha=1.0):
+    def _conv_bn(self, conv, bn, a, act, slope, residual=None, alpha=1.0):
+        """conv -> BatchNorm (training: statistics fused into the conv epilogue) -> act, y = residual + alpha*act(bn(z))."""
+        B, H, W, _ = a.shape
+        g = _geom(conv, B, H, W)
         C = bn.num_features
+        w, bias = ops.ohwi(conv.weight.data), (conv.bias.data if conv.bias is not None else None)
         if bn.training:
-            mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            z, mean, invstd = ops.conv_bn_train(g, a, w, bias, False, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                bn.num_batches_tracked)
             y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, act, slope, residual=residual, alpha=alpha)
-            return y, mean, invstd
+            return g, z, y, mean, invstd
+        z = ops.conv2d_fwd(g, a, w, bias)
         y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, act, slope, var_eps=bn.eps,
                              residual=residual, alpha=alpha)
-        return y, None, None
+        return g, z, y, None, None
 
     def _run_forward(self, x, target, mask, keep=True):
         B = x.shape[0]
@@ -247,10 +253,8 @@ class ResidualGenerator(FlatModule):
         ops.act_fwd(h, ACT_LRELU, slope, out=h)
         blocks = []
         for blk in self.resblocks:
-            g1, z1 = _conv_fwd(blk.conv1, h)
-            a1, m1, s1 = self._bn(blk.bn1, z1, ACT_LRELU, slope)
-            g2, z2 = _conv_fwd(blk.conv2, a1)
-            hn, m2, s2 = self._bn(blk.bn2, z2, ACT_NONE, 0.0, residual=h, alpha=0.1)      # x + 0.1 * out (:20)
+            g1, z1, a1, m1, s1 = self._conv_bn(blk.conv1, blk.bn1, h, ACT_LRELU, slope)
+            g2, z2, hn, m2, s2 = self._conv_bn(blk.conv2, blk.bn2, a1, ACT_NONE, 0.0, residual=h, alpha=0.1)   # x + 0.1*out (:20)
             if keep:
                 blocks.append((g1, h, z1, a1, m1, s1, g2, z2, m2, s2))
             h = hn

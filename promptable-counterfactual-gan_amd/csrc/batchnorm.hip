@@ -262,6 +262,80 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- fast paths: (C/4) is a power of two <= 256, so a thread's channel quad is the same in every grid-stride step:
+// the per-channel coefficients live in registers and the loop body is pure streaming (two 16-byte accesses per tensor in
+// flight per thread).
+__global__ void __launch_bounds__(256) bn_apply_act_fast_kernel(const float4* __restrict__ x, size_t n4, int C,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                float var_eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int act, float slope,
+                                                                const float4* __restrict__ residual, float alpha,
+                                                                float4* __restrict__ y) {
+  const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[c] + var_eps) : invstd[c];
+    sc[e] = (gamma ? gamma[c] : 1.f) * is;
+    sh[e] = (beta ? beta[c] : 0.f) - mean[c] * sc[e];
+  }
+  auto one = [&](float4 q, float4 r) {
+    q.x = fmaf(alpha, act_apply(fmaf(q.x, sc[0], sh[0]), act, slope), r.x);
+    q.y = fmaf(alpha, act_apply(fmaf(q.y, sc[1], sh[1]), act, slope), r.y);
+    q.z = fmaf(alpha, act_apply(fmaf(q.z, sc[2], sh[2]), act, slope), r.z);
+    q.w = fmaf(alpha, act_apply(fmaf(q.w, sc[3], sh[3]), act, slope), r.w);
+    return q;
+  };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  size_t i = gtid;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 q0 = x[i], q1 = x[i + stride];
+    const float4 r0 = residual ? residual[i] : zero, r1 = residual ? residual[i + stride] : zero;
+    y[i] = one(q0, r0);
+    y[i + stride] = one(q1, r1);
+  }
+  if (i < n4) y[i] = one(x[i], residual ? residual[i] : zero);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                                const float4* __restrict__ y, size_t n4, int C,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ coef, int act, float slope,
+                                                                float dy_scale, float4* __restrict__ dx) {
+  const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
+  float mu[4], is[4], k0[4], k1[4], k2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    mu[e] = mean[c]; is[e] = invstd[c]; k0[e] = coef[c]; k1[e] = coef[C + c]; k2[e] = coef[2 * C + c];
+  }
+  const bool has_act = act != PCG_ACT_NONE;
+  auto one = [&](float4 g, float4 xv, float4 yv) {
+    float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dz = dy_scale * gg[e] * (has_act ? act_grad_from_out(yy[e], act, slope) : 1.f);
+      const float xh = (xx[e] - mu[e]) * is[e];
+      gg[e] = k0[e] * (dz - k1[e] - xh * k2[e]);
+    }
+    return make_float4(gg[0], gg[1], gg[2], gg[3]);
+  };
+  const float4 ones = make_float4(1.f, 1.f, 1.f, 1.f);
+  size_t i = gtid;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 g0 = dy[i], g1 = dy[i + stride], x0 = x[i], x1 = x[i + stride];
+    const float4 y0 = has_act ? y[i] : ones, y1 = has_act ? y[i + stride] : ones;
+    dx[i] = one(g0, x0, y0);
+    dx[i + stride] = one(g1, x1, y1);
+  }
+  if (i < n4) dx[i] = one(dy[i], x[i], has_act ? y[i] : ones);
+}
+
+bool fast_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
+
 template <class Fn>
 int launch_colreduce(const Fn& fn, int64_t rows, int C, const ColPlan& cp, float* partial, hipStream_t s) {
   if (cp.vec == 4)
@@ -283,6 +357,17 @@ unsigned ew_blocks(size_t nv) {
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+}  // namespace pcg
+
+namespace pcg {
+// shared with conv_igemm.hip (BatchNorm statistics fused into the conv epilogue): partial[nparts][2][C] -> stats
+int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s) {
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+                     1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+  return launch_status("bn_stats_finalize_kernel");
+}
 }  // namespace pcg
 
 using namespace pcg;
@@ -323,7 +408,14 @@ extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const f
   PCG_REQUIRE(x && y && mean && invstd && rows > 0 && C > 0, "pcg_bn_apply_act: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)rows * C;
-  if (C % 4 == 0 && al16(x) && al16(y) && al16(residual))
+  if (fast_channels(C) && al16(x) && al16(y) && al16(residual)) {
+    unsigned blocks = (unsigned)((n / 4 + 511) / 512);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_apply_act_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n / 4, C, mean,
+                       invstd, var_eps, gamma, beta, act, slope, reinterpret_cast<const float4*>(residual), alpha,
+                       reinterpret_cast<float4*>(y));
+  } else if (C % 4 == 0 && al16(x) && al16(y) && al16(residual))
     hipLaunchKernelGGL(bn_apply_act_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, residual, alpha, y);
   else
     hipLaunchKernelGGL(bn_apply_act_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, residual, alpha, y);
@@ -350,7 +442,14 @@ extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, i
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
-  if (C % 4 == 0 && aligned)
+  if (fast_channels(C) && aligned) {
+    unsigned blocks = (unsigned)((n / 4 + 511) / 512);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
+                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx));
+  } else if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
                        (const float*)coef, act, slope, dy_scale, dx);
   else

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int m = m_block + row;
     return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
-  });
+  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr);
 }
 
 template <class Cfg>
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-  });
+  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr);
 }
 
 template <class Cfg>
@@ -211,14 +211,32 @@ extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
   return (thin_is_cin(g) || thin_is_cout(g)) ? thin_conv_dgrad_workspace_bytes(g) : 0;
 }
 
-extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                              void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+namespace pcg {
+int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s);
+}
+
+static bool mfma_layer(const pcg_conv_geom* g) { return !(thin_is_cin(g) || thin_is_cout(g)); }
+static int fwd_stat_rows(const pcg_conv_geom* g) { return ceil_div(g->B * g->OH * g->OW, 128) * 2; }
+static int dgrad_stat_rows(const pcg_conv_geom* g) {
+  int rows = 0;
+  const int s = g->stride;
+  for (int a = 0; a < s; ++a)
+    for (int b = 0; b < s; ++b) {
+      const int PHh = a < g->IH ? (g->IH - a + s - 1) / s : 0, PHw = b < g->IW ? (g->IW - b + s - 1) / s : 0;
+      rows += ceil_div(g->B * PHh * PHw, 128) * 2;
+    }
+  return rows;
+}
+
+static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                           float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
   if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd(g, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
   PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
   ConvP p = make_params(g);
-  p.x = x; p.w = w; p.bias = bias; p.out = y;
+  p.x = x; p.w = w; p.bias = bias; p.out = y; p.stat_partial = stat_partial;
   p.M = g->B * g->OH * g->OW; p.N = g->Cout;
   p.ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
   hipStream_t s = (hipStream_t)stream;
@@ -226,18 +244,44 @@ extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const floa
   return launch_fwd<Cfg128x64>(p, s);
 }
 
-extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
-                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                              void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t pcg_conv2d_fwd_bn_workspace_bytes(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK || !mfma_layer(g) || g->Cout % 4) return 0;
+  return (size_t)fwd_stat_rows(g) * 2 * g->Cout * sizeof(float);
+}
+extern "C" size_t pcg_conv2d_dgrad_bn_workspace_bytes(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK || !mfma_layer(g) || g->stride > 2 || g->Cin % 4) return 0;
+  return (size_t)dgrad_stat_rows(g) * 2 * g->Cin * sizeof(float);
+}
+
+extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float eps,
+                                 float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  const size_t need = pcg_conv2d_fwd_bn_workspace_bytes(g);
+  PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_bn: only MFMA layers (Cin > 3, Cout > 3, Cout %% 4 == 0); use pcg_conv2d_fwd + pcg_bn_train_stats");
+  PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_fwd_bn: null statistics output");
+  if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_fwd_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
+  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (float*)workspace, nullptr, 0, stream)) return e;
+  return launch_bn_stats_finalize((const float*)workspace, fwd_stat_rows(g), (int64_t)g->B * g->OH * g->OW, g->Cout, eps, momentum,
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
+}
+
+static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
+                             float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
   if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream);
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
   ConvP p = make_params(g);
-  p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx;
+  p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx; p.stat_partial = stat_partial;
   p.N = g->Cin;
   DgradPhases ph{};
-  int nph = 0, maxMp = 0;
+  int nph = 0, maxMp = 0, prow = 0;
   const int s = g->stride;
   for (int a = 0; a < s; ++a)
     for (int b = 0; b < s; ++b) {
@@ -254,12 +298,30 @@ extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const f
       f.dh0 = (a + g->pad - f.kh0) / s; f.dw0 = (b + g->pad - f.kw0) / s;
       f.dPHw = FastDiv((uint32_t)f.PHw); f.dPHh = FastDiv((uint32_t)f.PHh);
       if (f.Mp > maxMp) maxMp = f.Mp;
+      f.prow0 = prow; prow += ceil_div(f.Mp, 128) * 2;
       ++nph;
     }
   PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
   hipStream_t st = (hipStream_t)stream;
   if (p.N > 64) return launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st);
   return launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st);
+}
+
+extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
+                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_dgrad_impl(g, dy, w, bias_x, dx, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, float eps,
+                                   float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  const size_t need = pcg_conv2d_dgrad_bn_workspace_bytes(g);
+  PCG_REQUIRE(need > 0, "pcg_conv2d_dgrad_bn: only MFMA layers with stride <= 2; use pcg_conv2d_dgrad + pcg_bn_train_stats");
+  PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_dgrad_bn: null statistics output");
+  if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_dgrad_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
+  if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (float*)workspace, nullptr, 0, stream)) return e;
+  return launch_bn_stats_finalize((const float*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
 }
 
 extern "C" size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g) {

@@ -43,6 +43,7 @@ struct ConvP {
   const float* bias; // fwd: per-Cout       dgrad: per-Cin (nullable)
   float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
   const float* dy;   // dgrad / wgrad
+  float* stat_partial;  // nullable: fused BatchNorm statistics of the output, [partial row][2][N]
   uint32_t x_bytes, w_bytes, dy_bytes;
   int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int M, N;          // GEMM extents of this launch
@@ -58,6 +59,7 @@ struct PhaseInfo {
   int kh0, kw0;        // first tap of the phase
   int nth, ntw;        // taps per axis
   int dh0, dw0;        // oh = a + dh0 - jh ; ow = c + dw0 - jw
+  int prow0;           // first partial-statistics row of this phase
   FastDiv dPHw, dPHh;
 };
 struct DgradPhases { PhaseInfo p[4]; };

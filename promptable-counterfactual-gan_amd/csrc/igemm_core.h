@@ -207,7 +207,7 @@ constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
-                                                 const float* bias, RowBase row_base) {
+                                                 const float* bias, RowBase row_base, float* stat_row = nullptr) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
   constexpr int RPI = 64 / Q;              // rows per store instruction
@@ -223,17 +223,34 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int cq = lane % Q, r0 = lane / Q;
   const int n = n_block + wn * Cfg::WTN + 4 * cq;
-  if (n >= N) return;  // N % 4 == 0: a quad is entirely inside or outside
+  const bool nok = n < N;  // N % 4 == 0: a quad is entirely inside or outside
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+  if (bias && nok) bv = *reinterpret_cast<const float4*>(bias + n);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
   for (int k = 0; k < Cfg::WTM / RPI; ++k) {
     const int row = r0 + RPI * k;
     float* dst = row_base(wm * Cfg::WTM + row);
-    if (dst) {
+    if (dst && nok) {
       float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+    }
+  }
+  // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one partial row per
+  // (tile row, wave row); a finalize kernel adds the partial rows in a fixed order (bitwise reproducible)
+  if (stat_row) {   // wave-uniform
+#pragma unroll
+    for (int off = Q; off < 64; off <<= 1) {
+      s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+      s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+    }
+    if (r0 == 0 && nok) {
+      float* pr = stat_row + (size_t)wm * 2 * N;       // [wm][2][N] inside this tile row's slot
+      *reinterpret_cast<float4*>(pr + n) = s1;
+      *reinterpret_cast<float4*>(pr + N + n) = s2;
     }
   }
 }

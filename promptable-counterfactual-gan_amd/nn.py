@@ -238,27 +238,26 @@ class SequentialConvNet(FlatModule):
             g, OH, OW = b.geom(B, H, W)
             w = ops.ohwi(c.weight.data)
             bias = c.bias.data if c.bias is not None else None
-            if not b.transposed:
-                z = ops.conv2d_fwd(g, a, w, bias)
-            else:
-                z = ops.conv2d_dgrad(g, a, w, bias)
             C = c.out_channels
             mean = invstd = None
-            if b.bn is not None:
+            if b.bn is not None and b.bn.training:
                 bn = b.bn
-                if bn.training:
-                    mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                                                      bn.num_batches_tracked)
-                    y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
-                else:
-                    y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
-                                         var_eps=bn.eps, out=z)
-                    z = None
+                z, mean, invstd = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
+                                                    bn.running_var, bn.num_batches_tracked)
+                y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
+            elif b.bn is not None:
+                bn = b.bn
+                z = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
+                y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
+                                     var_eps=bn.eps, out=z)
+                z = None
             elif b.act != ACT_NONE:
+                z = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
                 y = ops.act_fwd(z, b.act, b.slope, out=z)  # in place, like nn.ReLU(True) / LeakyReLU(inplace=True)
                 z = None
             else:
-                y, z = z, None
+                y = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
+                z = None
             if keep:
                 saved.append((g, a, z, mean, invstd, y, b.bn is not None and not b.bn.training))
             a, H, W = y, OH, OW

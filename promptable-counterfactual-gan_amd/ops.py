@@ -131,6 +131,30 @@ def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
     return dx
 
 
+def conv_bn_train(g, a, w, bias, transposed, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """Convolution (transposed=False: fwd; True: dgrad = ConvTranspose2d forward) + training-mode BatchNorm statistics of
+    its output.  One fused call on MFMA layers (statistics come out of the conv epilogue), two calls otherwise.
+    Returns (z, save_mean, save_invstd)."""
+    _chk(a, "a"); _chk(w, "w")
+    lib = _lib.load()
+    C = g.Cin if transposed else g.Cout
+    shape = (g.B, g.IH, g.IW, g.Cin) if transposed else (g.B, g.OH, g.OW, g.Cout)
+    need = (lib.pcg_conv2d_dgrad_bn_workspace_bytes if transposed else lib.pcg_conv2d_fwd_bn_workspace_bytes)(ctypes.byref(g))
+    if need == 0:
+        z = conv2d_dgrad(g, a, w, bias) if transposed else conv2d_fwd(g, a, w, bias)
+        mean, invstd = bn_train_stats(z, C, eps, momentum, running_mean, running_var, num_batches_tracked)
+        return z, mean, invstd
+    z = torch.empty(shape, dtype=torch.float32, device=a.device)
+    mean = torch.empty(C, dtype=torch.float32, device=a.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=a.device)
+    ws = workspace(need, a.device)
+    fn = lib.pcg_conv2d_dgrad_bn if transposed else lib.pcg_conv2d_fwd_bn
+    with _Timed(g, "dgrad" if transposed else "fwd"):
+        check(fn(ctypes.byref(g), _p(a), _p(w), _p(bias), _p(z), eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                 _p(running_var), _p(num_batches_tracked), _p(ws), ws.numel(), _stream()), "pcg_conv2d_*_bn")
+    return z, mean, invstd
+
+
 def conv2d_wgrad(g, x, dy, dw, accumulate):
     """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(dw, "dw")
