@@ -148,14 +148,16 @@ int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float 
  * torch.optim.Adam over one flat fp32 parameter buffer: mnist_dcgan.py:126-127,164,175;
  * mnist/trainer.py:77-78,112,123.  [torch] non-amsgrad, eps outside the sqrt of the bias-corrected
  * second moment: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  `step` is the 1-based step count.   */
+/* Hyper-parameters are double, as in Python: 1-beta1, 1-beta2 and the bias corrections are formed in double and
+ * rounded to fp32 once (that is what torch does). */
 int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled_wd,
                   int64_t step, pcg_stream_t stream);
 
 /* hipGraph-capturable form: the step count lives on the device (*step_counter_dev is incremented by the
  * call) and the bias corrections are computed there in fp64; hyper_scratch2_dev is 2 floats of scratch. */
 int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+                             double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled_wd,
                              int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream);
 
 /* ---- CounteRGAN step: non-convolution pieces (conditional_counteRGAN/mnist) -------------------------

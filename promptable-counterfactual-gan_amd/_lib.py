@@ -32,6 +32,7 @@ class ConvGeom(ctypes.Structure):
 
 _c = ctypes
 _vp, _f, _i, _i64, _sz = _c.c_void_p, _c.c_float, _c.c_int, _c.c_int64, _c.c_size_t
+_d = _c.c_double
 _gp = _c.POINTER(ConvGeom)
 
 # name -> (restype, argtypes); every symbol include/pcgan_hip.h declares
@@ -72,8 +73,8 @@ PROTOTYPES = {
     "pcg_act_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "pcg_bce_fwd_bwd": (_i, [_vp, _vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),
     "pcg_bce_logits_fwd_bwd": (_i, [_vp, _f, _i64, _f, _vp, _vp, _vp, _vp]),
-    "pcg_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i64, _vp]),
-    "pcg_adam_step_capturable": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "pcg_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i, _i64, _vp]),
+    "pcg_adam_step_capturable": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp]),
     "pcg_patch_mask": (_i, [_vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_randint": (_i, [_vp, _i64, _c.c_int32, _c.c_int32, _vp, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_randn": (_i, [_vp, _i64, _f, _f, _c.c_uint64, _c.c_uint64, _vp]),

@@ -97,33 +97,35 @@ __global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict
 // hyper[0] = lr / (1 - beta1^step) ; hyper[1] = sqrt(1 - beta2^step)
 struct AdamHyper { float step_size, bc2_sqrt; };
 
-__global__ void adam_tick_kernel(int64_t* step_counter, float lr, float beta1, float beta2, AdamHyper* out) {
+__global__ void adam_tick_kernel(int64_t* step_counter, double lr, double beta1, double beta2, AdamHyper* out) {
   const int64_t t = step_counter[0] + 1;
   step_counter[0] = t;
-  const double bc1 = 1.0 - pow((double)beta1, (double)t);
-  const double bc2 = 1.0 - pow((double)beta2, (double)t);
-  out->step_size = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)t);
+  const double bc2 = 1.0 - pow(beta2, (double)t);
+  out->step_size = (float)(lr / bc1);
   out->bc2_sqrt = (float)sqrt(bc2);
 }
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float beta1, float beta2,
-                                         float eps, float wd, int decoupled, float step_size, float bc2_sqrt) {
-  if (wd != 0.f) {
-    if (decoupled) p *= (1.f - lr * wd);   // AdamW
-    else g = fmaf(wd, p, g);               // Adam L2
+struct AdamConst { float lr, w1, one_minus_w1, beta2, one_minus_beta2, eps, wd; int decoupled; };
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamConst& k, float step_size,
+                                         float bc2_sqrt) {
+  if (k.wd != 0.f) {
+    if (k.decoupled) p *= (1.f - k.lr * k.wd);   // AdamW
+    else g = fmaf(k.wd, p, g);                   // Adam L2
   }
-  // [torch] exp_avg.lerp_(grad, 1-beta1): weight < 0.5 ? a + w(b-a) : b - (b-a)(1-w)
-  const float w1 = 1.f - beta1;
-  m = (w1 < 0.5f) ? fmaf(w1, g - m, m) : g - (g - m) * (1.f - w1);
-  v = fmaf(v, beta2, (1.f - beta2) * g * g);
+  // [torch] exp_avg.lerp_(grad, 1-beta1): weight < 0.5 ? a + w(b-a) : b - (b-a)(1-w); the weights are formed in
+  // double on the host (as Python does) and rounded to fp32 once
+  m = (k.w1 < 0.5f) ? fmaf(k.w1, g - m, m) : g - (g - m) * k.one_minus_w1;
+  v = fmaf(v, k.beta2, k.one_minus_beta2 * g * g);
+  const float eps = k.eps;
   const float denom = sqrtf(v) / bc2_sqrt + eps;
   p = p - step_size * (m / denom);
 }
 
 template <int VEC>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
-                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                                                   float beta1, float beta2, float eps, float wd, int decoupled,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, AdamConst k,
                                                    AdamHyper hy, const AdamHyper* hy_dev) {
   if (hy_dev) hy = *hy_dev;
   const size_t nv = n / VEC;
@@ -133,16 +135,16 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
       const float4 g4 = reinterpret_cast<const float4*>(grad)[i];
       float4 m4 = reinterpret_cast<float4*>(m)[i];
       float4 v4 = reinterpret_cast<float4*>(v)[i];
-      adam_one(p4.x, g4.x, m4.x, v4.x, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
-      adam_one(p4.y, g4.y, m4.y, v4.y, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
-      adam_one(p4.z, g4.z, m4.z, v4.z, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
-      adam_one(p4.w, g4.w, m4.w, v4.w, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.x, g4.x, m4.x, v4.x, k, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.y, g4.y, m4.y, v4.y, k, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.z, g4.z, m4.z, v4.z, k, hy.step_size, hy.bc2_sqrt);
+      adam_one(p4.w, g4.w, m4.w, v4.w, k, hy.step_size, hy.bc2_sqrt);
       reinterpret_cast<float4*>(param)[i] = p4;
       reinterpret_cast<float4*>(m)[i] = m4;
       reinterpret_cast<float4*>(v)[i] = v4;
     } else {
       float p = param[i], mm = m[i], vv = v[i];
-      adam_one(p, grad[i], mm, vv, lr, beta1, beta2, eps, wd, decoupled, hy.step_size, hy.bc2_sqrt);
+      adam_one(p, grad[i], mm, vv, k, hy.step_size, hy.bc2_sqrt);
       param[i] = p; m[i] = mm; v[i] = vv;
     }
   }
@@ -166,15 +168,15 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p,
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s;
 }
 
-int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                float wd, int decoupled, AdamHyper hy, const AdamHyper* hy_dev, hipStream_t s) {
+int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                double wd, int decoupled, AdamHyper hy, const AdamHyper* hy_dev, hipStream_t s) {
   const bool vec = (n % 4 == 0) && al16(param) && al16(grad) && al16(m) && al16(v);
+  const AdamConst k{(float)lr, (float)(1.0 - beta1), (float)(1.0 - (1.0 - beta1)), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                    (float)wd, decoupled};
   if (vec)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)n, lr, beta1,
-                       beta2, eps, wd, decoupled, hy, hy_dev);
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)n, k, hy, hy_dev);
   else
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, param, grad, m, v, (size_t)n, lr, beta1,
-                       beta2, eps, wd, decoupled, hy, hy_dev);
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, param, grad, m, v, (size_t)n, k, hy, hy_dev);
   return launch_status("adam_kernel");
 }
 
@@ -219,19 +221,19 @@ extern "C" int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_
   return launch_status("bce_logits_kernel");
 }
 
-extern "C" int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int64_t step,
+extern "C" int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int decoupled_wd, int64_t step,
                              pcg_stream_t stream) {
   PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "pcg_adam_step: bad arguments");
   AdamHyper hy;
-  hy.step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
-  hy.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hy.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+  hy.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
   return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, nullptr,
                      (hipStream_t)stream);
 }
 
-extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                                        float beta1, float beta2, float eps, float weight_decay, int decoupled_wd,
+extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                                        double beta1, double beta2, double eps, double weight_decay, int decoupled_wd,
                                         int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream) {
   PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_counter_dev && hyper_scratch2_dev,
               "pcg_adam_step_capturable: bad arguments");
