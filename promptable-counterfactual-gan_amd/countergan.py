@@ -513,6 +513,14 @@ def build_mask_device(rng, x, patch_size, num_modifiable_patches):
     return rng.patch_mask(bs, h, w, patch_size, num_modifiable_patches, x.device)
 
 
+def grad_norm(net):
+    """trainer.py:41-42 — sqrt(sum ||p.grad||^2) over a net's parameters (per-epoch diagnostic, :142-143): one launch over
+    the flat gradient buffer (its alignment padding is zero), one host read."""
+    out = torch.empty(1, dtype=torch.float32, device=net.flat_grads.device)
+    ops.sumsq(net.flat_grads, out)
+    return float(out.item()) ** 0.5
+
+
 def make_optimizers(generator, discriminator, cfg=Config):
     """trainer.py:77-80."""
     opt_g = Adam(generator.parameters(), lr=cfg.g_lr)

@@ -11,7 +11,7 @@ namespace {
 
 constexpr int CR_THREADS = 256;
 constexpr int CR_MAX_BLOCKS = 512;
-constexpr int FIN_CH = 16, FIN_SL = 16;  // finalize: 16 channels x 16 partial-slices per 256-thread block
+constexpr int FIN_CH = 8, FIN_SL = 32;   // finalize: 16 channels x 16 partial-slices per 256-thread block
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
 
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
   }
 }
 
-// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+16, ... and the 16
+// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+32, ... and the 32
 // slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/8 dependent loads per thread).
 template <int NVAL>
 __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblocks, int C, int& c_out,
@@ -140,10 +140,23 @@ __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial,
   double acc[NVAL];
 #pragma unroll
   for (int k = 0; k < NVAL; ++k) acc[k] = 0.0;
-  if (c < C)
-    for (int b = sl; b < nblocks; b += FIN_SL)
+  if (c < C) {
+    int b = sl;
+    for (; b + 7 * FIN_SL < nblocks; b += 8 * FIN_SL) {   // 8 independent loads in flight, added in block order
+      float v[8][NVAL];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k) v[j][k] = partial[((size_t)(b + j * FIN_SL) * NVAL + k) * C + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k) acc[k] += (double)v[j][k];
+    }
+    for (; b < nblocks; b += FIN_SL)
 #pragma unroll
       for (int k = 0; k < NVAL; ++k) acc[k] += (double)partial[((size_t)b * NVAL + k) * C + c];
+  }
 #pragma unroll
   for (int k = 0; k < NVAL; ++k) red[k][sl][cl] = acc[k];
   __syncthreads();

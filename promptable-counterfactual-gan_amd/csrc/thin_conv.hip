@@ -408,6 +408,8 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
   PCG_THIN_WGRAD_CASE(3, 3, 2)
   PCG_THIN_WGRAD_CASE(3, 3, 3)
   PCG_THIN_WGRAD_CASE(1, 1, 1)
+  PCG_THIN_WGRAD_CASE(1, 1, 2)
+  PCG_THIN_WGRAD_CASE(1, 1, 3)
   {
     set_error("thin conv wgrad: kernel %dx%d with %d thin channels has no instantiation", g->KH, g->KW, p.Cs);
     return PCG_ERR_UNSUPPORTED;

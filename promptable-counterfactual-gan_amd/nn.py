@@ -118,10 +118,34 @@ class FlatModule(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
+class _LinearAsConv:
+    """nn.Linear seen as a 1x1 convolution on a [B, 1, 1, F] activation: its [out, in] weight is already OHWI."""
+
+    def __init__(self, lin):
+        self.lin = lin
+        self.in_channels, self.out_channels = lin.in_features, lin.out_features
+        self.kernel_size, self.stride, self.padding, self.dilation, self.groups = (1, 1), (1, 1), (0, 0), (1, 1), 1
+
+    @property
+    def weight(self):
+        return self.lin.weight
+
+    @property
+    def bias(self):
+        return self.lin.bias
+
+
+def _w_ohwi(t):
+    """Physical OHWI view of a conv weight (4-D, channels_last) or a Linear weight (2-D [out, in] = [out][1][1][in])."""
+    return t if t.dim() == 2 else ops.ohwi(t)
+
+
 class _Block:
-    """conv (or transposed conv) -> [BatchNorm2d] -> [activation]"""
+    """conv (or transposed conv, or Linear) -> [BatchNorm2d] -> [activation]"""
 
     def __init__(self, conv):
+        if isinstance(conv, nn.Linear):
+            conv = _LinearAsConv(conv)
         self.conv = conv
         self.transposed = isinstance(conv, nn.ConvTranspose2d)
         self.bn = None
@@ -152,7 +176,7 @@ class _Block:
 def _compile(seq):
     blocks = []
     for m in seq:
-        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
             blocks.append(_Block(m))
             continue
         if not blocks:
@@ -214,8 +238,11 @@ class SequentialConvNet(FlatModule):
         self._ensure_flat()
         if self._blocks is None:
             self._blocks = _compile(self.main)
+        flat_in = input.dim() == 2            # MLP: [B, F] is a [B, 1, 1, F] activation
+        if flat_in:
+            input = input.view(input.shape[0], input.shape[1], 1, 1)
         if input.dim() != 4:
-            raise PcgError(f"expected a [B, C, H, W] input, got shape {tuple(input.shape)}")
+            raise PcgError(f"expected a [B, C, H, W] or [B, F] input, got shape {tuple(input.shape)}")
         x = input.permute(0, 2, 3, 1)
         if not x.is_contiguous():
             x = x.contiguous()
@@ -225,7 +252,8 @@ class SequentialConvNet(FlatModule):
             y = _SeqFn.apply(self, x, *self.parameters())
         else:
             y, _ = self._run_forward(x, keep=False)
-        return y.permute(0, 3, 1, 2)
+        y = y.permute(0, 3, 1, 2)
+        return y.reshape(y.shape[0], y.shape[1]) if flat_in else y
 
     def _run_forward(self, x, keep=True):
         B, H, W, C = x.shape
@@ -236,7 +264,7 @@ class SequentialConvNet(FlatModule):
             if C != c.in_channels:
                 raise PcgError(f"channel mismatch: activation has {C}, layer expects {c.in_channels}")
             g, OH, OW = b.geom(B, H, W)
-            w = ops.ohwi(c.weight.data)
+            w = _w_ohwi(c.weight.data)
             bias = c.bias.data if c.bias is not None else None
             C = c.out_channels
             mean = invstd = None
@@ -293,7 +321,7 @@ class SequentialConvNet(FlatModule):
             own = True
             if need_p and c.weight.requires_grad:
                 gw, acc = self._grad_view(c.weight)
-                gw = ops.ohwi(gw)
+                gw = _w_ohwi(gw)
                 if not b.transposed:
                     ops.conv2d_wgrad(g, a, dz, gw, acc)
                 else:
@@ -305,10 +333,31 @@ class SequentialConvNet(FlatModule):
             if last and not need_x:
                 return None
             if not b.transposed:
-                d = ops.conv2d_dgrad(g, dz, ops.ohwi(c.weight.data))
+                d = ops.conv2d_dgrad(g, dz, _w_ohwi(c.weight.data))
             else:
-                d = ops.conv2d_fwd(g, dz, ops.ohwi(c.weight.data))
+                d = ops.conv2d_fwd(g, dz, _w_ohwi(c.weight.data))
         return d
+
+
+class HipSequential(SequentialConvNet):
+    """Drop-in for a bare `nn.Sequential(...)` (state_dict keys "0.weight", "2.bias", ... with no prefix), e.g. the MLPs
+    of simple_gan/moons/make_moons_gan.py:33-46."""
+
+    def __init__(self, *layers):
+        FlatModule.__init__(self)
+        for i, layer in enumerate(layers):
+            self.add_module(str(i), layer)
+        self._blocks = None
+
+    @property
+    def main(self):
+        return list(self.children())
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, i):
+        return list(self.children())[i]
 
 
 class BCELoss(nn.Module):

@@ -182,8 +182,46 @@ def make_countergan(path, batch=4, seed=0):
     print(buf.getvalue().strip().splitlines()[0])
 
 
+def make_moons(path, n=100, seed=5):
+    """simple_gan/moons/make_moons_gan.py: build_generator / build_discriminator / train_gan lifted from the syntax tree
+    (the module trains and plots at import).  One epoch over `n` seeded 2-D points (2 batches of 50); train_gan draws its
+    noise from the global torch RNG (:64,:79) and shuffles with numpy (:57): both are seeded and the draws replayed."""
+    path_src = os.path.join(REF, "simple_gan/moons/make_moons_gan.py")
+    with open(path_src) as f:
+        tree = ast.parse(f.read(), filename=path_src)
+    defs = [n_ for n_ in tree.body if isinstance(n_, ast.FunctionDef) and n_.name in ("build_generator", "build_discriminator", "train_gan")]
+    assert len(defs) == 3
+    ns = {"torch": torch, "nn": torch.nn, "np": np, "device": torch.device("cpu")}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path_src, "exec"), ns)
+    cfg = {"z_dim": 32, "hidden_dim": 128, "batch_size": 50, "lr": 1e-3, "epochs": 1}
+    torch.manual_seed(seed)
+    G = ns["build_generator"](cfg["z_dim"], cfg["hidden_dim"])
+    D = ns["build_discriminator"](cfg["hidden_dim"])
+    out = {}
+    for tag, net in (("G", G), ("D", D)):
+        for k, v in net.state_dict().items():
+            out[f"init.{tag}.{k}"] = v.numpy().copy()
+    rs = np.random.RandomState(seed)
+    X = rs.standard_normal((n, 2)).astype(np.float64)
+    np.random.seed(seed + 1)
+    Xs = X.copy(); np.random.shuffle(Xs)             # replay of :57
+    torch.manual_seed(seed + 2)
+    zs = [torch.randn(cfg["batch_size"], cfg["z_dim"]) for _ in range(2 * (n // cfg["batch_size"]))]   # replay of :64,:79
+    np.random.seed(seed + 1); torch.manual_seed(seed + 2)
+    lossD, lossG = ns["train_gan"](X, G, D, cfg)
+    out["X_shuffled"] = Xs.astype(np.float32)
+    out["z"] = torch.stack(zs).numpy()
+    out["loss_D_total"], out["loss_G_total"] = np.float64(lossD[0]), np.float64(lossG[0])
+    for tag, net in (("G", G), ("D", D)):
+        for k, v in net.state_dict().items():
+            out[f"final.{tag}.{k}"] = v.numpy().copy()
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.3f} MB; loss_D {lossD[0]:.5f} loss_G {lossG[0]:.5f}")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
     make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))
     make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))
+    make_moons(os.path.join(HERE, "moons_ref.npz"))

@@ -185,3 +185,14 @@ def test_device_batch_synthesis(pcg):
     z = rng.randn((512, 100, 1, 1), DEV).cpu()
     assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1.0) < 0.02
     assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.15
+
+
+def test_grad_norm_diagnostic(pcg):
+    """trainer.py:41-42,142-143: sqrt(sum ||p.grad||^2), from the flat gradient buffer."""
+    K = pcg.countergan
+    (G, D, C), _ = _build(pcg, seed=1)
+    x, y, t, m = (a.to(DEV) for a in CR.synthetic_batch(8, seed=2))
+    opt_g, opt_d, bce, ce = K.make_optimizers(G, D)
+    K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
+    ref = float(torch.sqrt(sum((p.grad.norm() ** 2) for p in G.parameters())).item())
+    np.testing.assert_allclose(K.grad_norm(G), ref, rtol=1e-5)

@@ -126,3 +126,25 @@ def test_countergan_step_matches_reference_train_loop(cgold):
             np.testing.assert_allclose(_digest(p.grad), cgold[f"grad.{tag}.{n}"], rtol=2e-4, atol=1e-7, err_msg=f"grad {tag}.{n}")
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(_digest(v.float()), cgold[f"final.{tag}.{k}"], rtol=1e-4, atol=5e-6, err_msg=f"final {tag}.{k}")
+
+
+# ---- simple_gan/moons (BASELINE config 1): oracle/moons_ref.py against the reference's own train_gan -----------------
+from oracle import moons_ref as MR  # noqa: E402
+
+
+def test_moons_epoch_matches_reference_train_gan(golden_dir):
+    gold = dict(np.load(os.path.join(golden_dir, "moons_ref.npz")))
+    G, D = MR.build_generator(32, 128), MR.build_discriminator(128)
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in gold.items() if k.startswith("init.G.")})
+    D.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in gold.items() if k.startswith("init.D.")})
+    optG, optD = MR.make_optimizers(G, D)
+    X, z = torch.from_numpy(gold["X_shuffled"]), torch.from_numpy(gold["z"])
+    totD = totG = 0.0
+    for i, real in enumerate(X.split(50)):
+        lD, lG = MR.moons_step(G, D, optG, optD, real, z[2 * i], z[2 * i + 1])
+        totD += lD; totG += lG
+    np.testing.assert_allclose(totD, float(gold["loss_D_total"]), rtol=1e-6)
+    np.testing.assert_allclose(totG, float(gold["loss_G_total"]), rtol=1e-6)
+    for tag, net in (("G", G), ("D", D)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), gold[f"final.{tag}.{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}.{k}")
