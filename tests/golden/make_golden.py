@@ -219,9 +219,41 @@ def make_moons(path, n=100, seed=5):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.3f} MB; loss_D {lossD[0]:.5f} loss_G {lossG[0]:.5f}")
 
 
+def make_countergan_trained(path_npz, path_pt, batch=8):
+    """Real-weight anchor: the generator checkpoint the reference ships (conditional_counteRGAN/mnist/results/generator.pt,
+    8,440 training steps — SURVEY.md §6) loaded into the reference's own ResidualGenerator, eval mode (BatchNorm running
+    statistics), forward on seeded inputs.  The checkpoint is data: it is copied next to the vectors as a fixture."""
+    import shutil
+    mdir = os.path.join(REF, "conditional_counteRGAN/mnist")
+    sys.path.insert(0, mdir)
+    import importlib
+    gen_mod = importlib.import_module("models.generator")
+    src = os.path.join(mdir, "results/generator.pt")
+    sd = torch.load(src, map_location="cpu", weights_only=True)
+    G = gen_mod.ResidualGenerator()
+    G.load_state_dict(sd)
+    G.eval()
+    g = torch.Generator().manual_seed(2024)
+    x = torch.rand(batch, 1, 28, 28, generator=g) * 2 - 1
+    t = torch.randint(0, 10, (batch,), generator=g)
+    pm = torch.zeros(batch, 16)
+    for b in range(batch):
+        pm[b, torch.randperm(16, generator=g)[:10]] = 1.0
+    mask = torch.nn.functional.interpolate(pm.view(batch, 1, 4, 4), size=(28, 28), mode="nearest")
+    with torch.no_grad():
+        raw, masked = G(x, t, mask)
+        x_cf = torch.clamp(x + masked, -1.0, 1.0)
+    np.savez_compressed(path_npz, x=x.numpy(), target=t.numpy(), mask=mask.numpy(), raw=raw.numpy(), masked=masked.numpy(),
+                        x_cf=x_cf.numpy())
+    shutil.copyfile(src, path_pt)
+    os.chmod(path_pt, 0o644)
+    print(f"wrote {path_npz} and {path_pt} ({os.path.getsize(path_pt) / 1e6:.2f} MB); |raw| max {raw.abs().max().item():.4f}")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
     make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))
     make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))
     make_moons(os.path.join(HERE, "moons_ref.npz"))
+    make_countergan_trained(os.path.join(HERE, "countergan_trained_eval.npz"), os.path.join(HERE, "countergan_generator_trained.pt"))

@@ -196,3 +196,22 @@ def test_grad_norm_diagnostic(pcg):
     K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
     ref = float(torch.sqrt(sum((p.grad.norm() ** 2) for p in G.parameters())).item())
     np.testing.assert_allclose(K.grad_norm(G), ref, rtol=1e-5)
+
+
+def test_trained_checkpoint_eval_forward(pcg, golden_dir):
+    """The generator checkpoint the reference ships (results/generator.pt) loads into the drop-in class unchanged and, in
+    eval mode (BatchNorm running statistics, the inference path of eval_utils.py / the Gradio app), reproduces the
+    reference module's counterfactual residuals."""
+    K = pcg.countergan
+    gold = dict(np.load(os.path.join(golden_dir, "countergan_trained_eval.npz")))
+    G = K.ResidualGenerator()
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "countergan_generator_trained.pt"), map_location="cpu", weights_only=True))
+    G.to(DEV).eval()
+    x, t, m = (torch.from_numpy(gold[k]).to(DEV) for k in ("x", "target", "mask"))
+    with torch.no_grad():
+        raw, masked = G(x, t, m)
+        x_cf = K.clamp_add(x, masked, -1.0, 1.0)
+    scale = float(np.abs(gold["raw"]).max())
+    np.testing.assert_allclose(raw.cpu().numpy(), gold["raw"], rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(masked.cpu().numpy(), gold["masked"], rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(x_cf.cpu().numpy(), gold["x_cf"], rtol=1e-4, atol=2e-5 * scale)

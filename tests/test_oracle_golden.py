@@ -148,3 +148,15 @@ def test_moons_epoch_matches_reference_train_gan(golden_dir):
     for tag, net in (("G", G), ("D", D)):
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(v.numpy(), gold[f"final.{tag}.{k}"], rtol=1e-5, atol=1e-6, err_msg=f"{tag}.{k}")
+
+
+def test_countergan_trained_checkpoint_eval_forward(golden_dir):
+    """Real-weight anchor: the reference's shipped generator.pt in eval mode (BatchNorm running statistics)."""
+    gold = dict(np.load(os.path.join(golden_dir, "countergan_trained_eval.npz")))
+    G = CR.ResidualGenerator()
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "countergan_generator_trained.pt"), map_location="cpu", weights_only=True))
+    G.eval()
+    with torch.no_grad():
+        raw, masked = G(torch.from_numpy(gold["x"]), torch.from_numpy(gold["target"]), torch.from_numpy(gold["mask"]))
+    np.testing.assert_allclose(raw.numpy(), gold["raw"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(masked.numpy(), gold["masked"], rtol=1e-5, atol=1e-6)
