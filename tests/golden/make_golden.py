@@ -250,6 +250,86 @@ def make_countergan_trained(path_npz, path_pt, batch=8):
     print(f"wrote {path_npz} and {path_pt} ({os.path.getsize(path_pt) / 1e6:.2f} MB); |raw| max {raw.abs().max().item():.4f}")
 
 
+def make_house(path, bs=64):
+    """conditional_counteRGAN/house_sales_kc_usa: ONE batch through the reference's own train_countergan (trainer.py:186-378,
+    epochs=1, a dataset of exactly one batch).  The loop draws everything from the global torch RNG after
+    torch.manual_seed(config['seed']); a forward pre-hook on the generator captures what it was called with (the shuffled
+    batch, the target one-hots, the feature mask) and the RNG state, from which the Gumbel noise of F.gumbel_softmax
+    (generator.py:90) is replayed; the discriminator, which train_countergan creates internally right after seeding, is
+    re-created the same way to record its initial state."""
+    import contextlib, importlib, io
+    mdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    scratch = "/tmp/pcg_golden_house"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)                      # config.py creates results/ in the cwd at import (config.py:4-11)
+    try:
+        sys.path.insert(0, mdir)
+        for name in list(sys.modules):
+            if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+                sys.modules.pop(name)
+        cfg = importlib.import_module("config").config
+        gen_mod = importlib.import_module("models.generator")
+        dis_mod = importlib.import_module("models.discriminator")
+        clf_mod = importlib.import_module("models.nn_classifier")
+        trainer = importlib.import_module("trainer")
+        cfg.update({"cuda": "cpu", "epochs": 1, "batch_size": bs, "scaler": None, "out_dir": scratch,
+                    "generator_path": os.path.join(scratch, "gen.pt")})
+        torch.manual_seed(0)
+        clf = clf_mod.NNClassifier(cfg["input_dim"], output_dim=cfg["num_classes"])
+        G = gen_mod.ResidualGenerator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"], continuous_idx=cfg["continuous_idx"],
+                                      categorical_info={k: {"n": v["n"], "raw_values": v["raw_values"]} for k, v in cfg["categorical_info"].items()},
+                                      tau=cfg["gumbel_tau"])
+        clf.eval()
+        for p_ in clf.parameters():
+            p_.requires_grad = False
+        out = {"meta.bs": np.int64(bs)}
+        for k, v in G.state_dict().items():
+            out[f"init.G.{k}"] = v.numpy().copy()
+        for k, v in clf.state_dict().items():
+            out[f"init.C.{k}"] = tensor_digest(v.float())
+        rs = np.random.RandomState(11)
+        X = rs.random_sample((bs, cfg["input_dim"])).astype(np.float32)
+        y = np.arange(bs) % cfg["num_classes"]
+        rs.shuffle(y)
+        cap = {}
+
+        def pre_hook(mod, args, kwargs):
+            cap["x"], cap["target_onehot"] = args[0].clone(), args[1].clone()
+            cap["mask"], cap["temperature"], cap["hard"] = kwargs["mask"].clone(), kwargs["temperature"], kwargs["hard"]
+            cap["rng"] = torch.get_rng_state()
+        h = G.register_forward_pre_hook(pre_hook, with_kwargs=True)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            trainer.train_countergan(G, cfg, X, y, clf)
+        h.remove()
+        assert cap["hard"] is False and abs(cap["temperature"] - 0.5) < 1e-12
+        # replay: discriminator init (train_countergan: torch.manual_seed(42) then Discriminator(...), :188,:227)
+        torch.manual_seed(cfg["seed"])
+        D0 = dis_mod.Discriminator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"])
+        for k, v in D0.state_dict().items():
+            out[f"init.D.{k}"] = v.numpy().copy()
+        # replay: Gumbel noise, in the order of the heads (generator.py:86-90)
+        torch.set_rng_state(cap["rng"])
+        for idx_str, head in G.fc_cat_logits.items():
+            out[f"gumbel.{idx_str}"] = (-torch.empty(bs, head.out_features).exponential_().log()).numpy()
+        # the DataLoader shuffled the rows: recover the permutation by matching rows
+        xb = cap["x"].numpy()
+        perm = np.array([int(np.argmin(np.abs(X - r).sum(1))) for r in xb])
+        assert np.array_equal(X[perm], xb)
+        out.update({"in.x": xb, "in.y": y[perm].astype(np.int64), "in.target_y": cap["target_onehot"].argmax(1).numpy(),
+                    "in.mask": cap["mask"].numpy(), "log": np.array(buf.getvalue())})
+        for k, v in G.state_dict().items():
+            out[f"final.G.{k}"] = v.numpy().copy()
+        for n_, p_ in G.named_parameters():
+            out[f"grad.G.{n_}"] = p_.grad.numpy().copy()
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+        print(buf.getvalue().strip().splitlines()[0])
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -257,3 +337,4 @@ if __name__ == "__main__":
     make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))
     make_moons(os.path.join(HERE, "moons_ref.npz"))
     make_countergan_trained(os.path.join(HERE, "countergan_trained_eval.npz"), os.path.join(HERE, "countergan_generator_trained.pt"))
+    make_house(os.path.join(HERE, "house_ref_b64.npz"))

@@ -160,3 +160,51 @@ def test_countergan_trained_checkpoint_eval_forward(golden_dir):
         raw, masked = G(torch.from_numpy(gold["x"]), torch.from_numpy(gold["target"]), torch.from_numpy(gold["mask"]))
     np.testing.assert_allclose(raw.numpy(), gold["raw"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(masked.numpy(), gold["masked"], rtol=1e-5, atol=1e-6)
+
+
+# ---- house_sales_kc_usa (tabular CounteRGAN): oracle/house_ref.py against ONE batch of the reference's own train_countergan
+from oracle import house_ref as HR  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hgold(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "house_ref_b64.npz")))
+
+
+def _house_setup(hgold, dtype=torch.float32):
+    G, D, clf = HR.build(seed=0)                      # same construction order as make_golden.py: clf, G (seed 0)
+    for k, v in clf.state_dict().items():
+        np.testing.assert_array_equal(_digest(v.float()), hgold[f"init.C.{k}"], err_msg=f"C.{k}")
+    assert [f"init.G.{k}" for k in G.state_dict()] == [k for k in hgold if k.startswith("init.G.")]
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.G.")})
+    assert [f"init.D.{k}" for k in D.state_dict()] == [k for k in hgold if k.startswith("init.D.")]   # weight_orig / _u / _v keys
+    D.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.D.")})
+    x, y, t, m = (torch.from_numpy(hgold[f"in.{n}"]) for n in ("x", "y", "target_y", "mask"))
+    gumbel = {int(k[7:]): torch.from_numpy(v) for k, v in hgold.items() if k.startswith("gumbel.")}
+    return G, D, clf, x, y, t, m, gumbel
+
+
+def test_house_step_matches_reference_train_loop(hgold):
+    import re
+    G, D, clf, x, y, t, m, gumbel = _house_setup(hgold)
+    assert bool((t != y).all()) and float(m[:, HR.CONFIG["immutable_idx"]].abs().sum()) == 0.0   # trainer.py:248-255
+    opt_G, opt_D = HR.make_optimizers(G, D)
+    out = HR.house_step(G, D, clf, opt_G, opt_D, x, y, t, m, gumbel, HR.cat_norm_maps())
+    log = str(hgold["log"])
+
+    def logged(pat):
+        return float(re.search(pat, log).group(1))
+    assert abs(out["d_real_p"] - logged(r"D\(real\)=([0-9.]+)")) <= 6e-4 and abs(out["d_fake_p"] - logged(r"D\(fake\)=([0-9.]+)")) <= 6e-4
+    assert abs(out["g_adv"] - logged(r"g_adv=(-?[0-9.]+)")) <= 7e-5 and abs(out["g_cls"] - logged(r"g_cls=([0-9.]+)")) <= 7e-5
+    assert abs(out["reg"] - logged(r"reg=([0-9.]+)")) <= 2e-6 and abs(out["mask_pen"] - logged(r"mask_pen=([0-9.]+)")) <= 7e-6
+    assert abs(out["D_loss"] - logged(r"\] D: (-?[0-9.]+)")) <= 7e-5 and abs(out["G_loss"] - logged(r", G: (-?[0-9.]+)")) <= 7e-5
+    for n, p in G.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), hgold[f"grad.G.{n}"], rtol=2e-4, atol=2e-6, err_msg=f"grad {n}")
+    for k, v in G.state_dict().items():
+        gk = f"grad.G.{k}"
+        if gk in hgold and np.abs(hgold[gk]).max() < 1e-6:
+            # a Linear bias in front of BatchNorm1d has an exactly-zero gradient; the stored one is fp32 noise and Adam
+            # turns its sign into a +-lr step: only bound the move
+            assert np.abs(v.numpy() - hgold[f"final.G.{k}"]).max() <= 2.2 * HR.CONFIG["lr_G"], k
+            continue
+        np.testing.assert_allclose(v.numpy(), hgold[f"final.G.{k}"], rtol=1e-4, atol=2e-5, err_msg=f"final {k}")
