@@ -201,11 +201,67 @@ int pcg_patch_mask(float* out /*[B][H][W]*/, int32_t B, int32_t H, int32_t W, in
 int pcg_randint(int64_t* out, int64_t n, int32_t low, int32_t high /*exclusive*/, const int64_t* exclude /*nullable*/,
                 uint64_t seed, uint64_t offset, pcg_stream_t stream);
 int pcg_randn(float* out, int64_t n, float mean, float std, uint64_t seed, uint64_t offset, pcg_stream_t stream);
+/* Gumbel(0,1) noise  -log(-log(u))  — the draw inside F.gumbel_softmax (models/generator.py:90 of house_sales_kc_usa) */
+int pcg_rand_gumbel(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream);
+/* Bernoulli(1/2) feature mask [B][D] with the listed columns forced to 0 — house_sales_kc_usa/trainer.py:253-255 */
+int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t* zero_cols /*device, nullable*/, int32_t n_zero_cols,
+                     uint64_t seed, uint64_t offset, pcg_stream_t stream);
 
 /* ---- helpers ---------------------------------------------------------------------------------- */
 int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);
 /* out[0] (+)= sum p[i]^2   (grad_norm diagnostic: mnist/trainer.py:41-42) */
 int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream);
+
+/* ---- tabular CounteRGAN (conditional_counteRGAN/house_sales_kc_usa), SURVEY.md section 8a row a15 -------------------
+ * All operands are dense row-major fp32 [rows][features]; the layer widths (38, 32, 21, 17, 10, 9, 30, 6, 2, 5, 13, 1)
+ * are too small and too ragged for the MFMA tiles, so these are bounds-checked VALU kernels.
+ *
+ * pcg_gemm: C[M][N] (+)= opA[M][K] . opB[K][N] (+ bias[N]); opA = A or A^T, opB = B or B^T (ld* = row stride of the
+ * stored matrix).  nn.Linear forward  y = x W^T + b  -> (0,1, B,out,in, x, W, y, bias)
+ *                  input gradient     dx = dy W       -> (0,0, B,in,out, dy, W, dx)
+ *                  weight gradient    dW += dy^T x    -> (1,0, out,in,B, dy, x, dW, accumulate=1)
+ * replaces the nn.Linear calls of models/generator.py:11-12,22-25,47,54-60, models/discriminator.py:9-15 and
+ * models/nn_classifier.py:8-27. */
+int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+             float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream);
+/* F.one_hot(idx, K).float() — trainer.py:250,290 */
+int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream);
+/* torch.cat([a, b], dim=1) and its backward — generator.py:73-74, discriminator.py:19 */
+int pcg_concat_cols(const float* a, int32_t ca, const float* b, int32_t cb, int32_t rows, float* out, pcg_stream_t stream);
+int pcg_split_cols(const float* d, int32_t ca, int32_t cb, int32_t rows, float* da /*nullable*/, float* db /*nullable*/,
+                   pcg_stream_t stream);
+/* FiLM modulation y = gamma*h + beta — generator.py:13-16; backward gives dgamma = dy*h, dh = dy*gamma (dbeta = dy) */
+int pcg_film_fwd(const float* gamma, const float* h, const float* beta, float* y, int64_t n, pcg_stream_t stream);
+int pcg_film_bwd(const float* dy, const float* gamma, const float* h, float* dgamma, float* dh, int64_t n, pcg_stream_t stream);
+/* F.gumbel_softmax(logits, tau, hard=False) over S heads packed side by side in T columns (seg_offsets[S+1], device
+ * int32), with the Gumbel(0,1) noise supplied — generator.py:86-90.  y = softmax((logits + noise)/tau) per head;
+ * y_hard (nullable) = one-hot of the per-head argmax of y: the forward value of hard=True (eval_utils.py:77), whose
+ * straight-through backward is the soft one below. */
+int pcg_gumbel_softmax_fwd(const float* logits, const float* noise, const int32_t* seg_offsets, int32_t S, int32_t T, int32_t B,
+                           float tau, float* y, float* y_hard /*nullable*/, pcg_stream_t stream);
+int pcg_gumbel_softmax_bwd(const float* dy, const float* y, const int32_t* seg_offsets, int32_t S, int32_t T, int32_t B, float tau,
+                           float* dlogits, pcg_stream_t stream);
+/* residual_full — trainer.py:266-279: column cont_idx[i] = cont[:, i]; categorical column cat_idx[s] =
+ * samples[:, head s] . norm_vals[head s] - x[:, cat_idx[s]].  ncont + S must equal D. */
+int pcg_assemble_residual_fwd(const float* cont, int32_t ncont, const int32_t* cont_idx, const float* samples,
+                              const int32_t* seg_offsets, int32_t S, int32_t T, const int32_t* cat_idx, const float* norm_vals,
+                              const float* x, int32_t D, int32_t B, float* residual, pcg_stream_t stream);
+int pcg_assemble_residual_bwd(const float* dres, int32_t ncont, const int32_t* cont_idx, const int32_t* seg_offsets, int32_t S,
+                              int32_t T, const int32_t* cat_idx, const float* norm_vals, int32_t D, int32_t B, float* dcont,
+                              float* dsamples, pcg_stream_t stream);
+/* tensor.mean() (Wasserstein critic losses, trainer.py:292,299) and its backward dx = grad_out * grad_scale / n */
+size_t pcg_mean_workspace_bytes(void);
+int pcg_mean_fwd(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_mean_bwd(const float* grad_out_dev /*nullable = 1*/, float grad_scale, int64_t n, float* dx, pcg_stream_t stream);
+/* torch.nn.utils.spectral_norm (n_power_iterations = 1) — discriminator.py:9-15.  Forward: when power_iteration != 0
+ * (training mode) v <- normalize(W^T u), u <- normalize(W v) in place, then sigma = u.(W v), w_bar = W / sigma.
+ * u_used / v_used (nullable): copies of the vectors this forward used — what torch's `u.clone()` keeps for backward,
+ * since a later forward overwrites u and v.  Backward (u, v constants): dW (+)= (dw_bar - <dw_bar, w_bar> u v^T) / sigma.
+ * Dimensions up to 256. */
+int pcg_spectral_norm_fwd(const float* w_orig, int32_t out_features, int32_t in_features, float* u, float* v, float eps,
+                          int power_iteration, float* w_bar, float* sigma, float* u_used, float* v_used, pcg_stream_t stream);
+int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, int32_t out_features, int32_t in_features, const float* u,
+                          const float* v, const float* sigma, float* dw_orig, int accumulate, pcg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,7 @@ class ResidualGenerator(nn.Module):
         self.residual_scaling = residual_scaling
         self.tau = tau
 
-    def forward(self, x, target_onehot, mask, gumbel, temperature=None):
+    def forward(self, x, target_onehot, mask, gumbel, temperature=None, hard=False):
         cond = torch.cat([target_onehot, mask], dim=1)            # :73
         h = F.relu(self.fc_in(torch.cat([x, cond], dim=1)))       # :74-75
         for b in self.blocks:
@@ -80,7 +80,11 @@ class ResidualGenerator(nn.Module):
         for idx_str, head in self.fc_cat_logits.items():
             logits = head(h)
             cat_logits[int(idx_str)] = logits
-            cat_samples[int(idx_str)] = ((logits + gumbel[int(idx_str)]) / tau).softmax(-1)   # [torch] gumbel_softmax, hard=False
+            soft = ((logits + gumbel[int(idx_str)]) / tau).softmax(-1)                       # [torch] F.gumbel_softmax
+            if hard:                                                                         # straight-through one-hot (eval_utils.py:77)
+                onehot = torch.zeros_like(soft).scatter_(-1, soft.max(-1, keepdim=True)[1], 1.0)
+                soft = onehot - soft.detach() + soft
+            cat_samples[int(idx_str)] = soft
         return cont_residual, cat_logits, cat_samples
 
 

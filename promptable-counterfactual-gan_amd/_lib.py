@@ -33,6 +33,7 @@ class ConvGeom(ctypes.Structure):
 _c = ctypes
 _vp, _f, _i, _i64, _sz = _c.c_void_p, _c.c_float, _c.c_int, _c.c_int64, _c.c_size_t
 _d = _c.c_double
+_i32 = _c.c_int32
 _gp = _c.POINTER(ConvGeom)
 
 # name -> (restype, argtypes); every symbol include/pcgan_hip.h declares
@@ -80,6 +81,23 @@ PROTOTYPES = {
     "pcg_randn": (_i, [_vp, _i64, _f, _f, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
     "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "pcg_gemm": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _vp]),
+    "pcg_onehot": (_i, [_vp, _i32, _i32, _vp, _vp]),
+    "pcg_concat_cols": (_i, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "pcg_split_cols": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "pcg_film_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "pcg_film_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "pcg_gumbel_softmax_fwd": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
+    "pcg_rand_gumbel": (_i, [_vp, _i64, _c.c_uint64, _c.c_uint64, _vp]),
+    "pcg_feature_mask": (_i, [_vp, _i32, _i32, _vp, _i32, _c.c_uint64, _c.c_uint64, _vp]),
+    "pcg_gumbel_softmax_bwd": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
+    "pcg_assemble_residual_fwd": (_i, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "pcg_assemble_residual_bwd": (_i, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "pcg_mean_workspace_bytes": (_sz, []),
+    "pcg_mean_fwd": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pcg_mean_bwd": (_i, [_vp, _f, _i64, _vp, _vp]),
+    "pcg_spectral_norm_fwd": (_i, [_vp, _i32, _i32, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_spectral_norm_bwd": (_i, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

@@ -110,6 +110,36 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
   }
 }
 
+__global__ void __launch_bounds__(256) gumbel_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+    const U4 r = draw(seed, offset, (uint64_t)i);
+    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j < n) out[j] = -logf(-logf(u01(v[e])));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ out, int B, int D, const int* __restrict__ zero_cols, int nz,
+                                                           uint64_t seed, uint64_t offset) {
+  const int64_t n = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+    const U4 r = draw(seed, offset, (uint64_t)i);
+    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j >= n) break;
+      const int col = (int)(j % D);
+      bool on = (v[e] >> 31) != 0u;
+      for (int z = 0; z < nz; ++z) on = on && zero_cols[z] != col;
+      out[j] = on ? 1.f : 0.f;
+    }
+  }
+}
+
 unsigned grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -144,4 +174,18 @@ extern "C" int pcg_randn(float* out, int64_t n, float mean, float std, uint64_t 
   PCG_REQUIRE(out && n > 0, "pcg_randn: bad arguments");
   hipLaunchKernelGGL(randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, mean, std, seed, offset);
   return launch_status("randn_kernel");
+}
+
+extern "C" int pcg_rand_gumbel(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && n > 0, "pcg_rand_gumbel: bad arguments");
+  hipLaunchKernelGGL(gumbel_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+  return launch_status("gumbel_kernel");
+}
+
+extern "C" int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t* zero_cols, int32_t n_zero_cols, uint64_t seed,
+                                uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && B > 0 && D > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0), "pcg_feature_mask: bad arguments");
+  hipLaunchKernelGGL(feature_mask_kernel, dim3(grid_for(((int64_t)B * D + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, B, D, zero_cols,
+                     n_zero_cols, seed, offset);
+  return launch_status("feature_mask_kernel");
 }

@@ -1,0 +1,384 @@
+// tabular.hip — building blocks of the tabular ("prompted counterfactual") CounteRGAN step,
+// conditional_counteRGAN/house_sales_kc_usa: every tensor is [batch][<=256 features], every weight fits in LDS.
+// Generic small GEMM (any M, N, K — the layer widths 38, 21, 17, 10, 9, 30, 6, 2, 5, 13 are not multiples of 4, so these
+// layers do not go through the MFMA implicit-GEMM path), FiLM, Gumbel-softmax heads, residual assembly, spectral
+// normalisation, one-hot, column concat/split, mean.  Round-1 status: correct and graph-capturable, but one launch per
+// op — the layer chain is launch-latency bound; the MI355X-shaped answer is one persistent fused kernel.
+// Reference call sites are cited next to each prototype in include/pcgan_hip.h.
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+unsigned ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// C[m][n] (+)= sum_k opA[m][k] * opB[k][n] (+ bias[n]);  opA = A (lda: row stride of [M][K]) or A^T (A stored [K][M]);
+// opB = B ([K][N]) or B^T (B stored [N][K]).  64x64 tile per block, 4x4 outputs per thread, K step 16.
+constexpr int GT = 64, GK = 16;
+__global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M, int N, int K, const float* __restrict__ A, int lda,
+                                                   const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                   const float* __restrict__ bias, int accumulate) {
+  __shared__ float As[GK][GT + 1], Bs[GK][GT + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    for (int e = threadIdx.x; e < GK * GT; e += 256) {
+      const int kk = e / GT, r = e - kk * GT;
+      const int k = k0 + kk, m = m0 + r, n = n0 + r;
+      As[kk][r] = (k < K && m < M) ? (transA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
+      Bs[kk][r] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = acc[i][j] + (bias ? bias[n] : 0.f);
+      float* c = C + (size_t)m * ldc + n;
+      *c = accumulate ? *c + v : v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * K; i += gridDim.x * 256) {
+    const int b = i / K, k = i - b * K;
+    out[i] = idx[b] == (int64_t)k ? 1.f : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) concat_cols_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                                          int rows, float* __restrict__ out) {
+  const int C = ca + cb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * C; i += gridDim.x * 256) {
+    const int r = i / C, c = i - r * C;
+    out[i] = c < ca ? a[(size_t)r * ca + c] : b[(size_t)r * cb + (c - ca)];
+  }
+}
+__global__ void __launch_bounds__(256) split_cols_kernel(const float* __restrict__ d, int ca, int cb, int rows, float* __restrict__ da,
+                                                         float* __restrict__ db) {
+  const int C = ca + cb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * C; i += gridDim.x * 256) {
+    const int r = i / C, c = i - r * C;
+    if (c < ca) { if (da) da[(size_t)r * ca + c] = d[i]; }
+    else if (db) db[(size_t)r * cb + (c - ca)] = d[i];
+  }
+}
+
+// FiLM: y = g*h + b (generator.py:13-16)
+__global__ void __launch_bounds__(256) film_fwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                       const float* __restrict__ b, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = fmaf(g[i], h[i], b[i]);
+}
+__global__ void __launch_bounds__(256) film_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ g,
+                                                       const float* __restrict__ h, float* __restrict__ dg, float* __restrict__ dh,
+                                                       size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = dy[i];
+    dg[i] = d * h[i];
+    dh[i] = d * g[i];
+  }
+}
+
+// Gumbel-softmax heads ([torch] F.gumbel_softmax, hard=False): within segment s of a row,
+// y = softmax((logits + noise)/tau).  One thread per (row, segment); segments are <= 30 wide.
+__global__ void __launch_bounds__(256) gumbel_softmax_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ noise,
+                                                                 const int* __restrict__ seg, int S, int T, int B, float inv_tau,
+                                                                 float* __restrict__ y, float* __restrict__ y_hard) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * S; i += gridDim.x * 256) {
+    const int b = i / S, s = i - b * S;
+    const int c0 = seg[s], c1 = seg[s + 1];
+    const float* l = logits + (size_t)b * T;
+    const float* g = noise + (size_t)b * T;
+    float mx = -INFINITY;
+    for (int c = c0; c < c1; ++c) mx = fmaxf(mx, (l[c] + g[c]) * inv_tau);
+    float se = 0.f;
+    for (int c = c0; c < c1; ++c) se += expf((l[c] + g[c]) * inv_tau - mx);
+    const float inv = 1.f / se;
+    float best = -1.f;
+    int arg = c0;
+    for (int c = c0; c < c1; ++c) {
+      const float p = expf((l[c] + g[c]) * inv_tau - mx) * inv;
+      y[(size_t)b * T + c] = p;
+      if (p > best) { best = p; arg = c; }   // first maximum, as y_soft.max(dim)[1]
+    }
+    if (y_hard) for (int c = c0; c < c1; ++c) y_hard[(size_t)b * T + c] = c == arg ? 1.f : 0.f;
+  }
+}
+// dlogits = y * (dy - sum_seg(dy*y)) / tau
+__global__ void __launch_bounds__(256) gumbel_softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const int* __restrict__ seg, int S, int T, int B, float inv_tau,
+                                                                 float* __restrict__ dl) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * S; i += gridDim.x * 256) {
+    const int b = i / S, s = i - b * S;
+    const int c0 = seg[s], c1 = seg[s + 1];
+    const size_t o = (size_t)b * T;
+    float dot = 0.f;
+    for (int c = c0; c < c1; ++c) dot = fmaf(dy[o + c], y[o + c], dot);
+    for (int c = c0; c < c1; ++c) dl[o + c] = y[o + c] * (dy[o + c] - dot) * inv_tau;
+  }
+}
+
+// residual_full (trainer.py:266-279): continuous columns copy cont[:, i]; categorical column f = samples[:, seg s] . norm[seg s] - x[:, f]
+__global__ void __launch_bounds__(256) assemble_fwd_kernel(const float* __restrict__ cont, int ncont, const int* __restrict__ cont_idx,
+                                                           const float* __restrict__ samples, const int* __restrict__ seg, int S,
+                                                           int T, const int* __restrict__ cat_idx, const float* __restrict__ norm,
+                                                           const float* __restrict__ x, int D, int B, float* __restrict__ res) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * (ncont + S); i += gridDim.x * 256) {
+    const int b = i / (ncont + S), j = i - b * (ncont + S);
+    if (j < ncont) {
+      res[(size_t)b * D + cont_idx[j]] = cont[(size_t)b * ncont + j];
+    } else {
+      const int s = j - ncont, f = cat_idx[s];
+      float acc = 0.f;
+      for (int c = seg[s]; c < seg[s + 1]; ++c) acc = fmaf(samples[(size_t)b * T + c], norm[c], acc);
+      res[(size_t)b * D + f] = acc - x[(size_t)b * D + f];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) assemble_bwd_kernel(const float* __restrict__ dres, int ncont, const int* __restrict__ cont_idx,
+                                                           const int* __restrict__ seg, int S, int T, const int* __restrict__ cat_idx,
+                                                           const float* __restrict__ norm, int D, int B, float* __restrict__ dcont,
+                                                           float* __restrict__ dsamples) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * (ncont + S); i += gridDim.x * 256) {
+    const int b = i / (ncont + S), j = i - b * (ncont + S);
+    if (j < ncont) {
+      dcont[(size_t)b * ncont + j] = dres[(size_t)b * D + cont_idx[j]];
+    } else {
+      const int s = j - ncont;
+      const float d = dres[(size_t)b * D + cat_idx[s]];
+      for (int c = seg[s]; c < seg[s + 1]; ++c) dsamples[(size_t)b * T + c] = d * norm[c];
+    }
+  }
+}
+
+// mean(x): per-block partials + fixed-order finish; bwd: dx = g * scale / n
+constexpr int MEAN_BLOCKS = 64;
+__global__ void __launch_bounds__(256) mean_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += x[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void mean_finish_kernel(const float* __restrict__ partial, int nparts, double inv_n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += (double)partial[i];
+    out[0] = (float)(s * inv_n);
+  }
+}
+__global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ gout, float scale, size_t n, float* __restrict__ dx) {
+  const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = g;
+}
+
+// ---- spectral normalisation ([torch] nn.utils.spectral_norm, n_power_iterations=1, eps=1e-12), one block per matrix ----
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+// training: v <- normalize(W^T u); u <- normalize(W v)  (in place);  sigma = u . (W v);  Wbar = W / sigma
+__global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
+                                                                float* __restrict__ v, float eps, int power_iter,
+                                                                float* __restrict__ Wbar, float* __restrict__ sigma_out,
+                                                                float* __restrict__ u_used, float* __restrict__ v_used) {
+  __shared__ float red[256];
+  __shared__ float su[256], sv[256];   // O, I <= 256 (host-checked)
+  for (int i = threadIdx.x; i < O; i += 256) su[i] = u[i];
+  for (int i = threadIdx.x; i < I; i += 256) sv[i] = v[i];
+  __syncthreads();
+  if (power_iter) {
+    float t = 0.f;
+    if ((int)threadIdx.x < I) { for (int o = 0; o < O; ++o) t = fmaf(W[(size_t)o * I + threadIdx.x], su[o], t); }
+    const float nv = sqrtf(block_sum((int)threadIdx.x < I ? t * t : 0.f, red));
+    if ((int)threadIdx.x < I) sv[threadIdx.x] = t / fmaxf(nv, eps);
+    __syncthreads();
+    float w = 0.f;
+    if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) w = fmaf(W[(size_t)threadIdx.x * I + i], sv[i], w); }
+    const float nu = sqrtf(block_sum((int)threadIdx.x < O ? w * w : 0.f, red));
+    if ((int)threadIdx.x < O) su[threadIdx.x] = w / fmaxf(nu, eps);
+    __syncthreads();
+    for (int i = threadIdx.x; i < O; i += 256) u[i] = su[i];
+    for (int i = threadIdx.x; i < I; i += 256) v[i] = sv[i];
+  }
+  if (u_used) for (int i = threadIdx.x; i < O; i += 256) u_used[i] = su[i];
+  if (v_used) for (int i = threadIdx.x; i < I; i += 256) v_used[i] = sv[i];
+  float wv = 0.f;
+  if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) wv = fmaf(W[(size_t)threadIdx.x * I + i], sv[i], wv); wv *= su[threadIdx.x]; }
+  const float sigma = block_sum((int)threadIdx.x < O ? wv : 0.f, red);
+  if (threadIdx.x == 0) sigma_out[0] = sigma;
+  const float inv = 1.f / sigma;
+  for (int e = threadIdx.x; e < O * I; e += 256) Wbar[e] = W[e] * inv;
+}
+// dW (+)= (dWbar - (sum dWbar*Wbar) u v^T) / sigma
+__global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O,
+                                                                int I, const float* __restrict__ u, const float* __restrict__ v,
+                                                                const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
+  __shared__ float red[256];
+  float t = 0.f;
+  for (int e = threadIdx.x; e < O * I; e += 256) t = fmaf(dWbar[e], Wbar[e], t);
+  const float dot = block_sum(t, red);
+  const float inv = 1.f / sigma[0];
+  for (int e = threadIdx.x; e < O * I; e += 256) {
+    const int o = e / I, i = e - o * I;
+    const float g = (dWbar[e] - dot * u[o] * v[i]) * inv;
+    dW[e] = accumulate ? dW[e] + g : g;
+  }
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+extern "C" int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                        int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "pcg_gemm: bad arguments");
+  hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
+                     A, lda, B, ldb, C, ldc, bias, accumulate);
+  return launch_status("gemm_kernel");
+}
+
+extern "C" int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream) {
+  PCG_REQUIRE(idx && out && B > 0 && K > 0, "pcg_onehot: bad arguments");
+  hipLaunchKernelGGL(onehot_kernel, dim3(ew_blocks((size_t)B * K)), dim3(256), 0, (hipStream_t)stream, idx, B, K, out);
+  return launch_status("onehot_kernel");
+}
+
+extern "C" int pcg_concat_cols(const float* a, int32_t ca, const float* b, int32_t cb, int32_t rows, float* out, pcg_stream_t stream) {
+  PCG_REQUIRE(a && b && out && ca > 0 && cb > 0 && rows > 0, "pcg_concat_cols: bad arguments");
+  hipLaunchKernelGGL(concat_cols_kernel, dim3(ew_blocks((size_t)rows * (ca + cb))), dim3(256), 0, (hipStream_t)stream, a, ca, b, cb,
+                     rows, out);
+  return launch_status("concat_cols_kernel");
+}
+
+extern "C" int pcg_split_cols(const float* d, int32_t ca, int32_t cb, int32_t rows, float* da, float* db, pcg_stream_t stream) {
+  PCG_REQUIRE(d && (da || db) && ca > 0 && cb > 0 && rows > 0, "pcg_split_cols: bad arguments");
+  hipLaunchKernelGGL(split_cols_kernel, dim3(ew_blocks((size_t)rows * (ca + cb))), dim3(256), 0, (hipStream_t)stream, d, ca, cb, rows,
+                     da, db);
+  return launch_status("split_cols_kernel");
+}
+
+extern "C" int pcg_film_fwd(const float* g, const float* h, const float* b, float* y, int64_t n, pcg_stream_t stream) {
+  PCG_REQUIRE(g && h && b && y && n > 0, "pcg_film_fwd: bad arguments");
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, g, h, b, y, (size_t)n);
+  return launch_status("film_fwd_kernel");
+}
+
+extern "C" int pcg_film_bwd(const float* dy, const float* g, const float* h, float* dg, float* dh, int64_t n, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && g && h && dg && dh && n > 0, "pcg_film_bwd: bad arguments");
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, g, h, dg, dh, (size_t)n);
+  return launch_status("film_bwd_kernel");
+}
+
+extern "C" int pcg_gumbel_softmax_fwd(const float* logits, const float* noise, const int32_t* seg_offsets, int32_t S, int32_t T,
+                                      int32_t B, float tau, float* y, float* y_hard, pcg_stream_t stream) {
+  PCG_REQUIRE(logits && noise && seg_offsets && y && S > 0 && T > 0 && B > 0 && tau > 0.f, "pcg_gumbel_softmax_fwd: bad arguments");
+  hipLaunchKernelGGL(gumbel_softmax_fwd_kernel, dim3(ew_blocks((size_t)B * S)), dim3(256), 0, (hipStream_t)stream, logits, noise,
+                     seg_offsets, S, T, B, 1.f / tau, y, y_hard);
+  return launch_status("gumbel_softmax_fwd_kernel");
+}
+
+extern "C" int pcg_gumbel_softmax_bwd(const float* dy, const float* y, const int32_t* seg_offsets, int32_t S, int32_t T, int32_t B,
+                                      float tau, float* dlogits, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && y && seg_offsets && dlogits && S > 0 && T > 0 && B > 0 && tau > 0.f, "pcg_gumbel_softmax_bwd: bad arguments");
+  hipLaunchKernelGGL(gumbel_softmax_bwd_kernel, dim3(ew_blocks((size_t)B * S)), dim3(256), 0, (hipStream_t)stream, dy, y, seg_offsets, S,
+                     T, B, 1.f / tau, dlogits);
+  return launch_status("gumbel_softmax_bwd_kernel");
+}
+
+extern "C" int pcg_assemble_residual_fwd(const float* cont, int32_t ncont, const int32_t* cont_idx, const float* samples,
+                                         const int32_t* seg_offsets, int32_t S, int32_t T, const int32_t* cat_idx, const float* norm_vals,
+                                         const float* x, int32_t D, int32_t B, float* residual, pcg_stream_t stream) {
+  PCG_REQUIRE(cont && cont_idx && samples && seg_offsets && cat_idx && norm_vals && x && residual && B > 0 && ncont + S == D,
+              "pcg_assemble_residual_fwd: bad arguments (every column must be continuous or categorical)");
+  hipLaunchKernelGGL(assemble_fwd_kernel, dim3(ew_blocks((size_t)B * D)), dim3(256), 0, (hipStream_t)stream, cont, ncont, cont_idx,
+                     samples, seg_offsets, S, T, cat_idx, norm_vals, x, D, B, residual);
+  return launch_status("assemble_fwd_kernel");
+}
+
+extern "C" int pcg_assemble_residual_bwd(const float* dres, int32_t ncont, const int32_t* cont_idx, const int32_t* seg_offsets, int32_t S,
+                                         int32_t T, const int32_t* cat_idx, const float* norm_vals, int32_t D, int32_t B, float* dcont,
+                                         float* dsamples, pcg_stream_t stream) {
+  PCG_REQUIRE(dres && cont_idx && seg_offsets && cat_idx && norm_vals && dcont && dsamples && B > 0 && ncont + S == D,
+              "pcg_assemble_residual_bwd: bad arguments");
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(ew_blocks((size_t)B * D)), dim3(256), 0, (hipStream_t)stream, dres, ncont, cont_idx,
+                     seg_offsets, S, T, cat_idx, norm_vals, D, B, dcont, dsamples);
+  return launch_status("assemble_bwd_kernel");
+}
+
+extern "C" size_t pcg_mean_workspace_bytes(void) { return MEAN_BLOCKS * sizeof(float); }
+
+extern "C" int pcg_mean_fwd(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(x && out && n > 0, "pcg_mean_fwd: bad arguments");
+  if (!workspace || workspace_bytes < pcg_mean_workspace_bytes()) { set_error("pcg_mean_fwd: workspace too small"); return PCG_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mean_partial_kernel, dim3(MEAN_BLOCKS), dim3(256), 0, s, x, (size_t)n, (float*)workspace);
+  if (int e = launch_status("mean_partial_kernel")) return e;
+  hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, MEAN_BLOCKS, 1.0 / (double)n, out);
+  return launch_status("mean_finish_kernel");
+}
+
+extern "C" int pcg_mean_bwd(const float* grad_out_dev, float grad_scale, int64_t n, float* dx, pcg_stream_t stream) {
+  PCG_REQUIRE(dx && n > 0, "pcg_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(mean_bwd_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, grad_out_dev, grad_scale, (size_t)n, dx);
+  return launch_status("mean_bwd_kernel");
+}
+
+extern "C" int pcg_spectral_norm_fwd(const float* w_orig, int32_t out_features, int32_t in_features, float* u, float* v, float eps,
+                                     int power_iteration, float* w_bar, float* sigma, float* u_used, float* v_used,
+                                     pcg_stream_t stream) {
+  PCG_REQUIRE(w_orig && u && v && w_bar && sigma && out_features > 0 && in_features > 0 && out_features <= 256 && in_features <= 256,
+              "pcg_spectral_norm_fwd: bad arguments (dimensions must be 1..256)");
+  hipLaunchKernelGGL(spectral_norm_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w_orig, out_features, in_features, u, v, eps,
+                     power_iteration, w_bar, sigma, u_used, v_used);
+  return launch_status("spectral_norm_fwd_kernel");
+}
+
+extern "C" int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, int32_t out_features, int32_t in_features, const float* u,
+                                     const float* v, const float* sigma, float* dw_orig, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(dw_bar && w_bar && u && v && sigma && dw_orig && out_features > 0 && in_features > 0 && out_features <= 256 && in_features <= 256,
+              "pcg_spectral_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dw_bar, w_bar, out_features, in_features, u, v,
+                     sigma, dw_orig, accumulate);
+  return launch_status("spectral_norm_bwd_kernel");
+}

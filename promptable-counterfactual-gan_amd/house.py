@@ -1,0 +1,605 @@
+"""Host-side mirror of `conditional_counteRGAN/house_sales_kc_usa/` (the tabular, "prompted" CounteRGAN) on the HIP kernels.
+
+    reference                                              here
+    ---------------------------------------------------    -----------------------------------------------------
+    config.py                          :13-82               CONFIG (the fields the step reads)
+    models/generator.py  FiLM :6-16, ResidualBlock :19-35   FiLM, ResidualBlock (parameter containers)
+    models/generator.py  ResidualGenerator :38-92           ResidualGenerator (same ctor args, same state_dict keys)
+    models/discriminator.py Discriminator :5-20             Discriminator (spectral-norm keys weight_orig / weight_u / weight_v)
+    models/nn_classifier.py NNClassifier :4-32              NNClassifier (frozen / eval use: forward + grad-input)
+    trainer.py  cat_norm_maps :205-223                      cat_norm_maps
+    trainer.py  train_countergan loop body :241-316         make_optimizers + train_step (+ train_countergan loop)
+
+Every network is one autograd node that sequences C-ABI calls (csrc/tabular.hip + the BatchNorm / activation / loss kernels)
+and accumulates parameter gradients straight into the FlatModule's flat gradient buffer.  The categorical heads are packed
+side by side: `logits` / `samples` are [B, T] with T = sum of category counts (70 for the King-County config), head s
+occupying columns seg[s]..seg[s+1]; the reference's dict views are column slices of those.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
+from .countergan import CrossEntropyLoss, abs_mean, grad_norm  # noqa: F401  (same loss kernels)
+from .nn import FlatModule
+from .optim import Adam
+
+FEATURES = ["bedrooms", "bathrooms", "sqft_living", "sqft_lot", "floors", "waterfront", "view", "condition", "grade",
+            "sqft_above", "sqft_basement", "yr_built", "yr_renovated", "lat", "long", "sqft_living15", "sqft_lot15"]
+# config.py:13-82 — category counts of the shipped dataset; `raw_values` come from the data loader (data_utils.py) at run time
+CONFIG = {
+    "input_dim": 17, "num_classes": 4, "hidden_dim": 32, "lr_G": 1e-3, "lr_D": 1e-3, "batch_size": 128, "epochs": 60,
+    "lambda_cls": 2.0, "lambda_reg": 1.0, "lambda_mask": 1.0, "gumbel_tau": 0.5,
+    "immutable_idx": [FEATURES.index(f) for f in ("lat", "long", "yr_built", "yr_renovated")],
+    "categorical_info": {FEATURES.index(f): {"n": n} for f, n in
+                         (("bedrooms", 9), ("bathrooms", 30), ("floors", 6), ("waterfront", 2), ("view", 5), ("condition", 5),
+                          ("grade", 13))},
+}
+CONFIG["continuous_idx"] = [i for i in range(17) if i not in CONFIG["categorical_info"]]
+
+
+def _ncat(info):
+    return int(info["n"]) if isinstance(info, dict) else int(info)
+
+
+# ---- Linear helpers: rows of activations x [B, in] against an [out, in] weight ------------------------------------------
+def _lin_fwd(lin, x, weight=None, out=None, ldc=None):
+    w = lin.weight.data if weight is None else weight
+    B = x.shape[0]
+    return ops.gemm(x, w, B, w.shape[0], w.shape[1], transB=True, bias=lin.bias.data if lin.bias is not None else None, out=out, ldc=ldc)
+
+
+def _lin_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):
+    O, I = w.shape
+    return ops.gemm(dy, w, B, I, O, lda=ldy if ldy is not None else O, out=out, accumulate=accumulate)
+
+
+def _ones(net, B, device):
+    o = getattr(net, "_ones_buf", None)
+    if o is None or o.numel() < B or o.device != device:
+        o = torch.empty(max(B, 1024), dtype=torch.float32, device=device)
+        ops.fill(o, 1.0)
+        net._ones_buf = o
+    return o
+
+
+def _lin_wgrad(net, lin, x, dy, ldy=None, weight_param=None, dw_out=None):
+    """dW += dy^T x, db += column sums of dy — accumulated into net's flat gradient buffer.  `dw_out`: write dW there
+    instead (spectral-norm layers post-process it)."""
+    B, I = x.shape
+    O = lin.out_features
+    ld = ldy if ldy is not None else O
+    if dw_out is not None:
+        ops.gemm(dy, x, O, I, B, transA=True, lda=ld, out=dw_out)
+    else:
+        gw, acc = net._grad_view(lin.weight if weight_param is None else weight_param)
+        ops.gemm(dy, x, O, I, B, transA=True, lda=ld, out=gw, accumulate=acc)
+    if lin.bias is not None and lin.bias.requires_grad:
+        gb, accb = net._grad_view(lin.bias)
+        ops.gemm(_ones(net, B, x.device), dy, 1, O, B, lda=B, ldb=ld, out=gb, accumulate=accb)   # ones[1,B] . dy[B,O]
+
+
+# ---- generator -------------------------------------------------------------------------------------------------------
+class FiLM(nn.Module):
+    """generator.py:6-16 (container; the arithmetic is pcg_film_fwd/bwd)."""
+
+    def __init__(self, hidden_dim, cond_dim):
+        super().__init__()
+        self.gamma = nn.Linear(cond_dim, hidden_dim)
+        self.beta = nn.Linear(cond_dim, hidden_dim)
+
+
+class ResidualBlock(nn.Module):
+    """generator.py:19-35 (container)."""
+
+    def __init__(self, hidden_dim, cond_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden_dim, hidden_dim)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.bn2 = nn.BatchNorm1d(hidden_dim)
+        self.film = FiLM(hidden_dim, cond_dim)
+
+
+class _GFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, target_onehot, mask, noise, tau, hard, *params):
+        cont, logits, samples, saved = net._run_forward(x, target_onehot, mask, noise, tau, hard)
+        ctx.net, ctx.saved = net, saved
+        ctx.set_materialize_grads(False)     # unused outputs (the logits, in the training step) arrive as None, not zeros
+        return cont, logits, samples
+
+    @staticmethod
+    def backward(ctx, d_cont, d_logits, d_samples):
+        ctx.net._run_backward(ctx.saved, d_cont, d_logits, d_samples)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class ResidualGenerator(FlatModule):
+    """generator.py:38-92.  forward() returns what the reference returns — (cont_residual [B, n_cont], {idx: logits},
+    {idx: Gumbel-softmax samples}) — the dict entries being column slices of the packed tensors `forward_packed` returns.
+
+    Gumbel noise: `F.gumbel_softmax` draws it from torch's global generator (:90); here it is an explicit input —
+    `gumbel=` (a packed [B, T] tensor or a dict idx -> [B, n]) or, when omitted, a draw from `self.rng` (ops.DeviceRNG)."""
+
+    def __init__(self, input_dim, hidden_dim, num_classes, continuous_idx, categorical_info, n_blocks=5, residual_scaling=0.1, tau=0.5):
+        super().__init__()
+        self.input_dim = input_dim
+        self.num_classes = num_classes
+        self.continuous_idx = list(continuous_idx)
+        self.categorical_info = dict(categorical_info)
+        self.cond_dim = input_dim + num_classes
+        self.fc_in = nn.Linear(input_dim + self.cond_dim, hidden_dim)
+        self.blocks = nn.ModuleList([ResidualBlock(hidden_dim, self.cond_dim) for _ in range(n_blocks)])
+        self.fc_cont = nn.Linear(hidden_dim, len(self.continuous_idx))
+        self.fc_cat_logits = nn.ModuleDict({str(idx): nn.Linear(hidden_dim, _ncat(info)) for idx, info in self.categorical_info.items()})
+        self.residual_scaling = residual_scaling
+        self.tau = tau
+        self.hidden_dim = hidden_dim
+        self.cat_idx = [int(k) for k in self.fc_cat_logits.keys()]
+        sizes = [self.fc_cat_logits[str(i)].out_features for i in self.cat_idx]
+        self.seg = [0] + [int(v) for v in np.cumsum(sizes)]
+        self.total_cat = int(self.seg[-1])
+        self.rng = None
+        self._idx_dev = None
+
+    # -- small device-side index tables (seg offsets, column indices) -------------------------------------------------
+    def index_tables(self, device):
+        if self._idx_dev is None or self._idx_dev[0].device != device:
+            mk = lambda v: torch.tensor(list(v), dtype=torch.int32, device=device)  # noqa: E731
+            self._idx_dev = (mk(self.seg), mk(self.cat_idx), mk(self.continuous_idx))
+        return self._idx_dev
+
+    def pack_noise(self, gumbel):
+        """dict idx -> [B, n]  ->  packed [B, T] (setup-time helper for tests / supplied draws)."""
+        return torch.cat([gumbel[i] for i in self.cat_idx], dim=1).contiguous()
+
+    def _noise(self, gumbel, B, device):
+        if gumbel is None:
+            if self.rng is None:
+                self.rng = ops.DeviceRNG(seed=0)
+            return self.rng.gumbel((B, self.total_cat), device)
+        if isinstance(gumbel, dict):
+            gumbel = self.pack_noise(gumbel)
+        if tuple(gumbel.shape) != (B, self.total_cat):
+            raise PcgError(f"gumbel noise must be [B, {self.total_cat}], got {tuple(gumbel.shape)}")
+        return gumbel
+
+    def forward_packed(self, x, target_onehot, mask=None, temperature=None, hard=False, gumbel=None):
+        self._ensure_flat()
+        if not x.is_cuda:
+            raise PcgError(f"ResidualGenerator: input is on {x.device}; libpcgan_hip has no CPU path")
+        B = x.shape[0]
+        if mask is None:
+            mask = torch.empty_like(x)
+            ops.fill(mask, 1.0)                                                               # :70-71
+        tau = self.tau if temperature is None else float(temperature)
+        noise = self._noise(gumbel, B, x.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _GFn.apply(self, x, target_onehot, mask, noise, tau, bool(hard), *self.parameters())
+        return self._run_forward(x, target_onehot, mask, noise, tau, bool(hard), keep=False)[:3]
+
+    def forward(self, x, target_onehot, mask=None, temperature=None, hard=False, gumbel=None):
+        cont, logits, samples = self.forward_packed(x, target_onehot, mask, temperature, hard, gumbel)
+        cat_logits = {f: logits[:, self.seg[s]:self.seg[s + 1]] for s, f in enumerate(self.cat_idx)}
+        cat_samples = {f: samples[:, self.seg[s]:self.seg[s + 1]] for s, f in enumerate(self.cat_idx)}
+        return cont, cat_logits, cat_samples
+
+    # -- one block ----------------------------------------------------------------------------------------------------
+    def _bn(self, bn, z):
+        C = bn.num_features
+        if bn.training:
+            mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            return ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, ACT_NONE), mean, invstd
+        return ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, ACT_NONE, var_eps=bn.eps), None, None
+
+    def _run_forward(self, x, target_onehot, mask, noise, tau, hard, keep=True):
+        x = x.contiguous()
+        seg, cat_idx, cont_idx = self.index_tables(x.device)
+        B = x.shape[0]
+        cond = ops.concat_cols(target_onehot.contiguous(), mask.contiguous())                # :73
+        inp = ops.concat_cols(x, cond)                                                        # :74
+        h = _lin_fwd(self.fc_in, inp)
+        ops.act_fwd(h, ACT_RELU, 0.0, out=h)                                                  # :75
+        blocks = []
+        for blk in self.blocks:
+            gam = _lin_fwd(blk.film.gamma, cond)                                              # FiLM :13-14 (one module, used twice)
+            bet = _lin_fwd(blk.film.beta, cond)
+            z1 = _lin_fwd(blk.fc1, h)                                                         # :28
+            n1, m1, s1 = self._bn(blk.bn1, z1)
+            a1 = ops.film_fwd(gam, n1, bet)                                                   # :29
+            ops.act_fwd(a1, ACT_RELU, 0.0, out=a1)                                            # :30
+            z2 = _lin_fwd(blk.fc2, a1)                                                        # :31
+            n2, m2, s2 = self._bn(blk.bn2, z2)
+            f2 = ops.film_fwd(gam, n2, bet)                                                   # :33
+            hn = ops.axpby(1.0, h, 1.0, f2, out=f2)                                           # :34
+            if keep:
+                blocks.append((h, gam, z1, n1, m1, s1, a1, z2, n2, m2, s2))
+            h = hn
+        cont_raw = _lin_fwd(self.fc_cont, h)
+        cont = ops.axpby(self.residual_scaling, cont_raw, out=cont_raw)                       # :81
+        logits = torch.empty((B, self.total_cat), dtype=torch.float32, device=x.device)
+        for s, f in enumerate(self.cat_idx):
+            _lin_fwd(self.fc_cat_logits[str(f)], h, out=logits[:, self.seg[s]:], ldc=self.total_cat)   # :87
+        soft, hard_y = ops.gumbel_softmax_fwd(logits, noise, seg, tau, hard=hard)             # :90
+        saved = (cond, inp, blocks, h, soft, seg, tau) if keep else None
+        return cont, logits, (hard_y if hard else soft), saved
+
+    def _run_backward(self, saved, d_cont, d_logits, d_samples):
+        cond, inp, blocks, h_last, soft, seg, tau = saved
+        if any(not blk.bn1.training for blk in self.blocks):
+            raise PcgError("backward through an eval-mode BatchNorm1d is not implemented")
+        B = inp.shape[0]
+        T = self.total_cat
+        dh = None
+        if d_samples is not None:
+            dl = ops.gumbel_softmax_bwd(d_samples.contiguous(), soft, seg, tau)               # straight-through for hard=True
+            if d_logits is not None:
+                ops.axpby(1.0, dl, 1.0, d_logits.contiguous(), out=dl)
+        else:
+            dl = d_logits.contiguous() if d_logits is not None else None
+        if dl is not None:
+            dh = torch.empty((B, self.hidden_dim), dtype=torch.float32, device=inp.device)
+            for s, f in enumerate(self.cat_idx):
+                head = self.fc_cat_logits[str(f)]
+                dls = dl[:, self.seg[s]:]
+                _lin_wgrad(self, head, h_last, dls, ldy=T)
+                _lin_dgrad(head.weight.data, dls, B, ldy=T, out=dh, accumulate=s > 0)
+        if d_cont is not None:
+            dc = ops.axpby(self.residual_scaling, d_cont.contiguous())
+            _lin_wgrad(self, self.fc_cont, h_last, dc)
+            dh = _lin_dgrad(self.fc_cont.weight.data, dc, B, out=dh, accumulate=dh is not None)
+        if dh is None:
+            return
+        C = self.hidden_dim
+        for blk, (h, gam, z1, n1, m1, s1, a1, z2, n2, m2, s2) in zip(reversed(self.blocks), reversed(blocks)):
+            dgam2, dn2 = ops.film_bwd(dh, gam, n2)                                            # d f2 = dh (skip keeps dh too)
+            gg, acc = self._grad_view(blk.bn2.weight)
+            gb, _ = self._grad_view(blk.bn2.bias)
+            dz2 = ops.bn_act_bwd(dn2, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, gg, gb, acc)
+            _lin_wgrad(self, blk.fc2, a1, dz2)
+            da1 = _lin_dgrad(blk.fc2.weight.data, dz2, B)
+            ops.act_bwd(da1, a1, ACT_RELU, 0.0, out=da1)                                      # d f1
+            dgam1, dn1 = ops.film_bwd(da1, gam, n1)
+            gg, acc = self._grad_view(blk.bn1.weight)
+            gb, _ = self._grad_view(blk.bn1.bias)
+            dz1 = ops.bn_act_bwd(dn1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_NONE, 0.0, gg, gb, acc)
+            _lin_wgrad(self, blk.fc1, h, dz1)
+            # FiLM parameters: gamma sees dgam1 + dgam2, beta sees d f1 + d f2
+            dgam = ops.axpby(1.0, dgam1, 1.0, dgam2, out=dgam1)
+            dbet = ops.axpby(1.0, da1, 1.0, dh, out=dgam2)
+            _lin_wgrad(self, blk.film.gamma, cond, dgam)
+            _lin_wgrad(self, blk.film.beta, cond, dbet)
+            dh = _lin_dgrad(blk.fc1.weight.data, dz1, B, out=dh, accumulate=True)             # block path + skip path
+        ops.act_bwd(dh, blocks[0][0] if blocks else h_last, ACT_RELU, 0.0, out=dh)
+        _lin_wgrad(self, self.fc_in, inp, dh)
+
+
+# ---- residual assembly (trainer.py:266-279) -----------------------------------------------------------------------------
+class _AssembleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cont, samples, x, tables, norm_vals):
+        seg, cat_idx, cont_idx = tables
+        ctx.tables, ctx.norm, ctx.shape = tables, norm_vals, (cont.shape[1], samples.shape[1])
+        return ops.assemble_residual_fwd(cont.contiguous(), cont_idx, samples.contiguous(), seg, cat_idx, norm_vals, x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dres):
+        seg, cat_idx, cont_idx = ctx.tables
+        dcont, dsamples = ops.assemble_residual_bwd(dres.contiguous(), ctx.shape[0], cont_idx, seg, ctx.shape[1], cat_idx, ctx.norm)
+        return dcont, dsamples, None, None, None
+
+
+def assemble_residual(generator, cont, samples, x, norm_vals):
+    """residual_full [B, D]: continuous columns from `cont`, categorical columns = E_sample[normalised value] - x."""
+    return _AssembleFn.apply(cont, samples, x, generator.index_tables(x.device), norm_vals)
+
+
+def cat_norm_maps(generator, config, device):
+    """trainer.py:205-223 — packed [T] tensor of normalised category values, head order of the generator."""
+    scaler = config.get("scaler", None)
+    vals = []
+    for f in generator.cat_idx:
+        info = config["categorical_info"][f]
+        n = _ncat(info)
+        if scaler is not None:
+            lo, hi = float(scaler.data_min_[f]), float(scaler.data_max_[f])
+            raw = np.asarray(info["raw_values"], dtype=float)
+            vals.append((raw - lo) / ((hi - lo) + 1e-12))                                      # :211-216
+        else:
+            vals.append(np.arange(n, dtype=float) / max(1.0, n - 1))                           # :218-223
+    return torch.tensor(np.concatenate(vals), dtype=torch.float32, device=device)
+
+
+class _MaskMulFn(torch.autograd.Function):
+    """masked = res * mask; x_cf = x + masked (trainer.py:281-282)."""
+
+    @staticmethod
+    def forward(ctx, res, mask, x):
+        ctx.mask = mask
+        ctx.set_materialize_grads(False)
+        _, masked = ops.scale_mask_fwd(res.contiguous(), mask, 1.0)
+        x_cf = ops.axpby(1.0, x, 1.0, masked)
+        return masked, x_cf
+
+    @staticmethod
+    def backward(ctx, d_masked, d_xcf):
+        if d_masked is None:
+            dsum = d_xcf.contiguous()
+        elif d_xcf is None:
+            dsum = d_masked.contiguous()
+        else:
+            dsum = ops.axpby(1.0, d_masked.contiguous(), 1.0, d_xcf.contiguous())
+        return ops.scale_mask_bwd(None, dsum, ctx.mask, 1.0, like=ctx.mask), None, None
+
+
+class _MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.like = x
+        return ops.mean_fwd(x.contiguous()).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.mean_bwd(g.contiguous(), 1.0, ctx.like)
+
+
+def mean(x):
+    return _MeanFn.apply(x)
+
+
+# ---- discriminator ------------------------------------------------------------------------------------------------------
+class _DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, target_onehot, *params):
+        out, saved = net._run_forward(x, target_onehot)
+        ctx.net, ctx.saved = net, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx = ctx.net._run_backward(ctx.saved, dout, ctx.needs_input_grad[1], any(ctx.needs_input_grad[3:]))
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class Discriminator(FlatModule):
+    """discriminator.py:5-20 — a Wasserstein-style critic of four spectral-normalised Linears.  The torch spectral_norm
+    containers hold the state (`net.{0,2,4,6}.weight_orig / weight_u / weight_v / bias`); the power iteration, the
+    division by sigma and its backward run in pcg_spectral_norm_fwd/bwd.  As in torch, every training-mode forward does
+    one power iteration and updates u, v in place."""
+
+    def __init__(self, input_dim, hidden_dim, num_classes):
+        super().__init__()
+        self.net = nn.Sequential(
+            spectral_norm(nn.Linear(input_dim + num_classes, hidden_dim)), nn.LeakyReLU(0.2, inplace=True),
+            spectral_norm(nn.Linear(hidden_dim, hidden_dim * 2)), nn.LeakyReLU(0.2, inplace=True),
+            spectral_norm(nn.Linear(hidden_dim * 2, hidden_dim * 4)), nn.LeakyReLU(0.2, inplace=True),
+            spectral_norm(nn.Linear(hidden_dim * 4, 1)))
+        self.input_dim = input_dim
+
+    def _linears(self):
+        return [m for m in self.net if isinstance(m, nn.Linear)]
+
+    def forward(self, x, target_onehot):
+        self._ensure_flat()
+        if not x.is_cuda:
+            raise PcgError(f"Discriminator: input is on {x.device}; libpcgan_hip has no CPU path")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _DFn.apply(self, x, target_onehot, *self.parameters())
+        return self._run_forward(x, target_onehot, keep=False)[0]
+
+    def _run_forward(self, x, target_onehot, keep=True):
+        a = ops.concat_cols(x.contiguous(), target_onehot.contiguous())                       # :19
+        lins = self._linears()
+        layers = []
+        for i, lin in enumerate(lins):
+            w_bar, sigma, u, v = ops.spectral_norm_fwd(lin.weight_orig.data, lin.weight_u, lin.weight_v, 1e-12, self.training)
+            z = _lin_fwd(lin, a, weight=w_bar)
+            if i + 1 < len(lins):
+                ops.act_fwd(z, ACT_LRELU, 0.2, out=z)
+            if keep:
+                layers.append((a, z, w_bar, sigma, u, v))
+            a = z
+        return a, (layers if keep else None)
+
+    def _run_backward(self, layers, dout, need_x, need_p):
+        lins = self._linears()
+        d = dout.contiguous()
+        B = d.shape[0]
+        for i in range(len(lins) - 1, -1, -1):
+            lin = lins[i]
+            a, z, w_bar, sigma, u, v = layers[i]
+            if i + 1 < len(lins):
+                d = ops.act_bwd(d, z, ACT_LRELU, 0.2)
+            if need_p and lin.weight_orig.requires_grad:
+                dwb = torch.empty_like(w_bar)
+                _lin_wgrad(self, lin, a, d, dw_out=dwb)
+                gw, acc = self._grad_view(lin.weight_orig)
+                ops.spectral_norm_bwd(dwb, w_bar, u, v, sigma, gw, acc)
+            if i > 0 or need_x:
+                d = _lin_dgrad(w_bar, d, B)
+        if not need_x:
+            return None
+        dx, _ = ops.split_cols(d, self.input_dim, d.shape[1] - self.input_dim, need_b=False)
+        return dx
+
+
+# ---- frozen classifier ------------------------------------------------------------------------------------------------
+class _CFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x):
+        logits, saved = net._run_forward(x)
+        ctx.net, ctx.saved = net, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        return None, ctx.net._run_backward(ctx.saved, dlogits)
+
+
+class NNClassifier(nn.Module):
+    """nn_classifier.py:4-32 as the GAN step uses it: eval mode, parameters frozen (main.py:27-30) — forward and the
+    gradient with respect to the input row.  In eval mode each BatchNorm1d is a per-column affine map, so it is folded
+    into the following Linear once (fp64 at pack time): the step runs 5 GEMMs and 4 LeakyReLUs.  Training the
+    classifier (trainer.py:25-176) is not part of this path."""
+
+    def __init__(self, input_dim, output_dim=4):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Linear(input_dim, 256), nn.LeakyReLU(0.1), nn.BatchNorm1d(256), nn.Dropout(0.3),
+            nn.Linear(256, 256), nn.LeakyReLU(0.1), nn.BatchNorm1d(256), nn.Dropout(0.2),
+            nn.Linear(256, 128), nn.LeakyReLU(0.1), nn.BatchNorm1d(128), nn.Dropout(0.1),
+            nn.Linear(128, 64), nn.LeakyReLU(0.1), nn.BatchNorm1d(64),
+            nn.Linear(64, output_dim))
+        self._packed = None
+
+    def _pack(self):
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        if self.training:
+            raise PcgError("NNClassifier: only eval mode is implemented (the GAN step uses the frozen classifier)")
+        packed, scale, shift = [], None, None
+        with torch.no_grad():
+            for m in self.net:
+                if isinstance(m, nn.Linear):
+                    w, b = m.weight.double(), m.bias.double()
+                    if scale is not None:            # Linear(bn(a)) = a (W diag(s))^T + (W t + b)
+                        b = b + w @ shift
+                        w = w * scale[None, :]
+                        scale = shift = None
+                    packed.append((w.float().contiguous(), b.float().contiguous()))
+                elif isinstance(m, nn.BatchNorm1d):
+                    s = m.weight.double() / torch.sqrt(m.running_var.double() + m.eps)
+                    scale, shift = s, m.bias.double() - m.running_mean.double() * s
+        self._packed = (key, packed)
+        return packed
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise PcgError(f"NNClassifier: input is on {x.device}; libpcgan_hip has no CPU path")
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _CFn.apply(self, x)
+        return self._run_forward(x, keep=False)[0]
+
+    def _run_forward(self, x, keep=True):
+        packed = self._pack()
+        a = x.contiguous()
+        B = a.shape[0]
+        acts = []
+        for i, (w, b) in enumerate(packed):
+            z = ops.gemm(a, w, B, w.shape[0], w.shape[1], transB=True, bias=b)
+            if i + 1 < len(packed):
+                ops.act_fwd(z, ACT_LRELU, 0.1, out=z)
+                if keep:
+                    acts.append(z)
+            a = z
+        return a, (acts if keep else None)
+
+    def _run_backward(self, acts, dlogits):
+        packed = self._pack()
+        d = dlogits.contiguous()
+        B = d.shape[0]
+        for i in range(len(packed) - 1, -1, -1):
+            if i + 1 < len(packed):
+                d = ops.act_bwd(d, acts[i], ACT_LRELU, 0.1, out=d)
+            d = _lin_dgrad(packed[i][0], d, B)
+        return d
+
+
+# ---- trainer ------------------------------------------------------------------------------------------------------------
+def make_optimizers(generator, discriminator, config=CONFIG):
+    """trainer.py:229-230."""
+    return Adam(generator.parameters(), lr=config["lr_G"]), Adam(discriminator.parameters(), lr=config["lr_D"])
+
+
+def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config=CONFIG, gumbel=None,
+               ce=None, skip_dead_d_wgrad=True):
+    """One iteration of train_countergan's loop body (trainer.py:241-316) for a batch already on the GPU.  The draws —
+    `target_y` (:248-249), `mask` (:253-255) and the Gumbel noise inside G (gumbel=None: generator.rng) — are inputs.
+    Returns device tensors; the reference's `.item()` calls are the caller's."""
+    nc = config["num_classes"]
+    ce = ce if ce is not None else CrossEntropyLoss()
+    target_onehot = ops.onehot(target_y, nc)                                                  # :250
+    cont, _, samples = generator.forward_packed(x, target_onehot, mask, temperature=config["gumbel_tau"], hard=False,
+                                                gumbel=gumbel)                                # :259-261
+    residual_full = assemble_residual(generator, cont, samples, x, norm_vals)                 # :266-279
+    masked_residual, x_cf = _MaskMulFn.apply(residual_full, mask, x)                          # :281-282
+    mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                          # :287
+    # ---- D step
+    d_real = discriminator(x, ops.onehot(y, nc))                                              # :290
+    d_fake = discriminator(x_cf.detach(), target_onehot)                                      # :291
+    d_loss = mean(d_fake) - mean(d_real)                                                      # :292
+    opt_d.zero_grad()
+    d_loss.backward()
+    opt_d.step()                                                                              # :293-295
+    # ---- G step
+    if skip_dead_d_wgrad:            # the reference computes D's weight gradients here and never uses them (next zero_grad)
+        for p in discriminator.parameters():
+            p.requires_grad_(False)
+    try:
+        d_fake_for_g = discriminator(x_cf, target_onehot)                                     # :298
+        g_adv = -mean(d_fake_for_g)                                                           # :299
+        g_cls = ce(classifier(x_cf), target_y)                                                # :301-302
+        g_reg = abs_mean(masked_residual) * float(x.shape[1])                                 # :305  mean_b ||.||_1 = D * mean|.|
+        g_loss = g_adv + config["lambda_cls"] * g_cls + config["lambda_reg"] * g_reg + config["lambda_mask"] * mask_penalty_pre
+        opt_g.zero_grad()
+        g_loss.backward()                                                                     # :314-315
+    finally:
+        if skip_dead_d_wgrad:
+            for p in discriminator.parameters():
+                p.requires_grad_(True)
+    opt_g.step()                                                                              # :316
+    return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
+            "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+
+
+def draw_batch_randoms(rng, generator, y, config, device):
+    """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise)."""
+    B = y.shape[0]
+    target_y = rng.randint(0, config["num_classes"], B, device, exclude=y)
+    imm = getattr(generator, "_imm_dev", None)
+    if imm is None or imm.device != device:
+        imm = torch.tensor(list(config.get("immutable_idx", [])), dtype=torch.int32, device=device)
+        generator._imm_dev = imm
+    mask = rng.feature_mask(B, config["input_dim"], device, imm if imm.numel() else None)
+    return target_y, mask, rng.gumbel((B, generator.total_cat), device)
+
+
+def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):
+    """trainer.py:181-366 without the plotting / checkpoint tail: same loop, per-epoch means of D and G loss."""
+    opt_g, opt_d = make_optimizers(generator, discriminator, config)
+    norm_vals = cat_norm_maps(generator, config, device)
+    rng = rng if rng is not None else ops.DeviceRNG(seed=0)
+    classifier.eval()
+    history = []
+    for epoch in range(config["epochs"]):
+        d_sum = g_sum = 0.0
+        n = 0
+        for batch_idx, (x, y) in enumerate(loader):
+            x, y = x.to(device), y.to(device)
+            target_y, mask, noise = draw_batch_randoms(rng, generator, y, config, device)
+            out = train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel=noise)
+            d_sum += out["D_loss"].item(); g_sum += out["G_loss"].item()
+            n += 1
+            if batch_idx % log_every == 0:
+                print(f"[Epoch {epoch + 1}/{config['epochs']}] batch {batch_idx}: D_loss={out['D_loss'].item():.4f}, "
+                      f"G_loss={out['G_loss'].item():.4f}, g_adv={out['g_adv'].item():.4f}, g_cls={out['g_cls'].item():.4f}, "
+                      f"reg={out['reg'].item():.4f}, mask_pen={out['mask_pen'].item():.6f}")
+        history.append((d_sum / max(n, 1), g_sum / max(n, 1)))
+    return history
+
+
+def build(device, config=CONFIG, seed=0):
+    """(G, D, clf) on `device`, constructed in the reference's order (main.py: classifier, generator; trainer.py:227: D)."""
+    torch.manual_seed(seed)
+    clf = NNClassifier(config["input_dim"], config["num_classes"])
+    G = ResidualGenerator(config["input_dim"], config["hidden_dim"], config["num_classes"], config["continuous_idx"],
+                          config["categorical_info"], tau=config["gumbel_tau"])
+    D = Discriminator(config["input_dim"], config["hidden_dim"], config["num_classes"])
+    clf.eval()
+    for p in clf.parameters():
+        p.requires_grad = False
+    return G.to(device), D.to(device), clf.to(device)

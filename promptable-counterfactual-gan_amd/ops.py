@@ -376,6 +376,132 @@ def cross_entropy_fwd_bwd(logits, target, need_loss=True, need_grad=True, grad_o
     return loss, dz
 
 
+# ---- tabular CounteRGAN building blocks (csrc/tabular.hip) ----------------------------------------------------------------
+def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None, ldc=None, bias=None, accumulate=False):
+    """out[M][N] (+)= opA . opB (+ bias); A/B/out may be column slices of wider row-major buffers (ld* = row stride)."""
+    for t, n in ((A, "A"), (B, "B")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.PcgError(f"gemm: {n} must be an fp32 tensor on the GPU")
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ldc = ldc if ldc is not None else N
+    check(_lib.load().pcg_gemm(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(bool(accumulate)),
+                               _stream()), "pcg_gemm")
+    return out
+
+
+def onehot(idx, K):
+    _chk_idx(idx, K)
+    out = torch.empty((idx.numel(), K), dtype=torch.float32, device=idx.device)
+    check(_lib.load().pcg_onehot(_p(idx), idx.numel(), K, _p(out), _stream()), "pcg_onehot")
+    return out
+
+
+def concat_cols(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    rows = a.shape[0]
+    out = torch.empty((rows, a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+    check(_lib.load().pcg_concat_cols(_p(a), a.shape[1], _p(b), b.shape[1], rows, _p(out), _stream()), "pcg_concat_cols")
+    return out
+
+
+def split_cols(d, ca, cb, need_a=True, need_b=True):
+    _chk(d, "d")
+    rows = d.shape[0]
+    da = torch.empty((rows, ca), dtype=torch.float32, device=d.device) if need_a else None
+    db = torch.empty((rows, cb), dtype=torch.float32, device=d.device) if need_b else None
+    check(_lib.load().pcg_split_cols(_p(d), ca, cb, rows, _p(da), _p(db), _stream()), "pcg_split_cols")
+    return da, db
+
+
+def film_fwd(g, h, b):
+    _chk(g, "gamma"); _chk(h, "h"); _chk(b, "beta")
+    y = torch.empty_like(h)
+    check(_lib.load().pcg_film_fwd(_p(g), _p(h), _p(b), _p(y), h.numel(), _stream()), "pcg_film_fwd")
+    return y
+
+
+def film_bwd(dy, g, h):
+    _chk(dy, "dy")
+    dg, dh = torch.empty_like(h), torch.empty_like(h)
+    check(_lib.load().pcg_film_bwd(_p(dy), _p(g), _p(h), _p(dg), _p(dh), h.numel(), _stream()), "pcg_film_bwd")
+    return dg, dh
+
+
+def gumbel_softmax_fwd(logits, noise, seg_offsets, tau, hard=False):
+    """(y_soft, y_hard or None)"""
+    _chk(logits, "logits"); _chk(noise, "noise"); _chk(seg_offsets, "seg_offsets", torch.int32)
+    B, T = logits.shape
+    y = torch.empty_like(logits)
+    yh = torch.empty_like(logits) if hard else None
+    check(_lib.load().pcg_gumbel_softmax_fwd(_p(logits), _p(noise), _p(seg_offsets), seg_offsets.numel() - 1, T, B, float(tau), _p(y),
+                                             _p(yh), _stream()), "pcg_gumbel_softmax_fwd")
+    return y, yh
+
+
+def gumbel_softmax_bwd(dy, y, seg_offsets, tau):
+    _chk(dy, "dy")
+    B, T = y.shape
+    dl = torch.empty_like(y)
+    check(_lib.load().pcg_gumbel_softmax_bwd(_p(dy), _p(y), _p(seg_offsets), seg_offsets.numel() - 1, T, B, float(tau), _p(dl),
+                                             _stream()), "pcg_gumbel_softmax_bwd")
+    return dl
+
+
+def assemble_residual_fwd(cont, cont_idx, samples, seg_offsets, cat_idx, norm_vals, x):
+    _chk(cont, "cont"); _chk(samples, "samples"); _chk(x, "x"); _chk(norm_vals, "norm_vals")
+    B, D = x.shape
+    res = torch.empty_like(x)
+    check(_lib.load().pcg_assemble_residual_fwd(_p(cont), cont.shape[1], _p(cont_idx), _p(samples), _p(seg_offsets), cat_idx.numel(),
+                                                samples.shape[1], _p(cat_idx), _p(norm_vals), _p(x), D, B, _p(res), _stream()),
+          "pcg_assemble_residual_fwd")
+    return res
+
+
+def assemble_residual_bwd(dres, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
+    _chk(dres, "dres")
+    B, D = dres.shape
+    dcont = torch.empty((B, ncont), dtype=torch.float32, device=dres.device)
+    dsamples = torch.empty((B, T), dtype=torch.float32, device=dres.device)
+    check(_lib.load().pcg_assemble_residual_bwd(_p(dres), ncont, _p(cont_idx), _p(seg_offsets), cat_idx.numel(), T, _p(cat_idx),
+                                                _p(norm_vals), D, B, _p(dcont), _p(dsamples), _stream()), "pcg_assemble_residual_bwd")
+    return dcont, dsamples
+
+
+def mean_fwd(x):
+    _chk(x, "x")
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.pcg_mean_workspace_bytes(), x.device)
+    check(lib.pcg_mean_fwd(_p(x), x.numel(), _p(out), _p(ws), ws.numel(), _stream()), "pcg_mean_fwd")
+    return out
+
+
+def mean_bwd(grad_out, scale, like):
+    dx = torch.empty_like(like)
+    check(_lib.load().pcg_mean_bwd(_p(grad_out), float(scale), like.numel(), _p(dx), _stream()), "pcg_mean_bwd")
+    return dx
+
+
+def spectral_norm_fwd(w_orig, u, v, eps, power_iteration):
+    _chk(w_orig, "weight_orig"); _chk(u, "weight_u"); _chk(v, "weight_v")
+    O, I = w_orig.shape
+    w_bar = torch.empty_like(w_orig)
+    sigma = torch.empty(1, dtype=torch.float32, device=w_orig.device)
+    uu, vu = torch.empty_like(u), torch.empty_like(v)
+    check(_lib.load().pcg_spectral_norm_fwd(_p(w_orig), O, I, _p(u), _p(v), float(eps), int(bool(power_iteration)), _p(w_bar), _p(sigma),
+                                            _p(uu), _p(vu), _stream()), "pcg_spectral_norm_fwd")
+    return w_bar, sigma, uu, vu
+
+
+def spectral_norm_bwd(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate):
+    O, I = w_bar.shape
+    check(_lib.load().pcg_spectral_norm_bwd(_p(dw_bar), _p(w_bar), O, I, _p(u), _p(v), _p(sigma), _p(dw_orig), int(bool(accumulate)),
+                                            _stream()), "pcg_spectral_norm_bwd")
+
+
 # ---- device-side batch synthesis ---------------------------------------------------------------------------------
 class DeviceRNG:
     """Counter-based stream: every draw advances `offset`, so a (seed, call sequence) pair is reproducible."""
@@ -406,4 +532,20 @@ class DeviceRNG:
         out = torch.empty(shape, dtype=torch.float32, device=device)
         n = out.numel()
         check(_lib.load().pcg_randn(_p(out), n, mean, std, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_randn")
+        return out
+
+    def gumbel(self, shape, device):
+        """Gumbel(0,1) noise, the draw F.gumbel_softmax makes (house_sales_kc_usa/models/generator.py:90)."""
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        check(_lib.load().pcg_rand_gumbel(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_gumbel")
+        return out
+
+    def feature_mask(self, B, D, device, zero_cols=None):
+        """Bernoulli(1/2) modifiable-feature mask with immutable columns zeroed (house_sales_kc_usa/trainer.py:253-255);
+        zero_cols: int32 device tensor."""
+        out = torch.empty((B, D), dtype=torch.float32, device=device)
+        nz = 0 if zero_cols is None else zero_cols.numel()
+        check(_lib.load().pcg_feature_mask(_p(out), B, D, _p(zero_cols), nz, self.seed, self._advance((B * D + 3) // 4), _stream()),
+              "pcg_feature_mask")
         return out

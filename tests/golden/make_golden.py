@@ -330,6 +330,58 @@ def make_house(path, bs=64):
         os.chdir(cwd)
 
 
+def make_house_trained(path_npz, path_g, path_c, bs=32):
+    """Real-weight anchor for the tabular path: the generator and classifier checkpoints the reference ships
+    (house_sales_kc_usa/generator_model.pt, clf_model.pt) loaded into the reference's own modules, eval mode, with
+    hard=True Gumbel-softmax as eval_utils.py:76-77 calls it; the noise F.gumbel_softmax drew is replayed from the RNG
+    state captured just before the call.  The checkpoints are data and are copied next to the vectors."""
+    import importlib, shutil
+    mdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    scratch = "/tmp/pcg_golden_house"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        sys.path.insert(0, mdir)
+        for name in list(sys.modules):
+            if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+                sys.modules.pop(name)
+        cfg = importlib.import_module("config").config
+        gen_mod = importlib.import_module("models.generator")
+        clf_mod = importlib.import_module("models.nn_classifier")
+        G = gen_mod.ResidualGenerator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"], continuous_idx=cfg["continuous_idx"],
+                                      categorical_info={k: {"n": v["n"], "raw_values": v["raw_values"]} for k, v in cfg["categorical_info"].items()},
+                                      tau=cfg["gumbel_tau"])
+        clf = clf_mod.NNClassifier(cfg["input_dim"], output_dim=cfg["num_classes"])
+        G.load_state_dict(torch.load(os.path.join(mdir, "generator_model.pt"), map_location="cpu", weights_only=True))
+        clf.load_state_dict(torch.load(os.path.join(mdir, "clf_model.pt"), map_location="cpu", weights_only=True))
+        G.eval(); clf.eval()
+        g = torch.Generator().manual_seed(77)
+        x = torch.rand(bs, cfg["input_dim"], generator=g)
+        t = torch.randint(0, cfg["num_classes"], (bs,), generator=g)
+        mask = torch.ones(bs, cfg["input_dim"])
+        mask[:, cfg["immutable_idx"]] = 0.0                                   # eval_utils.py:48-50
+        onehot = torch.nn.functional.one_hot(t, cfg["num_classes"]).float()
+        torch.manual_seed(5)
+        state = torch.get_rng_state()
+        with torch.no_grad():
+            cont, cat_logits, cat_samples = G(x, onehot, mask=mask, temperature=cfg["gumbel_tau"], hard=True)
+            clf_logits = clf(x)
+        torch.set_rng_state(state)
+        out = {"x": x.numpy(), "target_y": t.numpy(), "mask": mask.numpy(), "cont": cont.numpy(), "clf_logits": clf_logits.numpy()}
+        for idx_str, head in G.fc_cat_logits.items():
+            out[f"gumbel.{idx_str}"] = (-torch.empty(bs, head.out_features).exponential_().log()).numpy()
+            out[f"logits.{idx_str}"] = cat_logits[int(idx_str)].numpy()
+            out[f"samples.{idx_str}"] = cat_samples[int(idx_str)].numpy()
+        np.savez_compressed(path_npz, **out)
+        for src, dst in (("generator_model.pt", path_g), ("clf_model.pt", path_c)):
+            shutil.copyfile(os.path.join(mdir, src), dst)
+            os.chmod(dst, 0o644)
+        print(f"wrote {path_npz}, {path_g}, {path_c}; |cont| max {cont.abs().max().item():.4f}")
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -338,3 +390,5 @@ if __name__ == "__main__":
     make_moons(os.path.join(HERE, "moons_ref.npz"))
     make_countergan_trained(os.path.join(HERE, "countergan_trained_eval.npz"), os.path.join(HERE, "countergan_generator_trained.pt"))
     make_house(os.path.join(HERE, "house_ref_b64.npz"))
+    make_house_trained(os.path.join(HERE, "house_trained_eval.npz"), os.path.join(HERE, "house_generator_trained.pt"),
+                       os.path.join(HERE, "house_classifier_trained.pt"))

@@ -1,0 +1,345 @@
+"""GPU parity, tabular CounteRGAN (conditional_counteRGAN/house_sales_kc_usa): the drop-ins in pcgan_amd.house against
+  (a) one batch of the reference's own train_countergan (tests/golden/house_ref_b64.npz, the draws it made recorded),
+  (b) the reference modules with the checkpoints the reference ships (tests/golden/house_trained_eval.npz), and
+  (c) the oracle restatement (oracle/house_ref.py) evaluated live in float64 (truth) and float32 (noise floor).
+One-hot / concatenation / hard samples must be bit-exact; floating point within the tolerances stated in each assert."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import house_ref as HR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pcg():
+    import pcgan_amd
+    from pcgan_amd import house  # noqa: F401
+    return pcgan_amd
+
+
+@pytest.fixture(scope="module")
+def hgold(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "house_ref_b64.npz")))
+
+
+def _dev(t):
+    return t.to(DEV).contiguous()
+
+
+def _close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_gemm_all_layouts(pcg):
+    """pcg_gemm against float64 matmul: ragged sizes (the layer widths of this model are 38, 21, 17, 10, 9, 30, ...),
+    transposes, strided column slices, bias, accumulate.  fp32 FMA accumulation over K <= 300: rtol 2e-5."""
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(1, 1, 1), (64, 32, 38), (130, 9, 32), (7, 70, 21), (256, 256, 17), (33, 1, 128), (1, 13, 300)]:
+        for tA in (False, True):
+            for tB in (False, True):
+                A = torch.randn((K, M) if tA else (M, K), generator=g)
+                Bm = torch.randn((N, K) if tB else (K, N), generator=g)
+                bias = torch.randn(N, generator=g)
+                ref = (A.double().T if tA else A.double()) @ (Bm.double().T if tB else Bm.double()) + bias.double()
+                out = ops.gemm(_dev(A), _dev(Bm), M, N, K, transA=tA, transB=tB, bias=_dev(bias))
+                _close(out, ref, 2e-5, 2e-5, f"{M}x{N}x{K} tA={tA} tB={tB}")
+    # column slices: A = columns 3..3+K of a wider buffer, C = columns 5..5+N of a wider buffer, accumulate on top
+    M, N, K = 50, 9, 12
+    Aw, Bm, Cw = torch.randn(M, 40, generator=g), torch.randn(N, K, generator=g), torch.randn(M, 30, generator=g)
+    Cd = _dev(Cw)
+    ops.gemm(_dev(Aw)[:, 3:], _dev(Bm), M, N, K, transB=True, lda=40, out=Cd[:, 5:], ldc=30, accumulate=True)
+    ref = Cw.double().clone()
+    ref[:, 5:5 + N] += Aw[:, 3:3 + K].double() @ Bm.double().T
+    _close(Cd, ref, 2e-5, 2e-5)
+
+
+def test_tabular_elementwise_ops(pcg):
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(2)
+    B = 77
+    idx = torch.randint(0, 4, (B,), generator=g)
+    assert torch.equal(ops.onehot(_dev(idx), 4).cpu(), F.one_hot(idx, 4).float())                      # bit-exact
+    a, b = torch.randn(B, 17, generator=g), torch.randn(B, 4, generator=g)
+    cat = ops.concat_cols(_dev(a), _dev(b))
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1))                                                # bit-exact
+    da, db = ops.split_cols(cat, 17, 4)
+    assert torch.equal(da.cpu(), a) and torch.equal(db.cpu(), b)
+    da, db = ops.split_cols(cat, 17, 4, need_b=False)
+    assert db is None and torch.equal(da.cpu(), a)
+    # FiLM
+    gm, h, bt, dy = (torch.randn(B, 32, generator=g) for _ in range(4))
+    _close(ops.film_fwd(_dev(gm), _dev(h), _dev(bt)), gm.double() * h.double() + bt.double(), 1e-6, 1e-6)
+    dg, dh = ops.film_bwd(_dev(dy), _dev(gm), _dev(h))
+    _close(dg, dy * h, 1e-6, 1e-7); _close(dh, dy * gm, 1e-6, 1e-7)
+    # mean
+    x = torch.randn(B, 1, generator=g)
+    _close(ops.mean_fwd(_dev(x)), x.double().mean().view(1), 1e-6, 1e-7)
+    gout = torch.tensor(-1.5)
+    _close(ops.mean_bwd(_dev(gout), 1.0, _dev(x)), torch.full_like(x, -1.5 / B), 1e-6, 0)
+
+
+def test_gumbel_softmax_heads_and_residual_assembly(pcg):
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(3)
+    B, sizes, D = 53, [9, 30, 6, 2, 5, 5, 13], 17
+    cat_idx, cont_idx = [0, 1, 4, 5, 6, 7, 8], [2, 3, 9, 10, 11, 12, 13, 14, 15, 16]
+    seg = [0] + list(np.cumsum(sizes)); T = int(seg[-1])
+    mk = lambda v: torch.tensor([int(i) for i in v], dtype=torch.int32, device=DEV)  # noqa: E731
+    segd, catd, contd = mk(seg), mk(cat_idx), mk(cont_idx)
+    logits = torch.randn(B, T, generator=g, dtype=torch.float64, requires_grad=True)
+    noise = -torch.empty(B, T, dtype=torch.float64).exponential_(generator=g).log()
+    cont = torch.randn(B, len(cont_idx), generator=g, dtype=torch.float64, requires_grad=True)
+    x = torch.rand(B, D, generator=g, dtype=torch.float64)
+    norm = torch.cat([torch.arange(n, dtype=torch.float64) / max(1, n - 1) for n in sizes])
+    tau = 0.5
+    # float64 reference with autograd, written as the reference trainer writes it (trainer.py:266-279)
+    soft = torch.cat([((logits[:, seg[s]:seg[s + 1]] + noise[:, seg[s]:seg[s + 1]]) / tau).softmax(-1) for s in range(len(sizes))], 1)
+    res = torch.zeros(B, D, dtype=torch.float64)
+    for i, f in enumerate(cont_idx):
+        res[:, f] = cont[:, i]
+    for s, f in enumerate(cat_idx):
+        res[:, f] = soft[:, seg[s]:seg[s + 1]].matmul(norm[seg[s]:seg[s + 1]]) - x[:, f]
+    dres = torch.randn(B, D, generator=g, dtype=torch.float64)
+    res.backward(dres)
+    y, yh = ops.gumbel_softmax_fwd(_dev(logits.detach().float()), _dev(noise.float()), segd, tau, hard=True)
+    _close(y, soft, 2e-5, 1e-7)                                                    # expf / fp32 softmax
+    for s in range(len(sizes)):                                                    # hard: one-hot of the soft argmax — exact
+        blk = yh[:, seg[s]:seg[s + 1]].cpu()
+        assert torch.equal(blk.sum(1), torch.ones(B)) and torch.equal(blk.argmax(1), soft[:, seg[s]:seg[s + 1]].argmax(1))
+    r = ops.assemble_residual_fwd(_dev(cont.detach().float()), contd, y, segd, catd, _dev(norm.float()), _dev(x.float()))
+    _close(r, res, 2e-5, 2e-6)
+    dcont, dsamp = ops.assemble_residual_bwd(_dev(dres.float()), len(cont_idx), contd, segd, T, catd, _dev(norm.float()))
+    _close(dcont, cont.grad, 1e-6, 1e-7)
+    dl = ops.gumbel_softmax_bwd(dsamp, y, segd, tau)
+    _close(dl, logits.grad, 1e-4, 1e-6)                                             # y*(dy - <dy,y>): cancellation at fp32 eps * |dy|
+
+
+def test_spectral_norm_matches_torch(pcg):
+    """pcg_spectral_norm_fwd/bwd against torch.nn.utils.spectral_norm on the CPU: the in-place power iteration (u, v after
+    each forward), W / sigma, and the gradient that reaches weight_orig."""
+    ops = pcg.ops
+    torch.manual_seed(4)
+    for (O, I) in [(32, 21), (64, 32), (128, 64), (1, 128)]:
+        lin = torch.nn.utils.spectral_norm(torch.nn.Linear(I, O))
+        w_orig, u, v = _dev(lin.weight_orig.detach()), _dev(lin.weight_u.clone()), _dev(lin.weight_v.clone())
+        x = torch.randn(40, I)
+        for it in range(2):                                                        # two training-mode forwards: u, v keep moving
+            lin.zero_grad()
+            out = lin(x)
+            out.square().sum().backward()
+            w_bar, sigma, uu, vu = ops.spectral_norm_fwd(w_orig, u, v, 1e-12, True)
+            _close(u, lin.weight_u, 1e-5, 1e-6, f"u {O}x{I} it{it}"); _close(v, lin.weight_v, 1e-5, 1e-6, f"v {O}x{I} it{it}")
+            assert torch.equal(uu, u) and torch.equal(vu, v)
+            _close(w_bar, lin.weight.detach(), 1e-5, 1e-6, f"w_bar {O}x{I}")
+            dwb = (2 * out.detach()).T @ x                                          # d(sum out^2)/d w_bar
+            gw = torch.zeros(O, I, device=DEV)
+            ops.spectral_norm_bwd(_dev(dwb), w_bar, uu, vu, sigma, gw, False)
+            _close(gw, lin.weight_orig.grad, 2e-4, 1e-5 * float(lin.weight_orig.grad.abs().max()), f"dW {O}x{I}")
+        lin.eval()                                                                  # eval: no power iteration
+        ub = u.clone()
+        w_bar, _, _, _ = ops.spectral_norm_fwd(w_orig, u, v, 1e-12, False)
+        lin(x)
+        assert torch.equal(ub, u)
+        _close(w_bar, lin.weight.detach(), 1e-5, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _load_golden_nets(pcg, hgold):
+    H = pcg.house
+    torch.manual_seed(0)
+    C = H.NNClassifier(17, 4)                                   # same construction order / seed as make_golden.py
+    G = H.ResidualGenerator(17, 32, 4, H.CONFIG["continuous_idx"], H.CONFIG["categorical_info"], tau=0.5)
+    D = H.Discriminator(17, 32, 4)
+    assert [f"init.G.{k}" for k in G.state_dict()] == [k for k in hgold if k.startswith("init.G.")]
+    assert [f"init.D.{k}" for k in D.state_dict()] == [k for k in hgold if k.startswith("init.D.")]   # weight_orig / _u / _v
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.G.")})
+    D.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.D.")})
+    C.eval()
+    for p in C.parameters():
+        p.requires_grad = False
+    return G.to(DEV), D.to(DEV), C.to(DEV)
+
+
+def _oracle_nets(hgold, dtype):
+    G, D, clf = HR.build(seed=0)
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.G.")})
+    D.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in hgold.items() if k.startswith("init.D.")})
+    return G.to(dtype), D.to(dtype), clf.to(dtype)
+
+
+def test_golden_reference_train_loop_batch(pcg, hgold):
+    """One batch of the reference's train_countergan: logged losses, G gradients, G parameters after Adam; the critic's
+    state after its Adam step (weight_orig, bias, u, v) against the float32 oracle run on the same draws."""
+    H = pcg.house
+    G, D, C = _load_golden_nets(pcg, hgold)
+    x, y, t, m = (_dev(torch.from_numpy(hgold[f"in.{n}"])) for n in ("x", "y", "target_y", "mask"))
+    gumbel = {int(k[7:]): torch.from_numpy(v) for k, v in hgold.items() if k.startswith("gumbel.")}
+    noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
+    opt_g, opt_d = H.make_optimizers(G, D)
+    norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
+    out = H.train_step(G, D, C, opt_g, opt_d, x, y, t, m, norm, gumbel=noise, skip_dead_d_wgrad=False)
+    log = str(hgold["log"])
+
+    def logged(pat):
+        return float(re.search(pat, log).group(1))
+    # printed with 3-6 decimals: half a unit of the last printed digit + fp32 noise
+    assert abs(torch.sigmoid(out["D_real"]).mean().item() - logged(r"D\(real\)=([0-9.]+)")) <= 6e-4
+    assert abs(torch.sigmoid(out["D_fake_forG"]).mean().item() - logged(r"D\(fake\)=([0-9.]+)")) <= 6e-4
+    assert abs(out["g_adv"].item() - logged(r"g_adv=(-?[0-9.]+)")) <= 7e-5 and abs(out["g_cls"].item() - logged(r"g_cls=([0-9.]+)")) <= 7e-5
+    assert abs(out["reg"].item() - logged(r"reg=([0-9.]+)")) <= 2e-6 and abs(out["mask_pen"].item() - logged(r"mask_pen=([0-9.]+)")) <= 7e-6
+    assert abs(out["D_loss"].item() - logged(r"\] D: (-?[0-9.]+)")) <= 7e-5 and abs(out["G_loss"].item() - logged(r", G: (-?[0-9.]+)")) <= 7e-5
+    lr = H.CONFIG["lr_G"]
+    for n, p in G.named_parameters():
+        ref = hgold[f"grad.G.{n}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-4, atol=2e-6 + 2e-5 * np.abs(ref).max(), err_msg=f"grad {n}")
+    for k, v in G.state_dict().items():
+        gk = f"grad.G.{k}"
+        if gk in hgold and np.abs(hgold[gk]).max() < 1e-6:
+            # a Linear bias in front of BatchNorm1d has an exactly-zero gradient; what is stored is fp32 noise whose sign
+            # Adam turns into a +-lr step: only bound the move
+            assert np.abs(v.cpu().numpy() - hgold[f"final.G.{k}"]).max() <= 2.2 * lr, k
+            continue
+        np.testing.assert_allclose(v.cpu().numpy(), hgold[f"final.G.{k}"], rtol=1e-4, atol=3e-5, err_msg=f"final {k}")
+    # critic: float32 oracle on the same draws (the golden file holds only D's initial state)
+    oG, oD, oC = _oracle_nets(hgold, torch.float32)
+    o_g, o_d = HR.make_optimizers(oG, oD)
+    HR.house_step(oG, oD, oC, o_g, o_d, x.cpu(), y.cpu(), t.cpu(), m.cpu(), gumbel, HR.cat_norm_maps())
+    for k, v in D.state_dict().items():
+        ref = oD.state_dict()[k]
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            _close(v, ref, 1e-4, 1e-5, k)                     # three power iterations per step (D(real), D(fake), D(fake) for G)
+        else:
+            # Adam's first step moves every weight by ~lr*sign(g): entries whose gradient is at noise level may flip
+            d = (v.cpu() - ref).abs()
+            assert float(d.max()) <= 2.2 * H.CONFIG["lr_D"] and int((d > 2e-5).sum()) <= max(2, 0.01 * d.numel()), (k, float(d.max()))
+
+
+@pytest.mark.parametrize("batch", [256])
+def test_step_vs_oracle_float64(pcg, hgold, batch):
+    """Synthetic batch: every loss, every G gradient and every D gradient of one step against the
+    float64 oracle; tolerance = max(1e-4 relative to the tensor's max, 3x the float32 oracle's own distance from float64)."""
+    H = pcg.house
+    G, D, C = _load_golden_nets(pcg, hgold)
+    x, y, t, m, gumbel = HR.synthetic_batch(batch, seed=9, dtype=torch.float64)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        oG, oD, oC = _oracle_nets(hgold, dt)
+        o_g, o_d = HR.make_optimizers(oG, oD)
+        losses = HR.house_step(oG, oD, oC, o_g, o_d, x.to(dt), y, t, m.to(dt), {f: v.to(dt) for f, v in gumbel.items()},
+                               {f: v.to(dt) for f, v in HR.cat_norm_maps().items()})
+        res[dt] = (losses, {n: p.grad.double().clone() for n, p in oG.named_parameters()},
+                   {n: p.grad.double().clone() for n, p in oD.named_parameters()},
+                   {k: v.double().clone() for k, v in oG.state_dict().items()})
+    opt_g, opt_d = H.make_optimizers(G, D)
+    norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
+    noise = G.pack_noise({f: _dev(v.float()) for f, v in gumbel.items()})
+    out = H.train_step(G, D, C, opt_g, opt_d, _dev(x.float()), _dev(y), _dev(t), _dev(m.float()), norm, gumbel=noise,
+                       skip_dead_d_wgrad=False)
+    l64, g64, d64, s64 = res[torch.float64]
+    l32, g32, d32, _ = res[torch.float32]
+    for k in ("D_loss", "G_loss", "g_adv", "g_cls", "reg", "mask_pen"):
+        tol = max(1e-5 + 1e-5 * abs(l64[k]), 3 * abs(l32[k] - l64[k]))
+        assert abs(out[k].item() - l64[k]) <= tol, (k, out[k].item(), l64[k], tol)
+
+    def check(mine, truth, noise32, label, net_scale):
+        # net_scale: the largest gradient entry of the whole net — a Linear bias in front of BatchNorm1d has a true gradient
+        # of exactly 0, and what any fp32 implementation returns there is summation noise relative to the net's scale
+        scale = float(truth.abs().max())
+        tol = max(1e-4 * scale, 3 * float((noise32 - truth).abs().max()), 1e-6 * net_scale)
+        err = float((mine.detach().cpu().double() - truth).abs().max())
+        assert err <= tol, (label, err, tol, scale)
+    g_scale, d_scale = max(float(v.abs().max()) for v in g64.values()), max(float(v.abs().max()) for v in d64.values())
+    for n, p in G.named_parameters():
+        check(p.grad, g64[n], g32[n], f"G grad {n}", g_scale)
+    for n, p in D.named_parameters():
+        check(p.grad, d64[n], d32[n], f"D grad {n}", d_scale)                  # D-step gradient + the G step's dead contribution, as in torch
+    # running statistics of the BatchNorm1d layers (updated once per step)
+    for k, v in G.state_dict().items():
+        if "running" in k:
+            _close(v, s64[k], 1e-4, 1e-6, k)
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1
+
+
+def test_skip_dead_d_wgrad_is_equivalent(pcg, hgold):
+    """skip_dead_d_wgrad=True only drops work whose result the reference discards: both nets end in the same state."""
+    H = pcg.house
+    x, y, t, m, gumbel = HR.synthetic_batch(64, seed=3)
+    states = []
+    for skip in (False, True):
+        G, D, C = _load_golden_nets(pcg, hgold)
+        opt_g, opt_d = H.make_optimizers(G, D)
+        norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
+        noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
+        for _ in range(2):
+            H.train_step(G, D, C, opt_g, opt_d, _dev(x), _dev(y), _dev(t), _dev(m), norm, gumbel=noise, skip_dead_d_wgrad=skip)
+        states.append({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+
+
+def test_trained_checkpoints_eval_forward(pcg, golden_dir):
+    """The checkpoints the reference ships, eval mode, hard Gumbel-softmax (eval_utils.py:76-77), reference-module outputs."""
+    H = pcg.house
+    gold = dict(np.load(os.path.join(golden_dir, "house_trained_eval.npz")))
+    G = H.ResidualGenerator(17, 32, 4, H.CONFIG["continuous_idx"], H.CONFIG["categorical_info"], tau=0.5)
+    C = H.NNClassifier(17, 4)
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "house_generator_trained.pt"), map_location="cpu", weights_only=True))
+    C.load_state_dict(torch.load(os.path.join(golden_dir, "house_classifier_trained.pt"), map_location="cpu", weights_only=True))
+    G, C = G.to(DEV).eval(), C.to(DEV).eval()
+    x, t, m = _dev(torch.from_numpy(gold["x"])), _dev(torch.from_numpy(gold["target_y"])), _dev(torch.from_numpy(gold["mask"]))
+    gumbel = {int(k[7:]): _dev(torch.from_numpy(v)) for k, v in gold.items() if k.startswith("gumbel.")}
+    with torch.no_grad():
+        cont, logits, samples = G(x, pcg.ops.onehot(t, 4), mask=m, temperature=0.5, hard=True, gumbel=gumbel)
+        cl = C(x)
+    _close(cont, torch.from_numpy(gold["cont"]), 1e-4, 2e-5)
+    _close(cl, torch.from_numpy(gold["clf_logits"]), 1e-4, 1e-4)         # BatchNorm folded into the next Linear: fp32 re-association
+    for f in gumbel:
+        _close(logits[f], torch.from_numpy(gold[f"logits.{f}"]), 1e-4, 1e-4)
+        assert torch.equal(samples[f].cpu(), torch.from_numpy(gold[f"samples.{f}"])), f    # one-hot: exact
+    # classifier input gradient (what the G step back-propagates through) against autograd on the oracle module, float64
+    _, _, oC = HR.build(seed=0)
+    oC.load_state_dict(torch.load(os.path.join(golden_dir, "house_classifier_trained.pt"), map_location="cpu", weights_only=True))
+    oC = oC.double().eval()
+    xr = torch.from_numpy(gold["x"]).double().requires_grad_(True)
+    F.cross_entropy(oC(xr), t.cpu()).backward()
+    xg = x.clone().requires_grad_(True)
+    H.CrossEntropyLoss()(C(xg), t).backward()
+    _close(xg.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()))
+
+
+def test_device_draws(pcg):
+    """trainer.py:248-255 + generator.py:90 on the device: targets differ from the source class, immutable columns are
+    never modifiable, the rest is Bernoulli(1/2); Gumbel(0,1) noise has mean 0.5772 and variance pi^2/6; deterministic."""
+    H, ops = pcg.house, pcg.ops
+    G = H.ResidualGenerator(17, 32, 4, H.CONFIG["continuous_idx"], H.CONFIG["categorical_info"]).to(DEV)
+    y = torch.randint(0, 4, (8192,), device=DEV)
+    t, mask, noise = H.draw_batch_randoms(ops.DeviceRNG(5), G, y, H.CONFIG, torch.device(DEV))
+    assert bool((t != y).all()) and int(t.min()) == 0 and int(t.max()) == 3
+    cnt = torch.bincount(t, minlength=4).float() / t.numel()
+    assert float((cnt - 0.25).abs().max()) < 0.02
+    mc = mask.mean(0).cpu()
+    imm = H.CONFIG["immutable_idx"]
+    assert float(mask[:, imm].abs().sum()) == 0.0 and set(mask.unique().tolist()) == {0.0, 1.0}
+    free = [i for i in range(17) if i not in imm]
+    assert float((mc[free] - 0.5).abs().max()) < 0.03
+    assert noise.shape == (8192, 70) and abs(float(noise.mean()) - 0.5772) < 0.01 and abs(float(noise.var()) - np.pi ** 2 / 6) < 0.03
+    t2, mask2, noise2 = H.draw_batch_randoms(ops.DeviceRNG(5), G, y, H.CONFIG, torch.device(DEV))
+    assert torch.equal(t, t2) and torch.equal(mask, mask2) and torch.equal(noise, noise2)
+    # the full loop runs on device draws and moves the losses
+    D, C = H.Discriminator(17, 32, 4).to(DEV), H.NNClassifier(17, 4).to(DEV).eval()
+    cfg = dict(H.CONFIG, epochs=2)
+    xs = torch.rand(4 * 128, 17)
+    ys = torch.randint(0, 4, (4 * 128,))
+    loader = [(xs[i * 128:(i + 1) * 128], ys[i * 128:(i + 1) * 128]) for i in range(4)]
+    hist = H.train_countergan(G, D, C, loader, cfg, torch.device(DEV), rng=ops.DeviceRNG(1), log_every=10 ** 9)
+    assert len(hist) == 2 and all(np.isfinite(v) for e in hist for v in e)

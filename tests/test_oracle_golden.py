@@ -208,3 +208,23 @@ def test_house_step_matches_reference_train_loop(hgold):
             assert np.abs(v.numpy() - hgold[f"final.G.{k}"]).max() <= 2.2 * HR.CONFIG["lr_G"], k
             continue
         np.testing.assert_allclose(v.numpy(), hgold[f"final.G.{k}"], rtol=1e-4, atol=2e-5, err_msg=f"final {k}")
+
+
+def test_house_trained_checkpoints_eval_forward(golden_dir):
+    """The generator / classifier checkpoints the reference ships, through the oracle restatement in eval mode with
+    hard Gumbel-softmax, against the reference modules' own outputs (tests/golden/make_golden.py: make_house_trained)."""
+    gold = dict(np.load(os.path.join(golden_dir, "house_trained_eval.npz")))
+    G, _, clf = HR.build(seed=0)
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "house_generator_trained.pt"), map_location="cpu", weights_only=True))
+    clf.load_state_dict(torch.load(os.path.join(golden_dir, "house_classifier_trained.pt"), map_location="cpu", weights_only=True))
+    G.eval(); clf.eval()
+    x, t, m = torch.from_numpy(gold["x"]), torch.from_numpy(gold["target_y"]), torch.from_numpy(gold["mask"])
+    gumbel = {int(k[7:]): torch.from_numpy(v) for k, v in gold.items() if k.startswith("gumbel.")}
+    with torch.no_grad():
+        cont, logits, samples = G(x, torch.nn.functional.one_hot(t, 4).float(), m, gumbel, temperature=0.5, hard=True)
+        cl = clf(x)
+    np.testing.assert_allclose(cont.numpy(), gold["cont"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cl.numpy(), gold["clf_logits"], rtol=1e-5, atol=1e-5)
+    for f in gumbel:
+        np.testing.assert_allclose(logits[f].numpy(), gold[f"logits.{f}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(samples[f].numpy(), gold[f"samples.{f}"])          # one-hot: exact
