@@ -224,6 +224,13 @@ int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_
  * models/nn_classifier.py:8-27. */
 int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
              float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream);
+/* nn.Linear weight + bias gradient in one launch, reducing over the batch with a deterministic split over row slabs:
+ * dW[O][I] (+)= dy^T x, db[O] (+)= column sums of dy (db nullable).  dy / x may be column slices (ld = row stride).
+ * tickets: caller-owned int32[pcg_linear_wgrad_ticket_count()], zero before first use; the kernel leaves it zero. */
+size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t I);
+int32_t pcg_linear_wgrad_ticket_count(void);
+int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW, float* db,
+                     int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets, pcg_stream_t stream);
 /* F.one_hot(idx, K).float() — trainer.py:250,290 */
 int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream);
 /* torch.cat([a, b], dim=1) and its backward — generator.py:73-74, discriminator.py:19 */

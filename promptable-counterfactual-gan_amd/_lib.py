@@ -82,6 +82,9 @@ PROTOTYPES = {
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
     "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
     "pcg_gemm": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _vp]),
+    "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "pcg_linear_wgrad_ticket_count": (_i32, []),
+    "pcg_linear_wgrad": (_i, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp]),
     "pcg_onehot": (_i, [_vp, _i32, _i32, _vp, _vp]),
     "pcg_concat_cols": (_i, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "pcg_split_cols": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

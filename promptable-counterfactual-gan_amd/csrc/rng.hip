@@ -110,6 +110,10 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
   }
 }
 
+// 23-bit variant whose largest value, 1 - 2^-24, is still below 1 in fp32 (u01's top value rounds to 1.0f, harmless under a
+// single log but an infinity under -log(-log(u)))
+__device__ __forceinline__ float u01_open(uint32_t v) { return ((float)(v >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
 __global__ void __launch_bounds__(256) gumbel_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
     const U4 r = draw(seed, offset, (uint64_t)i);
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(256) gumbel_kernel(float* __restrict__ out, in
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t j = i * 4 + e;
-      if (j < n) out[j] = -logf(-logf(u01(v[e])));
+      if (j < n) out[j] = -logf(-logf(u01_open(v[e])));
     }
   }
 }

@@ -32,11 +32,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   for (int k0 = 0; k0 < K; k0 += GK) {
+    // consecutive threads walk the contiguous direction of each operand (k for row-major A / transposed B, else m / n)
     for (int e = threadIdx.x; e < GK * GT; e += 256) {
-      const int kk = e / GT, r = e - kk * GT;
-      const int k = k0 + kk, m = m0 + r, n = n0 + r;
-      As[kk][r] = (k < K && m < M) ? (transA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
-      Bs[kk][r] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
+      {
+        const int kk = transA ? e / GT : e % GK, r = transA ? e % GT : e / GK;
+        const int k = k0 + kk, m = m0 + r;
+        As[kk][r] = (k < K && m < M) ? (transA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k]) : 0.f;
+      }
+      {
+        const int kk = transB ? e % GK : e / GT, r = transB ? e / GK : e % GT;
+        const int k = k0 + kk, n = n0 + r;
+        Bs[kk][r] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -64,6 +71,101 @@ __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M
       *c = accumulate ? *c + v : v;
     }
   }
+}
+
+// dW[O][I] (+)= dy^T x, db[O] (+)= column sums of dy, reducing over the B rows: the batch is split into S slabs across
+// blockIdx.z; every slab writes its partial tile, and the block that takes the last ticket of a tile adds the S partials in
+// slab order (deterministic, no float atomics).  x is seen with a virtual column of ones at index I, whose "weight gradient"
+// is the bias gradient.  tickets: caller-owned int32[tiles], zero before first use, left zero.
+__global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                           int B, int O, int I, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accW, int accB, int S, int chunk, float* __restrict__ partial,
+                                                           int* __restrict__ tickets) {
+  __shared__ float As[GK][GT + 1], Bs[GK][GT + 1];
+  __shared__ int s_last;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int kbeg = blockIdx.z * chunk, kend = min(B, kbeg + chunk);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    for (int e = threadIdx.x; e < GK * GT; e += 256) {
+      const int kk = e / GT, r = e - kk * GT;
+      const int k = k0 + kk, m = m0 + r, n = n0 + r;
+      const bool kin = k < kend;
+      As[kk][r] = (kin && m < O) ? dy[(size_t)k * ldy + m] : 0.f;
+      Bs[kk][r] = !kin ? 0.f : (n < I ? x[(size_t)k * ldx + n] : (n == I ? 1.f : 0.f));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const int NP = I + 1;
+  if (S > 1) {
+    float* mine = partial + (size_t)blockIdx.z * O * NP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+        if (m < O && n < NP) mine[(size_t)m * NP + n] = acc[i][j];
+      }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+      const int t = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == S - 1;
+      if (s_last) tickets[tile] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int z = 0; z < S; ++z) {          // slab order is the summation order; the 16 loads of one slab are independent
+      const float* src = partial + (size_t)z * O * NP;
+      float v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+          v[i][j] = (m < O && n < NP) ? src[(size_t)m * NP + n] : 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += v[i][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m >= O) continue;
+      if (n < I) {
+        float* p = dW + (size_t)m * I + n;
+        *p = accW ? *p + acc[i][j] : acc[i][j];
+      } else if (n == I && db) {
+        db[m] = accB ? db[m] + acc[i][j] : acc[i][j];
+      }
+    }
 }
 
 __global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
@@ -276,6 +378,44 @@ extern "C" int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K,
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
                      A, lda, B, ldb, C, ldc, bias, accumulate);
   return launch_status("gemm_kernel");
+}
+
+namespace {
+struct WgradPlan { int S, chunk, tiles; };
+WgradPlan plan_linear_wgrad(int B, int O, int I) {
+  const int tiles = ((I + 1 + GT - 1) / GT) * ((O + GT - 1) / GT);
+  int S = (256 + tiles - 1) / tiles;                 // aim at ~256 blocks (one per CU) ...
+  const int maxS = (B + 16 * GK - 1) / (16 * GK);    // ... of at least 256 rows each
+  if (S > maxS) S = maxS;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  int chunk = (B + S - 1) / S;
+  chunk = (chunk + GK - 1) / GK * GK;
+  S = (B + chunk - 1) / chunk;
+  return {S, chunk, tiles};
+}
+}  // namespace
+
+extern "C" size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t I) {
+  if (B <= 0 || O <= 0 || I <= 0) return 0;
+  const WgradPlan p = plan_linear_wgrad(B, O, I);
+  return p.S > 1 ? (size_t)p.S * O * (I + 1) * sizeof(float) : 0;
+}
+extern "C" int32_t pcg_linear_wgrad_ticket_count(void) { return 64; }
+
+extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW,
+                                float* db, int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                                pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && dW && B > 0 && O > 0 && I > 0 && ldy >= O && ldx >= I, "pcg_linear_wgrad: bad arguments");
+  const WgradPlan p = plan_linear_wgrad(B, O, I);
+  PCG_REQUIRE(p.tiles <= 64, "pcg_linear_wgrad: layer %dx%d needs %d tiles (limit 64: widths up to 511)", O, I, p.tiles);
+  if (p.S > 1) {
+    PCG_REQUIRE(tickets, "pcg_linear_wgrad: tickets buffer required");
+    if (!workspace || workspace_bytes < pcg_linear_wgrad_workspace_bytes(B, O, I)) { set_error("pcg_linear_wgrad: workspace too small"); return PCG_ERR_WORKSPACE; }
+  }
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((I + 1 + GT - 1) / GT, (O + GT - 1) / GT, p.S), dim3(256), 0, (hipStream_t)stream, dy, ldy, x,
+                     ldx, B, O, I, dW, db, accumulate_w, accumulate_b, p.S, p.chunk, (float*)workspace, tickets);
+  return launch_status("linear_wgrad_kernel");
 }
 
 extern "C" int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream) {

@@ -56,29 +56,17 @@ def _lin_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):
     return ops.gemm(dy, w, B, I, O, lda=ldy if ldy is not None else O, out=out, accumulate=accumulate)
 
 
-def _ones(net, B, device):
-    o = getattr(net, "_ones_buf", None)
-    if o is None or o.numel() < B or o.device != device:
-        o = torch.empty(max(B, 1024), dtype=torch.float32, device=device)
-        ops.fill(o, 1.0)
-        net._ones_buf = o
-    return o
-
-
-def _lin_wgrad(net, lin, x, dy, ldy=None, weight_param=None, dw_out=None):
-    """dW += dy^T x, db += column sums of dy — accumulated into net's flat gradient buffer.  `dw_out`: write dW there
-    instead (spectral-norm layers post-process it)."""
+def _lin_wgrad(net, lin, x, dy, ldy=None, dw_out=None):
+    """dW += dy^T x, db += column sums of dy — one launch, accumulated into net's flat gradient buffer.  `dw_out`: write
+    dW there instead (spectral-norm layers post-process it)."""
     B, I = x.shape
     O = lin.out_features
-    ld = ldy if ldy is not None else O
+    gb, accb = (net._grad_view(lin.bias) if lin.bias is not None and lin.bias.requires_grad else (None, False))
     if dw_out is not None:
-        ops.gemm(dy, x, O, I, B, transA=True, lda=ld, out=dw_out)
+        gw, acc = dw_out, False
     else:
-        gw, acc = net._grad_view(lin.weight if weight_param is None else weight_param)
-        ops.gemm(dy, x, O, I, B, transA=True, lda=ld, out=gw, accumulate=acc)
-    if lin.bias is not None and lin.bias.requires_grad:
-        gb, accb = net._grad_view(lin.bias)
-        ops.gemm(_ones(net, B, x.device), dy, 1, O, B, lda=B, ldb=ld, out=gb, accumulate=accb)   # ones[1,B] . dy[B,O]
+        gw, acc = net._grad_view(lin.weight)
+    ops.linear_wgrad(dy, x, B, O, I, gw, gb, ldy=ldy, accumulate_w=acc, accumulate_b=accb)
 
 
 # ---- generator -------------------------------------------------------------------------------------------------------
@@ -554,6 +542,55 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     opt_g.step()                                                                              # :316
     return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
             "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+
+
+class GraphedTrainStep:
+    """The whole training step — G forward, critic step, G step, both Adam updates, ~400 small kernels — captured once in a
+    HIP graph and replayed with one host call: this path is launch-latency bound, and the graph
+    removes the per-kernel host cost.  Inputs live in static device buffers (`x, y, target_y, mask, noise`): write the next
+    batch into them (`load(...)`, or draw straight into them) and call `replay()`; outputs are the static tensors in `out`.
+    Capture needs warm-up executions of real steps; the parameters, buffers and optimizer state are snapshotted before and
+    restored after, so constructing this object does not advance training."""
+
+    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3):
+        dev = norm_vals.device
+        D_in, T = config["input_dim"], generator.total_cat
+        self.x = torch.zeros((batch, D_in), dtype=torch.float32, device=dev)
+        self.y = torch.zeros((batch,), dtype=torch.int64, device=dev)
+        self.target_y = torch.ones((batch,), dtype=torch.int64, device=dev)
+        self.mask = torch.ones((batch, D_in), dtype=torch.float32, device=dev)
+        self.noise = torch.zeros((batch, T), dtype=torch.float32, device=dev)
+        nets = (generator, discriminator)
+        for n in nets:
+            n._ensure_flat()
+        saved = [(n.flat_params.clone(), [b.clone() for b in n.buffers()]) for n in nets]
+        osnap = [o.snapshot() for o in (opt_g, opt_d)]
+
+        def step():
+            return train_step(generator, discriminator, classifier, opt_g, opt_d, self.x, self.y, self.target_y, self.mask, norm_vals,
+                              config, gumbel=self.noise)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step()
+        for n, (fp, bufs) in zip(nets, saved):
+            n.flat_params.copy_(fp)
+            for b, b0 in zip(n.buffers(), bufs):
+                b.copy_(b0)
+        for o, sn in zip((opt_g, opt_d), osnap):
+            o.restore(sn)
+
+    def load(self, x, y, target_y, mask, noise):
+        self.x.copy_(x); self.y.copy_(y); self.target_y.copy_(target_y); self.mask.copy_(mask); self.noise.copy_(noise)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
 
 
 def draw_batch_randoms(rng, generator, y, config, device):

@@ -88,6 +88,16 @@ def workspace(nbytes, device):
     return buf
 
 
+def workspace2(nbytes, device):
+    """A second cached scratch buffer (slab partials of linear_wgrad), separate from `workspace` so the two never alias."""
+    key = (device.type, device.index, 2)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 def ohwi(w):
     """Physical [O, KH, KW, I] view of a conv parameter of logical shape [O, I, KH, KW] (channels_last memory)."""
     v = w.permute(0, 2, 3, 1)
@@ -390,6 +400,24 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     check(_lib.load().pcg_gemm(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(bool(accumulate)),
                                _stream()), "pcg_gemm")
     return out
+
+
+_tickets = {}
+
+
+def linear_wgrad(dy, x, B, O, I, dW, db=None, ldy=None, ldx=None, accumulate_w=False, accumulate_b=False):
+    """dW[O][I] (+)= dy^T x and db[O] (+)= colsum(dy) in one launch (deterministic slab split over the batch)."""
+    lib = _lib.load()
+    dev = x.device
+    key = (dev.type, dev.index)
+    tk = _tickets.get(key)
+    if tk is None:
+        tk = torch.zeros(lib.pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=dev)   # setup: zeroed once, kernels keep it zero
+        _tickets[key] = tk
+    nbytes = lib.pcg_linear_wgrad_workspace_bytes(B, O, I)
+    ws = workspace2(nbytes, dev) if nbytes else None
+    check(lib.pcg_linear_wgrad(_p(dy), ldy if ldy is not None else O, _p(x), ldx if ldx is not None else I, B, O, I, _p(dW), _p(db),
+                               int(bool(accumulate_w)), int(bool(accumulate_b)), _p(ws), nbytes, _p(tk), _stream()), "pcg_linear_wgrad")
 
 
 def onehot(idx, K):

@@ -122,6 +122,26 @@ class Adam(torch.optim.Optimizer):
             for st in built:
                 ops.fill(st["grad"], 0.0)
 
+    # -- state snapshot (used around HIP-graph warm-up, which has to execute real steps before capture) ---------------
+    def snapshot(self):
+        """Copies of (exp_avg, exp_avg_sq, step) per segment, or None if no step has built the state yet."""
+        if self._segments is None:
+            return None
+        return [[(st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone()) for st in built] for built in self._segments]
+
+    def restore(self, snap):
+        """Put the state back (snap=None: back to 'never stepped' — zero moments, step 0 — keeping the buffers, so a
+        captured graph that references them stays valid)."""
+        if self._segments is None:
+            return
+        for gi, built in enumerate(self._segments):
+            for si, st in enumerate(built):
+                if snap is None:
+                    ops.fill(st["exp_avg"], 0.0); ops.fill(st["exp_avg_sq"], 0.0); st["step"].zero_()
+                else:
+                    ea, es, stp = snap[gi][si]
+                    st["exp_avg"].copy_(ea); st["exp_avg_sq"].copy_(es); st["step"].copy_(stp)
+
     # number of kernel launches a step() issues (for tests / DESIGN.md)
     def num_segments(self):
         if self._stale():

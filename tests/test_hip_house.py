@@ -62,6 +62,33 @@ def test_gemm_all_layouts(pcg):
     _close(Cd, ref, 2e-5, 2e-5)
 
 
+def test_linear_wgrad_slab_split(pcg):
+    """pcg_linear_wgrad: weight and bias gradient in one launch; batches from one slab to many; strided dy; accumulate;
+    repeated calls (the ticket buffer must come back zero) and bit-identical results run to run (fixed slab order)."""
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(11)
+    for (B, O, I) in [(1, 1, 1), (64, 32, 38), (128, 9, 32), (1000, 32, 21), (4096, 256, 256), (5000, 64, 128), (20000, 1, 128), (777, 13, 32)]:
+        dy, x = torch.randn(B, O + 5, generator=g), torch.randn(B, I, generator=g)
+        dW0, db0 = torch.randn(O, I, generator=g), torch.randn(O, generator=g)
+        refW = dy[:, 2:2 + O].double().T @ x.double()
+        refb = dy[:, 2:2 + O].double().sum(0)
+        dyd, xd = _dev(dy), _dev(x)
+        tolW, tolb = 3e-6 * float(refW.abs().max()) + 1e-6, 3e-6 * float(refb.abs().max()) + 1e-6   # fp32 sums over B rows
+        outs = []
+        for rep in range(2):
+            dW, db = torch.empty(O, I, device=DEV), torch.empty(O, device=DEV)
+            ops.linear_wgrad(dyd[:, 2:], xd, B, O, I, dW, db, ldy=O + 5)
+            _close(dW, refW, 2e-5, tolW * 10, f"dW {B}x{O}x{I}"); _close(db, refb, 2e-5, tolb * 10, f"db {B}x{O}x{I}")
+            outs.append((dW.clone(), db.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        dW, db = _dev(dW0), _dev(db0)
+        ops.linear_wgrad(dyd[:, 2:], xd, B, O, I, dW, db, ldy=O + 5, accumulate_w=True, accumulate_b=True)
+        _close(dW, refW + dW0.double(), 2e-5, tolW * 10); _close(db, refb + db0.double(), 2e-5, tolb * 10)
+        dW = torch.empty(O, I, device=DEV)
+        ops.linear_wgrad(dyd[:, 2:], xd, B, O, I, dW, None, ldy=O + 5)                     # no bias
+        assert torch.equal(dW, outs[0][0])
+
+
 def test_tabular_elementwise_ops(pcg):
     ops = pcg.ops
     g = torch.Generator().manual_seed(2)
@@ -285,6 +312,33 @@ def test_skip_dead_d_wgrad_is_equivalent(pcg, hgold):
         states.append({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}})
     for k in states[0]:
         assert torch.equal(states[0][k], states[1][k]), k
+
+
+def test_graphed_step_equals_eager(pcg, hgold):
+    """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
+    it (warm-up + capture) does not advance the training state."""
+    H = pcg.house
+    batches = [HR.synthetic_batch(128, seed=s) for s in (1, 2, 3)]
+    states = []
+    for graphed in (False, True):
+        G, D, C = _load_golden_nets(pcg, hgold)
+        opt_g, opt_d = H.make_optimizers(G, D)
+        norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, 128) if graphed else None
+        losses = []
+        for (x, y, t, m, gumbel) in batches:
+            noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
+            if graphed:
+                gs.load(_dev(x), _dev(y), _dev(t), _dev(m), noise)
+                out = gs.replay()
+            else:
+                out = H.train_step(G, D, C, opt_g, opt_d, _dev(x), _dev(y), _dev(t), _dev(m), norm, gumbel=noise)
+            losses.append((out["D_loss"].item(), out["G_loss"].item()))
+        states.append(({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}},
+                       losses))
+    assert states[0][1] == states[1][1], (states[0][1], states[1][1])
+    for k in states[0][0]:
+        assert torch.equal(states[0][0][k], states[1][0][k]), k
 
 
 def test_trained_checkpoints_eval_forward(pcg, golden_dir):
