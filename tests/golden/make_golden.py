@@ -382,6 +382,84 @@ def make_house_trained(path_npz, path_g, path_c, bs=32):
         os.chdir(cwd)
 
 
+def make_wgan_small(path, width=16, batch=6, steps=3):
+    """conditional_gan/mnist/mnist_wgan_conditional.py cannot be imported (torchvision, torch.cuda.get_device_name, dataset and
+    training at import), so — as for DCGAN — its pure-torch pieces are lifted out of the syntax tree and executed unmodified,
+    with every "cuda" string constant turned into "cpu":
+      * Hyperparameter :21-31 + `hp = Hyperparameter()` :34, Generator :51-78, Critic :80-108
+      * nets / optimizers / all_labels / grad_tensor                      :116-126
+      * the body of the inner loop up to generator_optimizer.step()        :133-168
+    at reduced width (critic_size = generator_size = critic_hidden_size = `width`).  The loop draws noise / alpha / labels
+    from the global RNG; each step is seeded and the draws are replayed in the same order to record them."""
+    path_src = os.path.join(REF, "conditional_gan/mnist/mnist_wgan_conditional.py")
+    with open(path_src) as f:
+        tree = ast.parse(f.read(), filename=path_src)
+
+    class _Cpu(ast.NodeTransformer):
+        def visit_Constant(self, node):
+            return ast.copy_location(ast.Constant("cpu"), node) if node.value == "cuda" else node
+    tree = ast.fix_missing_locations(_Cpu().visit(tree))
+    hp_nodes, defs, setup, body = [], [], [], []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "Hyperparameter" or (isinstance(node, ast.Assign) and node.lineno == 34):
+            hp_nodes.append(node)
+        elif isinstance(node, ast.ClassDef) and node.name in ("Generator", "Critic"):
+            defs.append(node)
+        elif isinstance(node, ast.Assign) and node.lineno in (116, 118, 119, 123, 126):
+            setup.append(node)
+        elif isinstance(node, ast.For) and node.lineno == 129:
+            inner = [n for n in node.body if isinstance(n, ast.For)]
+            assert len(inner) == 1 and inner[0].lineno == 132, "reference layout changed"
+            body = [n for n in inner[0].body if 133 <= n.lineno <= 168]
+    assert len(hp_nodes) == 2 and len(defs) == 2 and len(setup) == 5 and body and body[-1].end_lineno == 168
+    from dataclasses import dataclass
+    ns = {"torch": torch, "nn": torch.nn, "optim": torch.optim, "autograd": torch.autograd, "dataclass": dataclass}
+    exec(compile(ast.Module(body=hp_nodes, type_ignores=[]), path_src, "exec"), ns)
+    hp = ns["hp"]
+    hp.critic_size = hp.generator_size = hp.critic_hidden_size = width
+    hp.batchsize = batch
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path_src, "exec"), ns)
+    torch.manual_seed(1)                                                   # :13
+    exec(compile(ast.Module(body=setup, type_ignores=[]), path_src, "exec"), ns)
+    critic, generator = ns["critic"], ns["generator"]
+    step_code = compile(ast.Module(body=body, type_ignores=[]), path_src, "exec")
+    out = {"meta.width": np.int64(width), "meta.batch": np.int64(batch), "meta.steps": np.int64(steps), "meta.n_critic": np.int64(hp.n_critic)}
+    _sd("init.C", critic, out)
+    _sd("init.G", generator, out)
+    for k in range(steps):
+        gen = torch.Generator().manual_seed(300 + k)
+        real = torch.rand(batch, 1, 28, 28, generator=gen) * 2 - 1
+        labels = torch.randint(0, hp.num_classes, (batch,), generator=gen)
+        torch.manual_seed(2000 + k)                                        # replay of the draws, in the loop body's order
+        noise = torch.randn((batch, hp.latent_size)); alpha = torch.rand((batch, 1))
+        g_step = k % hp.n_critic == 0
+        if g_step:
+            fake_idx = torch.randint(hp.num_classes, size=[batch]); noise_g = torch.randn((batch, hp.latent_size))
+        torch.manual_seed(2000 + k)
+        ns["data"], ns["batch_idx"] = (real, labels), k
+        exec(step_code, ns)
+        assert torch.equal(ns["alpha"], alpha) and torch.equal(ns["noise"], noise_g if g_step else noise)
+        out.update({f"step{k}.real": real.numpy(), f"step{k}.labels": labels.numpy(), f"step{k}.noise": noise.numpy(),
+                    f"step{k}.alpha": alpha.numpy(), f"step{k}.critic_loss": np.float32(ns["critic_loss"].item()),
+                    f"step{k}.gradient_penalty": np.float32(ns["gradient_penalty"].item()),
+                    f"step{k}.loss_real": np.float32(ns["critic_loss_real"].item()),
+                    f"step{k}.gradients": ns["gradients"].detach().numpy().copy()})
+        if g_step:
+            out.update({f"step{k}.fake_idx": fake_idx.numpy(), f"step{k}.noise_g": noise_g.numpy(),
+                        f"step{k}.generator_loss": np.float32(ns["generator_loss"].item())})
+        if k == 0:       # gradients right after the first critic+generator update (critic .grad = critic-step grads + the G step's)
+            for n_, p_ in critic.named_parameters():
+                out[f"step0.grad.C.{n_}"] = p_.grad.detach().numpy().copy()
+            for n_, p_ in generator.named_parameters():
+                out[f"step0.grad.G.{n_}"] = p_.grad.detach().numpy().copy()
+    _sd("final.C", critic, out)
+    _sd("final.G", generator, out)
+    for n_, p_ in critic.named_parameters():
+        out[f"final.grad.C.{n_}"] = p_.grad.detach().numpy().copy()      # last step had no G update: pure critic-step gradients
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -392,3 +470,4 @@ if __name__ == "__main__":
     make_house(os.path.join(HERE, "house_ref_b64.npz"))
     make_house_trained(os.path.join(HERE, "house_trained_eval.npz"), os.path.join(HERE, "house_generator_trained.pt"),
                        os.path.join(HERE, "house_classifier_trained.pt"))
+    make_wgan_small(os.path.join(HERE, "wgan_ref_small.npz"))

@@ -48,6 +48,17 @@ CONV_CASES = [
     (3, 3, 64, 28, 28, 3, 1, 1),       # conv_in (thin Cin=3)
     (3, 64, 1, 28, 28, 3, 1, 1),       # conv_out (thin Cout)
     (3, 2, 64, 28, 28, 3, 2, 1),       # D entry (thin Cin=2)
+    # WGAN-GP shapes (conditional_gan/mnist/mnist_wgan_conditional.py:51-108)
+    (2, 1, 256, 28, 28, 3, 2, 0),      # critic conv1 (thin Cin, no padding, 28 -> 13)
+    (2, 256, 512, 13, 13, 3, 2, 0),    # critic conv2 13 -> 6
+    (2, 512, 1024, 6, 6, 3, 2, 0),     # critic conv3 6 -> 2
+    (3, 8192, 1024, 1, 1, 1, 1, 0),    # critic Linear 8192 -> 1024 as a 1x1 conv
+    (2, 1024, 1024, 4, 4, 4, 1, 0),    # G ConvT(1024,1024,4,1,0) adjoint
+    (2, 512, 1024, 7, 7, 3, 2, 1),     # G ConvT(1024,512,3,2,1) adjoint (4 -> 7)
+    (2, 256, 512, 14, 14, 4, 2, 1),    # G ConvT(512,256,4,2,1) adjoint
+    (2, 1, 256, 28, 28, 4, 2, 1),      # G ConvT(256,1,4,2,1) adjoint (thin)
+    (3, 4, 8, 13, 13, 3, 2, 0), (3, 8, 16, 6, 6, 3, 2, 0), (3, 1, 4, 28, 28, 3, 2, 0),   # reduced-width golden critic
+    (3, 8, 16, 7, 7, 3, 2, 1), (3, 4, 8, 14, 14, 4, 2, 1), (3, 1, 4, 28, 28, 4, 2, 1), (3, 16, 16, 4, 4, 4, 1, 0),  # reduced G
     # ragged / tiny: partial tiles in M, N and K
     (1, 4, 4, 5, 5, 3, 1, 1),
     (2, 36, 20, 6, 10, 3, 2, 1),

@@ -228,3 +228,53 @@ def test_house_trained_checkpoints_eval_forward(golden_dir):
     for f in gumbel:
         np.testing.assert_allclose(logits[f].numpy(), gold[f"logits.{f}"], rtol=1e-5, atol=1e-5)
         np.testing.assert_array_equal(samples[f].numpy(), gold[f"samples.{f}"])          # one-hot: exact
+
+
+# ---- conditional WGAN-GP: oracle/wgan_ref.py against the reference's own classes + loop body at reduced width -------------
+from oracle import wgan_ref as WR  # noqa: E402
+
+
+def test_wgan_gp_steps_match_reference_loop(golden_dir):
+    gold = dict(np.load(os.path.join(golden_dir, "wgan_ref_small.npz")))
+    w, steps = int(gold["meta.width"]), int(gold["meta.steps"])
+    hp = WR.Hyperparameter(critic_size=w, generator_size=w, critic_hidden_size=w, batchsize=int(gold["meta.batch"]))
+    critic, generator = WR.build(hp, seed=1)
+    for k, v in critic.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), gold[f"init.C.{k}"], err_msg=k)       # same construction order, same seed (:13,:116)
+    for k, v in generator.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), gold[f"init.G.{k}"], err_msg=k)
+    c_opt, g_opt = WR.make_optimizers(critic, generator)
+    eye = torch.eye(hp.num_classes)
+    for k in range(steps):
+        real, labels = torch.from_numpy(gold[f"step{k}.real"]), torch.from_numpy(gold[f"step{k}.labels"])
+        out = WR.critic_step(critic, generator, c_opt, hp, real, eye[labels], torch.from_numpy(gold[f"step{k}.noise"]),
+                             torch.from_numpy(gold[f"step{k}.alpha"]))
+        gg = gold[f"step{k}.gradients"]       # steps after the first start from weights that already differ by Adam's fp32 noise
+        np.testing.assert_allclose(out["gradients"].numpy(), gg, rtol=1e-4, atol=2e-5 * np.abs(gg).max())
+        for name in ("critic_loss", "gradient_penalty", "loss_real"):
+            np.testing.assert_allclose(out[name], gold[f"step{k}.{name}"], rtol=2e-5, atol=1e-6, err_msg=f"step{k}.{name}")
+        if k % hp.n_critic == 0:
+            g = WR.generator_step(critic, generator, g_opt, eye[torch.from_numpy(gold[f"step{k}.fake_idx"])],
+                                  torch.from_numpy(gold[f"step{k}.noise_g"]))
+            np.testing.assert_allclose(g["generator_loss"], gold[f"step{k}.generator_loss"], rtol=2e-5, atol=1e-6)
+        if k == 0:
+            for net, tag in ((critic, "C"), (generator, "G")):
+                scale = max(float(np.abs(gold[f"step0.grad.{tag}.{n}"]).max()) for n, _ in net.named_parameters())
+                for n, p in net.named_parameters():
+                    ref = gold[f"step0.grad.{tag}.{n}"]
+                    # floor relative to the net's largest gradient: a conv bias in front of InstanceNorm / BatchNorm has a true
+                    # gradient of exactly 0, and what any fp32 run stores there is summation noise
+                    np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max() + 3e-6 * scale, err_msg=f"{tag}.{n}")
+    scale = max(float(np.abs(gold[f"final.grad.C.{n}"]).max()) for n, _ in critic.named_parameters())
+    for n, p in critic.named_parameters():
+        ref = gold[f"final.grad.C.{n}"]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max() + 3e-6 * scale, err_msg=n)
+    for net, tag in ((critic, "C"), (generator, "G")):
+        dead = {n for n, _ in net.named_parameters() if np.abs(gold.get(f"step0.grad.{tag}.{n}", np.ones(1))).max() < 1e-4}
+        for k_, v in net.state_dict().items():
+            if k_ in dead:      # zero-gradient biases: AdamW(beta1=0) turns the noise sign into a +-lr move per step
+                assert np.abs(v.numpy() - gold[f"final.{tag}.{k_}"]).max() <= 2.2 * 1e-4 * steps, k_
+                continue
+            # a BatchNorm running_mean inherits the +-lr wander of the dead conv bias in front of it
+            atol = 1e-4 if k_.endswith("running_mean") else 2e-5
+            np.testing.assert_allclose(v.numpy(), gold[f"final.{tag}.{k_}"], rtol=1e-4, atol=atol, err_msg=f"final.{tag}.{k_}")
