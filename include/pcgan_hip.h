@@ -270,6 +270,32 @@ int pcg_spectral_norm_fwd(const float* w_orig, int32_t out_features, int32_t in_
 int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, int32_t out_features, int32_t in_features, const float* u,
                           const float* v, const float* sigma, float* dw_orig, int accumulate, pcg_stream_t stream);
 
+/* ---- conditional WGAN-GP (conditional_gan/mnist/mnist_wgan_conditional.py), SURVEY.md section 8a row a14 -----------------
+ * nn.InstanceNorm2d(C, affine=True) (:88,91,94) on an NHWC activation [B][HW][C]: statistics per (sample, channel) over HW,
+ * biased variance, eps inside the square root; `act` fuses the LeakyReLU(0.2) that follows (:89,92,95). */
+int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C, const float* gamma, const float* beta, float eps, int act,
+                     float slope, float* y, float* mean /*[B*C]*/, float* invstd /*[B*C]*/, pcg_stream_t stream);
+/* backward: dx (nullable); per-sample partial sums dgamma_partial / dbeta_partial [B][C] (nullable; reduce over B with pcg_colsum) */
+int pcg_instnorm_bwd(const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean, const float* invstd,
+                     const float* gamma, float* dx, float* dgamma_partial, float* dbeta_partial, pcg_stream_t stream);
+/* backward of pcg_instnorm_bwd — what autograd.grad(..., create_graph=True) + critic_loss.backward() (:149,154) need: with r
+ * the cotangent on dx, returns the cotangents reaching dy (ddy), x (ez) and gamma (per-sample partials); any may be NULL. */
+int pcg_instnorm_bwd_bwd(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,
+                         const float* invstd, const float* gamma, float* ddy, float* ez, float* dgamma_partial, pcg_stream_t stream);
+/* nn.Flatten of an NCHW tensor (:96) from the NHWC activation, flat[b][c*HW + p] = act[b][p][c]; inverse != 0: the other way */
+int pcg_nhwc_to_nchw_flat(const float* src, float* dst, int32_t B, int32_t HW, int32_t C, int inverse, pcg_stream_t stream);
+/* interpolates = alpha*real + (1-alpha)*fake, alpha per sample (:147) */
+int pcg_interpolate(const float* alpha, const float* real, const float* fake, float* out, int32_t B, int32_t per_sample,
+                    pcg_stream_t stream);
+/* gradient penalty lambda * mean_b (||g_b||_2 - 1)^2 (:150): forward keeps the per-sample norms for the backward,
+ * dg = grad_out * 2*lambda/B * (||g_b|| - 1) * g_b / ||g_b|| */
+int pcg_gradient_penalty_fwd(const float* grads, int32_t B, int32_t per_sample, float lambda, float* norms /*[B]*/, float* penalty /*[1]*/,
+                             pcg_stream_t stream);
+int pcg_gradient_penalty_bwd(const float* grads, const float* norms, const float* grad_out_dev /*nullable = 1*/, int32_t B,
+                             int32_t per_sample, float lambda, float* dgrads, pcg_stream_t stream);
+/* torch.rand: uniform [0, 1) — the interpolation coefficients alpha (:146) */
+int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ from torch.nn.utils import spectral_norm
 from . import ops
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
 from .countergan import CrossEntropyLoss, abs_mean, grad_norm  # noqa: F401  (same loss kernels)
-from .nn import FlatModule
+from .nn import FlatModule, affine_fwd, linear_dgrad as _lin_dgrad, linear_fwd as _lin_fwd, linear_wgrad as _lin_wgrad, mean  # noqa: F401
 from .optim import Adam
 
 FEATURES = ["bedrooms", "bathrooms", "sqft_living", "sqft_lot", "floors", "waterfront", "view", "condition", "grade",
@@ -42,31 +42,6 @@ CONFIG["continuous_idx"] = [i for i in range(17) if i not in CONFIG["categorical
 
 def _ncat(info):
     return int(info["n"]) if isinstance(info, dict) else int(info)
-
-
-# ---- Linear helpers: rows of activations x [B, in] against an [out, in] weight ------------------------------------------
-def _lin_fwd(lin, x, weight=None, out=None, ldc=None):
-    w = lin.weight.data if weight is None else weight
-    B = x.shape[0]
-    return ops.gemm(x, w, B, w.shape[0], w.shape[1], transB=True, bias=lin.bias.data if lin.bias is not None else None, out=out, ldc=ldc)
-
-
-def _lin_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):
-    O, I = w.shape
-    return ops.gemm(dy, w, B, I, O, lda=ldy if ldy is not None else O, out=out, accumulate=accumulate)
-
-
-def _lin_wgrad(net, lin, x, dy, ldy=None, dw_out=None):
-    """dW += dy^T x, db += column sums of dy — one launch, accumulated into net's flat gradient buffer.  `dw_out`: write
-    dW there instead (spectral-norm layers post-process it)."""
-    B, I = x.shape
-    O = lin.out_features
-    gb, accb = (net._grad_view(lin.bias) if lin.bias is not None and lin.bias.requires_grad else (None, False))
-    if dw_out is not None:
-        gw, acc = dw_out, False
-    else:
-        gw, acc = net._grad_view(lin.weight)
-    ops.linear_wgrad(dy, x, B, O, I, gw, gb, ldy=ldy, accumulate_w=acc, accumulate_b=accb)
 
 
 # ---- generator -------------------------------------------------------------------------------------------------------
@@ -323,21 +298,6 @@ class _MaskMulFn(torch.autograd.Function):
         return ops.scale_mask_bwd(None, dsum, ctx.mask, 1.0, like=ctx.mask), None, None
 
 
-class _MeanFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        ctx.like = x
-        return ops.mean_fwd(x.contiguous()).view(())
-
-    @staticmethod
-    def backward(ctx, g):
-        return ops.mean_bwd(g.contiguous(), 1.0, ctx.like)
-
-
-def mean(x):
-    return _MeanFn.apply(x)
-
-
 # ---- discriminator ------------------------------------------------------------------------------------------------------
 class _DFn(torch.autograd.Function):
     @staticmethod
@@ -403,7 +363,7 @@ class Discriminator(FlatModule):
                 d = ops.act_bwd(d, z, ACT_LRELU, 0.2)
             if need_p and lin.weight_orig.requires_grad:
                 dwb = torch.empty_like(w_bar)
-                _lin_wgrad(self, lin, a, d, dw_out=dwb)
+                _lin_wgrad(self, lin, a, d, dw_out=dwb, weight_param=lin.weight_orig)
                 gw, acc = self._grad_view(lin.weight_orig)
                 ops.spectral_norm_bwd(dwb, w_bar, u, v, sigma, gw, acc)
             if i > 0 or need_x:
@@ -478,7 +438,7 @@ class NNClassifier(nn.Module):
         B = a.shape[0]
         acts = []
         for i, (w, b) in enumerate(packed):
-            z = ops.gemm(a, w, B, w.shape[0], w.shape[1], transB=True, bias=b)
+            z = affine_fwd(a, w, b)
             if i + 1 < len(packed):
                 ops.act_fwd(z, ACT_LRELU, 0.1, out=z)
                 if keep:

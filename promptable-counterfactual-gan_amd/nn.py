@@ -360,6 +360,81 @@ class HipSequential(SequentialConvNet):
         return list(self.children())[i]
 
 
+# ---- nn.Linear on rows [B, in] --------------------------------------------------------------------------------------------
+def _lin_mfma(B, I, O):
+    """Big layers go through the MFMA implicit-GEMM kernels as 1x1 convolutions (they need in_features % 4 == 0); narrow,
+    ragged (widths 1, 10, 17, 21, 38 ...) or tiny ones through the bounds-checked small GEMM."""
+    return I % 4 == 0 and I >= 64 and O >= 32 and B * I * O >= (1 << 24)
+
+
+def affine_fwd(x, w, bias=None):
+    """y = x w^T (+ bias) for a raw [out, in] weight (frozen / folded layers)."""
+    B = x.shape[0]
+    O, I = w.shape
+    if _lin_mfma(B, I, O):
+        return ops.conv2d_fwd(ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0), x, w, bias).view(B, O)
+    return ops.gemm(x, w, B, O, I, transB=True, bias=bias)
+
+
+def linear_fwd(lin, x, weight=None, out=None, ldc=None, use_bias=True):
+    """y = x W^T (+ b).  `weight` overrides lin.weight (spectral-norm layers pass W / sigma)."""
+    w = lin.weight.data if weight is None else weight
+    B = x.shape[0]
+    O, I = w.shape
+    bias = lin.bias.data if (use_bias and lin.bias is not None) else None
+    if out is None and _lin_mfma(B, I, O):
+        g = ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0)
+        return ops.conv2d_fwd(g, x, w, bias).view(B, O)
+    return ops.gemm(x, w, B, O, I, transB=True, bias=bias, out=out, ldc=ldc)
+
+
+def linear_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):
+    """dx = dy W (optionally accumulated into `out`)."""
+    O, I = w.shape
+    if ldy is None and out is None and _lin_mfma(B, I, O):
+        g = ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0)
+        return ops.conv2d_dgrad(g, dy, w).view(B, I)
+    return ops.gemm(dy, w, B, I, O, lda=ldy if ldy is not None else O, out=out, accumulate=accumulate)
+
+
+def linear_wgrad(net, lin, x, dy, ldy=None, dw_out=None, weight_param=None, use_bias=True):
+    """dW += dy^T x, db += column sums of dy, accumulated into net's flat gradient buffer.  `dw_out`: write dW there
+    instead (spectral-norm layers post-process it); `weight_param`: the parameter that owns the weight gradient when it is
+    not `lin.weight` (spectral norm: weight_orig)."""
+    B, I = x.shape
+    O = lin.out_features
+    wp = weight_param if weight_param is not None else getattr(lin, "weight", None)
+    has_b = use_bias and lin.bias is not None and lin.bias.requires_grad
+    gb, accb = net._grad_view(lin.bias) if has_b else (None, False)
+    if dw_out is not None:
+        gw, acc = dw_out, False
+    else:
+        gw, acc = net._grad_view(wp)
+    if ldy is None and _lin_mfma(B, I, O):
+        g = ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0)
+        ops.conv2d_wgrad(g, x, dy, gw, acc)
+        if gb is not None:
+            ops.colsum(B, O, dy, gb, accb)
+        return
+    ops.linear_wgrad(dy, x, B, O, I, gw, gb, ldy=ldy, accumulate_w=acc, accumulate_b=accb)
+
+
+class _MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.like = x
+        return ops.mean_fwd(x.contiguous()).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.mean_bwd(g.contiguous(), 1.0, ctx.like)
+
+
+def mean(x):
+    """tensor.mean() of a critic output (Wasserstein losses)."""
+    return _MeanFn.apply(x)
+
+
 class BCELoss(nn.Module):
     """nn.BCELoss() (reduction='mean') on the HIP kernel (mnist_dcgan.py:125)."""
 

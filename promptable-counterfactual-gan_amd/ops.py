@@ -530,6 +530,70 @@ def spectral_norm_bwd(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate):
                                             _stream()), "pcg_spectral_norm_bwd")
 
 
+# ---- WGAN-GP critic pieces (csrc/instnorm.hip) ----------------------------------------------------------------------------
+def instnorm_fwd(x, B, HW, C, gamma, beta, eps, act=0, slope=0.0):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(B * C, dtype=torch.float32, device=x.device)
+    check(_lib.load().pcg_instnorm_fwd(_p(x), B, HW, C, _p(gamma), _p(beta), float(eps), act, float(slope), _p(y), _p(mean), _p(invstd),
+                                       _stream()), "pcg_instnorm_fwd")
+    return y, mean, invstd
+
+
+def instnorm_bwd(dy, x, B, HW, C, mean, invstd, gamma, need_dx=True, need_params=True):
+    """(dx, dgamma_partial [B,C], dbeta_partial [B,C])"""
+    _chk(dy, "dy"); _chk(x, "x")
+    dx = torch.empty_like(x) if need_dx else None
+    dgp = torch.empty((B, C), dtype=torch.float32, device=x.device) if need_params else None
+    dbp = torch.empty((B, C), dtype=torch.float32, device=x.device) if need_params else None
+    check(_lib.load().pcg_instnorm_bwd(_p(dy), _p(x), B, HW, C, _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgp), _p(dbp), _stream()),
+          "pcg_instnorm_bwd")
+    return dx, dgp, dbp
+
+
+def instnorm_bwd_bwd(r, dy, x, B, HW, C, mean, invstd, gamma, need_ddy=True, need_ez=True, need_gamma=True):
+    """(ddy, ez, dgamma_partial [B,C])"""
+    _chk(r, "r"); _chk(dy, "dy"); _chk(x, "x")
+    ddy = torch.empty_like(x) if need_ddy else None
+    ez = torch.empty_like(x) if need_ez else None
+    dgp = torch.empty((B, C), dtype=torch.float32, device=x.device) if need_gamma else None
+    check(_lib.load().pcg_instnorm_bwd_bwd(_p(r), _p(dy), _p(x), B, HW, C, _p(mean), _p(invstd), _p(gamma), _p(ddy), _p(ez), _p(dgp),
+                                           _stream()), "pcg_instnorm_bwd_bwd")
+    return ddy, ez, dgp
+
+
+def nhwc_to_nchw_flat(src, B, HW, C, inverse=False):
+    _chk(src, "src")
+    dst = torch.empty_like(src)
+    check(_lib.load().pcg_nhwc_to_nchw_flat(_p(src), _p(dst), B, HW, C, int(bool(inverse)), _stream()), "pcg_nhwc_to_nchw_flat")
+    return dst
+
+
+def interpolate(alpha, real, fake):
+    _chk(alpha, "alpha"); _chk(real, "real"); _chk(fake, "fake")
+    B = alpha.numel()
+    out = torch.empty_like(real)
+    check(_lib.load().pcg_interpolate(_p(alpha), _p(real), _p(fake), _p(out), B, real.numel() // B, _stream()), "pcg_interpolate")
+    return out
+
+
+def gradient_penalty_fwd(grads, B, lam):
+    _chk(grads, "grads")
+    norms = torch.empty(B, dtype=torch.float32, device=grads.device)
+    pen = torch.empty(1, dtype=torch.float32, device=grads.device)
+    check(_lib.load().pcg_gradient_penalty_fwd(_p(grads), B, grads.numel() // B, float(lam), _p(norms), _p(pen), _stream()),
+          "pcg_gradient_penalty_fwd")
+    return pen, norms
+
+
+def gradient_penalty_bwd(grads, norms, grad_out, B, lam):
+    dg = torch.empty_like(grads)
+    check(_lib.load().pcg_gradient_penalty_bwd(_p(grads), _p(norms), _p(grad_out), B, grads.numel() // B, float(lam), _p(dg), _stream()),
+          "pcg_gradient_penalty_bwd")
+    return dg
+
+
 # ---- device-side batch synthesis ---------------------------------------------------------------------------------
 class DeviceRNG:
     """Counter-based stream: every draw advances `offset`, so a (seed, call sequence) pair is reproducible."""
@@ -576,4 +640,11 @@ class DeviceRNG:
         nz = 0 if zero_cols is None else zero_cols.numel()
         check(_lib.load().pcg_feature_mask(_p(out), B, D, _p(zero_cols), nz, self.seed, self._advance((B * D + 3) // 4), _stream()),
               "pcg_feature_mask")
+        return out
+
+    def rand(self, shape, device):
+        """torch.rand: uniform [0, 1) (WGAN-GP interpolation coefficients, mnist_wgan_conditional.py:146)."""
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        check(_lib.load().pcg_rand_uniform(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_uniform")
         return out
