@@ -78,6 +78,14 @@ int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const
                    float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x /*nullable: added per Cin channel (ConvTranspose2d bias)*/,
                      float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+/* The same with the activation that follows the layer fused into the output write — y = act(conv(x) + bias):
+ * Conv2d + LeakyReLU (mnist_dcgan.py:100-101, counteRGAN models/discriminator.py:17-24, generator.py:36-37,50),
+ * Conv2d + ReLU (models/classifier.py:7-12), Conv2d + Sigmoid (mnist_dcgan.py:110-111), ConvTranspose2d + Tanh
+ * (mnist_dcgan.py:88-89, mnist_wgan_conditional.py:70-71).  The backward needs only y (pcg_act_bwd). */
+int pcg_conv2d_fwd_act(const pcg_conv_geom* g, const float* x, const float* w, const float* bias /*nullable*/, int act, float slope,
+                       float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_dgrad_act(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x /*nullable*/, int act, float slope,
+                         float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g);
 /* dw[co,kh,kw,ci] (+)= sum_{b,oh,ow} dy[b,oh,ow,co] * x[b,oh*s-p+kh,ow*s-p+kw,ci];  accumulate!=0 adds into dw
  * (the reference accumulates .grad over two backward() calls: mnist_dcgan.py:153,161).             */
@@ -209,6 +217,9 @@ int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t* zero_cols 
 
 /* ---- helpers ---------------------------------------------------------------------------------- */
 int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);
+/* x[r][c] += bias[c] in place — the bias of a ConvTranspose2d that is run as one plain GEMM (a 1x1 input: all KH*KW output
+ * positions of a channel share the bias; mnist_dcgan.py:76, mnist_wgan_conditional.py:61) */
+int pcg_add_bias_rows(float* x, int64_t rows, int32_t C, const float* bias, pcg_stream_t stream);
 /* out[0] (+)= sum p[i]^2   (grad_norm diagnostic: mnist/trainer.py:41-42) */
 int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream);
 

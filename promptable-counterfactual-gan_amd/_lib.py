@@ -45,6 +45,8 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_act": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_act": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_fwd_bn_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_dgrad_bn_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -80,6 +82,7 @@ PROTOTYPES = {
     "pcg_randint": (_i, [_vp, _i64, _c.c_int32, _c.c_int32, _vp, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_randn": (_i, [_vp, _i64, _f, _f, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
+    "pcg_add_bias_rows": (_i, [_vp, _i64, _i32, _vp, _vp]),
     "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
     "pcg_instnorm_fwd": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "pcg_instnorm_bwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

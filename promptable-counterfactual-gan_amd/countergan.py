@@ -46,10 +46,10 @@ def _geom(conv, B, H, W):
     return ops.conv_geom(B, H, W, conv.in_channels, conv.out_channels, k[0], k[1], s[0], p[0])
 
 
-def _conv_fwd(conv, a):
+def _conv_fwd(conv, a, act=ACT_NONE, slope=0.0):
     B, H, W, _ = a.shape
     g = _geom(conv, B, H, W)
-    z = ops.conv2d_fwd(g, a, ops.ohwi(conv.weight.data), conv.bias.data if conv.bias is not None else None)
+    z = ops.conv2d_fwd(g, a, ops.ohwi(conv.weight.data), conv.bias.data if conv.bias is not None else None, act=act, slope=slope)
     return g, z
 
 
@@ -249,8 +249,7 @@ class ResidualGenerator(FlatModule):
         xr, mr = _as_rows(x, B), _as_rows(mask, B)
         slope = float(self.act.negative_slope)
         inp = ops.embed_concat_fwd(xr, target, self.embed.weight.data, mr).view(B, H, W, 3)
-        g_in, h = _conv_fwd(self.conv_in, inp)
-        ops.act_fwd(h, ACT_LRELU, slope, out=h)
+        g_in, h = _conv_fwd(self.conv_in, inp, ACT_LRELU, slope)
         blocks = []
         for blk in self.resblocks:
             g1, z1, a1, m1, s1 = self._conv_bn(blk.conv1, blk.bn1, h, ACT_LRELU, slope)
@@ -258,8 +257,7 @@ class ResidualGenerator(FlatModule):
             if keep:
                 blocks.append((g1, h, z1, a1, m1, s1, g2, z2, m2, s2))
             h = hn
-        g_mid, hm = _conv_fwd(self.conv_mid, h)
-        ops.act_fwd(hm, ACT_LRELU, slope, out=hm)
+        g_mid, hm = _conv_fwd(self.conv_mid, h, ACT_LRELU, slope)
         g_out, c = _conv_fwd(self.conv_out, hm)
         raw, masked = ops.scale_mask_fwd(c, mr, self.residual_scaling)
         saved = (inp, g_in, blocks, h, g_mid, hm, g_out, mr, target) if keep else None
@@ -347,8 +345,7 @@ class Discriminator(FlatModule):
         a = ops.embed_concat_fwd(_as_rows(x, B), cond_idx, self.cond_embed.weight.data, None).view(B, H, W, 2)
         layers = []
         for conv in self._convs():
-            g, z = _conv_fwd(conv, a)
-            ops.act_fwd(z, ACT_LRELU, 0.2, out=z)
+            g, z = _conv_fwd(conv, a, ACT_LRELU, 0.2)
             if keep:
                 layers.append((g, a, z))
             a = z
@@ -453,15 +450,13 @@ class CNNClassifier(nn.Module):
         for conv, w, b in cw:
             Bq, H, W, _ = a.shape
             g = _geom(conv, B, H, W)
-            z = ops.conv2d_fwd(g, a, w, b)
-            ops.act_fwd(z, ACT_RELU, 0.0, out=z)
+            z = ops.conv2d_fwd(g, a, w, b, act=ACT_RELU)
             if keep:
                 layers.append((g, w, z))
             a = z
         feat = a.numel() // B
         g1 = ops.conv_geom(B, 1, 1, feat, w1.shape[0], 1, 1, 1, 0)
-        h = ops.conv2d_fwd(g1, a.view(B, 1, 1, feat), w1, b1)
-        ops.act_fwd(h, ACT_RELU, 0.0, out=h)
+        h = ops.conv2d_fwd(g1, a.view(B, 1, 1, feat), w1, b1, act=ACT_RELU)
         g2 = ops.conv_geom(B, 1, 1, w1.shape[0], kp, 1, 1, 1, 0)
         logits = ops.conv2d_fwd(g2, h, w2, b2).view(B, kp)[:, : self.num_classes]
         saved = (layers, g1, w1, h, g2, w2, kp) if keep else None

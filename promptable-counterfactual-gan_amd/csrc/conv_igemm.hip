@@ -28,20 +28,26 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  // split-K (few output tiles, long K): slab blockIdx.y covers k-tiles [kt_begin, kt_begin + ktiles)
+  const int kt_begin = blockIdx.y * p.ktiles_per_split;
+  int ktiles = p.ktiles - kt_begin;
+  if (ktiles > p.ktiles_per_split) ktiles = p.ktiles_per_split;
 
   if (wave_id() >= 4) {  // producers
     const int tid = threadIdx.x - IG_LOADERS;
     FwdALoader<Cfg::BM> la(p, m_block, tid);
     FwdBLoader<Cfg::BN> lb(p, n_block, tid);
-    igemm_produce<Cfg>(la, lb, p.ktiles, smem, tid);
+    if (kt_begin) { la.seek(kt_begin); lb.seek(kt_begin); }
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, true, true>(p.ktiles, acc, smem);
-  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+  igemm_consume<Cfg, true, true>(ktiles, acc, smem);
+  float* out = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
+  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, blockIdx.y == 0 ? p.bias : nullptr, [&](int row) -> float* {
     const int m = m_block + row;
-    return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr);
+    return m < p.M ? out + (size_t)m * p.N + n_block : nullptr;
+  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope);
 }
 
 template <class Cfg>
@@ -80,7 +86,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr);
+  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope);
 }
 
 template <class Cfg>
@@ -156,14 +162,32 @@ int set_smem(K kernel, size_t bytes) {
 }
 
 template <class Cfg>
-int launch_fwd(ConvP p, hipStream_t s) {
+int launch_fwd(ConvP p, int splits, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(p.M, Cfg::BM);
   constexpr size_t smem = smem_bytes<Cfg, true, true>();
   static int once = set_smem(conv_fwd_kernel<Cfg>, smem);
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN), dim3(IG_THREADS), smem, s, p);
+  hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, splits), dim3(IG_THREADS), smem, s, p);
   return launch_status("conv_fwd_kernel");
+}
+
+// Forward split-K: when M*N gives far fewer tiles than the chip has CUs and K is long (small-batch layers with big weights:
+// the WGAN-GP critic's conv3 / 8192->1024 Linear, the generator's 1x1 -> 4x4 ConvT backward), K is cut into slabs that are
+// summed in slab order by slab_reduce — the same deterministic scheme as the weight gradient.
+struct FwdPlan { int splits, ktiles_per_split; };
+FwdPlan plan_fwd(const pcg_conv_geom* g) {
+  const int M = g->B * g->OH * g->OW, N = g->Cout;
+  const int tiles = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64);
+  const int ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
+  FwdPlan f{1, ktiles};
+  if (tiles > 96 || ktiles < 32) return f;
+  int splits = ceil_div(384, tiles);
+  if (splits > ktiles / 8) splits = ktiles / 8;
+  if (splits < 2) return f;
+  f.ktiles_per_split = ceil_div(ktiles, splits);
+  f.splits = ceil_div(ktiles, f.ktiles_per_split);
+  return f;
 }
 
 template <class Cfg>
@@ -204,7 +228,9 @@ using namespace pcg;
 
 extern "C" size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;
-  return (thin_is_cin(g) || thin_is_cout(g)) ? thin_conv_fwd_workspace_bytes(g) : 0;
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd_workspace_bytes(g);
+  const FwdPlan f = plan_fwd(g);
+  return f.splits > 1 ? (size_t)f.splits * g->B * g->OH * g->OW * g->Cout * sizeof(float) : 0;
 }
 extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;
@@ -230,23 +256,43 @@ static int dgrad_stat_rows(const pcg_conv_geom* g) {
 }
 
 static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                           float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+                           float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
+                           float slope = 0.f) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
-  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_fwd(g, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
+  PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_fwd: unknown activation %d", act);
+  if (thin_is_cin(g) || thin_is_cout(g))
+    return thin_conv_fwd(g, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
   PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
   ConvP p = make_params(g);
   p.x = x; p.w = w; p.bias = bias; p.out = y; p.stat_partial = stat_partial;
   p.M = g->B * g->OH * g->OW; p.N = g->Cout;
   p.ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
+  p.ktiles_per_split = p.ktiles;
   hipStream_t s = (hipStream_t)stream;
-  if (p.N > 64) return launch_fwd<Cfg128x128>(p, s);
-  return launch_fwd<Cfg128x64>(p, s);
+  // split-K needs the slab workspace and cannot fuse statistics or the activation (both need the complete sum)
+  FwdPlan f = plan_fwd(g);
+  const size_t need = (size_t)f.splits * p.M * p.N * sizeof(float);
+  if (f.splits > 1 && (stat_partial || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 15) || ((uintptr_t)y & 15) || (p.M * (size_t)p.N) % 4))
+    f = FwdPlan{1, p.ktiles};
+  const bool fuse = act_is_cheap(act) && f.splits == 1;   // the epilogue fuses ReLU / LeakyReLU; tanh / sigmoid run as a second pass
+  p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
+  if (f.splits > 1) { p.out = (float*)workspace; p.ktiles_per_split = f.ktiles_per_split; }
+  if (int e = p.N > 64 ? launch_fwd<Cfg128x128>(p, f.splits, s) : launch_fwd<Cfg128x64>(p, f.splits, s)) return e;
+  if (f.splits > 1) {
+    const size_t n = (size_t)p.M * p.N;
+    if (int e = launch_slab_reduce((const float*)workspace, y, n, n, f.splits, 0, s)) return e;
+  }
+  return (fuse || act == PCG_ACT_NONE) ? PCG_OK : pcg_act_fwd(y, (int64_t)p.M * p.N, act, slope, y, stream);
 }
 
 extern "C" int pcg_conv2d_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                               void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int pcg_conv2d_fwd_act(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, int act, float slope,
+                                  float* y, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream, act, slope);
 }
 
 extern "C" size_t pcg_conv2d_fwd_bn_workspace_bytes(const pcg_conv_geom* g) {
@@ -271,14 +317,19 @@ extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const f
 }
 
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
-                             float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+                             float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
+                             float slope = 0.f) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
-  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream);
+  PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_dgrad: unknown activation %d", act);
+  if (thin_is_cin(g) || thin_is_cout(g))
+    return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
   ConvP p = make_params(g);
+  const bool fuse = act_is_cheap(act);
   p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx; p.stat_partial = stat_partial;
+  p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   p.N = g->Cin;
   DgradPhases ph{};
   int nph = 0, maxMp = 0, prow = 0;
@@ -303,13 +354,17 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
     }
   PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
   hipStream_t st = (hipStream_t)stream;
-  if (p.N > 64) return launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st);
-  return launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st);
+  if (int e = p.N > 64 ? launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st) : launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st)) return e;
+  return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, stream);
 }
 
 extern "C" int pcg_conv2d_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                                 void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   return conv2d_dgrad_impl(g, dy, w, bias_x, dx, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int pcg_conv2d_dgrad_act(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, int act, float slope,
+                                    float* dx, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_dgrad_impl(g, dy, w, bias_x, dx, nullptr, workspace, workspace_bytes, stream, act, slope);
 }
 
 extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, float eps,

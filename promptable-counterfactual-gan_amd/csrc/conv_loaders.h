@@ -44,11 +44,13 @@ struct ConvP {
   float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
   const float* dy;   // dgrad / wgrad
   float* stat_partial;  // nullable: fused BatchNorm statistics of the output, [partial row][2][N]
+  int act; float slope; // activation fused into the epilogue (PCG_ACT_NONE: none; never together with stat_partial)
   uint32_t x_bytes, w_bytes, dy_bytes;
   int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int M, N;          // GEMM extents of this launch
   int tilesN;
   int ktiles;        // fwd: KH*KW*ceil(Cin/32)
+  int ktiles_per_split;  // fwd split-K (gridDim.y slabs of M*N floats at `out`); == ktiles when not split
   FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition
 };
 
@@ -94,6 +96,13 @@ struct FwdALoader {
     }
     kh = 0; kw = 0; ci0 = 0;
   }
+  // start at k-tile kt (split-K): kt = tap * ceil(Cin/32) + channel tile
+  __device__ __forceinline__ void seek(int kt) {
+    const int cpt = (Cin + IG_BK - 1) / IG_BK;
+    const int tap = kt / cpt;
+    ci0 = (kt - tap * cpt) * IG_BK;
+    kh = tap / KW; kw = tap - kh * KW;
+  }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const int tap = kh * KW + kw;
     const uint32_t delta = (uint32_t)(((kh * IW + kw) * Cin + ci0) * 4);
@@ -127,6 +136,12 @@ struct FwdBLoader {
       base[i] = n < p.N ? (uint32_t)((n * Ktot + kq4) * 4) : OOB_OFF;  // OOB_OFF + delta stays out of range
     }
     tapoff = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ void seek(int kt) {
+    const int cpt = (Cin + IG_BK - 1) / IG_BK;
+    const int tap = kt / cpt;
+    ci0 = (kt - tap * cpt) * IG_BK;
+    tapoff = tap * Cin;
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const uint32_t delta = (uint32_t)((tapoff + ci0) * 4);

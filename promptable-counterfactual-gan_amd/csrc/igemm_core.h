@@ -207,7 +207,8 @@ constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
-                                                 const float* bias, RowBase row_base, float* stat_row = nullptr) {
+                                                 const float* bias, RowBase row_base, float* stat_row = nullptr, int act = PCG_ACT_NONE,
+                                                 float slope = 0.f) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
   constexpr int RPI = 64 / Q;              // rows per store instruction
@@ -234,6 +235,9 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
     if (dst && nok) {
       float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      if (act != PCG_ACT_NONE) {   // wave-uniform; ReLU / LeakyReLU only (slope = 0 / negative slope), others are applied by the host wrapper
+        v.x = act_neg_scale(v.x, slope); v.y = act_neg_scale(v.y, slope); v.z = act_neg_scale(v.z, slope); v.w = act_neg_scale(v.w, slope);
+      }
       *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
       s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);

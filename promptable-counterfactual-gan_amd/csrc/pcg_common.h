@@ -65,6 +65,11 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     default: return v;
   }
 }
+// ReLU / LeakyReLU / identity as one select (neg = 0 / slope / 1): what the conv epilogues fuse; keeps their register count
+__device__ __forceinline__ float act_neg_scale(float v, float neg) { return v > 0.f ? v : v * neg; }
+static inline bool act_is_cheap(int act) { return act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU; }
+static inline float act_neg_of(int act, float slope) { return act == PCG_ACT_RELU ? 0.f : act == PCG_ACT_LRELU ? slope : 1.f; }
+
 // derivative expressed through the OUTPUT y of the activation
 __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
   switch (act) {

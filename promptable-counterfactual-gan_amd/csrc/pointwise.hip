@@ -253,6 +253,19 @@ extern "C" int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream) {
   return launch_status("fill_kernel");
 }
 
+namespace pcg { namespace {
+__global__ void __launch_bounds__(256) add_bias_rows_kernel(float* __restrict__ x, size_t n, int C, const float* __restrict__ bias) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] += bias[i % C];
+}
+} }
+
+extern "C" int pcg_add_bias_rows(float* x, int64_t rows, int32_t C, const float* bias, pcg_stream_t stream) {
+  PCG_REQUIRE(x && bias && rows > 0 && C > 0, "pcg_add_bias_rows: bad arguments");
+  const size_t n = (size_t)rows * C;
+  hipLaunchKernelGGL(add_bias_rows_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, C, bias);
+  return launch_status("add_bias_rows_kernel");
+}
+
 extern "C" int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream) {
   PCG_REQUIRE(p && out && n > 0, "pcg_sumsq: bad arguments");
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, out, accumulate);

@@ -9,9 +9,9 @@ inline bool thin_is_cin(const pcg_conv_geom* g) { return g->Cin <= 3; }
 inline bool thin_is_cout(const pcg_conv_geom* g) { return g->Cout <= 3 && !thin_is_cin(g); }
 
 int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
-                  size_t ws_bytes, hipStream_t s);
+                  size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f);
 int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f);
 size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g);   // optional scratch enabling the two-stage reduce path
 size_t thin_conv_dgrad_workspace_bytes(const pcg_conv_geom* g);
 size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g);

@@ -21,6 +21,7 @@ struct ThinP {
   const float* w;
   const float* bias;
   float* out;
+  int act; float slope;   // activation fused into the output write (PCG_ACT_NONE: none)
   int B, TH, TW, Cs, WH, WW, C;
   int KH, KW, stride, pad, transposed;
   int wsS, wsT, wsC;       // weight element (cs, tap, c) lives at cs*wsS + tap*wsT + c*wsC
@@ -81,6 +82,10 @@ __global__ void __launch_bounds__(256) thin_expand_kernel(ThinP p) {
           acc.z = fmaf(sv, w4.z, acc.z); acc.w = fmaf(sv, w4.w, acc.w);
         }
       }
+    if (p.act != PCG_ACT_NONE) {   // wide outputs fuse ReLU / LeakyReLU only (host falls back otherwise): neg = 0 / slope
+      acc.x = act_neg_scale(acc.x, p.slope); acc.y = act_neg_scale(acc.y, p.slope);
+      acc.z = act_neg_scale(acc.z, p.slope); acc.w = act_neg_scale(acc.w, p.slope);
+    }
     out4[idx] = acc;
   }
 }
@@ -126,9 +131,9 @@ __global__ void __launch_bounds__(256) thin_reduce_kernel(ThinP p) {
     }
     if (l16 == 0) {
       float* o = p.out + (size_t)pix * p.Cs;
-      o[0] = a0 + (p.bias ? p.bias[0] : 0.f);
-      if (p.Cs > 1) o[1] = a1 + (p.bias ? p.bias[1] : 0.f);
-      if (p.Cs > 2) o[2] = a2 + (p.bias ? p.bias[2] : 0.f);
+      o[0] = act_apply(a0 + (p.bias ? p.bias[0] : 0.f), p.act, p.slope);
+      if (p.Cs > 1) o[1] = act_apply(a1 + (p.bias ? p.bias[1] : 0.f), p.act, p.slope);
+      if (p.Cs > 2) o[2] = act_apply(a2 + (p.bias ? p.bias[2] : 0.f), p.act, p.slope);
     }
   }
 }
@@ -339,25 +344,36 @@ int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_strid
 }
 
 int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
-                  size_t ws_bytes, hipStream_t s) {
+                  size_t ws_bytes, hipStream_t s, int act, float slope) {
   ThinP p{};
+  p.act = act; p.slope = slope;
   const bool cin_thin = thin_is_cin(g);
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/true)) return e;
   p.w = w; p.bias = bias; p.out = y;
-  if (cin_thin) { p.thin = x; return launch_expand(p, s); }   // y wide
+  if (cin_thin) {                                              // y wide: fused ReLU / LeakyReLU, anything else as a second pass
+    p.thin = x;
+    const bool fuse = act_is_cheap(act);
+    p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
+    if (int e = launch_expand(p, s)) return e;
+    return fuse ? PCG_OK : pcg_act_fwd(y, (int64_t)g->B * g->OH * g->OW * g->Cout, act, slope, y, (pcg_stream_t)s);
+  }
   p.wide = x;                                                 // y thin
   return launch_reduce(p, ws, ws_bytes, s);
 }
 
 int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
+                    size_t ws_bytes, hipStream_t s, int act, float slope) {
   ThinP p{};
+  p.act = act; p.slope = slope;
   const bool cin_thin = thin_is_cin(g);
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/false)) return e;
   p.w = w; p.bias = bias_x; p.out = dx;
   if (cin_thin) { p.wide = dy; return launch_reduce(p, ws, ws_bytes, s); }  // dx thin
   p.thin = dy;                                                              // dx wide
-  return launch_expand(p, s);
+  const bool fuse = act_is_cheap(act);
+  p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
+  if (int e = launch_expand(p, s)) return e;
+  return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, (pcg_stream_t)s);
 }
 
 size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g) {

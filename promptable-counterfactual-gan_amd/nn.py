@@ -157,6 +157,7 @@ class _Block:
         if self.transposed and conv.output_padding != (0, 0):
             raise PcgError(f"output_padding is not supported: {conv}")
         self.kh, self.kw, self.stride, self.pad = k[0], k[1], s[0], p[0]
+        self.flat = False     # set by geom(): transposed conv on a 1x1 input run as one plain GEMM
 
     def geom(self, B, H, W):
         """Geometry of the (adjoint) convolution and the output spatial size, for an input [B, H, W, C]."""
@@ -166,6 +167,15 @@ class _Block:
             return g, g.OH, g.OW
         OH = (H - 1) * self.stride - 2 * self.pad + self.kh
         OW = (W - 1) * self.stride - 2 * self.pad + self.kw
+        if H == 1 and W == 1 and self.pad == 0 and (self.kh * self.kw * c.out_channels) % 4 == 0 and c.in_channels % 4 == 0 \
+                and c.in_channels > 3:
+            # a 1x1 input: the layer is ONE plain GEMM  out[b][(kh,kw,co)] = sum_ci a[b][ci] W[ci][(kh,kw,co)], and the
+            # ConvTranspose weight [ci][kh][kw][co] is exactly the OHWI weight of a 1x1 convolution with KH*KW*co "input"
+            # channels.  The same three kernels serve it (N = KH*KW*co instead of a 16-tap gather with one live tap per row).
+            g = ops.conv_geom(B, 1, 1, self.kh * self.kw * c.out_channels, c.in_channels, 1, 1, 1, 0)
+            self.flat = True
+            return g, OH, OW
+        self.flat = False
         # adjoint conv: x side = this layer's output (OH x OW x out_channels), y side = its input
         g = ops.conv_geom(B, OH, OW, c.out_channels, c.in_channels, self.kh, self.kw, self.stride, self.pad)
         if g.OH != H or g.OW != W:
@@ -268,7 +278,26 @@ class SequentialConvNet(FlatModule):
             bias = c.bias.data if c.bias is not None else None
             C = c.out_channels
             mean = invstd = None
-            if b.bn is not None and b.bn.training:
+            if b.transposed and b.flat:
+                # plain-GEMM form: bias is shared by the KH*KW positions of a channel, statistics are per channel over B*KH*KW rows
+                z = ops.conv2d_dgrad(g, a, w, None).view(B, OH, OW, C)
+                if bias is not None:
+                    ops.add_bias_rows(z, C, bias)
+                if b.bn is not None:
+                    bn = b.bn
+                    if bn.training:
+                        mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+                        y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
+                    else:
+                        y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
+                                             var_eps=bn.eps, out=z)
+                        z = None
+                elif b.act != ACT_NONE:
+                    y = ops.act_fwd(z, b.act, b.slope, out=z)
+                    z = None
+                else:
+                    y, z = z, None
+            elif b.bn is not None and b.bn.training:
                 bn = b.bn
                 z, mean, invstd = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
                                                     bn.running_var, bn.num_batches_tracked)
@@ -279,9 +308,9 @@ class SequentialConvNet(FlatModule):
                 y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
                                      var_eps=bn.eps, out=z)
                 z = None
-            elif b.act != ACT_NONE:
-                z = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
-                y = ops.act_fwd(z, b.act, b.slope, out=z)  # in place, like nn.ReLU(True) / LeakyReLU(inplace=True)
+            elif b.act != ACT_NONE:   # activation fused into the conv's output write
+                y = (ops.conv2d_dgrad(g, a, w, bias, act=b.act, slope=b.slope) if b.transposed
+                     else ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope))
                 z = None
             else:
                 y = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)

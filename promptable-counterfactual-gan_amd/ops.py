@@ -113,8 +113,8 @@ def conv_geom(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
 
 
 # ---- convolution family --------------------------------------------------------------------------
-def conv2d_fwd(g, x, w, bias=None, out=None):
-    """y[B,OH,OW,Cout] = conv(x[B,IH,IW,Cin], w OHWI) (+ bias)."""
+def conv2d_fwd(g, x, w, bias=None, out=None, act=0, slope=0.0):
+    """y[B,OH,OW,Cout] = act(conv(x[B,IH,IW,Cin], w OHWI) (+ bias))."""
     _chk(x, "x"); _chk(w, "w")
     assert x.numel() == g.B * g.IH * g.IW * g.Cin and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     y = out if out is not None else torch.empty((g.B, g.OH, g.OW, g.Cout), dtype=torch.float32, device=x.device)
@@ -122,13 +122,13 @@ def conv2d_fwd(g, x, w, bias=None, out=None):
     need = lib.pcg_conv2d_fwd_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, x.device) if need else None
     with _Timed(g, "fwd"):
-        check(lib.pcg_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(y), _p(ws), ws.numel() if need else 0, _stream()),
-              "pcg_conv2d_fwd")
+        check(lib.pcg_conv2d_fwd_act(ctypes.byref(g), _p(x), _p(w), _p(bias), int(act), float(slope), _p(y), _p(ws),
+                                     ws.numel() if need else 0, _stream()), "pcg_conv2d_fwd_act")
     return y
 
 
-def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
-    """dx[B,IH,IW,Cin] = conv_transpose(dy[B,OH,OW,Cout], w OHWI) (+ bias_x per Cin)."""
+def conv2d_dgrad(g, dy, w, bias_x=None, out=None, act=0, slope=0.0):
+    """dx[B,IH,IW,Cin] = act(conv_transpose(dy[B,OH,OW,Cout], w OHWI) (+ bias_x per Cin))."""
     _chk(dy, "dy"); _chk(w, "w")
     assert dy.numel() == g.B * g.OH * g.OW * g.Cout and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
@@ -136,8 +136,8 @@ def conv2d_dgrad(g, dy, w, bias_x=None, out=None):
     need = lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, dy.device) if need else None
     with _Timed(g, "dgrad"):
-        check(lib.pcg_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), _p(dx), _p(ws), ws.numel() if need else 0, _stream()),
-              "pcg_conv2d_dgrad")
+        check(lib.pcg_conv2d_dgrad_act(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), int(act), float(slope), _p(dx), _p(ws),
+                                       ws.numel() if need else 0, _stream()), "pcg_conv2d_dgrad_act")
     return dx
 
 
@@ -275,6 +275,13 @@ def fill(t, value):
     if t.numel():
         check(_lib.load().pcg_fill(_p(t), t.numel(), float(value), _stream()), "pcg_fill")
     return t
+
+
+def add_bias_rows(x, C, bias):
+    """x[..., c] += bias[c] in place."""
+    _chk(x, "x"); _chk(bias, "bias")
+    check(_lib.load().pcg_add_bias_rows(_p(x), x.numel() // C, C, _p(bias), _stream()), "pcg_add_bias_rows")
+    return x
 
 
 def sumsq(t, out, accumulate=False):

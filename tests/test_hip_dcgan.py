@@ -134,13 +134,17 @@ def test_full_width_step_vs_oracle(pcg, batch, skip):
     # weights after the Adam step: Adam divides by |g|, so a gradient at the noise level moves its weight by up to
     # 2*lr = 4e-4 whatever its size; require (a) no element beyond that bound, (b) all but 0.5 % (at least 2 elements) within 1e-4 + 5e-6
     lr = 2e-4
-    for net, r64net, tag in ((netG, r64G, "G"), (netD, r64D, "D")):
-        for (k, v), (_, t) in zip(net.state_dict().items(), r64net.state_dict().items()):
-            got, truth = v.cpu().double().numpy(), t.double().numpy()
+    # ... or 3x the number of elements the reference's own fp32 run has beyond it (the count of sign flips is a property of how
+    # many gradients sit at the noise level, not of the implementation)
+    for net, r32net, r64net, tag in ((netG, refG, r64G, "G"), (netD, refD, r64D, "D")):
+        for (k, v), (_, q), (_, t) in zip(net.state_dict().items(), r32net.state_dict().items(), r64net.state_dict().items()):
+            got, ref32, truth = v.cpu().double().numpy(), q.double().numpy(), t.double().numpy()
             diff = np.abs(got - truth)
             assert diff.max() <= 2.2 * lr + 1e-4 * np.abs(truth).max(), f"{tag} {k}: max diff {diff.max():.2e}"
             bad = int(np.sum(diff > 5e-6 + 1e-4 * np.abs(truth)))
-            assert bad <= max(2, int(5e-3 * diff.size)), f"{tag} {k}: {bad} of {diff.size} elements beyond tolerance"
+            bad_ref = int(np.sum(np.abs(ref32 - truth) > 5e-6 + 1e-4 * np.abs(truth)))
+            assert bad <= max(2, int(5e-3 * diff.size), 3 * bad_ref), \
+                f"{tag} {k}: {bad} of {diff.size} elements beyond tolerance (reference fp32: {bad_ref})"
 
 
 def test_skip_dead_d_wgrad_changes_nothing_observable(pcg):

@@ -111,6 +111,21 @@ def test_conv_fwd_dgrad_wgrad(pcg, B, Cin, Cout, H, W, k, s, p):
     assert err <= 2 * _tol(K, 8.0), f"wgrad accumulate max err {err}"
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [(4, 64, 128, 32, 32, 4, 2, 1), (3, 64, 64, 28, 28, 3, 1, 1), (8, 1, 64, 64, 64, 4, 2, 1),
+                                                   (8, 512, 1, 4, 4, 4, 1, 0), (3, 2, 64, 28, 28, 3, 2, 1), (3, 64, 1, 28, 28, 3, 1, 1)])
+@pytest.mark.parametrize("act,slope", [(O.ACT_LRELU, 0.2), (O.ACT_TANH, 0.0), (O.ACT_SIGMOID, 0.0), (O.ACT_RELU, 0.0)])
+def test_conv_fused_activation_equals_conv_then_activation(pcg, B, Cin, Cout, H, W, k, s, p, act, slope):
+    """pcg_conv2d_{fwd,dgrad}_act == the plain op followed by pcg_act_fwd, bit for bit (same arithmetic, one pass less)."""
+    ops = pcg.ops
+    g = ops.conv_geom(B, H, W, Cin, Cout, k, k, s, p)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, Cin, generator=gen).to(dev()); w = (torch.randn(Cout, k, k, Cin, generator=gen) * 0.1).to(dev())
+    dy = torch.randn(B, g.OH, g.OW, Cout, generator=gen).to(dev())
+    b_out, b_in = torch.randn(Cout, generator=gen).to(dev()), torch.randn(Cin, generator=gen).to(dev())
+    assert torch.equal(ops.conv2d_fwd(g, x, w, b_out, act=act, slope=slope), ops.act_fwd(ops.conv2d_fwd(g, x, w, b_out), act, slope))
+    assert torch.equal(ops.conv2d_dgrad(g, dy, w, b_in, act=act, slope=slope), ops.act_fwd(ops.conv2d_dgrad(g, dy, w, b_in), act, slope))
+
+
 def test_conv_rejects_bad_geometry(pcg):
     ops = pcg.ops
     g = ops.conv_geom(2, 8, 8, 8, 8, 4, 4, 2, 1)
