@@ -307,6 +307,14 @@ int pcg_gradient_penalty_bwd(const float* grads, const float* norms, const float
 /* torch.rand: uniform [0, 1) — the interpolation coefficients alpha (:146) */
 int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream);
 
+/* ---- counterfactual evaluation -----------------------------------------------------------------
+ * out[0] = class-flip rate = mean_b [argmax logits_cf[b] == target[b]];
+ * out[1] = prediction gain = mean_b (softmax(logits_cf[b])[target[b]] - q_b) with q_b = softmax(logits_ref[b])[target[b]]
+ * (house_sales_kc_usa/eval_utils.py:246-258) or, when logits_ref is NULL, softmax(logits_cf[b])[other[b]]
+ * (mnist/eval_utils.py:61-64).  Actionability (mean |residual|) is pcg_abs_mean_fwd. */
+int pcg_cf_metrics(const float* logits_cf, const float* logits_ref /*nullable*/, const int64_t* target, const int64_t* other /*nullable*/,
+                   int32_t B, int32_t K, float* out /*[2]*/, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

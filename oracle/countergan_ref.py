@@ -206,3 +206,18 @@ def build(seed=0):
     for p in classifier.parameters():                   # main.py:31-33
         p.requires_grad = False
     return generator, discriminator, classifier
+
+
+def evaluate_counterfactuals(generator, classifier, x, y_true, y_target):
+    """eval_utils.py:46-79 (eval mode, all-ones mask, clamp to [-1,1]; flip rate, prediction gain, actionability)."""
+    import torch.nn.functional as F
+    classifier.eval(); generator.eval()
+    with torch.no_grad():
+        residual = generator(x, y_target, torch.ones_like(x))[1]
+        x_cf = torch.clamp(x + residual, -1.0, 1.0)
+        logits = classifier(x_cf)
+        probs = F.softmax(logits, dim=1)
+    ar = torch.arange(len(y_target))
+    return {"class_flip_rate": (logits.argmax(1) == y_target).float().mean().item(),
+            "prediction_gain": (probs[ar, y_target] - probs[ar, y_true]).mean().item(),
+            "actionability": torch.abs(x_cf - x).mean().item()}, ((x + 1.0) / 2.0, (x_cf + 1.0) / 2.0)

@@ -158,6 +158,35 @@ def house_step(G, D, clf, opt_G, opt_D, x, y, target_y, mask, gumbel, norm_maps,
             "d_real_p": torch.sigmoid(D_real).mean().item(), "d_fake_p": torch.sigmoid(D_fake_forG).mean().item()}
 
 
+def build_counterfactuals(G, x, target_onehot, gumbel, norm_maps, config=CONFIG):
+    """eval_utils.py:25-181 for this generator's (cont_residual, cat_logits, cat_samples) signature: immutable mask :48-50,
+    hard Gumbel-softmax :76-77, residual assembly :127-171, mask :174-177, clamp to [0,1] :180."""
+    mask = torch.ones_like(x)
+    mask[:, config["immutable_idx"]] = 0.0
+    cont_residual, _, cat_samples = G(x, target_onehot, mask, gumbel, temperature=config["gumbel_tau"], hard=True)
+    residual_full = torch.zeros_like(x)
+    for i, f in enumerate(config["continuous_idx"]):
+        residual_full[:, f] = cont_residual[:, i]
+    for f, sample in cat_samples.items():
+        residual_full[:, f] = sample.matmul(norm_maps[f].to(x.dtype)) - x[:, f]
+    masked_residual = residual_full * mask
+    return masked_residual, torch.clamp(x + masked_residual, 0.0, 1.0)
+
+
+def metrics_one_target(G, clf, x, target, gumbel, norm_maps, config=CONFIG):
+    """One (batch, target class) step of compute_metrics_per_target, eval_utils.py:233-262, for rows whose class != target."""
+    nc = config["num_classes"]
+    target_vec = torch.full((x.shape[0],), target, dtype=torch.long)
+    masked_residual, _ = build_counterfactuals(G, x, F.one_hot(target_vec, nc).to(x.dtype), gumbel, norm_maps, config)
+    x_cf = x + masked_residual                                                                # :243
+    probs_orig, logits_cf = F.softmax(clf(x), dim=1), clf(x_cf)
+    probs_cf = F.softmax(logits_cf, dim=1)
+    ar = torch.arange(x.shape[0])
+    return {"class_flip": (logits_cf.argmax(1) == target_vec).float().mean().item(),
+            "prediction_gain": (probs_cf[ar, target_vec] - probs_orig[ar, target_vec]).mean().item(),
+            "avg_actionability": masked_residual.abs().mean().item(), "x_cf": x_cf}
+
+
 def build(seed=0, config=CONFIG):
     torch.manual_seed(seed)
     clf = NNClassifier(config["input_dim"], config["num_classes"])

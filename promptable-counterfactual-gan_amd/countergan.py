@@ -508,6 +508,35 @@ def build_mask_device(rng, x, patch_size, num_modifiable_patches):
     return rng.patch_mask(bs, h, w, patch_size, num_modifiable_patches, x.device)
 
 
+def evaluate_counterfactuals(generator, classifier, x, y_true, y_target, device=None):
+    """eval_utils.py:46-79 — eval-mode generator with an all-ones mask, clamp to [-1, 1], classifier; returns
+    ({class_flip_rate, prediction_gain, actionability}, (x_vis, x_cf_vis) in [0, 1])."""
+    classifier.eval(); generator.eval()
+    device = device if device is not None else next(generator.parameters()).device
+    x, y_true, y_target = x.to(device), y_true.to(device), y_target.to(device)
+    with torch.no_grad():
+        ones = torch.empty_like(x)
+        ops.fill(ones, 1.0)
+        residual = generator(x, y_target, ones)[1]                                          # :55
+        x_cf = clamp_add(x, residual, -1.0, 1.0)                                            # :57
+        logits = classifier(x_cf)                                                           # :58
+        m = ops.cf_metrics(logits.contiguous(), y_target, other=y_true).cpu()               # :61-64
+        diff = ops.axpby(1.0, x_cf, -1.0, x.contiguous())
+        actionability = abs_mean(diff).item()                                               # :66
+        x_vis = ops.axpby(0.5, x.contiguous(), out=None).add_(0.5).cpu()                    # :69-70 ([-1,1] -> [0,1]; host-side view)
+        x_cf_vis = ops.axpby(0.5, x_cf).add_(0.5).cpu()
+    return {"class_flip_rate": float(m[0]), "prediction_gain": float(m[1]), "actionability": actionability}, (x_vis, x_cf_vis)
+
+
+def generate_counterfactuals(generator, classifier, x, y, y_target, mask, device=None):
+    """eval_utils.py:489-497."""
+    generator.eval(); classifier.eval()
+    with torch.no_grad():
+        raw_residual, masked_residual = generator(x, y_target, mask)
+        x_cf = clamp_add(x, masked_residual, -1.0, 1.0)
+    return raw_residual, masked_residual, x_cf
+
+
 def grad_norm(net):
     """trainer.py:41-42 — sqrt(sum ||p.grad||^2) over a net's parameters (per-epoch diagnostic, :142-143): one launch over
     the flat gradient buffer (its alignment padding is zero), one host read."""

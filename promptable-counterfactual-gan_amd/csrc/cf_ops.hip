@@ -278,3 +278,52 @@ extern "C" int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* tar
                      loss, dlogits);
   return launch_status("cross_entropy_kernel");
 }
+
+namespace pcg { namespace {
+// counterfactual evaluation reductions (mnist/eval_utils.py:61-66; house_sales_kc_usa/eval_utils.py:246-258):
+//   flip = mean_b [argmax_k logits_cf[b] == target[b]]
+//   gain = mean_b ( softmax(logits_cf[b])[target[b]] - q_b ),  q_b = softmax(logits_ref[b])[target[b]] if logits_ref
+//                                                                   else softmax(logits_cf[b])[other[b]]
+__global__ void __launch_bounds__(256) cf_metrics_kernel(const float* __restrict__ lcf, const float* __restrict__ lref,
+                                                         const int64_t* __restrict__ target, const int64_t* __restrict__ other, int B, int K,
+                                                         float* __restrict__ out) {
+  __shared__ float r0[256], r1[256];
+  float flips = 0.f, gain = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = lcf + (size_t)b * K;
+    const int t = (int)target[b];
+    float mx = row[0]; int arg = 0;
+    for (int k = 1; k < K; ++k) if (row[k] > mx) { mx = row[k]; arg = k; }      // first maximum, as torch.argmax
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(row[k] - mx);
+    const float pt = expf(row[t] - mx) / se;
+    float q;
+    if (lref) {
+      const float* rr = lref + (size_t)b * K;
+      float m2 = rr[0];
+      for (int k = 1; k < K; ++k) m2 = fmaxf(m2, rr[k]);
+      float s2 = 0.f;
+      for (int k = 0; k < K; ++k) s2 += expf(rr[k] - m2);
+      q = expf(rr[t] - m2) / s2;
+    } else {
+      q = expf(row[(int)other[b]] - mx) / se;
+    }
+    flips += arg == t ? 1.f : 0.f;
+    gain += pt - q;
+  }
+  r0[threadIdx.x] = flips; r1[threadIdx.x] = gain;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = r0[0] / (float)B; out[1] = r1[0] / (float)B; }
+}
+} }
+
+extern "C" int pcg_cf_metrics(const float* logits_cf, const float* logits_ref, const int64_t* target, const int64_t* other, int32_t B,
+                              int32_t K, float* out, pcg_stream_t stream) {
+  PCG_REQUIRE(logits_cf && target && out && (logits_ref || other) && B > 0 && K > 0, "pcg_cf_metrics: bad arguments");
+  hipLaunchKernelGGL(cf_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_cf, logits_ref, target, other, B, K, out);
+  return launch_status("cf_metrics_kernel");
+}

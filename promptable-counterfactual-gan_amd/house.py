@@ -504,6 +504,67 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
             "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
 
 
+# ---- evaluation ------------------------------------------------------------------------------
+def build_counterfactuals(G, x, target_onehot, config, gumbel=None, norm_vals=None):
+    """eval_utils.py:25-181 for this generator's output signature: all features modifiable except the immutable ones, hard
+    Gumbel-softmax samples (:76-77), residual assembly (:127-171), clamp to [0, 1] (:180).  Returns (masked_residual, x_cf)."""
+    device = x.device
+    mask = torch.empty_like(x)
+    ops.fill(mask, 1.0)
+    imm = list(config.get("immutable_idx", []))
+    if imm:
+        mask[:, imm] = 0.0                                                                  # :48-50 (setup-sized strided fill)
+    norm_vals = norm_vals if norm_vals is not None else cat_norm_maps(G, config, device)    # :56-67
+    cont, _, samples = G.forward_packed(x, target_onehot, mask, temperature=config.get("gumbel_tau", None), hard=True, gumbel=gumbel)
+    residual_full = ops.assemble_residual_fwd(cont.contiguous(), G.index_tables(device)[2], samples.contiguous(),
+                                              G.index_tables(device)[0], G.index_tables(device)[1], norm_vals, x.contiguous())
+    _, masked = ops.scale_mask_fwd(residual_full, mask, 1.0)                                # :174-177
+    x_cf = ops.clamp_add_fwd(x.contiguous(), masked, 0.0, 1.0)                              # :180
+    return masked, x_cf
+
+
+def compute_metrics_per_target(generator, classifier, X, y, config, gumbel_per_call=None, rng=None, max_vis=500):
+    """eval_utils.py:185-289 — per target class: class-flip rate, prediction gain, mean |masked residual| over the samples whose
+    class differs from the target, averaged over batches.  X, y: numpy arrays (already MinMax-scaled).  `gumbel_per_call`: an
+    iterator of packed noise tensors, one per generator call, for runs that must reproduce given draws; otherwise `rng`."""
+    import numpy as np
+    device = next(generator.parameters()).device
+    bs_cfg = int(config.get("batch_size", 128))
+    X_t, y_t = torch.as_tensor(X, dtype=torch.float32), torch.as_tensor(y, dtype=torch.long)
+    num_classes = int(np.unique(np.asarray(y)).size)
+    generator.eval(); classifier.eval()
+    if gumbel_per_call is None and generator.rng is None:
+        generator.rng = rng if rng is not None else ops.DeviceRNG(seed=0)
+    norm_vals = cat_norm_maps(generator, config, device)
+    noise_it = iter(gumbel_per_call) if gumbel_per_call is not None else None
+    results, originals, cfs = [], [], []
+    with torch.no_grad():
+        for target in range(num_classes):
+            flips, gains, actions = [], [], []
+            for i in range(0, X_t.shape[0], bs_cfg):
+                xb, yb = X_t[i:i + bs_cfg], y_t[i:i + bs_cfg]
+                sel = yb != target                                                          # :224-226 (host-side selection)
+                if int(sel.sum()) == 0:
+                    continue
+                x = xb[sel].to(device).contiguous()
+                bs = x.shape[0]
+                target_vec = torch.full((bs,), target, dtype=torch.long, device=device)
+                target_onehot = ops.onehot(target_vec, num_classes)
+                noise = next(noise_it) if noise_it is not None else None
+                masked, _ = build_counterfactuals(generator, x, target_onehot, config, gumbel=noise, norm_vals=norm_vals)
+                x_cf = ops.axpby(1.0, x, 1.0, masked)                                       # :243 (unclamped, as the reference)
+                m = ops.cf_metrics(classifier(x_cf).contiguous(), target_vec, logits_ref=classifier(x).contiguous()).cpu()
+                flips.append(float(m[0])); gains.append(float(m[1])); actions.append(abs_mean(masked).item())
+                if sum(o.shape[0] for o in originals) < max_vis:
+                    originals.append(x.cpu()); cfs.append(x_cf.cpu())
+            results.append({"target_class": target, "class_flip": float(np.mean(flips)) if flips else float("nan"),
+                            "prediction_gain": float(np.mean(gains)) if gains else float("nan"),
+                            "avg_actionability": float(np.mean(actions)) if actions else float("nan")})
+    originals = torch.cat(originals, 0).numpy() if originals else np.empty((0, X_t.shape[1]))
+    cfs = torch.cat(cfs, 0).numpy() if cfs else np.empty((0, X_t.shape[1]))
+    return results, originals, cfs
+
+
 class GraphedTrainStep:
     """The whole training step — G forward, critic step, G step, both Adam updates, ~400 small kernels — captured once in a
     HIP graph and replayed with one host call: this path is launch-latency bound, and the graph

@@ -537,6 +537,15 @@ def spectral_norm_bwd(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate):
                                             _stream()), "pcg_spectral_norm_bwd")
 
 
+def cf_metrics(logits_cf, target, logits_ref=None, other=None):
+    """[class-flip rate, prediction gain] as a 2-element device tensor (see pcg_cf_metrics)."""
+    _chk(logits_cf, "logits_cf"); _chk_idx(target, logits_cf.shape[1], "target")
+    B, K = logits_cf.shape
+    out = torch.empty(2, dtype=torch.float32, device=logits_cf.device)
+    check(_lib.load().pcg_cf_metrics(_p(logits_cf), _p(logits_ref), _p(target), _p(other), B, K, _p(out), _stream()), "pcg_cf_metrics")
+    return out
+
+
 # ---- WGAN-GP critic pieces (csrc/instnorm.hip) ----------------------------------------------------------------------------
 def instnorm_fwd(x, B, HW, C, gamma, beta, eps, act=0, slope=0.0):
     _chk(x, "x")

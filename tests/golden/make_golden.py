@@ -460,6 +460,120 @@ def make_wgan_small(path, width=16, batch=6, steps=3):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def _lift_functions(path, names, ns):
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(defs) == len(names), (path, [d.name for d in defs])
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def make_house_eval(path, exact_rows=512):
+    """SURVEY.md section 8f item 2 — the counterfactual evaluation path of house_sales_kc_usa: `build_counterfactuals`
+    (eval_utils.py:25-181) and `compute_metrics_per_target` (:185-289) are lifted from the syntax tree (the module imports
+    seaborn, which is absent) and run with the reference's own modules, the checkpoints it ships and its own preprocessing of
+    the dataset it ships (data_utils.load_and_preprocess: quartile labels, MinMax).  Stored: the scaled test split (data), the
+    scaler range and category tables, the metrics of a full run (statistical anchor, next to the shipped
+    results/countergan_metrics.csv) and an exact case — the first `exact_rows` rows as one batch per target class, with the
+    hard Gumbel-softmax draws replayed from the RNG states captured at each generator call."""
+    import contextlib, importlib, io
+    import pandas as pd
+    from typing import Optional, Tuple
+    import torch.nn.functional as F
+    from torch.utils.data import DataLoader, TensorDataset
+    mdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    scratch = "/tmp/pcg_golden_house"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        sys.path.insert(0, mdir)
+        for name in list(sys.modules):
+            if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+                sys.modules.pop(name)
+        cfg = importlib.import_module("config").config
+        gen_mod = importlib.import_module("models.generator")
+        clf_mod = importlib.import_module("models.nn_classifier")
+        data_utils = importlib.import_module("data_utils")
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, X_test, _, y_test = data_utils.load_and_preprocess(os.path.join(mdir, "kc_house_data.csv"), cfg)
+        cfg["cuda"] = "cpu"
+        ns = {"torch": torch, "np": np, "pd": pd, "F": F, "TensorDataset": TensorDataset, "DataLoader": DataLoader, "Tuple": Tuple,
+              "Optional": Optional}
+        _lift_functions(os.path.join(mdir, "eval_utils.py"), ("build_counterfactuals", "compute_metrics_per_target"), ns)
+        G = gen_mod.ResidualGenerator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"], continuous_idx=cfg["continuous_idx"],
+                                      categorical_info={k: {"n": v["n"], "raw_values": v["raw_values"]} for k, v in cfg["categorical_info"].items()},
+                                      tau=cfg["gumbel_tau"])
+        clf = clf_mod.NNClassifier(cfg["input_dim"], output_dim=cfg["num_classes"])
+        G.load_state_dict(torch.load(os.path.join(mdir, "generator_model.pt"), map_location="cpu", weights_only=True))
+        clf.load_state_dict(torch.load(os.path.join(mdir, "clf_model.pt"), map_location="cpu", weights_only=True))
+        G.eval(); clf.eval()
+        out = {"X_test": X_test.astype(np.float32), "y_test": y_test.astype(np.int64),
+               "scaler.data_min": np.asarray(cfg["scaler"].data_min_, np.float64), "scaler.data_max": np.asarray(cfg["scaler"].data_max_, np.float64),
+               "meta.batch_size": np.int64(cfg["batch_size"]), "meta.exact_rows": np.int64(exact_rows)}
+        for f, info in cfg["categorical_info"].items():
+            out[f"raw_values.{f}"] = np.asarray(info["raw_values"], np.float64)
+        shipped = pd.read_csv(os.path.join(mdir, "results/countergan_metrics.csv"))
+        out["shipped.metrics"] = shipped[["class_flip", "prediction_gain", "avg_actionability"]].to_numpy(np.float64)
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            df, _, _ = ns["compute_metrics_per_target"](G, clf, X_test, y_test, cfg)
+        out["full.metrics"] = df[["class_flip", "prediction_gain", "avg_actionability"]].to_numpy(np.float64)
+        # exact case
+        states = []
+        h = G.register_forward_pre_hook(lambda m, a: states.append(torch.get_rng_state()))
+        cfg2 = dict(cfg, batch_size=exact_rows)
+        torch.manual_seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            df2, orig_vis, cf_vis = ns["compute_metrics_per_target"](G, clf, X_test[:exact_rows], y_test[:exact_rows], cfg2, max_vis=10 ** 9)
+        h.remove()
+        assert len(states) == cfg["num_classes"]
+        out["exact.metrics"] = df2[["class_flip", "prediction_gain", "avg_actionability"]].to_numpy(np.float64)
+        out["exact.x_cf"] = cf_vis.astype(np.float32)                       # concatenated over the target classes
+        for t, st in enumerate(states):
+            bs = int((y_test[:exact_rows] != t).sum())
+            torch.set_rng_state(st)
+            for idx_str, head in G.fc_cat_logits.items():
+                out[f"exact.gumbel.{t}.{idx_str}"] = (-torch.empty(bs, head.out_features).exponential_().log()).numpy()
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB; full-run metrics\n{out['full.metrics']}\nshipped\n{out['shipped.metrics']}")
+    finally:
+        os.chdir(cwd)
+
+
+def make_countergan_eval(path, batch=16):
+    """SURVEY.md section 8f item 2, mnist: `evaluate_counterfactuals` (conditional_counteRGAN/mnist/eval_utils.py:46-79), lifted
+    (the module imports seaborn), with the reference's ResidualGenerator + the generator checkpoint it ships and a seeded
+    CNNClassifier (the trained best_classifier.pt is not in the repository)."""
+    import importlib
+    import torch.nn.functional as F
+    mdir = os.path.join(REF, "conditional_counteRGAN/mnist")
+    sys.path.insert(0, mdir)
+    for name in list(sys.modules):
+        if name in ("config", "trainer") or name == "models" or name.startswith("models."):
+            sys.modules.pop(name)
+    gen_mod = importlib.import_module("models.generator")
+    clf_mod = importlib.import_module("models.classifier")
+    ns = {"torch": torch, "F": F}
+    _lift_functions(os.path.join(mdir, "eval_utils.py"), ("evaluate_counterfactuals",), ns)
+    G = gen_mod.ResidualGenerator()
+    G.load_state_dict(torch.load(os.path.join(mdir, "results/generator.pt"), map_location="cpu", weights_only=True))
+    torch.manual_seed(3)
+    C = clf_mod.CNNClassifier()
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(batch, 1, 28, 28, generator=g) * 2 - 1
+    y_true = torch.randint(0, 10, (batch,), generator=g)
+    y_target = torch.randint(0, 10, (batch,), generator=g)
+    metrics, (x_vis, x_cf_vis) = ns["evaluate_counterfactuals"](G, C, x, y_true, y_target, "cpu")
+    out = {"x": x.numpy(), "y_true": y_true.numpy(), "y_target": y_target.numpy(), "x_cf_vis": x_cf_vis.numpy(),
+           "metrics": np.array([metrics["class_flip_rate"], metrics["prediction_gain"], metrics["actionability"]], np.float64)}
+    for k, v in C.state_dict().items():          # seeded init (torch.manual_seed(3)): digests only, the test re-creates it
+        out[f"C.{k}"] = tensor_digest(v)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: metrics {out['metrics']}")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -471,3 +585,5 @@ if __name__ == "__main__":
     make_house_trained(os.path.join(HERE, "house_trained_eval.npz"), os.path.join(HERE, "house_generator_trained.pt"),
                        os.path.join(HERE, "house_classifier_trained.pt"))
     make_wgan_small(os.path.join(HERE, "wgan_ref_small.npz"))
+    make_house_eval(os.path.join(HERE, "house_eval.npz"))
+    make_countergan_eval(os.path.join(HERE, "countergan_eval.npz"))

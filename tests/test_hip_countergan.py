@@ -215,3 +215,21 @@ def test_trained_checkpoint_eval_forward(pcg, golden_dir):
     np.testing.assert_allclose(raw.cpu().numpy(), gold["raw"], rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(masked.cpu().numpy(), gold["masked"], rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(x_cf.cpu().numpy(), gold["x_cf"], rtol=1e-4, atol=2e-5 * scale)
+
+
+def test_evaluate_counterfactuals_matches_reference(pcg, golden_dir):
+    """eval_utils.py:46-79 lifted from the reference (tests/golden/make_golden.py: make_countergan_eval): shipped generator
+    checkpoint, seeded classifier; flip rate, prediction gain, actionability and the de-normalised counterfactual images."""
+    K = pcg.countergan
+    gold = dict(np.load(os.path.join(golden_dir, "countergan_eval.npz")))
+    G, C = K.ResidualGenerator(), None
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "countergan_generator_trained.pt"), map_location="cpu", weights_only=True))
+    torch.manual_seed(3)
+    C = K.CNNClassifier()
+    for k, v in C.state_dict().items():
+        np.testing.assert_array_equal(_digest(v), gold[f"C.{k}"], err_msg=k)
+    G, C = G.to(DEV), C.to(DEV)
+    m, (x_vis, x_cf_vis) = K.evaluate_counterfactuals(G, C, torch.from_numpy(gold["x"]), torch.from_numpy(gold["y_true"]),
+                                                      torch.from_numpy(gold["y_target"]), torch.device(DEV))
+    np.testing.assert_allclose([m["class_flip_rate"], m["prediction_gain"], m["actionability"]], gold["metrics"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(x_cf_vis.numpy(), gold["x_cf_vis"], rtol=1e-4, atol=2e-5)

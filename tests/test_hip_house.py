@@ -397,3 +397,50 @@ def test_device_draws(pcg):
     loader = [(xs[i * 128:(i + 1) * 128], ys[i * 128:(i + 1) * 128]) for i in range(4)]
     hist = H.train_countergan(G, D, C, loader, cfg, torch.device(DEV), rng=ops.DeviceRNG(1), log_every=10 ** 9)
     assert len(hist) == 2 and all(np.isfinite(v) for e in hist for v in e)
+
+
+# ---- evaluation path ------------------------------------------------------------------------------
+class _Scaler:
+    def __init__(self, lo, hi):
+        self.data_min_, self.data_max_ = lo, hi
+
+
+def _eval_setup(pcg, golden_dir):
+    H = pcg.house
+    gold = dict(np.load(os.path.join(golden_dir, "house_eval.npz")))
+    cfg = dict(H.CONFIG)
+    cfg["categorical_info"] = {f: {"n": len(gold[f"raw_values.{f}"]), "raw_values": gold[f"raw_values.{f}"].tolist()} for f in H.CONFIG["categorical_info"]}
+    cfg["scaler"] = _Scaler(gold["scaler.data_min"], gold["scaler.data_max"])
+    G = H.ResidualGenerator(17, 32, 4, cfg["continuous_idx"], cfg["categorical_info"], tau=0.5)
+    C = H.NNClassifier(17, 4)
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "house_generator_trained.pt"), map_location="cpu", weights_only=True))
+    C.load_state_dict(torch.load(os.path.join(golden_dir, "house_classifier_trained.pt"), map_location="cpu", weights_only=True))
+    return gold, cfg, G.to(DEV).eval(), C.to(DEV).eval()
+
+
+def test_eval_metrics_exact_case(pcg, golden_dir):
+    """compute_metrics_per_target on the first rows of the real (scaled) test split, one batch per target class, with the hard
+    Gumbel-softmax draws the reference made: its metrics and its counterfactual rows."""
+    H = pcg.house
+    gold, cfg, G, C = _eval_setup(pcg, golden_dir)
+    n = int(gold["meta.exact_rows"])
+    noise = [G.pack_noise({f: _dev(torch.from_numpy(gold[f"exact.gumbel.{t}.{f}"])) for f in G.cat_idx}) for t in range(4)]
+    res, orig, cfs = H.compute_metrics_per_target(G, C, gold["X_test"][:n], gold["y_test"][:n], dict(cfg, batch_size=n),
+                                                  gumbel_per_call=noise, max_vis=10 ** 9)
+    got = np.array([[r["class_flip"], r["prediction_gain"], r["avg_actionability"]] for r in res])
+    # flips are counts / B (a sample whose top-2 logits are within fp32 noise could change it by 1/B: none here); gains and
+    # actionability are fp32 means
+    np.testing.assert_allclose(got, gold["exact.metrics"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(cfs, gold["exact.x_cf"], rtol=1e-4, atol=2e-5)
+
+
+def test_eval_full_run_agrees_with_shipped_metrics(pcg, golden_dir):
+    """End-to-end anchor: the shipped generator + classifier on the reference's own test split, device-drawn Gumbel noise,
+    against results/countergan_metrics.csv as shipped (different random draws: agreement is statistical, 4323 rows)."""
+    H = pcg.house
+    gold, cfg, G, C = _eval_setup(pcg, golden_dir)
+    res, _, _ = H.compute_metrics_per_target(G, C, gold["X_test"], gold["y_test"], dict(cfg, batch_size=int(gold["meta.batch_size"])),
+                                             rng=pcg.ops.DeviceRNG(7))
+    got = np.array([[r["class_flip"], r["prediction_gain"], r["avg_actionability"]] for r in res])
+    assert np.abs(got - gold["shipped.metrics"]).max() < 0.01, got
+    assert np.abs(got - gold["full.metrics"]).max() < 0.01, got

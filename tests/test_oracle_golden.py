@@ -278,3 +278,48 @@ def test_wgan_gp_steps_match_reference_loop(golden_dir):
             # a BatchNorm running_mean inherits the +-lr wander of the dead conv bias in front of it
             atol = 1e-4 if k_.endswith("running_mean") else 2e-5
             np.testing.assert_allclose(v.numpy(), gold[f"final.{tag}.{k_}"], rtol=1e-4, atol=atol, err_msg=f"final.{tag}.{k_}")
+
+
+# ---- evaluation path: oracle restatements against the reference's lifted eval functions -----------
+def _house_eval_setup(golden_dir):
+    gold = dict(np.load(os.path.join(golden_dir, "house_eval.npz")))
+    G, _, clf = HR.build(seed=0)
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "house_generator_trained.pt"), map_location="cpu", weights_only=True))
+    clf.load_state_dict(torch.load(os.path.join(golden_dir, "house_classifier_trained.pt"), map_location="cpu", weights_only=True))
+    G.eval(); clf.eval()
+    lo, hi = gold["scaler.data_min"], gold["scaler.data_max"]
+    norm = {f: torch.tensor((gold[f"raw_values.{f}"] - lo[f]) / ((hi[f] - lo[f]) + 1e-12), dtype=torch.float32)
+            for f in HR.CONFIG["categorical_info"]}                                            # eval_utils.py:56-67
+    return gold, G, clf, norm
+
+
+def test_house_eval_metrics_match_reference(golden_dir):
+    gold, G, clf, norm = _house_eval_setup(golden_dir)
+    n = int(gold["meta.exact_rows"])
+    X, y = torch.from_numpy(gold["X_test"][:n]), gold["y_test"][:n]
+    cfs = []
+    with torch.no_grad():
+        for t in range(4):
+            x = X[torch.from_numpy(y != t)]
+            gumbel = {f: torch.from_numpy(gold[f"exact.gumbel.{t}.{f}"]) for f in HR.CONFIG["categorical_info"]}
+            m = HR.metrics_one_target(G, clf, x, t, gumbel, norm)
+            np.testing.assert_allclose([m["class_flip"], m["prediction_gain"], m["avg_actionability"]], gold["exact.metrics"][t],
+                                       rtol=1e-5, atol=1e-6, err_msg=f"target {t}")
+            cfs.append(m["x_cf"])
+    np.testing.assert_allclose(torch.cat(cfs).numpy(), gold["exact.x_cf"], rtol=1e-5, atol=1e-6)
+    # the reference's own full run reproduces the metrics file it ships (hard Gumbel draws differ: statistical agreement)
+    assert np.abs(gold["full.metrics"] - gold["shipped.metrics"]).max() < 0.01
+
+
+def test_countergan_eval_metrics_match_reference(golden_dir):
+    gold = dict(np.load(os.path.join(golden_dir, "countergan_eval.npz")))
+    G, _, _ = CR.build(seed=0)
+    G.load_state_dict(torch.load(os.path.join(golden_dir, "countergan_generator_trained.pt"), map_location="cpu", weights_only=True))
+    torch.manual_seed(3)
+    C = CR.CNNClassifier()
+    for k, v in C.state_dict().items():
+        np.testing.assert_array_equal(_digest(v), gold[f"C.{k}"], err_msg=k)
+    m, (x_vis, x_cf_vis) = CR.evaluate_counterfactuals(G, C, torch.from_numpy(gold["x"]), torch.from_numpy(gold["y_true"]),
+                                                       torch.from_numpy(gold["y_target"]))
+    np.testing.assert_allclose([m["class_flip_rate"], m["prediction_gain"], m["actionability"]], gold["metrics"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x_cf_vis.numpy(), gold["x_cf_vis"], rtol=1e-5, atol=1e-6)
