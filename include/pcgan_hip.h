@@ -315,6 +315,19 @@ int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_
 int pcg_cf_metrics(const float* logits_cf, const float* logits_ref /*nullable*/, const int64_t* target, const int64_t* other /*nullable*/,
                    int32_t B, int32_t K, float* out /*[2]*/, pcg_stream_t stream);
 
+/* ---- classifier pre-training -----------------------------------------------------------------
+ * nn.CrossEntropyLoss(weight=class_weight), mean reduction = weighted sum / sum of the weights of the targets
+ * (house_sales_kc_usa/trainer.py:55-57) */
+int pcg_cross_entropy_weighted_fwd_bwd(const float* logits, const int64_t* target, const float* class_weight, int32_t B, int32_t K,
+                                       float grad_scale, const float* grad_out_dev /*nullable*/, float* loss /*nullable*/,
+                                       float* dlogits /*nullable*/, pcg_stream_t stream);
+/* nn.Dropout / nn.Dropout2d in training mode, forward and backward (same map): y = x * mask * scale, scale = 1/(1-p).
+ * Dropout: inner = 1, mask has n entries; Dropout2d on an NHWC activation [B][HW][C]: inner = HW, mask is [B][C]
+ * (mnist/models/classifier.py:13,19; house_sales_kc_usa/models/nn_classifier.py:11,16,22).  The 0/1 mask is an input:
+ * pcg_rand_bernoulli draws it on the device (keep probability 1-p); parity runs pass the reference's draws. */
+int pcg_dropout_apply(const float* x, const float* mask, int64_t n, int32_t inner, int32_t C, float scale, float* y, pcg_stream_t stream);
+int pcg_rand_bernoulli(float* out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,3 +221,26 @@ def evaluate_counterfactuals(generator, classifier, x, y_true, y_target):
     return {"class_flip_rate": (logits.argmax(1) == y_target).float().mean().item(),
             "prediction_gain": (probs[ar, y_target] - probs[ar, y_true]).mean().item(),
             "actionability": torch.abs(x_cf - x).mean().item()}, ((x + 1.0) / 2.0, (x_cf + 1.0) / 2.0)
+
+
+def classifier_forward_train(C, x, masks):
+    """CNNClassifier.forward in training mode (classifier.py:22-28) with the Dropout2d(0.25) / Dropout(0.5) noise supplied:
+    masks = (m2d [B,128], m1 [B,256]) of {0,1}; [torch] dropout multiplies by mask / (1 - p)."""
+    m2d, m1 = masks
+    h = x
+    for m in C.conv:
+        h = h * (m2d[:, :, None, None].to(h.dtype) / (1 - m.p)) if isinstance(m, nn.Dropout2d) else m(h)
+    for m in C.fc:
+        h = h * (m1.to(h.dtype) / (1 - m.p)) if isinstance(m, nn.Dropout) else m(h)
+    return h
+
+
+def classifier_train_step(C, optimizer, x, y, masks):
+    """One iteration of train_classifier's inner loop, trainer.py:16-20."""
+    import torch.nn.functional as F
+    C.train()
+    optimizer.zero_grad()
+    loss = F.cross_entropy(classifier_forward_train(C, x, masks), y)
+    loss.backward()
+    optimizer.step()
+    return loss.item()

@@ -211,3 +211,28 @@ def synthetic_batch(batch, seed, config=CONFIG, dtype=torch.float32):
     mask[:, config["immutable_idx"]] = 0.0
     gumbel = {f: -torch.empty(batch, n, dtype=dtype).exponential_(generator=g).log() for f, n in config["categorical_info"].items()}
     return x, y, t, mask, gumbel
+
+
+def classifier_forward_train(clf, x, masks):
+    """NNClassifier.forward in training mode (nn_classifier.py:8-32) with the three Dropout noises supplied (masks of {0,1})."""
+    h, it = x, iter(masks)
+    for m in clf.net:
+        h = h * (next(it).to(h.dtype) / (1 - m.p)) if isinstance(m, nn.Dropout) else m(h)
+    return h
+
+
+def balanced_class_weights(y, num_classes):
+    """[sklearn] compute_class_weight('balanced'): n_samples / (n_classes * bincount(y))   (trainer.py:53)."""
+    import numpy as np
+    y = np.asarray(y)
+    return len(y) / (num_classes * np.bincount(y, minlength=num_classes).astype(np.float64))
+
+
+def classifier_train_step(clf, optimizer, class_weights, x, y, masks):
+    """One iteration of train_classifier's inner loop, trainer.py:78-87 (weighted CrossEntropyLoss :55-57)."""
+    clf.train()
+    optimizer.zero_grad()
+    loss = F.cross_entropy(classifier_forward_train(clf, x, masks), y, weight=class_weights)
+    loss.backward()
+    optimizer.step()
+    return loss.item()

@@ -30,6 +30,8 @@ class Config:
     num_epochs_gan = 20
     d_lr = 1e-5
     g_lr = 5e-5
+    cls_lr = 1e-3
+    num_epochs_clf = 10
     lambda_adv = 1.0
     lambda_cls = 1.0
     lambda_reg = 2.5
@@ -396,12 +398,29 @@ class _CFn(torch.autograd.Function):
         return None, ctx.net._run_backward(ctx.saved, dlogits)
 
 
-class CNNClassifier(nn.Module):
-    """classifier.py:4-28, as the GAN step uses it: eval mode, parameters frozen (main.py:30-33) — forward and the
-    gradient with respect to the input image.  Training it (trainer.py:8-39) is not part of this path."""
+class _CTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, masks, *params):
+        logits, saved = net._train_forward(x, masks)
+        ctx.net, ctx.saved = net, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.net._train_backward(ctx.saved, dlogits)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class CNNClassifier(FlatModule):
+    """classifier.py:4-28.  In the GAN step it is frozen and in eval mode (main.py:30-33): forward and the gradient with
+    respect to the input image, on packed weights.  In training mode (pre-training, trainer.py:8-39 — SURVEY.md section 8f
+    item 3) it is a regular trainable net: Dropout2d(0.25) / Dropout(0.5) masks come from `self.rng` (a device Philox
+    stream) or, for runs that must reproduce given draws, from `self.dropout_masks = [mask2d [B,128], mask [B,256]]`."""
 
     def __init__(self, num_classes=10):
         super().__init__()
+        self.rng = None
+        self.dropout_masks = None
         self.conv = nn.Sequential(
             nn.Conv2d(1, 32, 3, 1, 1), nn.ReLU(),
             nn.Conv2d(32, 64, 3, 2, 1), nn.ReLU(),
@@ -435,12 +454,69 @@ class CNNClassifier(nn.Module):
         self._packed = (key, packed)
         return packed
 
+    def train(self, mode=True):
+        # the optimizer kernel updates parameters in place without touching torch's version counters: drop the packed eval
+        # image whenever the mode changes so that eval after training sees the new weights
+        self._packed = None
+        return super().train(mode)
+
     def forward(self, x):
         if not x.is_cuda:
             raise PcgError(f"CNNClassifier: input is on {x.device}; libpcgan_hip has no CPU path")
+        if self.training:
+            self._ensure_flat()
+            B = x.shape[0]
+            masks = self.dropout_masks
+            if masks is None:
+                if self.rng is None:
+                    self.rng = ops.DeviceRNG(seed=0)
+                masks = [self.rng.bernoulli((B, 128), x.device, 0.75), self.rng.bernoulli((B, 256), x.device, 0.5)]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                return _CTrainFn.apply(self, x, masks, *self.parameters())
+            return self._train_forward(x, masks)[0]
         if torch.is_grad_enabled() and x.requires_grad:
             return _CFn.apply(self, x)
         return self._run_forward(x, keep=False)[0]
+
+    # -- training mode (trainer.py:15-20) ------------------------------------------------------------------------------------
+    def _train_forward(self, x, masks):
+        from .nn import linear_fwd
+        B = x.shape[0]
+        a = _as_rows(x, B).view(B, 28, 28, 1)
+        layers = []
+        for conv in (m for m in self.conv if isinstance(m, nn.Conv2d)):
+            g, y = _conv_fwd(conv, a, ACT_RELU)
+            layers.append((conv, g, a, y))
+            a = y
+        m2d, m1 = masks
+        HW, C = a.shape[1] * a.shape[2], a.shape[3]
+        ad = ops.dropout_apply(a, m2d.contiguous(), 0.25, inner=HW, C=C)                       # Dropout2d(0.25) :13
+        flat = ops.nhwc_to_nchw_flat(ad, B, HW, C).view(B, HW * C)                            # nn.Flatten of the NCHW tensor :16
+        fc1, fc2 = self.fc[1], self.fc[4]
+        h = linear_fwd(fc1, flat)
+        ops.act_fwd(h, ACT_RELU, 0.0, out=h)
+        hd = ops.dropout_apply(h, m1.contiguous(), 0.5)                                       # Dropout(0.5) :19
+        logits = linear_fwd(fc2, hd)
+        return logits, (layers, m2d, m1, flat, h, hd, (HW, C))
+
+    def _train_backward(self, saved, dlogits):
+        from .nn import linear_dgrad, linear_wgrad
+        layers, m2d, m1, flat, h, hd, (HW, C) = saved
+        B = flat.shape[0]
+        fc1, fc2 = self.fc[1], self.fc[4]
+        dl = dlogits.contiguous()
+        linear_wgrad(self, fc2, hd, dl)
+        d = linear_dgrad(fc2.weight.data, dl, B)
+        d = ops.dropout_apply(d, m1.contiguous(), 0.5, out=d)
+        ops.act_bwd(d, h, ACT_RELU, 0.0, out=d)
+        linear_wgrad(self, fc1, flat, d)
+        d = linear_dgrad(fc1.weight.data, d, B)
+        d = ops.nhwc_to_nchw_flat(d, B, HW, C, inverse=True).view(layers[-1][3].shape)
+        d = ops.dropout_apply(d, m2d.contiguous(), 0.25, inner=HW, C=C, out=d)
+        for i in range(len(layers) - 1, -1, -1):
+            conv, g, a, y = layers[i]
+            ops.act_bwd(d, y, ACT_RELU, 0.0, out=d)
+            d = _conv_bwd(self, conv, g, a, d, True, i > 0)
 
     def _run_forward(self, x, keep=True):
         cw, w1, b1, w2, b2, kp = self._pack()
@@ -535,6 +611,38 @@ def generate_counterfactuals(generator, classifier, x, y, y_target, mask, device
         raw_residual, masked_residual = generator(x, y_target, mask)
         x_cf = clamp_add(x, masked_residual, -1.0, 1.0)
     return raw_residual, masked_residual, x_cf
+
+
+def train_classifier(classifier, train_loader, valid_loader, cfg, device, save=True):
+    """trainer.py:8-39 — Adam(cls_lr), CrossEntropyLoss, per-epoch validation accuracy, best state saved to
+    cfg.classifier_path."""
+    optimizer = Adam(classifier.parameters(), lr=cfg.cls_lr)
+    criterion = CrossEntropyLoss()
+    best_acc, history = 0.0, []
+    for epoch in range(cfg.num_epochs_clf):
+        classifier.train()
+        for x, y in train_loader:
+            x, y = x.to(device), y.to(device)
+            optimizer.zero_grad()
+            loss = criterion(classifier(x), y)
+            loss.backward()
+            optimizer.step()
+        classifier.eval()
+        correct, total = 0.0, 0
+        with torch.no_grad():
+            for x, y in valid_loader:
+                x, y = x.to(device), y.to(device)
+                acc_b = ops.cf_metrics(classifier(x).contiguous(), y, other=y)[0].item()     # mean(argmax == y)
+                correct += acc_b * y.size(0)
+                total += y.size(0)
+        acc = correct / max(total, 1)
+        history.append(acc)
+        print(f"[Classifier] Epoch {epoch + 1}/{cfg.num_epochs_clf} | Val Acc: {acc:.4f}")
+        if acc > best_acc:
+            best_acc = acc
+            if save and getattr(cfg, "classifier_path", None):
+                torch.save({k: v.detach().cpu().contiguous() for k, v in classifier.state_dict().items()}, cfg.classifier_path)
+    return history
 
 
 def grad_norm(net):

@@ -327,3 +327,79 @@ extern "C" int pcg_cf_metrics(const float* logits_cf, const float* logits_ref, c
   hipLaunchKernelGGL(cf_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_cf, logits_ref, target, other, B, K, out);
   return launch_status("cf_metrics_kernel");
 }
+
+namespace pcg { namespace {
+// nn.CrossEntropyLoss(weight=w), reduction mean:  loss = sum_b w[t_b] * (lse_b - z_b[t_b]) / sum_b w[t_b]
+__global__ void __launch_bounds__(256) cross_entropy_weighted_kernel(const float* __restrict__ z, const int64_t* __restrict__ target,
+                                                                     const float* __restrict__ w, int B, int K, float grad_scale,
+                                                                     const float* __restrict__ gout, float* loss, float* __restrict__ dz) {
+  __shared__ float red[256];
+  __shared__ float s_wsum;
+  float ws = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    int64_t t = target[b];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    ws += w[t];
+  }
+  red[threadIdx.x] = ws;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_wsum = red[0];
+  __syncthreads();
+  const float wsum = s_wsum;
+  const float g = grad_scale * (gout ? gout[0] : 1.f) / wsum;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* r = z + (size_t)b * K;
+    float mx = r[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, r[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(r[k] - mx);
+    const float lse = mx + logf(se);
+    int64_t t = target[b];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    const float wt = w[t];
+    acc += wt * (lse - r[t]);
+    if (dz)
+      for (int k = 0; k < K; ++k) dz[(size_t)b * K + k] = g * wt * (expf(r[k] - lse) - (k == (int)t ? 1.f : 0.f));
+  }
+  __syncthreads();
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) loss[0] = red[0] / wsum;
+}
+
+// Dropout / Dropout2d: y[i] = x[i] * mask[m(i)] * scale, scale = 1/(1-p); mask has one entry per (row, channel) with
+// `inner` positions sharing it (Dropout: inner = 1 -> m(i) = i; Dropout2d on NHWC [B][HW][C]: inner = HW)
+__global__ void __launch_bounds__(256) dropout_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask, size_t n, int inner,
+                                                            int C, float scale, float* __restrict__ y) {
+  const size_t per = (size_t)inner * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t m = inner == 1 ? i : (i / per) * C + (i % C);
+    y[i] = x[i] * mask[m] * scale;
+  }
+}
+} }
+
+extern "C" int pcg_cross_entropy_weighted_fwd_bwd(const float* logits, const int64_t* target, const float* class_weight, int32_t B, int32_t K,
+                                                  float grad_scale, const float* grad_out_dev, float* loss, float* dlogits,
+                                                  pcg_stream_t stream) {
+  PCG_REQUIRE(logits && target && class_weight && B > 0 && K > 0 && (loss || dlogits), "pcg_cross_entropy_weighted_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_weighted_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, class_weight, B, K, grad_scale,
+                     grad_out_dev, loss, dlogits);
+  return launch_status("cross_entropy_weighted_kernel");
+}
+
+extern "C" int pcg_dropout_apply(const float* x, const float* mask, int64_t n, int32_t inner, int32_t C, float scale, float* y,
+                                 pcg_stream_t stream) {
+  PCG_REQUIRE(x && mask && y && n > 0 && inner > 0 && C > 0 && n % ((int64_t)inner * C) == 0, "pcg_dropout_apply: bad arguments");
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, mask, (size_t)n, inner, C, scale, y);
+  return launch_status("dropout_apply_kernel");
+}

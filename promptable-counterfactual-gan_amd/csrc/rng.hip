@@ -156,6 +156,18 @@ __global__ void __launch_bounds__(256) uniform_kernel(float* __restrict__ out, i
   }
 }
 
+__global__ void __launch_bounds__(256) bernoulli_kernel(float* __restrict__ out, int64_t n, float keep, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+    const U4 r = draw(seed, offset, (uint64_t)i);
+    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j < n) out[j] = (float)(v[e] >> 8) * (1.0f / 16777216.0f) < keep ? 1.f : 0.f;
+    }
+  }
+}
+
 unsigned grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -210,4 +222,10 @@ extern "C" int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t o
   PCG_REQUIRE(out && n > 0, "pcg_rand_uniform: bad arguments");
   hipLaunchKernelGGL(uniform_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
   return launch_status("uniform_kernel");
+}
+
+extern "C" int pcg_rand_bernoulli(float* out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, pcg_stream_t stream) {
+  PCG_REQUIRE(out && n > 0 && keep_prob >= 0.f && keep_prob <= 1.f, "pcg_rand_bernoulli: bad arguments");
+  hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, keep_prob, seed, offset);
+  return launch_status("bernoulli_kernel");
 }

@@ -401,14 +401,14 @@ extern "C" size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t
   const WgradPlan p = plan_linear_wgrad(B, O, I);
   return p.S > 1 ? (size_t)p.S * O * (I + 1) * sizeof(float) : 0;
 }
-extern "C" int32_t pcg_linear_wgrad_ticket_count(void) { return 64; }
+extern "C" int32_t pcg_linear_wgrad_ticket_count(void) { return 4096; }
 
 extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW,
                                 float* db, int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets,
                                 pcg_stream_t stream) {
   PCG_REQUIRE(dy && x && dW && B > 0 && O > 0 && I > 0 && ldy >= O && ldx >= I, "pcg_linear_wgrad: bad arguments");
   const WgradPlan p = plan_linear_wgrad(B, O, I);
-  PCG_REQUIRE(p.tiles <= 64, "pcg_linear_wgrad: layer %dx%d needs %d tiles (limit 64: widths up to 511)", O, I, p.tiles);
+  PCG_REQUIRE(p.tiles <= 4096, "pcg_linear_wgrad: layer %dx%d needs %d tiles (limit 4096)", O, I, p.tiles);
   if (p.S > 1) {
     PCG_REQUIRE(tickets, "pcg_linear_wgrad: tickets buffer required");
     if (!workspace || workspace_bytes < pcg_linear_wgrad_workspace_bytes(B, O, I)) { set_error("pcg_linear_wgrad: workspace too small"); return PCG_ERR_WORKSPACE; }

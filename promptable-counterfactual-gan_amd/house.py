@@ -387,14 +387,30 @@ class _CFn(torch.autograd.Function):
         return None, ctx.net._run_backward(ctx.saved, dlogits)
 
 
-class NNClassifier(nn.Module):
-    """nn_classifier.py:4-32 as the GAN step uses it: eval mode, parameters frozen (main.py:27-30) — forward and the
-    gradient with respect to the input row.  In eval mode each BatchNorm1d is a per-column affine map, so it is folded
-    into the following Linear once (fp64 at pack time): the step runs 5 GEMMs and 4 LeakyReLUs.  Training the
-    classifier (trainer.py:25-176) is not part of this path."""
+class _CTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, masks, *params):
+        logits, saved = net._train_forward(x, masks)
+        ctx.net, ctx.saved = net, saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.net._train_backward(ctx.saved, dlogits)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class NNClassifier(FlatModule):
+    """nn_classifier.py:4-32.  In the GAN step: eval mode, parameters frozen (main.py:27-30) — forward and the gradient with
+    respect to the input row; each BatchNorm1d is then a per-column affine map folded into the following Linear once (fp64 at
+    pack time): 5 GEMMs and 4 LeakyReLUs.  In training mode (pre-training, trainer.py:18-180 — SURVEY.md section 8f item 3):
+    Linear -> LeakyReLU(0.1) -> BatchNorm1d (batch statistics) -> Dropout, with the Dropout masks from `self.rng` (device
+    Philox stream) or `self.dropout_masks = [m0 [B,256], m1 [B,256], m2 [B,128]]` for runs that must reproduce given draws."""
 
     def __init__(self, input_dim, output_dim=4):
         super().__init__()
+        self.rng = None
+        self.dropout_masks = None
         self.net = nn.Sequential(
             nn.Linear(input_dim, 256), nn.LeakyReLU(0.1), nn.BatchNorm1d(256), nn.Dropout(0.3),
             nn.Linear(256, 256), nn.LeakyReLU(0.1), nn.BatchNorm1d(256), nn.Dropout(0.2),
@@ -425,12 +441,79 @@ class NNClassifier(nn.Module):
         self._packed = (key, packed)
         return packed
 
+    def train(self, mode=True):
+        # the optimizer kernel updates parameters in place without touching torch's version counters: drop the packed eval
+        # image whenever the mode changes so that eval after training sees the new weights
+        self._packed = None
+        return super().train(mode)
+
     def forward(self, x):
         if not x.is_cuda:
             raise PcgError(f"NNClassifier: input is on {x.device}; libpcgan_hip has no CPU path")
+        if self.training:
+            self._ensure_flat()
+            masks = self.dropout_masks
+            if masks is None:
+                if self.rng is None:
+                    self.rng = ops.DeviceRNG(seed=0)
+                masks = [self.rng.bernoulli((x.shape[0], m_.out_features), x.device, 1.0 - p_) for m_, p_ in self._dropout_sites()]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                return _CTrainFn.apply(self, x, masks, *self.parameters())
+            return self._train_forward(x, masks)[0]
         if torch.is_grad_enabled() and x.requires_grad:
             return _CFn.apply(self, x)
         return self._run_forward(x, keep=False)[0]
+
+    # -- training mode ------------------------------------------------------------------------------------------------------------
+    def _stages(self):
+        """[(Linear, BatchNorm1d, dropout p or None)] + the final Linear."""
+        mods, stages, i = list(self.net), [], 0
+        while i < len(mods) - 1:
+            lin, bn = mods[i], mods[i + 2]
+            p = mods[i + 3].p if i + 3 < len(mods) and isinstance(mods[i + 3], nn.Dropout) else None
+            stages.append((lin, bn, p))
+            i += 4 if p is not None else 3
+        return stages, mods[-1]
+
+    def _dropout_sites(self):
+        return [(lin, p) for lin, _, p in self._stages()[0] if p is not None]
+
+    def _train_forward(self, x, masks):
+        stages, last = self._stages()
+        a = x.contiguous()
+        saved, mi = [], 0
+        for lin, bn, p in stages:
+            z = _lin_fwd(lin, a)
+            ops.act_fwd(z, ACT_LRELU, 0.1, out=z)                                            # act output (BatchNorm input)
+            C = bn.num_features
+            mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+            n = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, ACT_NONE)
+            mask = None
+            if p is not None:
+                mask = masks[mi].contiguous(); mi += 1
+                n = ops.dropout_apply(n, mask, p, out=n)
+            saved.append((lin, bn, p, a, z, mean, invstd, mask))
+            a = n
+        logits = _lin_fwd(last, a)
+        return logits, (saved, last, a)
+
+    def _train_backward(self, saved_all, dlogits):
+        saved, last, a_last = saved_all
+        B = a_last.shape[0]
+        d = dlogits.contiguous()
+        _lin_wgrad(self, last, a_last, d)
+        d = _lin_dgrad(last.weight.data, d, B)
+        for idx in range(len(saved) - 1, -1, -1):
+            lin, bn, p, a, z, mean, invstd, mask = saved[idx]
+            if p is not None:
+                d = ops.dropout_apply(d, mask, p, out=d)
+            gg, acc = self._grad_view(bn.weight)
+            gb, _ = self._grad_view(bn.bias)
+            d = ops.bn_act_bwd(d, z, None, bn.num_features, mean, invstd, bn.weight.data, ACT_NONE, 0.0, gg, gb, acc)
+            ops.act_bwd(d, z, ACT_LRELU, 0.1, out=d)
+            _lin_wgrad(self, lin, a, d)
+            if idx > 0:
+                d = _lin_dgrad(lin.weight.data, d, B)
 
     def _run_forward(self, x, keep=True):
         packed = self._pack()
@@ -612,6 +695,102 @@ class GraphedTrainStep:
     def replay(self):
         self.graph.replay()
         return self.out
+
+
+class WeightedCrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss(weight=class_weights) (trainer.py:55-57)."""
+
+    def __init__(self, weight):
+        super().__init__()
+        self.register_buffer("weight", weight)
+
+    def forward(self, input, target):
+        return _WCEFn.apply(input, target, self.weight)
+
+
+class _WCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        zc = logits.contiguous()
+        ctx.save_for_backward(zc, target, weight)
+        loss, _ = ops.cross_entropy_weighted_fwd_bwd(zc, target, weight, need_grad=False)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        z, target, weight = ctx.saved_tensors
+        _, dz = ops.cross_entropy_weighted_fwd_bwd(z, target, weight, need_loss=False, grad_out=g.contiguous().view(1))
+        return dz, None, None
+
+
+def train_classifier(X_train_all, X_test, y_train_all, y_test, scaler, config, device=None, verbose=True):
+    """trainer.py:18-180 without the plotting tail: stratified validation split, class-weighted CrossEntropyLoss, AdamW,
+    ReduceLROnPlateau(factor 0.5, patience 4), early stopping on the validation loss; returns the model with its best state."""
+    import copy
+    import numpy as np
+    from sklearn.model_selection import train_test_split
+    from sklearn.utils.class_weight import compute_class_weight
+    from torch.utils.data import DataLoader, TensorDataset
+    from .optim import AdamW
+    device = torch.device(device if device is not None else config.get("cuda", "cuda:0"))
+    seed = config.get("seed", 42)
+    torch.manual_seed(seed); np.random.seed(seed)                                             # :20-22
+    X_train, X_val, y_train, y_val = train_test_split(X_train_all, y_train_all, test_size=config.get("val_frac", 0.10),
+                                                      random_state=seed, stratify=y_train_all)   # :29-31
+    num_classes = int(np.unique(y_train_all).size)
+    bs = config.get("clf_batch_size", config.get("batch_size", 128))
+    mk = lambda X, y: TensorDataset(torch.tensor(X, dtype=torch.float32), torch.tensor(y, dtype=torch.long))  # noqa: E731
+    train_loader = DataLoader(mk(X_train, y_train), batch_size=bs, shuffle=True, drop_last=False)
+    val_loader = DataLoader(mk(X_val, y_val), batch_size=bs, shuffle=False)
+    model = NNClassifier(config["input_dim"], output_dim=num_classes).to(device)              # :50
+    cw = compute_class_weight("balanced", classes=np.arange(num_classes), y=y_train)          # :53
+    criterion = WeightedCrossEntropyLoss(torch.tensor(cw, dtype=torch.float32, device=device))
+    optimizer = AdamW(model.parameters(), lr=config.get("clf_lr", 1e-3), weight_decay=config.get("clf_wd", 1e-4))   # :58
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.5, patience=4)           # :59
+    best_val, best_state, wait = float("inf"), None, 0
+    patience, epochs = config.get("clf_early_stopping", 15), config.get("clf_epochs", 100)
+    history = []
+    for epoch in range(1, epochs + 1):
+        model.train()
+        run_loss, correct, total = 0.0, 0.0, 0
+        for xb, yb in train_loader:
+            xb, yb = xb.to(device), yb.to(device)
+            optimizer.zero_grad()
+            logits = model(xb)
+            loss = criterion(logits, yb)
+            loss.backward()
+            optimizer.step()
+            n = xb.size(0)
+            run_loss += loss.item() * n
+            correct += ops.cf_metrics(logits.detach().contiguous(), yb, other=yb)[0].item() * n
+            total += n
+        model.eval()
+        v_loss, v_correct, v_total = 0.0, 0.0, 0
+        with torch.no_grad():
+            for xb, yb in val_loader:
+                xb, yb = xb.to(device), yb.to(device)
+                logits = model(xb).contiguous()
+                n = xb.size(0)
+                v_loss += ops.cross_entropy_weighted_fwd_bwd(logits, yb, criterion.weight, need_grad=False)[0].item() * n
+                v_correct += ops.cf_metrics(logits, yb, other=yb)[0].item() * n
+                v_total += n
+        val_loss = v_loss / v_total
+        scheduler.step(val_loss)                                                              # :128
+        history.append((run_loss / total, correct / total, val_loss, v_correct / v_total))
+        if val_loss < best_val - 1e-6:                                                        # :129-139
+            best_val, wait = val_loss, 0
+            best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            wait += 1
+        if verbose:
+            print(f"[Epoch {epoch}/{epochs}] train_loss={history[-1][0]:.4f}, train_acc={history[-1][1]:.4f} | "
+                  f"val_loss={val_loss:.4f}, val_acc={history[-1][3]:.4f} | wait={wait}")
+        if wait >= patience:
+            break
+    if best_state is not None:
+        model.load_state_dict(best_state)                                                     # :150-151
+    model.history = history
+    return model
 
 
 def draw_batch_randoms(rng, generator, y, config, device):

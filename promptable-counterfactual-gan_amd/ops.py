@@ -537,6 +537,25 @@ def spectral_norm_bwd(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate):
                                             _stream()), "pcg_spectral_norm_bwd")
 
 
+def cross_entropy_weighted_fwd_bwd(logits, target, class_weight, need_loss=True, need_grad=True, grad_out=None, grad_scale=1.0):
+    _chk(logits, "logits"); _chk_idx(target, logits.shape[-1], "target"); _chk(class_weight, "class_weight")
+    B, K = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device) if need_loss else None
+    dz = torch.empty_like(logits) if need_grad else None
+    check(_lib.load().pcg_cross_entropy_weighted_fwd_bwd(_p(logits), _p(target), _p(class_weight), B, K, float(grad_scale), _p(grad_out),
+                                                         _p(loss), _p(dz), _stream()), "pcg_cross_entropy_weighted_fwd_bwd")
+    return loss, dz
+
+
+def dropout_apply(x, mask, p, inner=1, C=None, out=None):
+    """y = x * mask / (1 - p); mask one entry per element (inner=1) or per (sample, channel) of an NHWC activation (inner=HW)."""
+    _chk(x, "x"); _chk(mask, "mask")
+    C = C if C is not None else x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.load().pcg_dropout_apply(_p(x), _p(mask), x.numel(), inner, C, 1.0 / (1.0 - p), _p(y), _stream()), "pcg_dropout_apply")
+    return y
+
+
 def cf_metrics(logits_cf, target, logits_ref=None, other=None):
     """[class-flip rate, prediction gain] as a 2-element device tensor (see pcg_cf_metrics)."""
     _chk(logits_cf, "logits_cf"); _chk_idx(target, logits_cf.shape[1], "target")
@@ -663,4 +682,12 @@ class DeviceRNG:
         out = torch.empty(shape, dtype=torch.float32, device=device)
         n = out.numel()
         check(_lib.load().pcg_rand_uniform(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_uniform")
+        return out
+
+    def bernoulli(self, shape, device, keep_prob):
+        """0/1 mask with P(1) = keep_prob — the noise nn.Dropout / nn.Dropout2d draw."""
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        check(_lib.load().pcg_rand_bernoulli(_p(out), n, float(keep_prob), self.seed, self._advance((n + 3) // 4), _stream()),
+              "pcg_rand_bernoulli")
         return out

@@ -574,6 +574,138 @@ def make_countergan_eval(path, batch=16):
     print(f"wrote {path}: metrics {out['metrics']}")
 
 
+def _dropout_recorder(module, store):
+    """Forward pre-hook factory: remember the RNG state right before a Dropout module draws its noise (training calls only)."""
+    def hook(mod, args):
+        if mod.training:
+            store.append((mod, tuple(args[0].shape), torch.get_rng_state()))
+    return module.register_forward_pre_hook(hook)
+
+
+def _replay_dropout(store):
+    """[torch] nn.Dropout: noise = empty_like(x).bernoulli_(1-p); nn.Dropout2d: noise = empty([B,C,1,1]).bernoulli_(1-p)."""
+    keep = torch.get_rng_state()
+    masks = []
+    for mod, shape, state in store:
+        torch.set_rng_state(state)
+        nshape = (shape[0], shape[1], 1, 1) if isinstance(mod, torch.nn.Dropout2d) else shape
+        masks.append(torch.empty(nshape).bernoulli_(1 - mod.p).reshape(shape[0], -1).numpy().copy())
+    torch.set_rng_state(keep)
+    return masks
+
+
+def make_classifier_pretrain(path_mnist, path_house):
+    """SURVEY.md section 8f item 3 — the classifier pre-training loops, run by the reference's own functions:
+    conditional_counteRGAN/mnist/trainer.py:train_classifier (:8-39) on two seeded batches + one validation batch, and
+    house_sales_kc_usa/trainer.py:train_classifier (:18-180) for one epoch of three batches (its NNClassifier is created
+    inside the function: the class it sees is wrapped to attach the hooks).  Dropout draws are replayed from captured RNG
+    states; the batches the shuffling DataLoader produced are captured at the model input."""
+    import contextlib, importlib, io, types
+    # ---- mnist
+    mdir = os.path.join(REF, "conditional_counteRGAN/mnist")
+    sys.path.insert(0, mdir)
+    for name in list(sys.modules):
+        if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+            sys.modules.pop(name)
+    clf_mod = importlib.import_module("models.classifier")
+    trainer = importlib.import_module("trainer")
+    torch.manual_seed(5)
+    C = clf_mod.CNNClassifier()
+    out = {}
+    for k, v in C.state_dict().items():
+        out[f"init.{k}"] = tensor_digest(v)
+    g = torch.Generator().manual_seed(31)
+    batches = [(torch.rand(8, 1, 28, 28, generator=g) * 2 - 1, torch.randint(0, 10, (8,), generator=g)) for _ in range(3)]
+    store = []
+    hooks = [_dropout_recorder(m, store) for m in C.modules() if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d))]
+    cfg = types.SimpleNamespace(cls_lr=1e-3, num_epochs_clf=1, classifier_path="/tmp/pcg_golden_clf.pt")
+    buf = io.StringIO()
+    torch.manual_seed(77)
+    with contextlib.redirect_stdout(buf):
+        trainer.train_classifier(C, batches[:2], batches[2:], cfg, "cpu")
+    for h in hooks:
+        h.remove()
+    masks = _replay_dropout(store)
+    assert len(masks) == 4
+    for i, (x, y) in enumerate(batches):
+        out[f"x{i}"], out[f"y{i}"] = x.numpy(), y.numpy()
+    for i, m in enumerate(masks):
+        out[f"mask{i}"] = m                                   # step0: Dropout2d [8,128], Dropout [8,256]; step1: same
+    out["log"] = np.array(buf.getvalue())
+    for k, v in C.state_dict().items():
+        out[f"final.{k}"] = tensor_digest(v)
+    out["final.fc.4.weight.full"] = C.state_dict()["fc.4.weight"].numpy().copy()
+    out["final.conv.0.weight.full"] = C.state_dict()["conv.0.weight"].numpy().copy()
+    np.savez_compressed(path_mnist, **out)
+    print(f"wrote {path_mnist}; {buf.getvalue().strip().splitlines()[0]}")
+    # ---- house
+    hdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    scratch = "/tmp/pcg_golden_house"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        sys.path.remove(mdir)
+        sys.path.insert(0, hdir)
+        for name in list(sys.modules):
+            if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+                sys.modules.pop(name)
+        cfg = importlib.import_module("config").config
+        trainer = importlib.import_module("trainer")
+        base_cls = trainer.NNClassifier
+        store, inputs, made = [], [], []
+
+        class Hooked(base_cls):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                made.append({kk: vv.clone() for kk, vv in self.state_dict().items()})
+                for m in self.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        _dropout_recorder(m, store)
+                self.register_forward_pre_hook(lambda mod, args: inputs.append((mod.training, args[0].clone())))
+        trainer.NNClassifier = Hooked
+        # the reference passes verbose=True to ReduceLROnPlateau (:59), a logging-only argument that torch >= 2.7 no longer
+        # accepts (the reference pins torch 2.4.1): drop it for the duration of the call
+        _RLP = torch.optim.lr_scheduler.ReduceLROnPlateau
+
+        class _RLPCompat(_RLP):
+            def __init__(self, *a, verbose=None, **k):
+                super().__init__(*a, **k)
+        torch.optim.lr_scheduler.ReduceLROnPlateau = _RLPCompat
+        rs = np.random.RandomState(3)
+        X = rs.random_sample((160, cfg["input_dim"])).astype(np.float64)
+        y = np.arange(160) % 4
+        rs.shuffle(y)
+        y[:10] = 0                                                             # a little imbalance: non-trivial class weights
+        cfg.update({"cuda": "cpu", "clf_epochs": 1, "batch_size": 48, "out_dir": scratch, "clf_model_path": os.path.join(scratch, "clf.pt")})
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            model = trainer.train_classifier(X, X[:8], y, y[:8], None, cfg)
+        trainer.NNClassifier = base_cls
+        torch.optim.lr_scheduler.ReduceLROnPlateau = _RLP
+        masks = _replay_dropout(store)
+        train_inputs = [t for tr, t in inputs if tr]
+        val_inputs = [t for tr, t in inputs if not tr]
+        assert len(train_inputs) == 3 and len(masks) == 9
+        out = {"X": X.astype(np.float32), "y": y.astype(np.int64), "log": np.array(buf.getvalue()), "meta.steps": np.int64(3)}
+        for k, v in made[0].items():
+            out[f"init.{k}"] = v.numpy().copy()
+        Xf = torch.tensor(X, dtype=torch.float32)
+        for i, t in enumerate(train_inputs):
+            rows = np.array([int(torch.nonzero((Xf == r).all(1))[0]) for r in t])
+            out[f"step{i}.rows"] = rows
+            for j in range(3):
+                out[f"step{i}.mask{j}"] = masks[3 * i + j]
+        vrows = np.concatenate([np.array([int(torch.nonzero((Xf == r).all(1))[0]) for r in t]) for t in val_inputs])
+        out["val.rows"] = vrows
+        for k, v in model.state_dict().items():
+            out[f"final.{k}"] = v.numpy().copy()
+        np.savez_compressed(path_house, **out)
+        print(f"wrote {path_house}; {buf.getvalue().strip().splitlines()[0]}")
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -587,3 +719,4 @@ if __name__ == "__main__":
     make_wgan_small(os.path.join(HERE, "wgan_ref_small.npz"))
     make_house_eval(os.path.join(HERE, "house_eval.npz"))
     make_countergan_eval(os.path.join(HERE, "countergan_eval.npz"))
+    make_classifier_pretrain(os.path.join(HERE, "classifier_pretrain_mnist.npz"), os.path.join(HERE, "classifier_pretrain_house.npz"))

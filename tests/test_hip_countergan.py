@@ -233,3 +233,60 @@ def test_evaluate_counterfactuals_matches_reference(pcg, golden_dir):
                                                       torch.from_numpy(gold["y_target"]), torch.device(DEV))
     np.testing.assert_allclose([m["class_flip_rate"], m["prediction_gain"], m["actionability"]], gold["metrics"], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(x_cf_vis.numpy(), gold["x_cf_vis"], rtol=1e-4, atol=2e-5)
+
+
+def test_classifier_pretraining_matches_reference(pcg, golden_dir):
+    """mnist/trainer.py:train_classifier as run by the reference on two seeded batches (+ one validation batch): CNNClassifier
+    in training mode with the reference's Dropout2d / Dropout draws, Adam(1e-3), CrossEntropyLoss.  (a) per step, from the
+    float64 oracle's current parameters: loss and every gradient (1e-4 of scale or 3x the float32 oracle's own distance);
+    (b) the free-running result against the reference's final state, every entry within the total possible Adam move, and
+    the validation accuracy it printed."""
+    import re
+    import torch.nn.functional as F
+    K = pcg.countergan
+    gold = dict(np.load(os.path.join(golden_dir, "classifier_pretrain_mnist.npz")))
+    torch.manual_seed(5)
+    o64 = CR.CNNClassifier()
+    init = {k: v.clone() for k, v in o64.state_dict().items()}
+    for k, v in init.items():
+        np.testing.assert_array_equal(_digest(v), gold[f"init.{k}"], err_msg=k)
+    o32 = CR.CNNClassifier(); o32.load_state_dict(init)
+    o64 = o64.double()
+    opt64 = torch.optim.Adam(o64.parameters(), lr=1e-3)
+    mine = K.CNNClassifier(); mine.load_state_dict(init)
+    mine = mine.to(DEV).train()
+    ce = K.CrossEntropyLoss()
+    for i in range(2):
+        x, y = torch.from_numpy(gold[f"x{i}"]), torch.from_numpy(gold[f"y{i}"])
+        masks = (torch.from_numpy(gold[f"mask{2 * i}"]), torch.from_numpy(gold[f"mask{2 * i + 1}"]))
+        sd = {k: v.float() for k, v in o64.state_dict().items()}
+        o32.load_state_dict(sd); mine.load_state_dict(sd)
+        o32.train(); o32.zero_grad()
+        l32 = F.cross_entropy(CR.classifier_forward_train(o32, x, masks), y); l32.backward()
+        l64 = CR.classifier_train_step(o64, opt64, x.double(), y, masks)
+        mine.dropout_masks = [m.to(DEV) for m in masks]
+        mine.zero_grad()
+        lm = ce(mine(x.to(DEV)), y.to(DEV)); lm.backward()
+        assert abs(lm.item() - l64) <= max(2e-5, 3 * abs(l32.item() - l64)), (i, lm.item(), l64)
+        for (n, p), (_, q32), (_, q64) in zip(mine.named_parameters(), o32.named_parameters(), o64.named_parameters()):
+            truth = q64.grad
+            tol = max(1e-4 * float(truth.abs().max()), 3 * float((q32.grad.double() - truth).abs().max()), 1e-8)
+            err = float((p.grad.cpu().double() - truth).abs().max())
+            assert err <= tol, (f"step {i} grad {n}", err, tol)
+    mine.load_state_dict(init)
+    opt = pcg.optim.Adam(mine.parameters(), lr=1e-3)
+    for i in range(2):
+        mine.dropout_masks = [torch.from_numpy(gold[f"mask{2 * i}"]).to(DEV), torch.from_numpy(gold[f"mask{2 * i + 1}"]).to(DEV)]
+        opt.zero_grad()
+        ce(mine(torch.from_numpy(gold[f"x{i}"]).to(DEV)), torch.from_numpy(gold[f"y{i}"]).to(DEV)).backward()
+        opt.step()
+    for k in ("fc.4.weight", "conv.0.weight"):
+        assert float(np.abs(mine.state_dict()[k].cpu().numpy() - gold[f"final.{k}.full"]).max()) <= 2.2 * 1e-3 * 2 + 1e-5, k
+    for k, v in mine.state_dict().items():
+        np.testing.assert_allclose(_digest(v)[3:], gold[f"final.{k}"][3:], rtol=0, atol=2.2 * 1e-3 * 2 + 1e-5, err_msg=k)
+    mine.dropout_masks = None
+    mine.eval()
+    with torch.no_grad():
+        acc = pcg.ops.cf_metrics(mine(torch.from_numpy(gold["x2"]).to(DEV)).contiguous(), torch.from_numpy(gold["y2"]).to(DEV),
+                                 other=torch.from_numpy(gold["y2"]).to(DEV))[0].item()
+    assert abs(acc - float(re.search(r"Val Acc: ([0-9.]+)", str(gold["log"])).group(1))) < 0.13   # 8 samples: at most one flips

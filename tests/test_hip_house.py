@@ -444,3 +444,84 @@ def test_eval_full_run_agrees_with_shipped_metrics(pcg, golden_dir):
     got = np.array([[r["class_flip"], r["prediction_gain"], r["avg_actionability"]] for r in res])
     assert np.abs(got - gold["shipped.metrics"]).max() < 0.01, got
     assert np.abs(got - gold["full.metrics"]).max() < 0.01, got
+
+
+# ---- classifier pre-training -------------------------------------------------------------------
+def test_classifier_pretraining_steps_match_reference(pcg, golden_dir):
+    """Three iterations of the reference's train_classifier (trainer.py:78-87: weighted CrossEntropyLoss, AdamW) with the
+    batches its shuffling loader produced and the Dropout draws it made.  First-layer units whose pre-activations keep one
+    sign over a batch have an exactly-zero bias gradient; any fp32 run holds noise there, Adam turns it into +-lr moves, and
+    the next batch amplifies them — so trajectories of different fp32 implementations separate by O(lr) per step.  Hence:
+    (a) per step, starting from the float64 oracle's current parameters, loss and every gradient against that oracle
+    (tolerance: 1e-4 of the tensor's scale or 3x the float32 oracle's own distance);  (b) the free-running 3-step result
+    against the reference's final state, every entry within the total possible Adam move."""
+    from test_oracle_golden import _house_clf_gold
+    H = pcg.house
+    gold, cw = _house_clf_gold(golden_dir)
+    init = {k[5:]: torch.from_numpy(v.copy()) for k, v in gold.items() if k.startswith("init.")}
+    X, y = torch.from_numpy(gold["X"]), torch.from_numpy(gold["y"])
+    o64, o32 = HR.NNClassifier(17, 4), HR.NNClassifier(17, 4)
+    o64.load_state_dict(init); o32.load_state_dict(init)
+    o64 = o64.double()
+    opt64 = torch.optim.AdamW(o64.parameters(), lr=1e-3, weight_decay=1e-4)
+    mine = H.NNClassifier(17, 4)
+    mine.load_state_dict(init)
+    mine = mine.to(DEV).train()
+    crit = H.WeightedCrossEntropyLoss(_dev(cw))
+    for i in range(int(gold["meta.steps"])):
+        r = torch.from_numpy(gold[f"step{i}.rows"])
+        masks = [torch.from_numpy(gold[f"step{i}.mask{j}"]) for j in range(3)]
+        sd = {k: v.float() if v.is_floating_point() else v.clone() for k, v in o64.state_dict().items()}
+        o32.load_state_dict(sd); mine.load_state_dict(sd)                       # teacher forcing: same starting point
+        o32.train(); o32.zero_grad()
+        l32 = F.cross_entropy(HR.classifier_forward_train(o32, X[r], masks), y[r], weight=cw)
+        l32.backward()
+        l64 = HR.classifier_train_step(o64, opt64, cw.double(), X[r].double(), y[r], masks)   # advances the teacher
+        mine.dropout_masks = [_dev(t) for t in masks]
+        mine.zero_grad()
+        lm = crit(mine(_dev(X[r])), _dev(y[r]))
+        lm.backward()
+        assert abs(lm.item() - l64) <= max(2e-5, 3 * abs(l32.item() - l64)), (i, lm.item(), l64)
+        for (n, p), (_, q32), (_, q64) in zip(mine.named_parameters(), o32.named_parameters(), o64.named_parameters()):
+            truth = q64.grad
+            tol = max(1e-4 * float(truth.abs().max()), 3 * float((q32.grad.double() - truth).abs().max()), 1e-8)
+            err = float((p.grad.cpu().double() - truth).abs().max())
+            assert err <= tol, (f"step {i} grad {n}", err, tol)
+    # (b) free run from the initial state
+    mine.load_state_dict(init)
+    for b_ in mine.modules():
+        if isinstance(b_, torch.nn.BatchNorm1d):
+            b_.num_batches_tracked.zero_()
+    opt = pcg.optim.AdamW(mine.parameters(), lr=1e-3, weight_decay=1e-4)
+    for i in range(int(gold["meta.steps"])):
+        r = torch.from_numpy(gold[f"step{i}.rows"])
+        mine.dropout_masks = [_dev(torch.from_numpy(gold[f"step{i}.mask{j}"])) for j in range(3)]
+        opt.zero_grad()
+        crit(mine(_dev(X[r])), _dev(y[r])).backward()
+        opt.step()
+    for k, v in mine.state_dict().items():
+        ref = gold[f"final.{k}"]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref)
+        elif "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-3, atol=2e-3, err_msg=k)
+        else:
+            assert float(np.abs(v.cpu().numpy() - ref).max()) <= 2.2 * 1e-3 * 3 + 1e-5, k
+
+
+def test_train_classifier_loop_learns(pcg):
+    """house.train_classifier (trainer.py:18-180 without plots) end to end on a separable synthetic problem, device-drawn
+    Dropout masks: validation accuracy well above chance, BatchNorm folded eval path consistent with training-mode weights."""
+    H = pcg.house
+    rs = np.random.RandomState(0)
+    y = rs.randint(0, 4, size=1200)
+    centers = rs.random_sample((4, 17))
+    X = np.clip(centers[y] + 0.05 * rs.standard_normal((1200, 17)), 0, 1)
+    cfg = dict(H.CONFIG, clf_epochs=6, batch_size=128, seed=1)
+    model = H.train_classifier(X[:1000], X[1000:], y[:1000], y[1000:], None, cfg, device=DEV, verbose=False)
+    assert model.history[-1][3] > 0.9, model.history
+    model.eval()
+    with torch.no_grad():
+        acc = pcg.ops.cf_metrics(model(_dev(torch.tensor(X[1000:], dtype=torch.float32))).contiguous(), _dev(torch.tensor(y[1000:])),
+                                 other=_dev(torch.tensor(y[1000:])))[0].item()
+    assert acc > 0.9
