@@ -328,6 +328,15 @@ int pcg_cross_entropy_weighted_fwd_bwd(const float* logits, const int64_t* targe
 int pcg_dropout_apply(const float* x, const float* mask, int64_t n, int32_t inner, int32_t C, float scale, float* y, pcg_stream_t stream);
 int pcg_rand_bernoulli(float* out, int64_t n, float keep_prob, uint64_t seed, uint64_t offset, pcg_stream_t stream);
 
+/* ---- input pipeline -------------------------------------------------------------------------
+ * transforms.Resize -> ToTensor -> Normalize (dconv_gan/mnist/mnist_dcgan.py:42-46) for a batch of 8-bit one-channel images:
+ * Pillow's separable fixed-point bilinear resize (bounds[2*i] = first source index, bounds[2*i+1] = taps, coefficients with 22
+ * fractional bits, ksize per output coordinate — built by the host as Pillow's precompute_coeffs does), rounding to uint8
+ * after each pass, then float32 v/255 and (t - mean)/std.  dst: [N][OH][OW] float32 (= [N,1,OH,OW]). */
+int pcg_resize8_normalize(const uint8_t* src, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, const int32_t* x_bounds,
+                          const int32_t* x_coeffs, int32_t x_ksize, const int32_t* y_bounds, const int32_t* y_coeffs, int32_t y_ksize,
+                          float mean, float stdv, float* dst, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "pcg_cross_entropy_weighted_fwd_bwd": (_i, [_vp, _vp, _vp, _i32, _i32, _f, _vp, _vp, _vp, _vp]),
     "pcg_dropout_apply": (_i, [_vp, _vp, _i64, _i32, _i32, _f, _vp, _vp]),
     "pcg_rand_bernoulli": (_i, [_vp, _i64, _f, _c.c_uint64, _c.c_uint64, _vp]),
+    "pcg_resize8_normalize": (_i, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp]),
     "pcg_cf_metrics": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pcg_gemm": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _vp]),
     "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -706,6 +706,25 @@ def make_classifier_pretrain(path_mnist, path_house):
         os.chdir(cwd)
 
 
+def make_mnist_resize(path, n=24):
+    """SURVEY.md section 8f item 4 — the DCGAN input transform (mnist_dcgan.py:42-46): transforms.Resize(64) on the PIL image
+    ([torchvision] F.resize of a PIL image = Image.resize(size, BILINEAR)), ToTensor ([torchvision] uint8 -> float32 .div(255)),
+    Normalize((0.5,), (0.5,)) (sub_(mean).div_(std)).  torchvision itself is absent here; Pillow — the library that does the
+    arithmetic — is present, and the two tensor steps are restated with the torch calls torchvision makes."""
+    from PIL import Image
+    rs = np.random.RandomState(12)
+    imgs = (rs.rand(n, 28, 28) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:28, 0:28]
+    for i in range(n // 2):                       # half of them digit-like: smooth blobs with saturated cores and black background
+        cy, cx, r = rs.uniform(8, 20), rs.uniform(8, 20), rs.uniform(3, 8)
+        imgs[i] = np.clip(320 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r)) - 30, 0, 255).astype(np.uint8)
+    resized = np.stack([np.asarray(Image.fromarray(im, mode="L").resize((64, 64), Image.BILINEAR)) for im in imgs])
+    t = torch.from_numpy(resized.copy()).to(torch.float32).div(255)
+    t = t.sub_(0.5).div_(0.5)
+    np.savez_compressed(path, images=imgs, resized_u8=resized, out=t.numpy().reshape(n, 1, 64, 64))
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.0f} KB")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
@@ -720,3 +739,4 @@ if __name__ == "__main__":
     make_house_eval(os.path.join(HERE, "house_eval.npz"))
     make_countergan_eval(os.path.join(HERE, "countergan_eval.npz"))
     make_classifier_pretrain(os.path.join(HERE, "classifier_pretrain_mnist.npz"), os.path.join(HERE, "classifier_pretrain_house.npz"))
+    make_mnist_resize(os.path.join(HERE, "mnist_resize.npz"))
