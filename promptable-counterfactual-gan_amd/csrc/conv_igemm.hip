@@ -90,12 +90,21 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split) {
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split, int tiles,
+                                                                   int slice_major) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+  // slice_major: 1-D grid, the output tiles of one K-slice are consecutive on ONE XCD, so the slice of dy / x they all read
+  // comes from HBM once and from that XCD's L2 afterwards (layers with few output tiles re-read their operands per tile)
+  uint32_t tile, split;
+  if (slice_major) {
+    const uint32_t l = xcd_remap(blockIdx.x, gridDim.x);
+    split = l / (uint32_t)tiles; tile = l - split * (uint32_t)tiles;
+  } else {
+    tile = xcd_remap(blockIdx.x, gridDim.x); split = blockIdx.y;
+  }
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
-  const int kt_begin = blockIdx.y * ktiles_per_split;
+  const int kt_begin = split * ktiles_per_split;
   int ktiles = ktiles_total - kt_begin;
   if (ktiles > ktiles_per_split) ktiles = ktiles_per_split;
 
@@ -108,7 +117,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, false, false>(ktiles, acc, smem);
-  float* slab = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
+  float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
     const int m = m_block + row;
     return m < p.M ? slab + (size_t)m * p.N + n_block : nullptr;
@@ -211,8 +220,9 @@ WgradPlan plan_wgrad(const pcg_conv_geom* g) {
   w.tiles = ceil_div(M, BM) * ceil_div(N, 128);
   const int64_t K = (int64_t)g->B * g->OH * g->OW;
   w.ktiles_total = (int)ceil_div64(K, IG_BK);
-  // aim for >= 2 blocks per CU (512 blocks) but keep >= 8 k-tiles (256 pixels) per slice
-  int splits = ceil_div(512, w.tiles);
+  // fill the 512 block slots (2 per CU) in ONE round — 515 blocks would run as 512 + a second round of 3 — but keep
+  // >= 8 k-tiles (256 pixels) per slice
+  int splits = w.tiles <= 512 ? 512 / w.tiles : 1;
   const int max_splits = w.ktiles_total / 8 > 0 ? w.ktiles_total / 8 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -406,21 +416,23 @@ extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const fl
   p.tilesN = ceil_div(p.N, 128);
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  static const int order_env = getenv("PCG_WGRAD_ORDER") ? atoi(getenv("PCG_WGRAD_ORDER")) : -1;   // A/B switch: 0 tile-major, 1 slice-major
+  const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
   if (wp.narrow) {
     using Cfg = TileCfg<64, 128, 1, 4>;
     constexpr size_t smem = smem_bytes<Cfg, false, false>();
     static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
     if (once != PCG_OK) return once;
-    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
-                       wp.ktiles_total, wp.ktiles_per_split);
+    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
+                       dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
     rc = launch_status("conv_wgrad_kernel<64x128>");
   } else {
     using Cfg = Cfg128x128;
     constexpr size_t smem = smem_bytes<Cfg, false, false>();
     static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
     if (once != PCG_OK) return once;
-    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, dim3((unsigned)wp.tiles, wp.splits), dim3(IG_THREADS), smem, s, p,
-                       wp.ktiles_total, wp.ktiles_per_split);
+    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
+                       dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
     rc = launch_status("conv_wgrad_kernel<128x128>");
   }
   if (rc != PCG_OK) return rc;
