@@ -337,6 +337,54 @@ int pcg_resize8_normalize(const uint8_t* src, int32_t N, int32_t IH, int32_t IW,
                           const int32_t* x_coeffs, int32_t x_ksize, const int32_t* y_bounds, const int32_t* y_coeffs, int32_t y_ksize,
                           float mean, float stdv, float* dst, pcg_stream_t stream);
 
+/* ---- fused tabular generator (house_sales_kc_usa/models/generator.py:38-92) -------------------------------------------------
+ * The whole ResidualGenerator forward (fc_in, 5 x [fc1, BatchNorm1d, FiLM, ReLU, fc2, BatchNorm1d, FiLM, residual add], the
+ * continuous head and the packed Gumbel-softmax heads) as 11 launches and its backward (down to the pre-activation gradients
+ * every Linear's weight gradient needs) as 11 launches: one thread per batch row, kernels cut at the BatchNorm statistics.
+ * Built for hidden width 32 and 5 blocks (the reference's configuration, config.py:15-17); all buffers are the caller's.
+ * Offsets are element offsets into ONE flat fp32 parameter buffer (and the gradient buffer of the same layout). */
+#define PCG_HOUSE_ROWS_PER_BLOCK 64
+typedef struct pcg_house_g_desc {
+  int32_t fc_in_w, fc_in_b;
+  int32_t fc1_w[5], fc1_b[5], bn1_g[5], bn1_b[5], fc2_w[5], fc2_b[5], bn2_g[5], bn2_b[5];
+  int32_t film_gamma_w[5], film_gamma_b[5], film_beta_w[5], film_beta_b[5];
+  int32_t cont_w, cont_b;
+  int32_t head_w[8], head_b[8], seg[9];      /* categorical heads and their packed column offsets (seg[nheads] = T) */
+  int32_t nheads, ncont, D, NC;              /* D = input_dim, NC = num_classes */
+  int32_t hidden, nblocks;                   /* must be 32 and 5 */
+} pcg_house_g_desc;
+
+typedef struct pcg_house_g_fwd_args {
+  const float* params;
+  const float *x, *onehot, *mask, *noise;    /* [B][D], [B][NC], [B][D], Gumbel noise [B][T] */
+  float* inp;                                /* out [B][D+NC+D]: (x, onehot, mask) — the cond operand of later weight gradients */
+  float *H, *Z1, *Z2;                        /* out [6][B][32], [5][B][32], [5][B][32]: block inputs and pre-BatchNorm activations */
+  float* P;                                  /* scratch [10][ceil(B/64)][2][32] partial statistics */
+  float* SM;                                 /* out [10][2][32] saved mean / invstd (layer order bn1_0, bn2_0, bn1_1, ...) */
+  float* running_mean[10]; float* running_var[10]; int64_t* num_batches_tracked[10];   /* nullable: BatchNorm buffers to update */
+  float *cont, *logits, *soft, *hard;        /* out [B][ncont], [B][T], [B][T], nullable [B][T] one-hot of the soft arg-max */
+  int32_t B;
+  float eps, momentum, tau, res_scale;
+} pcg_house_g_fwd_args;
+
+typedef struct pcg_house_g_bwd_args {
+  const float* params; float* grads;         /* BatchNorm gamma / beta gradients are written into `grads` (accumulate flag) */
+  const float *onehot, *mask;
+  const float *H, *Z1, *Z2, *SM, *soft;      /* from the forward */
+  const float *d_cont, *d_logits, *d_samples;/* nullable cotangents of the three outputs */
+  float *DH, *DZ1, *DZ2, *A1;                /* out [5][B][32] each: block-top gradients, pre-BN gradients (weight-gradient operands), ReLU outputs */
+  float* DN1;                                /* scratch [B][32] */
+  float *DG, *DB;                            /* out [5][B][32]: gradients at the FiLM gamma / beta Linear outputs */
+  float* DZIN;                               /* out [B][32]: gradient at fc_in's output */
+  float *DL, *DC;                            /* out [B][T], [B][ncont]: gradients at the head outputs */
+  float* Q;                                  /* scratch [10][ceil(B/64)][2][32] */
+  int32_t B, accumulate;
+  float tau, res_scale;
+} pcg_house_g_bwd_args;
+
+int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_fwd_args* args, pcg_stream_t stream);
+int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_bwd_args* args, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,33 @@ class ConvGeom(ctypes.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+_I, _P = ctypes.c_int32, ctypes.c_void_p
+
+
+class HouseGDesc(ctypes.Structure):
+    """pcg_house_g_desc (include/pcgan_hip.h)."""
+    _fields_ = ([("fc_in_w", _I), ("fc_in_b", _I)] +
+                [(n, _I * 5) for n in ("fc1_w", "fc1_b", "bn1_g", "bn1_b", "fc2_w", "fc2_b", "bn2_g", "bn2_b",
+                                       "film_gamma_w", "film_gamma_b", "film_beta_w", "film_beta_b")] +
+                [("cont_w", _I), ("cont_b", _I), ("head_w", _I * 8), ("head_b", _I * 8), ("seg", _I * 9)] +
+                [(n, _I) for n in ("nheads", "ncont", "D", "NC", "hidden", "nblocks")])
+
+
+class HouseGFwdArgs(ctypes.Structure):
+    """pcg_house_g_fwd_args."""
+    _fields_ = ([(n, _P) for n in ("params", "x", "onehot", "mask", "noise", "inp", "H", "Z1", "Z2", "P", "SM")] +
+                [("running_mean", _P * 10), ("running_var", _P * 10), ("num_batches_tracked", _P * 10)] +
+                [(n, _P) for n in ("cont", "logits", "soft", "hard")] + [("B", ctypes.c_int32)] +
+                [(n, ctypes.c_float) for n in ("eps", "momentum", "tau", "res_scale")])
+
+
+class HouseGBwdArgs(ctypes.Structure):
+    """pcg_house_g_bwd_args."""
+    _fields_ = ([(n, _P) for n in ("params", "grads", "onehot", "mask", "H", "Z1", "Z2", "SM", "soft", "d_cont", "d_logits", "d_samples",
+                                   "DH", "DZ1", "DZ2", "A1", "DN1", "DG", "DB", "DZIN", "DL", "DC", "Q")] +
+                [("B", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("tau", ctypes.c_float), ("res_scale", ctypes.c_float)])
+
+
 _c = ctypes
 _vp, _f, _i, _i64, _sz = _c.c_void_p, _c.c_float, _c.c_int, _c.c_int64, _c.c_size_t
 _d = _c.c_double
@@ -96,6 +123,8 @@ PROTOTYPES = {
     "pcg_dropout_apply": (_i, [_vp, _vp, _i64, _i32, _i32, _f, _vp, _vp]),
     "pcg_rand_bernoulli": (_i, [_vp, _i64, _f, _c.c_uint64, _c.c_uint64, _vp]),
     "pcg_resize8_normalize": (_i, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp]),
+    "pcg_house_g_fwd": (_i, [_c.POINTER(HouseGDesc), _c.POINTER(HouseGFwdArgs), _vp]),
+    "pcg_house_g_bwd": (_i, [_c.POINTER(HouseGDesc), _c.POINTER(HouseGBwdArgs), _vp]),
     "pcg_cf_metrics": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pcg_gemm": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _vp]),
     "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -1,0 +1,555 @@
+// house_fused.hip — the tabular ResidualGenerator (house_sales_kc_usa/models/generator.py:38-92) as a chain of "segment"
+// kernels.  Every tensor of this net is [B][32] and every weight matrix is at most 38 wide: one THREAD owns one batch row and
+// carries its whole hidden vector in registers; the weights of a segment sit in LDS and are read as broadcasts.  The only
+// cross-row dependencies are the ten BatchNorm1d batch statistics, so the net is cut there: a segment ends by writing its
+// pre-BatchNorm activations plus per-block column sums, and the next segment starts by turning those sums into mean / invstd
+// (fixed order, fp64) — the kernel boundary is the grid barrier.  Forward = 11 launches (op chain: ~95), backward = 11 launches
+// + the weight-gradient reductions (op chain: ~190).  Hidden width 32, 5 residual blocks (the reference's configuration)
+// are compile-time; other configurations use the op-chain path.
+#include <cstring>
+#include "pcg_common.h"
+
+namespace pcg {
+namespace {
+
+constexpr int HH = 32;            // hidden width
+constexpr int NBLK = 5;           // residual blocks
+constexpr int DIN = 17;           // input_dim   (config.py:14) — compile-time: every per-row loop unrolls into straight FMAs
+constexpr int NCLS = 4;           // num_classes (4 price quartiles)
+constexpr int MAXCOND = NCLS + DIN;          // cond = (one-hot target, mask)
+constexpr int MAXIN = DIN + MAXCOND;         // fc_in input = (x, cond)
+constexpr int MAXT = 96;          // packed categorical columns <= 96
+constexpr int MAXHEADS = 8;
+constexpr int FT = 64;            // threads per block = rows per block: one wave, so 4096 rows spread over 64 CUs
+
+struct GDesc {                    // element offsets into the flat parameter (and gradient) buffer + dimensions
+  int fc_in_w, fc_in_b;
+  int fc1_w[NBLK], fc1_b[NBLK], bn1_g[NBLK], bn1_b[NBLK], fc2_w[NBLK], fc2_b[NBLK], bn2_g[NBLK], bn2_b[NBLK];
+  int fg_w[NBLK], fg_b[NBLK], fb_w[NBLK], fb_b[NBLK];
+  int cont_w, cont_b;
+  int head_w[MAXHEADS], head_b[MAXHEADS], seg[MAXHEADS + 1];
+  int nheads, ncont, D, NC;     // D = input_dim, NC = num_classes; cond = NC + D, inp = D + cond
+  int hidden, nblocks;          // checked on the host (32, 5)
+};
+
+struct GBufs {
+  const float* x; const float* onehot; const float* mask; const float* noise;
+  float* inp;                     // [B][D + NC + D]   (x, onehot, mask): also the cond operand of the FiLM weight gradients
+  float* H;                       // [NBLK+1][B][HH]  block inputs h_0..h_5
+  float* Z1; float* Z2;           // [NBLK][B][HH]    pre-BatchNorm activations
+  float* P;                       // [2*NBLK][nblocks][2][HH]  partial column sums (sum, sum of squares) per BatchNorm
+  float* SM;                      // [2*NBLK][2][HH]  saved mean / invstd
+  float* running;                 // BatchNorm buffers are separate tensors: pointers per layer come in RS
+  float* cont; float* logits; float* soft; float* hard;   // outputs ([B][ncont], [B][T] x3; hard nullable)
+  int B, nblocks;
+  float eps, momentum, tau, res_scale;
+};
+
+struct BNState { float* running_mean[2 * NBLK]; float* running_var[2 * NBLK]; int64_t* nbt[2 * NBLK]; };
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------------
+// Weight matrices are NOT staged: every lane of a wave needs the same element at the same time, so they are read from
+// global memory at wave-uniform addresses — scalar loads into SGPRs that feed v_fma directly (no LDS traffic, no VGPRs).
+// Staging them in LDS and reading broadcasts was measured slower (60-86 us vs 34-64 us per segment at B = 4096).
+__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += FT) dst[i] = src[i];
+}
+
+// out[j] = b[j] + sum_i W[j][i] in[i], W row-major [HH][K] in LDS
+template <int K>
+__device__ __forceinline__ void lin_to32(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[K], float (&out)[HH]) {
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    float acc = b[j];
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc = fmaf(W[j * K + i], in[i], acc);
+    out[j] = acc;
+  }
+}
+template <int KMAX>
+__device__ __forceinline__ void lin_to32_rt(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[KMAX], int, float (&out)[HH]) {
+  lin_to32<KMAX>(W, b, in, out);
+}
+// out[i] = sum_j W[j][i] v[j]   (transposed: gradient with respect to the input of a 32 -> 32 Linear)
+__device__ __forceinline__ void lin_t32(const float* __restrict__ W, const float (&v)[HH], float (&out)[HH]) {
+#pragma unroll
+  for (int i = 0; i < HH; ++i) out[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < HH; ++j)
+#pragma unroll
+    for (int i = 0; i < HH; ++i) out[i] = fmaf(W[j * HH + i], v[j], out[i]);
+}
+
+// per-block column sums of v[0..31] and w[0..31] over the block's rows -> part[2][HH] of this block (fixed order)
+__device__ __forceinline__ void block_colsums(const float (&v)[HH], const float (&w)[HH], float* red /* [FT][HH+1] */,
+                                              float* red2 /* [8][HH] */, float* part) {
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < HH; ++j) red[threadIdx.x * (HH + 1) + j] = pass == 0 ? v[j] : w[j];
+    __syncthreads();
+    float s = 0.f;
+    for (int r = 0; r < 32; ++r) s += red[(g * 32 + r) * (HH + 1) + c];     // FT / 32 row groups
+    red2[g * HH + c] = s;
+    __syncthreads();
+    if (threadIdx.x < HH) {
+      float t = 0.f;
+      for (int q = 0; q < FT / 32; ++q) t += red2[q * HH + threadIdx.x];
+      part[pass * HH + threadIdx.x] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// mean / invstd of a BatchNorm from the per-block partials (fp64, block order); block 0 also maintains the module's buffers
+__device__ __forceinline__ void bn_finalize(const float* P, int nblocks, int B, float eps, float momentum, float* s_mean, float* s_inv,
+                                            float* save, float* rmean, float* rvar, int64_t* nbt) {
+  // all 64 lanes: lane (c, half) adds the partials of blocks half, half+2, ... of column c (8 loads in flight), then the two
+  // halves are combined in a fixed order
+  __shared__ double fin[2][2][HH];
+  {
+    const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
+    double s0 = 0.0, q0 = 0.0;
+#pragma unroll 8
+    for (int b = half; b < nblocks; b += 2) { s0 += (double)P[(size_t)b * 2 * HH + c]; q0 += (double)P[(size_t)b * 2 * HH + HH + c]; }
+    fin[half][0][c] = s0; fin[half][1][c] = q0;
+  }
+  __syncthreads();
+  if (threadIdx.x < HH) {
+    const double s = fin[0][0][threadIdx.x] + fin[1][0][threadIdx.x], q = fin[0][1][threadIdx.x] + fin[1][1][threadIdx.x];
+    const double mean = s / B;
+    double var = q / B - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    s_mean[threadIdx.x] = (float)mean; s_inv[threadIdx.x] = inv;
+    if (blockIdx.x == 0) {
+      save[threadIdx.x] = (float)mean; save[HH + threadIdx.x] = inv;
+      if (rmean) {
+        const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
+        rmean[threadIdx.x] = (float)((1.0 - momentum) * rmean[threadIdx.x] + momentum * mean);
+        rvar[threadIdx.x] = (float)((1.0 - momentum) * rvar[threadIdx.x] + momentum * unb);
+        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void load_cond(const GBufs& a, const GDesc& d, int row, bool on, float (&cond)[MAXCOND]) {
+#pragma unroll
+  for (int i = 0; i < NCLS; ++i) cond[i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) cond[NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
+}
+
+__device__ __forceinline__ void load32(const float* p, size_t row, bool on, float (&v)[HH]) {
+#pragma unroll
+  for (int j = 0; j < HH; j += 4) {
+    float4 q = on ? *reinterpret_cast<const float4*>(p + row * HH + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+  }
+}
+__device__ __forceinline__ void store32(float* p, size_t row, bool on, const float (&v)[HH]) {
+  if (!on) return;
+#pragma unroll
+  for (int j = 0; j < HH; j += 4) *reinterpret_cast<float4*>(p + row * HH + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+}
+
+// LDS layout shared by the kernels (floats)
+struct Smem {
+  float red[FT * (HH + 1)];
+  float red2[(FT / 32) * HH];
+  float gamma[HH], beta[HH], mean[HH], inv[HH];
+  float sums[2 * HH];
+};
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+// kind 0: fc_in + ReLU -> h0; z1_0 = fc1_0(h0), partial statistics
+__global__ void __launch_bounds__(FT) g_fwd_first_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
+  __shared__ Smem s;
+  constexpr int K = MAXIN;
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float inp[MAXIN];
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) inp[i] = on ? a.x[(size_t)row * DIN + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NCLS; ++i) inp[DIN + i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) inp[DIN + NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) a.inp[(size_t)row * K + i] = inp[i];
+  }
+  float h[HH], z[HH], zz[HH];
+  lin_to32_rt<MAXIN>(PRM + d.fc_in_w, PRM + d.fc_in_b, inp, K, h);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
+  store32(a.H, row, on, h);
+  lin_to32<HH>(PRM + d.fc1_w[0], PRM + d.fc1_b[0], h, z);
+  store32(a.Z1, row, on, z);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) { z[j] = on ? z[j] : 0.f; zz[j] = z[j] * z[j]; }
+  block_colsums(z, zz, s.red, s.red2, a.P + (size_t)blockIdx.x * 2 * HH);
+}
+
+// FiLM parameters of block k from cond
+__device__ __forceinline__ void film_params(const float* __restrict__ PRM, const GDesc& d, int k, const float (&cond)[MAXCOND],
+                                            float (&gam)[HH], float (&bet)[HH]) {
+  constexpr int C = MAXCOND;
+  lin_to32_rt<MAXCOND>(PRM + d.fg_w[k], PRM + d.fg_b[k], cond, C, gam);
+  lin_to32_rt<MAXCOND>(PRM + d.fb_w[k], PRM + d.fb_b[k], cond, C, bet);
+}
+
+// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
+__global__ void __launch_bounds__(FT) g_fwd_a_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+  __shared__ Smem s;
+  const int li = 2 * k;
+  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
+              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
+  stage(s.gamma, PRM + d.bn1_g[k], HH); stage(s.beta, PRM + d.bn1_b[k], HH);
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float cond[MAXCOND], gam[HH], bet[HH], z[HH], a1[HH], z2[HH], zz[HH];
+  load_cond(a, d, row, on, cond);
+  __syncthreads();                                // publishes gamma / beta
+  film_params(PRM, d, k, cond, gam, bet);
+  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    const float n = fmaf((z[j] - s.mean[j]) * s.inv[j], s.gamma[j], s.beta[j]);
+    const float f = fmaf(gam[j], n, bet[j]);
+    a1[j] = f > 0.f ? f : 0.f;
+  }
+  lin_to32<HH>(PRM + d.fc2_w[k], PRM + d.fc2_b[k], a1, z2);
+  store32(a.Z2 + (size_t)k * a.B * HH, row, on, z2);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) { z2[j] = on ? z2[j] : 0.f; zz[j] = z2[j] * z2[j]; }
+  block_colsums(z2, zz, s.red, s.red2, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// kind B (block k): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); then z1_{k+1} = fc1_{k+1}(h), or the output heads after the last block
+__global__ void __launch_bounds__(FT) g_fwd_b_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+  __shared__ Smem s;
+  const int li = 2 * k + 1;
+  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
+              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
+  stage(s.gamma, PRM + d.bn2_g[k], HH); stage(s.beta, PRM + d.bn2_b[k], HH);
+  const bool last = k == NBLK - 1;
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float cond[MAXCOND], gam[HH], bet[HH], z[HH], h[HH];
+  load_cond(a, d, row, on, cond);
+  __syncthreads();
+  film_params(PRM, d, k, cond, gam, bet);
+  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
+  load32(a.H + (size_t)k * a.B * HH, row, on, h);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    const float n = fmaf((z[j] - s.mean[j]) * s.inv[j], s.gamma[j], s.beta[j]);
+    h[j] += fmaf(gam[j], n, bet[j]);
+  }
+  store32(a.H + (size_t)(k + 1) * a.B * HH, row, on, h);
+  if (!last) {
+    float z1[HH], zz[HH];
+    lin_to32<HH>(PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1], h, z1);
+    store32(a.Z1 + (size_t)(k + 1) * a.B * HH, row, on, z1);
+#pragma unroll
+    for (int j = 0; j < HH; ++j) { z1[j] = on ? z1[j] : 0.f; zz[j] = z1[j] * z1[j]; }
+    block_colsums(z1, zz, s.red, s.red2, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+    return;
+  }
+  // ---- heads: continuous residual (scaled) and the packed categorical logits + Gumbel-softmax samples
+  const int T = d.seg[d.nheads];
+  if (!on) return;
+  for (int c = 0; c < d.ncont; ++c) {
+    float acc = PRM[d.cont_b + c];
+#pragma unroll
+    for (int i = 0; i < HH; ++i) acc = fmaf(PRM[d.cont_w + c * HH + i], h[i], acc);
+    a.cont[(size_t)row * d.ncont + c] = acc * a.res_scale;
+  }
+  const float inv_tau = 1.f / a.tau;
+  for (int hd = 0; hd < d.nheads; ++hd) {
+    const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
+    const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
+    const float* __restrict__ bh = PRM + d.head_b[hd] - c0;
+    float mx = -INFINITY;
+    for (int c = c0; c < c1; ++c) {
+      float acc = bh[c];
+#pragma unroll
+      for (int i = 0; i < HH; ++i) acc = fmaf(Wh[c * HH + i], h[i], acc);
+      a.logits[(size_t)row * T + c] = acc;
+      mx = fmaxf(mx, (acc + a.noise[(size_t)row * T + c]) * inv_tau);
+    }
+    float se = 0.f;
+    for (int c = c0; c < c1; ++c) se += expf((a.logits[(size_t)row * T + c] + a.noise[(size_t)row * T + c]) * inv_tau - mx);
+    const float inv = 1.f / se;
+    float best = -1.f; int arg = c0;
+    for (int c = c0; c < c1; ++c) {
+      const float p = expf((a.logits[(size_t)row * T + c] + a.noise[(size_t)row * T + c]) * inv_tau - mx) * inv;
+      a.soft[(size_t)row * T + c] = p;
+      if (p > best) { best = p; arg = c; }
+    }
+    if (a.hard) for (int c = c0; c < c1; ++c) a.hard[(size_t)row * T + c] = c == arg ? 1.f : 0.f;
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------------
+struct GBwd {
+  float* grads;                           // flat gradient buffer (BatchNorm gamma/beta gradients are written here)
+  const float* onehot; const float* mask;
+  const float* H; const float* Z1; const float* Z2; const float* SM; const float* soft;
+  const float* d_cont; const float* d_logits; const float* d_samples;   // nullable
+  float* DH;                              // [NBLK][B][HH]  gradient entering block k from above (k = NBLK-1 .. 0)
+  float* DZ1; float* DZ2; float* A1;      // [NBLK][B][HH]
+  float* DN1;                             // [B][HH] scratch: gradient at bn1's output of the block in flight
+  float* DG; float* DB;                   // [NBLK][B][HH]  FiLM gamma / beta output gradients
+  float* DZIN;                            // [B][HH]
+  float* DL; float* DC;                   // [B][T], [B][ncont]
+  float* Q;                               // [2*NBLK][nblocks][2][HH] partial sums of the BatchNorm backward
+  int B, nblocks, accumulate;
+  float tau, res_scale;
+};
+
+// recompute gam/bet of block k and x-hat / bn output of a saved pre-activation
+__device__ __forceinline__ void bn_apply32(const float (&z)[HH], const float* mean, const float* inv, const float* g, const float* b,
+                                           float (&xh)[HH], float (&n)[HH]) {
+#pragma unroll
+  for (int j = 0; j < HH; ++j) { xh[j] = (z[j] - mean[j]) * inv[j]; n[j] = fmaf(xh[j], g[j], b[j]); }
+}
+
+__device__ __forceinline__ void film_params_b(const float* __restrict__ PRM, const GBwd& a, const GDesc& d, int k, int row, bool on,
+                                              float (&gam)[HH], float (&bet)[HH]) {
+  constexpr int C = MAXCOND;
+  float cond[MAXCOND];
+#pragma unroll
+  for (int i = 0; i < NCLS; ++i) cond[i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) cond[NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
+  lin_to32_rt<MAXCOND>(PRM + d.fg_w[k], PRM + d.fg_b[k], cond, C, gam);
+  lin_to32_rt<MAXCOND>(PRM + d.fb_w[k], PRM + d.fb_b[k], cond, C, bet);
+}
+
+// part "a" of block k, shared by the first backward kernel and kind C: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2)
+__device__ __forceinline__ void bwd_part_a(const float* __restrict__ PRM, Smem& s, const GBwd& a, const GDesc& d, int k, int row, bool on,
+                                           const float (&dh)[HH]) {
+  float gam[HH], bet[HH], z[HH], xh[HH], v[HH], w[HH];
+  film_params_b(PRM, a, d, k, row, on, gam, bet);
+  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
+  const float* sm = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    xh[j] = (z[j] - sm[j]) * sm[HH + j];
+    v[j] = on ? dh[j] * gam[j] : 0.f;
+    w[j] = v[j] * xh[j];
+  }
+  block_colsums(v, w, s.red, s.red2, a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// first backward kernel: gradients of the heads -> dh entering the last block; then part a of that block
+__global__ void __launch_bounds__(FT) g_bwd_first_kernel(const float* __restrict__ PRM, GBwd a, GDesc d) {
+  __shared__ Smem s;
+  const int T = d.seg[d.nheads];
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float dh[HH];
+#pragma unroll
+  for (int i = 0; i < HH; ++i) dh[i] = 0.f;
+  if (on) {
+    for (int c = 0; c < d.ncont; ++c) {
+      const float dc = a.d_cont ? a.d_cont[(size_t)row * d.ncont + c] * a.res_scale : 0.f;
+      a.DC[(size_t)row * d.ncont + c] = dc;
+#pragma unroll
+      for (int i = 0; i < HH; ++i) dh[i] = fmaf(PRM[d.cont_w + c * HH + i], dc, dh[i]);
+    }
+    const float inv_tau = 1.f / a.tau;
+    for (int hd = 0; hd < d.nheads; ++hd) {
+      const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
+      const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
+      float dot = 0.f;
+      if (a.d_samples)
+        for (int c = c0; c < c1; ++c) dot = fmaf(a.d_samples[(size_t)row * T + c], a.soft[(size_t)row * T + c], dot);
+      for (int c = c0; c < c1; ++c) {
+        float dl = a.d_logits ? a.d_logits[(size_t)row * T + c] : 0.f;
+        if (a.d_samples) { const float y = a.soft[(size_t)row * T + c]; dl += y * (a.d_samples[(size_t)row * T + c] - dot) * inv_tau; }
+        a.DL[(size_t)row * T + c] = dl;
+#pragma unroll
+        for (int i = 0; i < HH; ++i) dh[i] = fmaf(Wh[c * HH + i], dl, dh[i]);
+      }
+    }
+  }
+  store32(a.DH + (size_t)(NBLK - 1) * a.B * HH, row, on, dh);
+  bwd_part_a(PRM, s, a, d, NBLK - 1, row, on, dh);
+}
+
+// sums of one BatchNorm backward from the partials; block 0 writes dgamma / dbeta
+__device__ __forceinline__ void bnb_finalize(Smem& s, const GBwd& a, int li, int g_off, int b_off) {
+  __shared__ double fin[2][2][HH];
+  {
+    const float* Q = a.Q + (size_t)li * a.nblocks * 2 * HH;
+    const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll 8
+    for (int b = half; b < a.nblocks; b += 2) { t1 += (double)Q[(size_t)b * 2 * HH + c]; t2 += (double)Q[(size_t)b * 2 * HH + HH + c]; }
+    fin[half][0][c] = t1; fin[half][1][c] = t2;
+  }
+  __syncthreads();
+  if (threadIdx.x < HH) {
+    const double s1 = fin[0][0][threadIdx.x] + fin[1][0][threadIdx.x], s2 = fin[0][1][threadIdx.x] + fin[1][1][threadIdx.x];
+    s.sums[threadIdx.x] = (float)(s1 / a.B); s.sums[HH + threadIdx.x] = (float)(s2 / a.B);
+    if (blockIdx.x == 0) {
+      float* gg = a.grads + g_off + threadIdx.x; float* gb = a.grads + b_off + threadIdx.x;
+      *gg = a.accumulate ? *gg + (float)s2 : (float)s2;
+      *gb = a.accumulate ? *gb + (float)s1 : (float)s1;
+    }
+  }
+  __syncthreads();
+}
+
+// kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
+__global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_b_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+  __shared__ Smem s;
+  bnb_finalize(s, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
+  stage(s.gamma, PRM + d.bn2_g[k], HH);
+  stage(s.mean, PRM + d.bn1_g[k], HH); stage(s.inv, PRM + d.bn1_b[k], HH);     // bn1's gamma / beta (names reused)
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float gam[HH], bet[HH], z[HH], dh[HH], dz2[HH], da1[HH];
+  __syncthreads();
+  film_params_b(PRM, a, d, k, row, on, gam, bet);
+  load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
+  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
+  const float* sm2 = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+  float dgam[HH];
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    const float xh = (z[j] - sm2[j]) * sm2[HH + j];
+    const float n2 = fmaf(xh, s.gamma[j], PRM[d.bn2_b[k] + j]);
+    const float dn2 = dh[j] * gam[j];
+    dz2[j] = s.gamma[j] * sm2[HH + j] * (dn2 - s.sums[j] - xh * s.sums[HH + j]);
+    dgam[j] = dh[j] * n2;
+  }
+  store32(a.DZ2 + (size_t)k * a.B * HH, row, on, dz2);
+  lin_t32(PRM + d.fc2_w[k], dz2, da1);
+  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
+  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+  float a1[HH], v[HH], w[HH], dbet[HH];
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    const float xh = (z[j] - sm1[j]) * sm1[HH + j];
+    const float n1 = fmaf(xh, s.mean[j], s.inv[j]);
+    const float f = fmaf(gam[j], n1, bet[j]);
+    a1[j] = f > 0.f ? f : 0.f;
+    const float df1 = f > 0.f ? da1[j] : 0.f;
+    dgam[j] = fmaf(df1, n1, dgam[j]);
+    dbet[j] = dh[j] + df1;
+    v[j] = on ? df1 * gam[j] : 0.f;          // dn1
+    w[j] = v[j] * xh;
+  }
+  store32(a.A1 + (size_t)k * a.B * HH, row, on, a1);
+  store32(a.DG + (size_t)k * a.B * HH, row, on, dgam);
+  store32(a.DB + (size_t)k * a.B * HH, row, on, dbet);
+  store32(a.DN1, row, on, v);
+  block_colsums(v, w, s.red, s.red2, a.Q + ((size_t)(2 * k) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
+__global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_c_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+  __shared__ Smem s;
+  bnb_finalize(s, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
+  stage(s.gamma, PRM + d.bn1_g[k], HH);
+  __syncthreads();
+  const int row = blockIdx.x * FT + threadIdx.x;
+  const bool on = row < a.B;
+  float z[HH], dn1[HH], dz1[HH], dh[HH], t[HH];
+  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
+  load32(a.DN1, row, on, dn1);
+  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+#pragma unroll
+  for (int j = 0; j < HH; ++j) {
+    const float xh = (z[j] - sm1[j]) * sm1[HH + j];
+    dz1[j] = s.gamma[j] * sm1[HH + j] * (dn1[j] - s.sums[j] - xh * s.sums[HH + j]);
+  }
+  store32(a.DZ1 + (size_t)k * a.B * HH, row, on, dz1);
+  lin_t32(PRM + d.fc1_w[k], dz1, t);
+  load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) dh[j] += t[j];
+  if (k > 0) {
+    store32(a.DH + (size_t)(k - 1) * a.B * HH, row, on, dh);
+    bwd_part_a(PRM, s, a, d, k - 1, row, on, dh);
+    return;
+  }
+  float h0[HH];
+  load32(a.H, row, on, h0);
+#pragma unroll
+  for (int j = 0; j < HH; ++j) dh[j] = h0[j] > 0.f ? dh[j] : 0.f;
+  store32(a.DZIN, row, on, dh);
+}
+
+}  // namespace
+}  // namespace pcg
+
+using namespace pcg;
+
+// C-side mirrors of the argument blocks (plain arrays of offsets / pointers: see include/pcgan_hip.h)
+extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_fwd_args* args, pcg_stream_t stream) {
+  PCG_REQUIRE(desc && args, "pcg_house_g_fwd: null argument block");
+  static_assert(sizeof(pcg_house_g_desc) == sizeof(GDesc), "descriptor layouts differ");
+  GDesc d;
+  std::memcpy(&d, desc, sizeof(d));
+  PCG_REQUIRE(desc->hidden == 32 && desc->nblocks == 5, "pcg_house_g_fwd: built for hidden width 32 and 5 residual blocks");
+  PCG_REQUIRE(d.D == DIN && d.NC == NCLS && d.nheads >= 0 && d.nheads <= MAXHEADS && d.ncont >= 0 &&
+                  d.ncont <= HH && d.seg[d.nheads] <= MAXT,
+              "pcg_house_g_fwd: built for input_dim 17, 4 classes, <= 8 heads / 96 packed categories");
+  PCG_REQUIRE(args->B > 0 && args->params && args->x && args->onehot && args->mask && args->noise && args->inp && args->H && args->Z1 &&
+                  args->Z2 && args->P && args->SM && args->cont && args->logits && args->soft,
+              "pcg_house_g_fwd: null buffer");
+  GBufs a{};
+  a.x = args->x; a.onehot = args->onehot; a.mask = args->mask; a.noise = args->noise; a.inp = args->inp;
+  a.H = args->H; a.Z1 = args->Z1; a.Z2 = args->Z2; a.P = args->P; a.SM = args->SM; a.cont = args->cont; a.logits = args->logits;
+  a.soft = args->soft; a.hard = args->hard; a.B = args->B; a.nblocks = (args->B + FT - 1) / FT; a.eps = args->eps;
+  a.momentum = args->momentum; a.tau = args->tau; a.res_scale = args->res_scale;
+  BNState bs{};
+  for (int i = 0; i < 2 * NBLK; ++i) { bs.running_mean[i] = args->running_mean[i]; bs.running_var[i] = args->running_var[i]; bs.nbt[i] = args->num_batches_tracked[i]; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(a.nblocks), block(FT);
+  hipLaunchKernelGGL(g_fwd_first_kernel, grid, block, 0, s, args->params, a, d);
+  if (int e = launch_status("g_fwd_first_kernel")) return e;
+  for (int k = 0; k < NBLK; ++k) {
+    hipLaunchKernelGGL(g_fwd_a_kernel, grid, block, 0, s, args->params, a, d, bs, k);
+    if (int e = launch_status("g_fwd_a_kernel")) return e;
+    hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);
+    if (int e = launch_status("g_fwd_b_kernel")) return e;
+  }
+  return PCG_OK;
+}
+
+extern "C" int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_bwd_args* args, pcg_stream_t stream) {
+  PCG_REQUIRE(desc && args, "pcg_house_g_bwd: null argument block");
+  GDesc d;
+  std::memcpy(&d, desc, sizeof(d));
+  PCG_REQUIRE(desc->hidden == 32 && desc->nblocks == 5 && d.D == DIN && d.NC == NCLS, "pcg_house_g_bwd: built for hidden width 32, 5 residual blocks, input_dim 17, 4 classes");
+  PCG_REQUIRE(args->B > 0 && args->params && args->grads && args->onehot && args->mask && args->H && args->Z1 && args->Z2 && args->SM &&
+                  args->soft && args->DH && args->DZ1 && args->DZ2 && args->A1 && args->DN1 && args->DG && args->DB && args->DZIN &&
+                  args->DL && args->DC && args->Q,
+              "pcg_house_g_bwd: null buffer");
+  GBwd a{};
+  a.grads = args->grads; a.onehot = args->onehot; a.mask = args->mask; a.H = args->H; a.Z1 = args->Z1; a.Z2 = args->Z2;
+  a.SM = args->SM; a.soft = args->soft; a.d_cont = args->d_cont; a.d_logits = args->d_logits; a.d_samples = args->d_samples; a.DH = args->DH;
+  a.DZ1 = args->DZ1; a.DZ2 = args->DZ2; a.A1 = args->A1; a.DN1 = args->DN1; a.DG = args->DG; a.DB = args->DB; a.DZIN = args->DZIN;
+  a.DL = args->DL; a.DC = args->DC; a.Q = args->Q; a.B = args->B; a.nblocks = (args->B + FT - 1) / FT; a.accumulate = args->accumulate;
+  a.tau = args->tau; a.res_scale = args->res_scale;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(a.nblocks), block(FT);
+  hipLaunchKernelGGL(g_bwd_first_kernel, grid, block, 0, s, args->params, a, d);
+  if (int e = launch_status("g_bwd_first_kernel")) return e;
+  for (int k = NBLK - 1; k >= 0; --k) {
+    hipLaunchKernelGGL(g_bwd_b_kernel, grid, block, 0, s, args->params, a, d, k);
+    if (int e = launch_status("g_bwd_b_kernel")) return e;
+    hipLaunchKernelGGL(g_bwd_c_kernel, grid, block, 0, s, args->params, a, d, k);
+    if (int e = launch_status("g_bwd_c_kernel")) return e;
+  }
+  return PCG_OK;
+}

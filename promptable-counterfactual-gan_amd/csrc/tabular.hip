@@ -137,20 +137,25 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int z = 0; z < S; ++z) {          // slab order is the summation order; the 16 loads of one slab are independent
-      const float* src = partial + (size_t)z * O * NP;
-      float v[4][4];
+    for (int z0 = 0; z0 < S; z0 += 4) {     // slab order is the summation order; the loads of four slabs are in flight together
+      float v[4][4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int zz = 0; zz < 4; ++zz) {
+        const float* src = partial + (size_t)(z0 + zz) * O * NP;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-          v[i][j] = (m < O && n < NP) ? src[(size_t)m * NP + n] : 0.f;
-        }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            v[zz][i][j] = (z0 + zz < S && m < O && n < NP) ? src[(size_t)m * NP + n] : 0.f;
+          }
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += v[i][j];
+      for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += v[zz][i][j];
     }
   }
 #pragma unroll

@@ -107,6 +107,110 @@ class ResidualGenerator(FlatModule):
         self.total_cat = int(self.seg[-1])
         self.rng = None
         self._idx_dev = None
+        self.use_fused = True        # fused segment kernels (csrc/house_fused.hip) when the configuration allows it
+        self._fdesc = None
+
+    # -- fused path -------------------------------------------------------------------------------------------------------------
+    def _fused_ok(self):
+        bn = self.blocks[0].bn1 if len(self.blocks) else None
+        return (self.use_fused and self.hidden_dim == 32 and len(self.blocks) == 5 and self.training and bn is not None
+                and self.input_dim == 17 and self.num_classes == 4 and self.total_cat <= 96 and len(self.cat_idx) <= 8
+                and len(self.continuous_idx) <= 32 and all(b_.bn1.momentum == bn.momentum and b_.bn2.eps == bn.eps for b_ in self.blocks))
+
+    def _fused_desc(self):
+        """Element offsets of every parameter in the flat buffer (rebuilt when the module is re-flattened)."""
+        from ._lib import HouseGDesc
+        key = self._flat.data_ptr()
+        if self._fdesc is not None and self._fdesc[0] == key:
+            return self._fdesc[1]
+        off = {id(p): o for p, o, _ in self._seg}
+        d = HouseGDesc()
+        d.fc_in_w, d.fc_in_b = off[id(self.fc_in.weight)], off[id(self.fc_in.bias)]
+        for k, blk in enumerate(self.blocks):
+            d.fc1_w[k], d.fc1_b[k] = off[id(blk.fc1.weight)], off[id(blk.fc1.bias)]
+            d.bn1_g[k], d.bn1_b[k] = off[id(blk.bn1.weight)], off[id(blk.bn1.bias)]
+            d.fc2_w[k], d.fc2_b[k] = off[id(blk.fc2.weight)], off[id(blk.fc2.bias)]
+            d.bn2_g[k], d.bn2_b[k] = off[id(blk.bn2.weight)], off[id(blk.bn2.bias)]
+            d.film_gamma_w[k], d.film_gamma_b[k] = off[id(blk.film.gamma.weight)], off[id(blk.film.gamma.bias)]
+            d.film_beta_w[k], d.film_beta_b[k] = off[id(blk.film.beta.weight)], off[id(blk.film.beta.bias)]
+        d.cont_w, d.cont_b = off[id(self.fc_cont.weight)], off[id(self.fc_cont.bias)]
+        for s_, f in enumerate(self.cat_idx):
+            head = self.fc_cat_logits[str(f)]
+            d.head_w[s_], d.head_b[s_] = off[id(head.weight)], off[id(head.bias)]
+        for s_, v in enumerate(self.seg):
+            d.seg[s_] = v
+        d.nheads, d.ncont, d.D, d.NC = len(self.cat_idx), len(self.continuous_idx), self.input_dim, self.num_classes
+        d.hidden, d.nblocks = self.hidden_dim, len(self.blocks)
+        self._fdesc = (key, d)
+        return d
+
+    def _fused_forward(self, x, target_onehot, mask, noise, tau, hard):
+        import ctypes
+        from ._lib import HouseGFwdArgs, load
+        dev = x.device
+        B, T, nc = x.shape[0], self.total_cat, len(self.continuous_idx)
+        x, target_onehot, mask, noise = x.contiguous(), target_onehot.contiguous(), mask.contiguous(), noise.contiguous()
+        nb = (B + 63) // 64          # PCG_HOUSE_ROWS_PER_BLOCK: one 64-row wave per block
+        f32 = dict(dtype=torch.float32, device=dev)
+        K = 2 * self.input_dim + self.num_classes
+        buf = {"inp": torch.empty((B, K), **f32), "H": torch.empty((6, B, 32), **f32), "Z1": torch.empty((5, B, 32), **f32),
+               "Z2": torch.empty((5, B, 32), **f32), "P": torch.empty((10, nb, 2, 32), **f32), "SM": torch.empty((10, 2, 32), **f32),
+               "cont": torch.empty((B, nc), **f32), "logits": torch.empty((B, T), **f32), "soft": torch.empty((B, T), **f32),
+               "hard": torch.empty((B, T), **f32) if hard else None}
+        a = HouseGFwdArgs()
+        a.params = self._flat.data_ptr()
+        a.x, a.onehot, a.mask, a.noise = x.data_ptr(), target_onehot.data_ptr(), mask.data_ptr(), noise.data_ptr()
+        for n in ("inp", "H", "Z1", "Z2", "P", "SM", "cont", "logits", "soft"):
+            setattr(a, n, buf[n].data_ptr())
+        a.hard = buf["hard"].data_ptr() if hard else None
+        for k, blk in enumerate(self.blocks):
+            for j, bn in ((2 * k, blk.bn1), (2 * k + 1, blk.bn2)):
+                a.running_mean[j], a.running_var[j] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                a.num_batches_tracked[j] = bn.num_batches_tracked.data_ptr()
+        bn0 = self.blocks[0].bn1
+        a.B, a.eps, a.momentum, a.tau, a.res_scale = B, bn0.eps, bn0.momentum, tau, self.residual_scaling
+        ops.check(load().pcg_house_g_fwd(ctypes.byref(self._fused_desc()), ctypes.byref(a), ops._stream()), "pcg_house_g_fwd")
+        saved = ("fused", buf, target_onehot, mask, tau, nb)
+        return buf["cont"], buf["logits"], (buf["hard"] if hard else buf["soft"]), saved
+
+    def _fused_backward(self, saved, d_cont, d_logits, d_samples):
+        import ctypes
+        from ._lib import HouseGBwdArgs, load
+        _, buf, onehot, mask, tau, nb = saved
+        B, T, nc = onehot.shape[0], self.total_cat, len(self.continuous_idx)
+        f32 = dict(dtype=torch.float32, device=onehot.device)
+        g = {n: torch.empty((5, B, 32), **f32) for n in ("DH", "DZ1", "DZ2", "A1", "DG", "DB")}
+        g.update({"DN1": torch.empty((B, 32), **f32), "DZIN": torch.empty((B, 32), **f32), "DL": torch.empty((B, T), **f32),
+                  "DC": torch.empty((B, nc), **f32), "Q": torch.empty((10, nb, 2, 32), **f32)})
+        # BatchNorm gamma / beta gradients are written by the kernels; all of them share the accumulate state of the net
+        _, acc = self._grad_view(self.blocks[0].bn1.weight)
+        for blk in self.blocks:
+            for p_ in (blk.bn1.weight, blk.bn1.bias, blk.bn2.weight, blk.bn2.bias):
+                self._grad_view(p_)
+        a = HouseGBwdArgs()
+        a.params, a.grads = self._flat.data_ptr(), self._gflat.data_ptr()
+        a.onehot, a.mask = onehot.data_ptr(), mask.data_ptr()
+        for n in ("H", "Z1", "Z2", "SM", "soft"):
+            setattr(a, n, buf[n].data_ptr())
+        keep = [t.contiguous() if t is not None else None for t in (d_cont, d_logits, d_samples)]
+        a.d_cont, a.d_logits, a.d_samples = (t.data_ptr() if t is not None else None for t in keep)
+        for n, t in g.items():
+            setattr(a, n, t.data_ptr())
+        a.B, a.accumulate, a.tau, a.res_scale = B, int(acc), tau, self.residual_scaling
+        ops.check(load().pcg_house_g_bwd(ctypes.byref(self._fused_desc()), ctypes.byref(a), ops._stream()), "pcg_house_g_bwd")
+        # weight (+ bias) gradients: one deterministic reduction over the batch per Linear
+        inp, K = buf["inp"], buf["inp"].shape[1]
+        cond = inp[:, self.input_dim:]
+        _lin_wgrad(self, self.fc_in, inp, g["DZIN"])
+        for k, blk in enumerate(self.blocks):
+            _lin_wgrad(self, blk.fc1, buf["H"][k], g["DZ1"][k])
+            _lin_wgrad(self, blk.fc2, g["A1"][k], g["DZ2"][k])
+            _lin_wgrad(self, blk.film.gamma, cond, g["DG"][k], ldx=K)
+            _lin_wgrad(self, blk.film.beta, cond, g["DB"][k], ldx=K)
+        h_last = buf["H"][5]
+        _lin_wgrad(self, self.fc_cont, h_last, g["DC"])
+        for s_, f in enumerate(self.cat_idx):
+            _lin_wgrad(self, self.fc_cat_logits[str(f)], h_last, g["DL"][:, self.seg[s_]:], ldy=T)
 
     # -- small device-side index tables (seg offsets, column indices) -------------------------------------------------
     def index_tables(self, device):
@@ -159,6 +263,8 @@ class ResidualGenerator(FlatModule):
         return ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, ACT_NONE, var_eps=bn.eps), None, None
 
     def _run_forward(self, x, target_onehot, mask, noise, tau, hard, keep=True):
+        if keep and self._fused_ok():
+            return self._fused_forward(x, target_onehot, mask, noise, tau, hard)
         x = x.contiguous()
         seg, cat_idx, cont_idx = self.index_tables(x.device)
         B = x.shape[0]
@@ -191,6 +297,8 @@ class ResidualGenerator(FlatModule):
         return cont, logits, (hard_y if hard else soft), saved
 
     def _run_backward(self, saved, d_cont, d_logits, d_samples):
+        if saved[0] == "fused":
+            return self._fused_backward(saved, d_cont, d_logits, d_samples)
         cond, inp, blocks, h_last, soft, seg, tau = saved
         if any(not blk.bn1.training for blk in self.blocks):
             raise PcgError("backward through an eval-mode BatchNorm1d is not implemented")

@@ -426,11 +426,12 @@ def linear_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):
     return ops.gemm(dy, w, B, I, O, lda=ldy if ldy is not None else O, out=out, accumulate=accumulate)
 
 
-def linear_wgrad(net, lin, x, dy, ldy=None, dw_out=None, weight_param=None, use_bias=True):
+def linear_wgrad(net, lin, x, dy, ldy=None, dw_out=None, weight_param=None, use_bias=True, ldx=None):
     """dW += dy^T x, db += column sums of dy, accumulated into net's flat gradient buffer.  `dw_out`: write dW there
     instead (spectral-norm layers post-process it); `weight_param`: the parameter that owns the weight gradient when it is
     not `lin.weight` (spectral norm: weight_orig)."""
-    B, I = x.shape
+    B = x.shape[0]
+    I = lin.in_features
     O = lin.out_features
     wp = weight_param if weight_param is not None else getattr(lin, "weight", None)
     has_b = use_bias and lin.bias is not None and lin.bias.requires_grad
@@ -439,13 +440,13 @@ def linear_wgrad(net, lin, x, dy, ldy=None, dw_out=None, weight_param=None, use_
         gw, acc = dw_out, False
     else:
         gw, acc = net._grad_view(wp)
-    if ldy is None and _lin_mfma(B, I, O):
+    if ldy is None and ldx is None and _lin_mfma(B, I, O):
         g = ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0)
         ops.conv2d_wgrad(g, x, dy, gw, acc)
         if gb is not None:
             ops.colsum(B, O, dy, gb, accb)
         return
-    ops.linear_wgrad(dy, x, B, O, I, gw, gb, ldy=ldy, accumulate_w=acc, accumulate_b=accb)
+    ops.linear_wgrad(dy, x, B, O, I, gw, gb, ldy=ldy, ldx=ldx, accumulate_w=acc, accumulate_b=accb)
 
 
 class _MeanFn(torch.autograd.Function):
