@@ -91,26 +91,46 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    for (int e = threadIdx.x; e < GK * GT; e += 256) {
-      const int kk = e / GT, r = e - kk * GT;
-      const int k = k0 + kk, m = m0 + r, n = n0 + r;
-      const bool kin = k < kend;
-      As[kk][r] = (kin && m < O) ? dy[(size_t)k * ldy + m] : 0.f;
-      Bs[kk][r] = !kin ? 0.f : (n < I ? x[(size_t)k * ldx + n] : (n == I ? 1.f : 0.f));
+  // The slab is walked in groups of WG_NS k-steps whose operands are ALL requested before the first one is used: the loop is
+  // latency-bound (a 32x33 output tile is a few hundred FMAs per step), so one exposed memory latency per 128 rows instead of
+  // one per 16 rows is what matters.
+  constexpr int WG_NS = 8, PER = GK * GT / 256;
+  for (int kc = kbeg; kc < kend; kc += GK * WG_NS) {
+    float ra[WG_NS][PER], rb[WG_NS][PER];
+#pragma unroll
+    for (int st = 0; st < WG_NS; ++st)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int kk = e / GT, r = e - kk * GT;
+        const int k = kc + st * GK + kk, m = m0 + r, n = n0 + r;
+        const bool kin = k < kend;
+        ra[st][q] = (kin && m < O) ? dy[(size_t)k * ldy + m] : 0.f;
+        rb[st][q] = !kin ? 0.f : (n < I ? x[(size_t)k * ldx + n] : (n == I ? 1.f : 0.f));
+      }
+#pragma unroll
+    for (int st = 0; st < WG_NS; ++st) {
+      if (kc + st * GK >= kend) break;            // block-uniform
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int kk = e / GT, r = e - kk * GT;
+        As[kk][r] = ra[st][q];
+        Bs[kk][r] = rb[st][q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < GK; ++kk) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < GK; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
   }
   const int NP = I + 1;
   if (S > 1) {
@@ -122,41 +142,34 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
         const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
         if (m < O && n < NP) mine[(size_t)m * NP + n] = acc[i][j];
       }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();                              // all partial stores of this block are issued (vector stores go to L2)
     if (threadIdx.x == 0) {
       const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+      // release: write this XCD's L2 back so the partials are visible device-wide; acquire: drop stale lines before the
+      // last block reads the other slabs.  One fence pair per block (thread 0, after the barrier), not one per thread.
       const int t = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       s_last = t == S - 1;
       if (s_last) tickets[tile] = 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int z0 = 0; z0 < S; z0 += 4) {     // slab order is the summation order; the loads of four slabs are in flight together
-      float v[4][4][4];
-#pragma unroll
-      for (int zz = 0; zz < 4; ++zz) {
-        const float* src = partial + (size_t)(z0 + zz) * O * NP;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            v[zz][i][j] = (z0 + zz < S && m < O && n < NP) ? src[(size_t)m * NP + n] : 0.f;
-          }
+    // the last block of the tile adds the S slabs in slab order; the tile's valid outputs are spread over all 256 threads
+    // (a 32x33 layer keeps only 72 threads busy in the 4x4 register blocking), eight slabs in flight per output
+    const int th = min(GT, O - m0), tw = min(GT, NP - n0);
+    for (int e = threadIdx.x; e < th * tw; e += 256) {
+      const int m = m0 + e / tw, n = n0 + e % tw;
+      const float* src = partial + (size_t)m * NP + n;
+      float sum = 0.f;
+#pragma unroll 8
+      for (int z = 0; z < S; ++z) sum += src[(size_t)z * O * NP];
+      if (n < I) {
+        float* p = dW + (size_t)m * I + n;
+        *p = accW ? *p + sum : sum;
+      } else if (db) {
+        db[m] = accB ? db[m] + sum : sum;
       }
-#pragma unroll
-      for (int zz = 0; zz < 4; ++zz)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += v[zz][i][j];
     }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -390,7 +403,7 @@ struct WgradPlan { int S, chunk, tiles; };
 WgradPlan plan_linear_wgrad(int B, int O, int I) {
   const int tiles = ((I + 1 + GT - 1) / GT) * ((O + GT - 1) / GT);
   int S = (256 + tiles - 1) / tiles;                 // aim at ~256 blocks (one per CU) ...
-  const int maxS = (B + 16 * GK - 1) / (16 * GK);    // ... of at least 256 rows each
+  const int maxS = (B + 8 * GK - 1) / (8 * GK);      // ... of at least 128 rows (one preloaded group of k-steps) each
   if (S > maxS) S = maxS;
   if (S > 64) S = 64;
   if (S < 1) S = 1;
