@@ -242,6 +242,15 @@ size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t I);
 int32_t pcg_linear_wgrad_ticket_count(void);
 int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW, float* db,
                      int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets, pcg_stream_t stream);
+/* The same for up to 40 small layers (O <= 64, I <= 63: one output tile each) that reduce over the SAME B rows, in one launch —
+ * the 35 Linear layers of the tabular generator's backward.  tickets: int32[>= n_items], zero before first use. */
+typedef struct pcg_wgrad_item {
+  const float* dy; const float* x; float* dW; float* db /*nullable*/;
+  int32_t ldy, ldx, O, I, accumulate_w, accumulate_b;
+} pcg_wgrad_item;
+size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, int32_t n_items);
+int pcg_linear_wgrad_grouped(const pcg_wgrad_item* items, int32_t n_items, int32_t B, void* workspace, size_t workspace_bytes,
+                             int32_t* tickets, pcg_stream_t stream);
 /* F.one_hot(idx, K).float() — trainer.py:250,290 */
 int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream);
 /* torch.cat([a, b], dim=1) and its backward — generator.py:73-74, discriminator.py:19 */

@@ -42,6 +42,11 @@ class HouseGDesc(ctypes.Structure):
                 [(n, _I) for n in ("nheads", "ncont", "D", "NC", "hidden", "nblocks")])
 
 
+class WgradItem(ctypes.Structure):
+    """pcg_wgrad_item."""
+    _fields_ = [("dy", _P), ("x", _P), ("dW", _P), ("db", _P)] + [(n, _I) for n in ("ldy", "ldx", "O", "I", "accumulate_w", "accumulate_b")]
+
+
 class HouseGFwdArgs(ctypes.Structure):
     """pcg_house_g_fwd_args."""
     _fields_ = ([(n, _P) for n in ("params", "x", "onehot", "mask", "noise", "inp", "H", "Z1", "Z2", "P", "SM")] +
@@ -130,6 +135,8 @@ PROTOTYPES = {
     "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pcg_linear_wgrad_ticket_count": (_i32, []),
     "pcg_linear_wgrad": (_i, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp]),
+    "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _i32]),
+    "pcg_linear_wgrad_grouped": (_i, [_c.POINTER(WgradItem), _i32, _i32, _vp, _sz, _vp, _vp]),
     "pcg_onehot": (_i, [_vp, _i32, _i32, _vp, _vp]),
     "pcg_concat_cols": (_i, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "pcg_split_cols": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

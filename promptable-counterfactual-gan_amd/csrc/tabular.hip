@@ -77,15 +77,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M
 // blockIdx.z; every slab writes its partial tile, and the block that takes the last ticket of a tile adds the S partials in
 // slab order (deterministic, no float atomics).  x is seen with a virtual column of ones at index I, whose "weight gradient"
 // is the bias gradient.  tickets: caller-owned int32[tiles], zero before first use, left zero.
-__global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                           int B, int O, int I, float* __restrict__ dW, float* __restrict__ db,
-                                                           int accW, int accB, int S, int chunk, float* __restrict__ partial,
-                                                           int* __restrict__ tickets) {
+__device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, int B, int O,
+                                                  int I, float* __restrict__ dW, float* __restrict__ db, int accW, int accB, int S,
+                                                  int chunk, float* __restrict__ partial, int* __restrict__ ticket, int tile_x, int tile_y,
+                                                  int slab) {
   __shared__ float As[GK][GT + 1], Bs[GK][GT + 1];
   __shared__ int s_last;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const int kbeg = blockIdx.z * chunk, kend = min(B, kbeg + chunk);
+  const int m0 = tile_y * GT, n0 = tile_x * GT;
+  const int kbeg = slab * chunk, kend = min(B, kbeg + chunk);
   float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
   }
   const int NP = I + 1;
   if (S > 1) {
-    float* mine = partial + (size_t)blockIdx.z * O * NP;
+    float* mine = partial + (size_t)slab * O * NP;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -144,12 +144,11 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
       }
     __syncthreads();                              // all partial stores of this block are issued (vector stores go to L2)
     if (threadIdx.x == 0) {
-      const int tile = blockIdx.y * gridDim.x + blockIdx.x;
       // release: write this XCD's L2 back so the partials are visible device-wide; acquire: drop stale lines before the
       // last block reads the other slabs.  One fence pair per block (thread 0, after the barrier), not one per thread.
-      const int t = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       s_last = t == S - 1;
-      if (s_last) tickets[tile] = 0;
+      if (s_last) *ticket = 0;
     }
     __syncthreads();
     if (!s_last) return;
@@ -184,6 +183,29 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
         db[m] = accB ? db[m] + acc[i][j] : acc[i][j];
       }
     }
+}
+
+__global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                           int B, int O, int I, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accW, int accB, int S, int chunk, float* __restrict__ partial,
+                                                           int* __restrict__ tickets) {
+  linear_wgrad_body(dy, ldy, x, ldx, B, O, I, dW, db, accW, accB, S, chunk, partial, tickets + blockIdx.y * gridDim.x + blockIdx.x, blockIdx.x,
+                    blockIdx.y, blockIdx.z);
+}
+
+// Many small layers of one backward pass in ONE launch (a step of the tabular generator has 35 of them): blockIdx.y picks the
+// layer, blockIdx.x the row slab.  Every layer here is a single 64x64 output tile (O <= 64, I + 1 <= 64).
+constexpr int WG_MAX_ITEMS = 40;
+struct WgradGroup {
+  const float* dy[WG_MAX_ITEMS]; const float* x[WG_MAX_ITEMS]; float* dW[WG_MAX_ITEMS]; float* db[WG_MAX_ITEMS];
+  int ldy[WG_MAX_ITEMS], ldx[WG_MAX_ITEMS], O[WG_MAX_ITEMS], I[WG_MAX_ITEMS], poff[WG_MAX_ITEMS];
+  unsigned char accW[WG_MAX_ITEMS], accB[WG_MAX_ITEMS];
+};
+__global__ void __launch_bounds__(256) linear_wgrad_grouped_kernel(WgradGroup g, int B, int S, int chunk, float* __restrict__ partial,
+                                                                   int* __restrict__ tickets) {
+  const int it = blockIdx.y;
+  linear_wgrad_body(g.dy[it], g.ldy[it], g.x[it], g.ldx[it], B, g.O[it], g.I[it], g.dW[it], g.db[it], g.accW[it], g.accB[it], S, chunk,
+                    partial + g.poff[it], tickets + it, 0, 0, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
@@ -434,6 +456,32 @@ extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, in
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3((I + 1 + GT - 1) / GT, (O + GT - 1) / GT, p.S), dim3(256), 0, (hipStream_t)stream, dy, ldy, x,
                      ldx, B, O, I, dW, db, accumulate_w, accumulate_b, p.S, p.chunk, (float*)workspace, tickets);
   return launch_status("linear_wgrad_kernel");
+}
+
+extern "C" size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, int32_t n_items) {
+  if (B <= 0 || n_items <= 0) return 0;
+  const WgradPlan p = plan_linear_wgrad(B, 32, 32);      // single-tile plan: S depends on B only
+  return (size_t)n_items * p.S * GT * GT * sizeof(float);
+}
+
+extern "C" int pcg_linear_wgrad_grouped(const pcg_wgrad_item* items, int32_t n_items, int32_t B, void* workspace, size_t workspace_bytes,
+                                        int32_t* tickets, pcg_stream_t stream) {
+  PCG_REQUIRE(items && n_items > 0 && n_items <= WG_MAX_ITEMS && B > 0 && tickets, "pcg_linear_wgrad_grouped: bad arguments (at most %d items)", WG_MAX_ITEMS);
+  const WgradPlan p = plan_linear_wgrad(B, 32, 32);
+  if (!workspace || workspace_bytes < pcg_linear_wgrad_grouped_workspace_bytes(B, n_items)) {
+    set_error("pcg_linear_wgrad_grouped: workspace too small"); return PCG_ERR_WORKSPACE;
+  }
+  WgradGroup g{};
+  for (int i = 0; i < n_items; ++i) {
+    const pcg_wgrad_item& it = items[i];
+    PCG_REQUIRE(it.dy && it.x && it.dW && it.O > 0 && it.O <= GT && it.I > 0 && it.I + 1 <= GT && it.ldy >= it.O && it.ldx >= it.I,
+                "pcg_linear_wgrad_grouped: item %d: a layer must fit one 64x64 tile (O <= 64, I <= 63)", i);
+    g.dy[i] = it.dy; g.x[i] = it.x; g.dW[i] = it.dW; g.db[i] = it.db; g.ldy[i] = it.ldy; g.ldx[i] = it.ldx; g.O[i] = it.O; g.I[i] = it.I;
+    g.accW[i] = it.accumulate_w != 0; g.accB[i] = it.accumulate_b != 0; g.poff[i] = i * p.S * GT * GT;
+  }
+  hipLaunchKernelGGL(linear_wgrad_grouped_kernel, dim3(p.S, n_items), dim3(256), 0, (hipStream_t)stream, g, B, p.S, p.chunk,
+                     (float*)workspace, tickets);
+  return launch_status("linear_wgrad_grouped_kernel");
 }
 
 extern "C" int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream) {

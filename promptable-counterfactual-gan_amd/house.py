@@ -198,19 +198,27 @@ class ResidualGenerator(FlatModule):
             setattr(a, n, t.data_ptr())
         a.B, a.accumulate, a.tau, a.res_scale = B, int(acc), tau, self.residual_scaling
         ops.check(load().pcg_house_g_bwd(ctypes.byref(self._fused_desc()), ctypes.byref(a), ops._stream()), "pcg_house_g_bwd")
-        # weight (+ bias) gradients: one deterministic reduction over the batch per Linear
+        # weight (+ bias) gradients of all 35 Linear layers: ONE launch (deterministic slab reduction per layer)
         inp, K = buf["inp"], buf["inp"].shape[1]
         cond = inp[:, self.input_dim:]
-        _lin_wgrad(self, self.fc_in, inp, g["DZIN"])
-        for k, blk in enumerate(self.blocks):
-            _lin_wgrad(self, blk.fc1, buf["H"][k], g["DZ1"][k])
-            _lin_wgrad(self, blk.fc2, g["A1"][k], g["DZ2"][k])
-            _lin_wgrad(self, blk.film.gamma, cond, g["DG"][k], ldx=K)
-            _lin_wgrad(self, blk.film.beta, cond, g["DB"][k], ldx=K)
         h_last = buf["H"][5]
-        _lin_wgrad(self, self.fc_cont, h_last, g["DC"])
+        items = []
+
+        def add(lin, x, dy, ldx=None, ldy=None):
+            gw, aw = self._grad_view(lin.weight)
+            gb, ab = self._grad_view(lin.bias)
+            items.append((dy, x, lin.out_features, lin.in_features, gw, gb, ldy if ldy is not None else lin.out_features,
+                          ldx if ldx is not None else lin.in_features, aw, ab))
+        add(self.fc_in, inp, g["DZIN"])
+        for k, blk in enumerate(self.blocks):
+            add(blk.fc1, buf["H"][k], g["DZ1"][k])
+            add(blk.fc2, g["A1"][k], g["DZ2"][k])
+            add(blk.film.gamma, cond, g["DG"][k], ldx=K)
+            add(blk.film.beta, cond, g["DB"][k], ldx=K)
+        add(self.fc_cont, h_last, g["DC"])
         for s_, f in enumerate(self.cat_idx):
-            _lin_wgrad(self, self.fc_cat_logits[str(f)], h_last, g["DL"][:, self.seg[s_]:], ldy=T)
+            add(self.fc_cat_logits[str(f)], h_last, g["DL"][:, self.seg[s_]:], ldy=T)
+        ops.linear_wgrad_grouped(items, B, onehot.device)
 
     # -- small device-side index tables (seg offsets, column indices) -------------------------------------------------
     def index_tables(self, device):
