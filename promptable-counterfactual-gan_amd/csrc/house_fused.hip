@@ -55,29 +55,55 @@ __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src,
   for (int i = threadIdx.x; i < n; i += FT) dst[i] = src[i];
 }
 
-// out[j] = b[j] + sum_i W[j][i] in[i], W row-major [HH][K] in LDS
+// Matrix-vector products of one segment, per lane (= per batch row).  A fully unrolled 32x32 product is 1024 FMAs of straight-
+// line code per layer — measured, the segment kernels then spend their time FETCHING INSTRUCTIONS (every line of a 50-100 KB
+// kernel is a cold miss executed once).  Instead the loop over the input index stays rolled: the weight matrix is staged
+// transposed in LDS ([i][j], so one input index needs 32 contiguous weights = 8 broadcast ds_read_b128), the lane's input
+// vector is parked in LDS ([i][lane], conflict-free), and the 32 accumulators live in registers.  ~40 instructions per
+// input index, a few hundred bytes of code per layer.
+//   out[j] = b[j] + sum_i W[j][i] in[i]          W row-major [HH][K] in global memory
 template <int K>
-__device__ __forceinline__ void lin_to32(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[K], float (&out)[HH]) {
+__device__ __forceinline__ void lin_to32(float* lds, const float* __restrict__ W, const float* __restrict__ b, const float (&in)[K],
+                                         float (&out)[HH]) {
+  float* Wt = lds; float* bl = lds + K * HH; float* V = bl + HH;
+  __syncthreads();                                           // the scratch area is free again
+  for (int e = threadIdx.x; e < K * HH; e += FT) { const int j = e / K, i = e - j * K; Wt[i * HH + j] = W[e]; }
+  if (threadIdx.x < HH) bl[threadIdx.x] = b[threadIdx.x];
 #pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    float acc = b[j];
+  for (int i = 0; i < K; ++i) V[i * FT + threadIdx.x] = in[i];
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < K; ++i) acc = fmaf(W[j * K + i], in[i], acc);
-    out[j] = acc;
+  for (int j = 0; j < HH; ++j) out[j] = bl[j];
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    const float a = V[i * FT + threadIdx.x];
+    const float* w = Wt + i * HH;
+#pragma unroll
+    for (int j = 0; j < HH; ++j) out[j] = fmaf(w[j], a, out[j]);
   }
 }
 template <int KMAX>
-__device__ __forceinline__ void lin_to32_rt(const float* __restrict__ W, const float* __restrict__ b, const float (&in)[KMAX], int, float (&out)[HH]) {
-  lin_to32<KMAX>(W, b, in, out);
+__device__ __forceinline__ void lin_to32_rt(float* lds, const float* __restrict__ W, const float* __restrict__ b, const float (&in)[KMAX], int,
+                                            float (&out)[HH]) {
+  lin_to32<KMAX>(lds, W, b, in, out);
 }
-// out[i] = sum_j W[j][i] v[j]   (transposed: gradient with respect to the input of a 32 -> 32 Linear)
-__device__ __forceinline__ void lin_t32(const float* __restrict__ W, const float (&v)[HH], float (&out)[HH]) {
+// out[i] = sum_j W[j][i] v[j]   (transposed: gradient with respect to the input of a 32 -> 32 Linear; W is already [j][i])
+__device__ __forceinline__ void lin_t32(float* lds, const float* __restrict__ W, const float (&v)[HH], float (&out)[HH]) {
+  float* Wl = lds; float* V = lds + HH * HH;
+  __syncthreads();
+  for (int e = threadIdx.x; e < HH * HH; e += FT) Wl[e] = W[e];
+#pragma unroll
+  for (int j = 0; j < HH; ++j) V[j * FT + threadIdx.x] = v[j];
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < HH; ++i) out[i] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < HH; ++j) {
+    const float a = V[j * FT + threadIdx.x];
+    const float* w = Wl + j * HH;
 #pragma unroll
-  for (int j = 0; j < HH; ++j)
-#pragma unroll
-    for (int i = 0; i < HH; ++i) out[i] = fmaf(W[j * HH + i], v[j], out[i]);
+    for (int i = 0; i < HH; ++i) out[i] = fmaf(w[i], a, out[i]);
+  }
 }
 
 // per-block column sums of v[0..31] and w[0..31] over the block's rows -> part[2][HH] of this block (fixed order)
@@ -157,11 +183,12 @@ __device__ __forceinline__ void store32(float* p, size_t row, bool on, const flo
 }
 
 // LDS layout shared by the kernels (floats)
-struct Smem {
+struct alignas(16) Smem {
   float red[FT * (HH + 1)];
   float red2[(FT / 32) * HH];
   float gamma[HH], beta[HH], mean[HH], inv[HH];
   float sums[2 * HH];
+  float lin[MAXIN * HH + HH + MAXIN * FT];     // scratch of lin_to32 / lin_t32: transposed weights, bias, the lanes' input vectors
 };
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
@@ -183,11 +210,11 @@ __global__ void __launch_bounds__(FT) g_fwd_first_kernel(const float* __restrict
     for (int i = 0; i < K; ++i) a.inp[(size_t)row * K + i] = inp[i];
   }
   float h[HH], z[HH], zz[HH];
-  lin_to32_rt<MAXIN>(PRM + d.fc_in_w, PRM + d.fc_in_b, inp, K, h);
+  lin_to32_rt<MAXIN>(s.lin, PRM + d.fc_in_w, PRM + d.fc_in_b, inp, K, h);
 #pragma unroll
   for (int j = 0; j < HH; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
   store32(a.H, row, on, h);
-  lin_to32<HH>(PRM + d.fc1_w[0], PRM + d.fc1_b[0], h, z);
+  lin_to32<HH>(s.lin, PRM + d.fc1_w[0], PRM + d.fc1_b[0], h, z);
   store32(a.Z1, row, on, z);
 #pragma unroll
   for (int j = 0; j < HH; ++j) { z[j] = on ? z[j] : 0.f; zz[j] = z[j] * z[j]; }
@@ -195,11 +222,10 @@ __global__ void __launch_bounds__(FT) g_fwd_first_kernel(const float* __restrict
 }
 
 // FiLM parameters of block k from cond
-__device__ __forceinline__ void film_params(const float* __restrict__ PRM, const GDesc& d, int k, const float (&cond)[MAXCOND],
+__device__ __forceinline__ void film_params(Smem& s, const float* __restrict__ PRM, const GDesc& d, int k, const float (&cond)[MAXCOND],
                                             float (&gam)[HH], float (&bet)[HH]) {
-  constexpr int C = MAXCOND;
-  lin_to32_rt<MAXCOND>(PRM + d.fg_w[k], PRM + d.fg_b[k], cond, C, gam);
-  lin_to32_rt<MAXCOND>(PRM + d.fb_w[k], PRM + d.fb_b[k], cond, C, bet);
+  lin_to32<MAXCOND>(s.lin, PRM + d.fg_w[k], PRM + d.fg_b[k], cond, gam);
+  lin_to32<MAXCOND>(s.lin, PRM + d.fb_w[k], PRM + d.fb_b[k], cond, bet);
 }
 
 // kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
@@ -214,7 +240,7 @@ __global__ void __launch_bounds__(FT) g_fwd_a_kernel(const float* __restrict__ P
   float cond[MAXCOND], gam[HH], bet[HH], z[HH], a1[HH], z2[HH], zz[HH];
   load_cond(a, d, row, on, cond);
   __syncthreads();                                // publishes gamma / beta
-  film_params(PRM, d, k, cond, gam, bet);
+  film_params(s, PRM, d, k, cond, gam, bet);
   load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
 #pragma unroll
   for (int j = 0; j < HH; ++j) {
@@ -222,7 +248,7 @@ __global__ void __launch_bounds__(FT) g_fwd_a_kernel(const float* __restrict__ P
     const float f = fmaf(gam[j], n, bet[j]);
     a1[j] = f > 0.f ? f : 0.f;
   }
-  lin_to32<HH>(PRM + d.fc2_w[k], PRM + d.fc2_b[k], a1, z2);
+  lin_to32<HH>(s.lin, PRM + d.fc2_w[k], PRM + d.fc2_b[k], a1, z2);
   store32(a.Z2 + (size_t)k * a.B * HH, row, on, z2);
 #pragma unroll
   for (int j = 0; j < HH; ++j) { z2[j] = on ? z2[j] : 0.f; zz[j] = z2[j] * z2[j]; }
@@ -242,7 +268,7 @@ __global__ void __launch_bounds__(FT) g_fwd_b_kernel(const float* __restrict__ P
   float cond[MAXCOND], gam[HH], bet[HH], z[HH], h[HH];
   load_cond(a, d, row, on, cond);
   __syncthreads();
-  film_params(PRM, d, k, cond, gam, bet);
+  film_params(s, PRM, d, k, cond, gam, bet);
   load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
   load32(a.H + (size_t)k * a.B * HH, row, on, h);
 #pragma unroll
@@ -253,7 +279,7 @@ __global__ void __launch_bounds__(FT) g_fwd_b_kernel(const float* __restrict__ P
   store32(a.H + (size_t)(k + 1) * a.B * HH, row, on, h);
   if (!last) {
     float z1[HH], zz[HH];
-    lin_to32<HH>(PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1], h, z1);
+    lin_to32<HH>(s.lin, PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1], h, z1);
     store32(a.Z1 + (size_t)(k + 1) * a.B * HH, row, on, z1);
 #pragma unroll
     for (int j = 0; j < HH; ++j) { z1[j] = on ? z1[j] : 0.f; zz[j] = z1[j] * z1[j]; }
@@ -319,7 +345,7 @@ __device__ __forceinline__ void bn_apply32(const float (&z)[HH], const float* me
   for (int j = 0; j < HH; ++j) { xh[j] = (z[j] - mean[j]) * inv[j]; n[j] = fmaf(xh[j], g[j], b[j]); }
 }
 
-__device__ __forceinline__ void film_params_b(const float* __restrict__ PRM, const GBwd& a, const GDesc& d, int k, int row, bool on,
+__device__ __forceinline__ void film_params_b(Smem& s, const float* __restrict__ PRM, const GBwd& a, const GDesc& d, int k, int row, bool on,
                                               float (&gam)[HH], float (&bet)[HH]) {
   constexpr int C = MAXCOND;
   float cond[MAXCOND];
@@ -327,15 +353,16 @@ __device__ __forceinline__ void film_params_b(const float* __restrict__ PRM, con
   for (int i = 0; i < NCLS; ++i) cond[i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
 #pragma unroll
   for (int i = 0; i < DIN; ++i) cond[NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
-  lin_to32_rt<MAXCOND>(PRM + d.fg_w[k], PRM + d.fg_b[k], cond, C, gam);
-  lin_to32_rt<MAXCOND>(PRM + d.fb_w[k], PRM + d.fb_b[k], cond, C, bet);
+  (void)C;
+  lin_to32<MAXCOND>(s.lin, PRM + d.fg_w[k], PRM + d.fg_b[k], cond, gam);
+  lin_to32<MAXCOND>(s.lin, PRM + d.fb_w[k], PRM + d.fb_b[k], cond, bet);
 }
 
 // part "a" of block k, shared by the first backward kernel and kind C: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2)
 __device__ __forceinline__ void bwd_part_a(const float* __restrict__ PRM, Smem& s, const GBwd& a, const GDesc& d, int k, int row, bool on,
                                            const float (&dh)[HH]) {
   float gam[HH], bet[HH], z[HH], xh[HH], v[HH], w[HH];
-  film_params_b(PRM, a, d, k, row, on, gam, bet);
+  film_params_b(s, PRM, a, d, k, row, on, gam, bet);
   load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
   const float* sm = a.SM + (size_t)(2 * k + 1) * 2 * HH;
 #pragma unroll
@@ -417,7 +444,7 @@ __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const bool on = row < a.B;
   float gam[HH], bet[HH], z[HH], dh[HH], dz2[HH], da1[HH];
   __syncthreads();
-  film_params_b(PRM, a, d, k, row, on, gam, bet);
+  film_params_b(s, PRM, a, d, k, row, on, gam, bet);
   load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
   load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
   const float* sm2 = a.SM + (size_t)(2 * k + 1) * 2 * HH;
@@ -431,7 +458,7 @@ __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1)))
     dgam[j] = dh[j] * n2;
   }
   store32(a.DZ2 + (size_t)k * a.B * HH, row, on, dz2);
-  lin_t32(PRM + d.fc2_w[k], dz2, da1);
+  lin_t32(s.lin, PRM + d.fc2_w[k], dz2, da1);
   load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
   const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
   float a1[HH], v[HH], w[HH], dbet[HH];
@@ -472,7 +499,7 @@ __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1)))
     dz1[j] = s.gamma[j] * sm1[HH + j] * (dn1[j] - s.sums[j] - xh * s.sums[HH + j]);
   }
   store32(a.DZ1 + (size_t)k * a.B * HH, row, on, dz1);
-  lin_t32(PRM + d.fc1_w[k], dz1, t);
+  lin_t32(s.lin, PRM + d.fc1_w[k], dz1, t);
   load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
 #pragma unroll
   for (int j = 0; j < HH; ++j) dh[j] += t[j];
