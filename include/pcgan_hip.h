@@ -235,6 +235,9 @@ int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_
  * models/nn_classifier.py:8-27. */
 int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
              float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream);
+/* pcg_gemm with the layer's ReLU / LeakyReLU fused into the output write (Linear + LeakyReLU: discriminator.py:9-14, nn_classifier.py:8-25) */
+int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                 float* C, int32_t ldc, const float* bias, int accumulate, int act, float slope, pcg_stream_t stream);
 /* nn.Linear weight + bias gradient in one launch, reducing over the batch with a deterministic split over row slabs:
  * dW[O][I] (+)= dy^T x, db[O] (+)= column sums of dy (db nullable).  dy / x may be column slices (ld = row stride).
  * tickets: caller-owned int32[pcg_linear_wgrad_ticket_count()], zero before first use; the kernel leaves it zero. */
@@ -287,6 +290,13 @@ int pcg_mean_bwd(const float* grad_out_dev /*nullable = 1*/, float grad_scale, i
  * Dimensions up to 256. */
 int pcg_spectral_norm_fwd(const float* w_orig, int32_t out_features, int32_t in_features, float* u, float* v, float eps,
                           int power_iteration, float* w_bar, float* sigma, float* u_used, float* v_used, pcg_stream_t stream);
+/* all (up to 8) spectral-norm layers of a net in one launch — arrays of per-layer arguments, host-side arrays of device pointers */
+int pcg_spectral_norm_fwd_batched(int32_t n, const float* const* w_orig, const int32_t* out_features, const int32_t* in_features,
+                                  float* const* u, float* const* v, float eps, int power_iteration, float* const* w_bar,
+                                  float* const* sigma, float* const* u_used, float* const* v_used, pcg_stream_t stream);
+int pcg_spectral_norm_bwd_batched(int32_t n, const float* const* dw_bar, const float* const* w_bar, const int32_t* out_features,
+                                  const int32_t* in_features, const float* const* u, const float* const* v, const float* const* sigma,
+                                  float* const* dw_orig, const int32_t* accumulate, pcg_stream_t stream);
 int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, int32_t out_features, int32_t in_features, const float* u,
                           const float* v, const float* sigma, float* dw_orig, int accumulate, pcg_stream_t stream);
 

@@ -137,6 +137,9 @@ PROTOTYPES = {
     "pcg_linear_wgrad": (_i, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp]),
     "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _i32]),
     "pcg_linear_wgrad_grouped": (_i, [_c.POINTER(WgradItem), _i32, _i32, _vp, _sz, _vp, _vp]),
+    "pcg_gemm_act": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _i, _f, _vp]),
+    "pcg_spectral_norm_fwd_batched": (_i, [_i32, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_spectral_norm_bwd_batched": (_i, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_onehot": (_i, [_vp, _i32, _i32, _vp, _vp]),
     "pcg_concat_cols": (_i, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "pcg_split_cols": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

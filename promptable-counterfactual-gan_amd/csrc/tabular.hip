@@ -22,7 +22,7 @@ unsigned ew_blocks(size_t n) {
 constexpr int GT = 64, GK = 16;
 __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M, int N, int K, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-                                                   const float* __restrict__ bias, int accumulate) {
+                                                   const float* __restrict__ bias, int accumulate, int act_on, float neg) {
   __shared__ float As[GK][GT + 1], Bs[GK][GT + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M
       if (n >= N) continue;
       float v = acc[i][j] + (bias ? bias[n] : 0.f);
       float* c = C + (size_t)m * ldc + n;
-      *c = accumulate ? *c + v : v;
+      if (accumulate) v += *c;
+      if (act_on) v = act_neg_scale(v, neg);       // fused ReLU / LeakyReLU of the layer (after the accumulation, if any)
+      *c = v;
     }
   }
 }
@@ -359,10 +361,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 // training: v <- normalize(W^T u); u <- normalize(W v)  (in place);  sigma = u . (W v);  Wbar = W / sigma
-__global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
-                                                                float* __restrict__ v, float eps, int power_iter,
-                                                                float* __restrict__ Wbar, float* __restrict__ sigma_out,
-                                                                float* __restrict__ u_used, float* __restrict__ v_used) {
+__device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__ W, int O, int I, float* __restrict__ u,
+                                                       float* __restrict__ v, float eps, int power_iter, float* __restrict__ Wbar,
+                                                       float* __restrict__ sigma_out, float* __restrict__ u_used,
+                                                       float* __restrict__ v_used) {
   __shared__ float red[256];
   __shared__ float su[256], sv[256];   // O, I <= 256 (host-checked)
   for (int i = threadIdx.x; i < O; i += 256) su[i] = u[i];
@@ -391,10 +393,16 @@ __global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __r
   const float inv = 1.f / sigma;
   for (int e = threadIdx.x; e < O * I; e += 256) Wbar[e] = W[e] * inv;
 }
+__global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
+                                                                float* __restrict__ v, float eps, int power_iter,
+                                                                float* __restrict__ Wbar, float* __restrict__ sigma_out,
+                                                                float* __restrict__ u_used, float* __restrict__ v_used) {
+  spectral_norm_fwd_body(W, O, I, u, v, eps, power_iter, Wbar, sigma_out, u_used, v_used);
+}
 // dW (+)= (dWbar - (sum dWbar*Wbar) u v^T) / sigma
-__global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O,
-                                                                int I, const float* __restrict__ u, const float* __restrict__ v,
-                                                                const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
+__device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O, int I,
+                                                       const float* __restrict__ u, const float* __restrict__ v,
+                                                       const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
   __shared__ float red[256];
   float t = 0.f;
   for (int e = threadIdx.x; e < O * I; e += 256) t = fmaf(dWbar[e], Wbar[e], t);
@@ -406,6 +414,24 @@ __global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __r
     dW[e] = accumulate ? dW[e] + g : g;
   }
 }
+__global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O,
+                                                                int I, const float* __restrict__ u, const float* __restrict__ v,
+                                                                const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
+  spectral_norm_bwd_body(dWbar, Wbar, O, I, u, v, sigma, dW, accumulate);
+}
+
+// all spectral-norm layers of a net in one launch (one block per layer): the critic has four
+constexpr int SN_MAX = 8;
+struct SnFwdBatch { const float* W[SN_MAX]; float* u[SN_MAX]; float* v[SN_MAX]; float* Wbar[SN_MAX]; float* sigma[SN_MAX]; float* uu[SN_MAX]; float* vu[SN_MAX]; int O[SN_MAX], I[SN_MAX]; };
+struct SnBwdBatch { const float* dWbar[SN_MAX]; const float* Wbar[SN_MAX]; const float* u[SN_MAX]; const float* v[SN_MAX]; const float* sigma[SN_MAX]; float* dW[SN_MAX]; int O[SN_MAX], I[SN_MAX], acc[SN_MAX]; };
+__global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBatch b, float eps, int power_iter) {
+  const int l = blockIdx.x;
+  spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar[l], b.sigma[l], b.uu[l], b.vu[l]);
+}
+__global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBatch b) {
+  const int l = blockIdx.x;
+  spectral_norm_bwd_body(b.dWbar[l], b.Wbar[l], b.O[l], b.I[l], b.u[l], b.v[l], b.sigma[l], b.dW[l], b.acc[l]);
+}
 
 }  // namespace
 }  // namespace pcg
@@ -416,8 +442,49 @@ extern "C" int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K,
                         int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream) {
   PCG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "pcg_gemm: bad arguments");
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
-                     A, lda, B, ldb, C, ldc, bias, accumulate);
+                     A, lda, B, ldb, C, ldc, bias, accumulate, 0, 1.f);
   return launch_status("gemm_kernel");
+}
+
+extern "C" int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                            int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, int act, float slope, pcg_stream_t stream) {
+  PCG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "pcg_gemm_act: bad arguments");
+  PCG_REQUIRE(act_is_cheap(act), "pcg_gemm_act: only ReLU / LeakyReLU are fused (activation %d)", act);
+  hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
+                     A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope));
+  return launch_status("gemm_kernel");
+}
+
+extern "C" int pcg_spectral_norm_fwd_batched(int32_t n, const float* const* w_orig, const int32_t* out_features, const int32_t* in_features,
+                                             float* const* u, float* const* v, float eps, int power_iteration, float* const* w_bar,
+                                             float* const* sigma, float* const* u_used, float* const* v_used, pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && n <= SN_MAX && w_orig && out_features && in_features && u && v && w_bar && sigma && u_used && v_used,
+              "pcg_spectral_norm_fwd_batched: bad arguments (at most %d layers)", SN_MAX);
+  SnFwdBatch b{};
+  for (int l = 0; l < n; ++l) {
+    PCG_REQUIRE(w_orig[l] && u[l] && v[l] && w_bar[l] && sigma[l] && out_features[l] > 0 && out_features[l] <= 256 && in_features[l] > 0 &&
+                    in_features[l] <= 256, "pcg_spectral_norm_fwd_batched: layer %d: bad arguments", l);
+    b.W[l] = w_orig[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.Wbar[l] = w_bar[l]; b.sigma[l] = sigma[l]; b.uu[l] = u_used[l]; b.vu[l] = v_used[l];
+    b.O[l] = out_features[l]; b.I[l] = in_features[l];
+  }
+  hipLaunchKernelGGL(spectral_norm_fwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b, eps, power_iteration);
+  return launch_status("spectral_norm_fwd_batched_kernel");
+}
+
+extern "C" int pcg_spectral_norm_bwd_batched(int32_t n, const float* const* dw_bar, const float* const* w_bar, const int32_t* out_features,
+                                             const int32_t* in_features, const float* const* u, const float* const* v,
+                                             const float* const* sigma, float* const* dw_orig, const int32_t* accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && n <= SN_MAX && dw_bar && w_bar && out_features && in_features && u && v && sigma && dw_orig && accumulate,
+              "pcg_spectral_norm_bwd_batched: bad arguments");
+  SnBwdBatch b{};
+  for (int l = 0; l < n; ++l) {
+    PCG_REQUIRE(dw_bar[l] && w_bar[l] && u[l] && v[l] && sigma[l] && dw_orig[l] && out_features[l] > 0 && out_features[l] <= 256 &&
+                    in_features[l] > 0 && in_features[l] <= 256, "pcg_spectral_norm_bwd_batched: layer %d: bad arguments", l);
+    b.dWbar[l] = dw_bar[l]; b.Wbar[l] = w_bar[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.sigma[l] = sigma[l]; b.dW[l] = dw_orig[l];
+    b.O[l] = out_features[l]; b.I[l] = in_features[l]; b.acc[l] = accumulate[l];
+  }
+  hipLaunchKernelGGL(spectral_norm_bwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b);
+  return launch_status("spectral_norm_bwd_batched_kernel");
 }
 
 namespace {

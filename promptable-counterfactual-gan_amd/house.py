@@ -457,12 +457,13 @@ class Discriminator(FlatModule):
     def _run_forward(self, x, target_onehot, keep=True):
         a = ops.concat_cols(x.contiguous(), target_onehot.contiguous())                       # :19
         lins = self._linears()
+        # power iteration + W / sigma of all four layers: one launch
+        sn = ops.spectral_norm_fwd_batched([l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins],
+                                           1e-12, self.training)
         layers = []
         for i, lin in enumerate(lins):
-            w_bar, sigma, u, v = ops.spectral_norm_fwd(lin.weight_orig.data, lin.weight_u, lin.weight_v, 1e-12, self.training)
-            z = _lin_fwd(lin, a, weight=w_bar)
-            if i + 1 < len(lins):
-                ops.act_fwd(z, ACT_LRELU, 0.2, out=z)
+            w_bar, sigma, u, v = sn[i]
+            z = _lin_fwd(lin, a, weight=w_bar, act=ACT_LRELU if i + 1 < len(lins) else ACT_NONE, slope=0.2)   # LeakyReLU fused
             if keep:
                 layers.append((a, z, w_bar, sigma, u, v))
             a = z
@@ -472,6 +473,7 @@ class Discriminator(FlatModule):
         lins = self._linears()
         d = dout.contiguous()
         B = d.shape[0]
+        sn_items = []
         for i in range(len(lins) - 1, -1, -1):
             lin = lins[i]
             a, z, w_bar, sigma, u, v = layers[i]
@@ -481,9 +483,11 @@ class Discriminator(FlatModule):
                 dwb = torch.empty_like(w_bar)
                 _lin_wgrad(self, lin, a, d, dw_out=dwb, weight_param=lin.weight_orig)
                 gw, acc = self._grad_view(lin.weight_orig)
-                ops.spectral_norm_bwd(dwb, w_bar, u, v, sigma, gw, acc)
+                sn_items.append((dwb, w_bar, u, v, sigma, gw, acc))
             if i > 0 or need_x:
                 d = _lin_dgrad(w_bar, d, B)
+        if sn_items:
+            ops.spectral_norm_bwd_batched(sn_items)                                          # all layers: one launch
         if not need_x:
             return None
         dx, _ = ops.split_cols(d, self.input_dim, d.shape[1] - self.input_dim, need_b=False)
@@ -637,9 +641,8 @@ class NNClassifier(FlatModule):
         B = a.shape[0]
         acts = []
         for i, (w, b) in enumerate(packed):
-            z = affine_fwd(a, w, b)
+            z = affine_fwd(a, w, b, act=ACT_LRELU if i + 1 < len(packed) else ACT_NONE, slope=0.1)
             if i + 1 < len(packed):
-                ops.act_fwd(z, ACT_LRELU, 0.1, out=z)
                 if keep:
                     acts.append(z)
             a = z

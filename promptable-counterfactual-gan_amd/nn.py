@@ -396,25 +396,25 @@ def _lin_mfma(B, I, O):
     return I % 4 == 0 and I >= 64 and O >= 32 and B * I * O >= (1 << 24)
 
 
-def affine_fwd(x, w, bias=None):
-    """y = x w^T (+ bias) for a raw [out, in] weight (frozen / folded layers)."""
+def affine_fwd(x, w, bias=None, act=ACT_NONE, slope=0.0):
+    """y = act(x w^T (+ bias)) for a raw [out, in] weight (frozen / folded layers); act: none / ReLU / LeakyReLU, fused."""
     B = x.shape[0]
     O, I = w.shape
     if _lin_mfma(B, I, O):
-        return ops.conv2d_fwd(ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0), x, w, bias).view(B, O)
-    return ops.gemm(x, w, B, O, I, transB=True, bias=bias)
+        return ops.conv2d_fwd(ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0), x, w, bias, act=act, slope=slope).view(B, O)
+    return ops.gemm(x, w, B, O, I, transB=True, bias=bias, act=act, slope=slope)
 
 
-def linear_fwd(lin, x, weight=None, out=None, ldc=None, use_bias=True):
-    """y = x W^T (+ b).  `weight` overrides lin.weight (spectral-norm layers pass W / sigma)."""
+def linear_fwd(lin, x, weight=None, out=None, ldc=None, use_bias=True, act=ACT_NONE, slope=0.0):
+    """y = act(x W^T (+ b)).  `weight` overrides lin.weight (spectral-norm layers pass W / sigma); act: none / ReLU / LeakyReLU."""
     w = lin.weight.data if weight is None else weight
     B = x.shape[0]
     O, I = w.shape
     bias = lin.bias.data if (use_bias and lin.bias is not None) else None
     if out is None and _lin_mfma(B, I, O):
         g = ops.conv_geom(B, 1, 1, I, O, 1, 1, 1, 0)
-        return ops.conv2d_fwd(g, x, w, bias).view(B, O)
-    return ops.gemm(x, w, B, O, I, transB=True, bias=bias, out=out, ldc=ldc)
+        return ops.conv2d_fwd(g, x, w, bias, act=act, slope=slope).view(B, O)
+    return ops.gemm(x, w, B, O, I, transB=True, bias=bias, out=out, ldc=ldc, act=act, slope=slope)
 
 
 def linear_dgrad(w, dy, B, ldy=None, out=None, accumulate=False):

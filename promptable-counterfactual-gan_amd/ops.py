@@ -394,7 +394,7 @@ def cross_entropy_fwd_bwd(logits, target, need_loss=True, need_grad=True, grad_o
 
 
 # ---- tabular CounteRGAN building blocks (csrc/tabular.hip) ----------------------------------------------------------------
-def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None, ldc=None, bias=None, accumulate=False):
+def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None, ldc=None, bias=None, accumulate=False, act=0, slope=0.0):
     """out[M][N] (+)= opA . opB (+ bias); A/B/out may be column slices of wider row-major buffers (ld* = row stride)."""
     for t, n in ((A, "A"), (B, "B")):
         if not t.is_cuda or t.dtype != torch.float32:
@@ -404,8 +404,8 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     ldc = ldc if ldc is not None else N
-    check(_lib.load().pcg_gemm(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(bool(accumulate)),
-                               _stream()), "pcg_gemm")
+    check(_lib.load().pcg_gemm_act(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(bool(accumulate)),
+                                   int(act), float(slope), _stream()), "pcg_gemm_act")
     return out
 
 
@@ -549,6 +549,35 @@ def spectral_norm_fwd(w_orig, u, v, eps, power_iteration):
     check(_lib.load().pcg_spectral_norm_fwd(_p(w_orig), O, I, _p(u), _p(v), float(eps), int(bool(power_iteration)), _p(w_bar), _p(sigma),
                                             _p(uu), _p(vu), _stream()), "pcg_spectral_norm_fwd")
     return w_bar, sigma, uu, vu
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def spectral_norm_fwd_batched(w_origs, us, vs, eps, power_iteration):
+    """[(w_bar, sigma, u_used, v_used)] for all layers in one launch."""
+    n = len(w_origs)
+    outs = [(torch.empty_like(w), torch.empty(1, dtype=torch.float32, device=w.device), torch.empty_like(u), torch.empty_like(v))
+            for w, u, v in zip(w_origs, us, vs)]
+    I32 = ctypes.c_int32 * n
+    check(_lib.load().pcg_spectral_norm_fwd_batched(n, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]), I32(*[w.shape[1] for w in w_origs]),
+                                                    _ptr_array(us), _ptr_array(vs), float(eps), int(bool(power_iteration)),
+                                                    _ptr_array([o[0] for o in outs]), _ptr_array([o[1] for o in outs]),
+                                                    _ptr_array([o[2] for o in outs]), _ptr_array([o[3] for o in outs]), _stream()),
+          "pcg_spectral_norm_fwd_batched")
+    return outs
+
+
+def spectral_norm_bwd_batched(items):
+    """items: [(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate)] — all layers in one launch."""
+    n = len(items)
+    I32 = ctypes.c_int32 * n
+    check(_lib.load().pcg_spectral_norm_bwd_batched(n, _ptr_array([i[0] for i in items]), _ptr_array([i[1] for i in items]),
+                                                    I32(*[i[1].shape[0] for i in items]), I32(*[i[1].shape[1] for i in items]),
+                                                    _ptr_array([i[2] for i in items]), _ptr_array([i[3] for i in items]),
+                                                    _ptr_array([i[4] for i in items]), _ptr_array([i[5] for i in items]),
+                                                    I32(*[int(bool(i[6])) for i in items]), _stream()), "pcg_spectral_norm_bwd_batched")
 
 
 def spectral_norm_bwd(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate):
