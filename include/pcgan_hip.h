@@ -134,6 +134,11 @@ int pcg_bn_act_bwd(const float* dy, const float* x, const float* y /*nullable wh
                    int act, float slope, float dy_scale /* dz = dy_scale*dy*act'(.) : the alpha of the forward */,
                    float* dx, float* dgamma, float* dbeta, int accumulate,
                    void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* The same without reading y: for ReLU / LeakyReLU the mask act'(y) is the sign of the BatchNorm output, recomputed from x with the
+ * forward's own expression fma(x, gamma*invstd, beta - mean*gamma*invstd) — two HBM reads of the activation less per layer. */
+int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx, float* dgamma,
+                           float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "pcg_bn_train_stats": (_i, [_vp, _i64, _c.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_bn_apply_act": (_i, [_vp, _i64, _c.c_int32, _vp, _vp, _f, _vp, _vp, _i, _f, _vp, _f, _vp, _vp]),
     "pcg_bn_act_bwd": (_i, [_vp, _vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_bn_act_bwd_premask": (_i, [_vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_embed_concat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _vp]),
     "pcg_embed_concat_bwd": (_i, [_vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _i, _vp]),
     "pcg_axpby": (_i, [_vp, _f, _vp, _f, _vp, _i64, _vp]),

@@ -288,7 +288,7 @@ class ResidualGenerator(FlatModule):
             da1 = _conv_bwd(self, blk.conv2, g2, a1, dz2, True, True)
             dg1, acc = self._grad_view(blk.bn1.weight)
             db1, _ = self._grad_view(blk.bn1.bias)
-            dz1 = ops.bn_act_bwd(da1, z1, a1, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc)
+            dz1 = ops.bn_act_bwd(da1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc, beta=blk.bn1.bias.data)
             dconv = _conv_bwd(self, blk.conv1, g1, h, dz1, True, True)
             dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)          # skip path + block path
         ops.act_bwd(dh, blocks[0][1] if blocks else h_last, ACT_LRELU, slope, out=dh)   # h0 = LeakyReLU(conv_in(inp))

@@ -68,11 +68,21 @@ struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
   static constexpr int NVAL = 2;
   const float* dy; const float* x; const float* y; const float* mean; const float* invstd;
   int act; float slope; float dy_scale;
+  const float* gamma; const float* beta;   // y == nullptr: the ReLU / LeakyReLU mask is the sign of the recomputed BatchNorm output
   template <int VEC>
   __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
     float g[VEC], xv[VEC], yv[VEC];
     ldv<VEC>(dy, idx, g); ldv<VEC>(x, idx, xv);
-    if (act != PCG_ACT_NONE) ldv<VEC>(y, idx, yv);
+    if (act != PCG_ACT_NONE) {
+      if (y) ldv<VEC>(y, idx, yv);
+      else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float sc = gamma[c0 + e] * invstd[c0 + e];
+          yv[e] = fmaf(xv[e], sc, beta[c0 + e] - mean[c0 + e] * sc);      // same expression as bn_apply_act
+        }
+      }
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
@@ -248,7 +258,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, size_t n, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, int act, float slope,
-                                                           float dy_scale, float* __restrict__ dx) {
+                                                           float dy_scale, float* __restrict__ dx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta) {
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     const int c0 = (int)((i * VEC) % (size_t)C);
@@ -256,16 +267,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     if constexpr (VEC == 4) {
       const float4 a = reinterpret_cast<const float4*>(dy)[i];
       const float4 b = reinterpret_cast<const float4*>(x)[i];
-      const float4 c = act != PCG_ACT_NONE ? reinterpret_cast<const float4*>(y)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 c = (act != PCG_ACT_NONE && y) ? reinterpret_cast<const float4*>(y)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
       g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
       xv[0] = b.x; xv[1] = b.y; xv[2] = b.z; xv[3] = b.w;
       yv[0] = c.x; yv[1] = c.y; yv[2] = c.z; yv[3] = c.w;
     } else {
-      g[0] = dy[i]; xv[0] = x[i]; yv[0] = act != PCG_ACT_NONE ? y[i] : 1.f;
+      g[0] = dy[i]; xv[0] = x[i]; yv[0] = (act != PCG_ACT_NONE && y) ? y[i] : 1.f;
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int c = c0 + e;
+      if (act != PCG_ACT_NONE && !y) { const float sc = gamma[c] * invstd[c]; yv[e] = fmaf(xv[e], sc, beta[c] - mean[c] * sc); }
       const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
       const float xh = (xv[e] - mean[c]) * invstd[c];
       g[e] = coef[c] * (dz - coef[C + c] - xh * coef[2 * C + c]);
@@ -316,20 +328,25 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
                                                                 const float4* __restrict__ y, size_t n4, int C,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, int act, float slope,
-                                                                float dy_scale, float4* __restrict__ dx) {
+                                                                float dy_scale, float4* __restrict__ dx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta) {
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
-  float mu[4], is[4], k0[4], k1[4], k2[4];
+  float mu[4], is[4], k0[4], k1[4], k2[4], msc[4], msh[4];
+  const bool premask = act != PCG_ACT_NONE && y == nullptr;     // mask from the recomputed BatchNorm output: y is not read
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = c0 + e;
     mu[e] = mean[c]; is[e] = invstd[c]; k0[e] = coef[c]; k1[e] = coef[C + c]; k2[e] = coef[2 * C + c];
+    msc[e] = premask ? gamma[c] * invstd[c] : 0.f;
+    msh[e] = premask ? beta[c] - mean[c] * msc[e] : 0.f;
   }
   const bool has_act = act != PCG_ACT_NONE;
   auto one = [&](float4 g, float4 xv, float4 yv) {
     float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      if (premask) yy[e] = fmaf(xx[e], msc[e], msh[e]);
       const float dz = dy_scale * gg[e] * (has_act ? act_grad_from_out(yy[e], act, slope) : 1.f);
       const float xh = (xx[e] - mu[e]) * is[e];
       gg[e] = k0[e] * (dz - k1[e] - xh * k2[e]);
@@ -340,11 +357,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
   size_t i = gtid;
   for (; i + stride < n4; i += 2 * stride) {
     const float4 g0 = dy[i], g1 = dy[i + stride], x0 = x[i], x1 = x[i + stride];
-    const float4 y0 = has_act ? y[i] : ones, y1 = has_act ? y[i + stride] : ones;
+    const float4 y0 = (has_act && !premask) ? y[i] : ones, y1 = (has_act && !premask) ? y[i + stride] : ones;
     dx[i] = one(g0, x0, y0);
     dx[i + stride] = one(g1, x1, y1);
   }
-  if (i < n4) dx[i] = one(dy[i], x[i], has_act ? y[i] : ones);
+  if (i < n4) dx[i] = one(dy[i], x[i], (has_act && !premask) ? y[i] : ones);
 }
 
 bool fast_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
@@ -435,11 +452,12 @@ extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const f
   return launch_status("bn_apply_act_kernel");
 }
 
-extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
-                              const float* invstd, const float* gamma, int act, float slope, float dy_scale, float* dx,
-                              float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
-                              pcg_stream_t stream) {
-  PCG_REQUIRE(dy && x && (y || act == PCG_ACT_NONE) && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
+static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx,
+                           float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
+  PCG_REQUIRE(y || act == PCG_ACT_NONE || (gamma && beta && (act == PCG_ACT_RELU || act == PCG_ACT_LRELU)),
+              "pcg_bn_act_bwd: without y the activation must be ReLU / LeakyReLU and gamma, beta must be given");
   if (!workspace || workspace_bytes < pcg_bn_workspace_bytes(rows, C)) {
     set_error("pcg_bn_act_bwd: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_workspace_bytes(rows, C));
     return PCG_ERR_WORKSPACE;
@@ -449,7 +467,7 @@ extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, i
   const ColPlan cp = plan_cols(rows, C, aligned);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)cp.nblocks * 2 * C;
-  FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale};
+  FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
@@ -461,14 +479,31 @@ extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, i
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
-                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx));
+                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx), gamma, beta);
   } else if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
-                       (const float*)coef, act, slope, dy_scale, dx);
+                       (const float*)coef, act, slope, dy_scale, dx, gamma, beta);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
-                       (const float*)coef, act, slope, dy_scale, dx);
+                       (const float*)coef, act, slope, dy_scale, dx, gamma, beta);
   return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
+                              const float* invstd, const float* gamma, int act, float slope, float dy_scale, float* dx,
+                              float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                              pcg_stream_t stream) {
+  PCG_REQUIRE(y || act == PCG_ACT_NONE, "pcg_bn_act_bwd: y is required with an activation (or use pcg_bn_act_bwd_premask)");
+  return bn_act_bwd_impl(dy, x, y, rows, C, mean, invstd, gamma, nullptr, act, slope, dy_scale, dx, dgamma, dbeta, accumulate, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx,
+                                      float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                                      pcg_stream_t stream) {
+  return bn_act_bwd_impl(dy, x, nullptr, rows, C, mean, invstd, gamma, beta, act, slope, dy_scale, dx, dgamma, dbeta, accumulate, workspace,
+                         workspace_bytes, stream);
 }
 
 extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate, void* workspace,

@@ -342,7 +342,9 @@ class SequentialConvNet(FlatModule):
                     db, acc2 = self._grad_view(bn.bias)
                     if acc != acc2:
                         raise PcgError("inconsistent .grad state on BatchNorm weight/bias")
-                dz = ops.bn_act_bwd(d, z, y, C, mean, invstd, bn.weight.data, b.act, b.slope, dg, db, acc)
+                # ReLU / LeakyReLU: the mask is recomputed from z (no read of y)
+                dz = ops.bn_act_bwd(d, z, None if b.act in (ACT_RELU, ACT_LRELU) else y, C, mean, invstd, bn.weight.data, b.act, b.slope, dg,
+                                    db, acc, beta=bn.bias.data)
             elif b.act != ACT_NONE:
                 dz = ops.act_bwd(d, y, b.act, b.slope, out=d if own else None)
             else:

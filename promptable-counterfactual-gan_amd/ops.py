@@ -208,7 +208,9 @@ def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps
     return y
 
 
-def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None, dy_scale=1.0):
+def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None, dy_scale=1.0, beta=None):
+    """BatchNorm(train) + activation backward.  y=None with ReLU / LeakyReLU and `beta` given: the mask is recomputed from x
+    (pcg_bn_act_bwd_premask) instead of read from the saved activation."""
     _chk(dy, "dy"); _chk(x, "x")
     if y is not None:
         _chk(y, "y")
@@ -216,6 +218,12 @@ def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accu
     dx = out if out is not None else torch.empty_like(x)
     lib = _lib.load()
     ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
+    if y is None and act in (ACT_RELU, ACT_LRELU):
+        if beta is None:
+            raise _lib.PcgError("bn_act_bwd: pass y, or beta to recompute the activation mask")
+        check(lib.pcg_bn_act_bwd_premask(_p(dy), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), act, slope, dy_scale, _p(dx),
+                                         _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_act_bwd_premask")
+        return dx
     check(lib.pcg_bn_act_bwd(_p(dy), _p(x), _p(y), rows, C, _p(mean), _p(invstd), _p(gamma), act, slope, dy_scale, _p(dx), _p(dgamma),
                              _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_act_bwd")
     return dx
