@@ -197,3 +197,58 @@ def test_module_surface(pcg):
     # same weights + same running stats -> same output (running stats were updated once by the first forward)
     netG.load_state_dict(sd)
     assert torch.equal(net2(z), netG(z))
+
+
+# ---- BASELINE size (batch 512, width 64): size-independent properties instead of an oracle run ------------------------------------
+FULL_LAYERS = [  # (Cin, Cout, H, k, s, p) of the (adjoint) convolutions of the DCGAN-64 step at batch 512
+    (1, 64, 64, 4, 2, 1), (64, 128, 32, 4, 2, 1), (128, 256, 16, 4, 2, 1), (256, 512, 8, 4, 2, 1), (512, 1, 4, 4, 1, 0),
+    (8192, 100, 1, 1, 1, 0)]                                             # last: G's first ConvTranspose as the plain GEMM it runs as
+
+
+@pytest.mark.parametrize("Cin,Cout,H,k,s,p", FULL_LAYERS)
+def test_full_size_adjoint_identities(pcg, Cin, Cout, H, k, s, p):
+    """At the bench's shapes the three kernels of a layer must be each other's adjoints / derivatives:
+        <dy, conv(x; w)> = <dgrad(dy; w), x> = <wgrad(x, dy), w>          (bias-free, fp32: 2e-4 relative to sqrt(sum of squares))
+    and conv is linear in x.  No oracle is involved, so this runs at batch 512."""
+    ops = pcg.ops
+    B = 512
+    g = ops.conv_geom(B, H, H, Cin, Cout, k, k, s, p)
+    gen = torch.Generator(device=DEV).manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, H, H, Cin, device=DEV, generator=gen)
+    x2 = torch.randn(B, H, H, Cin, device=DEV, generator=gen)
+    w = torch.randn(Cout, k, k, Cin, device=DEV, generator=gen) / float(np.sqrt(Cin * k * k))
+    dy = torch.randn(B, g.OH, g.OW, Cout, device=DEV, generator=gen)
+    y = ops.conv2d_fwd(g, x, w)
+    dx = ops.conv2d_dgrad(g, dy, w)
+    dw = torch.empty_like(w)
+    ops.conv2d_wgrad(g, x, dy, dw, False)
+    a = float((dy.double() * y.double()).sum())
+    b = float((dx.double() * x.double()).sum())
+    c = float((dw.double() * w.double()).sum())
+    scale = float(np.sqrt(float((dy.double() ** 2).sum()) * float((y.double() ** 2).sum())))
+    assert abs(a - b) <= 2e-4 * scale and abs(a - c) <= 2e-4 * scale, (a, b, c, scale)
+    y12 = ops.conv2d_fwd(g, ops.axpby(0.5, x, -1.5, x2), w)
+    lin = ops.axpby(0.5, y, -1.5, ops.conv2d_fwd(g, x2, w))
+    assert float((y12 - lin).abs().max()) <= 2e-5 * float(lin.abs().max()) + 1e-5
+
+
+def test_full_size_step_is_deterministic_and_dp_ready(pcg):
+    """Batch 512, reference widths: two steps from identical state and inputs give bit-identical losses, parameters, BatchNorm
+    buffers and Adam state (fixed summation orders everywhere) — what data-parallel replicas rely on to stay in lockstep."""
+    D = pcg.dcgan
+    real = torch.rand(512, 1, 64, 64, device=DEV) * 2 - 1
+    noise = torch.randn(512, 100, 1, 1, device=DEV)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        netG, netD = D.Generator().to(DEV), D.Discriminator().to(DEV)
+        netG.apply(D.weights_init); netD.apply(D.weights_init)
+        crit, optD, optG = D.make_optimizers(netG, netD)
+        for _s in range(2):
+            o = D.train_step(netG, netD, crit, optD, optG, real, noise)
+        outs.append(([o[k].item() for k in ("errD_real", "errD_fake", "errG")],
+                     {**{f"G.{k}": v.clone() for k, v in netG.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in netD.state_dict().items()}}))
+        assert all(np.isfinite(v) for v in outs[-1][0])
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
