@@ -409,6 +409,13 @@ typedef struct pcg_house_g_bwd_args {
 int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_fwd_args* args, pcg_stream_t stream);
 int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_bwd_args* args, pcg_stream_t stream);
 
+/* Loss composition on the device: total = sum_i w_i * term_i for up to 8 one-element loss tensors, e.g.
+ * G_loss = G_adv + lambda_cls*G_cls + lambda_reg*G_reg + lambda_mask*mask_pen (house_sales_kc_usa/trainer.py:307-312); the backward
+ * hands every term its w_i * grad_out.  One launch each instead of a dozen scalar tensor-op kernels. */
+int pcg_weighted_sum_fwd(int32_t n, const float* const* terms, const float* weights, float* out, pcg_stream_t stream);
+int pcg_weighted_sum_bwd(int32_t n, const float* weights, const float* grad_out_dev /*nullable = 1*/, float* const* grads /*entries nullable*/,
+                         pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

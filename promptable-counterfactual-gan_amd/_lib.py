@@ -131,6 +131,8 @@ PROTOTYPES = {
     "pcg_resize8_normalize": (_i, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _vp]),
     "pcg_house_g_fwd": (_i, [_c.POINTER(HouseGDesc), _c.POINTER(HouseGFwdArgs), _vp]),
     "pcg_house_g_bwd": (_i, [_c.POINTER(HouseGDesc), _c.POINTER(HouseGBwdArgs), _vp]),
+    "pcg_weighted_sum_fwd": (_i, [_i32, _vp, _vp, _vp, _vp]),
+    "pcg_weighted_sum_bwd": (_i, [_i32, _vp, _vp, _vp, _vp]),
     "pcg_cf_metrics": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pcg_gemm": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _vp]),
     "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -403,3 +403,37 @@ extern "C" int pcg_dropout_apply(const float* x, const float* mask, int64_t n, i
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(ew_blocks((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, mask, (size_t)n, inner, C, scale, y);
   return launch_status("dropout_apply_kernel");
 }
+
+namespace pcg { namespace {
+constexpr int WS_MAX = 8;
+struct WsTerms { const float* v[WS_MAX]; float w[WS_MAX]; float* g[WS_MAX]; int n; };
+// total = sum_i w_i * v_i[0] (scalar losses); backward: g_i[0] = w_i * grad_out[0]
+__global__ void weighted_sum_fwd_kernel(WsTerms t, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < t.n; ++i) s = fmaf(t.w[i], t.v[i][0], s);
+    out[0] = s;
+  }
+}
+__global__ void weighted_sum_bwd_kernel(WsTerms t, const float* __restrict__ grad_out) {
+  if ((int)threadIdx.x < t.n && blockIdx.x == 0 && t.g[threadIdx.x]) t.g[threadIdx.x][0] = t.w[threadIdx.x] * (grad_out ? grad_out[0] : 1.f);
+}
+} }
+
+extern "C" int pcg_weighted_sum_fwd(int32_t n, const float* const* terms, const float* weights, float* out, pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && n <= WS_MAX && terms && weights && out, "pcg_weighted_sum_fwd: bad arguments (at most %d terms)", WS_MAX);
+  WsTerms t{};
+  t.n = n;
+  for (int i = 0; i < n; ++i) { PCG_REQUIRE(terms[i], "pcg_weighted_sum_fwd: null term %d", i); t.v[i] = terms[i]; t.w[i] = weights[i]; }
+  hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, out);
+  return launch_status("weighted_sum_fwd_kernel");
+}
+
+extern "C" int pcg_weighted_sum_bwd(int32_t n, const float* weights, const float* grad_out_dev, float* const* grads, pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && n <= WS_MAX && weights && grads, "pcg_weighted_sum_bwd: bad arguments");
+  WsTerms t{};
+  t.n = n;
+  for (int i = 0; i < n; ++i) { t.w[i] = weights[i]; t.g[i] = grads[i]; }
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, grad_out_dev);
+  return launch_status("weighted_sum_bwd_kernel");
+}

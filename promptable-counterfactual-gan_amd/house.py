@@ -23,7 +23,7 @@ from torch.nn.utils import spectral_norm
 from . import ops
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
 from .countergan import CrossEntropyLoss, abs_mean, grad_norm  # noqa: F401  (same loss kernels)
-from .nn import FlatModule, affine_fwd, linear_dgrad as _lin_dgrad, linear_fwd as _lin_fwd, linear_wgrad as _lin_wgrad, mean  # noqa: F401
+from .nn import FlatModule, affine_fwd, linear_dgrad as _lin_dgrad, linear_fwd as _lin_fwd, linear_wgrad as _lin_wgrad, mean, weighted_sum  # noqa: F401
 from .optim import Adam
 
 FEATURES = ["bedrooms", "bathrooms", "sqft_living", "sqft_lot", "floors", "waterfront", "view", "condition", "grade",
@@ -681,7 +681,7 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     # ---- D step
     d_real = discriminator(x, ops.onehot(y, nc))                                              # :290
     d_fake = discriminator(x_cf.detach(), target_onehot)                                      # :291
-    d_loss = mean(d_fake) - mean(d_real)                                                      # :292
+    d_loss = weighted_sum([mean(d_fake), mean(d_real)], [1.0, -1.0])                          # :292
     opt_d.zero_grad()
     d_loss.backward()
     opt_d.step()                                                                              # :293-295
@@ -691,10 +691,15 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
             p.requires_grad_(False)
     try:
         d_fake_for_g = discriminator(x_cf, target_onehot)                                     # :298
-        g_adv = -mean(d_fake_for_g)                                                           # :299
+        m_fake = mean(d_fake_for_g)
         g_cls = ce(classifier(x_cf), target_y)                                                # :301-302
-        g_reg = abs_mean(masked_residual) * float(x.shape[1])                                 # :305  mean_b ||.||_1 = D * mean|.|
-        g_loss = g_adv + config["lambda_cls"] * g_cls + config["lambda_reg"] * g_reg + config["lambda_mask"] * mask_penalty_pre
+        am = abs_mean(masked_residual)                                                        # :305  mean_b ||.||_1 = D * mean|.|
+        d_feat = float(x.shape[1])
+        g_loss = weighted_sum([m_fake, g_cls, am, mask_penalty_pre],
+                              [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]])   # :299, :307-312
+        with torch.no_grad():                                                                 # logged values
+            g_adv = weighted_sum([m_fake], [-1.0])
+            g_reg = weighted_sum([am], [d_feat])
         opt_g.zero_grad()
         g_loss.backward()                                                                     # :314-315
     finally:

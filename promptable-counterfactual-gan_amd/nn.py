@@ -467,6 +467,24 @@ def mean(x):
     return _MeanFn.apply(x)
 
 
+class _WeightedSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights, ctx.shapes = weights, [t.shape for t in terms]
+        return ops.weighted_sum_fwd([t.contiguous() for t in terms], weights).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ops.weighted_sum_bwd(ctx.weights, g.contiguous(), ctx.needs_input_grad[1:])
+        return (None,) + tuple(t.view(s) if t is not None else None for t, s in zip(gs, ctx.shapes))
+
+
+def weighted_sum(terms, weights):
+    """sum_i weights[i] * terms[i] for one-element loss tensors — the loss compositions of the training loops
+    (d_loss = -D_real.mean() + D_fake.mean(); G_loss = G_adv + lambda_cls G_cls + ...) as one launch forward and one backward."""
+    return _WeightedSumFn.apply(tuple(float(w) for w in weights), *terms)
+
+
 class BCELoss(nn.Module):
     """nn.BCELoss() (reduction='mean') on the HIP kernel (mnist_dcgan.py:125)."""
 

@@ -613,6 +613,25 @@ def dropout_apply(x, mask, p, inner=1, C=None, out=None):
     return y
 
 
+def weighted_sum_fwd(terms, weights):
+    n = len(terms)
+    out = torch.empty(1, dtype=torch.float32, device=terms[0].device)
+    check(_lib.load().pcg_weighted_sum_fwd(n, _ptr_array(terms), (ctypes.c_float * n)(*[float(w) for w in weights]), _p(out), _stream()),
+          "pcg_weighted_sum_fwd")
+    return out
+
+
+def weighted_sum_bwd(weights, grad_out, needs):
+    """[w_i * grad_out as a one-element tensor, or None where needs[i] is False]"""
+    n = len(weights)
+    dev = grad_out.device
+    outs = [torch.empty(1, dtype=torch.float32, device=dev) if need else None for need in needs]
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() if o is not None else None for o in outs])
+    check(_lib.load().pcg_weighted_sum_bwd(n, (ctypes.c_float * n)(*[float(w) for w in weights]), _p(grad_out), ptrs, _stream()),
+          "pcg_weighted_sum_bwd")
+    return outs
+
+
 def cf_metrics(logits_cf, target, logits_ref=None, other=None):
     """[class-flip rate, prediction gain] as a 2-element device tensor (see pcg_cf_metrics)."""
     _chk(logits_cf, "logits_cf"); _chk_idx(target, logits_cf.shape[1], "target")
