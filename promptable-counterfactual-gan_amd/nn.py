@@ -485,6 +485,48 @@ def weighted_sum(terms, weights):
     return _WeightedSumFn.apply(tuple(float(w) for w in weights), *terms)
 
 
+class GraphedStep:
+    """A whole training step captured once in a HIP graph and replayed with one host call — for the configurations whose step is
+    too short for the host to keep the GPU fed kernel by kernel (small per-GPU batches, the tabular nets).
+
+        gs = GraphedStep(lambda: train_step(G, D, ..., x, y, ...), inputs={"x": x, "y": y, ...}, modules=[G, D], optimizers=[opt_g, opt_d])
+        gs.load(x=next_x, y=next_y, ...); out = gs.replay()
+
+    `inputs` are the static device tensors the step closes over (load() copies new values into them); `out` is whatever the step
+    returned (static tensors too).  Capture needs warm-up executions of real steps: parameters, buffers and optimizer state of the
+    given modules / optimizers are snapshotted before and restored after, so building the object does not advance training."""
+
+    def __init__(self, step_fn, inputs, modules, optimizers, warmup=3):
+        self.inputs = dict(inputs)
+        for m in modules:
+            m._ensure_flat()
+        saved = [(m.flat_params.clone(), [b.clone() for b in m.buffers()]) for m in modules]
+        osnap = [o.snapshot() for o in optimizers]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn()
+        for m, (fp, bufs) in zip(modules, saved):
+            m.flat_params.copy_(fp)
+            for b, b0 in zip(m.buffers(), bufs):
+                b.copy_(b0)
+        for o, sn in zip(optimizers, osnap):
+            o.restore(sn)
+
+    def load(self, **tensors):
+        for k, v in tensors.items():
+            self.inputs[k].copy_(v)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 class BCELoss(nn.Module):
     """nn.BCELoss() (reduction='mean') on the HIP kernel (mnist_dcgan.py:125)."""
 

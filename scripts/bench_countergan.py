@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph (pcgan_amd.nn.GraphedStep)")
 args = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -24,6 +25,14 @@ batches = [tuple(t.to(dev) for t in CR.synthetic_batch(args.batch, seed=s)) for 
 def step(i):
     x, y, t, m = batches[i % 2]
     return K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
+if args.graph:
+    from pcgan_amd.nn import GraphedStep
+    x, y, t, m = (b.clone() for b in batches[0])
+    gs = GraphedStep(lambda: K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m), {"x": x, "y": y, "t": t, "m": m}, [G, D], [opt_g, opt_d])
+    def step(i):
+        bx, by, bt, bm = batches[i % 2]
+        gs.load(x=bx, y=by, t=bt, m=bm)
+        return gs.replay()
 for i in range(args.warmup):
     out = step(i)
 torch.cuda.synchronize()
