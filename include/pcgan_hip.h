@@ -250,13 +250,15 @@ size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t I);
 int32_t pcg_linear_wgrad_ticket_count(void);
 int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW, float* db,
                      int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets, pcg_stream_t stream);
-/* The same for up to 40 small layers (O <= 64, I <= 63: one output tile each) that reduce over the SAME B rows, in one launch —
- * the 35 Linear layers of the tabular generator's backward.  tickets: int32[>= n_items], zero before first use. */
+/* The same for up to 40 items that reduce over the SAME B rows, in one launch — the 35 Linear layers of the tabular generator's
+ * backward.  An item is ONE 64x64 output tile (tile_x over the I + 1 columns incl. the bias column, tile_y over the O rows) of a
+ * layer: small layers are a single item (tile 0, 0); a 128x64 layer is four.  tickets: int32[>= n_items], zero before first use. */
 typedef struct pcg_wgrad_item {
   const float* dy; const float* x; float* dW; float* db /*nullable*/;
-  int32_t ldy, ldx, O, I, accumulate_w, accumulate_b;
+  int32_t ldy, ldx, O, I, accumulate_w, accumulate_b, tile_x, tile_y;
 } pcg_wgrad_item;
-size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, int32_t n_items);
+int32_t pcg_linear_wgrad_grouped_slabs(int32_t B);
+size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, const pcg_wgrad_item* items, int32_t n_items);
 int pcg_linear_wgrad_grouped(const pcg_wgrad_item* items, int32_t n_items, int32_t B, void* workspace, size_t workspace_bytes,
                              int32_t* tickets, pcg_stream_t stream);
 /* F.one_hot(idx, K).float() — trainer.py:250,290 */
@@ -415,6 +417,16 @@ int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_bwd_args* ar
 int pcg_weighted_sum_fwd(int32_t n, const float* const* terms, const float* weights, float* out, pcg_stream_t stream);
 int pcg_weighted_sum_bwd(int32_t n, const float* weights, const float* grad_out_dev /*nullable = 1*/, float* const* grads /*entries nullable*/,
                          pcg_stream_t stream);
+
+/* The tabular spectral-norm critic (house_sales_kc_usa/models/discriminator.py:5-20) as one forward and one backward launch, one
+ * thread per row; w_bar[l] / bias[l]: the four layers' normalised weights (from pcg_spectral_norm_fwd_batched) and biases.
+ * Forward writes the concatenated input a0 [B][21] and the post-LeakyReLU activations a1 [B][32], a2 [B][64], a3 [B][128];
+ * backward writes the pre-activation gradients d3, d2, d1 (the dy operands of the weight gradients; layer 4's is dout itself)
+ * and, if dx != NULL, the gradient of the first D input columns.  Built for input_dim + num_classes = 21, hidden width 32. */
+int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t B, int32_t D, int32_t NC, const float* const* w_bar,
+                         const float* const* bias, float slope, float* a0, float* a1, float* a2, float* a3, float* out, pcg_stream_t stream);
+int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* const* w_bar, float slope, const float* a1, const float* a2,
+                         const float* a3, float* d3, float* d2, float* d1, float* dx /*nullable*/, pcg_stream_t stream);
 
 #ifdef __cplusplus
 }

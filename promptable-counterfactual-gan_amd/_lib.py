@@ -44,7 +44,8 @@ class HouseGDesc(ctypes.Structure):
 
 class WgradItem(ctypes.Structure):
     """pcg_wgrad_item."""
-    _fields_ = [("dy", _P), ("x", _P), ("dW", _P), ("db", _P)] + [(n, _I) for n in ("ldy", "ldx", "O", "I", "accumulate_w", "accumulate_b")]
+    _fields_ = [("dy", _P), ("x", _P), ("dW", _P), ("db", _P)] + [(n, _I) for n in ("ldy", "ldx", "O", "I", "accumulate_w", "accumulate_b",
+                                                                                      "tile_x", "tile_y")]
 
 
 class HouseGFwdArgs(ctypes.Structure):
@@ -138,7 +139,10 @@ PROTOTYPES = {
     "pcg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pcg_linear_wgrad_ticket_count": (_i32, []),
     "pcg_linear_wgrad": (_i, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i, _i, _vp, _sz, _vp, _vp]),
-    "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _i32]),
+    "pcg_linear_wgrad_grouped_slabs": (_i32, [_i32]),
+    "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _c.POINTER(WgradItem), _i32]),
+    "pcg_house_critic_fwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_house_critic_bwd": (_i, [_vp, _i32, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_linear_wgrad_grouped": (_i, [_c.POINTER(WgradItem), _i32, _i32, _vp, _sz, _vp, _vp]),
     "pcg_gemm_act": (_i, [_i, _i, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i, _i, _f, _vp]),
     "pcg_spectral_norm_fwd_batched": (_i, [_i32, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),

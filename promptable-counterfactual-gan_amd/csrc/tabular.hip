@@ -201,13 +201,13 @@ constexpr int WG_MAX_ITEMS = 40;
 struct WgradGroup {
   const float* dy[WG_MAX_ITEMS]; const float* x[WG_MAX_ITEMS]; float* dW[WG_MAX_ITEMS]; float* db[WG_MAX_ITEMS];
   int ldy[WG_MAX_ITEMS], ldx[WG_MAX_ITEMS], O[WG_MAX_ITEMS], I[WG_MAX_ITEMS], poff[WG_MAX_ITEMS];
-  unsigned char accW[WG_MAX_ITEMS], accB[WG_MAX_ITEMS];
+  unsigned char accW[WG_MAX_ITEMS], accB[WG_MAX_ITEMS], tx[WG_MAX_ITEMS], ty[WG_MAX_ITEMS];
 };
 __global__ void __launch_bounds__(256) linear_wgrad_grouped_kernel(WgradGroup g, int B, int S, int chunk, float* __restrict__ partial,
                                                                    int* __restrict__ tickets) {
   const int it = blockIdx.y;
   linear_wgrad_body(g.dy[it], g.ldy[it], g.x[it], g.ldx[it], B, g.O[it], g.I[it], g.dW[it], g.db[it], g.accW[it], g.accB[it], S, chunk,
-                    partial + g.poff[it], tickets + it, 0, 0, blockIdx.x);
+                    partial + g.poff[it], tickets + it, g.tx[it], g.ty[it], blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
@@ -525,26 +525,35 @@ extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, in
   return launch_status("linear_wgrad_kernel");
 }
 
-extern "C" size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, int32_t n_items) {
-  if (B <= 0 || n_items <= 0) return 0;
-  const WgradPlan p = plan_linear_wgrad(B, 32, 32);      // single-tile plan: S depends on B only
-  return (size_t)n_items * p.S * GT * GT * sizeof(float);
+extern "C" int32_t pcg_linear_wgrad_grouped_slabs(int32_t B) { return B > 0 ? plan_linear_wgrad(B, 32, 32).S : 0; }   // single-tile plan: depends on B only
+
+extern "C" size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, const pcg_wgrad_item* items, int32_t n_items) {
+  if (B <= 0 || n_items <= 0 || !items) return 0;
+  const WgradPlan p = plan_linear_wgrad(B, 32, 32);
+  size_t total = 0;
+  for (int i = 0; i < n_items; ++i) total += (size_t)p.S * items[i].O * (items[i].I + 1);
+  return total * sizeof(float);
 }
 
 extern "C" int pcg_linear_wgrad_grouped(const pcg_wgrad_item* items, int32_t n_items, int32_t B, void* workspace, size_t workspace_bytes,
                                         int32_t* tickets, pcg_stream_t stream) {
   PCG_REQUIRE(items && n_items > 0 && n_items <= WG_MAX_ITEMS && B > 0 && tickets, "pcg_linear_wgrad_grouped: bad arguments (at most %d items)", WG_MAX_ITEMS);
   const WgradPlan p = plan_linear_wgrad(B, 32, 32);
-  if (!workspace || workspace_bytes < pcg_linear_wgrad_grouped_workspace_bytes(B, n_items)) {
+  if (!workspace || workspace_bytes < pcg_linear_wgrad_grouped_workspace_bytes(B, items, n_items)) {
     set_error("pcg_linear_wgrad_grouped: workspace too small"); return PCG_ERR_WORKSPACE;
   }
   WgradGroup g{};
+  size_t off = 0;
   for (int i = 0; i < n_items; ++i) {
     const pcg_wgrad_item& it = items[i];
-    PCG_REQUIRE(it.dy && it.x && it.dW && it.O > 0 && it.O <= GT && it.I > 0 && it.I + 1 <= GT && it.ldy >= it.O && it.ldx >= it.I,
-                "pcg_linear_wgrad_grouped: item %d: a layer must fit one 64x64 tile (O <= 64, I <= 63)", i);
+    PCG_REQUIRE(it.dy && it.x && it.dW && it.O > 0 && it.I > 0 && it.ldy >= it.O && it.ldx >= it.I && it.tile_x >= 0 && it.tile_y >= 0 &&
+                    it.tile_x * GT <= it.I && it.tile_y * GT < it.O && it.tile_x < 256 && it.tile_y < 256,
+                "pcg_linear_wgrad_grouped: item %d: bad layer / tile", i);
     g.dy[i] = it.dy; g.x[i] = it.x; g.dW[i] = it.dW; g.db[i] = it.db; g.ldy[i] = it.ldy; g.ldx[i] = it.ldx; g.O[i] = it.O; g.I[i] = it.I;
-    g.accW[i] = it.accumulate_w != 0; g.accB[i] = it.accumulate_b != 0; g.poff[i] = i * p.S * GT * GT;
+    g.accW[i] = it.accumulate_w != 0; g.accB[i] = it.accumulate_b != 0; g.tx[i] = (unsigned char)it.tile_x; g.ty[i] = (unsigned char)it.tile_y;
+    PCG_REQUIRE(off < (1u << 30), "pcg_linear_wgrad_grouped: workspace offset overflow");
+    g.poff[i] = (int)off;
+    off += (size_t)p.S * it.O * (it.I + 1);
   }
   hipLaunchKernelGGL(linear_wgrad_grouped_kernel, dim3(p.S, n_items), dim3(256), 0, (hipStream_t)stream, g, B, p.S, p.chunk,
                      (float*)workspace, tickets);

@@ -454,12 +454,31 @@ class Discriminator(FlatModule):
             return _DFn.apply(self, x, target_onehot, *self.parameters())
         return self._run_forward(x, target_onehot, keep=False)[0]
 
+    def _fused_ok(self, x, target_onehot):
+        lins = self._linears()
+        return (getattr(self, "use_fused", True) and [l.out_features for l in lins] == [32, 64, 128, 1] and lins[0].in_features == 21
+                and x.shape[1] + target_onehot.shape[1] == 21)
+
     def _run_forward(self, x, target_onehot, keep=True):
-        a = ops.concat_cols(x.contiguous(), target_onehot.contiguous())                       # :19
         lins = self._linears()
         # power iteration + W / sigma of all four layers: one launch
         sn = ops.spectral_norm_fwd_batched([l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins],
                                            1e-12, self.training)
+        if self._fused_ok(x, target_onehot):
+            # the four layers as ONE launch, one thread per row (csrc/house_critic_fused.hip)
+            import ctypes
+            from ._lib import load
+            x, target_onehot = x.contiguous(), target_onehot.contiguous()
+            B = x.shape[0]
+            f32 = dict(dtype=torch.float32, device=x.device)
+            acts = [torch.empty((B, n), **f32) for n in (21, 32, 64, 128)]
+            out = torch.empty((B, 1), **f32)
+            wb = [t[0] for t in sn]
+            ops.check(load().pcg_house_critic_fwd(ops._p(x), ops._p(target_onehot), B, x.shape[1], target_onehot.shape[1], ops._ptr_array(wb),
+                                                  ops._ptr_array([l.bias.data for l in lins]), 0.2, ops._p(acts[0]), ops._p(acts[1]),
+                                                  ops._p(acts[2]), ops._p(acts[3]), ops._p(out), ops._stream()), "pcg_house_critic_fwd")
+            return out, (("fused", acts, sn) if keep else None)
+        a = ops.concat_cols(x.contiguous(), target_onehot.contiguous())                       # :19
         layers = []
         for i, lin in enumerate(lins):
             w_bar, sigma, u, v = sn[i]
@@ -469,7 +488,33 @@ class Discriminator(FlatModule):
             a = z
         return a, (layers if keep else None)
 
+    def _fused_backward(self, saved, dout, need_x, need_p):
+        from ._lib import load
+        _, acts, sn = saved
+        lins = self._linears()
+        d4 = dout.contiguous()
+        B = d4.shape[0]
+        f32 = dict(dtype=torch.float32, device=d4.device)
+        d3, d2, d1 = (torch.empty((B, n), **f32) for n in (128, 64, 32))
+        dx = torch.empty((B, self.input_dim), **f32) if need_x else None
+        ops.check(load().pcg_house_critic_bwd(ops._p(d4), B, self.input_dim, ops._ptr_array([t[0] for t in sn]), 0.2, ops._p(acts[1]),
+                                              ops._p(acts[2]), ops._p(acts[3]), ops._p(d3), ops._p(d2), ops._p(d1), ops._p(dx),
+                                              ops._stream()), "pcg_house_critic_bwd")
+        if need_p and lins[0].weight_orig.requires_grad:
+            items, sn_items = [], []
+            for lin, a, d, (w_bar, sigma, u, v) in zip(lins, acts, (d1, d2, d3, d4), sn):
+                dwb = torch.empty_like(w_bar)
+                gb, accb = self._grad_view(lin.bias)
+                items.append((d, a, lin.out_features, lin.in_features, dwb, gb, lin.out_features, lin.in_features, False, accb))
+                gw, acc = self._grad_view(lin.weight_orig)
+                sn_items.append((dwb, w_bar, u, v, sigma, gw, acc))
+            ops.linear_wgrad_grouped(items, B, d4.device)                                    # all weight + bias gradients: one launch
+            ops.spectral_norm_bwd_batched(sn_items)                                          # through W / sigma: one launch
+        return dx
+
     def _run_backward(self, layers, dout, need_x, need_p):
+        if layers[0] == "fused":
+            return self._fused_backward(layers, dout, need_x, need_p)
         lins = self._linears()
         d = dout.contiguous()
         B = d.shape[0]

@@ -436,21 +436,28 @@ def linear_wgrad(dy, x, B, O, I, dW, db=None, ldy=None, ldx=None, accumulate_w=F
 
 
 def linear_wgrad_grouped(items, B, device):
-    """items: list of (dy, x, O, I, dW, db or None, ldy, ldx, accumulate_w, accumulate_b) — small layers (one 64x64 tile each) that
-    reduce over the same B rows, all in one launch."""
+    """items: list of (dy, x, O, I, dW, db or None, ldy, ldx, accumulate_w, accumulate_b) — layers that reduce over the same B rows,
+    all in one launch; a layer wider than one 64x64 tile is expanded into one item per tile."""
     lib = _lib.load()
-    n = len(items)
+    tiles = []
+    for it in items:
+        O, I = it[2], it[3]
+        for ty in range((O + 63) // 64):
+            for tx in range((I + 1 + 63) // 64):
+                tiles.append(it + (tx, ty))
+    n = len(tiles)
     arr = (_lib.WgradItem * n)()
-    for k, (dy, x, O, I, dW, db, ldy, ldx, aw, ab) in enumerate(items):
+    for k, (dy, x, O, I, dW, db, ldy, ldx, aw, ab, tx, ty) in enumerate(tiles):
         arr[k].dy, arr[k].x, arr[k].dW, arr[k].db = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else None)
         arr[k].ldy, arr[k].ldx, arr[k].O, arr[k].I = ldy, ldx, O, I
         arr[k].accumulate_w, arr[k].accumulate_b = int(bool(aw)), int(bool(ab))
+        arr[k].tile_x, arr[k].tile_y = tx, ty
     key = (device.type, device.index)
     tk = _tickets.get(key)
     if tk is None:
         tk = torch.zeros(lib.pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=device)
         _tickets[key] = tk
-    nbytes = lib.pcg_linear_wgrad_grouped_workspace_bytes(B, n)
+    nbytes = lib.pcg_linear_wgrad_grouped_workspace_bytes(B, arr, n)
     ws = workspace2(nbytes, device)
     check(lib.pcg_linear_wgrad_grouped(arr, n, B, _p(ws), nbytes, _p(tk), _stream()), "pcg_linear_wgrad_grouped")
 

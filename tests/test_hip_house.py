@@ -346,6 +346,30 @@ def test_fused_generator_kernels_match_the_op_chain(pcg, hgold):
         _close(res[0][4][n], res[1][4][n], 1e-5, 1e-6, f"buffer {n}")
 
 
+def test_fused_critic_kernels_match_the_op_chain(pcg, hgold):
+    """csrc/house_critic_fused.hip (one forward + one backward launch, one thread per row; weight gradients through the grouped
+    reduction, a 128x64 layer as four tiles) against the per-op path: output, input gradient, every parameter gradient and the
+    power-iteration buffers."""
+    H = pcg.house
+    x, y, t, m, _ = HR.synthetic_batch(300, seed=6)
+    res = []
+    for fused in (True, False):
+        _, D, _ = _load_golden_nets(pcg, hgold)
+        D.use_fused = fused
+        xi = _dev(x).requires_grad_(True)
+        out = D(xi, pcg.ops.onehot(_dev(t), 4))
+        g = torch.Generator().manual_seed(2)
+        out.backward(_dev(torch.randn(out.shape, generator=g)))
+        res.append((out.detach(), xi.grad.clone(), {n: p.grad.clone() for n, p in D.named_parameters()}, {n: b.clone() for n, b in D.named_buffers()}))
+    _close(res[0][0], res[1][0], 2e-5, 2e-6)
+    _close(res[0][1], res[1][1], 1e-4, 2e-5 * float(res[1][1].abs().max()))
+    scale = max(float(v.abs().max()) for v in res[1][2].values())
+    for n in res[0][2]:
+        _close(res[0][2][n], res[1][2][n], 1e-4, 2e-5 * float(res[1][2][n].abs().max()) + 2e-6 * scale, f"grad {n}")
+    for n in res[0][3]:
+        _close(res[0][3][n], res[1][3][n], 1e-6, 1e-7, f"buffer {n}")
+
+
 def test_graphed_step_equals_eager(pcg, hgold):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
     it (warm-up + capture) does not advance the training state."""
