@@ -11,7 +11,8 @@ throughout (v_mfma_f32_32x32x2_f32 for the contractions).  Rank 0 prints ONE JSO
 
 roofline: the dominant kernels are the fp32-MFMA implicit-GEMM convolutions (conv_{fwd,dgrad,wgrad}_kernel).  Every
 launch of that family inside the timed region is bracketed by HIP events on the launch stream; `achieved` =
-sum of algorithmic FLOPs (2*B*OH*OW*Cout*KH*KW*Cin per launch) / sum of event-measured durations (every 4th timed step); `peak` = 157.3
+sum of algorithmic FLOPs (2*B*OH*OW*Cout*KH*KW*Cin per launch) / sum of event-measured durations (the timed steps that run
+eagerly: every --event-every-th; the others replay the captured HIP graph of the same step); `peak` = 157.3
 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `step_frac` = algorithmic FLOPs of the whole step (2.237 GFLOP/image,
 SURVEY.md §8d) / wall time / peak — the number the 50 % target is stated on.
 cpu_baseline: the oracle restatement of the reference loop (oracle/dcgan_ref.py, PyTorch CPU fp32) timed on the host
@@ -73,6 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL gradient-sync path even with one rank")
+    ap.add_argument("--eager", action="store_true", help="enqueue every step kernel by kernel instead of replaying the captured HIP graph(s)")
+    ap.add_argument("--event-every", type=int, default=8, help="every n-th timed step runs eagerly with HIP events around the conv launches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +100,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        dp = GradSync()
+        dp = GradSync(always_exchange=args.force_dp)
 
     # random-init weights of the reference architecture (weights_init distribution), identical on every rank
     torch.manual_seed(1)
@@ -114,8 +117,28 @@ def main():
     reals = [(torch.rand(args.batch, 1, 64, 64, generator=g) * 2 - 1).to(dev) for _ in range(nbatches)]
     noises = [torch.randn(args.batch, 100, 1, 1, generator=g).to(dev) for _ in range(nbatches)]
 
-    def step(i):
+    def eager_step(i):
         return D.train_step(netG, netD, crit, optD, optG, reals[i % nbatches], noises[i % nbatches], dp=dp)
+
+    # The step is captured once as HIP graph(s) and replayed (segments cut at the gradient exchanges when data-parallel): the
+    # kernels and their order are those of eager_step, the host issues 1-4 calls per step instead of ~130 launches, so a slow or
+    # shared host cannot starve the GPU.  The next batch is copied into the graph's static input buffers inside the timed region.
+    gs = None
+    if not args.eager:
+        from pcgan_amd.nn import GraphedStep
+        s_real, s_noise = reals[0].clone(), noises[0].clone()
+        if dp is None:
+            gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise), {"real": s_real, "noise": s_noise},
+                             [netG, netD], [optD, optG])
+        else:
+            gs = GraphedStep(lambda d: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, dp=d),
+                             {"real": s_real, "noise": s_noise}, [netG, netD], [optD, optG], dp=dp)
+
+    def step(i, eager=False):
+        if gs is None or eager:
+            return eager_step(i)
+        gs.load(real=reals[i % nbatches], noise=noises[i % nbatches])
+        return gs.replay()
 
     def barrier():
         if dp is not None:
@@ -127,17 +150,20 @@ def main():
         dp.wait_all()
     torch.cuda.synchronize()
 
-    # HIP events around every launch of the implicit-GEMM family, on a sample of the timed steps (every 4th): bracketing
-    # all ~35 launches of every step costs ~3 % of throughput (event packets between kernels), sampling keeps it < 1 %
+    # HIP events around every launch of the implicit-GEMM family, on a sample of the timed steps (those run eagerly; events
+    # cannot be read back from inside a graph): bracketing all ~35 launches costs ~3 % of a step, sampling keeps it < 1 %
     records = []
     hook = (lambda label, flops, t0, t1: records.append((label, flops, t0, t1))) if not args.no_kernel_events else None
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev = max(1, args.event_every)
+    sampled = [i for i in range(args.steps) if hook is not None and i % ev == ev // 2]
     for i in range(args.steps):
-        ops.set_conv_hook(hook if i % 4 == 0 else None)
-        out = step(args.warmup + i)
+        timed = i in sampled
+        ops.set_conv_hook(hook if timed else None)
+        out = step(args.warmup + i, eager=timed)
     host_enqueue = time.perf_counter() - t0      # the host is done issuing; the GPU is still working if this < elapsed
     if dp is not None:
         dp.wait_all()
@@ -175,7 +201,7 @@ def main():
             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
             "kernel": "fp32-MFMA implicit-GEMM conv family (igemm_mainloop: conv_fwd/dgrad/wgrad_kernel); wgrad spans include slab_reduce",
             "step_frac": round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "gemm_time_share": round(tot_t / (elapsed * len(range(0, args.steps, 4)) / args.steps), 4),
+            "gemm_time_share": round(tot_t / (elapsed * len(sampled) / args.steps), 4),
             "per_kernel": {k: {"launches": a[0], "avg_ms": round(a[2] / a[0] * 1e3, 4),
                                "tflops": round(a[1] / a[2] / 1e12, 2)} for k, a in sorted(agg.items())},
         }
@@ -195,6 +221,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+            "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",
         }
         print(json.dumps(line), flush=True)
     if dp is not None:

@@ -485,32 +485,70 @@ def weighted_sum(terms, weights):
     return _WeightedSumFn.apply(tuple(float(w) for w in weights), *terms)
 
 
+class _CutDP:
+    """Stands in for a `parallel.GradSync` while a step is being captured: every exchange point (wait / sync_now / sync_then) ends
+    the graph segment being captured, runs the real operation eagerly and starts the next segment.  RCCL collectives and the
+    cross-stream event waits therefore stay ordinary stream operations between graph launches."""
+
+    def __init__(self, dp, owner):
+        self._dp, self._owner = dp, owner
+
+    def wait(self, net):
+        self._owner._cut(lambda: self._dp.wait(net))
+
+    def sync_now(self, net):
+        self._owner._cut(lambda: self._dp.sync_now(net))
+
+    def sync_then(self, net, fn):
+        self._owner._cut(lambda: self._dp.sync_then(net, fn))
+
+    def wait_all(self):
+        self._owner._cut(self._dp.wait_all)
+
+
 class GraphedStep:
-    """A whole training step captured once in a HIP graph and replayed with one host call — for the configurations whose step is
-    too short for the host to keep the GPU fed kernel by kernel (small per-GPU batches, the tabular nets).
+    """A whole training step captured once in a HIP graph and replayed with one host call — the host then cannot starve the GPU,
+    whether the step is short (small per-GPU batches, the tabular nets) or the host cores are slow or shared.
 
         gs = GraphedStep(lambda: train_step(G, D, ..., x, y, ...), inputs={"x": x, "y": y, ...}, modules=[G, D], optimizers=[opt_g, opt_d])
         gs.load(x=next_x, y=next_y, ...); out = gs.replay()
 
     `inputs` are the static device tensors the step closes over (load() copies new values into them); `out` is whatever the step
     returned (static tensors too).  Capture needs warm-up executions of real steps: parameters, buffers and optimizer state of the
-    given modules / optimizers are snapshotted before and restored after, so building the object does not advance training."""
+    given modules / optimizers are snapshotted before and restored after, so building the object does not advance training.
 
-    def __init__(self, step_fn, inputs, modules, optimizers, warmup=3):
+    Data-parallel steps: pass the `parallel.GradSync` as `dp`; `step_fn` then takes one argument (the object to hand to the
+    training step as its `dp`).  The step is captured as a chain of graph segments cut at the exchange points; replay() launches
+    segment, exchange, segment, ... in the captured order (all segments share one memory pool, so the order is fixed)."""
+
+    def __init__(self, step_fn, inputs, modules, optimizers, warmup=3, dp=None):
         self.inputs = dict(inputs)
         for m in modules:
             m._ensure_flat()
         saved = [(m.flat_params.clone(), [b.clone() for b in m.buffers()]) for m in modules]
         osnap = [o.snapshot() for o in optimizers]
+        run = step_fn if dp is None else (lambda: step_fn(dp))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                step_fn()
+                run()
+            if dp is not None:
+                dp.wait_all()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = step_fn()
+        self.program = []          # [(graph, eager operation after it or None)]
+        self._pool = None
+        self._tick = torch.zeros(1, device=self.inputs[next(iter(self.inputs))].device) if self.inputs else torch.zeros(1, device="cuda")
+        self._begin()
+        try:
+            self.out = step_fn() if dp is None else step_fn(_CutDP(dp, self))
+        except BaseException:
+            self._ctx.__exit__(None, None, None)
+            raise
+        self._end(None)
+        if dp is not None:
+            dp.wait_all()
+        self.graph = self.program[0][0]
         for m, (fp, bufs) in zip(modules, saved):
             m.flat_params.copy_(fp)
             for b, b0 in zip(m.buffers(), bufs):
@@ -518,12 +556,33 @@ class GraphedStep:
         for o, sn in zip(optimizers, osnap):
             o.restore(sn)
 
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
+        self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
+        self._ctx.__enter__()
+        self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
+
+    def _end(self, op):
+        self._ctx.__exit__(None, None, None)
+        if self._pool is None:
+            self._pool = self._g.pool()
+        self.program.append((self._g, op))
+
+    def _cut(self, op):
+        self._end(op)
+        op()                       # capture executes nothing; the exchange itself runs (state is restored after capture)
+        self._begin()
+
     def load(self, **tensors):
         for k, v in tensors.items():
             self.inputs[k].copy_(v)
 
     def replay(self):
-        self.graph.replay()
+        for g, op in self.program:
+            g.replay()
+            if op is not None:
+                op()
         return self.out
 
 

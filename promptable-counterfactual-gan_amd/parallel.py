@@ -12,7 +12,9 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_exchange=False):
+        """always_exchange: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)."""
+        self.always_exchange = always_exchange
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised torch.distributed process group")
         self.group = group
@@ -22,7 +24,7 @@ class GradSync:
         self._pending = {}
 
     def _allreduce_mean(self, flat):
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return
         if self.backend == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)

@@ -252,3 +252,72 @@ def test_full_size_step_is_deterministic_and_dp_ready(pcg):
     assert outs[0][0] == outs[1][0]
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def _fresh_dcgan(D, seed=5):
+    torch.manual_seed(seed)
+    netG, netD = D.Generator().to(DEV), D.Discriminator().to(DEV)
+    netG.apply(D.weights_init); netD.apply(D.weights_init)
+    return (netG, netD) + tuple(D.make_optimizers(netG, netD))
+
+
+def _state(netG, netD):
+    return {**{f"G.{k}": v.clone() for k, v in netG.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in netD.state_dict().items()}}
+
+
+@pytest.mark.parametrize("with_dp", [False, True])
+def test_graph_replay_is_bit_identical_to_eager(pcg, with_dp):
+    """bench.py replays the step as HIP graph(s): same kernels, same order.  Three steps eager vs three replays (with a mixed
+    eager step in between, as bench.py's event-sampled steps do) from the same state on the same batches give bit-identical
+    losses, parameters and BatchNorm buffers.  with_dp: the data-parallel form — segments cut at the gradient exchanges, the
+    exchanges issued through RCCL on a one-rank group (parallel.GradSync(always_exchange=True))."""
+    import torch.distributed as dist
+    from pcgan_amd.nn import GraphedStep
+    D = pcg.dcgan
+    B = 64
+    g = torch.Generator().manual_seed(11)
+    reals = [(torch.rand(B, 1, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(4)]
+    noises = [torch.randn(B, 100, 1, 1, generator=g).to(DEV) for _ in range(4)]
+    dp = None
+    if with_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        if with_dp:
+            from pcgan_amd.parallel import GradSync
+            dp = GradSync(always_exchange=True)
+        # eager
+        netG, netD, crit, optD, optG = _fresh_dcgan(D)
+        for i in range(4):
+            o = D.train_step(netG, netD, crit, optD, optG, reals[i], noises[i], dp=dp)
+        if dp is not None:
+            dp.wait_all()
+        want = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], _state(netG, netD))
+        # graph replay, step 2 eager in between
+        netG, netD, crit, optD, optG = _fresh_dcgan(D)
+        s_real, s_noise = reals[0].clone(), noises[0].clone()
+        if dp is None:
+            gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise), {"real": s_real, "noise": s_noise},
+                             [netG, netD], [optD, optG])
+            assert len(gs.program) == 1
+        else:
+            gs = GraphedStep(lambda d: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, dp=d),
+                             {"real": s_real, "noise": s_noise}, [netG, netD], [optD, optG], dp=dp)
+            assert len(gs.program) == 4      # cut at wait(G), sync_now(D), sync_then(G)
+        for i in range(4):
+            if i == 2:
+                o = D.train_step(netG, netD, crit, optD, optG, reals[i], noises[i], dp=dp)
+            else:
+                gs.load(real=reals[i], noise=noises[i])
+                o = gs.replay()
+        if dp is not None:
+            dp.wait_all()
+        got = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], _state(netG, netD))
+        assert all(np.isfinite(v) for v in got[0])
+        assert got[0] == want[0]
+        for k in want[1]:
+            assert torch.equal(got[1][k], want[1][k]), k
+    finally:
+        if with_dp:
+            dist.destroy_process_group()
