@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(256) thin_reduce_kernel(ThinP p) {
 }
 
 #include "thin_fast.inc"
+#include "thin_rows.inc"
 
 // Each block owns `ppb` iteration pixels; thread (cq, pl) accumulates NT float4 sums over pixels pl, pl+PL, ...
 // then the PL pixel-lanes are summed through LDS in a fixed order and the block writes its slab in dw layout.
@@ -223,6 +224,44 @@ __global__ void __launch_bounds__(256) slab_reduce1_kernel(const float* __restri
   }
 }
 
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// row-block plan (thin_rows.inc): direct tap map with any stride, or the transposed map with stride 1; the wide grid must be
+// a real image (>= 64 pixels) and the thin tensor addressable with 32-bit byte offsets
+bool rows_plan(const ThinP& p, RowsP& rp, size_t* patch_bytes, int px_per_thread = 16, size_t max_patch_bytes = 40 * 1024) {
+  const bool direct = !p.transposed;
+  if (!direct && p.stride != 1) return false;
+  const int CQ = p.C / 4;
+  if (p.C % 4 || CQ > 256 || !is_pow2(CQ)) return false;
+  if (p.IH_ * p.IW_ < 64) return false;
+  if ((int64_t)p.B * p.TH * p.TW * p.Cs * 4 >= (1ll << 31)) return false;
+  const int PL = 256 / CQ;
+  int R;
+  if (px_per_thread == 16) {               // expand: about 16 pixels per thread, at least 256 per unit
+    int target = PL * 16;
+    if (target < 256) target = 256;
+    R = (target + p.IW_ - 1) / p.IW_;
+  } else {                                 // wgrad: at most px_per_thread pixels per thread (they live in registers)
+    R = PL * px_per_thread / p.IW_;
+    if (R < 1) return false;
+  }
+  if (R > p.IH_) R = p.IH_;
+  rp.s = direct ? p.stride : 1;
+  rp.flip = direct ? 0 : 1;
+  rp.qh_off = direct ? -p.pad : p.pad - p.KH + 1;
+  rp.qw_off = direct ? -p.pad : p.pad - p.KW + 1;
+  rp.R = R;
+  rp.upi = (p.IH_ + R - 1) / R;
+  rp.nunits = p.B * rp.upi;
+  rp.PH = (R - 1) * rp.s + p.KH;
+  rp.PW = (p.IW_ - 1) * rp.s + p.KW;
+  rp.dUPI = FastDiv((uint32_t)rp.upi);
+  rp.dPWC = FastDiv((uint32_t)(rp.PW * p.Cs));
+  rp.dCS = FastDiv((uint32_t)p.Cs);
+  *patch_bytes = (size_t)rp.PH * rp.PW * p.Cs * sizeof(float);
+  return *patch_bytes <= max_patch_bytes;
+}
+
 // geometry -> ThinP for the two thin families
 int fill_common(ThinP& p, const pcg_conv_geom* g, bool cin_thin, bool iter_on_output) {
   p.B = g->B; p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
@@ -255,6 +294,23 @@ int launch_expand(ThinP& p, hipStream_t s) {
   const size_t smem = lds_weight_bytes(p);
   PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
   const bool k44 = p.KH == 4 && p.KW == 4, k33 = p.KH == 3 && p.KW == 3, k11 = p.KH == 1 && p.KW == 1;
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  if ((k44 || k33) && (k33 || p.Cs == 1) && rows_plan(p, rp, &patch_bytes)) {
+    const size_t sm = smem > patch_bytes ? smem : patch_bytes;
+    const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
+    const unsigned blocks = (unsigned)(rp.nunits < 4096 ? rp.nunits : 4096);
+#define PCG_ROWS_EXPAND_CASE(KH_, KW_, CS_)                                                                                  \
+    if (p.KH == KH_ && p.Cs == CS_) {                                                                                         \
+      hipLaunchKernelGGL((thin_rows_expand_kernel<KH_, KW_, CS_>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes);      \
+      return launch_status("thin_rows_expand_kernel");                                                                        \
+    }
+    PCG_ROWS_EXPAND_CASE(4, 4, 1)
+    PCG_ROWS_EXPAND_CASE(3, 3, 1)
+    PCG_ROWS_EXPAND_CASE(3, 3, 2)
+    PCG_ROWS_EXPAND_CASE(3, 3, 3)
+#undef PCG_ROWS_EXPAND_CASE
+  }
   if (fast_ok(p) && (k44 || k33 || k11) && (int64_t)p.npix * (p.C / 16) < (1ll << 31)) {
     ThinP q = p;
     q.dCQ = FastDiv((uint32_t)(p.C / 16));
@@ -309,6 +365,13 @@ generic:
   return launch_status("thin_reduce_kernel");
 }
 
+// row-block wgrad: number of slabs (= blocks); units per block = ceil(nunits / nblocks)
+int rows_wgrad_blocks(const RowsP& rp) { return rp.nunits < 512 ? rp.nunits : 512; }
+bool rows_wgrad_ok(const ThinP& p, const pcg_conv_geom* g, RowsP& rp, size_t* patch_bytes) {
+  const bool k44 = g->KH == 4 && g->KW == 4 && p.Cs == 1, k33 = g->KH == 3 && g->KW == 3;
+  return (k44 || k33) && rows_plan(p, rp, patch_bytes, ROWS_NPT, (size_t)ROWS_MAXP * 256 * sizeof(float));
+}
+
 struct ThinWgradPlan { int ppb, nblocks; };
 ThinWgradPlan plan_thin_wgrad(int npix, int C) {
   ThinWgradPlan w;
@@ -320,8 +383,6 @@ ThinWgradPlan plan_thin_wgrad(int npix, int C) {
   w.nblocks = (npix + ppb - 1) / ppb;
   return w;
 }
-
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
@@ -395,7 +456,13 @@ size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (C % 4 != 0 || C / 4 > 256 || !is_pow2(C / 4)) return 0;
   const int npix = cin_thin ? g->B * g->OH * g->OW : g->B * g->IH * g->IW;
   const ThinWgradPlan wp = plan_thin_wgrad(npix, C);
-  return (size_t)wp.nblocks * (size_t)g->Cout * g->KH * g->KW * g->Cin * sizeof(float);
+  size_t blocks = (size_t)wp.nblocks;
+  ThinP p{};
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  if (fill_common(p, g, cin_thin, cin_thin) == PCG_OK && rows_wgrad_ok(p, g, rp, &patch_bytes) && (size_t)rows_wgrad_blocks(rp) > blocks)
+    blocks = (size_t)rows_wgrad_blocks(rp);
+  return blocks * (size_t)g->Cout * g->KH * g->KW * g->Cin * sizeof(float);
 }
 
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
@@ -408,13 +475,33 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
   if (cin_thin) { p.wide = dy; p.thin = x; } else { p.wide = x; p.thin = dy; }
   const ThinWgradPlan wp = plan_thin_wgrad(p.npix, p.C);
   const int wn = g->Cout * g->KH * g->KW * g->Cin;
-  const size_t need = (size_t)wp.nblocks * wn * sizeof(float);
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  const bool rows = rows_wgrad_ok(p, g, rp, &patch_bytes);
+  const int nslabs = rows ? rows_wgrad_blocks(rp) : wp.nblocks;
+  const size_t need = (size_t)nslabs * wn * sizeof(float);
   if (ws == nullptr || ws_bytes < need) {
     set_error("thin conv wgrad: workspace %zu B < required %zu B", ws_bytes, need);
     return PCG_ERR_WORKSPACE;
   }
   float* slab = (float*)ws;
   const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
+  if (rows) {
+    const int upb = (rp.nunits + nslabs - 1) / nslabs;
+    const int nb = (rp.nunits + upb - 1) / upb;      // blocks that own at least one unit (<= nslabs)
+#define PCG_ROWS_WGRAD_CASE(KH_, KW_, CS_)                                                                                       \
+    if (g->KH == KH_ && p.Cs == CS_) {                                                                                            \
+      hipLaunchKernelGGL((thin_rows_wgrad_kernel<KH_, KW_, CS_>), dim3(nb), dim3(256), 2 * ((patch_bytes + 15) & ~(size_t)15), s, p, rp, slab, wn, upb, \
+                         thin_bytes);                                                                                             \
+      if (int e = launch_status("thin_rows_wgrad_kernel")) return e;                                                              \
+      return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, nb, accumulate, s);                                             \
+    }
+    PCG_ROWS_WGRAD_CASE(4, 4, 1)
+    PCG_ROWS_WGRAD_CASE(3, 3, 1)
+    PCG_ROWS_WGRAD_CASE(3, 3, 2)
+    PCG_ROWS_WGRAD_CASE(3, 3, 3)
+#undef PCG_ROWS_WGRAD_CASE
+  }
 #define PCG_THIN_WGRAD_CASE(KH_, KW_, CS_)                                                                          \
   if (g->KH == KH_ && g->KW == KW_ && p.Cs == CS_) {                                                                 \
     hipLaunchKernelGGL((thin_wgrad_kernel<KH_, KW_, CS_>), dim3(wp.nblocks), dim3(256), 0, s, p, slab, wp.ppb, wn, thin_bytes); \

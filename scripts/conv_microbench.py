@@ -21,6 +21,8 @@ LAYERS = {
     "G1": (512, 100, 4, 4, 1, 0), "G2": (256, 512, 8, 4, 2, 1), "G3": (128, 256, 16, 4, 2, 1), "G4": (64, 128, 32, 4, 2, 1),
     "G5": (1, 64, 64, 4, 2, 1),
     "R64": (64, 64, 28, 3, 1, 1),
+    # counteRGAN thin layers: conv_in 3->64, conv_out 64->1, discriminator entry 2->64 (s2)
+    "CI": (3, 64, 28, 3, 1, 1), "CO": (64, 1, 28, 3, 1, 1), "CD": (2, 64, 28, 3, 2, 1),
     # WGAN-GP (mnist_wgan_conditional.py:51-108) at width 1024: critic convs, critic Linear 8192->1024, generator ConvT adjoints
     "WC2": (256, 512, 13, 3, 2, 0), "WC3": (512, 1024, 6, 3, 2, 0), "WL1": (8192, 1024, 1, 1, 1, 0),
     "WG1": (1024, 1024, 4, 4, 1, 0), "WG2": (512, 1024, 7, 3, 2, 1), "WG3": (256, 512, 14, 4, 2, 1),
