@@ -103,6 +103,28 @@ int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, co
 int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                         float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* Backward-pass epilogues (MFMA layers).  In autograd's sweep through `Conv -> [BatchNorm] -> ReLU/LeakyReLU -> Conv` (D:
+ * mnist_dcgan.py:100-110, G: :76-87) the gradient w.r.t. a layer's OUTPUT a = act(..) is produced by the grad-input kernel of the
+ * layer above; these entry points apply the lower layer's activation derivative while that tile is still in registers:
+ *   _mask  : dx = conv_dgrad(dy, w) * act'(a_below)            (a_below = the post-activation output, same shape as dx) —
+ *            replaces the pcg_act_bwd pass of a Conv + LeakyReLU layer without BatchNorm (mnist_dcgan.py:100-101);
+ *   _bnbwd : dx = conv_dgrad(dy, w) * act'(bn(z_below)) with the mask recomputed from the pre-BatchNorm output z_below as
+ *            fma(z, gamma*invstd, beta - mean*gamma*invstd) > 0, and the per-channel sums of dx and dx*xhat written as partial
+ *            rows ([pcg_conv2d_*_bn_partial_rows][2][C], buffer of pcg_conv2d_*_bn_workspace_bytes) — the reduction pass of
+ *            BatchNorm's backward disappears; finish with pcg_bn_bwd_partial.
+ * The `fwd` forms are the same for ConvTranspose2d layers (their grad-input is a forward convolution).  act: none / ReLU / LeakyReLU. */
+int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope,
+                          float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_fwd_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* a_below, int act, float slope,
+                        float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_dgrad_bnbwd(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dx,
+                           void* partial, size_t partial_bytes, pcg_stream_t stream);
+int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, int act, float slope, float* y,
+                         void* partial, size_t partial_bytes, pcg_stream_t stream);
+int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g);
+int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */
 size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C);
 int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate,
@@ -139,6 +161,14 @@ int pcg_bn_act_bwd(const float* dy, const float* x, const float* y /*nullable wh
 int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx, float* dgamma,
                            float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
+/* BatchNorm backward from the partial sums a pcg_conv2d_*_bnbwd call left behind: dm = dy*act'(.) (already masked), partial =
+ * [nparts][2][C] (sum dm, sum dm*xhat).  Fixed-order fp64 finalize (dgamma, dbeta as in pcg_bn_act_bwd) + the elementwise pass
+ * dx = gamma*invstd*(dm - mean(dm) - xhat*mean(dm*xhat)).  workspace: pcg_bn_bwd_partial_workspace_bytes(C). */
+size_t pcg_bn_bwd_partial_workspace_bytes(int32_t C);
+int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                       const float* gamma, const float* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                       int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */

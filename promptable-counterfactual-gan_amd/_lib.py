@@ -84,6 +84,14 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_bn_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_mask": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_mask": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_bnbwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_bnbwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_bn_partial_rows": (_c.c_int32, [_gp]),
+    "pcg_conv2d_dgrad_bn_partial_rows": (_c.c_int32, [_gp]),
+    "pcg_bn_bwd_partial_workspace_bytes": (_sz, [_c.c_int32]),
+    "pcg_bn_bwd_partial": (_i, [_vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_colsum_workspace_bytes": (_sz, [_i64, _c.c_int32]),

@@ -506,6 +506,39 @@ extern "C" int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t r
                          workspace_bytes, stream);
 }
 
+extern "C" size_t pcg_bn_bwd_partial_workspace_bytes(int32_t C) { return (size_t)3 * C * sizeof(float); }
+
+extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                  const float* gamma, const float* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                                  int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dm && x && mean && invstd && partial && dx && rows > 0 && C > 0 && nparts > 0, "pcg_bn_bwd_partial: bad arguments");
+  if (!workspace || workspace_bytes < pcg_bn_bwd_partial_workspace_bytes(C)) {
+    set_error("pcg_bn_bwd_partial: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_bwd_partial_workspace_bytes(C));
+    return PCG_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+                     1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
+  const bool aligned = al16(dm) && al16(x) && al16(dx);
+  const size_t n = (size_t)rows * C;
+  if (fast_channels(C) && aligned) {
+    unsigned blocks = (unsigned)((n / 4 + 511) / 512);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
+                       reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, PCG_ACT_NONE,
+                       0.f, 1.f, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr);
+  } else if (C % 4 == 0 && aligned)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
+                       (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
+                       (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
+  return launch_status("bn_bwd_apply_kernel");
+}
+
 extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate, void* workspace,
                           size_t workspace_bytes, pcg_stream_t stream) {
   PCG_REQUIRE(dy && db && rows > 0 && C > 0, "pcg_colsum: bad arguments");

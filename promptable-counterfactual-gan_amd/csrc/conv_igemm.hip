@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, blockIdx.y == 0 ? p.bias : nullptr, [&](int row) -> float* {
     const int m = m_block + row;
     return m < p.M ? out + (size_t)m * p.N + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope);
+  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
 }
 
 template <class Cfg>
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope);
+  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
 }
 
 template <class Cfg>
@@ -267,7 +267,7 @@ static int dgrad_stat_rows(const pcg_conv_geom* g) {
 
 static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                            float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
-                           float slope = 0.f) {
+                           float slope = 0.f, const EpiAux* epi = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
   PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_fwd: unknown activation %d", act);
@@ -276,6 +276,7 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
   ConvP p = make_params(g);
   p.x = x; p.w = w; p.bias = bias; p.out = y; p.stat_partial = stat_partial;
+  if (epi) p.epi = *epi;
   p.M = g->B * g->OH * g->OW; p.N = g->Cout;
   p.ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
   p.ktiles_per_split = p.ktiles;
@@ -283,7 +284,7 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   // split-K needs the slab workspace and cannot fuse statistics or the activation (both need the complete sum)
   FwdPlan f = plan_fwd(g);
   const size_t need = (size_t)f.splits * p.M * p.N * sizeof(float);
-  if (f.splits > 1 && (stat_partial || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 15) || ((uintptr_t)y & 15) || (p.M * (size_t)p.N) % 4))
+  if (f.splits > 1 && (stat_partial || epi || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 15) || ((uintptr_t)y & 15) || (p.M * (size_t)p.N) % 4))
     f = FwdPlan{1, p.ktiles};
   const bool fuse = act_is_cheap(act) && f.splits == 1;   // the epilogue fuses ReLU / LeakyReLU; tanh / sigmoid run as a second pass
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
@@ -328,7 +329,7 @@ extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const f
 
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                              float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
-                             float slope = 0.f) {
+                             float slope = 0.f, const EpiAux* epi = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
   PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_dgrad: unknown activation %d", act);
@@ -339,6 +340,7 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   ConvP p = make_params(g);
   const bool fuse = act_is_cheap(act);
   p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx; p.stat_partial = stat_partial;
+  if (epi) p.epi = *epi;
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   p.N = g->Cin;
   DgradPhases ph{};
@@ -388,6 +390,68 @@ extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, cons
   return launch_bn_stats_finalize((const float*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
                                   save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
 }
+
+// ---- backward-pass epilogues: the gradient w.r.t. the layer below's OUTPUT leaves the kernel already multiplied by that
+// layer's ReLU / LeakyReLU derivative, optionally with BatchNorm-backward's two column sums taken on the way -------------------
+static int epi_common(const char* who, const pcg_conv_geom* g, const float* out, const float* aux, int act, float slope, EpiAux* e) {
+  PCG_REQUIRE(mfma_layer(g), "%s: only MFMA layers (Cin > 3 and Cout > 3); use the unfused calls", who);
+  PCG_REQUIRE(aux && out, "%s: null pointer", who);
+  PCG_REQUIRE(act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU, "%s: activation %d is not none / ReLU / LeakyReLU", who, act);
+  PCG_REQUIRE((((uintptr_t)aux | (uintptr_t)out) & 15) == 0, "%s: tensors must be 16-byte aligned", who);
+  e->neg = act_neg_of(act, slope);
+  e->delta_bytes = (int64_t)((intptr_t)aux - (intptr_t)out);
+  return PCG_OK;
+}
+
+extern "C" int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope,
+                                     float* dx, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_MASK;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_dgrad_mask", g, dx, a_below, act, slope, &e)) return rc;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
+}
+extern "C" int pcg_conv2d_fwd_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* a_below, int act, float slope,
+                                   float* y, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_MASK;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_fwd_mask", g, y, a_below, act, slope, &e)) return rc;
+  return conv2d_fwd_impl(g, x, w, nullptr, y, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
+}
+
+static int bnbwd_epi(const char* who, const pcg_conv_geom* g, const float* out, const float* z_below, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, float slope, size_t need, void* partial, size_t partial_bytes,
+                     EpiAux* e) {
+  PCG_REQUIRE(need > 0, "%s: layer not eligible (MFMA layers, stride <= 2, channel count %% 4 == 0)", who);
+  PCG_REQUIRE(mean && invstd && gamma && beta, "%s: null BatchNorm parameter", who);
+  PCG_REQUIRE((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "%s: BatchNorm vectors must be 16-byte aligned", who);
+  if (!partial || partial_bytes < need) { set_error("%s: partial-sum buffer %zu B < required %zu B", who, partial_bytes, need); return PCG_ERR_WORKSPACE; }
+  e->mode = EPI_BNBWD;
+  e->mean = mean; e->invstd = invstd; e->gamma = gamma; e->beta = beta;
+  return epi_common(who, g, out, z_below, act, slope, e);
+}
+
+extern "C" int pcg_conv2d_dgrad_bnbwd(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dx,
+                                      void* partial, size_t partial_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = bnbwd_epi("pcg_conv2d_dgrad_bnbwd", g, dx, z_below, mean, invstd, gamma, beta, act, slope,
+                         pcg_conv2d_dgrad_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (float*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
+extern "C" int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, int act, float slope, float* y,
+                                    void* partial, size_t partial_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = bnbwd_epi("pcg_conv2d_fwd_bnbwd", g, y, z_below, mean, invstd, gamma, beta, act, slope,
+                         pcg_conv2d_fwd_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
+  return conv2d_fwd_impl(g, x, w, nullptr, y, (float*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
+extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
+extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 
 extern "C" size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;

@@ -205,10 +205,24 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
 template <class Cfg>
 constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 
+// Backward-pass epilogues (the tile is a gradient w.r.t. the OUTPUT a = act(..) of the layer below; `aux` is a tensor of the
+// same shape and addressing as the output):
+//   EPI_MASK   aux = a (post-activation).  v *= (aux > 0 ? 1 : neg)            — ReLU / LeakyReLU backward, no extra pass
+//   EPI_BNBWD  aux = z (the layer below's pre-BatchNorm conv output).  pre = z*sc + sh (sc = gamma*invstd, sh = beta - mean*sc),
+//              v *= (pre > 0 ? 1 : neg), xhat = (z - mean)*invstd; column sums of v and v*xhat go to the partial rows
+//              (-> dbeta, dgamma and the two means BatchNorm's backward needs): no separate reduction pass over (dy, z).
+enum { EPI_NONE = 0, EPI_MASK = 1, EPI_BNBWD = 2 };
+struct EpiAux {
+  int mode;                 // EPI_*
+  float neg;                // slope of the negative side (0 ReLU, 0.2 LeakyReLU, 1 = no activation)
+  int64_t delta_bytes;      // (char*)aux - (char*)out
+  const float* mean; const float* invstd; const float* gamma; const float* beta;   // EPI_BNBWD, per output column
+};
+
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
                                                  const float* bias, RowBase row_base, float* stat_row = nullptr, int act = PCG_ACT_NONE,
-                                                 float slope = 0.f) {
+                                                 float slope = 0.f, const EpiAux* epi = nullptr) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
   constexpr int RPI = 64 / Q;              // rows per store instruction
@@ -228,19 +242,56 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && nok) bv = *reinterpret_cast<const float4*>(bias + n);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  const int emode = epi ? epi->mode : EPI_NONE;   // wave-uniform
+  if (emode == EPI_NONE) {
 #pragma unroll
-  for (int k = 0; k < Cfg::WTM / RPI; ++k) {
-    const int row = r0 + RPI * k;
-    float* dst = row_base(wm * Cfg::WTM + row);
-    if (dst && nok) {
-      float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
-      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-      if (act != PCG_ACT_NONE) {   // wave-uniform; ReLU / LeakyReLU only (slope = 0 / negative slope), others are applied by the host wrapper
-        v.x = act_neg_scale(v.x, slope); v.y = act_neg_scale(v.y, slope); v.z = act_neg_scale(v.z, slope); v.w = act_neg_scale(v.w, slope);
+    for (int k = 0; k < Cfg::WTM / RPI; ++k) {
+      const int row = r0 + RPI * k;
+      float* dst = row_base(wm * Cfg::WTM + row);
+      if (dst && nok) {
+        float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (act != PCG_ACT_NONE) {   // wave-uniform; ReLU / LeakyReLU only (slope = 0 / negative slope), others are applied by the host wrapper
+          v.x = act_neg_scale(v.x, slope); v.y = act_neg_scale(v.y, slope); v.z = act_neg_scale(v.z, slope); v.w = act_neg_scale(v.w, slope);
+        }
+        *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
       }
-      *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
-      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-      s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+    }
+  } else {
+    const float neg = epi->neg;
+    const int64_t delta = epi->delta_bytes;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sc;
+    if (emode == EPI_BNBWD && nok) {
+      mu = *reinterpret_cast<const float4*>(epi->mean + n);
+      is = *reinterpret_cast<const float4*>(epi->invstd + n);
+      const float4 ga = *reinterpret_cast<const float4*>(epi->gamma + n), be = *reinterpret_cast<const float4*>(epi->beta + n);
+      sc = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
+      sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+    }
+    // all aux loads of the wave tile first (independent of the LDS reads), then the arithmetic
+    float4 u[Cfg::WTM / RPI];
+#pragma unroll
+    for (int k = 0; k < Cfg::WTM / RPI; ++k) {
+      float* dst = row_base(wm * Cfg::WTM + r0 + RPI * k);
+      u[k] = (dst && nok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < Cfg::WTM / RPI; ++k) {
+      const int row = r0 + RPI * k;
+      float* dst = row_base(wm * Cfg::WTM + row);
+      if (dst && nok) {
+        float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
+        // same expression as bn_bwd_apply / FnBnBwd use for the recomputed BatchNorm output (sc = 1, sh = 0 for EPI_MASK)
+        const float4 pre = make_float4(fmaf(u[k].x, sc.x, sh.x), fmaf(u[k].y, sc.y, sh.y), fmaf(u[k].z, sc.z, sh.z), fmaf(u[k].w, sc.w, sh.w));
+        v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
+        *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x = fmaf(v.x, (u[k].x - mu.x) * is.x, s2.x); s2.y = fmaf(v.y, (u[k].y - mu.y) * is.y, s2.y);
+        s2.z = fmaf(v.z, (u[k].z - mu.z) * is.z, s2.z); s2.w = fmaf(v.w, (u[k].w - mu.w) * is.w, s2.w);
+      }
     }
   }
   // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one partial row per

@@ -238,6 +238,9 @@ class SequentialConvNet(FlatModule):
     one channel (MNIST images, z as [B, z, 1, 1]) are NHWC already, so no relayout happens at the boundary.
     """
 
+    fuse_backward_epilogue = True   # A/B switch (tests compare both forms): activation derivative / BatchNorm-backward sums of the
+                                    # layer below taken in the grad-input kernel's epilogue instead of in separate passes
+
     def __init__(self, main):
         super().__init__()
         self.main = main
@@ -326,6 +329,11 @@ class SequentialConvNet(FlatModule):
         d = dy
         own = False  # never write into autograd's incoming grad tensor; deeper gradients are ours to overwrite
         nblk = len(self._blocks)
+        # `fused`: how the gradient `d` arriving at block idx was produced by the grad-input kernel of block idx+1:
+        #   None                  plain gradient w.r.t. the block's output
+        #   ("mask",)             already multiplied by the block's ReLU / LeakyReLU derivative
+        #   ("bn", partial, n)    the same, plus BatchNorm-backward's column sums in `partial` (n partial rows)
+        fused = None
         for idx in range(nblk - 1, -1, -1):
             b = self._blocks[idx]
             g, a, z, mean, invstd, y, bn_eval = saved[idx]
@@ -342,13 +350,16 @@ class SequentialConvNet(FlatModule):
                     db, acc2 = self._grad_view(bn.bias)
                     if acc != acc2:
                         raise PcgError("inconsistent .grad state on BatchNorm weight/bias")
-                # ReLU / LeakyReLU: the mask is recomputed from z (no read of y)
-                dz = ops.bn_act_bwd(d, z, None if b.act in (ACT_RELU, ACT_LRELU) else y, C, mean, invstd, bn.weight.data, b.act, b.slope, dg,
-                                    db, acc, beta=bn.bias.data)
-            elif b.act != ACT_NONE:
-                dz = ops.act_bwd(d, y, b.act, b.slope, out=d if own else None)
-            else:
+                if fused is not None:
+                    dz = ops.bn_bwd_partial(d, z, C, mean, invstd, bn.weight.data, fused[1], fused[2], dg, db, acc, out=d)
+                else:
+                    # ReLU / LeakyReLU: the mask is recomputed from z (no read of y)
+                    dz = ops.bn_act_bwd(d, z, None if b.act in (ACT_RELU, ACT_LRELU) else y, C, mean, invstd, bn.weight.data, b.act, b.slope, dg,
+                                        db, acc, beta=bn.bias.data)
+            elif fused is not None or b.act == ACT_NONE:
                 dz = d
+            else:
+                dz = ops.act_bwd(d, y, b.act, b.slope, out=d if own else None)
             own = True
             if need_p and c.weight.requires_grad:
                 gw, acc = self._grad_view(c.weight)
@@ -363,6 +374,26 @@ class SequentialConvNet(FlatModule):
             last = idx == 0
             if last and not need_x:
                 return None
+            # grad-input of this block = gradient w.r.t. the output of the block below; apply that block's activation derivative
+            # (and take its BatchNorm-backward sums) in the epilogue when both layers allow it
+            fused = None
+            if not last and self.fuse_backward_epilogue:
+                lo = self._blocks[idx - 1]
+                _, _, zl, ml, il, yl, lo_eval = saved[idx - 1]
+                w = _w_ohwi(c.weight.data)
+                res = None
+                if lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU) and not (b.transposed and b.flat):
+                    if lo.bn is not None and not lo_eval and zl is not None:
+                        res = ops.conv_bwd_data_fused(g, dz, w, b.transposed, lo.act, lo.slope, z_below=zl,
+                                                      bn=(ml, il, lo.bn.weight.data, lo.bn.bias.data))
+                        if res is not None:
+                            d, fused = res[0], ("bn", res[1], res[2])
+                    elif lo.bn is None and lo.act != ACT_NONE:
+                        res = ops.conv_bwd_data_fused(g, dz, w, b.transposed, lo.act, lo.slope, a_below=yl)
+                        if res is not None:
+                            d, fused = res[0], ("mask",)
+                if res is not None:
+                    continue
             if not b.transposed:
                 d = ops.conv2d_dgrad(g, dz, _w_ohwi(c.weight.data))
             else:

@@ -165,6 +165,55 @@ def conv_bn_train(g, a, w, bias, transposed, eps, momentum, running_mean, runnin
     return z, mean, invstd
 
 
+def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=None, z_below=None, bn=None):
+    """Gradient w.r.t. a layer's input with the activation derivative of the layer BELOW applied in the epilogue.
+    transposed=False: Conv2d (grad-input kernel); True: ConvTranspose2d (its grad-input is a forward convolution).
+    z_below + bn=(mean, invstd, gamma, beta): the layer below is Conv -> BatchNorm(train) -> act; returns (dm, partial, nparts)
+    for bn_bwd_partial.  a_below: the layer below is Conv -> act without BatchNorm; returns (dx_masked, None, 0).
+    Returns None when the layer is not eligible (thin layers, split-K): the caller then takes the unfused path."""
+    lib = _lib.load()
+    if g.Cin <= 3 or g.Cout <= 3 or g.Cin % 4 or g.Cout % 4 or g.stride > 2:
+        return None
+    shape = (g.B, g.OH, g.OW, g.Cout) if transposed else (g.B, g.IH, g.IW, g.Cin)
+    if transposed and lib.pcg_conv2d_fwd_workspace_bytes(ctypes.byref(g)) != 0:   # split-K forward: sums are incomplete per slab
+        return None
+    _chk(d, "d"); _chk(w, "w")
+    out = torch.empty(shape, dtype=torch.float32, device=d.device)
+    if bn is None:
+        _chk(a_below, "a_below")
+        assert a_below.numel() == out.numel()
+        fn = lib.pcg_conv2d_fwd_mask if transposed else lib.pcg_conv2d_dgrad_mask
+        with _Timed(g, "fwd" if transposed else "dgrad"):
+            check(fn(ctypes.byref(g), _p(d), _p(w), _p(a_below), int(below_act), float(below_slope), _p(out), None, 0, _stream()),
+                  "pcg_conv2d_*_mask")
+        return out, None, 0
+    _chk(z_below, "z_below")
+    assert z_below.numel() == out.numel()
+    mean, invstd, gamma, beta = bn
+    need = (lib.pcg_conv2d_fwd_bn_workspace_bytes if transposed else lib.pcg_conv2d_dgrad_bn_workspace_bytes)(ctypes.byref(g))
+    if need == 0:
+        return None
+    nparts = (lib.pcg_conv2d_fwd_bn_partial_rows if transposed else lib.pcg_conv2d_dgrad_bn_partial_rows)(ctypes.byref(g))
+    partial = torch.empty(need // 4, dtype=torch.float32, device=d.device)   # own tensor: lives until bn_bwd_partial has read it
+    fn = lib.pcg_conv2d_fwd_bnbwd if transposed else lib.pcg_conv2d_dgrad_bnbwd
+    with _Timed(g, "fwd" if transposed else "dgrad"):
+        check(fn(ctypes.byref(g), _p(d), _p(w), _p(z_below), _p(mean), _p(invstd), _p(gamma), _p(beta), int(below_act), float(below_slope),
+                 _p(out), _p(partial), need, _stream()), "pcg_conv2d_*_bnbwd")
+    return out, partial, nparts
+
+
+def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None):
+    """BatchNorm backward from the column sums a fused grad-input epilogue left in `partial` (dm is already masked)."""
+    _chk(dm, "dm"); _chk(x, "x")
+    rows = x.numel() // C
+    dx = out if out is not None else torch.empty_like(x)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_bn_bwd_partial_workspace_bytes(C), x.device)
+    check(lib.pcg_bn_bwd_partial(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
+                                 _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_bwd_partial")
+    return dx
+
+
 def conv2d_wgrad(g, x, dy, dw, accumulate):
     """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(dw, "dw")

@@ -321,3 +321,33 @@ def test_graph_replay_is_bit_identical_to_eager(pcg, with_dp):
     finally:
         if with_dp:
             dist.destroy_process_group()
+
+
+def test_fused_backward_epilogue_equals_separate_passes(pcg):
+    """The grad-input kernels apply the activation derivative of the layer below (and take BatchNorm-backward's column sums) in
+    their epilogue; SequentialConvNet.fuse_backward_epilogue = False runs the separate act_bwd / reduction passes instead.  Same
+    masks (same fma expression), sums in a different fixed order: all gradients of one D-step + G-step agree to 2e-5 rel-L2
+    (fp32 summation-order noise; the oracle tests bound the absolute error of both forms)."""
+    D = pcg.dcgan
+    from pcgan_amd.nn import SequentialConvNet
+    g = torch.Generator().manual_seed(21)
+    real = (torch.rand(32, 1, 64, 64, generator=g) * 2 - 1).to(DEV)
+    noise = torch.randn(32, 100, 1, 1, generator=g).to(DEV)
+    grads = {}
+    try:
+        for fuse in (True, False):
+            SequentialConvNet.fuse_backward_epilogue = fuse
+            netG, netD, crit, optD, optG = _fresh_dcgan(D, seed=9)
+            netD.zero_grad(); netG.zero_grad()
+            crit(netD(real), torch.ones(32, device=DEV)).backward()
+            fake = netG(noise)
+            crit(netD(fake), torch.zeros(32, device=DEV)).backward()        # through D into G
+            grads[fuse] = {**{f"D.{n}": p.grad.clone() for n, p in netD.named_parameters()},
+                           **{f"G.{n}": p.grad.clone() for n, p in netG.named_parameters()}}
+    finally:
+        SequentialConvNet.fuse_backward_epilogue = True
+    for k, ref in grads[False].items():
+        got = grads[True][k]
+        assert torch.isfinite(got).all(), k
+        l2 = _rel_l2(got.cpu().numpy(), ref.cpu().numpy())
+        assert l2 <= 2e-5, f"{k}: rel-L2 {l2:.2e}"
