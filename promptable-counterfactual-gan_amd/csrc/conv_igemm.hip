@@ -54,11 +54,18 @@ template <class Cfg>
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
-  const PhaseInfo& f = phases.p[blockIdx.y];
+  // phases.interleave (all phases the same size, 1-D grid): the sub-pixel phases of one tile are neighbours in launch order and
+  // on one XCD — they gather the same dy rows, which then come from HBM once and from that XCD's L2 for the other phases
+  uint32_t bx = blockIdx.x, py = blockIdx.y;
+  if (phases.interleave) {
+    const uint32_t l = xcd_remap(blockIdx.x, gridDim.x);
+    py = l % (uint32_t)phases.interleave; bx = l / (uint32_t)phases.interleave;
+  }
+  const PhaseInfo& f = phases.p[py];
   const int tilesM = (f.Mp + Cfg::BM - 1) / Cfg::BM;
   const uint32_t ntiles = (uint32_t)tilesM * p.tilesN;
-  if (blockIdx.x >= ntiles) return;  // phases can differ in size (odd IH/IW); uniform per block
-  const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
+  if (bx >= ntiles) return;  // phases can differ in size (odd IH/IW); uniform per block
+  const uint32_t tile = phases.interleave ? bx : xcd_remap(bx, ntiles);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
   const int ktiles = f.nth * f.ntw * ((p.Cout + IG_BK - 1) / IG_BK);
@@ -206,7 +213,15 @@ int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStre
   constexpr size_t smem = smem_bytes<Cfg, true, false>();
   static int once = set_smem(conv_dgrad_kernel<Cfg>, smem);
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, ph);
+  static const int il_env = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
+  DgradPhases phl = ph;
+  bool same = nphases > 1 && il_env;
+  for (int i = 1; i < nphases; ++i) same = same && ph.p[i].Mp == ph.p[0].Mp;
+  phl.interleave = same ? nphases : 0;
+  if (same)
+    hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN * nphases), dim3(IG_THREADS), smem, s, p, phl);
+  else
+    hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, phl);
   return launch_status("conv_dgrad_kernel");
 }
 

@@ -65,7 +65,7 @@ struct PhaseInfo {
   int prow0;           // first partial-statistics row of this phase
   FastDiv dPHw, dPHh;
 };
-struct DgradPhases { PhaseInfo p[4]; };
+struct DgradPhases { PhaseInfo p[4]; int interleave; };   // interleave = number of equal-sized phases sharing a 1-D grid, or 0
 
 // ---- forward: A = im2col rows of x (K-major), B = OHWI weight rows (K-major) --------------------------------
 template <int ROWS_>
