@@ -160,6 +160,8 @@ def main():
     t0 = time.perf_counter()
     ev = max(1, args.event_every)
     sampled = [i for i in range(args.steps) if hook is not None and i % ev == ev // 2]
+    if hook is not None and not sampled and args.steps > 0:
+        sampled = [args.steps // 2]               # short runs still carry a live roofline measurement
     for i in range(args.steps):
         timed = i in sampled
         ops.set_conv_hook(hook if timed else None)

@@ -11,7 +11,7 @@ namespace {
 
 constexpr int CR_THREADS = 256;
 constexpr int CR_MAX_BLOCKS = 512;
-constexpr int FIN_CH = 8, FIN_SL = 32;   // finalize: 16 channels x 16 partial-slices per 256-thread block
+constexpr int FIN_CH = 8, FIN_SL = 128;  // finalize: 8 channels x 128 partial-row slices per 1024-thread block (the loop over partial rows is latency-bound)
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
 
@@ -139,10 +139,10 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
   }
 }
 
-// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+32, ... and the 32
-// slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/8 dependent loads per thread).
-template <int NVAL>
-__device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial, int nblocks, int C, int& c_out,
+// Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+FIN_SL, ... and the FIN_SL
+// slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/(8 FIN_SL) dependent load batches per thread).
+template <int NVAL, class SrcT>
+__device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, int nblocks, int C, int& c_out,
                                               double (&sum)[NVAL]) {
   __shared__ double red[NVAL][FIN_SL][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
@@ -153,7 +153,7 @@ __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial,
   if (c < C) {
     int b = sl;
     for (; b + 7 * FIN_SL < nblocks; b += 8 * FIN_SL) {   // 8 independent loads in flight, added in block order
-      float v[8][NVAL];
+      SrcT v[8][NVAL];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -175,19 +175,21 @@ __device__ __forceinline__ bool finalize_sums(const float* __restrict__ partial,
 #pragma unroll
   for (int k = 0; k < NVAL; ++k) {
     double s = 0.0;
-    for (int j = 0; j < FIN_SL; ++j) s += red[k][j][cl];
+#pragma unroll 8
+    for (int j = 0; j < FIN_SL; ++j) s += red[k][j][cl];   // (a full unroll of FIN_SL LDS reads spills to scratch: slow dispatch)
     sum[k] = s;
   }
   return true;
 }
 
+template <class SrcT>
 __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_kernel(
-    const float* __restrict__ partial, int nblocks, int C, double inv_rows, double unbias, float eps, float momentum,
+    const SrcT* __restrict__ partial, int nblocks, int C, double inv_rows, double unbias, float eps, float momentum,
     float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
   int c;
   double sm[2];
-  if (!finalize_sums<2>(partial, nblocks, C, c, sm)) return;
+  if (!finalize_sums<2, SrcT>(partial, nblocks, C, c, sm)) return;
   const double mean = sm[0] * inv_rows;
   double var = sm[1] * inv_rows - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -201,22 +203,67 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) colsum_finalize_kernel(const 
                                                                          int C, float* out, int accumulate) {
   int c;
   double sm[1];
-  if (!finalize_sums<1>(partial, nblocks, C, c, sm)) return;
+  if (!finalize_sums<1, float>(partial, nblocks, C, c, sm)) return;
   out[c] = (accumulate ? out[c] : 0.f) + (float)sm[0];
 }
 
 // coef[0][c] = gamma*invstd ; coef[1][c] = mean(dz) ; coef[2][c] = mean(dz*xhat)
+template <class SrcT>
 __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(
-    const float* __restrict__ partial, int nblocks, int C, double inv_rows, const float* gamma, const float* invstd,
+    const SrcT* __restrict__ partial, int nblocks, int C, double inv_rows, const float* gamma, const float* invstd,
     float* coef, float* dgamma, float* dbeta, int accumulate) {
   int c;
   double sm[2];
-  if (!finalize_sums<2>(partial, nblocks, C, c, sm)) return;
+  if (!finalize_sums<2, SrcT>(partial, nblocks, C, c, sm)) return;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sm[0];
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sm[1];
   coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
   coef[C + c] = (float)(sm[0] * inv_rows);
   coef[2 * C + c] = (float)(sm[1] * inv_rows);
+}
+
+// Many partial rows (the conv epilogues leave one per 64 output rows: 12544 for a 1024x28x28 activation) make the finalize a
+// latency-bound loop in a handful of blocks.  Level 1 below sums groups of `rpc` consecutive rows, full rows coalesced, in fp64
+// into out[chunk][cols] (cols = NVAL*C); the finalize kernels then read <= PRE_CHUNKS rows of doubles.  Fixed orders throughout.
+constexpr int PRE_CHUNKS = 256, PRE_MIN_ROWS = 4096;   // below ~4k rows the direct finalize (128 row slices per block) is as fast
+__global__ void __launch_bounds__(256) partial_presum_kernel(const float* __restrict__ partial, int nparts, int cols, int rpc,
+                                                             double* __restrict__ out) {
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int r0 = blockIdx.x * rpc;
+  int r1 = r0 + rpc; if (r1 > nparts) r1 = nparts;
+  const float* src = partial + (size_t)r0 * cols + col;
+  double acc = 0.0;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * cols];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (double)v[j];
+    src += (size_t)8 * cols;
+  }
+  for (; r < r1; ++r) { acc += (double)*src; src += cols; }
+  out[(size_t)blockIdx.x * cols + col] = acc;
+}
+
+struct PrePlan { int rpc, nchunks; };
+PrePlan plan_presum(int nparts) {
+  PrePlan q{0, 0};
+  if (nparts < PRE_MIN_ROWS) return q;
+  q.rpc = (nparts + PRE_CHUNKS - 1) / PRE_CHUNKS;
+  q.nchunks = (nparts + q.rpc - 1) / q.rpc;
+  return q;
+}
+size_t presum_offset_floats(int nparts, int cols) { return (((size_t)nparts * cols) + 1) & ~(size_t)1; }   // 8-byte aligned tail
+// returns the fp64 chunk sums (and their count) if the partial rows were pre-summed, nullptr otherwise
+const double* launch_presum(const float* partial, int nparts, int cols, int* nchunks, hipStream_t s) {
+  const PrePlan q = plan_presum(nparts);
+  if (q.nchunks == 0) return nullptr;
+  double* out = reinterpret_cast<double*>(const_cast<float*>(partial) + presum_offset_floats(nparts, cols));
+  hipLaunchKernelGGL(partial_presum_kernel, dim3(q.nchunks, (cols + 255) / 256), dim3(256), 0, s, partial, nparts, cols, q.rpc, out);
+  *nchunks = q.nchunks;
+  return out;
 }
 
 // ---- elementwise passes (float4 when C % 4 == 0) -------------------------------------------------
@@ -391,11 +438,23 @@ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 namespace pcg {
 // shared with conv_igemm.hip (BatchNorm statistics fused into the conv epilogue): partial[nparts][2][C] -> stats
+size_t bn_partial_buffer_bytes(int nparts, int C) {
+  // partial[nparts][2][C] floats (+ the fp64 chunk sums of the two-level finalize when there are many rows)
+  const PrePlan q = plan_presum(nparts);
+  return presum_offset_floats(nparts, 2 * C) * sizeof(float) + (size_t)q.nchunks * 2 * C * sizeof(double);
+}
 int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
-                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s) {
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
+                             bool has_presum_tail) {
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
-                     1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+  int nchunks = 0;
+  const double* pre = has_presum_tail ? launch_presum(partial, nparts, 2 * C, &nchunks, s) : nullptr;
+  if (pre)
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pre, nchunks, C,
+                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+  else
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   return launch_status("bn_stats_finalize_kernel");
 }
 }  // namespace pcg
@@ -426,7 +485,7 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
   FnStats fn{x};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                      num_batches_tracked);
   return launch_status("bn_stats_finalize_kernel");
@@ -469,7 +528,7 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   float* coef = partial + (size_t)cp.nblocks * 2 * C;
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
@@ -518,8 +577,14 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
   }
   hipStream_t s = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
-                     1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  int nchunks = 0;
+  const double* pre = launch_presum(partial, nparts, 2 * C, &nchunks, s);   // the buffer of pcg_conv2d_*_bn_workspace_bytes has the tail
+  if (pre)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pre, nchunks, C,
+                       1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+                       1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const bool aligned = al16(dm) && al16(x) && al16(dx);
   const size_t n = (size_t)rows * C;

@@ -264,7 +264,9 @@ extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
 
 namespace pcg {
 int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
-                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s);
+                             float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
+                             bool has_presum_tail);
+size_t bn_partial_buffer_bytes(int nparts, int C);
 }
 
 static bool mfma_layer(const pcg_conv_geom* g) { return !(thin_is_cin(g) || thin_is_cout(g)); }
@@ -323,11 +325,11 @@ extern "C" int pcg_conv2d_fwd_act(const pcg_conv_geom* g, const float* x, const 
 
 extern "C" size_t pcg_conv2d_fwd_bn_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK || !mfma_layer(g) || g->Cout % 4) return 0;
-  return (size_t)fwd_stat_rows(g) * 2 * g->Cout * sizeof(float);
+  return bn_partial_buffer_bytes(fwd_stat_rows(g), g->Cout);
 }
 extern "C" size_t pcg_conv2d_dgrad_bn_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK || !mfma_layer(g) || g->stride > 2 || g->Cin % 4) return 0;
-  return (size_t)dgrad_stat_rows(g) * 2 * g->Cin * sizeof(float);
+  return bn_partial_buffer_bytes(dgrad_stat_rows(g), g->Cin);
 }
 
 extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float eps,
@@ -339,7 +341,7 @@ extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const f
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_fwd_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
   if (int e = conv2d_fwd_impl(g, x, w, bias, y, (float*)workspace, nullptr, 0, stream)) return e;
   return launch_bn_stats_finalize((const float*)workspace, fwd_stat_rows(g), (int64_t)g->B * g->OH * g->OW, g->Cout, eps, momentum,
-                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
 }
 
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
@@ -403,7 +405,7 @@ extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, cons
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_dgrad_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
   if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (float*)workspace, nullptr, 0, stream)) return e;
   return launch_bn_stats_finalize((const float*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
-                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
 }
 
 // ---- backward-pass epilogues: the gradient w.r.t. the layer below's OUTPUT leaves the kernel already multiplied by that
