@@ -123,6 +123,10 @@ int pcg_conv2d_dgrad_bnbwd(const pcg_conv_geom* g, const float* dy, const float*
 int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
                          const float* invstd, const float* gamma, const float* beta, int act, float slope, float* y,
                          void* partial, size_t partial_bytes, pcg_stream_t stream);
+/* dx = conv_dgrad(dy, w) + addend  (addend may be dx itself: in-place accumulation) — the skip connection of a residual block
+ * in the backward sweep (`x + 0.1*out`, conditional_counteRGAN/mnist/models/generator.py:20): no separate add pass.  MFMA layers. */
+int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, float* dx,
+                         void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g);
 int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */

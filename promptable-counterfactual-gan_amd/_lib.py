@@ -88,6 +88,7 @@ PROTOTYPES = {
     "pcg_conv2d_fwd_mask": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad_bnbwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_fwd_bnbwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_add": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_fwd_bn_partial_rows": (_c.c_int32, [_gp]),
     "pcg_conv2d_dgrad_bn_partial_rows": (_c.c_int32, [_gp]),
     "pcg_bn_bwd_partial_workspace_bytes": (_sz, [_c.c_int32]),

@@ -55,15 +55,33 @@ def _conv_fwd(conv, a, act=ACT_NONE, slope=0.0):
     return g, z
 
 
-def _conv_bwd(net, conv, g, a, dz, need_p, need_x):
-    """Accumulate weight/bias gradients into net's flat buffer; return grad wrt the conv input (or None)."""
+def _conv_wgrad(net, conv, g, a, dz, need_p=True):
+    """Accumulate weight/bias gradients into net's flat buffer."""
     if need_p and conv.weight.requires_grad:
         gw, acc = net._grad_view(conv.weight)
         ops.conv2d_wgrad(g, a, dz, ops.ohwi(gw), acc)
         if conv.bias is not None:
             gb, accb = net._grad_view(conv.bias)
             ops.colsum(dz.numel() // conv.out_channels, conv.out_channels, dz, gb, accb)
+
+
+def _conv_bwd(net, conv, g, a, dz, need_p, need_x):
+    """Accumulate weight/bias gradients into net's flat buffer; return grad wrt the conv input (or None)."""
+    _conv_wgrad(net, conv, g, a, dz, need_p)
     return ops.conv2d_dgrad(g, dz, ops.ohwi(conv.weight.data)) if need_x else None
+
+
+def _dgrad_act(g, dz, w, a_below, act, slope):
+    """conv_dgrad(dz, w) * act'(a_below): one launch when the layer is an MFMA layer, grad-input + pcg_act_bwd otherwise."""
+    res = ops.conv_bwd_data_fused(g, dz, w, False, act, slope, a_below=a_below) if FUSE_BACKWARD_EPILOGUE else None
+    if res is not None:
+        return res[0]
+    d = ops.conv2d_dgrad(g, dz, w)
+    return ops.act_bwd(d, a_below.view(d.shape), act, slope, out=d)
+
+
+FUSE_BACKWARD_EPILOGUE = True   # A/B switch for the tests: activation derivative / BatchNorm-backward sums / skip-connection add in
+                                # the grad-input kernel's epilogue (ops.conv_bwd_data_fused, conv2d_dgrad_add) vs separate passes
 
 
 def _as_rows(t, B):
@@ -285,12 +303,22 @@ class ResidualGenerator(FlatModule):
             dg2, acc = self._grad_view(blk.bn2.weight)
             db2, _ = self._grad_view(blk.bn2.bias)
             dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1)
-            da1 = _conv_bwd(self, blk.conv2, g2, a1, dz2, True, True)
+            _conv_wgrad(self, blk.conv2, g2, a1, dz2)
             dg1, acc = self._grad_view(blk.bn1.weight)
             db1, _ = self._grad_view(blk.bn1.bias)
-            dz1 = ops.bn_act_bwd(da1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc, beta=blk.bn1.bias.data)
-            dconv = _conv_bwd(self, blk.conv1, g1, h, dz1, True, True)
-            dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)          # skip path + block path
+            res = (ops.conv_bwd_data_fused(g2, dz2, ops.ohwi(blk.conv2.weight.data), False, ACT_LRELU, slope, z_below=z1,
+                                           bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data)) if FUSE_BACKWARD_EPILOGUE else None)
+            if res is not None:      # LeakyReLU mask + BatchNorm-backward column sums came out of conv2's grad-input epilogue
+                dz1 = ops.bn_bwd_partial(res[0], z1, C, m1, s1, blk.bn1.weight.data, res[1], res[2], dg1, db1, acc, out=res[0])
+            else:
+                da1 = ops.conv2d_dgrad(g2, dz2, ops.ohwi(blk.conv2.weight.data))
+                dz1 = ops.bn_act_bwd(da1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc, beta=blk.bn1.bias.data)
+            _conv_wgrad(self, blk.conv1, g1, h, dz1)
+            if FUSE_BACKWARD_EPILOGUE:   # skip path + block path: the add happens in conv1's grad-input epilogue, in place
+                dh = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh)
+            else:
+                dconv = ops.conv2d_dgrad(g1, dz1, ops.ohwi(blk.conv1.weight.data))
+                dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)
         ops.act_bwd(dh, blocks[0][1] if blocks else h_last, ACT_LRELU, slope, out=dh)   # h0 = LeakyReLU(conv_in(inp))
         dinp = _conv_bwd(self, self.conv_in, g_in, inp, dh, True, True)
         ge, acc = self._grad_view(self.embed.weight)
@@ -371,12 +399,24 @@ class Discriminator(FlatModule):
         dpool = ops.conv2d_dgrad(gl, dl, head.weight.data)
         d = ops.avgpool_bwd(dpool, B, HWq, Cq).view(layers[-1][2].shape)
         convs = self._convs()
+        masked = False          # d already carries the LeakyReLU derivative of layer i (applied in layer i+1's grad-input epilogue)
         for i in range(len(convs) - 1, -1, -1):
             g, a, y = layers[i]
-            ops.act_bwd(d, y, ACT_LRELU, 0.2, out=d)
+            if not masked:
+                ops.act_bwd(d, y, ACT_LRELU, 0.2, out=d)
             last = i == 0
             need_in = (not last) or need_x or (need_p and self.cond_embed.weight.requires_grad)
-            d = _conv_bwd(self, convs[i], g, a, d, need_p, need_in)
+            _conv_wgrad(self, convs[i], g, a, d, need_p)
+            masked = False
+            if not need_in:
+                d = None
+                continue
+            w = ops.ohwi(convs[i].weight.data)
+            res = ops.conv_bwd_data_fused(g, d, w, False, ACT_LRELU, 0.2, a_below=a) if (not last and FUSE_BACKWARD_EPILOGUE) else None
+            if res is not None:
+                d, masked = res[0], True
+            else:
+                d = ops.conv2d_dgrad(g, d, w)
         if d is None:
             return None
         ge, acc = (self._grad_view(self.cond_embed.weight) if need_p and self.cond_embed.weight.requires_grad else (None, False))
@@ -544,13 +584,12 @@ class CNNClassifier(FlatModule):
         dl = torch.empty((B, kp), dtype=torch.float32, device=dlogits.device)
         ops.fill(dl, 0.0)
         dl[:, : self.num_classes].copy_(dlogits)      # pad 10 -> 12 columns (tiny strided copy)
-        d = ops.conv2d_dgrad(g2, dl, w2)
-        ops.act_bwd(d, h, ACT_RELU, 0.0, out=d)
-        d = ops.conv2d_dgrad(g1, d, w1)
-        for g, w, y in reversed(layers):
+        d = _dgrad_act(g2, dl, w2, h, ACT_RELU, 0.0)
+        d = _dgrad_act(g1, d, w1, layers[-1][2], ACT_RELU, 0.0)
+        for idx in range(len(layers) - 1, -1, -1):
+            g, w, y = layers[idx]
             d = d.view(y.shape)
-            ops.act_bwd(d, y, ACT_RELU, 0.0, out=d)
-            d = ops.conv2d_dgrad(g, d, w)
+            d = _dgrad_act(g, d, w, layers[idx - 1][2], ACT_RELU, 0.0) if idx > 0 else ops.conv2d_dgrad(g, d, w)
         return d.view(B, 1, 28, 28)
 
 

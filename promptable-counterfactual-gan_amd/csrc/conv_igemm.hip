@@ -437,6 +437,15 @@ extern "C" int pcg_conv2d_fwd_mask(const pcg_conv_geom* g, const float* x, const
   return conv2d_fwd_impl(g, x, w, nullptr, y, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
 }
 
+extern "C" int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, float* dx,
+                                    void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_ADD;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_dgrad_add", g, dx, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
+}
+
 static int bnbwd_epi(const char* who, const pcg_conv_geom* g, const float* out, const float* z_below, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, int act, float slope, size_t need, void* partial, size_t partial_bytes,
                      EpiAux* e) {

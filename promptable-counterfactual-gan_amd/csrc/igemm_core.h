@@ -211,7 +211,8 @@ constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 //   EPI_BNBWD  aux = z (the layer below's pre-BatchNorm conv output).  pre = z*sc + sh (sc = gamma*invstd, sh = beta - mean*sc),
 //              v *= (pre > 0 ? 1 : neg), xhat = (z - mean)*invstd; column sums of v and v*xhat go to the partial rows
 //              (-> dbeta, dgamma and the two means BatchNorm's backward needs): no separate reduction pass over (dy, z).
-enum { EPI_NONE = 0, EPI_MASK = 1, EPI_BNBWD = 2 };
+//   EPI_ADD    aux = an addend of the output's shape (may BE the output: in-place accumulation).  v += aux   — skip connections
+enum { EPI_NONE = 0, EPI_MASK = 1, EPI_BNBWD = 2, EPI_ADD = 3 };
 struct EpiAux {
   int mode;                 // EPI_*
   float neg;                // slope of the negative side (0 ReLU, 0.2 LeakyReLU, 1 = no activation)
@@ -285,8 +286,12 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       if (dst && nok) {
         float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
         // same expression as bn_bwd_apply / FnBnBwd use for the recomputed BatchNorm output (sc = 1, sh = 0 for EPI_MASK)
-        const float4 pre = make_float4(fmaf(u[k].x, sc.x, sh.x), fmaf(u[k].y, sc.y, sh.y), fmaf(u[k].z, sc.z, sh.z), fmaf(u[k].w, sc.w, sh.w));
-        v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
+        if (emode == EPI_ADD) {   // wave-uniform
+          v.x += u[k].x; v.y += u[k].y; v.z += u[k].z; v.w += u[k].w;
+        } else {
+          const float4 pre = make_float4(fmaf(u[k].x, sc.x, sh.x), fmaf(u[k].y, sc.y, sh.y), fmaf(u[k].z, sc.z, sh.z), fmaf(u[k].w, sc.w, sh.w));
+          v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
+        }
         *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
         s2.x = fmaf(v.x, (u[k].x - mu.x) * is.x, s2.x); s2.y = fmaf(v.y, (u[k].y - mu.y) * is.y, s2.y);

@@ -202,6 +202,16 @@ def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=Non
     return out, partial, nparts
 
 
+def conv2d_dgrad_add(g, dy, w, addend, out=None):
+    """dx = conv_dgrad(dy, w) + addend (out may be `addend`: in place) — the add of a skip connection in the grad-input epilogue."""
+    _chk(dy, "dy"); _chk(w, "w"); _chk(addend, "addend")
+    assert addend.numel() == g.B * g.IH * g.IW * g.Cin
+    dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
+    with _Timed(g, "dgrad"):
+        check(_lib.load().pcg_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(dx), None, 0, _stream()), "pcg_conv2d_dgrad_add")
+    return dx
+
+
 def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None):
     """BatchNorm backward from the column sums a fused grad-input epilogue left in `partial` (dm is already masked)."""
     _chk(dm, "dm"); _chk(x, "x")

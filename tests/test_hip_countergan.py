@@ -290,3 +290,35 @@ def test_classifier_pretraining_matches_reference(pcg, golden_dir):
         acc = pcg.ops.cf_metrics(mine(torch.from_numpy(gold["x2"]).to(DEV)).contiguous(), torch.from_numpy(gold["y2"]).to(DEV),
                                  other=torch.from_numpy(gold["y2"]).to(DEV))[0].item()
     assert abs(acc - float(re.search(r"Val Acc: ([0-9.]+)", str(gold["log"])).group(1))) < 0.13   # 8 samples: at most one flips
+
+
+def test_fused_backward_epilogues_equal_separate_passes(pcg):
+    """countergan.FUSE_BACKWARD_EPILOGUE: the LeakyReLU / ReLU derivative of the layer below, BatchNorm-backward's column sums
+    (bn1 of every residual block) and the skip-connection add are taken in the grad-input kernels' epilogue.  Against the separate
+    passes: the add is bit-identical by construction, masks use the same expression, only the order of the BatchNorm sums differs —
+    all G and D gradients of one training step agree to 2e-5 rel-L2 (entries that are pure summation noise excepted: a conv bias
+    in front of a BatchNorm has an exactly-zero gradient)."""
+    K = pcg.countergan
+    x, y, t, m = (a.to(DEV) for a in CR.synthetic_batch(32, seed=7))
+    grads = {}
+    try:
+        for fuse in (True, False):
+            K.FUSE_BACKWARD_EPILOGUE = fuse
+            (G, D, C), _ = _build(pcg, seed=4)
+            opt_g, opt_d, bce, ce = K.make_optimizers(G, D)
+            K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
+            grads[fuse] = {**{f"G.{n}": p.grad.clone() for n, p in G.named_parameters()},
+                           **{f"D.{n}": p.grad.clone() for n, p in D.named_parameters()}}
+    finally:
+        K.FUSE_BACKWARD_EPILOGUE = True
+    checked = 0
+    for k, ref in grads[False].items():
+        got = grads[True][k]
+        assert torch.isfinite(got).all(), k
+        if k.startswith("G.resblocks") and k.endswith((".conv1.bias", ".conv2.bias")):
+            continue   # zero in exact arithmetic (bias in front of BatchNorm): fp32 summation noise in every implementation
+        r, g_ = ref.double().cpu().numpy(), got.double().cpu().numpy()
+        l2 = np.linalg.norm(g_ - r) / max(np.linalg.norm(r), 1e-30)
+        assert l2 <= 2e-5, f"{k}: rel-L2 {l2:.2e}"
+        checked += 1
+    assert checked >= 45
