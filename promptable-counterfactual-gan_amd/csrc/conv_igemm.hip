@@ -131,6 +131,39 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   });
 }
 
+// col2im for the "one GEMM + scatter" form of the grad-input (see dgrad_as_gemm): dx[b,ih,iw,ci] = bias[ci] + sum over the taps
+// (kh,kw) that reach (ih,iw) of dcol[b,oh,ow][(kh,kw,ci)], taps added in (kh,kw) order.  Every dcol element is read once.
+__global__ void __launch_bounds__(256) col2im_kernel(const float4* __restrict__ dcol, float4* __restrict__ dx, const float* __restrict__ bias,
+                                                     int B, int IH, int IW, int CQ, int OH, int OW, int KH, int KW, int stride, int pad,
+                                                     FastDiv dCQ, FastDiv dIW, FastDiv dIH, int act, float neg) {
+  const uint32_t total = (uint32_t)B * IH * IW * CQ;
+  for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    uint32_t pix, cq, t, iw, b, ih;
+    dCQ.divmod(idx, pix, cq);
+    dIW.divmod(pix, t, iw);
+    dIH.divmod(t, b, ih);
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < KH; ++kh) {
+      const int th = (int)ih + pad - kh;
+      if (th < 0 || th % stride) continue;
+      const int oh = th / stride;
+      if (oh >= OH) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int tw = (int)iw + pad - kw;
+        if (tw < 0 || tw % stride) continue;
+        const int ow = tw / stride;
+        if (ow >= OW) continue;
+        const float4 v = dcol[((size_t)(((int)b * OH + oh) * OW + ow) * (KH * KW) + (kh * KW + kw)) * CQ + cq];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (act != PCG_ACT_NONE) {
+      acc.x = act_neg_scale(acc.x, neg); acc.y = act_neg_scale(acc.y, neg); acc.z = act_neg_scale(acc.z, neg); acc.w = act_neg_scale(acc.w, neg);
+    }
+    dx[idx] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -215,7 +248,9 @@ int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStre
   if (once != PCG_OK) return once;
   static const int il_env = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
   DgradPhases phl = ph;
-  bool same = nphases > 1 && il_env;
+  // only for small weight tensors: interleaved phases keep ALL phases' weight slices live in an XCD's 4 MB L2 at once (measured:
+  // WGAN-GP's 8 MB ConvT weights ran 20 % slower interleaved, DCGAN's 0.5 MB D2 / G4 layers 1-3 % faster)
+  bool same = nphases > 1 && il_env && p.w_bytes <= (1u << 20);
   for (int i = 1; i < nphases; ++i) same = same && ph.p[i].Mp == ph.p[0].Mp;
   phl.interleave = same ? nphases : 0;
   if (same)
@@ -257,9 +292,24 @@ extern "C" size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g) {
   const FwdPlan f = plan_fwd(g);
   return f.splits > 1 ? (size_t)f.splits * g->B * g->OH * g->OW * g->Cout * sizeof(float) : 0;
 }
+// Grad-input as ONE balanced GEMM + col2im.  With a kernel size that is not a multiple of the stride (k3 s2: WGAN-GP critic,
+// mnist_wgan_conditional.py:84-90) the sub-pixel phases see 4 : 2 : 2 : 1 taps; the phase kernel's longest blocks are then the
+// critical path (measured 30-60 TFLOP/s on the critic's conv2 / conv3).  dcol[B*OH*OW][KH*KW*Cin] = dy * W is the grad-input of
+// the 1x1 convolution with Cin' = KH*KW*Cin on the SAME weight bytes (OHWI rows are [Cout][KH*KW*Cin]) — same MACs as the phase
+// form, every block the same K = Cout — followed by a col2im pass over dcol (HBM-bound, 2 x |dcol| extra traffic).
+static bool dgrad_as_gemm(const pcg_conv_geom* g) {
+  if (thin_is_cin(g) || thin_is_cout(g)) return false;
+  if (g->stride < 2 || (g->KH % g->stride == 0 && g->KW % g->stride == 0)) return false;
+  if (g->Cout < 512 || g->Cin % 4 || g->Cout % 4) return false;          // K = Cout: >= 16 k-tiles per block
+  const int64_t bytes = (int64_t)g->B * g->OH * g->OW * g->KH * g->KW * g->Cin * 4;
+  return bytes < (1ll << 31);
+}
+static size_t dgrad_gemm_bytes(const pcg_conv_geom* g) { return (size_t)g->B * g->OH * g->OW * g->KH * g->KW * g->Cin * sizeof(float); }
+
 extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;
-  return (thin_is_cin(g) || thin_is_cout(g)) ? thin_conv_dgrad_workspace_bytes(g) : 0;
+  if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_dgrad_workspace_bytes(g);
+  return dgrad_as_gemm(g) ? dgrad_gemm_bytes(g) : 0;
 }
 
 namespace pcg {
@@ -354,6 +404,23 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
     return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
+  if (!epi && !stat_partial && dgrad_as_gemm(g) && workspace && workspace_bytes >= dgrad_gemm_bytes(g) &&
+      (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0) {
+    pcg_conv_geom g1 = {g->B, g->OH, g->OW, g->KH * g->KW * g->Cin, g->OH, g->OW, g->Cout, 1, 1, 1, 0};
+    float* dcol = (float*)workspace;
+    if (int e = conv2d_dgrad_impl(&g1, dy, w, nullptr, dcol, nullptr, nullptr, 0, stream)) return e;
+    const bool fuse_act = act_is_cheap(act);
+    const int CQ = g->Cin / 4;
+    const uint64_t total = (uint64_t)g->B * g->IH * g->IW * CQ;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(col2im_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(dcol),
+                       reinterpret_cast<float4*>(dx), bias_x, g->B, g->IH, g->IW, CQ, g->OH, g->OW, g->KH, g->KW, g->stride, g->pad,
+                       FastDiv((uint32_t)CQ), FastDiv((uint32_t)g->IW), FastDiv((uint32_t)g->IH), fuse_act ? act : PCG_ACT_NONE,
+                       act_neg_of(fuse_act ? act : PCG_ACT_NONE, slope));
+    if (int e = launch_status("col2im_kernel")) return e;
+    return fuse_act ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, stream);
+  }
   ConvP p = make_params(g);
   const bool fuse = act_is_cheap(act);
   p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx; p.stat_partial = stat_partial;
