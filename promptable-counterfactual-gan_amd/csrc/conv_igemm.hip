@@ -230,6 +230,19 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
   const int tiles = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64);
   const int ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
   FwdPlan f{1, ktiles};
+  if (tiles > 256 && tiles < 448 && ktiles >= 32) {
+    // a little over one block per CU (288 tiles: 32 CUs get two full-K blocks, the others one — the critic's conv2 at batch 256
+    // ran at 73 TFLOP/s): 3-4 K-slices bring the blocks per CU to ceil(tiles*s/256)/s ~ 1.25 instead of 2
+    int best = 1;
+    double bc = 2.0;
+    for (int s = 2; s <= 4; ++s) {
+      const double c = (double)ceil_div(tiles * s, 256) / s;
+      if (c < bc - 1e-9) { bc = c; best = s; }
+    }
+    f.ktiles_per_split = ceil_div(ktiles, best);
+    f.splits = ceil_div(ktiles, f.ktiles_per_split);
+    return f;
+  }
   if (tiles > 96 || ktiles < 32) return f;
   int splits = ceil_div(384, tiles);
   if (splits > ktiles / 8) splits = ktiles / 8;
@@ -276,6 +289,25 @@ WgradPlan plan_wgrad(const pcg_conv_geom* g) {
   const int max_splits = w.ktiles_total / 8 > 0 ? w.ktiles_total / 8 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  // When the tiles do not divide the chip (288 tiles of a 1024 x 4608 gradient: 32 CUs get two full-K blocks, the rest one) a few
+  // more K-slices balance the CUs at the price of slab traffic.  Cost model per candidate s, in us: n = blocks per CU (ceil),
+  // n * k-tiles per slice * time per k-tile (one block alone on a CU exposes its latencies: x1.2) + s slabs written and read
+  // at ~4 TB/s.  The 512-slot rule above stands unless the model sees > 5 % to gain (it agrees on every DCGAN / counteRGAN layer).
+  auto cost = [&](int s, int* s_eff) {
+    const int kps = ceil_div(w.ktiles_total, s), se = ceil_div(w.ktiles_total, kps);
+    const int n = ceil_div(w.tiles * se, 256);
+    *s_eff = se;
+    return (double)n * kps * (w.narrow ? 1.0 : 1.95) * (n == 1 ? 1.2 : 1.0) + (double)se * M * N * 8.0 / 4.0e6;
+  };
+  int se = 0;
+  const double c0 = cost(splits, &se);
+  double cb = c0;
+  int sb = splits;
+  for (int s = 1; s <= max_splits && s <= 64; ++s) {
+    const double c = cost(s, &se);
+    if (se == s && c < cb * 0.98) { cb = c; sb = s; }
+  }
+  if (cb < 0.95 * c0) splits = sb;
   w.ktiles_per_split = ceil_div(w.ktiles_total, splits);
   w.splits = ceil_div(w.ktiles_total, w.ktiles_per_split);
   return w;
