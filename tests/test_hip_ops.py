@@ -255,3 +255,36 @@ def test_fill_sumsq_colsum(pcg):
         db = torch.ones(C, device=d)
         ops.colsum(rows, C, torch.from_numpy(a).to(d), db, accumulate=True)
         np.testing.assert_allclose(db.cpu().numpy() - 1.0, a.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", [(2, 32, 512, 9, 9, 3, 2, 1), (3, 16, 512, 6, 6, 3, 2, 0), (2, 8, 640, 11, 7, 3, 2, 1)])
+def test_dgrad_gemm_col2im_path_equals_phase_kernel(pcg, B, Cin, Cout, H, W, k, s, p):
+    """Kernel sizes that are not a multiple of the stride (k3 s2: the WGAN-GP critic) take the 'one GEMM + col2im' grad-input when
+    the caller provides pcg_conv2d_dgrad_workspace_bytes of scratch, and the sub-pixel-phase kernel without it.  Same MACs, taps
+    summed per output pixel in a different association: both agree with each other and with torch's conv_transpose2d
+    (2e-6 * sqrt(K) * scale, the tolerance of the other conv tests), with a ConvTranspose bias and a fused ReLU on top."""
+    import ctypes
+    from pcgan_amd import _lib
+    ops = pcg.ops
+    g = ops.conv_geom(B, H, W, Cin, Cout, k, k, s, p)
+    gen = torch.Generator().manual_seed(B * 100 + Cin)
+    w = torch.randn(Cout, k, k, Cin, generator=gen) * 0.1
+    dy = torch.randn(B, g.OH, g.OW, Cout, generator=gen)
+    b_in = torch.randn(Cin, generator=gen)
+    lib = _lib.load()
+    assert lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g)) == B * g.OH * g.OW * k * k * Cin * 4
+    wd, dyd, bd = w.to(dev()), dy.to(dev()), b_in.to(dev())
+    got_gemm = ops.conv2d_dgrad(g, dyd, wd, bd, act=O.ACT_RELU)                       # workspace given -> GEMM + col2im
+    got_phase = torch.empty_like(got_gemm)
+    _lib.check(lib.pcg_conv2d_dgrad_act(ctypes.byref(g), ops._p(dyd), ops._p(wd), ops._p(bd), O.ACT_RELU, 0.0, ops._p(got_phase), None, 0,
+                                        ops._stream()), "pcg_conv2d_dgrad_act")          # no workspace -> phase kernel
+    ref = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b_in.double(), stride=s,
+                                               padding=p, output_padding=(H + 2 * p - k) % s if H == W else 0)
+    if ref.shape[2:] != (H, W):   # output_padding per axis
+        ref = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b_in.double(), stride=s,
+                                                   padding=p, output_padding=((H + 2 * p - k) % s, (W + 2 * p - k) % s))
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    tol = _tol(Cout * k * k, 4.0)
+    assert (got_gemm.cpu().double() - ref).abs().max().item() <= tol
+    assert (got_phase.cpu().double() - ref).abs().max().item() <= tol
+    assert (got_gemm - got_phase).abs().max().item() <= tol
