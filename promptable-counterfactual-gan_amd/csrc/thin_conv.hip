@@ -331,7 +331,16 @@ int launch_expand(ThinP& p, hipStream_t s) {
 }
 
 // scratch the two-stage reduce wants: T[wide pixels][16]
+// 2..3 thin channels, 3x3 taps: 18 / 27 dot products per wide pixel, T rows of 32 floats
+bool fast32_ok(const ThinP& p) {
+  return p.Cs >= 2 && p.Cs <= 3 && p.KH == 3 && p.KW == 3 && p.stride <= 2 && p.C % 16 == 0 && lds_weight_bytes(p) <= 64 * 1024;
+}
+
 size_t reduce_scratch_bytes(const ThinP& p) {
+  if (fast32_ok(p)) {
+    const int64_t b = (int64_t)p.B * p.WH * p.WW * 32 * 4;
+    return b < (1ll << 31) ? (size_t)b : 0;
+  }
   if (!fast_ok(p)) return 0;
   const int64_t b = (int64_t)p.B * p.WH * p.WW * 16 * 4;
   return b < (1ll << 31) ? (size_t)b : 0;
@@ -341,6 +350,20 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
   const size_t smem = lds_weight_bytes(p);
   PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
   const size_t need = reduce_scratch_bytes(p);
+  if (need && ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0 && fast32_ok(p)) {
+    float* T = (float*)ws;
+    ThinP q = p;
+    q.npix = p.B * p.WH * p.WW;  // stage 1 walks the wide tensor
+    unsigned blocks = (unsigned)((q.npix + 15) / 16);
+    if (blocks > 8192) blocks = 8192;
+    if (p.Cs == 2) hipLaunchKernelGGL(thin_tapdot32_kernel<18>, dim3(blocks), dim3(256), smem, s, q, T);
+    else hipLaunchKernelGGL(thin_tapdot32_kernel<27>, dim3(blocks), dim3(256), smem, s, q, T);
+    if (int e = launch_status("thin_tapdot32_kernel")) return e;
+    unsigned b2 = (unsigned)(((int64_t)p.npix * p.Cs + 255) / 256);
+    if (b2 > 8192) b2 = 8192;
+    hipLaunchKernelGGL(thin_col2im32_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need);
+    return launch_status("thin_col2im32_kernel");
+  }
   if (need && ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0) {
     float* T = (float*)ws;
     ThinP q = p;
