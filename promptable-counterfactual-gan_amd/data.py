@@ -5,6 +5,7 @@
     dset.MNIST(root, train=True) raw idx files                        read_idx_images / read_idx_labels (host, numpy)
     transforms.Resize(64) + ToTensor + Normalize((0.5,), (0.5,))      ResizeNormalize (device, bit-exact Pillow bilinear)
       dconv_gan/mnist/mnist_dcgan.py:42-46
+    data_utils.load_and_preprocess(csv, config)  (house_sales_kc_usa/data_utils.py:5-41)   load_house_sales / MinMax (host, numpy)
 """
 import gzip
 import math
@@ -86,3 +87,81 @@ class ResizeNormalize:
                                                     ops._p(xb), ops._p(xk), self.xks, ops._p(yb), ops._p(yk), self.yks, self.mean, self.std,
                                                     ops._p(out), ops._stream()), "pcg_resize8_normalize")
         return out
+
+
+# ---- house_sales_kc_usa/data_utils.py:5-41 — CSV -> quartile price classes -> 80/20 split -> MinMax (host side, as in the reference) ----
+class MinMax:
+    """The part of sklearn's MinMaxScaler (feature_range (0, 1)) the reference uses: fit on the training split, `transform`,
+    `inverse_transform`, and the attributes trainer.py:207-217 reads (`data_min_`, `data_max_`, `scale_`, `min_`).  Same arithmetic
+    and order of operations as sklearn (X * scale_ + min_, zero ranges scaled by 1), so results are bit-identical."""
+
+    def fit(self, X):
+        X = np.asarray(X, np.float64)
+        self.data_min_, self.data_max_ = X.min(axis=0), X.max(axis=0)
+        self.data_range_ = self.data_max_ - self.data_min_
+        rng = self.data_range_.copy()
+        rng[rng < 10 * np.finfo(rng.dtype).eps] = 1.0          # sklearn _handle_zeros_in_scale
+        self.scale_ = 1.0 / rng
+        self.min_ = 0.0 - self.data_min_ * self.scale_
+        self.n_features_in_ = X.shape[1]
+        return self
+
+    def transform(self, X):
+        X = np.array(X, np.float64, copy=True)
+        X *= self.scale_
+        X += self.min_
+        return X
+
+    def fit_transform(self, X):
+        return self.fit(X).transform(X)
+
+    def inverse_transform(self, X):
+        X = np.array(X, np.float64, copy=True)
+        X -= self.min_
+        X /= self.scale_
+        return X
+
+
+def _split_indices(n, test_size=0.2, seed=42):
+    """sklearn.model_selection.train_test_split(shuffle=True): ShuffleSplit's one permutation of a RandomState(seed) — the first
+    ceil(test_size * n) indices are the test rows, the next floor((1 - test_size) * n) the training rows."""
+    n_test = int(math.ceil(test_size * n))
+    n_train = int(math.floor((1.0 - test_size) * n))
+    perm = np.random.RandomState(seed).permutation(n)
+    return perm[n_test:n_test + n_train], perm[:n_test]
+
+
+def load_house_sales(data_path, config, verbose=False):
+    """house_sales_kc_usa/data_utils.py:5-41 `load_and_preprocess(data_path, config)` without pandas / scikit-learn:
+    drop id / date / zipcode (:9), bedrooms clipped at 8 (:10), price -> 4 quartile classes (pd.qcut: linear-interpolated
+    quantiles, right-closed bins, lowest edge included, :12-13), features = every remaining column but the price (:26), 80/20
+    shuffle split with seed 42 (:37), MinMax fitted on the training split (:39-41).  Stores `bins` and `scaler` in `config`
+    like the reference.  Returns (X_train_scaled, X_test_scaled, y_train, y_test) as float64 / int64 arrays."""
+    import csv
+    with open(data_path, newline="") as f:
+        rd = csv.reader(f)
+        header = next(rd)
+        rows = [r for r in rd if r]
+    drop = {"id", "date", "zipcode"}
+    keep = [i for i, h in enumerate(header) if h not in drop]
+    names = [header[i] for i in keep]
+    data = np.array([[float(r[i]) for i in keep] for r in rows], np.float64)
+    if "bedrooms" in names:
+        b = names.index("bedrooms")
+        data[data[:, b] > 8, b] = 8.0
+    price = data[:, names.index("price")]
+    bins = np.unique(np.quantile(price, [0.0, 0.25, 0.5, 0.75, 1.0]))               # duplicates='drop'
+    y = np.clip(np.searchsorted(bins, price, side="left") - 1, 0, len(bins) - 2).astype(np.int64)   # (lo, hi] bins, lowest included
+    config["bins"] = bins
+    feat = [i for i, nme in enumerate(names) if nme != "price"]
+    X = data[:, feat]
+    if verbose:
+        for i in range(len(bins) - 1):
+            print(f"Class {i}: ${bins[i]:,.0f} - ${bins[i + 1]:,.0f}")
+    tr, te = _split_indices(len(X))
+    scaler = MinMax()
+    X_train = scaler.fit_transform(X[tr])
+    X_test = scaler.transform(X[te])
+    config["scaler"] = scaler
+    config["feature_names"] = [names[i] for i in feat]
+    return X_train, X_test, y[tr], y[te]

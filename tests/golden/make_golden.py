@@ -594,6 +594,38 @@ def _replay_dropout(store):
     return masks
 
 
+def make_house_preprocess(path_csv, path_npz, nrows=3000):
+    """SURVEY.md section 8f item 4 — house_sales_kc_usa/data_utils.py:load_and_preprocess run UNMODIFIED (imported) on the first
+    `nrows` data rows of the dataset the reference ships (kc_house_data.csv; the subset is committed as a data fixture, the
+    full file does not travel).  Stored: both scaled splits, both label vectors, the quartile bin edges and the scaler range."""
+    import contextlib, importlib, io
+    mdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    with open(os.path.join(mdir, "kc_house_data.csv")) as f:
+        lines = f.readlines()
+    with open(path_csv, "w") as f:
+        f.writelines(lines[: nrows + 1])
+    scratch = "/tmp/pcg_golden_house"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        sys.path.insert(0, mdir)
+        for name in list(sys.modules):
+            if name in ("config", "data_utils"):
+                sys.modules.pop(name)
+        data_utils = importlib.import_module("data_utils")
+        cfg = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            Xtr, Xte, ytr, yte = data_utils.load_and_preprocess(path_csv, cfg)
+        np.savez_compressed(path_npz, X_train=np.asarray(Xtr, np.float64), X_test=np.asarray(Xte, np.float64),
+                            y_train=np.asarray(ytr, np.int64), y_test=np.asarray(yte, np.int64), bins=np.asarray(cfg["bins"], np.float64),
+                            data_min=np.asarray(cfg["scaler"].data_min_, np.float64), data_max=np.asarray(cfg["scaler"].data_max_, np.float64))
+        print(f"wrote {path_npz}: train {Xtr.shape}, test {Xte.shape}, bins {cfg['bins']}")
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(mdir)
+
+
 def make_classifier_pretrain(path_mnist, path_house):
     """SURVEY.md section 8f item 3 — the classifier pre-training loops, run by the reference's own functions:
     conditional_counteRGAN/mnist/trainer.py:train_classifier (:8-39) on two seeded batches + one validation batch, and
@@ -740,3 +772,4 @@ if __name__ == "__main__":
     make_countergan_eval(os.path.join(HERE, "countergan_eval.npz"))
     make_classifier_pretrain(os.path.join(HERE, "classifier_pretrain_mnist.npz"), os.path.join(HERE, "classifier_pretrain_house.npz"))
     make_mnist_resize(os.path.join(HERE, "mnist_resize.npz"))
+    make_house_preprocess(os.path.join(HERE, "kc_house_head3000.csv"), os.path.join(HERE, "house_preprocess.npz"))

@@ -34,3 +34,25 @@ def test_idx_readers(tmp_path):
     (tmp_path / "lab").write_bytes(struct.pack(">II", 2049, 3) + bytes([7, 0, 9]))
     assert np.array_equal(data.read_idx_images(tmp_path / "img"), imgs)
     assert np.array_equal(data.read_idx_labels(tmp_path / "lab"), np.array([7, 0, 9]))
+
+
+def test_house_sales_preprocessing_matches_reference_bit_for_bit(golden_dir):
+    """`pcgan_amd.data.load_house_sales` (numpy only) against the reference's own
+    `data_utils.load_and_preprocess` (pandas qcut + sklearn train_test_split + MinMaxScaler), run unmodified by
+    tests/golden/make_golden.py on the first 3000 rows of the dataset it ships: same quartile edges, same labels, same shuffled
+    split, and bit-identical scaled features (float64)."""
+    import os
+    import numpy as np
+    from pcgan_amd import data
+    gold = np.load(os.path.join(golden_dir, "house_preprocess.npz"))
+    cfg = {}
+    Xtr, Xte, ytr, yte = data.load_house_sales(os.path.join(golden_dir, "kc_house_head3000.csv"), cfg)
+    assert np.array_equal(cfg["bins"], gold["bins"])
+    assert np.array_equal(ytr, gold["y_train"]) and np.array_equal(yte, gold["y_test"])
+    assert Xtr.dtype == np.float64 and Xtr.shape == gold["X_train"].shape and Xte.shape == gold["X_test"].shape
+    assert np.array_equal(Xtr, gold["X_train"]) and np.array_equal(Xte, gold["X_test"])
+    sc = cfg["scaler"]
+    assert np.array_equal(sc.data_min_, gold["data_min"]) and np.array_equal(sc.data_max_, gold["data_max"])
+    back = sc.inverse_transform(Xte)
+    assert np.allclose(sc.transform(back), Xte, rtol=0, atol=1e-12)
+    assert len(cfg["feature_names"]) == 17 and cfg["feature_names"][0] == "bedrooms"
