@@ -6,6 +6,8 @@
     transforms.Resize(64) + ToTensor + Normalize((0.5,), (0.5,))      ResizeNormalize (device, bit-exact Pillow bilinear)
       dconv_gan/mnist/mnist_dcgan.py:42-46
     data_utils.load_and_preprocess(csv, config)  (house_sales_kc_usa/data_utils.py:5-41)   load_house_sales / MinMax (host, numpy)
+    data_utils.get_dataloaders(...)  (conditional_counteRGAN/mnist/data_utils.py:6-32)      get_dataloaders / normalize_mnist /
+                                                                                          stratified_split / DeviceLoader
 """
 import gzip
 import math
@@ -165,3 +167,75 @@ def load_house_sales(data_path, config, verbose=False):
     config["scaler"] = scaler
     config["feature_names"] = [names[i] for i in feat]
     return X_train, X_test, y[tr], y[te]
+
+
+# ---- conditional_counteRGAN/mnist/data_utils.py:6-32 — MNIST idx -> ToTensor + Normalize -> stratified 90/10 split -> loaders ----------
+def normalize_mnist(images_u8, device):
+    """transforms.ToTensor() + Normalize((0.5,), (0.5,)) (data_utils.py:9-12) for a whole uint8 image array at once:
+    [N, H, W] uint8 -> [N, 1, H, W] float32 in [-1, 1] on `device`, with torchvision's two roundings (x / 255, then (v - 0.5) / 0.5).
+    One-off upload of the data set (plumbing: plain tensor arithmetic, not a hot-path kernel)."""
+    x = torch.from_numpy(np.array(images_u8, dtype=np.uint8, copy=True)).to(device)     # frombuffer arrays are read-only
+    return x.to(torch.float32).div_(255.0).sub_(0.5).div_(0.5).unsqueeze(1)
+
+
+def stratified_split(labels, test_size=0.1, seed=None):
+    """train_test_split(indices, test_size=0.1, stratify=targets) (data_utils.py:19): every class keeps its share in both parts
+    (largest-remainder rounding of the per-class test counts, like sklearn's StratifiedShuffleSplit).  The reference call is
+    unseeded, so only the stratification is reproducible, not the particular indices."""
+    labels = np.asarray(labels)
+    rng = np.random.RandomState(seed)
+    n = len(labels)
+    n_test = int(math.ceil(test_size * n))
+    classes, counts = np.unique(labels, return_counts=True)
+    want = counts * (n_test / n)
+    take = np.floor(want).astype(int)
+    for c in np.argsort(-(want - take), kind="stable")[: n_test - take.sum()]:
+        take[c] += 1
+    train, test = [], []
+    for c, k in zip(classes, take):
+        idx = rng.permutation(np.nonzero(labels == c)[0])
+        test.append(idx[:k]); train.append(idx[k:])
+    return rng.permutation(np.concatenate(train)), rng.permutation(np.concatenate(test))
+
+
+class DeviceLoader:
+    """What `train_countergan(generator, discriminator, classifier, train_loader, cfg, device)` iterates over (trainer.py:89:
+    `for x, y in train_loader`): batches of a data set that already lives on the device — DataLoader(shuffle=True) without the
+    per-batch host collation and PCIe copy (60000 x 784 floats = 188 MB of 288 GB).  Like DataLoader, the last short batch is
+    kept, and each epoch draws a new permutation."""
+
+    def __init__(self, x, y, batch_size, shuffle=True, seed=None):
+        if x.shape[0] != y.shape[0]:
+            raise PcgError(f"DeviceLoader: {x.shape[0]} samples but {y.shape[0]} labels")
+        self.x, self.y, self.batch_size, self.shuffle = x, y, int(batch_size), shuffle
+        self._gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self._gen.manual_seed(seed)
+
+    def __len__(self):
+        return (self.x.shape[0] + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.x.shape[0]
+        order = torch.randperm(n, generator=self._gen).to(self.x.device) if self.shuffle else None
+        for i in range(0, n, self.batch_size):
+            if order is None:
+                yield self.x[i:i + self.batch_size], self.y[i:i + self.batch_size]
+            else:
+                idx = order[i:i + self.batch_size]
+                yield self.x.index_select(0, idx), self.y.index_select(0, idx)
+
+
+def get_dataloaders(images_path, labels_path, test_images_path, test_labels_path, batch_size=128, device="cuda", valid_size=0.1, seed=None):
+    """data_utils.py:6-32 on the raw idx files: (train_loader, valid_loader, test_loader, (x_full, y_full)) with the data set
+    normalised once and resident on `device`."""
+    x = normalize_mnist(read_idx_images(images_path), device)
+    y_np = read_idx_labels(labels_path)
+    y = torch.from_numpy(y_np).to(device)
+    tr, va = stratified_split(y_np, valid_size, seed)
+    tr_t, va_t = torch.from_numpy(tr).to(device), torch.from_numpy(va).to(device)
+    xt = normalize_mnist(read_idx_images(test_images_path), device)
+    yt = torch.from_numpy(read_idx_labels(test_labels_path)).to(device)
+    return (DeviceLoader(x.index_select(0, tr_t), y.index_select(0, tr_t), batch_size, True, seed),
+            DeviceLoader(x.index_select(0, va_t), y.index_select(0, va_t), batch_size, False),
+            DeviceLoader(xt, yt, batch_size, False), (x, y))

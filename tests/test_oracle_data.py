@@ -56,3 +56,39 @@ def test_house_sales_preprocessing_matches_reference_bit_for_bit(golden_dir):
     back = sc.inverse_transform(Xte)
     assert np.allclose(sc.transform(back), Xte, rtol=0, atol=1e-12)
     assert len(cfg["feature_names"]) == 17 and cfg["feature_names"][0] == "bedrooms"
+
+
+def test_mnist_loader_pieces_host_logic(tmp_path):
+    """conditional_counteRGAN/mnist/data_utils.py:6-32 restated for device-resident data (checked here on CPU tensors: the
+    pieces are tensor plumbing, no HIP kernel): ToTensor + Normalize arithmetic, the stratified 90/10 split, DataLoader-like
+    batching (last short batch kept, a fresh permutation per epoch, every sample exactly once)."""
+    import gzip, struct
+    import numpy as np
+    import torch
+    from pcgan_amd import data
+    rng = np.random.RandomState(0)
+    imgs = rng.randint(0, 256, size=(203, 28, 28)).astype(np.uint8)
+    labels = rng.randint(0, 10, size=203).astype(np.uint8)
+    pi, pl = tmp_path / "img-idx3-ubyte.gz", tmp_path / "lab-idx1-ubyte"
+    with gzip.open(pi, "wb") as f:
+        f.write(struct.pack(">IIII", 2051, 203, 28, 28) + imgs.tobytes())
+    with open(pl, "wb") as f:
+        f.write(struct.pack(">II", 2049, 203) + labels.tobytes())
+    x = data.normalize_mnist(data.read_idx_images(pi), "cpu")
+    want = (torch.from_numpy(imgs).float().div(255).unsqueeze(1) - 0.5) / 0.5            # ToTensor, then Normalize((0.5,), (0.5,))
+    assert x.shape == (203, 1, 28, 28) and torch.equal(x, want) and x.min() >= -1 and x.max() <= 1
+    tr, va = data.stratified_split(labels, 0.1, seed=3)
+    assert len(va) == 21 and len(tr) == 182 and len(np.intersect1d(tr, va)) == 0
+    cnt, cva = np.bincount(labels, minlength=10), np.bincount(labels[va], minlength=10)
+    assert np.all(np.abs(cva - cnt * 0.1) < 1.0)                                             # every class keeps its share
+    tl, vl, sl, (xf, yf) = data.get_dataloaders(pi, pl, pi, pl, batch_size=64, device="cpu", seed=1)
+    assert len(tl) == 3 and len(vl) == 1 and len(sl) == 4 and xf.shape[0] == 203
+    seen = []
+    for e in range(2):
+        got = [(xb, yb) for xb, yb in tl]
+        assert [b[0].shape[0] for b in got] == [64, 64, 54] and all(b[0].shape[1:] == (1, 28, 28) for b in got)
+        seen.append(torch.cat([b[1] for b in got]))
+    assert not torch.equal(seen[0], seen[1]) and torch.equal(seen[0].sort().values, seen[1].sort().values)
+    for xb, yb in sl:                                                                       # unshuffled: file order
+        pass
+    assert torch.equal(torch.cat([b[1] for b in sl]), torch.from_numpy(labels.astype(np.int64)))
