@@ -438,9 +438,75 @@ __global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBat
 
 using namespace pcg;
 
+namespace {
+// C[m][n] = act(sum_k A[m][k] * W[n][k] + bias[n]) for 1..4 output columns and a long K (the critic's Linear(1024 -> 1) head,
+// mnist_wgan_conditional.py:101): one wave per row, lanes stride over k with 16-byte loads, butterfly sum.  The 64x64-tile kernel
+// above runs such a shape as M/64 blocks of K/16 dependent load -> LDS -> barrier steps (140 us for 768 x 1024 -> 1; this: ~5 us).
+template <int NN>
+__global__ void __launch_bounds__(256) rowdot_kernel(int M, int K, const float* __restrict__ A, int lda, const float* __restrict__ W, int ldb,
+                                                     float* __restrict__ C, int ldc, const float* __restrict__ bias, int accumulate,
+                                                     int act_on, float neg) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* a = A + (size_t)row * lda;
+  float acc[NN];
+#pragma unroll
+  for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+  const bool vec = ((((uintptr_t)a | (uintptr_t)W) & 15) == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+  int k = 0;
+  if (vec) {
+    for (k = lane * 4; k + 3 < K; k += 256) {
+      const float4 av = *reinterpret_cast<const float4*>(a + k);
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const float4 wv = *reinterpret_cast<const float4*>(W + (size_t)n * ldb + k);
+        acc[n] = fmaf(av.x, wv.x, acc[n]); acc[n] = fmaf(av.y, wv.y, acc[n]); acc[n] = fmaf(av.z, wv.z, acc[n]); acc[n] = fmaf(av.w, wv.w, acc[n]);
+      }
+    }
+    k = K & ~3;                         // scalar tail below
+    k += lane;
+  } else {
+    k = lane;
+  }
+  for (; k < K; k += 64) {
+    const float av = a[k];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = fmaf(av, W[(size_t)n * ldb + k], acc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    float v = acc[n];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) {
+      v += bias ? bias[n] : 0.f;
+      float* c = C + (size_t)row * ldc + n;
+      if (accumulate) v += *c;
+      if (act_on) v = act_neg_scale(v, neg);
+      *c = v;
+    }
+  }
+}
+
+bool launch_rowdot(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, int accumulate, int act_on, float neg, hipStream_t s) {
+  if (transA || !transB || N > 4 || K < 256) return false;
+  const dim3 grid((M + 3) / 4), block(256);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(rowdot_kernel<1>, grid, block, 0, s, M, K, A, lda, B, ldb, C, ldc, bias, accumulate, act_on, neg); break;
+    case 2: hipLaunchKernelGGL(rowdot_kernel<2>, grid, block, 0, s, M, K, A, lda, B, ldb, C, ldc, bias, accumulate, act_on, neg); break;
+    case 3: hipLaunchKernelGGL(rowdot_kernel<3>, grid, block, 0, s, M, K, A, lda, B, ldb, C, ldc, bias, accumulate, act_on, neg); break;
+    default: hipLaunchKernelGGL(rowdot_kernel<4>, grid, block, 0, s, M, K, A, lda, B, ldb, C, ldc, bias, accumulate, act_on, neg); break;
+  }
+  return true;
+}
+}  // namespace
+
 extern "C" int pcg_gemm(int transA, int transB, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                         int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, pcg_stream_t stream) {
   PCG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "pcg_gemm: bad arguments");
+  if (launch_rowdot(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, 0, 1.f, (hipStream_t)stream)) return launch_status("rowdot_kernel");
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
                      A, lda, B, ldb, C, ldc, bias, accumulate, 0, 1.f);
   return launch_status("gemm_kernel");
@@ -450,6 +516,8 @@ extern "C" int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_
                             int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, int act, float slope, pcg_stream_t stream) {
   PCG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N, "pcg_gemm_act: bad arguments");
   PCG_REQUIRE(act_is_cheap(act), "pcg_gemm_act: only ReLU / LeakyReLU are fused (activation %d)", act);
+  if (launch_rowdot(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope), (hipStream_t)stream))
+    return launch_status("rowdot_kernel");
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
                      A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope));
   return launch_status("gemm_kernel");

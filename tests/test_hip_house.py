@@ -52,6 +52,15 @@ def test_gemm_all_layouts(pcg):
                 ref = (A.double().T if tA else A.double()) @ (Bm.double().T if tB else Bm.double()) + bias.double()
                 out = ops.gemm(_dev(A), _dev(Bm), M, N, K, transA=tA, transB=tB, bias=_dev(bias))
                 _close(out, ref, 2e-5, 2e-5, f"{M}x{N}x{K} tA={tA} tB={tB}")
+    # long K, 1..4 output columns (the critic heads: Linear(1024 -> 1)): the one-wave-per-row kernel; K % 4 != 0 and an unaligned
+    # row stride take its scalar paths; accumulate + fused LeakyReLU on top
+    for (M, N, K, lda) in [(768, 1, 1024, 1024), (5, 4, 1027, 1027), (130, 3, 300, 304), (9, 2, 256, 260)]:
+        Aw, Bm, bias, C0 = torch.randn(M, lda, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ref = Aw[:, :K].double() @ Bm.double().T + bias.double()
+        _close(ops.gemm(_dev(Aw), _dev(Bm), M, N, K, transB=True, lda=lda, bias=_dev(bias)), ref, 2e-5, 1e-4, f"rowdot {M}x{N}x{K}")
+        Cd = _dev(C0)
+        ops.gemm(_dev(Aw), _dev(Bm), M, N, K, transB=True, lda=lda, bias=_dev(bias), out=Cd, accumulate=True, act=pcg.ops.ACT_LRELU, slope=0.2)
+        _close(Cd, torch.nn.functional.leaky_relu(ref + C0.double(), 0.2), 2e-5, 1e-4, f"rowdot acc+act {M}x{N}x{K}")
     # column slices: A = columns 3..3+K of a wider buffer, C = columns 5..5+N of a wider buffer, accumulate on top
     M, N, K = 50, 9, 12
     Aw, Bm, Cw = torch.randn(M, 40, generator=g), torch.randn(N, K, generator=g), torch.randn(M, 30, generator=g)
