@@ -30,6 +30,31 @@ __global__ void __launch_bounds__(256) embed_concat_fwd_kernel(const float* __re
   }
 }
 
+// dtable[k][p] (+)= sum over b with idx[b]==k of dinp[b][p][1]: thread (i = (k,p), g) adds the matching rows of batch chunk g in
+// ascending order, the 16 chunk sums are added in chunk order through LDS (fixed association: reproducible).  One thread per (k,p)
+// walking the whole batch alone was a 1024-step dependent chain in 31 blocks (108 us at batch 1024).
+__global__ void __launch_bounds__(256) embed_table_grad_kernel(const float* __restrict__ dinp, const int64_t* __restrict__ idx,
+                                                               float* __restrict__ dtable, int B, int HW, int C, int K, int accumulate) {
+  __shared__ float red[16][16];
+  const int il = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il, total = K * HW;
+  float s = 0.f;
+  if (i < total) {
+    const int k = i / HW, p = i - k * HW;
+    const int chunk = (B + 15) / 16, b0 = g * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
+    for (int b = b0; b < b1; ++b)
+      if (idx[b] == (int64_t)k) s += dinp[((size_t)b * HW + p) * C + 1];
+  }
+  red[g][il] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float t = accumulate ? dtable[i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][il];
+    dtable[i] = t;
+  }
+}
+
 // dtable[k][p] (+)= sum over b with idx[b]==k (ascending b) of dinp[b][p][1] ; dx[b][p] = dinp[b][p][0] (optional)
 __global__ void __launch_bounds__(256) embed_concat_bwd_kernel(const float* __restrict__ dinp, const int64_t* __restrict__ idx,
                                                                float* __restrict__ dtable, float* __restrict__ dx, int B, int HW,
@@ -147,14 +172,16 @@ __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restric
   }
 }
 
-// softmax cross-entropy, reduction mean: one thread per row (K is the number of classes: 10)
-__global__ void __launch_bounds__(256) cross_entropy_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, int B,
-                                                            int K, float grad_scale, const float* __restrict__ gout,
-                                                            float* loss, float* __restrict__ dz) {
-  __shared__ float red[256];
+// softmax cross-entropy, reduction mean: one thread per row (K is the number of classes: 10), ONE block so that the loss is summed
+// in a fixed order; 1024 threads for large batches (batch 4096 on 256 threads was 16 rows of expf/logf per thread: 24 us)
+__global__ void __launch_bounds__(1024) cross_entropy_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, int B,
+                                                             int K, float grad_scale, const float* __restrict__ gout,
+                                                             float* loss, float* __restrict__ dz) {
+  __shared__ float red[1024];
+  const int nt = blockDim.x;    // power of two
   float acc = 0.f;
   const float g = grad_scale * (gout ? gout[0] : 1.f) / (float)B;
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = threadIdx.x; b < B; b += nt) {
     const float* r = z + (size_t)b * K;
     float mx = r[0];
     for (int k = 1; k < K; ++k) mx = fmaxf(mx, r[k]);
@@ -169,7 +196,7 @@ __global__ void __launch_bounds__(256) cross_entropy_kernel(const float* __restr
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = nt >> 1; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -192,6 +219,13 @@ extern "C" int pcg_embed_concat_fwd(const float* x, const int64_t* idx, const fl
 extern "C" int pcg_embed_concat_bwd(const float* dinp, const int64_t* idx, float* dtable, float* dx, int32_t B, int32_t HW,
                                     int32_t C, int32_t K, int accumulate, pcg_stream_t stream) {
   PCG_REQUIRE(dinp && idx && (dtable || dx) && B > 0 && HW > 0 && K > 0 && C >= 2, "pcg_embed_concat_bwd: bad arguments");
+  if (dtable && B >= 64) {     // table gradient with the batch split over 16 thread groups; the optional dx copy as its own launch
+    hipLaunchKernelGGL(embed_table_grad_kernel, dim3((unsigned)(((size_t)K * HW + 15) / 16)), dim3(256), 0, (hipStream_t)stream, dinp, idx,
+                       dtable, B, HW, C, K, accumulate);
+    if (int e = launch_status("embed_table_grad_kernel")) return e;
+    if (!dx) return PCG_OK;
+    dtable = nullptr;
+  }
   const size_t work = dx ? (size_t)B * HW : (size_t)K * HW;
   hipLaunchKernelGGL(embed_concat_bwd_kernel, dim3(ew_blocks(work)), dim3(256), 0, (hipStream_t)stream, dinp, idx, dtable, dx, B, HW,
                      C, K, accumulate);
@@ -274,8 +308,8 @@ extern "C" int pcg_avgpool_bwd(const float* dy, float* dx, int32_t B, int32_t HW
 extern "C" int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, int32_t B, int32_t K, float grad_scale,
                                          const float* grad_out_dev, float* loss, float* dlogits, pcg_stream_t stream) {
   PCG_REQUIRE(logits && target && B > 0 && K > 0 && (loss || dlogits), "pcg_cross_entropy_fwd_bwd: bad arguments");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, B, K, grad_scale, grad_out_dev,
-                     loss, dlogits);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, (hipStream_t)stream, logits, target, B, K, grad_scale,
+                     grad_out_dev, loss, dlogits);
   return launch_status("cross_entropy_kernel");
 }
 

@@ -215,6 +215,38 @@ __global__ void __launch_bounds__(256) slab_reduce4_kernel(const float4* __restr
     o[i] = a;
   }
 }
+// Few outputs, many slabs (the thin layers' 1024-float gradients arrive as 512 slabs): one thread per output would walk all slabs
+// alone (4 blocks, 64 dependent load batches: 24 us).  Here 16 threads share an output: thread (i, g) adds slabs g, g+16, ... in
+// order, the 16 group sums are added in group order through LDS — a fixed association, reproducible run to run.
+__global__ void __launch_bounds__(256) slab_reduce4_wide_kernel(const float4* __restrict__ s, float4* __restrict__ o, size_t n4,
+                                                                size_t stride4, int nslabs, int accumulate) {
+  __shared__ float4 red[16][16];
+  const int il = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + il;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int z = g;
+    for (; z + 7 * 16 < nslabs; z += 8 * 16) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s[(size_t)(z + 16 * j) * stride4 + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; z < nslabs; z += 16) {
+      const float4 v = s[(size_t)z * stride4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[g][il] = a;
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    float4 t = accumulate ? o[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float4 v = red[j][il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    o[i] = t;
+  }
+}
 __global__ void __launch_bounds__(256) slab_reduce1_kernel(const float* __restrict__ s, float* __restrict__ o, size_t n,
                                                            size_t stride, int nslabs, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -413,6 +445,11 @@ int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_strid
   const bool vec = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)slab | (uintptr_t)dw) & 15) == 0;
   if (vec) {
     const size_t n4 = n / 4;
+    if (nslabs >= 64 && n4 <= 16 * 1024) {   // few outputs, many slabs: 16 threads per output
+      hipLaunchKernelGGL(slab_reduce4_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, reinterpret_cast<const float4*>(slab),
+                         reinterpret_cast<float4*>(dw), n4, slab_stride / 4, nslabs, accumulate);
+      return launch_status("slab_reduce_kernel");
+    }
     unsigned blocks = (unsigned)((n4 + 63) / 64);
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
