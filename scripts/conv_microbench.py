@@ -21,6 +21,8 @@ LAYERS = {
     "G1": (512, 100, 4, 4, 1, 0), "G2": (256, 512, 8, 4, 2, 1), "G3": (128, 256, 16, 4, 2, 1), "G4": (64, 128, 32, 4, 2, 1),
     "G5": (1, 64, 64, 4, 2, 1),
     "R64": (64, 64, 28, 3, 1, 1),
+    # tile-overhead probes: the same N = 64 output with longer K (9 x Cin), and N = 128 with the short K
+    "R128x64": (128, 64, 28, 3, 1, 1), "R256x64": (256, 64, 28, 3, 1, 1), "R64x128": (64, 128, 28, 3, 1, 1),
     # counteRGAN thin layers: conv_in 3->64, conv_out 64->1, discriminator entry 2->64 (s2)
     "CI": (3, 64, 28, 3, 1, 1), "CO": (64, 1, 28, 3, 1, 1), "CD": (2, 64, 28, 3, 2, 1),
     # WGAN-GP (mnist_wgan_conditional.py:51-108) at width 1024: critic convs, critic Linear 8192->1024, generator ConvT adjoints
