@@ -170,13 +170,17 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p,
 
 int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                 double wd, int decoupled, AdamHyper hy, const AdamHyper* hy_dev, hipStream_t s) {
-  const bool vec = (n % 4 == 0) && al16(param) && al16(grad) && al16(m) && al16(v);
+  const bool al = al16(param) && al16(grad) && al16(m) && al16(v);
   const AdamConst k{(float)lr, (float)(1.0 - beta1), (float)(1.0 - (1.0 - beta1)), (float)beta2, (float)(1.0 - beta2), (float)eps,
                     (float)wd, decoupled};
-  if (vec)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)n, k, hy, hy_dev);
-  else
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, param, grad, m, v, (size_t)n, k, hy, hy_dev);
+  // 16-byte lanes over the bulk, a scalar launch for the 1..3 trailing elements (a flat buffer that ends in a bias of one element —
+  // the WGAN-GP critic's Linear(1024, 1) — used to send all 25 M parameters down the scalar kernel)
+  const int64_t bulk = al ? (n & ~(int64_t)3) : 0;
+  if (bulk)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)bulk / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, k, hy, hy_dev);
+  if (n > bulk)
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)(n - bulk))), dim3(256), 0, s, param + bulk, grad + bulk, m + bulk, v + bulk,
+                       (size_t)(n - bulk), k, hy, hy_dev);
   return launch_status("adam_kernel");
 }
 
@@ -248,8 +252,9 @@ extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* 
 extern "C" int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream) {
   PCG_REQUIRE(p && n > 0, "pcg_fill: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (n % 4 == 0 && al16(p)) hipLaunchKernelGGL(fill_kernel<4>, dim3(ew_blocks((size_t)n / 4)), dim3(256), 0, s, p, (size_t)n, value);
-  else hipLaunchKernelGGL(fill_kernel<1>, dim3(ew_blocks((size_t)n)), dim3(256), 0, s, p, (size_t)n, value);
+  const int64_t bulk = al16(p) ? (n & ~(int64_t)3) : 0;    // 16-byte stores over the bulk, scalar stores for the 1..3 trailing elements
+  if (bulk) hipLaunchKernelGGL(fill_kernel<4>, dim3(ew_blocks((size_t)bulk / 4)), dim3(256), 0, s, p, (size_t)bulk, value);
+  if (n > bulk) hipLaunchKernelGGL(fill_kernel<1>, dim3(ew_blocks((size_t)(n - bulk))), dim3(256), 0, s, p + bulk, (size_t)(n - bulk), value);
   return launch_status("fill_kernel");
 }
 
