@@ -288,3 +288,39 @@ def test_dgrad_gemm_col2im_path_equals_phase_kernel(pcg, B, Cin, Cout, H, W, k, 
     assert (got_gemm.cpu().double() - ref).abs().max().item() <= tol
     assert (got_phase.cpu().double() - ref).abs().max().item() <= tol
     assert (got_gemm - got_phase).abs().max().item() <= tol
+
+
+def test_large_partial_row_counts_two_level_finalize(pcg):
+    """>= 4096 conv-epilogue partial rows (one per 64 output rows) take the two-level fp64 finalize.  At M = 64*64*64 = 262144 rows
+    (4096 partial rows): BatchNorm statistics out of the conv epilogue vs the separate colreduce pass over the conv output, and the
+    fused backward (mask + column sums in the grad-input epilogue, then pcg_bn_bwd_partial) vs grad-input + pcg_bn_act_bwd_premask."""
+    ops = pcg.ops
+    B, C, H = 64, 64, 64
+    g = ops.conv_geom(B, H, H, C, C, 3, 3, 1, 1)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, H, C, generator=gen).to(dev())
+    w = (torch.randn(C, 3, 3, C, generator=gen) * 0.05).to(dev())
+    rm, rv, nbt = torch.zeros(C, device=dev()), torch.ones(C, device=dev()), torch.zeros((), dtype=torch.int64, device=dev())
+    z, mean, invstd = ops.conv_bn_train(g, x, w, None, False, 1e-5, 0.1, rm, rv, nbt)
+    z2 = ops.conv2d_fwd(g, x, w, None)
+    assert torch.equal(z, z2)
+    rm2, rv2, nbt2 = torch.zeros(C, device=dev()), torch.ones(C, device=dev()), torch.zeros((), dtype=torch.int64, device=dev())
+    mean2, invstd2 = ops.bn_train_stats(z2, C, 1e-5, 0.1, rm2, rv2, nbt2)
+    zd = z.double()
+    mref = zd.mean(dim=(0, 1, 2)); iref = 1.0 / torch.sqrt(zd.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    for got_m, got_i in ((mean, invstd), (mean2, invstd2)):
+        assert (got_m.double() - mref).abs().max().item() <= 1e-6 and ((got_i.double() - iref).abs() / iref).max().item() <= 1e-6
+    assert torch.allclose(rm, rm2, rtol=0, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-6, atol=0) and int(nbt) == 1
+    # backward: the layer above is the same conv; its grad-input carries the LeakyReLU mask and the column sums of this BatchNorm
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(dev()), (torch.randn(C, generator=gen) * 0.1).to(dev())
+    dz_up = torch.randn(B, H, H, C, generator=gen).to(dev())
+    res = ops.conv_bwd_data_fused(g, dz_up, w, False, O.ACT_LRELU, 0.2, z_below=z, bn=(mean, invstd, gamma, beta))
+    assert res is not None and res[2] >= 4096
+    dg, db = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    dz_f = ops.bn_bwd_partial(res[0], z, C, mean, invstd, gamma, res[1], res[2], dg, db, False)
+    d_plain = ops.conv2d_dgrad(g, dz_up, w)
+    dg2, db2 = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    dz_s = ops.bn_act_bwd(d_plain, z, None, C, mean, invstd, gamma, O.ACT_LRELU, 0.2, dg2, db2, False, beta=beta)
+    for a, b_, what in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (dz_f, dz_s, "dz")):
+        den = max(b_.double().norm().item(), 1e-30)
+        assert ((a.double() - b_.double()).norm().item() / den) <= 2e-6, what
