@@ -127,12 +127,19 @@ def main():
     if not args.eager:
         from pcgan_amd.nn import GraphedStep
         s_real, s_noise = reals[0].clone(), noises[0].clone()
-        if dp is None:
-            gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise), {"real": s_real, "noise": s_noise},
-                             [netG, netD], [optD, optG])
-        else:
-            gs = GraphedStep(lambda d: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, dp=d),
-                             {"real": s_real, "noise": s_noise}, [netG, netD], [optD, optG], dp=dp)
+        try:
+            if dp is None:
+                gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise), {"real": s_real, "noise": s_noise},
+                                 [netG, netD], [optD, optG])
+            else:
+                gs = GraphedStep(lambda d: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, dp=d),
+                                 {"real": s_real, "noise": s_noise}, [netG, netD], [optD, optG], dp=dp)
+        except Exception as e:   # capture is an optimisation of the host side only: the same step runs eagerly (every rank takes the
+            gs = None            # same path: the failure modes are deterministic — an unsupported capture of some runtime call)
+            print(f"[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); running eager launches", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            if dp is not None:
+                dp.wait_all()
 
     def step(i, eager=False):
         if gs is None or eager:
