@@ -12,7 +12,7 @@ throughout (v_mfma_f32_32x32x2_f32 for the contractions).  Rank 0 prints ONE JSO
 roofline: the dominant kernels are the fp32-MFMA implicit-GEMM convolutions (conv_{fwd,dgrad,wgrad}_kernel).  Every
 launch of that family inside the timed region is bracketed by HIP events on the launch stream; `achieved` =
 sum of algorithmic FLOPs (2*B*OH*OW*Cout*KH*KW*Cin per launch) / sum of event-measured durations (the timed steps that run
-eagerly: every --event-every-th; the others replay the captured HIP graph of the same step); `peak` = 157.3
+eagerly: one per --event-every steps, at most three; the others replay the captured HIP graph of the same step); `peak` = 157.3
 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).  `step_frac` = algorithmic FLOPs of the whole step (2.237 GFLOP/image,
 SURVEY.md §8d) / wall time / peak — the number the 50 % target is stated on.
 cpu_baseline: the oracle restatement of the reference loop (oracle/dcgan_ref.py, PyTorch CPU fp32) timed on the host
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket conv launches with HIP events")
     ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL gradient-sync path even with one rank")
     ap.add_argument("--eager", action="store_true", help="enqueue every step kernel by kernel instead of replaying the captured HIP graph(s)")
-    ap.add_argument("--event-every", type=int, default=8, help="every n-th timed step runs eagerly with HIP events around the conv launches")
+    ap.add_argument("--event-every", type=int, default=8, help="one timed step per this many (at most 3 in total) runs eagerly with HIP events around the conv launches")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,10 +165,10 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev = max(1, args.event_every)
-    sampled = [i for i in range(args.steps) if hook is not None and i % ev == ev // 2]
-    if hook is not None and not sampled and args.steps > 0:
-        sampled = [args.steps // 2]               # short runs still carry a live roofline measurement
+    # steps that run eagerly with events: one per --event-every timed steps, at most 3, evenly spread (>= 1: short runs still carry a
+    # live roofline measurement); 2 of the default 20
+    nsamp = 0 if hook is None or args.steps <= 0 else max(1, min(3, args.steps // max(1, args.event_every)))
+    sampled = sorted({min(args.steps - 1, ((2 * j + 1) * args.steps) // (2 * nsamp)) for j in range(nsamp)})
     for i in range(args.steps):
         timed = i in sampled
         ops.set_conv_hook(hook if timed else None)
