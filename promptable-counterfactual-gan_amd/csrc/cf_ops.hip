@@ -133,12 +133,32 @@ __global__ void __launch_bounds__(256) abs_mean_partial_kernel(const float* __re
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ void abs_mean_finish_kernel(const float* __restrict__ partial, int nparts, double inv_n, float* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += (double)partial[i];
-    out[0] = (float)(s * inv_n);
+// fixed-order tree over the block partials in fp64 (one thread walking all 256 partials was a 10 us dependent chain)
+__global__ void __launch_bounds__(256) abs_mean_finish_kernel(const float* __restrict__ partial, int nparts, double inv_n, float* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+// small tensors (the tabular step: 4096 x 17): the whole reduction in ONE block, one launch instead of two
+__global__ void __launch_bounds__(1024) abs_mean_small_kernel(const float* __restrict__ a, const float* __restrict__ m, int one_minus,
+                                                              size_t n, double inv_n, float* out) {
+  __shared__ double red[1024];
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += fabsf(a[i] * am_weight(m, i, one_minus));
+  red[threadIdx.x] = (double)acc;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
 }
 // da (+)= g * sign(a*w) * w / n      ([torch] abs'(0) = 0)
 __global__ void __launch_bounds__(256) abs_mean_bwd_kernel(const float* __restrict__ a, const float* __restrict__ m, int one_minus,
@@ -279,9 +299,13 @@ extern "C" int pcg_abs_mean_fwd(const float* a, const float* m, int one_minus_m,
   }
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
+  if (n <= 128 * 1024) {
+    hipLaunchKernelGGL(abs_mean_small_kernel, dim3(1), dim3(1024), 0, s, a, m, one_minus_m, (size_t)n, 1.0 / (double)n, out);
+    return launch_status("abs_mean_small_kernel");
+  }
   hipLaunchKernelGGL(abs_mean_partial_kernel, dim3(AM_BLOCKS), dim3(256), 0, s, a, m, one_minus_m, (size_t)n, partial);
   if (int e = launch_status("abs_mean_partial_kernel")) return e;
-  hipLaunchKernelGGL(abs_mean_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)partial, AM_BLOCKS, 1.0 / (double)n, out);
+  hipLaunchKernelGGL(abs_mean_finish_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, AM_BLOCKS, 1.0 / (double)n, out);
   return launch_status("abs_mean_finish_kernel");
 }
 

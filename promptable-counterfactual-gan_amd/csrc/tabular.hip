@@ -343,6 +343,19 @@ __global__ void mean_finish_kernel(const float* __restrict__ partial, int nparts
     out[0] = (float)(s * inv_n);
   }
 }
+// small tensors (a critic output of 4096 rows): the whole mean in ONE block — one launch instead of two, fixed tree order
+__global__ void __launch_bounds__(1024) mean_small_kernel(const float* __restrict__ x, size_t n, double inv_n, float* out) {
+  __shared__ double red[1024];
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  red[threadIdx.x] = (double)acc;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
 __global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ gout, float scale, size_t n, float* __restrict__ dx) {
   const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = g;
@@ -702,6 +715,10 @@ extern "C" int pcg_mean_fwd(const float* x, int64_t n, float* out, void* workspa
   PCG_REQUIRE(x && out && n > 0, "pcg_mean_fwd: bad arguments");
   if (!workspace || workspace_bytes < pcg_mean_workspace_bytes()) { set_error("pcg_mean_fwd: workspace too small"); return PCG_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
+  if (n <= 128 * 1024) {
+    hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(1024), 0, s, x, (size_t)n, 1.0 / (double)n, out);
+    return launch_status("mean_small_kernel");
+  }
   hipLaunchKernelGGL(mean_partial_kernel, dim3(MEAN_BLOCKS), dim3(256), 0, s, x, (size_t)n, (float*)workspace);
   if (int e = launch_status("mean_partial_kernel")) return e;
   hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, MEAN_BLOCKS, 1.0 / (double)n, out);
