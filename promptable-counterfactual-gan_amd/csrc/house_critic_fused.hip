@@ -1,7 +1,7 @@
 // house_critic_fused.hip — the tabular spectral-norm critic (house_sales_kc_usa/models/discriminator.py:5-20:
-// Linear 21->32, 32->64, 64->128 with LeakyReLU(0.2), Linear 128->1) as ONE forward and ONE backward kernel, one thread per
-// batch row (same scheme as house_fused.hip: rolled loops over the input index, transposed weights staged in LDS, the lane's
-// input vector parked in LDS, accumulators in registers).  The weights are the spectral-normalised W / sigma that
+// Linear 21->32, 32->64, 64->128 with LeakyReLU(0.2), Linear 128->1) as ONE forward and ONE backward kernel: a block owns 64 batch
+// rows (lane = row) and four waves that each compute a quarter of every layer's output columns (rolled loops over the input index,
+// weights staged in LDS and read as broadcasts, the rows' input vectors parked in LDS, accumulators in registers).  The weights are the spectral-normalised W / sigma that
 // pcg_spectral_norm_fwd_batched produced; the weight gradients are reduced afterwards by pcg_linear_wgrad_grouped from the
 // per-layer pre-activation gradients this backward writes.  Widths are the reference configuration (input 17 + 4 classes,
 // hidden 32): compile-time.
@@ -10,143 +10,207 @@
 namespace pcg {
 namespace {
 
-constexpr int CT = 64;                                  // rows per block = one wave
+constexpr int CT = 64;                                  // rows per block (lane = row)
+constexpr int NW = 4;                                   // waves per block: wave q owns a quarter of every layer's output columns
 constexpr int C0 = 21, C1 = 32, C2 = 64, C3 = 128;      // layer widths (input_dim + num_classes, hidden, 2*hidden, 4*hidden)
-constexpr int C_LDS = C2 * C3 + C3 + C3 * CT;           // floats: largest [K][N] weight image + bias + parked vectors
-
-// out[j<N] = b[j] + sum_{i<K} W[j][i] in[i]      (W row-major [N][K] in global memory)
-template <int K, int N>
-__device__ __forceinline__ void lin_kn(float* lds, const float* __restrict__ W, const float* __restrict__ b, const float (&in)[K],
-                                       float (&out)[N]) {
-  float* Wt = lds; float* bl = lds + K * N; float* V = bl + N;
-  __syncthreads();
-  for (int e = threadIdx.x; e < K * N; e += CT) { const int j = e / K, i = e - j * K; Wt[i * N + j] = W[e]; }
-  for (int j = threadIdx.x; j < N; j += CT) bl[j] = b[j];
-#pragma unroll
-  for (int i = 0; i < K; ++i) V[i * CT + threadIdx.x] = in[i];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < N; ++j) out[j] = bl[j];
-#pragma unroll 1
-  for (int i = 0; i < K; ++i) {
-    const float a = V[i * CT + threadIdx.x];
-    const float* w = Wt + i * N;
-#pragma unroll
-    for (int j = 0; j < N; ++j) out[j] = fmaf(w[j], a, out[j]);
-  }
-}
-// out[i<K] = sum_{j<N} W[j][i] v[j]              (gradient with respect to the input of the layer)
-template <int K, int N>
-__device__ __forceinline__ void lin_t_kn(float* lds, const float* __restrict__ W, const float (&v)[N], float (&out)[K]) {
-  float* Wl = lds; float* V = lds + K * N;
-  __syncthreads();
-  for (int e = threadIdx.x; e < K * N; e += CT) Wl[e] = W[e];
-#pragma unroll
-  for (int j = 0; j < N; ++j) V[j * CT + threadIdx.x] = v[j];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < K; ++i) out[i] = 0.f;
-#pragma unroll 1
-  for (int j = 0; j < N; ++j) {
-    const float a = V[j * CT + threadIdx.x];
-    const float* w = Wl + j * K;
-#pragma unroll
-    for (int i = 0; i < K; ++i) out[i] = fmaf(w[i], a, out[i]);
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void lrelu(float (&v)[N], float slope) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-}
-template <int N>
-__device__ __forceinline__ void store_row(float* p, size_t row, bool on, const float (&v)[N]) {
-  if (!on) return;
-  if constexpr (N % 4 == 0) {
-#pragma unroll
-    for (int j = 0; j < N; j += 4) *reinterpret_cast<float4*>(p + row * N + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < N; ++j) p[row * N + j] = v[j];
-  }
-}
-template <int N>
-__device__ __forceinline__ void load_row(const float* p, size_t row, bool on, float (&v)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; j += 4) {
-    const float4 q = on ? *reinterpret_cast<const float4*>(p + row * N + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-  }
-}
+// LDS (floats): weight image of the largest layer + bias + two parked-vector buffers (ping-pong between layers) + 4 x 64 partials
+constexpr int V_FLOATS = C3 * CT;
+constexpr int C_LDS = C2 * C3 + C3 + 2 * V_FLOATS + NW * CT;
 
 struct CW { const float* w[4]; const float* b[4]; };
 
-__global__ void __launch_bounds__(CT) critic_fwd_kernel(const float* __restrict__ x, int D, const float* __restrict__ onehot, int NC, int B,
-                                                        CW p, float slope, float* __restrict__ a0, float* __restrict__ a1,
-                                                        float* __restrict__ a2, float* __restrict__ a3, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int row = blockIdx.x * CT + threadIdx.x;
-  const bool on = row < B;
-  float in0[C0];
+// One thread per (row, quarter): a block is 64 rows x 4 waves.  A row per THREAD alone (the first version) ran 4096 rows as 64
+// waves on a chip with 1024 SIMDs, each a serial chain over all 32..128 outputs of a layer; splitting the output columns over
+// four waves quadruples the wave count at the same total work, and the weights are staged by 256 threads instead of 64.
+// Layer inputs travel through LDS ("parked" [K][CT]: conflict-free, lane = row), weights are broadcast reads.
+
+// stage W ([N][K] row-major in global) transposed as Wt[i][j] (forward) / as is (backward), and the bias
+template <int K, int N, bool TRANSPOSE>
+__device__ __forceinline__ void stage_w(float* Wl, float* bl, const float* __restrict__ W, const float* __restrict__ b) {
+  for (int e = threadIdx.x; e < K * N; e += CT * NW) {
+    if (TRANSPOSE) { const int j = e / K, i = e - j * K; Wl[i * N + j] = W[e]; }
+    else Wl[e] = W[e];
+  }
+  if (b) for (int j = threadIdx.x; j < N; j += CT * NW) bl[j] = b[j];
+}
+// out[NO] = b[j0..] + sum_{i<K} Wt[i][j0 + .] * V[i][row]
+template <int K, int N, int NO>
+__device__ __forceinline__ void lin_cols(const float* Wt, const float* bl, const float* V, int row, int j0, float (&out)[NO]) {
 #pragma unroll
-  for (int i = 0; i < C0; ++i) in0[i] = !on ? 0.f : (i < D ? x[(size_t)row * D + i] : onehot[(size_t)row * NC + (i - D)]);   // D + NC == C0 (host-checked)
-  store_row<C0>(a0, row, on, in0);                                       // torch.cat([x, target_onehot], 1)  (:19)
-  float h1[C1];
-  lin_kn<C0, C1>(lds, p.w[0], p.b[0], in0, h1);
-  lrelu<C1>(h1, slope);
-  store_row<C1>(a1, row, on, h1);
-  float h2[C2];
-  lin_kn<C1, C2>(lds, p.w[1], p.b[1], h1, h2);
-  lrelu<C2>(h2, slope);
-  store_row<C2>(a2, row, on, h2);
-  float h3[C3];
-  lin_kn<C2, C3>(lds, p.w[2], p.b[2], h2, h3);
-  lrelu<C3>(h3, slope);
-  store_row<C3>(a3, row, on, h3);
-  float acc = p.b[3][0];
-#pragma unroll 8
-  for (int j = 0; j < C3; ++j) acc = fmaf(p.w[3][j], h3[j], acc);
-  if (on) out[row] = acc;
+  for (int j = 0; j < NO; ++j) out[j] = bl[j0 + j];
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    const float a = V[i * CT + row];
+    const float* w = Wt + i * N + j0;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) out[j] = fmaf(w[j], a, out[j]);
+  }
+}
+// out[KO] = sum_{j<N} Wl[j][i0 + .] * V[j][row]            (gradient with respect to the layer's inputs i0..i0+KO)
+template <int K, int N, int KO>
+__device__ __forceinline__ void lin_rows_t(const float* Wl, const float* V, int row, int i0, float (&out)[KO]) {
+#pragma unroll
+  for (int i = 0; i < KO; ++i) out[i] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < N; ++j) {
+    const float a = V[j * CT + row];
+    const float* w = Wl + j * K + i0;
+#pragma unroll
+    for (int i = 0; i < KO; ++i) out[i] = fmaf(w[i], a, out[i]);
+  }
+}
+// LeakyReLU, store the thread's NO columns of its row, park them for the next layer
+template <int N, int NO>
+__device__ __forceinline__ void finish_cols(float (&v)[NO], float slope, float* __restrict__ gl, size_t grow, bool on, float* Vnext, int row,
+                                            int j0) {
+#pragma unroll
+  for (int j = 0; j < NO; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(gl + grow * N + j0 + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+  }
+#pragma unroll
+  for (int j = 0; j < NO; ++j) Vnext[(j0 + j) * CT + row] = v[j];
+}
+
+__global__ void __launch_bounds__(CT * NW) critic_fwd_kernel(const float* __restrict__ x, int D, const float* __restrict__ onehot, int NC, int B,
+                                                             CW p, float slope, float* __restrict__ a0, float* __restrict__ a1,
+                                                             float* __restrict__ a2, float* __restrict__ a3, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wl = lds; float* bl = lds + C2 * C3; float* Va = bl + C3; float* Vb = Va + V_FLOATS; float* part = Vb + V_FLOATS;
+  const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * CT + lane;
+  const bool on = row < (size_t)B;
+  // torch.cat([x, target_onehot], 1) (:19): wave q brings in inputs q, q+4, ... of its rows, stores them to a0 and parks them
+  for (int i = q; i < C0; i += NW) {
+    const float v = !on ? 0.f : (i < D ? x[row * D + i] : onehot[row * NC + (i - D)]);   // D + NC == C0 (host-checked)
+    if (on) a0[row * C0 + i] = v;
+    Va[i * CT + lane] = v;
+  }
+  stage_w<C0, C1, true>(Wl, bl, p.w[0], p.b[0]);
+  __syncthreads();
+  {
+    float h[C1 / NW];
+    lin_cols<C0, C1, C1 / NW>(Wl, bl, Va, lane, q * (C1 / NW), h);
+    finish_cols<C1, C1 / NW>(h, slope, a1, row, on, Vb, lane, q * (C1 / NW));
+  }
+  __syncthreads();
+  stage_w<C1, C2, true>(Wl, bl, p.w[1], p.b[1]);
+  __syncthreads();
+  {
+    float h[C2 / NW];
+    lin_cols<C1, C2, C2 / NW>(Wl, bl, Vb, lane, q * (C2 / NW), h);
+    finish_cols<C2, C2 / NW>(h, slope, a2, row, on, Va, lane, q * (C2 / NW));
+  }
+  __syncthreads();
+  stage_w<C2, C3, true>(Wl, bl, p.w[2], p.b[2]);
+  __syncthreads();
+  float acc = 0.f;
+  {
+    constexpr int NO = C3 / NW;
+    float h[NO];
+    lin_cols<C2, C3, NO>(Wl, bl, Va, lane, q * NO, h);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) h[j] = h[j] > 0.f ? h[j] : h[j] * slope;
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(a3 + row * C3 + q * NO + j) = make_float4(h[j], h[j + 1], h[j + 2], h[j + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) acc = fmaf(p.w[3][q * NO + j], h[j], acc);     // Linear(128 -> 1): this wave's quarter of the dot
+  }
+  part[q * CT + lane] = acc;
+  __syncthreads();
+  if (q == 0 && on) out[row] = p.b[3][0] + ((part[lane] + part[CT + lane]) + (part[2 * CT + lane] + part[3 * CT + lane]));
 }
 
 // pre-activation gradients d3, d2, d1 (operands of the weight gradients) and, optionally, the gradient of the first D inputs
-__global__ void __launch_bounds__(CT) critic_bwd_kernel(const float* __restrict__ dout, int B, CW p, float slope, const float* __restrict__ a1,
-                                                        const float* __restrict__ a2, const float* __restrict__ a3,
-                                                        float* __restrict__ d3o, float* __restrict__ d2o, float* __restrict__ d1o,
-                                                        float* __restrict__ dx, int D) {
+__global__ void __launch_bounds__(CT * NW) critic_bwd_kernel(const float* __restrict__ dout, int B, CW p, float slope, const float* __restrict__ a1,
+                                                             const float* __restrict__ a2, const float* __restrict__ a3,
+                                                             float* __restrict__ d3o, float* __restrict__ d2o, float* __restrict__ d1o,
+                                                             float* __restrict__ dx, int D) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int row = blockIdx.x * CT + threadIdx.x;
-  const bool on = row < B;
+  float* Wl = lds; float* Va = lds + C2 * C3 + C3; float* Vb = Va + V_FLOATS;
+  const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * CT + lane;
+  const bool on = row < (size_t)B;
   const float g = on ? dout[row] : 0.f;
-  float d3[C3], act[C3];
-  load_row<C3>(a3, row, on, act);
-#pragma unroll
-  for (int j = 0; j < C3; ++j) d3[j] = g * p.w[3][j] * (act[j] > 0.f ? 1.f : slope);
-  store_row<C3>(d3o, row, on, d3);
-  float d2[C2];
-  lin_t_kn<C2, C3>(lds, p.w[2], d3, d2);
   {
-    float a[C2];
-    load_row<C2>(a2, row, on, a);
+    constexpr int NO = C3 / NW;        // d3 = dout * w4 * LeakyReLU'(a3): this wave's quarter
+    float d[NO];
 #pragma unroll
-    for (int j = 0; j < C2; ++j) d2[j] *= (a[j] > 0.f ? 1.f : slope);
+    for (int j = 0; j < NO; j += 4) {
+      const float4 a = on ? *reinterpret_cast<const float4*>(a3 + row * C3 + q * NO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[j] = g * p.w[3][q * NO + j] * (a.x > 0.f ? 1.f : slope);         d[j + 1] = g * p.w[3][q * NO + j + 1] * (a.y > 0.f ? 1.f : slope);
+      d[j + 2] = g * p.w[3][q * NO + j + 2] * (a.z > 0.f ? 1.f : slope); d[j + 3] = g * p.w[3][q * NO + j + 3] * (a.w > 0.f ? 1.f : slope);
+    }
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(d3o + row * C3 + q * NO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) Va[(q * NO + j) * CT + lane] = d[j];
   }
-  store_row<C2>(d2o, row, on, d2);
-  float d1[C1];
-  lin_t_kn<C1, C2>(lds, p.w[1], d2, d1);
+  stage_w<C2, C3, false>(Wl, nullptr, p.w[2], nullptr);
+  __syncthreads();
   {
-    float a[C1];
-    load_row<C1>(a1, row, on, a);
+    constexpr int KO = C2 / NW;
+    float d[KO];
+    lin_rows_t<C2, C3, KO>(Wl, Va, lane, q * KO, d);
 #pragma unroll
-    for (int j = 0; j < C1; ++j) d1[j] *= (a[j] > 0.f ? 1.f : slope);
+    for (int j = 0; j < KO; j += 4) {
+      const float4 a = on ? *reinterpret_cast<const float4*>(a2 + row * C2 + q * KO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[j] *= a.x > 0.f ? 1.f : slope; d[j + 1] *= a.y > 0.f ? 1.f : slope; d[j + 2] *= a.z > 0.f ? 1.f : slope; d[j + 3] *= a.w > 0.f ? 1.f : slope;
+    }
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < KO; j += 4) *reinterpret_cast<float4*>(d2o + row * C2 + q * KO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < KO; ++j) Vb[(q * KO + j) * CT + lane] = d[j];
   }
-  store_row<C1>(d1o, row, on, d1);
-  if (dx) {
-    float d0[C0];
-    lin_t_kn<C0, C1>(lds, p.w[0], d1, d0);
-    if (on)
-      for (int i = 0; i < D; ++i) dx[(size_t)row * D + i] = d0[i];
+  __syncthreads();
+  stage_w<C1, C2, false>(Wl, nullptr, p.w[1], nullptr);
+  __syncthreads();
+  {
+    constexpr int KO = C1 / NW;
+    float d[KO];
+    lin_rows_t<C1, C2, KO>(Wl, Vb, lane, q * KO, d);
+#pragma unroll
+    for (int j = 0; j < KO; j += 4) {
+      const float4 a = on ? *reinterpret_cast<const float4*>(a1 + row * C1 + q * KO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[j] *= a.x > 0.f ? 1.f : slope; d[j + 1] *= a.y > 0.f ? 1.f : slope; d[j + 2] *= a.z > 0.f ? 1.f : slope; d[j + 3] *= a.w > 0.f ? 1.f : slope;
+    }
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < KO; j += 4) *reinterpret_cast<float4*>(d1o + row * C1 + q * KO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < KO; ++j) Va[(q * KO + j) * CT + lane] = d[j];
+  }
+  if (dx) {   // block-uniform
+    __syncthreads();
+    stage_w<C0, C1, false>(Wl, nullptr, p.w[0], nullptr);
+    __syncthreads();
+    constexpr int KO = (C0 + NW - 1) / NW;            // 6, 6, 6, 3 of the 21 input columns
+    float d[KO];
+    // the last wave's window is clipped: it reads weights of columns < C0 only through the guarded store below, LDS reads stay in
+    // the staged image (K*N floats) because i0 + KO <= C0 + 3 < 2*C0 and j*K + i0 + i < N*K for j < N-1; the last row is guarded
+    const int i0 = q * KO;
+#pragma unroll
+    for (int i = 0; i < KO; ++i) d[i] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < C1; ++j) {
+      const float a = Va[j * CT + lane];
+      const float* w = Wl + j * C0 + i0;
+#pragma unroll
+      for (int i = 0; i < KO; ++i) d[i] = fmaf(i0 + i < C0 ? w[i] : 0.f, a, d[i]);
+    }
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < KO; ++i)
+        if (i0 + i < D) dx[row * D + i0 + i] = d[i];
+    }
   }
 }
 
@@ -170,7 +234,7 @@ extern "C" int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t
   for (int l = 0; l < 4; ++l) { PCG_REQUIRE(w_bar[l] && bias[l], "pcg_house_critic_fwd: null layer %d", l); p.w[l] = w_bar[l]; p.b[l] = bias[l]; }
   static int once = set_lds(reinterpret_cast<const void*>(critic_fwd_kernel));
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + CT - 1) / CT), dim3(CT), C_LDS * sizeof(float), (hipStream_t)stream, x, D, onehot, NC, B, p,
+  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + CT - 1) / CT), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, x, D, onehot, NC, B, p,
                      slope, a0, a1, a2, a3, out);
   return launch_status("critic_fwd_kernel");
 }
@@ -182,7 +246,7 @@ extern "C" int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, con
   for (int l = 0; l < 4; ++l) { PCG_REQUIRE(w_bar[l], "pcg_house_critic_bwd: null layer %d", l); p.w[l] = w_bar[l]; }
   static int once = set_lds(reinterpret_cast<const void*>(critic_bwd_kernel));
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + CT - 1) / CT), dim3(CT), C_LDS * sizeof(float), (hipStream_t)stream, dout, B, p, slope, a1, a2,
+  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + CT - 1) / CT), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, dout, B, p, slope, a1, a2,
                      a3, d3, d2, d1, dx, D);
   return launch_status("critic_bwd_kernel");
 }
