@@ -134,7 +134,7 @@ __device__ __forceinline__ void bn_finalize(const float* P, int nblocks, int B, 
   // all 64 lanes: lane (c, half) adds the partials of blocks half, half+2, ... of column c (8 loads in flight), then the two
   // halves are combined in a fixed order
   __shared__ double fin[2][2][HH];
-  {
+  if (threadIdx.x < FT) {   // (the four-wave kernels call this with 256 threads: the first wave does the work)
     const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
     double s0 = 0.0, q0 = 0.0;
 #pragma unroll 8
@@ -319,6 +319,138 @@ __global__ void __launch_bounds__(FT) g_fwd_b_kernel(const float* __restrict__ P
     }
     if (a.hard) for (int c = c0; c < c1; ++c) a.hard[(size_t)row * T + c] = c == arg ? 1.f : 0.f;
   }
+}
+
+// ---- forward, four waves per 64 rows --------------------------------------------------------------------------------------------
+// One thread per row (above) runs 4096 rows as 64 waves on 1024 SIMDs.  Here a block is the same 64 rows (lane = row) and four
+// waves, each owning 8 of the 32 channels: its quarter of every matrix-vector product (weights staged transposed in LDS by all 256
+// threads and read as broadcasts, the rows' input vectors parked in LDS), of the BatchNorm / FiLM / residual arithmetic and of the
+// per-block column sums (wave butterfly, fixed order).  Used for kinds A and B of the forward except the last block's heads.
+constexpr int NQ = 4, HQ = HH / NQ;
+struct alignas(16) Smem4 {
+  float gamma[HH], beta[HH], mean[HH], inv[HH];
+  float Wt[2][HH * HH];        // transposed weight images [i][j]: FiLM gamma + beta (21 x 32 each), or one 32 x 32 Linear
+  float bl[2][HH];
+  float V[HH * FT], V2[HH * FT];   // parked input vectors [i][row]
+};
+template <int K>
+__device__ __forceinline__ void stage_t4(float* Wt, float* bl, const float* __restrict__ W, const float* __restrict__ b) {
+  for (int e = threadIdx.x; e < K * HH; e += FT * NQ) { const int j = e / K, i = e - j * K; Wt[i * HH + j] = W[e]; }
+  if (threadIdx.x < HH) bl[threadIdx.x] = b[threadIdx.x];
+}
+template <int K>
+__device__ __forceinline__ void lin_q(const float* Wt, const float* bl, const float* V, int lane, int q, float (&out)[HQ]) {
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) out[j] = bl[q * HQ + j];
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    const float a = V[i * FT + lane];
+    const float* w = Wt + i * HH + q * HQ;
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) out[j] = fmaf(w[j], a, out[j]);
+  }
+}
+__device__ __forceinline__ void load8(const float* p, size_t row, int q, bool on, float (&v)[HQ]) {
+#pragma unroll
+  for (int j = 0; j < HQ; j += 4) {
+    const float4 t = on ? *reinterpret_cast<const float4*>(p + row * HH + q * HQ + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void store8(float* p, size_t row, int q, bool on, const float (&v)[HQ]) {
+  if (!on) return;
+#pragma unroll
+  for (int j = 0; j < HQ; j += 4) *reinterpret_cast<float4*>(p + row * HH + q * HQ + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+}
+__device__ __forceinline__ void park8(float* V, int lane, int q, const float (&v)[HQ]) {
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) V[(q * HQ + j) * FT + lane] = v[j];
+}
+// cond = (one-hot target, mask): wave q brings in elements q, q+4, ... of its rows
+__device__ __forceinline__ void park_cond(float* V, const GBufs& a, size_t row, bool on, int lane, int q) {
+  for (int i = q; i < MAXCOND; i += NQ)
+    V[i * FT + lane] = !on ? 0.f : (i < NCLS ? a.onehot[row * NCLS + i] : a.mask[row * DIN + (i - NCLS)]);
+}
+// column sums of v and v*v over the block's 64 rows for this wave's 8 channels -> part[2][HH] (butterfly: a fixed order)
+__device__ __forceinline__ void wave_colsums(const float (&v)[HQ], bool on, int lane, int q, float* part) {
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    float s1 = on ? v[j] : 0.f, s2 = s1 * s1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (lane == 0) { part[q * HQ + j] = s1; part[HH + q * HQ + j] = s2; }
+  }
+}
+
+// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
+__global__ void __launch_bounds__(FT * NQ) g_fwd_a4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+  __shared__ Smem4 s;
+  const int li = 2 * k;
+  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
+              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
+  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn1_b[k] + threadIdx.x]; }
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  park_cond(s.V, a, row, on, lane, q);
+  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
+  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
+  __syncthreads();
+  float gam[HQ], bet[HQ], z[HQ], a1[HQ];
+  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
+  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float n = fmaf((z[j] - s.mean[c]) * s.inv[c], s.gamma[c], s.beta[c]);
+    const float f = fmaf(gam[j], n, bet[j]);
+    a1[j] = f > 0.f ? f : 0.f;
+  }
+  park8(s.V2, lane, q, a1);
+  __syncthreads();                                   // FiLM images read by every wave; a1 complete
+  stage_t4<HH>(s.Wt[0], s.bl[0], PRM + d.fc2_w[k], PRM + d.fc2_b[k]);
+  __syncthreads();
+  float z2[HQ];
+  lin_q<HH>(s.Wt[0], s.bl[0], s.V2, lane, q, z2);
+  store8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z2);
+  wave_colsums(z2, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// kind B (block k < NBLK-1): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); z1_{k+1} = fc1_{k+1}(h), partial statistics
+__global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+  __shared__ Smem4 s;
+  const int li = 2 * k + 1;
+  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
+              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
+  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = PRM[d.bn2_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn2_b[k] + threadIdx.x]; }
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  park_cond(s.V, a, row, on, lane, q);
+  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
+  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
+  __syncthreads();
+  float gam[HQ], bet[HQ], z[HQ], h[HQ];
+  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
+  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
+  load8(a.H + (size_t)k * a.B * HH, row, q, on, h);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float n = fmaf((z[j] - s.mean[c]) * s.inv[c], s.gamma[c], s.beta[c]);
+    h[j] += fmaf(gam[j], n, bet[j]);
+  }
+  store8(a.H + (size_t)(k + 1) * a.B * HH, row, q, on, h);
+  park8(s.V2, lane, q, h);
+  __syncthreads();
+  stage_t4<HH>(s.Wt[0], s.bl[0], PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1]);
+  __syncthreads();
+  float z1[HQ];
+  lin_q<HH>(s.Wt[0], s.bl[0], s.V2, lane, q, z1);
+  store8(a.Z1 + (size_t)(k + 1) * a.B * HH, row, q, on, z1);
+  wave_colsums(z1, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------------
@@ -544,10 +676,14 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
   const dim3 grid(a.nblocks), block(FT);
   hipLaunchKernelGGL(g_fwd_first_kernel, grid, block, 0, s, args->params, a, d);
   if (int e = launch_status("g_fwd_first_kernel")) return e;
+  static const int four = getenv("PCG_HOUSE_4WAVE") ? atoi(getenv("PCG_HOUSE_4WAVE")) : 1;   // A/B switch
+  const dim3 block4(FT * NQ);
   for (int k = 0; k < NBLK; ++k) {
-    hipLaunchKernelGGL(g_fwd_a_kernel, grid, block, 0, s, args->params, a, d, bs, k);
+    if (four) hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    else hipLaunchKernelGGL(g_fwd_a_kernel, grid, block, 0, s, args->params, a, d, bs, k);
     if (int e = launch_status("g_fwd_a_kernel")) return e;
-    hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);
+    if (four && k < NBLK - 1) hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    else hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);   // the last block: + the output heads
     if (int e = launch_status("g_fwd_b_kernel")) return e;
   }
   return PCG_OK;
