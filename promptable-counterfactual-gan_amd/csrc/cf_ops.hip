@@ -151,7 +151,15 @@ __global__ void __launch_bounds__(1024) abs_mean_small_kernel(const float* __res
                                                               size_t n, double inv_n, float* out) {
   __shared__ double red[1024];
   float acc = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 1024) acc += fabsf(a[i] * am_weight(m, i, one_minus));
+  size_t i = threadIdx.x;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {       // 8 independent loads in flight (one dependent load per element was 23 us for 70 k)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[i + j * 1024] * am_weight(m, i + j * 1024, one_minus);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += fabsf(v[j]);
+  }
+  for (; i < n; i += 1024) acc += fabsf(a[i] * am_weight(m, i, one_minus));
   red[threadIdx.x] = (double)acc;
   __syncthreads();
   for (int k = 512; k > 0; k >>= 1) {

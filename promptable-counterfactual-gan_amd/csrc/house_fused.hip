@@ -417,7 +417,8 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_a4_kernel(const float* __restri
   wave_colsums(z2, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
-// kind B (block k < NBLK-1): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); z1_{k+1} = fc1_{k+1}(h), partial statistics
+// kind B (block k): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); z1_{k+1} = fc1_{k+1}(h), partial statistics (after the last
+// block the output heads follow instead: g_heads4_kernel)
 __global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
   __shared__ Smem4 s;
   const int li = 2 * k + 1;
@@ -443,6 +444,7 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restri
     h[j] += fmaf(gam[j], n, bet[j]);
   }
   store8(a.H + (size_t)(k + 1) * a.B * HH, row, q, on, h);
+  if (k == NBLK - 1) return;                         // block-uniform
   park8(s.V2, lane, q, h);
   __syncthreads();
   stage_t4<HH>(s.Wt[0], s.bl[0], PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1]);
@@ -451,6 +453,52 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restri
   lin_q<HH>(s.Wt[0], s.bl[0], s.V2, lane, q, z1);
   store8(a.Z1 + (size_t)(k + 1) * a.B * HH, row, q, on, z1);
   wave_colsums(z1, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// Output heads on four waves: the continuous residual head and the categorical heads (logits, Gumbel-softmax samples) are dealt to
+// the waves by the host (largest first onto the least loaded wave); every wave reads the 32-vector of its rows and walks its heads
+// exactly as the one-wave kernel does.
+struct HeadOwner { signed char owner[MAXHEADS + 1]; };   // [nheads] = the continuous head
+__global__ void __launch_bounds__(FT * NQ) g_heads4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, HeadOwner ho) {
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  if (row >= (size_t)a.B) return;
+  float h[HH];
+  load32(a.H + (size_t)NBLK * a.B * HH, row, true, h);
+  const int T = d.seg[d.nheads];
+  if (ho.owner[d.nheads] == q) {
+    for (int c = 0; c < d.ncont; ++c) {
+      float acc = PRM[d.cont_b + c];
+#pragma unroll
+      for (int i = 0; i < HH; ++i) acc = fmaf(PRM[d.cont_w + c * HH + i], h[i], acc);
+      a.cont[row * d.ncont + c] = acc * a.res_scale;
+    }
+  }
+  const float inv_tau = 1.f / a.tau;
+  for (int hd = 0; hd < d.nheads; ++hd) {
+    if (ho.owner[hd] != q) continue;               // wave-uniform
+    const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
+    const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
+    const float* __restrict__ bh = PRM + d.head_b[hd] - c0;
+    float mx = -INFINITY;
+    for (int c = c0; c < c1; ++c) {
+      float acc = bh[c];
+#pragma unroll
+      for (int i = 0; i < HH; ++i) acc = fmaf(Wh[c * HH + i], h[i], acc);
+      a.logits[row * T + c] = acc;
+      mx = fmaxf(mx, (acc + a.noise[row * T + c]) * inv_tau);
+    }
+    float se = 0.f;
+    for (int c = c0; c < c1; ++c) se += expf((a.logits[row * T + c] + a.noise[row * T + c]) * inv_tau - mx);
+    const float inv = 1.f / se;
+    float best = -1.f; int arg = c0;
+    for (int c = c0; c < c1; ++c) {
+      const float p = expf((a.logits[row * T + c] + a.noise[row * T + c]) * inv_tau - mx) * inv;
+      a.soft[row * T + c] = p;
+      if (p > best) { best = p; arg = c; }
+    }
+    if (a.hard) for (int c = c0; c < c1; ++c) a.hard[row * T + c] = c == arg ? 1.f : 0.f;
+  }
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------------
@@ -682,9 +730,27 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
     if (four) hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
     else hipLaunchKernelGGL(g_fwd_a_kernel, grid, block, 0, s, args->params, a, d, bs, k);
     if (int e = launch_status("g_fwd_a_kernel")) return e;
-    if (four && k < NBLK - 1) hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    if (four) hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
     else hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);   // the last block: + the output heads
     if (int e = launch_status("g_fwd_b_kernel")) return e;
+  }
+  if (four) {   // output heads: dealt to the four waves, largest first onto the least loaded wave
+    HeadOwner ho{};
+    int size[MAXHEADS + 1], load[NQ] = {0, 0, 0, 0};
+    bool done[MAXHEADS + 1] = {};
+    for (int h = 0; h < d.nheads; ++h) size[h] = d.seg[h + 1] - d.seg[h];
+    size[d.nheads] = d.ncont;
+    for (int it = 0; it <= d.nheads; ++it) {
+      int best = -1;
+      for (int j = 0; j <= d.nheads; ++j)
+        if (!done[j] && (best < 0 || size[j] > size[best])) best = j;
+      int w = 0;
+      for (int j = 1; j < NQ; ++j)
+        if (load[j] < load[w]) w = j;
+      done[best] = true; ho.owner[best] = (signed char)w; load[w] += size[best];
+    }
+    hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, ho);
+    if (int e = launch_status("g_heads4_kernel")) return e;
   }
   return PCG_OK;
 }
