@@ -332,6 +332,7 @@ struct alignas(16) Smem4 {
   float Wt[2][HH * HH];        // transposed weight images [i][j]: FiLM gamma + beta (21 x 32 each), or one 32 x 32 Linear
   float bl[2][HH];
   float V[HH * FT], V2[HH * FT];   // parked input vectors [i][row]
+  float sums[2 * HH];              // backward: mean(dz), mean(dz * xhat) of the BatchNorm in flight
 };
 template <int K>
 __device__ __forceinline__ void stage_t4(float* Wt, float* bl, const float* __restrict__ W, const float* __restrict__ b) {
@@ -367,9 +368,10 @@ __device__ __forceinline__ void park8(float* V, int lane, int q, const float (&v
   for (int j = 0; j < HQ; ++j) V[(q * HQ + j) * FT + lane] = v[j];
 }
 // cond = (one-hot target, mask): wave q brings in elements q, q+4, ... of its rows
-__device__ __forceinline__ void park_cond(float* V, const GBufs& a, size_t row, bool on, int lane, int q) {
+__device__ __forceinline__ void park_cond(float* V, const float* __restrict__ onehot, const float* __restrict__ mask, size_t row, bool on,
+                                          int lane, int q) {
   for (int i = q; i < MAXCOND; i += NQ)
-    V[i * FT + lane] = !on ? 0.f : (i < NCLS ? a.onehot[row * NCLS + i] : a.mask[row * DIN + (i - NCLS)]);
+    V[i * FT + lane] = !on ? 0.f : (i < NCLS ? onehot[row * NCLS + i] : mask[row * DIN + (i - NCLS)]);
 }
 // column sums of v and v*v over the block's 64 rows for this wave's 8 channels -> part[2][HH] (butterfly: a fixed order)
 __device__ __forceinline__ void wave_colsums(const float (&v)[HQ], bool on, int lane, int q, float* part) {
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_a4_kernel(const float* __restri
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  park_cond(s.V, a, row, on, lane, q);
+  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
   stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
   stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
   __syncthreads();
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restri
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  park_cond(s.V, a, row, on, lane, q);
+  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
   stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
   stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
   __syncthreads();
@@ -591,9 +593,9 @@ __global__ void __launch_bounds__(FT) g_bwd_first_kernel(const float* __restrict
 }
 
 // sums of one BatchNorm backward from the partials; block 0 writes dgamma / dbeta
-__device__ __forceinline__ void bnb_finalize(Smem& s, const GBwd& a, int li, int g_off, int b_off) {
+__device__ __forceinline__ void bnb_finalize(float* sums, const GBwd& a, int li, int g_off, int b_off) {
   __shared__ double fin[2][2][HH];
-  {
+  if (threadIdx.x < FT) {   // (the four-wave kernels call this with 256 threads: the first wave does the work)
     const float* Q = a.Q + (size_t)li * a.nblocks * 2 * HH;
     const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
     double t1 = 0.0, t2 = 0.0;
@@ -604,7 +606,7 @@ __device__ __forceinline__ void bnb_finalize(Smem& s, const GBwd& a, int li, int
   __syncthreads();
   if (threadIdx.x < HH) {
     const double s1 = fin[0][0][threadIdx.x] + fin[1][0][threadIdx.x], s2 = fin[0][1][threadIdx.x] + fin[1][1][threadIdx.x];
-    s.sums[threadIdx.x] = (float)(s1 / a.B); s.sums[HH + threadIdx.x] = (float)(s2 / a.B);
+    sums[threadIdx.x] = (float)(s1 / a.B); sums[HH + threadIdx.x] = (float)(s2 / a.B);
     if (blockIdx.x == 0) {
       float* gg = a.grads + g_off + threadIdx.x; float* gb = a.grads + b_off + threadIdx.x;
       *gg = a.accumulate ? *gg + (float)s2 : (float)s2;
@@ -617,7 +619,7 @@ __device__ __forceinline__ void bnb_finalize(Smem& s, const GBwd& a, int li, int
 // kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
 __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_b_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
   __shared__ Smem s;
-  bnb_finalize(s, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
+  bnb_finalize(s.sums, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
   stage(s.gamma, PRM + d.bn2_g[k], HH);
   stage(s.mean, PRM + d.bn1_g[k], HH); stage(s.inv, PRM + d.bn1_b[k], HH);     // bn1's gamma / beta (names reused)
   const int row = blockIdx.x * FT + threadIdx.x;
@@ -664,7 +666,7 @@ __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
 __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_c_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
   __shared__ Smem s;
-  bnb_finalize(s, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
+  bnb_finalize(s.sums, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
   stage(s.gamma, PRM + d.bn1_g[k], HH);
   __syncthreads();
   const int row = blockIdx.x * FT + threadIdx.x;
@@ -695,10 +697,223 @@ __global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1)))
   store32(a.DZIN, row, on, dh);
 }
 
+// ---- backward, four waves per 64 rows (same split as the forward: wave q owns channels 8q .. 8q+7) -------------------------------
+// out[8] = sum_j Wl[j][8q + .] * V[j][row]      (Wl = the Linear's weight as stored, [out j][in i]: gradient w.r.t. its input)
+__device__ __forceinline__ void lin_tq(const float* Wl, const float* V, int lane, int q, float (&out)[HQ]) {
+#pragma unroll
+  for (int i = 0; i < HQ; ++i) out[i] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < HH; ++j) {
+    const float a = V[j * FT + lane];
+    const float* w = Wl + j * HH + q * HQ;
+#pragma unroll
+    for (int i = 0; i < HQ; ++i) out[i] = fmaf(w[i], a, out[i]);
+  }
+}
+__device__ __forceinline__ void stage_asis4(float* Wl, const float* __restrict__ W) {
+  for (int e = threadIdx.x; e < HH * HH; e += FT * NQ) Wl[e] = W[e];
+}
+// column sums of v and w over the block's 64 rows for this wave's 8 channels -> part[2][HH]
+__device__ __forceinline__ void wave_colsums2(const float (&v)[HQ], const float (&w)[HQ], int lane, int q, float* part) {
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    float s1 = v[j], s2 = w[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (lane == 0) { part[q * HQ + j] = s1; part[HH + q * HQ + j] = s2; }
+  }
+}
+// part "a" of block k: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2).  Uses s.V / s.Wt[1] (free at every call site).
+__device__ __forceinline__ void bwd_part_a4(const float* __restrict__ PRM, Smem4& s, const GBwd& a, const GDesc& d, int k, size_t row, bool on,
+                                            int lane, int q, const float (&dh)[HQ]) {
+  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
+  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fg_w[k], PRM + d.fg_b[k]);
+  __syncthreads();
+  float gam[HQ], z[HQ], v[HQ], w[HQ];
+  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, gam);
+  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
+  const float* sm = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float xh = (z[j] - sm[c]) * sm[HH + c];
+    v[j] = on ? dh[j] * gam[j] : 0.f;
+    w[j] = v[j] * xh;
+  }
+  wave_colsums2(v, w, lane, q, a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// first backward kernel: gradients of the heads (dealt to the waves like the forward) -> dh entering the last block; part a
+__global__ void __launch_bounds__(FT * NQ) g_bwd_first4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, HeadOwner ho) {
+  __shared__ Smem4 s;
+  __shared__ float part[NQ][HH][FT];        // per-wave partial dh
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  const int T = d.seg[d.nheads];
+  float dh[HH];
+#pragma unroll
+  for (int i = 0; i < HH; ++i) dh[i] = 0.f;
+  if (on) {
+    if (ho.owner[d.nheads] == q) {
+      for (int c = 0; c < d.ncont; ++c) {
+        const float dc = a.d_cont ? a.d_cont[row * d.ncont + c] * a.res_scale : 0.f;
+        a.DC[row * d.ncont + c] = dc;
+#pragma unroll
+        for (int i = 0; i < HH; ++i) dh[i] = fmaf(PRM[d.cont_w + c * HH + i], dc, dh[i]);
+      }
+    }
+    const float inv_tau = 1.f / a.tau;
+    for (int hd = 0; hd < d.nheads; ++hd) {
+      if (ho.owner[hd] != q) continue;             // wave-uniform
+      const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
+      const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
+      float dot = 0.f;
+      if (a.d_samples)
+        for (int c = c0; c < c1; ++c) dot = fmaf(a.d_samples[row * T + c], a.soft[row * T + c], dot);
+      for (int c = c0; c < c1; ++c) {
+        float dl = a.d_logits ? a.d_logits[row * T + c] : 0.f;
+        if (a.d_samples) { const float y = a.soft[row * T + c]; dl += y * (a.d_samples[row * T + c] - dot) * inv_tau; }
+        a.DL[row * T + c] = dl;
+#pragma unroll
+        for (int i = 0; i < HH; ++i) dh[i] = fmaf(Wh[c * HH + i], dl, dh[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HH; ++i) part[q][i][lane] = dh[i];
+  __syncthreads();
+  float d8[HQ];
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    d8[j] = (part[0][c][lane] + part[1][c][lane]) + (part[2][c][lane] + part[3][c][lane]);
+  }
+  store8(a.DH + (size_t)(NBLK - 1) * a.B * HH, row, q, on, d8);
+  bwd_part_a4(PRM, s, a, d, NBLK - 1, row, on, lane, q, d8);
+}
+
+// kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
+__global__ void __launch_bounds__(FT * NQ) g_bwd_b4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+  __shared__ Smem4 s;
+  bnb_finalize(s.sums, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
+  if (threadIdx.x < HH) {
+    s.gamma[threadIdx.x] = PRM[d.bn2_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn2_b[k] + threadIdx.x];
+    s.mean[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x]; s.inv[threadIdx.x] = PRM[d.bn1_b[k] + threadIdx.x];   // bn1's gamma / beta (names reused)
+  }
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
+  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
+  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
+  __syncthreads();
+  float gam[HQ], bet[HQ], z[HQ], dh[HQ], dz2[HQ], da1[HQ], dgam[HQ];
+  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
+  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
+  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
+  const float* sm2 = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float xh = (z[j] - sm2[c]) * sm2[HH + c];
+    const float n2 = fmaf(xh, s.gamma[c], s.beta[c]);
+    const float dn2 = dh[j] * gam[j];
+    dz2[j] = s.gamma[c] * sm2[HH + c] * (dn2 - s.sums[c] - xh * s.sums[HH + c]);
+    dgam[j] = dh[j] * n2;
+  }
+  store8(a.DZ2 + (size_t)k * a.B * HH, row, q, on, dz2);
+  park8(s.V2, lane, q, dz2);
+  __syncthreads();                                   // FiLM images read by every wave; dz2 complete
+  stage_asis4(s.Wt[0], PRM + d.fc2_w[k]);
+  __syncthreads();
+  lin_tq(s.Wt[0], s.V2, lane, q, da1);
+  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+  float a1[HQ], v[HQ], w[HQ], dbet[HQ];
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float xh = (z[j] - sm1[c]) * sm1[HH + c];
+    const float n1 = fmaf(xh, s.mean[c], s.inv[c]);
+    const float f = fmaf(gam[j], n1, bet[j]);
+    a1[j] = f > 0.f ? f : 0.f;
+    const float df1 = f > 0.f ? da1[j] : 0.f;
+    dgam[j] = fmaf(df1, n1, dgam[j]);
+    dbet[j] = dh[j] + df1;
+    v[j] = on ? df1 * gam[j] : 0.f;          // dn1
+    w[j] = v[j] * xh;
+  }
+  store8(a.A1 + (size_t)k * a.B * HH, row, q, on, a1);
+  store8(a.DG + (size_t)k * a.B * HH, row, q, on, dgam);
+  store8(a.DB + (size_t)k * a.B * HH, row, q, on, dbet);
+  store8(a.DN1, row, q, on, v);
+  wave_colsums2(v, w, lane, q, a.Q + ((size_t)(2 * k) * a.nblocks + blockIdx.x) * 2 * HH);
+}
+
+// kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
+__global__ void __launch_bounds__(FT * NQ) g_bwd_c4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+  __shared__ Smem4 s;
+  bnb_finalize(s.sums, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
+  if (threadIdx.x < HH) s.gamma[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x];
+  stage_asis4(s.Wt[0], PRM + d.fc1_w[k]);
+  __syncthreads();
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  float z[HQ], dn1[HQ], dz1[HQ], dh[HQ], t[HQ];
+  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+  load8(a.DN1, row, q, on, dn1);
+  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    const int c = q * HQ + j;
+    const float xh = (z[j] - sm1[c]) * sm1[HH + c];
+    dz1[j] = s.gamma[c] * sm1[HH + c] * (dn1[j] - s.sums[c] - xh * s.sums[HH + c]);
+  }
+  store8(a.DZ1 + (size_t)k * a.B * HH, row, q, on, dz1);
+  park8(s.V2, lane, q, dz1);
+  __syncthreads();
+  lin_tq(s.Wt[0], s.V2, lane, q, t);
+  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) dh[j] += t[j];
+  if (k > 0) {                                       // block-uniform
+    store8(a.DH + (size_t)(k - 1) * a.B * HH, row, q, on, dh);
+    bwd_part_a4(PRM, s, a, d, k - 1, row, on, lane, q, dh);
+    return;
+  }
+  float h0[HQ];
+  load8(a.H, row, q, on, h0);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) dh[j] = h0[j] > 0.f ? dh[j] : 0.f;
+  store8(a.DZIN, row, q, on, dh);
+}
+
 }  // namespace
 }  // namespace pcg
 
 using namespace pcg;
+
+// output heads (and the continuous head, index nheads) dealt to the four waves: largest first onto the least loaded wave
+static HeadOwner deal_heads(const GDesc& d) {
+  HeadOwner ho{};
+  int size[MAXHEADS + 1], load[NQ] = {0, 0, 0, 0};
+  bool done[MAXHEADS + 1] = {};
+  for (int h = 0; h < d.nheads; ++h) size[h] = d.seg[h + 1] - d.seg[h];
+  size[d.nheads] = d.ncont;
+  for (int it = 0; it <= d.nheads; ++it) {
+    int best = -1;
+    for (int j = 0; j <= d.nheads; ++j)
+      if (!done[j] && (best < 0 || size[j] > size[best])) best = j;
+    int w = 0;
+    for (int j = 1; j < NQ; ++j)
+      if (load[j] < load[w]) w = j;
+    done[best] = true; ho.owner[best] = (signed char)w; load[w] += size[best];
+  }
+  return ho;
+}
 
 // C-side mirrors of the argument blocks (plain arrays of offsets / pointers: see include/pcgan_hip.h)
 extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_fwd_args* args, pcg_stream_t stream) {
@@ -734,22 +949,8 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
     else hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);   // the last block: + the output heads
     if (int e = launch_status("g_fwd_b_kernel")) return e;
   }
-  if (four) {   // output heads: dealt to the four waves, largest first onto the least loaded wave
-    HeadOwner ho{};
-    int size[MAXHEADS + 1], load[NQ] = {0, 0, 0, 0};
-    bool done[MAXHEADS + 1] = {};
-    for (int h = 0; h < d.nheads; ++h) size[h] = d.seg[h + 1] - d.seg[h];
-    size[d.nheads] = d.ncont;
-    for (int it = 0; it <= d.nheads; ++it) {
-      int best = -1;
-      for (int j = 0; j <= d.nheads; ++j)
-        if (!done[j] && (best < 0 || size[j] > size[best])) best = j;
-      int w = 0;
-      for (int j = 1; j < NQ; ++j)
-        if (load[j] < load[w]) w = j;
-      done[best] = true; ho.owner[best] = (signed char)w; load[w] += size[best];
-    }
-    hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, ho);
+  if (four) {
+    hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
     if (int e = launch_status("g_heads4_kernel")) return e;
   }
   return PCG_OK;
@@ -772,12 +973,17 @@ extern "C" int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_b
   a.tau = args->tau; a.res_scale = args->res_scale;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.nblocks), block(FT);
-  hipLaunchKernelGGL(g_bwd_first_kernel, grid, block, 0, s, args->params, a, d);
+  static const int four = getenv("PCG_HOUSE_4WAVE") ? atoi(getenv("PCG_HOUSE_4WAVE")) : 1;   // A/B switch
+  const dim3 block4(FT * NQ);
+  if (four) hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
+  else hipLaunchKernelGGL(g_bwd_first_kernel, grid, block, 0, s, args->params, a, d);
   if (int e = launch_status("g_bwd_first_kernel")) return e;
   for (int k = NBLK - 1; k >= 0; --k) {
-    hipLaunchKernelGGL(g_bwd_b_kernel, grid, block, 0, s, args->params, a, d, k);
+    if (four) hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    else hipLaunchKernelGGL(g_bwd_b_kernel, grid, block, 0, s, args->params, a, d, k);
     if (int e = launch_status("g_bwd_b_kernel")) return e;
-    hipLaunchKernelGGL(g_bwd_c_kernel, grid, block, 0, s, args->params, a, d, k);
+    if (four) hipLaunchKernelGGL(g_bwd_c4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    else hipLaunchKernelGGL(g_bwd_c_kernel, grid, block, 0, s, args->params, a, d, k);
     if (int e = launch_status("g_bwd_c_kernel")) return e;
   }
   return PCG_OK;
