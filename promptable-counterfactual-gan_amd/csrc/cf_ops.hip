@@ -307,7 +307,7 @@ extern "C" int pcg_abs_mean_fwd(const float* a, const float* m, int one_minus_m,
   }
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  if (n <= 128 * 1024) {
+  if (n <= 16 * 1024) {   // one block is enough up to ~16 elements per thread; beyond, 256 blocks + the parallel finish are faster
     hipLaunchKernelGGL(abs_mean_small_kernel, dim3(1), dim3(1024), 0, s, a, m, one_minus_m, (size_t)n, 1.0 / (double)n, out);
     return launch_status("abs_mean_small_kernel");
   }

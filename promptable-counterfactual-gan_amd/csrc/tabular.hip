@@ -715,7 +715,7 @@ extern "C" int pcg_mean_fwd(const float* x, int64_t n, float* out, void* workspa
   PCG_REQUIRE(x && out && n > 0, "pcg_mean_fwd: bad arguments");
   if (!workspace || workspace_bytes < pcg_mean_workspace_bytes()) { set_error("pcg_mean_fwd: workspace too small"); return PCG_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  if (n <= 128 * 1024) {
+  if (n <= 16 * 1024) {
     hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(1024), 0, s, x, (size_t)n, 1.0 / (double)n, out);
     return launch_status("mean_small_kernel");
   }
