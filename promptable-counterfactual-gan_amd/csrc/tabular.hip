@@ -161,8 +161,15 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ dy, 
       const int m = m0 + e / tw, n = n0 + e % tw;
       const float* src = partial + (size_t)m * NP + n;
       float sum = 0.f;
-#pragma unroll 8
-      for (int z = 0; z < S; ++z) sum += src[(size_t)z * O * NP];
+      int z = 0;
+      for (; z + 16 <= S; z += 16) {       // 16 slabs in flight per output (the tail of the launch is this one block's latency chain)
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(z + j) * O * NP];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += v[j];
+      }
+      for (; z < S; ++z) sum += src[(size_t)z * O * NP];
       if (n < I) {
         float* p = dW + (size_t)m * I + n;
         *p = accW ? *p + sum : sum;
