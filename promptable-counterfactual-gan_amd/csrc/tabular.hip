@@ -381,23 +381,33 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return r;
 }
 // training: v <- normalize(W^T u); u <- normalize(W v)  (in place);  sigma = u . (W v);  Wbar = W / sigma
+// The matrix is staged once in LDS (row stride made odd: the row-wise products then hit 32 different banks) and the three
+// matrix-vector products read it from there; matrices beyond 48 KB take the global-memory form.
+constexpr int SN_LDS_FLOATS = 12288;
 __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__ W, int O, int I, float* __restrict__ u,
                                                        float* __restrict__ v, float eps, int power_iter, float* __restrict__ Wbar,
                                                        float* __restrict__ sigma_out, float* __restrict__ u_used,
                                                        float* __restrict__ v_used) {
   __shared__ float red[256];
   __shared__ float su[256], sv[256];   // O, I <= 256 (host-checked)
+  __shared__ float sW[SN_LDS_FLOATS];
+  const int ld = (I & 1) ? I : I + 1;
+  const bool in_lds = O * ld <= SN_LDS_FLOATS;      // block-uniform
   for (int i = threadIdx.x; i < O; i += 256) su[i] = u[i];
   for (int i = threadIdx.x; i < I; i += 256) sv[i] = v[i];
+  if (in_lds)
+    for (int e = threadIdx.x; e < O * I; e += 256) { const int o = e / I, i = e - o * I; sW[o * ld + i] = W[e]; }
   __syncthreads();
+  const float* M = in_lds ? sW : W;
+  const int lm = in_lds ? ld : I;
   if (power_iter) {
     float t = 0.f;
-    if ((int)threadIdx.x < I) { for (int o = 0; o < O; ++o) t = fmaf(W[(size_t)o * I + threadIdx.x], su[o], t); }
+    if ((int)threadIdx.x < I) { for (int o = 0; o < O; ++o) t = fmaf(M[(size_t)o * lm + threadIdx.x], su[o], t); }
     const float nv = sqrtf(block_sum((int)threadIdx.x < I ? t * t : 0.f, red));
     if ((int)threadIdx.x < I) sv[threadIdx.x] = t / fmaxf(nv, eps);
     __syncthreads();
     float w = 0.f;
-    if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) w = fmaf(W[(size_t)threadIdx.x * I + i], sv[i], w); }
+    if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) w = fmaf(M[(size_t)threadIdx.x * lm + i], sv[i], w); }
     const float nu = sqrtf(block_sum((int)threadIdx.x < O ? w * w : 0.f, red));
     if ((int)threadIdx.x < O) su[threadIdx.x] = w / fmaxf(nu, eps);
     __syncthreads();
@@ -407,11 +417,14 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   if (u_used) for (int i = threadIdx.x; i < O; i += 256) u_used[i] = su[i];
   if (v_used) for (int i = threadIdx.x; i < I; i += 256) v_used[i] = sv[i];
   float wv = 0.f;
-  if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) wv = fmaf(W[(size_t)threadIdx.x * I + i], sv[i], wv); wv *= su[threadIdx.x]; }
+  if ((int)threadIdx.x < O) { for (int i = 0; i < I; ++i) wv = fmaf(M[(size_t)threadIdx.x * lm + i], sv[i], wv); wv *= su[threadIdx.x]; }
   const float sigma = block_sum((int)threadIdx.x < O ? wv : 0.f, red);
   if (threadIdx.x == 0) sigma_out[0] = sigma;
   const float inv = 1.f / sigma;
-  for (int e = threadIdx.x; e < O * I; e += 256) Wbar[e] = W[e] * inv;
+  for (int e = threadIdx.x; e < O * I; e += 256) {
+    const int o = e / I, i = e - o * I;
+    Wbar[e] = (in_lds ? sW[o * ld + i] : W[e]) * inv;
+  }
 }
 __global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
                                                                 float* __restrict__ v, float eps, int power_iter,
@@ -425,7 +438,15 @@ __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__
                                                        const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
   __shared__ float red[256];
   float t = 0.f;
-  for (int e = threadIdx.x; e < O * I; e += 256) t = fmaf(dWbar[e], Wbar[e], t);
+  int e0 = threadIdx.x;
+  for (; e0 + 7 * 256 < O * I; e0 += 8 * 256) {      // 16 independent loads in flight, products added in element order
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = dWbar[e0 + 256 * j]; b[j] = Wbar[e0 + 256 * j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t = fmaf(a[j], b[j], t);
+  }
+  for (; e0 < O * I; e0 += 256) t = fmaf(dWbar[e0], Wbar[e0], t);
   const float dot = block_sum(t, red);
   const float inv = 1.f / sigma[0];
   for (int e = threadIdx.x; e < O * I; e += 256) {
