@@ -11,7 +11,9 @@ namespace {
 
 constexpr int CR_THREADS = 256;
 constexpr int CR_MAX_BLOCKS = 512;
-constexpr int FIN_CH = 8, FIN_SL = 128;  // finalize: 8 channels x 128 partial-row slices per 1024-thread block (the loop over partial rows is latency-bound)
+constexpr int FIN_CH = 8, FIN_SL = 128;  // finalize: 8 channels x (32 | 128) partial-row slices per (256 | 1024)-thread block: the loop over the
+                                         // partial rows is latency-bound, so many rows get many slices; few rows the cheaper small block
+static inline int fin_threads(int nparts) { return nparts <= 1024 ? FIN_CH * 32 : FIN_CH * FIN_SL; }
 
 struct ColPlan { int vec, CG, TX, TY, nblocks, rows_per_block; };
 
@@ -145,6 +147,7 @@ template <int NVAL, class SrcT>
 __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, int nblocks, int C, int& c_out,
                                               double (&sum)[NVAL]) {
   __shared__ double red[NVAL][FIN_SL][FIN_CH];
+  const int SL = blockDim.x / FIN_CH;          // 32 or 128 slices (fin_threads)
   const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   double acc[NVAL];
@@ -152,18 +155,18 @@ __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, 
   for (int k = 0; k < NVAL; ++k) acc[k] = 0.0;
   if (c < C) {
     int b = sl;
-    for (; b + 7 * FIN_SL < nblocks; b += 8 * FIN_SL) {   // 8 independent loads in flight, added in block order
+    for (; b + 7 * SL < nblocks; b += 8 * SL) {   // 8 independent loads in flight, added in block order
       SrcT v[8][NVAL];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int k = 0; k < NVAL; ++k) v[j][k] = partial[((size_t)(b + j * FIN_SL) * NVAL + k) * C + c];
+        for (int k = 0; k < NVAL; ++k) v[j][k] = partial[((size_t)(b + j * SL) * NVAL + k) * C + c];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int k = 0; k < NVAL; ++k) acc[k] += (double)v[j][k];
     }
-    for (; b < nblocks; b += FIN_SL)
+    for (; b < nblocks; b += SL)
 #pragma unroll
       for (int k = 0; k < NVAL; ++k) acc[k] += (double)partial[((size_t)b * NVAL + k) * C + c];
   }
@@ -176,7 +179,7 @@ __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, 
   for (int k = 0; k < NVAL; ++k) {
     double s = 0.0;
 #pragma unroll 8
-    for (int j = 0; j < FIN_SL; ++j) s += red[k][j][cl];   // (a full unroll of FIN_SL LDS reads spills to scratch: slow dispatch)
+    for (int j = 0; j < SL; ++j) s += red[k][j][cl];   // (a full unroll of the LDS reads spills to scratch: slow dispatch)
     sum[k] = s;
   }
   return true;
@@ -450,10 +453,10 @@ int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int
   int nchunks = 0;
   const double* pre = has_presum_tail ? launch_presum(partial, nparts, 2 * C, &nchunks, s) : nullptr;
   if (pre)
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pre, nchunks, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
                        1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   else
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
                        1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   return launch_status("bn_stats_finalize_kernel");
 }
@@ -485,7 +488,7 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
   FnStats fn{x};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                      num_batches_tracked);
   return launch_status("bn_stats_finalize_kernel");
@@ -528,7 +531,7 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   float* coef = partial + (size_t)cp.nblocks * 2 * C;
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
@@ -580,10 +583,10 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
   int nchunks = 0;
   const double* pre = launch_presum(partial, nparts, 2 * C, &nchunks, s);   // the buffer of pcg_conv2d_*_bn_workspace_bytes has the tail
   if (pre)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pre, nchunks, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
                        1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, partial, nparts, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
                        1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const bool aligned = al16(dm) && al16(x) && al16(dx);
@@ -616,6 +619,6 @@ extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, i
   float* partial = (float*)workspace;
   FnSum fn{dy};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
   return launch_status("colsum_finalize_kernel");
 }
