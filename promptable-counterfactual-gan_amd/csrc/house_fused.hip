@@ -1,9 +1,10 @@
 // house_fused.hip — the tabular ResidualGenerator (house_sales_kc_usa/models/generator.py:38-92) as a chain of "segment"
-// kernels.  Every tensor of this net is [B][32] and every weight matrix is at most 38 wide: one THREAD owns one batch row and
-// carries its whole hidden vector in registers; the weights of a segment sit in LDS and are read as broadcasts.  The only
+// kernels.  Every tensor of this net is [B][32] and every weight matrix is at most 38 wide: a block owns 64 batch rows (lane = row)
+// and four waves that each carry 8 of the 32 channels in registers (the entry segment still gives a thread the whole row); the
+// weights of a segment sit in LDS and are read as broadcasts, the rows' input vectors are parked in LDS between layers.  The only
 // cross-row dependencies are the ten BatchNorm1d batch statistics, so the net is cut there: a segment ends by writing its
 // pre-BatchNorm activations plus per-block column sums, and the next segment starts by turning those sums into mean / invstd
-// (fixed order, fp64) — the kernel boundary is the grid barrier.  Forward = 11 launches (op chain: ~95), backward = 11 launches
+// (fixed order, fp64) — the kernel boundary is the grid barrier.  Forward = 12 launches (op chain: ~95), backward = 11 launches
 // + the weight-gradient reductions (op chain: ~190).  Hidden width 32, 5 residual blocks (the reference's configuration)
 // are compile-time; other configurations use the op-chain path.
 #include <cstring>
@@ -87,25 +88,6 @@ __device__ __forceinline__ void lin_to32_rt(float* lds, const float* __restrict_
                                             float (&out)[HH]) {
   lin_to32<KMAX>(lds, W, b, in, out);
 }
-// out[i] = sum_j W[j][i] v[j]   (transposed: gradient with respect to the input of a 32 -> 32 Linear; W is already [j][i])
-__device__ __forceinline__ void lin_t32(float* lds, const float* __restrict__ W, const float (&v)[HH], float (&out)[HH]) {
-  float* Wl = lds; float* V = lds + HH * HH;
-  __syncthreads();
-  for (int e = threadIdx.x; e < HH * HH; e += FT) Wl[e] = W[e];
-#pragma unroll
-  for (int j = 0; j < HH; ++j) V[j * FT + threadIdx.x] = v[j];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < HH; ++i) out[i] = 0.f;
-#pragma unroll 1
-  for (int j = 0; j < HH; ++j) {
-    const float a = V[j * FT + threadIdx.x];
-    const float* w = Wl + j * HH;
-#pragma unroll
-    for (int i = 0; i < HH; ++i) out[i] = fmaf(w[i], a, out[i]);
-  }
-}
-
 // per-block column sums of v[0..31] and w[0..31] over the block's rows -> part[2][HH] of this block (fixed order)
 __device__ __forceinline__ void block_colsums(const float (&v)[HH], const float (&w)[HH], float* red /* [FT][HH+1] */,
                                               float* red2 /* [8][HH] */, float* part) {
@@ -162,13 +144,6 @@ __device__ __forceinline__ void bn_finalize(const float* P, int nblocks, int B, 
   __syncthreads();
 }
 
-__device__ __forceinline__ void load_cond(const GBufs& a, const GDesc& d, int row, bool on, float (&cond)[MAXCOND]) {
-#pragma unroll
-  for (int i = 0; i < NCLS; ++i) cond[i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
-#pragma unroll
-  for (int i = 0; i < DIN; ++i) cond[NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
-}
-
 __device__ __forceinline__ void load32(const float* p, size_t row, bool on, float (&v)[HH]) {
 #pragma unroll
   for (int j = 0; j < HH; j += 4) {
@@ -188,7 +163,7 @@ struct alignas(16) Smem {
   float red2[(FT / 32) * HH];
   float gamma[HH], beta[HH], mean[HH], inv[HH];
   float sums[2 * HH];
-  float lin[MAXIN * HH + HH + MAXIN * FT];     // scratch of lin_to32 / lin_t32: transposed weights, bias, the lanes' input vectors
+  float lin[MAXIN * HH + HH + MAXIN * FT];     // scratch of lin_to32: transposed weights, bias, the lanes' input vectors
 };
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
@@ -219,106 +194,6 @@ __global__ void __launch_bounds__(FT) g_fwd_first_kernel(const float* __restrict
 #pragma unroll
   for (int j = 0; j < HH; ++j) { z[j] = on ? z[j] : 0.f; zz[j] = z[j] * z[j]; }
   block_colsums(z, zz, s.red, s.red2, a.P + (size_t)blockIdx.x * 2 * HH);
-}
-
-// FiLM parameters of block k from cond
-__device__ __forceinline__ void film_params(Smem& s, const float* __restrict__ PRM, const GDesc& d, int k, const float (&cond)[MAXCOND],
-                                            float (&gam)[HH], float (&bet)[HH]) {
-  lin_to32<MAXCOND>(s.lin, PRM + d.fg_w[k], PRM + d.fg_b[k], cond, gam);
-  lin_to32<MAXCOND>(s.lin, PRM + d.fb_w[k], PRM + d.fb_b[k], cond, bet);
-}
-
-// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
-__global__ void __launch_bounds__(FT) g_fwd_a_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
-  __shared__ Smem s;
-  const int li = 2 * k;
-  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
-              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
-  stage(s.gamma, PRM + d.bn1_g[k], HH); stage(s.beta, PRM + d.bn1_b[k], HH);
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float cond[MAXCOND], gam[HH], bet[HH], z[HH], a1[HH], z2[HH], zz[HH];
-  load_cond(a, d, row, on, cond);
-  __syncthreads();                                // publishes gamma / beta
-  film_params(s, PRM, d, k, cond, gam, bet);
-  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    const float n = fmaf((z[j] - s.mean[j]) * s.inv[j], s.gamma[j], s.beta[j]);
-    const float f = fmaf(gam[j], n, bet[j]);
-    a1[j] = f > 0.f ? f : 0.f;
-  }
-  lin_to32<HH>(s.lin, PRM + d.fc2_w[k], PRM + d.fc2_b[k], a1, z2);
-  store32(a.Z2 + (size_t)k * a.B * HH, row, on, z2);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) { z2[j] = on ? z2[j] : 0.f; zz[j] = z2[j] * z2[j]; }
-  block_colsums(z2, zz, s.red, s.red2, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
-}
-
-// kind B (block k): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); then z1_{k+1} = fc1_{k+1}(h), or the output heads after the last block
-__global__ void __launch_bounds__(FT) g_fwd_b_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
-  __shared__ Smem s;
-  const int li = 2 * k + 1;
-  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
-              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
-  stage(s.gamma, PRM + d.bn2_g[k], HH); stage(s.beta, PRM + d.bn2_b[k], HH);
-  const bool last = k == NBLK - 1;
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float cond[MAXCOND], gam[HH], bet[HH], z[HH], h[HH];
-  load_cond(a, d, row, on, cond);
-  __syncthreads();
-  film_params(s, PRM, d, k, cond, gam, bet);
-  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
-  load32(a.H + (size_t)k * a.B * HH, row, on, h);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    const float n = fmaf((z[j] - s.mean[j]) * s.inv[j], s.gamma[j], s.beta[j]);
-    h[j] += fmaf(gam[j], n, bet[j]);
-  }
-  store32(a.H + (size_t)(k + 1) * a.B * HH, row, on, h);
-  if (!last) {
-    float z1[HH], zz[HH];
-    lin_to32<HH>(s.lin, PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1], h, z1);
-    store32(a.Z1 + (size_t)(k + 1) * a.B * HH, row, on, z1);
-#pragma unroll
-    for (int j = 0; j < HH; ++j) { z1[j] = on ? z1[j] : 0.f; zz[j] = z1[j] * z1[j]; }
-    block_colsums(z1, zz, s.red, s.red2, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
-    return;
-  }
-  // ---- heads: continuous residual (scaled) and the packed categorical logits + Gumbel-softmax samples
-  const int T = d.seg[d.nheads];
-  if (!on) return;
-  for (int c = 0; c < d.ncont; ++c) {
-    float acc = PRM[d.cont_b + c];
-#pragma unroll
-    for (int i = 0; i < HH; ++i) acc = fmaf(PRM[d.cont_w + c * HH + i], h[i], acc);
-    a.cont[(size_t)row * d.ncont + c] = acc * a.res_scale;
-  }
-  const float inv_tau = 1.f / a.tau;
-  for (int hd = 0; hd < d.nheads; ++hd) {
-    const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-    const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
-    const float* __restrict__ bh = PRM + d.head_b[hd] - c0;
-    float mx = -INFINITY;
-    for (int c = c0; c < c1; ++c) {
-      float acc = bh[c];
-#pragma unroll
-      for (int i = 0; i < HH; ++i) acc = fmaf(Wh[c * HH + i], h[i], acc);
-      a.logits[(size_t)row * T + c] = acc;
-      mx = fmaxf(mx, (acc + a.noise[(size_t)row * T + c]) * inv_tau);
-    }
-    float se = 0.f;
-    for (int c = c0; c < c1; ++c) se += expf((a.logits[(size_t)row * T + c] + a.noise[(size_t)row * T + c]) * inv_tau - mx);
-    const float inv = 1.f / se;
-    float best = -1.f; int arg = c0;
-    for (int c = c0; c < c1; ++c) {
-      const float p = expf((a.logits[(size_t)row * T + c] + a.noise[(size_t)row * T + c]) * inv_tau - mx) * inv;
-      a.soft[(size_t)row * T + c] = p;
-      if (p > best) { best = p; arg = c; }
-    }
-    if (a.hard) for (int c = c0; c < c1; ++c) a.hard[(size_t)row * T + c] = c == arg ? 1.f : 0.f;
-  }
 }
 
 // ---- forward, four waves per 64 rows --------------------------------------------------------------------------------------------
@@ -520,78 +395,6 @@ struct GBwd {
   float tau, res_scale;
 };
 
-// recompute gam/bet of block k and x-hat / bn output of a saved pre-activation
-__device__ __forceinline__ void bn_apply32(const float (&z)[HH], const float* mean, const float* inv, const float* g, const float* b,
-                                           float (&xh)[HH], float (&n)[HH]) {
-#pragma unroll
-  for (int j = 0; j < HH; ++j) { xh[j] = (z[j] - mean[j]) * inv[j]; n[j] = fmaf(xh[j], g[j], b[j]); }
-}
-
-__device__ __forceinline__ void film_params_b(Smem& s, const float* __restrict__ PRM, const GBwd& a, const GDesc& d, int k, int row, bool on,
-                                              float (&gam)[HH], float (&bet)[HH]) {
-  constexpr int C = MAXCOND;
-  float cond[MAXCOND];
-#pragma unroll
-  for (int i = 0; i < NCLS; ++i) cond[i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
-#pragma unroll
-  for (int i = 0; i < DIN; ++i) cond[NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
-  (void)C;
-  lin_to32<MAXCOND>(s.lin, PRM + d.fg_w[k], PRM + d.fg_b[k], cond, gam);
-  lin_to32<MAXCOND>(s.lin, PRM + d.fb_w[k], PRM + d.fb_b[k], cond, bet);
-}
-
-// part "a" of block k, shared by the first backward kernel and kind C: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2)
-__device__ __forceinline__ void bwd_part_a(const float* __restrict__ PRM, Smem& s, const GBwd& a, const GDesc& d, int k, int row, bool on,
-                                           const float (&dh)[HH]) {
-  float gam[HH], bet[HH], z[HH], xh[HH], v[HH], w[HH];
-  film_params_b(s, PRM, a, d, k, row, on, gam, bet);
-  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
-  const float* sm = a.SM + (size_t)(2 * k + 1) * 2 * HH;
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    xh[j] = (z[j] - sm[j]) * sm[HH + j];
-    v[j] = on ? dh[j] * gam[j] : 0.f;
-    w[j] = v[j] * xh[j];
-  }
-  block_colsums(v, w, s.red, s.red2, a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH);
-}
-
-// first backward kernel: gradients of the heads -> dh entering the last block; then part a of that block
-__global__ void __launch_bounds__(FT) g_bwd_first_kernel(const float* __restrict__ PRM, GBwd a, GDesc d) {
-  __shared__ Smem s;
-  const int T = d.seg[d.nheads];
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float dh[HH];
-#pragma unroll
-  for (int i = 0; i < HH; ++i) dh[i] = 0.f;
-  if (on) {
-    for (int c = 0; c < d.ncont; ++c) {
-      const float dc = a.d_cont ? a.d_cont[(size_t)row * d.ncont + c] * a.res_scale : 0.f;
-      a.DC[(size_t)row * d.ncont + c] = dc;
-#pragma unroll
-      for (int i = 0; i < HH; ++i) dh[i] = fmaf(PRM[d.cont_w + c * HH + i], dc, dh[i]);
-    }
-    const float inv_tau = 1.f / a.tau;
-    for (int hd = 0; hd < d.nheads; ++hd) {
-      const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-      const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
-      float dot = 0.f;
-      if (a.d_samples)
-        for (int c = c0; c < c1; ++c) dot = fmaf(a.d_samples[(size_t)row * T + c], a.soft[(size_t)row * T + c], dot);
-      for (int c = c0; c < c1; ++c) {
-        float dl = a.d_logits ? a.d_logits[(size_t)row * T + c] : 0.f;
-        if (a.d_samples) { const float y = a.soft[(size_t)row * T + c]; dl += y * (a.d_samples[(size_t)row * T + c] - dot) * inv_tau; }
-        a.DL[(size_t)row * T + c] = dl;
-#pragma unroll
-        for (int i = 0; i < HH; ++i) dh[i] = fmaf(Wh[c * HH + i], dl, dh[i]);
-      }
-    }
-  }
-  store32(a.DH + (size_t)(NBLK - 1) * a.B * HH, row, on, dh);
-  bwd_part_a(PRM, s, a, d, NBLK - 1, row, on, dh);
-}
-
 // sums of one BatchNorm backward from the partials; block 0 writes dgamma / dbeta
 __device__ __forceinline__ void bnb_finalize(float* sums, const GBwd& a, int li, int g_off, int b_off) {
   __shared__ double fin[2][2][HH];
@@ -614,87 +417,6 @@ __device__ __forceinline__ void bnb_finalize(float* sums, const GBwd& a, int li,
     }
   }
   __syncthreads();
-}
-
-// kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
-__global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_b_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
-  __shared__ Smem s;
-  bnb_finalize(s.sums, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
-  stage(s.gamma, PRM + d.bn2_g[k], HH);
-  stage(s.mean, PRM + d.bn1_g[k], HH); stage(s.inv, PRM + d.bn1_b[k], HH);     // bn1's gamma / beta (names reused)
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float gam[HH], bet[HH], z[HH], dh[HH], dz2[HH], da1[HH];
-  __syncthreads();
-  film_params_b(s, PRM, a, d, k, row, on, gam, bet);
-  load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
-  load32(a.Z2 + (size_t)k * a.B * HH, row, on, z);
-  const float* sm2 = a.SM + (size_t)(2 * k + 1) * 2 * HH;
-  float dgam[HH];
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    const float xh = (z[j] - sm2[j]) * sm2[HH + j];
-    const float n2 = fmaf(xh, s.gamma[j], PRM[d.bn2_b[k] + j]);
-    const float dn2 = dh[j] * gam[j];
-    dz2[j] = s.gamma[j] * sm2[HH + j] * (dn2 - s.sums[j] - xh * s.sums[HH + j]);
-    dgam[j] = dh[j] * n2;
-  }
-  store32(a.DZ2 + (size_t)k * a.B * HH, row, on, dz2);
-  lin_t32(s.lin, PRM + d.fc2_w[k], dz2, da1);
-  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
-  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
-  float a1[HH], v[HH], w[HH], dbet[HH];
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    const float xh = (z[j] - sm1[j]) * sm1[HH + j];
-    const float n1 = fmaf(xh, s.mean[j], s.inv[j]);
-    const float f = fmaf(gam[j], n1, bet[j]);
-    a1[j] = f > 0.f ? f : 0.f;
-    const float df1 = f > 0.f ? da1[j] : 0.f;
-    dgam[j] = fmaf(df1, n1, dgam[j]);
-    dbet[j] = dh[j] + df1;
-    v[j] = on ? df1 * gam[j] : 0.f;          // dn1
-    w[j] = v[j] * xh;
-  }
-  store32(a.A1 + (size_t)k * a.B * HH, row, on, a1);
-  store32(a.DG + (size_t)k * a.B * HH, row, on, dgam);
-  store32(a.DB + (size_t)k * a.B * HH, row, on, dbet);
-  store32(a.DN1, row, on, v);
-  block_colsums(v, w, s.red, s.red2, a.Q + ((size_t)(2 * k) * a.nblocks + blockIdx.x) * 2 * HH);
-}
-
-// kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
-__global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(1, 1))) g_bwd_c_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
-  __shared__ Smem s;
-  bnb_finalize(s.sums, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
-  stage(s.gamma, PRM + d.bn1_g[k], HH);
-  __syncthreads();
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float z[HH], dn1[HH], dz1[HH], dh[HH], t[HH];
-  load32(a.Z1 + (size_t)k * a.B * HH, row, on, z);
-  load32(a.DN1, row, on, dn1);
-  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
-#pragma unroll
-  for (int j = 0; j < HH; ++j) {
-    const float xh = (z[j] - sm1[j]) * sm1[HH + j];
-    dz1[j] = s.gamma[j] * sm1[HH + j] * (dn1[j] - s.sums[j] - xh * s.sums[HH + j]);
-  }
-  store32(a.DZ1 + (size_t)k * a.B * HH, row, on, dz1);
-  lin_t32(s.lin, PRM + d.fc1_w[k], dz1, t);
-  load32(a.DH + (size_t)k * a.B * HH, row, on, dh);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) dh[j] += t[j];
-  if (k > 0) {
-    store32(a.DH + (size_t)(k - 1) * a.B * HH, row, on, dh);
-    bwd_part_a(PRM, s, a, d, k - 1, row, on, dh);
-    return;
-  }
-  float h0[HH];
-  load32(a.H, row, on, h0);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) dh[j] = h0[j] > 0.f ? dh[j] : 0.f;
-  store32(a.DZIN, row, on, dh);
 }
 
 // ---- backward, four waves per 64 rows (same split as the forward: wave q owns channels 8q .. 8q+7) -------------------------------
@@ -939,20 +661,15 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
   const dim3 grid(a.nblocks), block(FT);
   hipLaunchKernelGGL(g_fwd_first_kernel, grid, block, 0, s, args->params, a, d);
   if (int e = launch_status("g_fwd_first_kernel")) return e;
-  static const int four = getenv("PCG_HOUSE_4WAVE") ? atoi(getenv("PCG_HOUSE_4WAVE")) : 1;   // A/B switch
   const dim3 block4(FT * NQ);
   for (int k = 0; k < NBLK; ++k) {
-    if (four) hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
-    else hipLaunchKernelGGL(g_fwd_a_kernel, grid, block, 0, s, args->params, a, d, bs, k);
-    if (int e = launch_status("g_fwd_a_kernel")) return e;
-    if (four) hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
-    else hipLaunchKernelGGL(g_fwd_b_kernel, grid, block, 0, s, args->params, a, d, bs, k);   // the last block: + the output heads
-    if (int e = launch_status("g_fwd_b_kernel")) return e;
+    hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    if (int e = launch_status("g_fwd_a4_kernel")) return e;
+    hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    if (int e = launch_status("g_fwd_b4_kernel")) return e;
   }
-  if (four) {
-    hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
-    if (int e = launch_status("g_heads4_kernel")) return e;
-  }
+  hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
+  if (int e = launch_status("g_heads4_kernel")) return e;
   return PCG_OK;
 }
 
@@ -972,19 +689,14 @@ extern "C" int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_b
   a.DL = args->DL; a.DC = args->DC; a.Q = args->Q; a.B = args->B; a.nblocks = (args->B + FT - 1) / FT; a.accumulate = args->accumulate;
   a.tau = args->tau; a.res_scale = args->res_scale;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(a.nblocks), block(FT);
-  static const int four = getenv("PCG_HOUSE_4WAVE") ? atoi(getenv("PCG_HOUSE_4WAVE")) : 1;   // A/B switch
-  const dim3 block4(FT * NQ);
-  if (four) hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
-  else hipLaunchKernelGGL(g_bwd_first_kernel, grid, block, 0, s, args->params, a, d);
-  if (int e = launch_status("g_bwd_first_kernel")) return e;
+  const dim3 grid(a.nblocks), block4(FT * NQ);
+  hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
+  if (int e = launch_status("g_bwd_first4_kernel")) return e;
   for (int k = NBLK - 1; k >= 0; --k) {
-    if (four) hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, d, k);
-    else hipLaunchKernelGGL(g_bwd_b_kernel, grid, block, 0, s, args->params, a, d, k);
-    if (int e = launch_status("g_bwd_b_kernel")) return e;
-    if (four) hipLaunchKernelGGL(g_bwd_c4_kernel, grid, block4, 0, s, args->params, a, d, k);
-    else hipLaunchKernelGGL(g_bwd_c_kernel, grid, block, 0, s, args->params, a, d, k);
-    if (int e = launch_status("g_bwd_c_kernel")) return e;
+    hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    if (int e = launch_status("g_bwd_b4_kernel")) return e;
+    hipLaunchKernelGGL(g_bwd_c4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    if (int e = launch_status("g_bwd_c4_kernel")) return e;
   }
   return PCG_OK;
 }
