@@ -5,6 +5,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL; weak scaling: 512 images per GPU)
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes, one per
+GPU; the parent never touches the GPU) and relays rank 0's JSON line; under torch.distributed.run it is a rank.
+
 A "step" = D(real) fwd+bwd, G fwd, D(fake.detach()) fwd+bwd, Adam(D), D(fake) fwd, bwd through D into G, Adam(G)
 on a synthetic MNIST-shaped batch (U[-1,1) 64x64 images, N(0,1) noise) that is already resident in HBM.  fp32
 throughout (v_mfma_f32_32x32x2_f32 for the contractions).  Rank 0 prints ONE JSON line.
@@ -46,23 +49,83 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(batch=256, steps=2):
-    """Reference loop restated on PyTorch-CPU (oracle), bounded sample: 1 warm-up + `steps` timed steps."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch=BATCH_PER_GPU, steps=3, threads=None):
+    """Reference loop restated on PyTorch-CPU (oracle) at the bench batch: 1 warm-up step, then the median
+    of `steps` timed steps — a bounded sample (~10 s of CPU work)."""
     from oracle import dcgan_ref as R
-    # the GPU box gives one GPU a 16-core share; measured there: 8 thr 221, 16 thr 328, 32 thr 207, 64 thr 87 img/s
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box gives the job a 16-core share of the host; measured there (r01): 8 thr 221, 16 thr 328, 32 thr 207, 64 thr
+    # 87 img/s — more threads than the share make the CPU figure worse, so the default is the share
+    cores = threads or min(16, avail)
     torch.set_num_threads(cores)
     netG, netD = R.build(None, seed=1)
     crit, optD, optG = R.make_optimizers(netG, netD)
     real, noise = R.synthetic_batch(batch, seed=0)
     R.dcgan_step(netG, netD, crit, optD, optG, real, noise)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         R.dcgan_step(netG, netD, crit, optD, optG, real, noise)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} G+D steps at batch {batch} (bench batch {BATCH_PER_GPU}), 1 warm-up step, PyTorch-CPU fp32 "
-                      f"restatement of mnist_dcgan.py:147-175 (oracle/dcgan_ref.py)"}
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch / med, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "host_cpus_visible": avail,
+            "step_seconds": [round(t, 3) for t in times],
+            "sample": f"median of {steps} G+D steps at batch {batch} (= the bench batch), after 1 warm-up step; PyTorch-CPU fp32 "
+                      f"restatement of mnist_dcgan.py:147-175 (oracle/dcgan_ref.py), {torch.get_num_threads()} threads"}
+
+
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as CHILD processes — one per GPU, the
+    environment torch.distributed.run would give them — before anything in this process touches the GPU, relay rank 0's stdout
+    (the JSON line) and fail if any rank fails.  The parent only counts devices (no HIP initialisation) and waits."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py --gpus {n}: this node exposes {have} GPU(s); one rank per GPU is required (no oversubscription)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0 inherits stdout (its JSON line is the bench output); the other ranks print nothing there, their stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending.values():      # exactly the processes started above
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def params_digest(nets):
+    """One int64 per net: the wrap-around sum of the parameter bits — equal on two replicas iff (up to a 2^-64 collision) their
+    flat parameter buffers are bit-identical.  Runs after the timed region (ATen reduction: diagnostics, not the step)."""
+    return torch.stack([n.flat_params.view(torch.int32).to(torch.int64).sum() for n in nets])
 
 
 def main():
@@ -76,14 +139,19 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL gradient-sync path even with one rank")
     ap.add_argument("--eager", action="store_true", help="enqueue every step kernel by kernel instead of replaying the captured HIP graph(s)")
     ap.add_argument("--event-every", type=int, default=8, help="one timed step per this many (at most 3 in total) runs eagerly with HIP events around the conv launches")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: min(16, visible cores))")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N>1 must be launched by torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world} (one rank per GPU; start it with "
+                 f"--nproc-per-node {args.gpus} or let `python bench.py --gpus N` start the ranks itself)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -94,12 +162,14 @@ def main():
     pcgan_amd.load()
 
     dp = None
+    rccl_ranks = None
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         from pcgan_amd.parallel import GradSync, broadcast_parameters
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        rccl_ranks = dist.get_world_size()          # what RCCL actually spans (the driver checks it against --gpus)
         dp = GradSync(always_exchange=args.force_dp)
 
     # random-init weights of the reference architecture (weights_init distribution), identical on every rank
@@ -186,6 +256,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # data-parallel replicas must hold bit-identical parameters after the timed steps (same start, same averaged gradients,
+    # same Adam): all-gather a digest of both nets' flat parameter buffers and compare
+    replicas_identical = None
+    if dp is not None:
+        dig = params_digest([netG, netD])
+        allg = [torch.empty_like(dig) for _ in range(world)]
+        torch.distributed.all_gather(allg, dig)
+        replicas_identical = all(torch.equal(a, allg[0]) for a in allg)
+        if not replicas_identical:
+            sys.exit(f"rank {rank}: replicas diverged — parameter digests {[a.tolist() for a in allg]}")
+
     losses = {k: float(out[k].item()) for k in ("errD_real", "errD_fake", "errG")}
     if not all(v == v and abs(v) < 1e4 for v in losses.values()):
         sys.exit(f"non-finite losses after the timed region: {losses}")
@@ -217,7 +298,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(batch=args.batch, threads=args.cpu_threads)
 
     if rank == 0:
         line = {
@@ -229,6 +310,7 @@ def main():
                                    f"batch {args.batch} per GPU, full G+D step incl. BatchNorm, BCE, Adam x2",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
+            "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",
         }

@@ -242,7 +242,8 @@ int pcg_cross_entropy_fwd_bwd(const float* logits, const int64_t* target, int32_
 /* ---- device-side batch synthesis (counter-based Philox-4x32-10; deterministic in (seed, offset)) ---------------
  * Replaces the per-iteration host draws of the training loops: build_mask (trainer.py:45-72: per sample choose
  * `num_selected` of the (H/patch)x(W/patch) patches, nearest-upsample to HxW), torch.randint targets (trainer.py:94;
- * `exclude` != NULL draws uniformly from the classes other than exclude[i]: house_sales trainer.py:248-249) and
+ * `exclude` != NULL applies house_sales trainer.py:248-249's rule: draw k uniformly over [low, high) and map a collision
+ * k == exclude[i] to low + (k - low + 1) % (high - low), i.e. the next class gets probability 2/K, the others 1/K) and
  * torch.randn latent noise (mnist_dcgan.py:156).  Streams differ from torch's generators by design. */
 int pcg_patch_mask(float* out /*[B][H][W]*/, int32_t B, int32_t H, int32_t W, int32_t patch_size, int32_t num_selected,
                    uint64_t seed, uint64_t offset, pcg_stream_t stream);

@@ -124,6 +124,36 @@ def dcgan_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, confi
     }
 
 
+def dcgan_train(dataloader, config, netG, netD, log=None):
+    """The outer loop, mnist_dcgan.py:125-198, without the plots: optimizers (:125-127), the fixed viz noise (:130, drawn from
+    the global generator BEFORE the first iteration), per iteration the loop body (noise drawn from the global generator, :156),
+    the running sums of errG / errD (:184-185), and — every 500 iterations and at the very end (:187) — a forward of netG on
+    viz_noise under no_grad with the net still in training mode (:188-189), which updates its BatchNorm running statistics.
+    Returns (epoch_G_losses, epoch_D_losses, img_list of raw generated batches, iters)."""
+    c = dict(DEFAULT_CONFIG, **(config or {}))
+    criterion, optimizerD, optimizerG = make_optimizers(netG, netD, c)
+    viz_noise = torch.randn(c["batch_size"], c["z_dim"], 1, 1)                          # :130
+    img_list, epoch_G_losses, epoch_D_losses = [], [], []
+    iters = 0
+    for epoch in range(c["epochs"]):                                                   # :140
+        running_G_loss = running_D_loss = 0.0
+        for i, data in enumerate(dataloader):                                          # :143
+            real = data[0]
+            noise = torch.randn(real.size(0), c["z_dim"], 1, 1)                        # :156
+            out = dcgan_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, c)
+            if log is not None and i % 200 == 0:                                       # :178-181
+                log(f"[{epoch}/{c['epochs']}][{i}/{len(dataloader)}] Loss_D: {out['errD']:.4f} Loss_G: {out['errG']:.4f}")
+            running_G_loss += out["errG"]                                              # :184
+            running_D_loss += out["errD"]                                              # :185
+            if iters % 500 == 0 or (epoch == c["epochs"] - 1 and i == len(dataloader) - 1):   # :187
+                with torch.no_grad():
+                    img_list.append(netG(viz_noise).detach().cpu())                   # :188-189
+            iters += 1
+        epoch_G_losses.append(running_G_loss / len(dataloader))                        # :195-198
+        epoch_D_losses.append(running_D_loss / len(dataloader))
+    return epoch_G_losses, epoch_D_losses, img_list, iters
+
+
 def synthetic_batch(batch, seed, config=None, dtype=torch.float32):
     """Seeded MNIST-shaped synthetic batch: real ~ U[-1,1) [B,C,64,64], z ~ N(0,1) [B,z,1,1]."""
     c = dict(DEFAULT_CONFIG, **(config or {}))

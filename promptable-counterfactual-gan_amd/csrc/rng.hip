@@ -81,10 +81,11 @@ __global__ void __launch_bounds__(256) randint_kernel(int64_t* __restrict__ out,
     for (int e = 0; e < 4; ++e) {
       const int64_t j = i * 4 + e;
       if (j >= n) break;
-      if (exclude) {  // uniform over the span minus exclude[j] (house-sales: target != source class, trainer.py:248-249)
-        const uint32_t k = (uint32_t)(((uint64_t)v[e] * (uint64_t)(span - 1)) >> 32);
+      if (exclude) {  // the reference's rule (house-sales trainer.py:248-249): k uniform over the WHOLE span, a collision with
+                      // exclude[j] maps to the next class (cyclically) — P(exclude+1) = 2/span, 1/span for the others, never exclude
+        const uint32_t k = (uint32_t)(((uint64_t)v[e] * (uint64_t)span) >> 32);
         const int64_t ex = exclude[j] - lo;
-        out[j] = lo + (int64_t)(k >= (uint32_t)ex ? k + 1 : k);
+        out[j] = lo + (int64_t)((int64_t)k == ex ? (k + 1u) % span : k);
       } else {
         out[j] = lo + (int64_t)(((uint64_t)v[e] * (uint64_t)span) >> 32);
       }

@@ -8,7 +8,9 @@ reference), same loss / optimizer construction and the same D-step / G-step sequ
     Generator / Discriminator  :72-116              Generator / Discriminator (SequentialConvNet)
     criterion, optimizerD/G    :125-127             make_optimizers -> pcgan_amd BCELoss, Adam
     loop body                  :147-175             train_step (no host sync inside; scalars stay on device)
+    outer loop                 :129-198             train (epochs x batches, logging, the train-mode viz forward :187-191)
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -171,3 +173,63 @@ def build(cfg=None, device="cuda", seed=None):
     netD = Discriminator(c).to(device)
     netD.apply(weights_init)
     return netG, netD
+
+
+def train(dataloader, cfg=None, netG=None, netD=None, device="cuda", log=print, device_rng=None, dp=None):
+    """The reference's training script from the fixed viz noise to the per-epoch loss averages (mnist_dcgan.py:129-198) with
+    its plotting left out: `dataloader` yields (images, ...) batches (:143,148), per iteration one `train_step`, every 200
+    iterations the log line (:178-181), every 500 iterations and at the very end a forward of the generator on the fixed
+    `viz_noise` under no_grad (:187-191).  That viz forward runs with the generator in TRAINING mode in the reference, so it
+    updates the BatchNorm running statistics — it is part of the numerical path and is kept; the image-grid rendering
+    (torchvision.make_grid, :190) is plotting and is not: `img_list` holds the raw generated batches on the CPU.
+
+    Noise: drawn like the reference does (`torch.randn` from torch's global generator, here on the CPU and copied to the device:
+    seed-for-seed the draws of the reference's CPU path), or on the GPU from `device_rng` (an ops.DeviceRNG).
+    Host syncs: the reference calls .item() six times per iteration; here the loss tensors are read once per epoch (and at the log
+    lines), summed in the same order, so the averages are the same numbers.
+    Returns a dict: netG, netD, epoch_G_losses, epoch_D_losses, img_list, iters."""
+    c = _cfg(cfg)
+    dev = torch.device(device)
+    if netG is None or netD is None:
+        netG, netD = build(c, device=dev)                                     # :119-122
+    criterion, optimizerD, optimizerG = make_optimizers(netG, netD, c)        # :125-127
+
+    def randn(b):
+        if device_rng is not None:
+            return device_rng.randn((b, c["z_dim"], 1, 1), dev)
+        return torch.randn(b, c["z_dim"], 1, 1).to(dev)
+
+    viz_noise = randn(c["batch_size"])                                        # :130
+    img_list, epoch_G_losses, epoch_D_losses = [], [], []
+    iters = 0
+    nbatches = len(dataloader)
+    log("Starting Training Loop...")                                          # :139
+    for epoch in range(c["epochs"]):                                          # :140
+        pending = []                                                          # (errD_real, errD_fake, errG) device scalars of the epoch
+        for i, data in enumerate(dataloader):                                 # :143
+            real = data[0].to(dev)                                            # :148
+            noise = randn(real.size(0))                                       # :156
+            out = train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, c, dp=dp)   # :147-175
+            pending.append((out["errD_real"], out["errD_fake"], out["errG"]))
+            if i % 200 == 0:                                                  # :178-181
+                errD = float(np.float32(out["errD_real"].item()) + np.float32(out["errD_fake"].item()))   # :163
+                log(f"[{epoch}/{c['epochs']}][{i}/{nbatches}] Loss_D: {errD:.4f} Loss_G: {out['errG'].item():.4f} "
+                    f"D(x): {ops.mean_fwd(out['out_real'].detach().contiguous()).item():.4f} "
+                    f"D(G(z)): {ops.mean_fwd(out['out_fake'].detach().contiguous()).item():.4f} / "
+                    f"{ops.mean_fwd(out['out_g'].detach().contiguous()).item():.4f}")
+            if iters % 500 == 0 or (epoch == c["epochs"] - 1 and i == nbatches - 1):   # :187
+                if dp is not None:
+                    dp.wait(netG)                                             # Adam(G) of this iteration runs on the side stream
+                with torch.no_grad():
+                    img_list.append(netG(viz_noise).detach().cpu())           # :188-189 (train mode: updates running stats)
+            iters += 1                                                        # :193
+        running_G_loss = running_D_loss = 0.0                                 # :141-142, :184-185 (same order of additions)
+        for e_real, e_fake, e_g in pending:
+            running_G_loss += e_g.item()
+            running_D_loss += float(np.float32(e_real.item()) + np.float32(e_fake.item()))   # errD is an fp32 sum (:163)
+        epoch_G_losses.append(running_G_loss / nbatches)                      # :195-198
+        epoch_D_losses.append(running_D_loss / nbatches)
+    if dp is not None:
+        dp.wait_all()
+    return {"netG": netG, "netD": netD, "epoch_G_losses": epoch_G_losses, "epoch_D_losses": epoch_D_losses, "img_list": img_list,
+            "iters": iters}

@@ -537,6 +537,39 @@ class _CutDP:
         self._owner._cut(self._dp.wait_all)
 
 
+class _HipGraphCapture:
+    """Capture backend of GraphedStep: HIP graphs (torch.cuda.CUDAGraph), every segment in ONE memory pool."""
+
+    def __init__(self, device):
+        self._pool = None
+        self._tick = torch.zeros(1, device=device)
+
+    def warmup(self, run, n, dp):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(n):
+                run()
+            if dp is not None:
+                dp.wait_all()
+        torch.cuda.current_stream().wait_stream(side)
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
+        self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
+        self._ctx.__enter__()
+        self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
+
+    def end(self):
+        self._ctx.__exit__(None, None, None)
+        if self._pool is None:
+            self._pool = self._g.pool()
+        return self._g             # .replay()
+
+    abort = end
+
+
 class GraphedStep:
     """A whole training step captured once in a HIP graph and replayed with one host call — the host then cannot starve the GPU,
     whether the step is short (small per-GPU batches, the tabular nets) or the host cores are slow or shared.
@@ -550,31 +583,28 @@ class GraphedStep:
 
     Data-parallel steps: pass the `parallel.GradSync` as `dp`; `step_fn` then takes one argument (the object to hand to the
     training step as its `dp`).  The step is captured as a chain of graph segments cut at the exchange points; replay() launches
-    segment, exchange, segment, ... in the captured order (all segments share one memory pool, so the order is fixed)."""
+    segment, exchange, segment, ... in the captured order (all segments share one memory pool, so the order is fixed).
 
-    def __init__(self, step_fn, inputs, modules, optimizers, warmup=3, dp=None):
+    `capture`: the capture backend (begin / end -> object with replay() / abort / warmup); default HIP graphs.  The CPU rehearsal of
+    the segment program (tests/test_parallel_gloo.py, world size 2 over gloo) passes a recording backend instead."""
+
+    def __init__(self, step_fn, inputs, modules, optimizers, warmup=3, dp=None, capture=None):
         self.inputs = dict(inputs)
         for m in modules:
             m._ensure_flat()
         saved = [(m.flat_params.clone(), [b.clone() for b in m.buffers()]) for m in modules]
         osnap = [o.snapshot() for o in optimizers]
         run = step_fn if dp is None else (lambda: step_fn(dp))
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                run()
-            if dp is not None:
-                dp.wait_all()
-        torch.cuda.current_stream().wait_stream(side)
+        if capture is None:
+            capture = _HipGraphCapture(self.inputs[next(iter(self.inputs))].device if self.inputs else torch.device("cuda"))
+        self._capture = capture
+        capture.warmup(run, max(1, warmup), dp)
         self.program = []          # [(graph, eager operation after it or None)]
-        self._pool = None
-        self._tick = torch.zeros(1, device=self.inputs[next(iter(self.inputs))].device) if self.inputs else torch.zeros(1, device="cuda")
-        self._begin()
+        capture.begin()
         try:
             self.out = step_fn() if dp is None else step_fn(_CutDP(dp, self))
         except BaseException:
-            self._ctx.__exit__(None, None, None)
+            capture.abort()
             raise
         self._end(None)
         if dp is not None:
@@ -587,23 +617,13 @@ class GraphedStep:
         for o, sn in zip(optimizers, osnap):
             o.restore(sn)
 
-    def _begin(self):
-        self._g = torch.cuda.CUDAGraph()
-        # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
-        self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
-        self._ctx.__enter__()
-        self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
-
     def _end(self, op):
-        self._ctx.__exit__(None, None, None)
-        if self._pool is None:
-            self._pool = self._g.pool()
-        self.program.append((self._g, op))
+        self.program.append((self._capture.end(), op))
 
     def _cut(self, op):
         self._end(op)
         op()                       # capture executes nothing; the exchange itself runs (state is restored after capture)
-        self._begin()
+        self._capture.begin()
 
     def load(self, **tensors):
         for k, v in tensors.items():

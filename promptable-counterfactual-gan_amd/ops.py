@@ -77,25 +77,47 @@ def _chk(t, name, dtype=torch.float32):
     return t
 
 
-def workspace(nbytes, device):
-    """A cached scratch buffer on `device`, grown on demand.  Stream-ordered use on the current stream only."""
-    key = (device.type, device.index)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        nbytes = max(int(nbytes), 1 << 20)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf
+_ws_retired = []   # scratch buffers that were outgrown: kept alive for the life of the process (see workspace())
 
 
-def workspace2(nbytes, device):
-    """A second cached scratch buffer (slab partials of linear_wgrad), separate from `workspace` so the two never alias."""
-    key = (device.type, device.index, 2)
+def _scratch(kind, nbytes, device):
+    """A cached scratch buffer per (device, HIP stream, kind), grown on demand.
+
+    Stream-ordered use: the buffer belongs to the stream that is current at the call, so work issued on a side stream
+    (GradSync.sync_then callbacks, graph capture streams) never shares scratch with the main stream.  A buffer that is outgrown
+    is RETIRED, never freed: a captured HIP graph (nn.GraphedStep, house.GraphedTrainStep) has its address baked into split-K
+    slabs / BatchNorm partial rows / weight-gradient slabs, and returning it to the caching allocator would let a later replay
+    write into memory that meanwhile belongs to another tensor (tests/test_hip_graph.py)."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, stream, kind)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+def workspace(nbytes, device):
+    """Scratch for the current stream (split-K slabs, BatchNorm partial rows, reductions)."""
+    return _scratch(0, nbytes, device)
+
+
+def workspace2(nbytes, device):
+    """A second scratch buffer (slab partials of linear_wgrad), separate from `workspace` so the two never alias."""
+    return _scratch(2, nbytes, device)
+
+
+def _ticket_buffer(device):
+    """Zero-initialised ticket counters of the linear weight-gradient kernels (they leave them zero), one set per stream."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, stream, "tickets")
+    tk = _ws_cache.get(key)
+    if tk is None:
+        tk = torch.zeros(_lib.load().pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=device)   # setup: zeroed once
+        _ws_cache[key] = tk
+    return tk
 
 
 def ohwi(w):
@@ -476,18 +498,11 @@ def gemm(A, B, M, N, K, transA=False, transB=False, lda=None, ldb=None, out=None
     return out
 
 
-_tickets = {}
-
-
 def linear_wgrad(dy, x, B, O, I, dW, db=None, ldy=None, ldx=None, accumulate_w=False, accumulate_b=False):
     """dW[O][I] (+)= dy^T x and db[O] (+)= colsum(dy) in one launch (deterministic slab split over the batch)."""
     lib = _lib.load()
     dev = x.device
-    key = (dev.type, dev.index)
-    tk = _tickets.get(key)
-    if tk is None:
-        tk = torch.zeros(lib.pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=dev)   # setup: zeroed once, kernels keep it zero
-        _tickets[key] = tk
+    tk = _ticket_buffer(dev)
     nbytes = lib.pcg_linear_wgrad_workspace_bytes(B, O, I)
     ws = workspace2(nbytes, dev) if nbytes else None
     check(lib.pcg_linear_wgrad(_p(dy), ldy if ldy is not None else O, _p(x), ldx if ldx is not None else I, B, O, I, _p(dW), _p(db),
@@ -511,11 +526,7 @@ def linear_wgrad_grouped(items, B, device):
         arr[k].ldy, arr[k].ldx, arr[k].O, arr[k].I = ldy, ldx, O, I
         arr[k].accumulate_w, arr[k].accumulate_b = int(bool(aw)), int(bool(ab))
         arr[k].tile_x, arr[k].tile_y = tx, ty
-    key = (device.type, device.index)
-    tk = _tickets.get(key)
-    if tk is None:
-        tk = torch.zeros(lib.pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=device)
-        _tickets[key] = tk
+    tk = _ticket_buffer(device)
     nbytes = lib.pcg_linear_wgrad_grouped_workspace_bytes(B, arr, n)
     ws = workspace2(nbytes, device)
     check(lib.pcg_linear_wgrad_grouped(arr, n, B, _p(ws), nbytes, _p(tk), _stream()), "pcg_linear_wgrad_grouped")
@@ -780,6 +791,11 @@ class DeviceRNG:
         self.offset = 0
 
     def _advance(self, n):
+        # the Philox offset is a kernel ARGUMENT held on the host: a draw captured into a HIP graph would replay the same numbers
+        # on every launch.  Draw outside the captured step and feed the result in as a static input (GraphedStep.load).
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise _lib.PcgError("DeviceRNG draw during HIP-graph capture: the captured kernel would replay identical random numbers; "
+                                "draw before the step and pass the tensors in (GraphedStep inputs)")
         off = self.offset
         self.offset += int(n)
         return off

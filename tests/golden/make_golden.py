@@ -99,6 +99,47 @@ def make_dcgan_small(path, g_hidden=8, d_hidden=8, z_dim=16, batch=4, steps=3):
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def make_dcgan_loop(path, g_hidden=8, d_hidden=8, z_dim=16, batch=4, epochs=2, nbatches=3):
+    """The reference's OUTER loop (mnist_dcgan.py:129-198: viz noise, epochs x batches, running losses, the train-mode viz forward
+    every 500 iterations and at the end) lifted from the syntax tree and executed unmodified on a seeded synthetic `dataloader`.
+    `vutils.make_grid` (torchvision, image-grid plotting, :190) is outside the numerical path: a pass-through keeps the raw batch."""
+    import types
+    config = {"image_channel": 1, "z_dim": z_dim, "g_hidden": g_hidden, "d_hidden": d_hidden, "real_label": 1.0,
+              "fake_label": 0.0, "lr": 2e-4, "seed": 1, "batch_size": batch, "epochs": epochs}
+    ns, setup_code, _ = _lift_dcgan(config)
+    src = os.path.join(REF, "dconv_gan/mnist/mnist_dcgan.py")
+    with open(src) as f:
+        tree = ast.parse(f.read(), filename=src)
+    loop = [n for n in tree.body if 129 <= n.lineno <= 198]
+    assert loop and isinstance(loop[-1], ast.For) and loop[-1].lineno == 140 and loop[-1].end_lineno == 198, "reference layout changed"
+    loop_code = compile(ast.Module(body=loop, type_ignores=[]), src, "exec")
+    torch.manual_seed(config["seed"])                      # :33
+    exec(setup_code, ns)                                   # nets + init + optimizers, :119-127
+    out = {"meta.g_hidden": np.int64(g_hidden), "meta.d_hidden": np.int64(d_hidden), "meta.z_dim": np.int64(z_dim),
+           "meta.batch": np.int64(batch), "meta.epochs": np.int64(epochs), "meta.nbatches": np.int64(nbatches)}
+    _sd("init.G", ns["netG"], out)
+    _sd("init.D", ns["netD"], out)
+    gen = torch.Generator().manual_seed(4242)
+    data = [(torch.rand(batch, 1, 64, 64, generator=gen) * 2 - 1,) for _ in range(nbatches)]
+    for k, (r,) in enumerate(data):
+        out[f"data.{k}"] = r.numpy()
+    ns["dataloader"] = data
+    ns["vutils"] = types.SimpleNamespace(make_grid=lambda t, **kw: t)
+    torch.manual_seed(777)                                 # the loop's global-RNG draws: viz_noise (:130), then one noise per iteration (:156)
+    out["meta.loop_seed"] = np.int64(777)
+    exec(loop_code, ns)
+    out["epoch_G_losses"] = np.asarray(ns["epoch_G_losses"], np.float64)
+    out["epoch_D_losses"] = np.asarray(ns["epoch_D_losses"], np.float64)
+    out["iters"] = np.int64(ns["iters"])
+    out["viz_noise"] = ns["viz_noise"].numpy()
+    for k, img in enumerate(ns["img_list"]):
+        out[f"img.{k}"] = img.numpy()
+    _sd("final.G", ns["netG"], out)
+    _sd("final.D", ns["netD"], out)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def tensor_digest(t, nsamples=64):
     """[sum, sum|.|, sum of squares] in float64 + `nsamples` strided samples: a compact pin for a large tensor."""
     a = np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float64).ravel()
@@ -760,7 +801,12 @@ def make_mnist_resize(path, n=24):
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
+    only = sys.argv[1:]
+    if only == ["dcgan_loop"]:          # regenerate one fixture without touching the others
+        make_dcgan_loop(os.path.join(HERE, "dcgan_loop_small.npz"))
+        sys.exit(0)
     make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))
+    make_dcgan_loop(os.path.join(HERE, "dcgan_loop_small.npz"))
     make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))
     make_moons(os.path.join(HERE, "moons_ref.npz"))
     make_countergan_trained(os.path.join(HERE, "countergan_trained_eval.npz"), os.path.join(HERE, "countergan_generator_trained.pt"))

@@ -182,6 +182,14 @@ def test_device_batch_synthesis(pcg):
     src = torch.randint(0, 4, (50000,), device=DEV)
     t2 = rng.randint(0, 4, 50000, DEV, exclude=src)
     assert not bool((t2 == src).any()) and t2.min() == 0 and t2.max() == 3              # house_sales trainer.py:248-249
+    # the reference's rule conditioned on the source class y: randint over all K, a collision goes to (y + 1) % K — so
+    # P(y+1 | y) = 2/K and 1/K for the two remaining classes (NOT uniform over the K-1 others)
+    for y in range(4):
+        sel_y = (src == y)
+        n_y = int(sel_y.sum())
+        p = torch.bincount(t2[sel_y], minlength=4).float().cpu() / n_y
+        want = torch.full((4,), 0.25); want[y] = 0.0; want[(y + 1) % 4] = 0.5
+        assert float((p - want).abs().max()) < 5 * (0.25 / n_y) ** 0.5, (y, p.tolist())
     z = rng.randn((512, 100, 1, 1), DEV).cpu()
     assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1.0) < 0.02
     assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.15

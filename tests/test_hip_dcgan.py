@@ -84,6 +84,35 @@ def test_golden_reference_trajectory(pcg, golden_dir):
     _check_grads(list(netD.named_parameters()), [(n, gold[f"final.D.grad.{n}"]) for n, _ in netD.named_parameters()], "D")
 
 
+def test_outer_loop_golden(pcg, golden_dir):
+    """dcgan.train against the reference's own outer loop (mnist_dcgan.py:129-198, lifted by make_golden.make_dcgan_loop): the
+    per-epoch loss averages, the generated viz batches and the final state — including BatchNorm running statistics and
+    num_batches_tracked, which count the two train-mode viz forwards (:187-191) on top of the six training iterations."""
+    D = pcg.dcgan
+    gold = dict(np.load(os.path.join(golden_dir, "dcgan_loop_small.npz")))
+    cfg = {"g_hidden": int(gold["meta.g_hidden"]), "d_hidden": int(gold["meta.d_hidden"]), "z_dim": int(gold["meta.z_dim"]),
+           "batch_size": int(gold["meta.batch"]), "epochs": int(gold["meta.epochs"])}
+    netG, netD = D.Generator(cfg), D.Discriminator(cfg)
+    _load_sd(netG, {k[7:]: torch.from_numpy(v.copy()) for k, v in gold.items() if k.startswith("init.G.")})
+    _load_sd(netD, {k[7:]: torch.from_numpy(v.copy()) for k, v in gold.items() if k.startswith("init.D.")})
+    netG.to(DEV); netD.to(DEV)
+    data = [(torch.from_numpy(gold[f"data.{k}"]),) for k in range(int(gold["meta.nbatches"]))]
+    lines = []
+    torch.manual_seed(int(gold["meta.loop_seed"]))          # same global-generator draws as the reference's CPU run
+    out = D.train(data, cfg, netG=netG, netD=netD, device=DEV, log=lines.append)
+    assert out["iters"] == int(gold["iters"]) and len(out["img_list"]) == 2
+    assert lines[0] == "Starting Training Loop..." and lines[1].startswith("[0/2][0/3] Loss_D: 1.68") and len(lines) == 3
+    np.testing.assert_allclose(out["epoch_G_losses"], gold["epoch_G_losses"], rtol=1e-4)
+    np.testing.assert_allclose(out["epoch_D_losses"], gold["epoch_D_losses"], rtol=1e-4)
+    for k, img in enumerate(out["img_list"]):
+        np.testing.assert_allclose(img.numpy(), gold[f"img.{k}"], rtol=1e-3, atol=1e-4)
+    assert int(netG.state_dict()["main.1.num_batches_tracked"]) == 8
+    for key, v in netG.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), gold[f"final.G.{key}"], rtol=2e-4, atol=2e-5, err_msg=key)
+    for key, v in netD.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), gold[f"final.D.{key}"], rtol=2e-4, atol=2e-5, err_msg=key)
+
+
 def _noise_aware(got, truth64, ref32, what, base_l2=1e-4, base_max=1e-3):
     """Accept `got` (HIP, fp32) if it is as close to the float64 evaluation of the reference algorithm as the stated
     tolerance, or within 3x the distance of the reference's own fp32 CPU result from that float64 truth.  At tiny

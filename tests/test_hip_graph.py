@@ -1,0 +1,88 @@
+"""GPU: scratch-buffer lifetime against captured HIP graphs.  A captured step has the addresses of its split-K slabs,
+BatchNorm partial rows and weight-gradient slabs baked in; ops._scratch therefore keys scratch by (device, stream) and RETIRES an
+outgrown buffer instead of freeing it.  Also: a DeviceRNG draw inside a capture must fail loudly (it would replay the same numbers)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pcg():
+    import pcgan_amd
+    from pcgan_amd import dcgan  # noqa: F401
+    return pcgan_amd
+
+
+def _fresh(D, cfg, seed=5):
+    torch.manual_seed(seed)
+    netG, netD = D.Generator(cfg).to(DEV), D.Discriminator(cfg).to(DEV)
+    netG.apply(D.weights_init); netD.apply(D.weights_init)
+    return (netG, netD) + tuple(D.make_optimizers(netG, netD, cfg))
+
+
+def test_larger_eager_op_after_capture_does_not_corrupt_replay(pcg):
+    from pcgan_amd.nn import GraphedStep
+    D, ops = pcg.dcgan, pcg.ops
+    cfg = {"g_hidden": 32, "d_hidden": 32, "z_dim": 64}
+    B = 32
+    g = torch.Generator().manual_seed(3)
+    reals = [(torch.rand(B, 1, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(3)]
+    noises = [torch.randn(B, 64, 1, 1, generator=g).to(DEV) for _ in range(3)]
+    # eager trajectory
+    netG, netD, crit, optD, optG = _fresh(D, cfg)
+    for i in range(3):
+        o = D.train_step(netG, netD, crit, optD, optG, reals[i], noises[i], cfg)
+    want = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params.clone(), netD.flat_params.clone())
+    # captured, then a MUCH larger eager weight gradient (grows every scratch buffer of the main stream) and a burst of
+    # allocations that would recycle any freed block, then replay
+    netG, netD, crit, optD, optG = _fresh(D, cfg)
+    s_real, s_noise = reals[0].clone(), noises[0].clone()
+    gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, cfg), {"real": s_real, "noise": s_noise},
+                     [netG, netD], [optD, optG])
+    retired_before = len(ops._ws_retired)
+    small = ops.workspace(1 << 20, torch.device(DEV))
+    geom = ops.conv_geom(256, 32, 32, 128, 256, 4, 4, 2, 1)
+    x = torch.randn(256, 32, 32, 128, device=DEV)
+    dy = torch.randn(256, geom.OH, geom.OW, 256, device=DEV)
+    dw = torch.empty(256, 4, 4, 128, device=DEV)
+    ops.conv2d_wgrad(geom, x, dy, dw, False)
+    big = ops.workspace(1 << 20, torch.device(DEV))
+    if big.data_ptr() != small.data_ptr():          # the main stream's buffer was outgrown: the old one must still be alive
+        assert len(ops._ws_retired) > retired_before and any(t.data_ptr() == small.data_ptr() for t in ops._ws_retired)
+    junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(16)]     # poison whatever the allocator hands out
+    for i in range(3):
+        gs.load(real=reals[i], noise=noises[i])
+        o = gs.replay()
+    torch.cuda.synchronize()
+    del junk
+    got = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params, netD.flat_params)
+    assert got[0] == want[0]
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+
+
+def test_scratch_is_per_stream_and_retired_not_freed(pcg):
+    ops = pcg.ops
+    dev = torch.device(DEV)
+    side = torch.cuda.Stream()
+    a = ops.workspace(1 << 20, dev)
+    with torch.cuda.stream(side):
+        b = ops.workspace(1 << 20, dev)
+        n0 = len(ops._ws_retired)
+        c = ops.workspace(b.numel() + 1, dev)       # outgrow the side stream's buffer
+        assert len(ops._ws_retired) == n0 + 1 and ops._ws_retired[-1] is b and c.numel() > b.numel()
+    assert a.data_ptr() != b.data_ptr()             # side-stream work (GradSync.sync_then callbacks) never shares scratch with main
+    assert ops.workspace(1 << 20, dev).data_ptr() == a.data_ptr()
+    assert ops.workspace2(1 << 20, dev).data_ptr() != a.data_ptr()
+
+
+def test_rng_draw_inside_capture_raises(pcg):
+    ops = pcg.ops
+    rng = ops.DeviceRNG(seed=3)
+    rng.randn((16,), torch.device(DEV))             # fine outside a capture
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(pcg.PcgError, match="capture"):
+        with torch.cuda.graph(g):
+            torch.zeros(1, device=DEV).add_(1.0)
+            rng.randn((16,), torch.device(DEV))

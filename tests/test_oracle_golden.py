@@ -80,6 +80,28 @@ def test_training_steps_match_reference_loop_body(gold):
         np.testing.assert_allclose(p.grad.numpy(), gold[f"final.D.grad.{n}"], rtol=1e-4, atol=1e-6, err_msg=n)
 
 
+def test_outer_loop_matches_reference(golden_dir):
+    """mnist_dcgan.py:129-198 (lifted and run unmodified by make_golden.make_dcgan_loop): epochs x batches, running loss averages,
+    the train-mode viz forward at iteration 0 and at the very end (it moves the generator's BatchNorm running statistics)."""
+    gold = dict(np.load(os.path.join(golden_dir, "dcgan_loop_small.npz")))
+    cfg = dict(_cfg(gold), batch_size=int(gold["meta.batch"]), epochs=int(gold["meta.epochs"]))
+    netG, netD = R.Generator(cfg), R.Discriminator(cfg)
+    _load(netG, gold, "init.G"); _load(netD, gold, "init.D")
+    data = [(torch.from_numpy(gold[f"data.{k}"]),) for k in range(int(gold["meta.nbatches"]))]
+    torch.manual_seed(int(gold["meta.loop_seed"]))
+    g_losses, d_losses, imgs, iters = R.dcgan_train(data, cfg, netG, netD)
+    assert iters == int(gold["iters"]) == 6 and len(imgs) == 2
+    np.testing.assert_allclose(g_losses, gold["epoch_G_losses"], rtol=1e-5)
+    np.testing.assert_allclose(d_losses, gold["epoch_D_losses"], rtol=1e-5)
+    for k, img in enumerate(imgs):
+        np.testing.assert_allclose(img.numpy(), gold[f"img.{k}"], rtol=1e-4, atol=2e-5)
+    assert int(netG.state_dict()["main.1.num_batches_tracked"]) == int(gold["final.G.main.1.num_batches_tracked"]) == 6 + 2
+    for k, v in netG.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), gold[f"final.G.{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+    for k, v in netD.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), gold[f"final.D.{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 # ---- CounteRGAN/mnist: oracle/countergan_ref.py against the reference's own modules + train_countergan --------------
 from oracle import countergan_ref as CR  # noqa: E402
 
