@@ -167,12 +167,14 @@ int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t rows, int32_
                            float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
 /* BatchNorm backward from the partial sums a pcg_conv2d_*_bnbwd call left behind: dm = dy*act'(.) (already masked), partial =
- * [nparts][2][C] (sum dm, sum dm*xhat) in the buffer of pcg_conv2d_*_bn_workspace_bytes (its tail is scratch for the two-level
+ * fp64 [nparts][2][C] (sum dm, sum dm*xhat: every per-channel sum of the BatchNorm family is accumulated in double, as the
+ * reference's CPU path does — [torch] at::acc_type<float, false>) in the opaque, 8-byte-aligned buffer of
+ * pcg_conv2d_*_bn_workspace_bytes (its tail is scratch for the two-level
  * finalize used when there are >= 4096 partial rows).  Fixed-order fp64 finalize (dgamma, dbeta as in pcg_bn_act_bwd) + the elementwise pass
  * dx = gamma*invstd*(dm - mean(dm) - xhat*mean(dm*xhat)).  workspace: pcg_bn_bwd_partial_workspace_bytes(C). */
 size_t pcg_bn_bwd_partial_workspace_bytes(int32_t C);
 int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                       const float* gamma, const float* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                       const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
                        int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------

@@ -49,21 +49,24 @@ struct FnStats {  // sum x, sum x^2
   static constexpr int NVAL = 2;
   const float* x;
   template <int VEC>
-  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
+  __device__ __forceinline__ void eval(size_t idx, int c0, double (&o)[2][VEC]) const {
     (void)c0;
     float v[VEC];
     ldv<VEC>(x, idx, v);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { o[0][e] = v[e]; o[1][e] = v[e] * v[e]; }
+    for (int e = 0; e < VEC; ++e) { o[0][e] = (double)v[e]; o[1][e] = (double)v[e] * (double)v[e]; }   // exact in fp64
   }
 };
 struct FnSum {  // sum dy
   static constexpr int NVAL = 1;
   const float* x;
   template <int VEC>
-  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[1][VEC]) const {
+  __device__ __forceinline__ void eval(size_t idx, int c0, double (&o)[1][VEC]) const {
     (void)c0;
-    ldv<VEC>(x, idx, o[0]);
+    float v[VEC];
+    ldv<VEC>(x, idx, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[0][e] = (double)v[e];
   }
 };
 struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
@@ -72,7 +75,7 @@ struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
   int act; float slope; float dy_scale;
   const float* gamma; const float* beta;   // y == nullptr: the ReLU / LeakyReLU mask is the sign of the recomputed BatchNorm output
   template <int VEC>
-  __device__ __forceinline__ void eval(size_t idx, int c0, float (&o)[2][VEC]) const {
+  __device__ __forceinline__ void eval(size_t idx, int c0, double (&o)[2][VEC]) const {
     float g[VEC], xv[VEC], yv[VEC];
     ldv<VEC>(dy, idx, g); ldv<VEC>(x, idx, xv);
     if (act != PCG_ACT_NONE) {
@@ -89,17 +92,17 @@ struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
     for (int e = 0; e < VEC; ++e) {
       const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
       const float xh = (xv[e] - mean[c0 + e]) * invstd[c0 + e];
-      o[0][e] = dz; o[1][e] = dz * xh;
+      o[0][e] = (double)dz; o[1][e] = (double)dz * (double)xh;
     }
   }
 };
 
-// partial[blk][k][C]
+// partial[blk][k][C] (fp64: the reference's CPU path accumulates these sums in double — [torch] at::acc_type<float, false>)
 template <int VEC, class Fn>
 __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t rows, int C, int CG, int TX, int TY,
-                                                               int rows_per_block, float* __restrict__ partial) {
+                                                               int rows_per_block, double* __restrict__ partial) {
   constexpr int NVAL = Fn::NVAL;
-  __shared__ float red[NVAL * VEC * CR_THREADS];
+  __shared__ double red[NVAL * VEC * CR_THREADS];
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
@@ -107,14 +110,14 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
   for (int ps = 0; ps < passes; ++ps) {
     const int cg = ps * TX + tx;
     const bool cok = cg < CG;
-    float acc[NVAL][VEC];
+    double acc[NVAL][VEC];
 #pragma unroll
     for (int k = 0; k < NVAL; ++k)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[k][e] = 0.f;
+      for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0;
     if (cok) {
       for (int64_t r = r0 + ty; r < r1; r += TY) {
-        float o[NVAL][VEC];
+        double o[NVAL][VEC];
         fn.template eval<VEC>((size_t)r * C + (size_t)cg * VEC, cg * VEC, o);
 #pragma unroll
         for (int k = 0; k < NVAL; ++k)
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
       for (int k = 0; k < NVAL; ++k)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float s = 0.f;
+          double s = 0.0;
           for (int j = 0; j < TY; ++j) s += red[(k * VEC + e) * CR_THREADS + j * TX + tx];
           partial[((size_t)blockIdx.x * NVAL + k) * C + cg * VEC + e] = s;
         }
@@ -202,11 +205,11 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_kernel(
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
 }
 
-__global__ void __launch_bounds__(FIN_CH * FIN_SL) colsum_finalize_kernel(const float* __restrict__ partial, int nblocks,
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) colsum_finalize_kernel(const double* __restrict__ partial, int nblocks,
                                                                          int C, float* out, int accumulate) {
   int c;
   double sm[1];
-  if (!finalize_sums<1, float>(partial, nblocks, C, c, sm)) return;
+  if (!finalize_sums<1, double>(partial, nblocks, C, c, sm)) return;
   out[c] = (accumulate ? out[c] : 0.f) + (float)sm[0];
 }
 
@@ -229,24 +232,24 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(
 // latency-bound loop in a handful of blocks.  Level 1 below sums groups of `rpc` consecutive rows, full rows coalesced, in fp64
 // into out[chunk][cols] (cols = NVAL*C); the finalize kernels then read <= PRE_CHUNKS rows of doubles.  Fixed orders throughout.
 constexpr int PRE_CHUNKS = 256, PRE_MIN_ROWS = 4096;   // below ~4k rows the direct finalize (128 row slices per block) is as fast
-__global__ void __launch_bounds__(256) partial_presum_kernel(const float* __restrict__ partial, int nparts, int cols, int rpc,
+__global__ void __launch_bounds__(256) partial_presum_kernel(const double* __restrict__ partial, int nparts, int cols, int rpc,
                                                              double* __restrict__ out) {
   const int col = blockIdx.y * 256 + threadIdx.x;
   if (col >= cols) return;
   const int r0 = blockIdx.x * rpc;
   int r1 = r0 + rpc; if (r1 > nparts) r1 = nparts;
-  const float* src = partial + (size_t)r0 * cols + col;
+  const double* src = partial + (size_t)r0 * cols + col;
   double acc = 0.0;
   int r = r0;
   for (; r + 8 <= r1; r += 8) {
-    float v[8];
+    double v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * cols];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += (double)v[j];
+    for (int j = 0; j < 8; ++j) acc += v[j];
     src += (size_t)8 * cols;
   }
-  for (; r < r1; ++r) { acc += (double)*src; src += cols; }
+  for (; r < r1; ++r) { acc += *src; src += cols; }
   out[(size_t)blockIdx.x * cols + col] = acc;
 }
 
@@ -258,12 +261,12 @@ PrePlan plan_presum(int nparts) {
   q.nchunks = (nparts + q.rpc - 1) / q.rpc;
   return q;
 }
-size_t presum_offset_floats(int nparts, int cols) { return (((size_t)nparts * cols) + 1) & ~(size_t)1; }   // 8-byte aligned tail
+size_t presum_offset(int nparts, int cols) { return (size_t)nparts * cols; }   // the chunk sums follow the partial rows
 // returns the fp64 chunk sums (and their count) if the partial rows were pre-summed, nullptr otherwise
-const double* launch_presum(const float* partial, int nparts, int cols, int* nchunks, hipStream_t s) {
+const double* launch_presum(const double* partial, int nparts, int cols, int* nchunks, hipStream_t s) {
   const PrePlan q = plan_presum(nparts);
   if (q.nchunks == 0) return nullptr;
-  double* out = reinterpret_cast<double*>(const_cast<float*>(partial) + presum_offset_floats(nparts, cols));
+  double* out = const_cast<double*>(partial) + presum_offset(nparts, cols);
   hipLaunchKernelGGL(partial_presum_kernel, dim3(q.nchunks, (cols + 255) / 256), dim3(256), 0, s, partial, nparts, cols, q.rpc, out);
   *nchunks = q.nchunks;
   return out;
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
 bool fast_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
 
 template <class Fn>
-int launch_colreduce(const Fn& fn, int64_t rows, int C, const ColPlan& cp, float* partial, hipStream_t s) {
+int launch_colreduce(const Fn& fn, int64_t rows, int C, const ColPlan& cp, double* partial, hipStream_t s) {
   if (cp.vec == 4)
     hipLaunchKernelGGL((colreduce_kernel<4, Fn>), dim3(cp.nblocks), dim3(CR_THREADS), 0, s, fn, rows, C, cp.CG, cp.TX, cp.TY,
                        cp.rows_per_block, partial);
@@ -442,11 +445,11 @@ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 namespace pcg {
 // shared with conv_igemm.hip (BatchNorm statistics fused into the conv epilogue): partial[nparts][2][C] -> stats
 size_t bn_partial_buffer_bytes(int nparts, int C) {
-  // partial[nparts][2][C] floats (+ the fp64 chunk sums of the two-level finalize when there are many rows)
+  // partial[nparts][2][C] doubles (+ the chunk sums of the two-level finalize when there are many rows)
   const PrePlan q = plan_presum(nparts);
-  return presum_offset_floats(nparts, 2 * C) * sizeof(float) + (size_t)q.nchunks * 2 * C * sizeof(double);
+  return (presum_offset(nparts, 2 * C) + (size_t)q.nchunks * 2 * C) * sizeof(double);
 }
-int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
+int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
                              bool has_presum_tail) {
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
@@ -456,7 +459,7 @@ int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int
     hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
                        1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   else
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
                        1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
   return launch_status("bn_stats_finalize_kernel");
 }
@@ -466,10 +469,10 @@ using namespace pcg;
 
 extern "C" size_t pcg_bn_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  // partial[nblocks][2][C] + coef[3][C]; the plan with vec=1 never has more blocks than vec=4
+  // fp64 partial[nblocks][2][C] + fp32 coef[3][C]; the plan with vec=1 never has more blocks than vec=4
   const ColPlan a = plan_cols(rows, C, true), b = plan_cols(rows, C, false);
   const int nb = a.nblocks > b.nblocks ? a.nblocks : b.nblocks;
-  return ((size_t)nb * 2 * C + 3 * (size_t)C) * sizeof(float);
+  return (size_t)nb * 2 * C * sizeof(double) + 3 * (size_t)C * sizeof(float);
 }
 extern "C" size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C) { return pcg_bn_workspace_bytes(rows, C); }
 
@@ -484,11 +487,11 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
   }
   hipStream_t s = (hipStream_t)stream;
   const ColPlan cp = plan_cols(rows, C, al16(x));
-  float* partial = (float*)workspace;
+  double* partial = (double*)workspace;
   FnStats fn{x};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                      num_batches_tracked);
   return launch_status("bn_stats_finalize_kernel");
@@ -527,11 +530,11 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = al16(dy) && al16(x) && al16(y) && al16(dx);  // al16(nullptr) is true
   const ColPlan cp = plan_cols(rows, C, aligned);
-  float* partial = (float*)workspace;
-  float* coef = partial + (size_t)cp.nblocks * 2 * C;
+  double* partial = (double*)workspace;
+  float* coef = reinterpret_cast<float*>(partial + (size_t)cp.nblocks * 2 * C);
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C,
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
@@ -571,9 +574,11 @@ extern "C" int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t r
 extern "C" size_t pcg_bn_bwd_partial_workspace_bytes(int32_t C) { return (size_t)3 * C * sizeof(float); }
 
 extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                                  const float* gamma, const float* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                                  const float* gamma, const void* partial_, int32_t nparts, float* dx, float* dgamma, float* dbeta,
                                   int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  const double* partial = static_cast<const double*>(partial_);
   PCG_REQUIRE(dm && x && mean && invstd && partial && dx && rows > 0 && C > 0 && nparts > 0, "pcg_bn_bwd_partial: bad arguments");
+  PCG_REQUIRE(((uintptr_t)partial & 7) == 0, "pcg_bn_bwd_partial: the partial-sum buffer must be 8-byte aligned");
   if (!workspace || workspace_bytes < pcg_bn_bwd_partial_workspace_bytes(C)) {
     set_error("pcg_bn_bwd_partial: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_bwd_partial_workspace_bytes(C));
     return PCG_ERR_WORKSPACE;
@@ -586,7 +591,7 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
                        1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
                        1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const bool aligned = al16(dm) && al16(x) && al16(dx);
@@ -616,9 +621,9 @@ extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, i
   }
   hipStream_t s = (hipStream_t)stream;
   const ColPlan cp = plan_cols(rows, C, al16(dy));
-  float* partial = (float*)workspace;
+  double* partial = (double*)workspace;
   FnSum fn{dy};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const float*)partial, cp.nblocks, C, db, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C, db, accumulate);
   return launch_status("colsum_finalize_kernel");
 }

@@ -345,7 +345,7 @@ extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
 }
 
 namespace pcg {
-int launch_bn_stats_finalize(const float* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
+int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
                              bool has_presum_tail);
 size_t bn_partial_buffer_bytes(int nparts, int C);
@@ -365,7 +365,7 @@ static int dgrad_stat_rows(const pcg_conv_geom* g) {
 }
 
 static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
-                           float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
+                           double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
                            float slope = 0.f, const EpiAux* epi = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
@@ -421,13 +421,13 @@ extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const f
   PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_bn: only MFMA layers (Cin > 3, Cout > 3, Cout %% 4 == 0); use pcg_conv2d_fwd + pcg_bn_train_stats");
   PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_fwd_bn: null statistics output");
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_fwd_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
-  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (float*)workspace, nullptr, 0, stream)) return e;
-  return launch_bn_stats_finalize((const float*)workspace, fwd_stat_rows(g), (int64_t)g->B * g->OH * g->OW, g->Cout, eps, momentum,
+  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (double*)workspace, nullptr, 0, stream)) return e;
+  return launch_bn_stats_finalize((const double*)workspace, fwd_stat_rows(g), (int64_t)g->B * g->OH * g->OW, g->Cout, eps, momentum,
                                   save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
 }
 
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
-                             float* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
+                             double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
                              float slope = 0.f, const EpiAux* epi = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
@@ -502,8 +502,8 @@ extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, cons
   PCG_REQUIRE(need > 0, "pcg_conv2d_dgrad_bn: only MFMA layers with stride <= 2; use pcg_conv2d_dgrad + pcg_bn_train_stats");
   PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_dgrad_bn: null statistics output");
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_dgrad_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
-  if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (float*)workspace, nullptr, 0, stream)) return e;
-  return launch_bn_stats_finalize((const float*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
+  if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (double*)workspace, nullptr, 0, stream)) return e;
+  return launch_bn_stats_finalize((const double*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
                                   save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
 }
 
@@ -564,7 +564,7 @@ extern "C" int pcg_conv2d_dgrad_bnbwd(const pcg_conv_geom* g, const float* dy, c
   if (int rc = check_geom(g)) return rc;
   if (int rc = bnbwd_epi("pcg_conv2d_dgrad_bnbwd", g, dx, z_below, mean, invstd, gamma, beta, act, slope,
                          pcg_conv2d_dgrad_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
-  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (float*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
 }
 extern "C" int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, int act, float slope, float* y,
@@ -573,7 +573,7 @@ extern "C" int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, cons
   if (int rc = check_geom(g)) return rc;
   if (int rc = bnbwd_epi("pcg_conv2d_fwd_bnbwd", g, y, z_below, mean, invstd, gamma, beta, act, slope,
                          pcg_conv2d_fwd_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
-  return conv2d_fwd_impl(g, x, w, nullptr, y, (float*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+  return conv2d_fwd_impl(g, x, w, nullptr, y, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
 }
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }

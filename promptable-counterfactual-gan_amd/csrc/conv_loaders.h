@@ -43,7 +43,7 @@ struct ConvP {
   const float* bias; // fwd: per-Cout       dgrad: per-Cin (nullable)
   float* out;        // fwd: y              dgrad: dx                     wgrad: slab base
   const float* dy;   // dgrad / wgrad
-  float* stat_partial;  // nullable: fused BatchNorm statistics of the output, [partial row][2][N]
+  double* stat_partial; // nullable: fused BatchNorm statistics of the output, fp64 [partial row][2][N]
   int act; float slope; // activation fused into the epilogue (PCG_ACT_NONE: none; never together with stat_partial)
   EpiAux epi;           // backward-pass epilogue (mode EPI_NONE: off); EPI_BNBWD writes its column sums to stat_partial
   uint32_t x_bytes, w_bytes, dy_bytes;

@@ -222,7 +222,7 @@ struct EpiAux {
 
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
-                                                 const float* bias, RowBase row_base, float* stat_row = nullptr, int act = PCG_ACT_NONE,
+                                                 const float* bias, RowBase row_base, double* stat_row = nullptr, int act = PCG_ACT_NONE,
                                                  float slope = 0.f, const EpiAux* epi = nullptr) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
@@ -242,7 +242,11 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
   const bool nok = n < N;  // N % 4 == 0: a quad is entirely inside or outside
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && nok) bv = *reinterpret_cast<const float4*>(bias + n);
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  // column sums for the fused BatchNorm statistics / BatchNorm-backward sums: accumulated in fp64 (the reference's CPU path sums
+  // in double — [torch] at::acc_type<float, false> — and BatchNorm's backward subtracts these means from strongly correlated
+  // gradients: an fp32 chain of 16+ same-sign adds is 1e-6 off, which the cancellation amplifies to 1e-3 in the weight gradients)
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool want_sums = stat_row != nullptr;   // wave-uniform
   const int emode = epi ? epi->mode : EPI_NONE;   // wave-uniform
   if (emode == EPI_NONE) {
 #pragma unroll
@@ -256,8 +260,11 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
           v.x = act_neg_scale(v.x, slope); v.y = act_neg_scale(v.y, slope); v.z = act_neg_scale(v.z, slope); v.w = act_neg_scale(v.w, slope);
         }
         *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        if (want_sums) {
+          const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+          s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+          s2[0] = fma(d0, d0, s2[0]); s2[1] = fma(d1, d1, s2[1]); s2[2] = fma(d2, d2, s2[2]); s2[3] = fma(d3, d3, s2[3]);
+        }
       }
     }
   } else {
@@ -293,24 +300,26 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
           v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
         }
         *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x = fmaf(v.x, (u[k].x - mu.x) * is.x, s2.x); s2.y = fmaf(v.y, (u[k].y - mu.y) * is.y, s2.y);
-        s2.z = fmaf(v.z, (u[k].z - mu.z) * is.z, s2.z); s2.w = fmaf(v.w, (u[k].w - mu.w) * is.w, s2.w);
+        if (want_sums) {
+          s1[0] += (double)v.x; s1[1] += (double)v.y; s1[2] += (double)v.z; s1[3] += (double)v.w;
+          s2[0] = fma((double)v.x, (double)((u[k].x - mu.x) * is.x), s2[0]); s2[1] = fma((double)v.y, (double)((u[k].y - mu.y) * is.y), s2[1]);
+          s2[2] = fma((double)v.z, (double)((u[k].z - mu.z) * is.z), s2[2]); s2[3] = fma((double)v.w, (double)((u[k].w - mu.w) * is.w), s2[3]);
+        }
       }
     }
   }
-  // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one partial row per
+  // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one fp64 partial row per
   // (tile row, wave row); a finalize kernel adds the partial rows in a fixed order (bitwise reproducible)
-  if (stat_row) {   // wave-uniform
+  if (want_sums) {
 #pragma unroll
     for (int off = Q; off < 64; off <<= 1) {
-      s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
-      s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], off); s2[e] += __shfl_xor(s2[e], off); }
     }
     if (r0 == 0 && nok) {
-      float* pr = stat_row + (size_t)wm * 2 * N;       // [wm][2][N] inside this tile row's slot
-      *reinterpret_cast<float4*>(pr + n) = s1;
-      *reinterpret_cast<float4*>(pr + N + n) = s2;
+      double* pr = stat_row + (size_t)wm * 2 * N;      // [wm][2][N] inside this tile row's slot
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pr[n + e] = s1[e]; pr[N + n + e] = s2[e]; }
     }
   }
 }
