@@ -103,6 +103,40 @@ int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, co
 int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                         float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* ---- input transforms: BatchNorm + ReLU / LeakyReLU of the PRODUCING layer applied inside the consumer's gather ------------------
+ * In `Conv -> BatchNorm(train) -> LeakyReLU -> Conv` (mnist_dcgan.py:102-110, G: :76-87) the activated tensor a = act(bn(z)) is
+ * only ever read by the next convolution (forward, and again by that layer's weight gradient).  With a transform the consumer
+ * reads the pre-BatchNorm tensor z itself and evaluates act(z*scale[c] + shift[c]) between the gather and the LDS write, so the
+ * separate BatchNorm-apply pass and the activated copy of every such activation disappear.  scale / shift are the folded
+ * BatchNorm (scale = gamma*invstd, shift = beta - mean*scale — exactly the expression pcg_bn_apply_act evaluates, so results are
+ * bit-identical to the unfused sequence); zero padding stays zero.  MFMA layers only (Cin > 3, Cout > 3, channel counts % 4 == 0).
+ *   _fwd_bn_xf / _dgrad_bn_xf : as pcg_conv2d_{fwd,dgrad}_bn with the transform `xf` (nullable) on the input operand (x resp. dy
+ *                               — the forward input of a ConvTranspose2d layer) and, if coef_out != NULL, the folded scale / shift
+ *                               [2][C] of THIS layer's BatchNorm (gamma, beta required) written by the statistics finalize —
+ *                               ready to be the next consumer's transform;
+ *   _fwd_xf / _dgrad_xf       : as pcg_conv2d_{fwd,dgrad}_act with a transform on the input operand;
+ *   _wgrad_xf                 : weight gradient with the transform on x (Conv2d) or on dy (ConvTranspose2d, whose forward input
+ *                               sits on the dy side of the adjoint geometry) — at most one of the two. */
+typedef struct pcg_in_xform {
+  const float* scale;   /* [C], 16-byte aligned; NULL: no transform */
+  const float* shift;   /* [C] */
+  int32_t act;          /* PCG_ACT_NONE / PCG_ACT_RELU / PCG_ACT_LRELU */
+  float slope;
+} pcg_in_xform;
+int pcg_conv2d_fwd_bn_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf, const float* w, const float* bias, float* y,
+                         float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, const float* gamma, const float* beta, float* coef_out /*nullable [2][Cout]*/,
+                         void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_dgrad_bn_xf(const pcg_conv_geom* g, const float* dy, const pcg_in_xform* xf, const float* w, const float* bias_x, float* dx,
+                           float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, const float* gamma, const float* beta, float* coef_out /*nullable [2][Cin]*/,
+                           void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_fwd_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf, const float* w, const float* bias, int act,
+                      float slope, float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_dgrad_xf(const pcg_conv_geom* g, const float* dy, const pcg_in_xform* xf, const float* w, const float* bias_x, int act,
+                        float slope, float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf_x, const float* dy, const pcg_in_xform* xf_dy,
+                        float* dw, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 /* Backward-pass epilogues (MFMA layers).  In autograd's sweep through `Conv -> [BatchNorm] -> ReLU/LeakyReLU -> Conv` (D:
  * mnist_dcgan.py:100-110, G: :76-87) the gradient w.r.t. a layer's OUTPUT a = act(..) is produced by the grad-input kernel of the
  * layer above; these entry points apply the lower layer's activation derivative while that tile is still in registers:
@@ -145,6 +179,11 @@ int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float eps, float
                        float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked /*nullable: += 1*/,
                        void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* the same + the folded scale / shift [2][C] of y = x*scale + shift (gamma, beta required when coef_out != NULL) */
+int pcg_bn_train_stats_coef(const float* x, int64_t rows, int32_t C, float eps, float momentum,
+                            float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, const float* gamma, const float* beta, float* coef_out,
+                            void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 /* y = act( (x-mean)*invstd*gamma + beta ).  var_eps < 0: `invstd_or_var` holds invstd (training: save_invstd);
  * var_eps >= 0: it holds a variance and invstd = rsqrt(var + var_eps) (eval mode: running_var, eps).   */
 int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd_or_var,

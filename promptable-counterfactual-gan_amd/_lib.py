@@ -63,11 +63,17 @@ class HouseGBwdArgs(ctypes.Structure):
                 [("B", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("tau", ctypes.c_float), ("res_scale", ctypes.c_float)])
 
 
+class InXform(ctypes.Structure):
+    """pcg_in_xform."""
+    _fields_ = [("scale", _P), ("shift", _P), ("act", _I), ("slope", ctypes.c_float)]
+
+
 _c = ctypes
 _vp, _f, _i, _i64, _sz = _c.c_void_p, _c.c_float, _c.c_int, _c.c_int64, _c.c_size_t
 _d = _c.c_double
 _i32 = _c.c_int32
 _gp = _c.POINTER(ConvGeom)
+_xp = _c.POINTER(InXform)
 
 # name -> (restype, argtypes); every symbol include/pcgan_hip.h declares
 PROTOTYPES = {
@@ -93,6 +99,12 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_bn_partial_rows": (_c.c_int32, [_gp]),
     "pcg_bn_bwd_partial_workspace_bytes": (_sz, [_c.c_int32]),
     "pcg_bn_bwd_partial": (_i, [_vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _c.c_int32, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_bn_xf": (_i, [_gp, _vp, _xp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_bn_xf": (_i, [_gp, _vp, _xp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_xf": (_i, [_gp, _vp, _xp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_dgrad_xf": (_i, [_gp, _vp, _xp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_wgrad_xf": (_i, [_gp, _vp, _xp, _vp, _xp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_bn_train_stats_coef": (_i, [_vp, _i64, _c.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_colsum_workspace_bytes": (_sz, [_i64, _c.c_int32]),

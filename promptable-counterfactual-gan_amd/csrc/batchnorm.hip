@@ -83,8 +83,9 @@ struct FnBnBwd {  // sum dz, sum dz*xhat with dz = dy_scale*dy*act'(y)
       else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float sc = gamma[c0 + e] * invstd[c0 + e];
-          yv[e] = fmaf(xv[e], sc, beta[c0 + e] - mean[c0 + e] * sc);      // same expression as bn_apply_act
+          float sc, sh;
+          bn_fold(gamma[c0 + e], beta[c0 + e], mean[c0 + e], invstd[c0 + e], sc, sh);
+          yv[e] = fmaf(xv[e], sc, sh);      // same expression as bn_apply_act
         }
       }
     }
@@ -191,7 +192,8 @@ __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, 
 template <class SrcT>
 __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_kernel(
     const SrcT* __restrict__ partial, int nblocks, int C, double inv_rows, double unbias, float eps, float momentum,
-    float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked) {
+    float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+    const float* gamma, const float* beta, float* coef /* nullable: [2][C] scale / shift of y = x*sc + sh */) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
   int c;
   double sm[2];
@@ -201,6 +203,7 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_kernel(
   if (var < 0.0) var = 0.0;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (coef) bn_fold(gamma[c], beta[c], (float)mean, (float)(1.0 / sqrt(var + (double)eps)), coef[c], coef[C + c]);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
 }
@@ -297,8 +300,8 @@ __global__ void __launch_bounds__(256) bn_apply_act_kernel(const float* __restri
     for (int e = 0; e < VEC; ++e) {
       const int c = c0 + e;
       const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[c] + var_eps) : invstd[c];
-      const float sc = (gamma ? gamma[c] : 1.f) * is;
-      const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+      float sc, sh;
+      bn_fold(gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, mean[c], is, sc, sh);
       v[e] = fmaf(alpha, act_apply(fmaf(v[e], sc, sh), act, slope), rs[e]);
     }
     if constexpr (VEC == 4) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int c = c0 + e;
-      if (act != PCG_ACT_NONE && !y) { const float sc = gamma[c] * invstd[c]; yv[e] = fmaf(xv[e], sc, beta[c] - mean[c] * sc); }
+      if (act != PCG_ACT_NONE && !y) { float sc, sh; bn_fold(gamma[c], beta[c], mean[c], invstd[c], sc, sh); yv[e] = fmaf(xv[e], sc, sh); }
       const float dz = dy_scale * g[e] * (act != PCG_ACT_NONE ? act_grad_from_out(yv[e], act, slope) : 1.f);
       const float xh = (xv[e] - mean[c]) * invstd[c];
       g[e] = coef[c] * (dz - coef[C + c] - xh * coef[2 * C + c]);
@@ -356,8 +359,7 @@ __global__ void __launch_bounds__(256) bn_apply_act_fast_kernel(const float4* __
   for (int e = 0; e < 4; ++e) {
     const int c = c0 + e;
     const float is = var_eps >= 0.f ? 1.f / sqrtf(invstd[c] + var_eps) : invstd[c];
-    sc[e] = (gamma ? gamma[c] : 1.f) * is;
-    sh[e] = (beta ? beta[c] : 0.f) - mean[c] * sc[e];
+    bn_fold(gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, mean[c], is, sc[e], sh[e]);
   }
   auto one = [&](float4 q, float4 r) {
     q.x = fmaf(alpha, act_apply(fmaf(q.x, sc[0], sh[0]), act, slope), r.x);
@@ -391,8 +393,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
   for (int e = 0; e < 4; ++e) {
     const int c = c0 + e;
     mu[e] = mean[c]; is[e] = invstd[c]; k0[e] = coef[c]; k1[e] = coef[C + c]; k2[e] = coef[2 * C + c];
-    msc[e] = premask ? gamma[c] * invstd[c] : 0.f;
-    msh[e] = premask ? beta[c] - mean[c] * msc[e] : 0.f;
+    msc[e] = 0.f; msh[e] = 0.f;
+    if (premask) bn_fold(gamma[c], beta[c], mean[c], invstd[c], msc[e], msh[e]);
   }
   const bool has_act = act != PCG_ACT_NONE;
   auto one = [&](float4 g, float4 xv, float4 yv) {
@@ -451,16 +453,16 @@ size_t bn_partial_buffer_bytes(int nparts, int C) {
 }
 int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
-                             bool has_presum_tail) {
+                             bool has_presum_tail, const float* gamma, const float* beta, float* coef) {
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   int nchunks = 0;
   const double* pre = has_presum_tail ? launch_presum(partial, nparts, 2 * C, &nchunks, s) : nullptr;
   if (pre)
     hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
-                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt, gamma, beta, coef);
   else
     hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
-                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+                       1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt, gamma, beta, coef);
   return launch_status("bn_stats_finalize_kernel");
 }
 }  // namespace pcg
@@ -480,7 +482,16 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
                                   float* save_invstd, float* running_mean, float* running_var,
                                   int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
                                   pcg_stream_t stream) {
+  return pcg_bn_train_stats_coef(x, rows, C, eps, momentum, save_mean, save_invstd, running_mean, running_var, num_batches_tracked,
+                                 nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcg_bn_train_stats_coef(const float* x, int64_t rows, int32_t C, float eps, float momentum, float* save_mean,
+                                       float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                       const float* gamma, const float* beta, float* coef_out, void* workspace,
+                                       size_t workspace_bytes, pcg_stream_t stream) {
   PCG_REQUIRE(x && save_mean && save_invstd && rows > 0 && C > 0, "pcg_bn_train_stats: bad arguments");
+  PCG_REQUIRE(!coef_out || (gamma && beta), "pcg_bn_train_stats_coef: coef_out needs gamma and beta");
   if (!workspace || workspace_bytes < pcg_bn_workspace_bytes(rows, C)) {
     set_error("pcg_bn_train_stats: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_workspace_bytes(rows, C));
     return PCG_ERR_WORKSPACE;
@@ -493,7 +504,7 @@ extern "C" int pcg_bn_train_stats(const float* x, int64_t rows, int32_t C, float
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
-                     num_batches_tracked);
+                     num_batches_tracked, gamma, beta, coef_out);
   return launch_status("bn_stats_finalize_kernel");
 }
 

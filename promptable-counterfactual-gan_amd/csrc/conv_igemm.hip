@@ -22,7 +22,9 @@ namespace {
 // role of this wave, provably wave-uniform for the compiler (scalar branch, no exec masking)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-template <class Cfg>
+// XF (here and below): the activation operand carries an input transform (ConvP::in_sc) — a separate instantiation, so the
+// plain kernels pay nothing for it.
+template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -35,7 +37,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
 
   if (wave_id() >= 4) {  // producers
     const int tid = threadIdx.x - IG_LOADERS;
-    FwdALoader<Cfg::BM> la(p, m_block, tid);
+    FwdALoader<Cfg::BM, XF> la(p, m_block, tid);
     FwdBLoader<Cfg::BN> lb(p, n_block, tid);
     if (kt_begin) { la.seek(kt_begin); lb.seek(kt_begin); }
     igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
 }
 
-template <class Cfg>
+template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
       }
       rowpix[r] = pix;
     }
-    DgradALoader<Cfg::BM> la(p, f, m_block, tid);
+    DgradALoader<Cfg::BM, XF> la(p, f, m_block, tid);
     DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
     igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
     return;
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, Dgra
   }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
 }
 
-template <class Cfg>
+template <class Cfg, bool XFA, bool XFB>   // XFA: the dy operand is a transformed activation (ConvTranspose2d layers); XFB: x is
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split, int tiles,
                                                                    int slice_major) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -117,8 +119,8 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
 
   if (wave_id() >= 4) {
     const int tid = threadIdx.x - IG_LOADERS;
-    WgradALoader<Cfg::BM> la(p, m_block, kt_begin, tid);
-    WgradBLoader<Cfg::BN> lb(p, n_block, kt_begin, tid);
+    WgradALoader<Cfg::BM, XFA> la(p, m_block, kt_begin, tid);
+    WgradBLoader<Cfg::BN, XFB> lb(p, n_block, kt_begin, tid);
     igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
     return;
   }
@@ -196,6 +198,18 @@ ConvP make_params(const pcg_conv_geom* g) {
   return p;
 }
 
+// validate an input transform for an operand with C channels and put it into the kernel parameters
+int set_xform(const char* who, const pcg_in_xform* xf, int C, ConvP* p) {
+  if (!xf || !xf->scale) return PCG_OK;
+  PCG_REQUIRE(xf->shift != nullptr, "%s: input transform without shift", who);
+  PCG_REQUIRE(xf->act == PCG_ACT_NONE || xf->act == PCG_ACT_RELU || xf->act == PCG_ACT_LRELU,
+              "%s: input transform activation %d is not none / ReLU / LeakyReLU", who, xf->act);
+  PCG_REQUIRE(C % 4 == 0 && (((uintptr_t)xf->scale | (uintptr_t)xf->shift) & 15) == 0,
+              "%s: input transform needs a channel count %% 4 == 0 and 16-byte aligned scale / shift", who);
+  p->in_sc = xf->scale; p->in_sh = xf->shift; p->in_neg = act_neg_of(xf->act, xf->slope); p->in_c_bytes = (uint32_t)C * 4u;
+  return PCG_OK;
+}
+
 template <class Cfg, bool AK, bool BK_>
 constexpr size_t smem_bytes() {
   constexpr int a = igemm_smem_floats<Cfg, AK, BK_>(), b = epilogue_smem_floats<Cfg>();
@@ -210,15 +224,19 @@ int set_smem(K kernel, size_t bytes) {
   return PCG_OK;
 }
 
-template <class Cfg>
-int launch_fwd(ConvP p, int splits, hipStream_t s) {
+template <class Cfg, bool XF>
+int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(p.M, Cfg::BM);
   constexpr size_t smem = smem_bytes<Cfg, true, true>();
-  static int once = set_smem(conv_fwd_kernel<Cfg>, smem);
+  static int once = set_smem(conv_fwd_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(conv_fwd_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, splits), dim3(IG_THREADS), smem, s, p);
+  hipLaunchKernelGGL((conv_fwd_kernel<Cfg, XF>), dim3((unsigned)tilesM * p.tilesN, splits), dim3(IG_THREADS), smem, s, p);
   return launch_status("conv_fwd_kernel");
+}
+template <class Cfg>
+int launch_fwd(const ConvP& p, int splits, hipStream_t s) {
+  return p.in_sc ? launch_fwd_x<Cfg, true>(p, splits, s) : launch_fwd_x<Cfg, false>(p, splits, s);
 }
 
 // Forward split-K: when M*N gives far fewer tiles than the chip has CUs and K is long (small-batch layers with big weights:
@@ -252,12 +270,12 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
   return f;
 }
 
-template <class Cfg>
-int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
+template <class Cfg, bool XF>
+int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(maxMp, Cfg::BM);
   constexpr size_t smem = smem_bytes<Cfg, true, false>();
-  static int once = set_smem(conv_dgrad_kernel<Cfg>, smem);
+  static int once = set_smem(conv_dgrad_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
   static const int il_env = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
   DgradPhases phl = ph;
@@ -267,10 +285,14 @@ int launch_dgrad(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStre
   for (int i = 1; i < nphases; ++i) same = same && ph.p[i].Mp == ph.p[0].Mp;
   phl.interleave = same ? nphases : 0;
   if (same)
-    hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN * nphases), dim3(IG_THREADS), smem, s, p, phl);
+    hipLaunchKernelGGL((conv_dgrad_kernel<Cfg, XF>), dim3((unsigned)tilesM * p.tilesN * nphases), dim3(IG_THREADS), smem, s, p, phl);
   else
-    hipLaunchKernelGGL(conv_dgrad_kernel<Cfg>, dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, phl);
+    hipLaunchKernelGGL((conv_dgrad_kernel<Cfg, XF>), dim3((unsigned)tilesM * p.tilesN, nphases), dim3(IG_THREADS), smem, s, p, phl);
   return launch_status("conv_dgrad_kernel");
+}
+template <class Cfg>
+int launch_dgrad(const ConvP& p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
+  return p.in_sc ? launch_dgrad_x<Cfg, true>(p, ph, nphases, maxMp, s) : launch_dgrad_x<Cfg, false>(p, ph, nphases, maxMp, s);
 }
 
 struct WgradPlan { int splits, ktiles_total, ktiles_per_split, tiles; bool narrow; };
@@ -347,7 +369,7 @@ extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
 namespace pcg {
 int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
-                             bool has_presum_tail);
+                             bool has_presum_tail, const float* gamma = nullptr, const float* beta = nullptr, float* coef = nullptr);
 size_t bn_partial_buffer_bytes(int nparts, int C);
 }
 
@@ -366,16 +388,19 @@ static int dgrad_stat_rows(const pcg_conv_geom* g) {
 
 static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                            double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
-                           float slope = 0.f, const EpiAux* epi = nullptr) {
+                           float slope = 0.f, const EpiAux* epi = nullptr, const pcg_in_xform* xf = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && w && y, "pcg_conv2d_fwd: null pointer");
   PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_fwd: unknown activation %d", act);
-  if (thin_is_cin(g) || thin_is_cout(g))
+  if (thin_is_cin(g) || thin_is_cout(g)) {
+    PCG_REQUIRE(!(xf && xf->scale), "pcg_conv2d_fwd: input transforms are only implemented on the MFMA path (Cin > 3 and Cout > 3)");
     return thin_conv_fwd(g, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
+  }
   PCG_REQUIRE(g->Cin % 4 == 0, "pcg_conv2d_fwd: Cin=%d must be a multiple of 4 for the MFMA path (1..3-channel layers take the thin path)", g->Cin);
   ConvP p = make_params(g);
   p.x = x; p.w = w; p.bias = bias; p.out = y; p.stat_partial = stat_partial;
   if (epi) p.epi = *epi;
+  if (int e = set_xform("pcg_conv2d_fwd", xf, g->Cin, &p)) return e;
   p.M = g->B * g->OH * g->OW; p.N = g->Cout;
   p.ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
   p.ktiles_per_split = p.ktiles;
@@ -414,29 +439,45 @@ extern "C" size_t pcg_conv2d_dgrad_bn_workspace_bytes(const pcg_conv_geom* g) {
   return bn_partial_buffer_bytes(dgrad_stat_rows(g), g->Cin);
 }
 
-extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float eps,
-                                 float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                                 int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+extern "C" int pcg_conv2d_fwd_bn_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf, const float* w, const float* bias,
+                                    float* y, float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean,
+                                    float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
+                                    float* coef_out, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   const size_t need = pcg_conv2d_fwd_bn_workspace_bytes(g);
   PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_bn: only MFMA layers (Cin > 3, Cout > 3, Cout %% 4 == 0); use pcg_conv2d_fwd + pcg_bn_train_stats");
   PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_fwd_bn: null statistics output");
+  PCG_REQUIRE(!coef_out || (gamma && beta), "pcg_conv2d_fwd_bn_xf: coef_out needs gamma and beta");
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_fwd_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
-  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (double*)workspace, nullptr, 0, stream)) return e;
+  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (double*)workspace, nullptr, 0, stream, PCG_ACT_NONE, 0.f, nullptr, xf)) return e;
   return launch_bn_stats_finalize((const double*)workspace, fwd_stat_rows(g), (int64_t)g->B * g->OH * g->OW, g->Cout, eps, momentum,
-                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true,
+                                  gamma, beta, coef_out);
+}
+extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float eps,
+                                 float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return pcg_conv2d_fwd_bn_xf(g, x, nullptr, w, bias, y, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                              num_batches_tracked, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int pcg_conv2d_fwd_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf, const float* w, const float* bias,
+                                 int act, float slope, float* y, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream, act, slope, nullptr, xf);
 }
 
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                              double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
-                             float slope = 0.f, const EpiAux* epi = nullptr) {
+                             float slope = 0.f, const EpiAux* epi = nullptr, const pcg_in_xform* xf = nullptr) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(dy && w && dx, "pcg_conv2d_dgrad: null pointer");
   PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_dgrad: unknown activation %d", act);
-  if (thin_is_cin(g) || thin_is_cout(g))
+  const bool has_xf = xf && xf->scale;
+  if (thin_is_cin(g) || thin_is_cout(g)) {
+    PCG_REQUIRE(!has_xf, "pcg_conv2d_dgrad: input transforms are only implemented on the MFMA path (Cin > 3 and Cout > 3)");
     return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
+  }
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
-  if (!epi && !stat_partial && dgrad_as_gemm(g) && workspace && workspace_bytes >= dgrad_gemm_bytes(g) &&
+  if (!epi && !stat_partial && !has_xf && dgrad_as_gemm(g) && workspace && workspace_bytes >= dgrad_gemm_bytes(g) &&
       (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0) {
     pcg_conv_geom g1 = {g->B, g->OH, g->OW, g->KH * g->KW * g->Cin, g->OH, g->OW, g->Cout, 1, 1, 1, 0};
     float* dcol = (float*)workspace;
@@ -457,6 +498,7 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   const bool fuse = act_is_cheap(act);
   p.dy = dy; p.w = w; p.bias = bias_x; p.out = dx; p.stat_partial = stat_partial;
   if (epi) p.epi = *epi;
+  if (int e = set_xform("pcg_conv2d_dgrad", xf, g->Cout, &p)) return e;
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   p.N = g->Cin;
   DgradPhases ph{};
@@ -495,16 +537,29 @@ extern "C" int pcg_conv2d_dgrad_act(const pcg_conv_geom* g, const float* dy, con
   return conv2d_dgrad_impl(g, dy, w, bias_x, dx, nullptr, workspace, workspace_bytes, stream, act, slope);
 }
 
-extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, float eps,
-                                   float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                                   int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+extern "C" int pcg_conv2d_dgrad_bn_xf(const pcg_conv_geom* g, const float* dy, const pcg_in_xform* xf, const float* w, const float* bias_x,
+                                      float* dx, float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
+                                      float* coef_out, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   const size_t need = pcg_conv2d_dgrad_bn_workspace_bytes(g);
   PCG_REQUIRE(need > 0, "pcg_conv2d_dgrad_bn: only MFMA layers with stride <= 2; use pcg_conv2d_dgrad + pcg_bn_train_stats");
   PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_dgrad_bn: null statistics output");
+  PCG_REQUIRE(!coef_out || (gamma && beta), "pcg_conv2d_dgrad_bn_xf: coef_out needs gamma and beta");
   if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_dgrad_bn: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
-  if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (double*)workspace, nullptr, 0, stream)) return e;
+  if (int e = conv2d_dgrad_impl(g, dy, w, bias_x, dx, (double*)workspace, nullptr, 0, stream, PCG_ACT_NONE, 0.f, nullptr, xf)) return e;
   return launch_bn_stats_finalize((const double*)workspace, dgrad_stat_rows(g), (int64_t)g->B * g->IH * g->IW, g->Cin, eps, momentum,
-                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true);
+                                  save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream, true,
+                                  gamma, beta, coef_out);
+}
+extern "C" int pcg_conv2d_dgrad_bn(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, float eps,
+                                   float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return pcg_conv2d_dgrad_bn_xf(g, dy, nullptr, w, bias_x, dx, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                                num_batches_tracked, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int pcg_conv2d_dgrad_xf(const pcg_conv_geom* g, const float* dy, const pcg_in_xform* xf, const float* w, const float* bias_x,
+                                   int act, float slope, float* dx, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return conv2d_dgrad_impl(g, dy, w, bias_x, dx, nullptr, workspace, workspace_bytes, stream, act, slope, nullptr, xf);
 }
 
 // ---- backward-pass epilogues: the gradient w.r.t. the layer below's OUTPUT leaves the kernel already multiplied by that
@@ -585,12 +640,33 @@ extern "C" size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g) {
   return (size_t)w.splits * (size_t)g->Cout * (size_t)g->KH * g->KW * g->Cin * sizeof(float);
 }
 
-extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
-                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+template <class Cfg, bool XFA, bool XFB>
+static int launch_wgrad_x(const ConvP& p, const WgradPlan& wp, int slice_major, hipStream_t s) {
+  constexpr size_t smem = smem_bytes<Cfg, false, false>();
+  static int once = set_smem(conv_wgrad_kernel<Cfg, XFA, XFB>, smem);
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL((conv_wgrad_kernel<Cfg, XFA, XFB>), slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
+                     dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
+  return launch_status("conv_wgrad_kernel");
+}
+template <class Cfg>
+static int launch_wgrad(const ConvP& p, const WgradPlan& wp, int slice_major, int xf_side, hipStream_t s) {
+  if (xf_side == 1) return launch_wgrad_x<Cfg, false, true>(p, wp, slice_major, s);    // x is a transformed activation
+  if (xf_side == 2) return launch_wgrad_x<Cfg, true, false>(p, wp, slice_major, s);    // dy is
+  return launch_wgrad_x<Cfg, false, false>(p, wp, slice_major, s);
+}
+
+extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf_x, const float* dy,
+                                   const pcg_in_xform* xf_dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                                   pcg_stream_t stream) {
   if (int e = check_geom(g)) return e;
   PCG_REQUIRE(x && dy && dw, "pcg_conv2d_wgrad: null pointer");
-  if (thin_is_cin(g) || thin_is_cout(g))
+  const bool hx = xf_x && xf_x->scale, hy = xf_dy && xf_dy->scale;
+  PCG_REQUIRE(!(hx && hy), "pcg_conv2d_wgrad_xf: at most one operand can carry an input transform");
+  if (thin_is_cin(g) || thin_is_cout(g)) {
+    PCG_REQUIRE(!hx && !hy, "pcg_conv2d_wgrad: input transforms are only implemented on the MFMA path (Cin > 3 and Cout > 3)");
     return thin_conv_wgrad(g, x, dy, dw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+  }
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   const WgradPlan wp = plan_wgrad(g);
   const size_t need = pcg_conv2d_wgrad_workspace_bytes(g);
@@ -603,29 +679,18 @@ extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const fl
   p.x = x; p.dy = dy; p.out = (float*)workspace;
   p.M = g->Cout; p.N = g->KH * g->KW * g->Cin;
   p.tilesN = ceil_div(p.N, 128);
+  if (int e = hx ? set_xform("pcg_conv2d_wgrad_xf", xf_x, g->Cin, &p) : set_xform("pcg_conv2d_wgrad_xf", xf_dy, g->Cout, &p)) return e;
   hipStream_t s = (hipStream_t)stream;
-  int rc;
   static const int order_env = getenv("PCG_WGRAD_ORDER") ? atoi(getenv("PCG_WGRAD_ORDER")) : -1;   // A/B switch: 0 tile-major, 1 slice-major
   const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
-  if (wp.narrow) {
-    using Cfg = TileCfg<64, 128, 1, 4>;
-    constexpr size_t smem = smem_bytes<Cfg, false, false>();
-    static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
-    if (once != PCG_OK) return once;
-    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
-                       dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
-    rc = launch_status("conv_wgrad_kernel<64x128>");
-  } else {
-    using Cfg = Cfg128x128;
-    constexpr size_t smem = smem_bytes<Cfg, false, false>();
-    static int once = set_smem(conv_wgrad_kernel<Cfg>, smem);
-    if (once != PCG_OK) return once;
-    hipLaunchKernelGGL(conv_wgrad_kernel<Cfg>, slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
-                       dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
-    rc = launch_status("conv_wgrad_kernel<128x128>");
-  }
+  const int side = hx ? 1 : hy ? 2 : 0;
+  const int rc = wp.narrow ? launch_wgrad<TileCfg<64, 128, 1, 4>>(p, wp, slice_major, side, s) : launch_wgrad<Cfg128x128>(p, wp, slice_major, side, s);
   if (rc != PCG_OK) return rc;
   const size_t n = (size_t)p.M * p.N;
   return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s);
 }
 
+extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return pcg_conv2d_wgrad_xf(g, x, nullptr, dy, nullptr, dw, accumulate, workspace, workspace_bytes, stream);
+}

@@ -46,6 +46,10 @@ struct ConvP {
   double* stat_partial; // nullable: fused BatchNorm statistics of the output, fp64 [partial row][2][N]
   int act; float slope; // activation fused into the epilogue (PCG_ACT_NONE: none; never together with stat_partial)
   EpiAux epi;           // backward-pass epilogue (mode EPI_NONE: off); EPI_BNBWD writes its column sums to stat_partial
+  // input transform (in_sc != nullptr): the ACTIVATION operand of this launch (fwd: x; dgrad: dy; wgrad: x or dy, see the kernel's
+  // template flags) is read as act(v * in_sc[c] + in_sh[c]) — the producing layer's BatchNorm + ReLU / LeakyReLU applied inside
+  // the gather, so that layer's output is never written in its activated form.  Padding / tile-edge zeros stay zeros.
+  const float* in_sc; const float* in_sh; float in_neg; uint32_t in_c_bytes;
   uint32_t x_bytes, w_bytes, dy_bytes;
   int B, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int M, N;          // GEMM extents of this launch
@@ -67,16 +71,40 @@ struct PhaseInfo {
 };
 struct DgradPhases { PhaseInfo p[4]; int interleave; };   // interleave = number of equal-sized phases sharing a 1-D grid, or 0
 
+// Input transform of a K-major activation gather (k = channel): the k-tile's channel quad changes every tile, so its scale /
+// shift quads are fetched with the tile (two more 16-byte loads, L1/L2 hits on a <= 4 KB table) and applied between the arrival
+// of the gathered registers and the ds_write; `ok` bits remember which rows were real (zero padding must stay zero).
+struct XfK {
+  rsrc_t rsc, rsh;
+  float4 sc, sh;
+  float neg;
+  uint32_t ok;
+  __device__ __forceinline__ void init(const ConvP& p) {
+    rsc = make_rsrc(p.in_sc, p.in_c_bytes); rsh = make_rsrc(p.in_sh, p.in_c_bytes); neg = p.in_neg; ok = 0;
+  }
+  __device__ __forceinline__ void fetch(uint32_t c_off_bytes, bool kok) {
+    sc = buf_load4(rsc, kok ? c_off_bytes : OOB_OFF);
+    sh = buf_load4(rsh, kok ? c_off_bytes : OOB_OFF);
+  }
+};
+__device__ __forceinline__ float4 xf_apply(float4 v, float4 sc, float4 sh, float neg, bool ok) {
+  float4 t = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  t.x = act_neg_scale(t.x, neg); t.y = act_neg_scale(t.y, neg); t.z = act_neg_scale(t.z, neg); t.w = act_neg_scale(t.w, neg);
+  return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---- forward: A = im2col rows of x (K-major), B = OHWI weight rows (K-major) --------------------------------
-template <int ROWS_>
+template <int ROWS_, bool XF = false>
 struct FwdALoader {
   static constexpr bool KMAJOR = true;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV], mask[NV];
   int IW, Cin, KW, kh, kw, ci0, kq4;
+  XfK xf;
 
   __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block, int tid) {
+    if constexpr (XF) xf.init(p);
     rs = make_rsrc(p.x, p.x_bytes);
     IW = p.IW; Cin = p.Cin; KW = p.KW;
     kq4 = (tid & 7) * 4;
@@ -108,13 +136,23 @@ struct FwdALoader {
     const int tap = kh * KW + kw;
     const uint32_t delta = (uint32_t)(((kh * IW + kw) * Cin + ci0) * 4);
     const bool kok = kq4 < Cin - ci0;
+    uint32_t okbits = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const bool ok = kok && ((mask[i] >> tap) & 1u);
       v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
+      if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
     }
+    if constexpr (XF) { xf.ok = okbits; xf.fetch((uint32_t)((ci0 + kq4) * 4), kok); }
     ci0 += IG_BK;
     if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+  }
+  // applied to the registers of the tile fetched by the LAST load_next, right before they are written to LDS
+  __device__ __forceinline__ void transform(float4 (&v)[NV]) {
+    if constexpr (XF) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = xf_apply(v[i], xf.sc, xf.sh, xf.neg, (xf.ok >> i) & 1u);
+    }
   }
 };
 
@@ -152,6 +190,7 @@ struct FwdBLoader {
     ci0 += IG_BK;
     if (ci0 >= Cin) { ci0 = 0; tapoff += Cin; }
   }
+  __device__ __forceinline__ void transform(float4 (&)[NV]) {}
 };
 
 // ---- dgrad: per sub-pixel phase; A = dy rows gathered (K-major, k = co), B = w[co][tap][ci] slices (MN-major) ----
@@ -164,7 +203,7 @@ struct DgradTapIter {  // k-tiles run over (jh, jw, co-chunk)
   }
 };
 
-template <int ROWS_>
+template <int ROWS_, bool XF = false>
 struct DgradALoader {
   static constexpr bool KMAJOR = true;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
@@ -172,8 +211,10 @@ struct DgradALoader {
   uint32_t base[NV], mask[NV];
   int OW, Cout, kq4;
   DgradTapIter it;
+  XfK xf;
 
   __device__ __forceinline__ DgradALoader(const ConvP& p, const PhaseInfo& f, int m_block, int tid) {
+    if constexpr (XF) xf.init(p);
     rs = make_rsrc(p.dy, p.dy_bytes);
     OW = p.OW; Cout = p.Cout;
     kq4 = (tid & 7) * 4;
@@ -199,12 +240,21 @@ struct DgradALoader {
     const int tap = it.jh * it.ntw + it.jw;
     const uint32_t delta = (uint32_t)((it.co0 - (it.jh * OW + it.jw) * Cout) * 4);
     const bool kok = kq4 < Cout - it.co0;
+    uint32_t okbits = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const bool ok = kok && ((mask[i] >> tap) & 1u);
       v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
+      if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
     }
+    if constexpr (XF) { xf.ok = okbits; xf.fetch((uint32_t)((it.co0 + kq4) * 4), kok); }
     it.advance();
+  }
+  __device__ __forceinline__ void transform(float4 (&v)[NV]) {
+    if constexpr (XF) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = xf_apply(v[i], xf.sc, xf.sh, xf.neg, (xf.ok >> i) & 1u);
+    }
   }
 };
 
@@ -237,10 +287,13 @@ struct DgradBLoader {
     for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, (kr0 + KR * i) < krem ? base[i] + delta : OOB_OFF);
     it.advance();
   }
+  __device__ __forceinline__ void transform(float4 (&)[NV]) {}
 };
 
 // ---- wgrad: k = output pixel; A = dy[pixel][co] (MN-major), B = x gathered at the tap's shift (MN-major) -------
-template <int ROWS_>
+// MN-major activation gathers (wgrad): a thread's channel quad is fixed for the whole kernel, so the transform's scale / shift
+// live in registers; XF = the operand is an activation to be read as act(v*sc + sh).
+template <int ROWS_, bool XF = false>
 struct WgradALoader {
   static constexpr bool KMAJOR = false;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
@@ -248,6 +301,7 @@ struct WgradALoader {
   rsrc_t rs;
   uint32_t base[NV];
   int Cout, K, q0, kr0;
+  float4 sc, sh; float neg; uint32_t okb; bool mok;
 
   __device__ __forceinline__ WgradALoader(const ConvP& p, int m_block, int kt_begin, int tid) {
     rs = make_rsrc(p.dy, p.dy_bytes);
@@ -255,20 +309,38 @@ struct WgradALoader {
     const int c4 = tid % C4;
     kr0 = tid / C4;
     const int m = m_block + 4 * c4;
+    mok = m < p.M;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) base[i] = m < p.M ? (uint32_t)(((kr0 + KR * i) * Cout + m) * 4) : OOB_OFF;
+    for (int i = 0; i < NV; ++i) base[i] = mok ? (uint32_t)(((kr0 + KR * i) * Cout + m) * 4) : OOB_OFF;
     q0 = kt_begin * IG_BK;
+    if constexpr (XF) {
+      neg = p.in_neg; okb = 0;
+      sc = mok ? *reinterpret_cast<const float4*>(p.in_sc + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sh = mok ? *reinterpret_cast<const float4*>(p.in_sh + m) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const uint32_t delta = (uint32_t)(q0 * Cout * 4);
     const int krem = K - q0;
+    uint32_t okbits = 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, (kr0 + KR * i) < krem ? base[i] + delta : OOB_OFF);
+    for (int i = 0; i < NV; ++i) {
+      const bool ok = (kr0 + KR * i) < krem;
+      v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
+      if constexpr (XF) okbits |= ((ok && mok) ? 1u : 0u) << i;
+    }
+    if constexpr (XF) okb = okbits;
     q0 += IG_BK;
+  }
+  __device__ __forceinline__ void transform(float4 (&v)[NV]) {
+    if constexpr (XF) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = xf_apply(v[i], sc, sh, neg, (okb >> i) & 1u);
+    }
   }
 };
 
-template <int ROWS_>
+template <int ROWS_, bool XF = false>
 struct WgradBLoader {
   static constexpr bool KMAJOR = false;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
@@ -277,6 +349,7 @@ struct WgradBLoader {
   int IH, IW, Cin, stride, K, q0, dh, dw, ci;  // dh = kh - pad
   bool nok;
   FastDiv dOW, dOH;
+  float4 sc, sh; float neg; uint32_t okb;
 
   __device__ __forceinline__ WgradBLoader(const ConvP& p, int n_block, int kt_begin, int tid) {
     rs = make_rsrc(p.x, p.x_bytes);
@@ -290,8 +363,14 @@ struct WgradBLoader {
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     dh = kh - p.pad; dw = kw - p.pad;
     q0 = kt_begin * IG_BK + tid / C4;
+    if constexpr (XF) {
+      neg = p.in_neg; okb = 0;
+      sc = nok ? *reinterpret_cast<const float4*>(p.in_sc + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sh = nok ? *reinterpret_cast<const float4*>(p.in_sh + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    uint32_t okbits = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int q = q0 + KR * i;
@@ -302,8 +381,16 @@ struct WgradBLoader {
       const bool ok = nok && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
       const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci) * 4);
       v[i] = buf_load4(rs, ok ? off : OOB_OFF);
+      if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
     }
+    if constexpr (XF) okb = okbits;
     q0 += IG_BK;
+  }
+  __device__ __forceinline__ void transform(float4 (&v)[NV]) {
+    if constexpr (XF) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = xf_apply(v[i], sc, sh, neg, (okb >> i) & 1u);
+    }
   }
 };
 

@@ -100,6 +100,7 @@ constexpr int igemm_smem_floats() {
 // Loader concept (per-thread state of a producer thread, constructed with its loader-thread id 0..255):
 //   static constexpr bool KMAJOR; static constexpr int ROWS;
 //   __device__ void load_next(float4 (&v)[ROWS/32]);   // gathers the next k-tile (sequential) into registers
+//   __device__ void transform(float4 (&v)[ROWS/32]);   // applied to the registers of the last load_next before the ds_write
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float* smem, int tid) {
   using IA = LdsImage<Cfg::BM, LA::KMAJOR>;
@@ -111,6 +112,7 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
   if (ktiles > 0) {
     la.load_next(ra);
     lb.load_next(rb);
+    la.transform(ra); lb.transform(rb);     // input transform of the tile just fetched (no-op for plain loaders)
     IA::store(As, ra, tid);
     IB::store(Bs, rb, tid);
     if (ktiles > 1) {
@@ -123,6 +125,7 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
   for (int kt = 0; kt < ktiles; ++kt) {
 #ifndef PCG_ABL_PRODUCER_IDLE   // timing-only ablation: producers just keep the barrier protocol
     if (kt + 1 < ktiles) {
+      la.transform(ra); lb.transform(rb);
       IA::store(As + nxt * IA::FLOATS, ra, tid);
       IB::store(Bs + nxt * IB::FLOATS, rb, tid);
     }
@@ -275,8 +278,8 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       mu = *reinterpret_cast<const float4*>(epi->mean + n);
       is = *reinterpret_cast<const float4*>(epi->invstd + n);
       const float4 ga = *reinterpret_cast<const float4*>(epi->gamma + n), be = *reinterpret_cast<const float4*>(epi->beta + n);
-      sc = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
-      sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+      bn_fold(ga.x, be.x, mu.x, is.x, sc.x, sh.x); bn_fold(ga.y, be.y, mu.y, is.y, sc.y, sh.y);
+      bn_fold(ga.z, be.z, mu.z, is.z, sc.z, sh.z); bn_fold(ga.w, be.w, mu.w, is.w, sc.w, sh.w);
     }
     // all aux loads of the wave tile first (independent of the LDS reads), then the arithmetic
     float4 u[Cfg::WTM / RPI];

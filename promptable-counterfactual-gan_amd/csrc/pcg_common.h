@@ -70,6 +70,13 @@ __device__ __forceinline__ float act_neg_scale(float v, float neg) { return v > 
 static inline bool act_is_cheap(int act) { return act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU; }
 static inline float act_neg_of(int act, float slope) { return act == PCG_ACT_RELU ? 0.f : act == PCG_ACT_LRELU ? slope : 1.f; }
 
+// BatchNorm as one fma per element: y = x*sc + sh.  ONE definition for every place that applies it or recomputes its sign
+// (bn_apply_act, the input transforms of the conv gathers, the backward epilogues' masks): they must agree bit for bit.
+__device__ __forceinline__ void bn_fold(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
+  sc = gamma * invstd;
+  sh = fmaf(-mean, sc, beta);
+}
+
 // derivative expressed through the OUTPUT y of the activation
 __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
   switch (act) {

@@ -240,6 +240,12 @@ class SequentialConvNet(FlatModule):
 
     fuse_backward_epilogue = True   # A/B switch (tests compare both forms): activation derivative / BatchNorm-backward sums of the
                                     # layer below taken in the grad-input kernel's epilogue instead of in separate passes
+    fold_bn_apply = False           # A/B switch: BatchNorm(train) + ReLU / LeakyReLU applied inside the next convolution's gathers
+                                    # (forward and weight gradient) instead of as a pass that writes the activated tensor.
+                                    # Bit-identical results; OFF by default because it is SLOWER on gfx950 (profiles/README.md r02:
+                                    # DCGAN step 10.97 -> 11.26 ms): the ~16 VALU per gathered float4 in the producer waves are not
+                                    # hidden behind the consumers' MFMAs (+10..20 % on every conv kernel that carries a transform),
+                                    # while the pass it removes streams at 6 TB/s (0.21 ms per step)
 
     def __init__(self, main):
         super().__init__()
@@ -268,11 +274,25 @@ class SequentialConvNet(FlatModule):
         y = y.permute(0, 3, 1, 2)
         return y.reshape(y.shape[0], y.shape[1]) if flat_in else y
 
+    def _can_consume_xform(self, nxt, B, H, W):
+        """Can block `nxt` read its input [B, H, W, C] through an input transform (MFMA conv kernels only)?"""
+        if nxt.transposed:
+            OH = (H - 1) * nxt.stride - 2 * nxt.pad + nxt.kh
+            OW = (W - 1) * nxt.stride - 2 * nxt.pad + nxt.kw
+            if H == 1 and W == 1 and nxt.pad == 0:
+                return False                    # 1x1 input: plain-GEMM form
+            g = ops.conv_geom(B, OH, OW, nxt.conv.out_channels, nxt.conv.in_channels, nxt.kh, nxt.kw, nxt.stride, nxt.pad)
+        else:
+            g = ops.conv_geom(B, H, W, nxt.conv.in_channels, nxt.conv.out_channels, nxt.kh, nxt.kw, nxt.stride, nxt.pad)
+        return ops.xform_ok(g, "dy" if nxt.transposed else "x")
+
     def _run_forward(self, x, keep=True):
         B, H, W, C = x.shape
         saved = []
         a = x
-        for b in self._blocks:
+        xf = None     # input transform pending on `a`: a is then the producer's PRE-BatchNorm output (see fold_bn_apply)
+        nblk = len(self._blocks)
+        for idx, b in enumerate(self._blocks):
             c = b.conv
             if C != c.in_channels:
                 raise PcgError(f"channel mismatch: activation has {C}, layer expects {c.in_channels}")
@@ -281,14 +301,23 @@ class SequentialConvNet(FlatModule):
             bias = c.bias.data if c.bias is not None else None
             C = c.out_channels
             mean = invstd = None
+            xf_in, xf = xf, None
+            # BatchNorm(train) + ReLU / LeakyReLU of this block folded into the NEXT block's gathers: this block then never
+            # writes its activated output
+            fold = (self.fold_bn_apply and idx + 1 < nblk and b.bn is not None and b.bn.training
+                    and b.act in (ACT_NONE, ACT_RELU, ACT_LRELU) and self._can_consume_xform(self._blocks[idx + 1], B, OH, OW))
             if b.transposed and b.flat:
                 # plain-GEMM form: bias is shared by the KH*KW positions of a channel, statistics are per channel over B*KH*KW rows
-                z = ops.conv2d_dgrad(g, a, w, None).view(B, OH, OW, C)
+                z = ops.conv2d_dgrad(g, a, w, None, xf=xf_in).view(B, OH, OW, C)
                 if bias is not None:
                     ops.add_bias_rows(z, C, bias)
                 if b.bn is not None:
                     bn = b.bn
-                    if bn.training:
+                    if bn.training and fold:
+                        mean, invstd, coef = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                                bn.num_batches_tracked, gamma=bn.weight.data, beta=bn.bias.data)
+                        y, xf = None, ops.InputXform(coef, b.act, b.slope)
+                    elif bn.training:
                         mean, invstd = ops.bn_train_stats(z, C, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked)
                         y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
                     else:
@@ -302,25 +331,31 @@ class SequentialConvNet(FlatModule):
                     y, z = z, None
             elif b.bn is not None and b.bn.training:
                 bn = b.bn
-                z, mean, invstd = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
-                                                    bn.running_var, bn.num_batches_tracked)
-                y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
+                if fold:
+                    z, mean, invstd, coef = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
+                                                              bn.running_var, bn.num_batches_tracked, xf=xf_in,
+                                                              gamma=bn.weight.data, beta=bn.bias.data)
+                    y, xf = None, ops.InputXform(coef, b.act, b.slope)
+                else:
+                    z, mean, invstd = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
+                                                        bn.running_var, bn.num_batches_tracked, xf=xf_in)
+                    y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
             elif b.bn is not None:
                 bn = b.bn
-                z = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
+                z = ops.conv2d_dgrad(g, a, w, bias, xf=xf_in) if b.transposed else ops.conv2d_fwd(g, a, w, bias, xf=xf_in)
                 y = ops.bn_apply_act(z, C, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
                                      var_eps=bn.eps, out=z)
                 z = None
             elif b.act != ACT_NONE:   # activation fused into the conv's output write
-                y = (ops.conv2d_dgrad(g, a, w, bias, act=b.act, slope=b.slope) if b.transposed
-                     else ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope))
+                y = (ops.conv2d_dgrad(g, a, w, bias, act=b.act, slope=b.slope, xf=xf_in) if b.transposed
+                     else ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope, xf=xf_in))
                 z = None
             else:
-                y = ops.conv2d_dgrad(g, a, w, bias) if b.transposed else ops.conv2d_fwd(g, a, w, bias)
+                y = ops.conv2d_dgrad(g, a, w, bias, xf=xf_in) if b.transposed else ops.conv2d_fwd(g, a, w, bias, xf=xf_in)
                 z = None
             if keep:
-                saved.append((g, a, z, mean, invstd, y, b.bn is not None and not b.bn.training))
-            a, H, W = y, OH, OW
+                saved.append((g, a, z, mean, invstd, y, b.bn is not None and not b.bn.training, xf_in))
+            a, H, W = (y if xf is None else z), OH, OW
         return a, saved
 
     def _run_backward(self, saved, dy, need_x, need_p):
@@ -336,7 +371,7 @@ class SequentialConvNet(FlatModule):
         fused = None
         for idx in range(nblk - 1, -1, -1):
             b = self._blocks[idx]
-            g, a, z, mean, invstd, y, bn_eval = saved[idx]
+            g, a, z, mean, invstd, y, bn_eval, xf_in = saved[idx]
             c = b.conv
             C = c.out_channels
             if b.bn is not None:
@@ -364,10 +399,10 @@ class SequentialConvNet(FlatModule):
             if need_p and c.weight.requires_grad:
                 gw, acc = self._grad_view(c.weight)
                 gw = _w_ohwi(gw)
-                if not b.transposed:
-                    ops.conv2d_wgrad(g, a, dz, gw, acc)
+                if not b.transposed:      # `a` may be the layer below's pre-BatchNorm output read through its transform
+                    ops.conv2d_wgrad(g, a, dz, gw, acc, xf_x=xf_in)
                 else:
-                    ops.conv2d_wgrad(g, dz, a, gw, acc)
+                    ops.conv2d_wgrad(g, dz, a, gw, acc, xf_dy=xf_in)
                 if c.bias is not None and c.bias.requires_grad:
                     gb, accb = self._grad_view(c.bias)
                     ops.colsum(dz.numel() // C, C, dz, gb, accb)
@@ -379,7 +414,7 @@ class SequentialConvNet(FlatModule):
             fused = None
             if not last and self.fuse_backward_epilogue:
                 lo = self._blocks[idx - 1]
-                _, _, zl, ml, il, yl, lo_eval = saved[idx - 1]
+                _, _, zl, ml, il, yl, lo_eval, _ = saved[idx - 1]
                 w = _w_ohwi(c.weight.data)
                 res = None
                 if lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU) and not (b.transposed and b.flat):

@@ -135,8 +135,30 @@ def conv_geom(B, IH, IW, Cin, Cout, KH, KW, stride, pad):
 
 
 # ---- convolution family --------------------------------------------------------------------------
-def conv2d_fwd(g, x, w, bias=None, out=None, act=0, slope=0.0):
-    """y[B,OH,OW,Cout] = act(conv(x[B,IH,IW,Cin], w OHWI) (+ bias))."""
+class InputXform:
+    """An activation that exists only as (pre-BatchNorm tensor z, folded BatchNorm coef[2][C], activation): consumers read
+    act(z * coef[0][c] + coef[1][c]) inside their gathers (pcg_in_xform, include/pcgan_hip.h)."""
+
+    def __init__(self, coef, act, slope):
+        C = coef.numel() // 2
+        self.coef, self.act, self.slope, self.C = coef, int(act), float(slope), C
+        self.c_struct = _lib.InXform(coef.data_ptr(), coef.data_ptr() + 4 * C, int(act), float(slope))
+
+    def ref(self):
+        return ctypes.byref(self.c_struct)
+
+
+def xform_ok(g, operand):
+    """Can the conv kernels of geometry g take an input transform?  (MFMA path only; operand: 'x' -> Cin channels, 'dy' -> Cout.)"""
+    return g.Cin > 3 and g.Cout > 3 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and g.stride <= 2
+
+
+def _xref(xf):
+    return xf.ref() if xf is not None else None
+
+
+def conv2d_fwd(g, x, w, bias=None, out=None, act=0, slope=0.0, xf=None):
+    """y[B,OH,OW,Cout] = act(conv(x[B,IH,IW,Cin], w OHWI) (+ bias)); xf: input transform on x (InputXform)."""
     _chk(x, "x"); _chk(w, "w")
     assert x.numel() == g.B * g.IH * g.IW * g.Cin and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     y = out if out is not None else torch.empty((g.B, g.OH, g.OW, g.Cout), dtype=torch.float32, device=x.device)
@@ -144,13 +166,19 @@ def conv2d_fwd(g, x, w, bias=None, out=None, act=0, slope=0.0):
     need = lib.pcg_conv2d_fwd_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, x.device) if need else None
     with _Timed(g, "fwd"):
-        check(lib.pcg_conv2d_fwd_act(ctypes.byref(g), _p(x), _p(w), _p(bias), int(act), float(slope), _p(y), _p(ws),
-                                     ws.numel() if need else 0, _stream()), "pcg_conv2d_fwd_act")
+        if xf is not None:
+            assert xf.C == g.Cin
+            check(lib.pcg_conv2d_fwd_xf(ctypes.byref(g), _p(x), xf.ref(), _p(w), _p(bias), int(act), float(slope), _p(y), _p(ws),
+                                        ws.numel() if need else 0, _stream()), "pcg_conv2d_fwd_xf")
+        else:
+            check(lib.pcg_conv2d_fwd_act(ctypes.byref(g), _p(x), _p(w), _p(bias), int(act), float(slope), _p(y), _p(ws),
+                                         ws.numel() if need else 0, _stream()), "pcg_conv2d_fwd_act")
     return y
 
 
-def conv2d_dgrad(g, dy, w, bias_x=None, out=None, act=0, slope=0.0):
-    """dx[B,IH,IW,Cin] = act(conv_transpose(dy[B,OH,OW,Cout], w OHWI) (+ bias_x per Cin))."""
+def conv2d_dgrad(g, dy, w, bias_x=None, out=None, act=0, slope=0.0, xf=None):
+    """dx[B,IH,IW,Cin] = act(conv_transpose(dy[B,OH,OW,Cout], w OHWI) (+ bias_x per Cin)); xf: input transform on dy (the forward
+    input of a ConvTranspose2d layer)."""
     _chk(dy, "dy"); _chk(w, "w")
     assert dy.numel() == g.B * g.OH * g.OW * g.Cout and w.numel() == g.Cout * g.KH * g.KW * g.Cin
     dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
@@ -158,33 +186,43 @@ def conv2d_dgrad(g, dy, w, bias_x=None, out=None, act=0, slope=0.0):
     need = lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, dy.device) if need else None
     with _Timed(g, "dgrad"):
-        check(lib.pcg_conv2d_dgrad_act(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), int(act), float(slope), _p(dx), _p(ws),
-                                       ws.numel() if need else 0, _stream()), "pcg_conv2d_dgrad_act")
+        if xf is not None:
+            assert xf.C == g.Cout
+            check(lib.pcg_conv2d_dgrad_xf(ctypes.byref(g), _p(dy), xf.ref(), _p(w), _p(bias_x), int(act), float(slope), _p(dx), _p(ws),
+                                          ws.numel() if need else 0, _stream()), "pcg_conv2d_dgrad_xf")
+        else:
+            check(lib.pcg_conv2d_dgrad_act(ctypes.byref(g), _p(dy), _p(w), _p(bias_x), int(act), float(slope), _p(dx), _p(ws),
+                                           ws.numel() if need else 0, _stream()), "pcg_conv2d_dgrad_act")
     return dx
 
 
-def conv_bn_train(g, a, w, bias, transposed, eps, momentum, running_mean, running_var, num_batches_tracked):
+def conv_bn_train(g, a, w, bias, transposed, eps, momentum, running_mean, running_var, num_batches_tracked, xf=None, gamma=None,
+                  beta=None):
     """Convolution (transposed=False: fwd; True: dgrad = ConvTranspose2d forward) + training-mode BatchNorm statistics of
     its output.  One fused call on MFMA layers (statistics come out of the conv epilogue), two calls otherwise.
-    Returns (z, save_mean, save_invstd)."""
+    xf: input transform on the activation operand `a`.  gamma + beta given: also return the folded scale / shift [2][C] of this
+    layer's BatchNorm (written by the statistics finalize — the next consumer's transform).
+    Returns (z, save_mean, save_invstd) or (z, save_mean, save_invstd, coef)."""
     _chk(a, "a"); _chk(w, "w")
     lib = _lib.load()
     C = g.Cin if transposed else g.Cout
     shape = (g.B, g.IH, g.IW, g.Cin) if transposed else (g.B, g.OH, g.OW, g.Cout)
     need = (lib.pcg_conv2d_dgrad_bn_workspace_bytes if transposed else lib.pcg_conv2d_fwd_bn_workspace_bytes)(ctypes.byref(g))
+    want_coef = gamma is not None
     if need == 0:
-        z = conv2d_dgrad(g, a, w, bias) if transposed else conv2d_fwd(g, a, w, bias)
-        mean, invstd = bn_train_stats(z, C, eps, momentum, running_mean, running_var, num_batches_tracked)
-        return z, mean, invstd
+        z = conv2d_dgrad(g, a, w, bias, xf=xf) if transposed else conv2d_fwd(g, a, w, bias, xf=xf)
+        return (z,) + tuple(bn_train_stats(z, C, eps, momentum, running_mean, running_var, num_batches_tracked, gamma=gamma, beta=beta))
     z = torch.empty(shape, dtype=torch.float32, device=a.device)
     mean = torch.empty(C, dtype=torch.float32, device=a.device)
     invstd = torch.empty(C, dtype=torch.float32, device=a.device)
+    coef = torch.empty(2 * C, dtype=torch.float32, device=a.device) if want_coef else None
     ws = workspace(need, a.device)
-    fn = lib.pcg_conv2d_dgrad_bn if transposed else lib.pcg_conv2d_fwd_bn
+    fn = lib.pcg_conv2d_dgrad_bn_xf if transposed else lib.pcg_conv2d_fwd_bn_xf
     with _Timed(g, "dgrad" if transposed else "fwd"):
-        check(fn(ctypes.byref(g), _p(a), _p(w), _p(bias), _p(z), eps, momentum, _p(mean), _p(invstd), _p(running_mean),
-                 _p(running_var), _p(num_batches_tracked), _p(ws), ws.numel(), _stream()), "pcg_conv2d_*_bn")
-    return z, mean, invstd
+        check(fn(ctypes.byref(g), _p(a), _xref(xf), _p(w), _p(bias), _p(z), eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                 _p(running_var), _p(num_batches_tracked), _p(gamma), _p(beta), _p(coef), _p(ws), ws.numel(), _stream()),
+              "pcg_conv2d_*_bn_xf")
+    return (z, mean, invstd, coef) if want_coef else (z, mean, invstd)
 
 
 def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=None, z_below=None, bn=None):
@@ -246,16 +284,21 @@ def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta
     return dx
 
 
-def conv2d_wgrad(g, x, dy, dw, accumulate):
-    """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x."""
+def conv2d_wgrad(g, x, dy, dw, accumulate, xf_x=None, xf_dy=None):
+    """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x.  xf_x / xf_dy: input transform on the operand that
+    is an activation (x for Conv2d; dy for ConvTranspose2d, whose forward input sits on the dy side of the adjoint geometry)."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(dw, "dw")
     assert dw.numel() == g.Cout * g.KH * g.KW * g.Cin
     lib = _lib.load()
     need = lib.pcg_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, x.device)
     with _Timed(g, "wgrad"):
-        check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
-              "pcg_conv2d_wgrad")
+        if xf_x is None and xf_dy is None:
+            check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
+                  "pcg_conv2d_wgrad")
+        else:
+            check(lib.pcg_conv2d_wgrad_xf(ctypes.byref(g), _p(x), _xref(xf_x), _p(dy), _xref(xf_dy), _p(dw), int(bool(accumulate)), _p(ws),
+                                          ws.numel(), _stream()), "pcg_conv2d_wgrad_xf")
     return dw
 
 
@@ -268,16 +311,19 @@ def colsum(dy2d_rows, C, dy, db, accumulate):
 
 
 # ---- BatchNorm + activation -------------------------------------------------------------------------
-def bn_train_stats(x, C, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+def bn_train_stats(x, C, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None, gamma=None, beta=None):
+    """(save_mean, save_invstd); with gamma + beta also the folded scale / shift [2][C] (see conv_bn_train)."""
     _chk(x, "x")
     rows = x.numel() // C
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    coef = torch.empty(2 * C, dtype=torch.float32, device=x.device) if gamma is not None else None
     lib = _lib.load()
     ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
-    check(lib.pcg_bn_train_stats(_p(x), rows, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-                                 _p(num_batches_tracked), _p(ws), ws.numel(), _stream()), "pcg_bn_train_stats")
-    return mean, invstd
+    check(lib.pcg_bn_train_stats_coef(_p(x), rows, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                                      _p(num_batches_tracked), _p(gamma), _p(beta), _p(coef), _p(ws), ws.numel(), _stream()),
+          "pcg_bn_train_stats")
+    return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
 def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps=-1.0, out=None, residual=None, alpha=1.0):

@@ -380,3 +380,33 @@ def test_fused_backward_epilogue_equals_separate_passes(pcg):
         assert torch.isfinite(got).all(), k
         l2 = _rel_l2(got.cpu().numpy(), ref.cpu().numpy())
         assert l2 <= 2e-5, f"{k}: rel-L2 {l2:.2e}"
+
+
+def test_folded_bn_apply_equals_separate_pass(pcg):
+    """SequentialConvNet.fold_bn_apply: BatchNorm(train) + ReLU / LeakyReLU of a layer applied inside the next convolution's
+    gathers (forward and weight gradient) instead of by pcg_bn_apply_act.  Same scale / shift expression, same values into the
+    same MFMA order: two full training steps are BIT-identical with the switch on and off — losses, parameters, BatchNorm
+    buffers and gradients."""
+    D = pcg.dcgan
+    from pcgan_amd.nn import SequentialConvNet
+    g = torch.Generator().manual_seed(33)
+    reals = [(torch.rand(48, 1, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(2)]
+    noises = [torch.randn(48, 100, 1, 1, generator=g).to(DEV) for _ in range(2)]
+    res = {}
+    try:
+        for fold in (True, False):
+            SequentialConvNet.fold_bn_apply = fold
+            netG, netD, crit, optD, optG = _fresh_dcgan(D, seed=4)
+            for i in range(2):
+                o = D.train_step(netG, netD, crit, optD, optG, reals[i], noises[i], skip_dead_d_wgrad=False)
+            with torch.no_grad():
+                viz = netG(noises[0]).clone()                       # the no_grad / keep=False forward folds too
+            res[fold] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], _state(netG, netD),
+                         netG.flat_grads.clone(), netD.flat_grads.clone(), viz)
+    finally:
+        SequentialConvNet.fold_bn_apply = True
+    assert res[True][0] == res[False][0]
+    for k in res[False][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    for i in (2, 3, 4):
+        assert torch.equal(res[True][i], res[False][i])

@@ -324,3 +324,70 @@ def test_large_partial_row_counts_two_level_finalize(pcg):
     for a, b_, what in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (dz_f, dz_s, "dz")):
         den = max(b_.double().norm().item(), 1e-30)
         assert ((a.double() - b_.double()).norm().item() / den) <= 2e-6, what
+
+
+# ---- input transforms: BatchNorm + ReLU / LeakyReLU of the producing layer applied inside the consumer's gathers -----------------
+XF_CASES = [
+    # B, Cin, Cout, H, W, k, s, p
+    (4, 64, 128, 32, 32, 4, 2, 1),     # DCGAN D2->D3 shape family (128x128 tile)
+    (4, 128, 64, 16, 16, 4, 2, 1),     # N = 64 tile
+    (3, 64, 64, 28, 28, 3, 1, 1),      # 3x3 s1 (padding on all sides: padded taps must stay zero AFTER the transform)
+    (2, 36, 20, 6, 10, 3, 2, 1),       # ragged: K tail (Cin = 36 -> second k-tile has 4 live channels), partial M / N tiles
+    (3, 128, 256, 7, 7, 3, 2, 1),      # odd extent: unequal sub-pixel phases in the grad-input kernel
+    (2, 8192, 1024, 1, 1, 1, 1, 0),    # split-K forward (long K, few tiles)
+]
+
+
+@pytest.mark.parametrize("act,slope", [(2, 0.2), (1, 0.0), (0, 0.0)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,p", XF_CASES)
+def test_input_transform_equals_bn_apply_then_conv(pcg, B, Cin, Cout, H, W, k, s, p, act, slope):
+    """pcg_conv2d_{fwd,dgrad,wgrad}_xf read act(z*scale + shift) inside the gather.  scale / shift come from the statistics
+    finalize with the same expression pcg_bn_apply_act evaluates, so every result is BIT-identical to materialising
+    a = act(bn(z)) first and running the plain kernel on it."""
+    ops = pcg.ops
+    g = torch.Generator(device="cuda:0").manual_seed(B * 1000 + Cin + k)
+    geom = ops.conv_geom(B, H, W, Cin, Cout, k, k, s, p)
+    w = torch.randn(Cout, k, k, Cin, generator=g, device="cuda:0") / math.sqrt(Cin * k * k)
+    # (1) the transformed operand is x (Conv2d forward + weight gradient)
+    zx = torch.randn(B, H, W, Cin, generator=g, device="cuda:0") * 1.5 + 0.3
+    gam, bet = torch.rand(Cin, generator=g, device="cuda:0") + 0.5, torch.randn(Cin, generator=g, device="cuda:0") * 0.3
+    mean, invstd, coef = ops.bn_train_stats(zx, Cin, 1e-5, 0.1, gamma=gam, beta=bet)
+    a = ops.bn_apply_act(zx, Cin, mean, invstd, gam, bet, act, slope)
+    xf = ops.InputXform(coef, act, slope)
+    dy = torch.randn(B, geom.OH, geom.OW, Cout, generator=g, device="cuda:0")
+    assert torch.equal(ops.conv2d_fwd(geom, zx, w, xf=xf), ops.conv2d_fwd(geom, a, w))
+    assert torch.equal(ops.conv2d_fwd(geom, zx, w, act=2, slope=0.2, xf=xf), ops.conv2d_fwd(geom, a, w, act=2, slope=0.2))
+    dw1, dw2 = torch.empty_like(w), torch.empty_like(w)
+    ops.conv2d_wgrad(geom, zx, dy, dw1, False, xf_x=xf)
+    ops.conv2d_wgrad(geom, a, dy, dw2, False)
+    assert torch.equal(dw1, dw2)
+    # fused statistics + coefficient output of the consumer itself
+    gam2, bet2 = torch.rand(Cout, generator=g, device="cuda:0") + 0.5, torch.randn(Cout, generator=g, device="cuda:0") * 0.3
+    r1 = ops.conv_bn_train(geom, zx, w, None, False, 1e-5, 0.1, None, None, None, xf=xf, gamma=gam2, beta=bet2)
+    r2 = ops.conv_bn_train(geom, a, w, None, False, 1e-5, 0.1, None, None, None)
+    assert len(r1) == 4 and all(torch.equal(u, v) for u, v in zip(r1[:3], r2))
+    sc = gam2 * r1[2]
+    assert torch.equal(r1[3][:Cout], sc) and torch.allclose(r1[3][Cout:], bet2 - r1[1] * sc, rtol=1e-6, atol=1e-7)
+    # (2) the transformed operand is dy (ConvTranspose2d forward = grad-input kernel, and its weight gradient)
+    zy = torch.randn(B, geom.OH, geom.OW, Cout, generator=g, device="cuda:0") * 0.7 - 0.2
+    mean, invstd, coef = ops.bn_train_stats(zy, Cout, 1e-5, 0.1, gamma=gam2, beta=bet2)
+    ay = ops.bn_apply_act(zy, Cout, mean, invstd, gam2, bet2, act, slope)
+    xfy = ops.InputXform(coef, act, slope)
+    assert torch.equal(ops.conv2d_dgrad(geom, zy, w, xf=xfy), ops.conv2d_dgrad(geom, ay, w))
+    xg = torch.randn(B, H, W, Cin, generator=g, device="cuda:0")
+    ops.conv2d_wgrad(geom, xg, zy, dw1, False, xf_dy=xfy)
+    ops.conv2d_wgrad(geom, xg, ay, dw2, False)
+    assert torch.equal(dw1, dw2)
+    if s <= 2:
+        r1 = ops.conv_bn_train(geom, zy, w, None, True, 1e-5, 0.1, None, None, None, xf=xfy, gamma=gam, beta=bet)
+        r2 = ops.conv_bn_train(geom, ay, w, None, True, 1e-5, 0.1, None, None, None)
+        assert all(torch.equal(u, v) for u, v in zip(r1[:3], r2))
+
+
+def test_input_transform_rejected_on_thin_layers(pcg):
+    ops = pcg.ops
+    geom = ops.conv_geom(2, 8, 8, 64, 1, 4, 4, 2, 1)
+    coef = torch.ones(128, device="cuda:0")
+    with pytest.raises(pcg.PcgError, match="MFMA path"):
+        ops.conv2d_fwd(geom, torch.zeros(2, 8, 8, 64, device="cuda:0"), torch.zeros(1, 4, 4, 64, device="cuda:0"),
+                       xf=ops.InputXform(coef, 1, 0.0))
