@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="exercise the RCCL gradient-sync path even with one rank")
     ap.add_argument("--eager", action="store_true", help="enqueue every step kernel by kernel instead of replaying the captured HIP graph(s)")
     ap.add_argument("--event-every", type=int, default=8, help="one timed step per this many (at most 3 in total) runs eagerly with HIP events around the conv launches")
+    ap.add_argument("--sync-bn", action="store_true", help="exact global-batch BatchNorm across the ranks (SURVEY.md 8e option ii); implies --eager")
+    ap.add_argument("--torch-collectives", action="store_true", help="A/B: gradient exchange on torch.distributed's RCCL communicator instead of the library's (pcg_dp_*)")
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: min(16, visible cores))")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -169,8 +171,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        rccl_ranks = dist.get_world_size()          # what RCCL actually spans (the driver checks it against --gpus)
-        dp = GradSync(always_exchange=args.force_dp)
+        dp = GradSync(always_exchange=args.force_dp, native=not args.torch_collectives, sync_bn=args.sync_bn)
+        if args.sync_bn:
+            args.eager = True
+        rccl_ranks = dp.rccl_ranks()                # ranks of the communicator that carries the gradient exchange (the driver checks it against --gpus)
 
     # random-init weights of the reference architecture (weights_init distribution), identical on every rank
     torch.manual_seed(1)
@@ -179,7 +183,7 @@ def main():
     crit, optD, optG = D.make_optimizers(netG, netD)
     if dp is not None:
         netG.flat_params, netD.flat_params  # flatten
-        broadcast_parameters(netG); broadcast_parameters(netD)
+        broadcast_parameters(netG, dp=dp); broadcast_parameters(netD, dp=dp)
 
     # synthetic MNIST-shaped batches, resident in HBM before the timed region; each rank its own shard
     g = torch.Generator().manual_seed(1234 + rank)
@@ -311,11 +315,16 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
             "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
+            "batchnorm": None if dp is None else ("global batch (statistic sums all-reduced)" if dp.sync_bn else "per replica"),
+            "collectives": None if dp is None else ("libpcgan_hip pcg_dp_* (RCCL behind the C ABI)" if dp.native else "torch.distributed nccl"),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",
         }
         print(json.dumps(line), flush=True)
     if dp is not None:
+        from pcgan_amd.parallel import shutdown
+        torch.cuda.synchronize()
+        shutdown()
         torch.distributed.destroy_process_group()
 
 

@@ -505,6 +505,42 @@ int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t B, int32_t
 int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* const* w_bar, float slope, const float* a1, const float* a2,
                          const float* a3, float* d3, float* d2, float* d1, float* dx /*nullable*/, pcg_stream_t stream);
 
+/* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
+ * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per
+ * optimizer step: the average of the net's flat fp32 gradient bucket.  The library owns the RCCL communicator (bound at run time,
+ * no link-time dependency), a side HIP stream and the ordering events.  Bootstrap: rank 0 makes an id (pcg_dp_unique_id), the
+ * host layer ships the 128 bytes to the other ranks by any means (the Python layer: torch.distributed's store), every rank calls
+ * pcg_dp_init on ITS GPU (the current HIP device).  None of these calls may be captured in a HIP graph: the step is captured as
+ * graph segments cut at the exchange points (nn.GraphedStep).
+ *   pcg_dp_allreduce          buf <- mean over ranks, in stream order on `stream`
+ *   pcg_dp_allreduce_begin    the same on the library's side stream, after everything queued on producer_stream so far;
+ *                             `slot` (0..7) names the reduction
+ *   pcg_dp_side_stream        that stream: the caller may queue work behind the reduction (Adam), then pcg_dp_record(slot)
+ *   pcg_dp_allreduce_wait     consumer_stream waits on the GPU for slot (the reduction and whatever pcg_dp_record covered)
+ *   pcg_dp_allreduce_sum_f64  sum of doubles in stream order (exact-BatchNorm statistic sums, 2*C values per layer)
+ *   pcg_dp_broadcast          bytes from rank `root` (initial weights, BatchNorm buffers)
+ *   pcg_dp_sync_batchnorm     exact global-batch BatchNorm (SURVEY.md §8e option ii; the reference's BatchNorm spans the whole batch,
+ *                             mnist_dcgan.py:77-87): while enabled, every BatchNorm-family entry point (pcg_bn_train_stats*,
+ *                             pcg_conv2d_*_bn*, pcg_bn_act_bwd*, pcg_bn_bwd_partial) sums its per-channel partial rows locally in
+ *                             the usual fixed order, all-reduces the 2*C fp64 sums (sum x, sum x^2 | sum dy, sum dy*xhat) over the
+ *                             ranks in stream order, and finalises with rows*world rows — N ranks x B/N images compute what one
+ *                             process computes on B (equal shards assumed).  dgamma / dbeta stay local sums (they are averaged with
+ *                             the gradient bucket).  These calls then contain an RCCL collective: do not capture them in a graph. */
+#define PCG_DP_UNIQUE_ID_BYTES 128
+int pcg_dp_unique_id(void* id_out /*[PCG_DP_UNIQUE_ID_BYTES]*/);
+int pcg_dp_init(const void* id /*[PCG_DP_UNIQUE_ID_BYTES]*/, int32_t rank, int32_t world);
+int32_t pcg_dp_world(void);   /* 0 before pcg_dp_init */
+int32_t pcg_dp_rank(void);
+pcg_stream_t pcg_dp_side_stream(void);
+int pcg_dp_allreduce(float* buf, int64_t n, pcg_stream_t stream);
+int pcg_dp_allreduce_begin(float* buf, int64_t n, int32_t slot, pcg_stream_t producer_stream);
+int pcg_dp_record(int32_t slot);
+int pcg_dp_allreduce_wait(int32_t slot, pcg_stream_t consumer_stream);
+int pcg_dp_allreduce_sum_f64(double* buf, int64_t n, pcg_stream_t stream);
+int pcg_dp_broadcast(void* buf, int64_t nbytes, int32_t root, pcg_stream_t stream);
+int pcg_dp_sync_batchnorm(int32_t enable);
+int pcg_dp_shutdown(void);
+
 #ifdef __cplusplus
 }
 #endif

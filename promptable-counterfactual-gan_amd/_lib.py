@@ -105,6 +105,19 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_xf": (_i, [_gp, _vp, _xp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_wgrad_xf": (_i, [_gp, _vp, _xp, _vp, _xp, _vp, _i, _vp, _sz, _vp]),
     "pcg_bn_train_stats_coef": (_i, [_vp, _i64, _c.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_dp_unique_id": (_i, [_vp]),
+    "pcg_dp_init": (_i, [_vp, _i32, _i32]),
+    "pcg_dp_world": (_i32, []),
+    "pcg_dp_rank": (_i32, []),
+    "pcg_dp_side_stream": (_vp, []),
+    "pcg_dp_allreduce": (_i, [_vp, _i64, _vp]),
+    "pcg_dp_allreduce_begin": (_i, [_vp, _i64, _i32, _vp]),
+    "pcg_dp_record": (_i, [_i32]),
+    "pcg_dp_allreduce_wait": (_i, [_i32, _vp]),
+    "pcg_dp_allreduce_sum_f64": (_i, [_vp, _i64, _vp]),
+    "pcg_dp_broadcast": (_i, [_vp, _i64, _i32, _vp]),
+    "pcg_dp_sync_batchnorm": (_i, [_i32]),
+    "pcg_dp_shutdown": (_i, []),
     "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_colsum_workspace_bytes": (_sz, [_i64, _c.c_int32]),

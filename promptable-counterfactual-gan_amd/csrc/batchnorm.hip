@@ -7,6 +7,11 @@
 #include "pcg_common.h"
 
 namespace pcg {
+// dp_rccl.hip: exact global-batch BatchNorm under data parallelism
+bool dp_sync_bn();
+int dp_world();
+int dp_allreduce_f64(double* buf, int64_t n, hipStream_t s);
+
 namespace {
 
 constexpr int CR_THREADS = 256;
@@ -216,16 +221,30 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) colsum_finalize_kernel(const 
   out[c] = (accumulate ? out[c] : 0.f) + (float)sm[0];
 }
 
+// exact-BatchNorm mode, step 1: this rank's [2][C] sums of the partial rows (same fixed order as the finalize kernels), written
+// twice — `local` stays, `global` is all-reduced over the ranks and then finalised as ONE partial row
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_sums_kernel(const double* __restrict__ partial, int nblocks, int C,
+                                                                 double* __restrict__ local, double* __restrict__ global) {
+  int c;
+  double sm[2];
+  if (!finalize_sums<2, double>(partial, nblocks, C, c, sm)) return;
+  local[c] = sm[0]; local[C + c] = sm[1];
+  global[c] = sm[0]; global[C + c] = sm[1];
+}
+
 // coef[0][c] = gamma*invstd ; coef[1][c] = mean(dz) ; coef[2][c] = mean(dz*xhat)
 template <class SrcT>
 __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(
     const SrcT* __restrict__ partial, int nblocks, int C, double inv_rows, const float* gamma, const float* invstd,
-    float* coef, float* dgamma, float* dbeta, int accumulate) {
+    float* coef, float* dgamma, float* dbeta, int accumulate, const double* __restrict__ local /* nullable [2][C]: this rank's sums */) {
   int c;
   double sm[2];
   if (!finalize_sums<2, SrcT>(partial, nblocks, C, c, sm)) return;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sm[0];
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sm[1];
+  // exact-BatchNorm mode: `partial` holds the sums over ALL ranks (they make the two means below); the parameter gradients are
+  // this rank's own sums — they are averaged across ranks with the rest of the gradient bucket
+  const double l0 = local ? local[c] : sm[0], l1 = local ? local[C + c] : sm[1];
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)l0;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)l1;
   coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
   coef[C + c] = (float)(sm[0] * inv_rows);
   coef[2 * C + c] = (float)(sm[1] * inv_rows);
@@ -273,6 +292,14 @@ const double* launch_presum(const double* partial, int nparts, int cols, int* nc
   hipLaunchKernelGGL(partial_presum_kernel, dim3(q.nchunks, (cols + 255) / 256), dim3(256), 0, s, partial, nparts, cols, q.rpc, out);
   *nchunks = q.nchunks;
   return out;
+}
+
+// exact-BatchNorm mode: reduce `src` (partial rows or chunk sums) to this rank's sums, all-reduce them, and hand back what the
+// finalize kernel should read instead: one row of global sums.  scratch: 4*C doubles ([2][C] local | [2][C] global).
+int sync_exchange(const double* src, int nrows, int C, double* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(bn_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nrows)), 0, s, src, nrows, C, scratch, scratch + 2 * C);
+  if (int e = launch_status("bn_sums_kernel")) return e;
+  return dp_allreduce_f64(scratch + 2 * C, 2 * (int64_t)C, s);
 }
 
 // ---- elementwise passes (float4 when C % 4 == 0) -------------------------------------------------
@@ -449,14 +476,21 @@ namespace pcg {
 size_t bn_partial_buffer_bytes(int nparts, int C) {
   // partial[nparts][2][C] doubles (+ the chunk sums of the two-level finalize when there are many rows)
   const PrePlan q = plan_presum(nparts);
-  return (presum_offset(nparts, 2 * C) + (size_t)q.nchunks * 2 * C) * sizeof(double);
+  return (presum_offset(nparts, 2 * C) + (size_t)q.nchunks * 2 * C + 4 * (size_t)C) * sizeof(double);   // + exact-BatchNorm scratch
 }
 int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
                              bool has_presum_tail, const float* gamma, const float* beta, float* coef) {
-  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   int nchunks = 0;
   const double* pre = has_presum_tail ? launch_presum(partial, nparts, 2 * C, &nchunks, s) : nullptr;
+  if (dp_sync_bn()) {
+    PCG_REQUIRE(has_presum_tail, "exact BatchNorm: buffer without scratch tail");
+    double* scratch = const_cast<double*>(partial) + presum_offset(nparts, 2 * C) + (size_t)plan_presum(nparts).nchunks * 2 * C;
+    if (int e = sync_exchange(pre ? pre : partial, pre ? nchunks : nparts, C, scratch, s)) return e;
+    partial = scratch + 2 * C; nparts = 1; pre = nullptr;
+    rows *= dp_world();
+  }
+  const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
   if (pre)
     hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
                        1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt, gamma, beta, coef);
@@ -471,10 +505,11 @@ using namespace pcg;
 
 extern "C" size_t pcg_bn_workspace_bytes(int64_t rows, int32_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  // fp64 partial[nblocks][2][C] + fp32 coef[3][C]; the plan with vec=1 never has more blocks than vec=4
+  // fp64 partial[nblocks][2][C] + fp64 exact-BatchNorm scratch [4][C] + fp32 coef[3][C]; the plan with vec=1 never has more
+  // blocks than vec=4
   const ColPlan a = plan_cols(rows, C, true), b = plan_cols(rows, C, false);
   const int nb = a.nblocks > b.nblocks ? a.nblocks : b.nblocks;
-  return (size_t)nb * 2 * C * sizeof(double) + 3 * (size_t)C * sizeof(float);
+  return ((size_t)nb * 2 * C + 4 * (size_t)C) * sizeof(double) + 3 * (size_t)C * sizeof(float);
 }
 extern "C" size_t pcg_colsum_workspace_bytes(int64_t rows, int32_t C) { return pcg_bn_workspace_bytes(rows, C); }
 
@@ -501,8 +536,16 @@ extern "C" int pcg_bn_train_stats_coef(const float* x, int64_t rows, int32_t C, 
   double* partial = (double*)workspace;
   FnStats fn{x};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
+  const double* src = partial;
+  int nsrc = cp.nblocks;
+  if (dp_sync_bn()) {   // exact global-batch statistics: all-reduce this rank's sums, finalise them as one row over rows*world
+    double* scratch = partial + (size_t)cp.nblocks * 2 * C;
+    if (int e = sync_exchange(partial, cp.nblocks, C, scratch, s)) return e;
+    src = scratch + 2 * C; nsrc = 1;
+    rows *= dp_world();
+  }
   const double unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nsrc)), 0, s, src, nsrc, C,
                      1.0 / (double)rows, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                      num_batches_tracked, gamma, beta, coef_out);
   return launch_status("bn_stats_finalize_kernel");
@@ -542,11 +585,21 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   const bool aligned = al16(dy) && al16(x) && al16(y) && al16(dx);  // al16(nullptr) is true
   const ColPlan cp = plan_cols(rows, C, aligned);
   double* partial = (double*)workspace;
-  float* coef = reinterpret_cast<float*>(partial + (size_t)cp.nblocks * 2 * C);
+  double* scratch = partial + (size_t)cp.nblocks * 2 * C;
+  float* coef = reinterpret_cast<float*>(scratch + 4 * (size_t)C);
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cp.nblocks)), 0, s, (const double*)partial, cp.nblocks, C,
-                     1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  const double* src = partial;
+  const double* local = nullptr;
+  int nsrc = cp.nblocks;
+  int64_t rows_all = rows;
+  if (dp_sync_bn()) {
+    if (int e = sync_exchange(partial, cp.nblocks, C, scratch, s)) return e;
+    src = scratch + 2 * C; nsrc = 1; local = scratch;
+    rows_all = rows * dp_world();
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nsrc)), 0, s, src, nsrc, C,
+                     1.0 / (double)rows_all, gamma, invstd, coef, dgamma, dbeta, accumulate, local);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
   if (fast_channels(C) && aligned) {
@@ -598,12 +651,18 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
   float* coef = (float*)workspace;
   int nchunks = 0;
   const double* pre = launch_presum(partial, nparts, 2 * C, &nchunks, s);   // the buffer of pcg_conv2d_*_bn_workspace_bytes has the tail
-  if (pre)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nchunks)), 0, s, pre, nchunks, C,
-                       1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
-  else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nparts)), 0, s, partial, nparts, C,
-                       1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  const double* src = pre ? pre : partial;
+  const double* local = nullptr;
+  int nsrc = pre ? nchunks : nparts;
+  int64_t rows_all = rows;
+  if (dp_sync_bn()) {
+    double* scratch = const_cast<double*>(partial) + presum_offset(nparts, 2 * C) + (size_t)plan_presum(nparts).nchunks * 2 * C;
+    if (int e = sync_exchange(src, nsrc, C, scratch, s)) return e;
+    src = scratch + 2 * C; nsrc = 1; local = scratch;
+    rows_all = rows * dp_world();
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nsrc)), 0, s, src, nsrc, C,
+                     1.0 / (double)rows_all, gamma, invstd, coef, dgamma, dbeta, accumulate, local);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const bool aligned = al16(dm) && al16(x) && al16(dx);
   const size_t n = (size_t)rows * C;

@@ -625,6 +625,9 @@ class GraphedStep:
 
     def __init__(self, step_fn, inputs, modules, optimizers, warmup=3, dp=None, capture=None):
         self.inputs = dict(inputs)
+        if dp is not None and getattr(dp, "sync_bn", False):
+            raise PcgError("exact-BatchNorm mode (GradSync(sync_bn=True)) issues RCCL collectives inside the BatchNorm calls, which "
+                           "cannot be captured in a HIP graph: run the step eagerly")
         for m in modules:
             m._ensure_flat()
         saved = [(m.flat_params.clone(), [b.clone() for b in m.buffers()]) for m in modules]

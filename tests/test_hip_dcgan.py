@@ -294,12 +294,13 @@ def _state(netG, netD):
     return {**{f"G.{k}": v.clone() for k, v in netG.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in netD.state_dict().items()}}
 
 
-@pytest.mark.parametrize("with_dp", [False, True])
+@pytest.mark.parametrize("with_dp", [False, "native", "torch"])
 def test_graph_replay_is_bit_identical_to_eager(pcg, with_dp):
     """bench.py replays the step as HIP graph(s): same kernels, same order.  Three steps eager vs three replays (with a mixed
     eager step in between, as bench.py's event-sampled steps do) from the same state on the same batches give bit-identical
     losses, parameters and BatchNorm buffers.  with_dp: the data-parallel form — segments cut at the gradient exchanges, the
-    exchanges issued through RCCL on a one-rank group (parallel.GradSync(always_exchange=True))."""
+    exchanges issued through RCCL on a one-rank group (parallel.GradSync(always_exchange=True)): "native" = the library's own
+    communicator behind the C ABI (pcg_dp_allreduce / _begin / _record / _wait on its side stream), "torch" = torch.distributed's."""
     import torch.distributed as dist
     from pcgan_amd.nn import GraphedStep
     D = pcg.dcgan
@@ -315,7 +316,8 @@ def test_graph_replay_is_bit_identical_to_eager(pcg, with_dp):
     try:
         if with_dp:
             from pcgan_amd.parallel import GradSync
-            dp = GradSync(always_exchange=True)
+            dp = GradSync(always_exchange=True, native=(with_dp == "native"))
+            assert dp.native == (with_dp == "native") and dp.rccl_ranks() == 1
         # eager
         netG, netD, crit, optD, optG = _fresh_dcgan(D)
         for i in range(4):

@@ -86,3 +86,84 @@ def test_rng_draw_inside_capture_raises(pcg):
         with torch.cuda.graph(g):
             torch.zeros(1, device=DEV).add_(1.0)
             rng.randn((16,), torch.device(DEV))
+
+
+def test_native_rccl_exports_one_rank(pcg):
+    """pcg_dp_* (RCCL behind the C ABI) on a one-rank communicator: in-stream average, side-stream begin / record / wait with
+    follow-up work queued behind the reduction, float64 sum, broadcast — and the ordering against the producer stream."""
+    import ctypes
+    import os
+    import torch.distributed as dist
+    from pcgan_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29549")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        dp = parallel.GradSync(always_exchange=True)
+        assert dp.native and dp.rccl_ranks() == 1
+        lib = pcg.load()
+        assert lib.pcg_dp_world() == 1 and lib.pcg_dp_rank() == 0 and lib.pcg_dp_side_stream()
+
+        class Net:
+            pass
+        net = Net()
+        net.flat_grads = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+        want = net.flat_grads.clone()
+        dp.sync_now(net)                                     # mean over one rank: unchanged
+        assert torch.equal(net.flat_grads, want)
+        # side stream: the reduction must see the producer's writes, the follow-up must see the reduction, the consumer both
+        net.flat_grads.mul_(2.0)                             # producer work on the main stream
+        out = torch.zeros_like(net.flat_grads)
+        dp.sync_then(net, lambda: out.copy_(net.flat_grads).add_(1.0))
+        dp.wait(net)
+        assert torch.equal(out, want * 2 + 1)
+        t = torch.full((256,), 0.1, dtype=torch.float64, device=DEV)
+        dp.allreduce_sum_f64_(t)
+        assert torch.equal(t, torch.full((256,), 0.1, dtype=torch.float64, device=DEV))
+        b = torch.randn(1000, device=DEV)
+        b0 = b.clone()
+        dp.broadcast_(b, 0)
+        assert torch.equal(b, b0)
+        torch.cuda.synchronize()
+    finally:
+        parallel.shutdown()
+        assert pcg.load().pcg_dp_world() == 0
+        dist.destroy_process_group()
+
+
+def test_exact_batchnorm_mode_one_rank_equals_per_replica(pcg):
+    """pcg_dp_sync_batchnorm on a one-rank communicator: every BatchNorm-family call takes the three-step path (this rank's sums
+    in the usual fixed order -> fp64 all-reduce -> finalize of ONE row of global sums with rows*world rows).  With world = 1 the
+    all-reduce is the identity and the sums are added in the same order, so a full DCGAN step — conv-epilogue statistics,
+    stand-alone statistics, both BatchNorm-backward forms — is BIT-identical to the default mode."""
+    import os
+    import torch.distributed as dist
+    from pcgan_amd import parallel
+    from pcgan_amd.nn import GraphedStep
+    D = pcg.dcgan
+    cfg = {"g_hidden": 32, "d_hidden": 32, "z_dim": 64}
+    g = torch.Generator().manual_seed(8)
+    real = (torch.rand(24, 1, 64, 64, generator=g) * 2 - 1).to(DEV)
+    noise = torch.randn(24, 64, 1, 1, generator=g).to(DEV)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29551")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    res = {}
+    try:
+        for sync in (False, True):
+            dp = parallel.GradSync(always_exchange=True, sync_bn=sync)
+            netG, netD, crit, optD, optG = _fresh(D, cfg)
+            for _ in range(2):
+                o = D.train_step(netG, netD, crit, optD, optG, real, noise, cfg, dp=dp, skip_dead_d_wgrad=False)
+            dp.wait_all()
+            res[sync] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params.clone(), netD.flat_params.clone(),
+                         [b.clone() for b in netD.buffers()] + [b.clone() for b in netG.buffers()])
+            if sync:
+                with pytest.raises(pcg.PcgError, match="eagerly"):
+                    GraphedStep(lambda d: None, {"real": real}, [netG, netD], [optD, optG], dp=dp)
+        assert res[True][0] == res[False][0]
+        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+        assert all(torch.equal(a, b) for a, b in zip(res[True][3], res[False][3]))
+    finally:
+        parallel.shutdown()
+        dist.destroy_process_group()

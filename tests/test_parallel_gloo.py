@@ -249,3 +249,41 @@ def test_bench_launcher_starts_ranks_and_propagates_failure(tmp_path, monkeypatc
     assert bad.returncode == 7 and "rank 1 exited with 7" in bad.stderr
     few = subprocess.run([sys.executable, "-c", drv % 1], capture_output=True, text=True, timeout=120)
     assert few.returncode != 0 and "exposes 1 GPU" in few.stderr
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcgan_amd.parallel import GradSync
+    dp = GradSync(sync_bn=True)
+    # exact-BatchNorm exchange: each rank holds the fp64 sums (sum x, sum x^2 | sum dy, sum dy*xhat) of ITS shard; after the
+    # all-reduce every rank holds the sums of the whole batch — what the statistics finalize then consumes (rows * world).
+    # Integer-valued fp32 data: every partial sum is exact in fp64, so "2 ranks x B/2 == 1 rank x B" holds bit for bit.
+    g = torch.Generator().manual_seed(5)
+    B, C = 64, 16
+    x = torch.randint(-50, 50, (B, 7, C), generator=g).float()
+    shard = x[rank * (B // world):(rank + 1) * (B // world)].double().reshape(-1, C)
+    sums = torch.cat([shard.sum(0), (shard * shard).sum(0)])
+    dp.allreduce_sum_f64_(sums)
+    full = x.double().reshape(-1, C)
+    want = torch.cat([full.sum(0), (full * full).sum(0)])
+    rows = full.shape[0]
+    mean, var = sums[:C] / rows, sums[C:] / rows - (sums[:C] / rows) ** 2
+    ok = torch.equal(sums, want) and torch.allclose(mean, full.mean(0), rtol=0, atol=1e-12) \
+        and torch.allclose(var, full.var(0, unbiased=False), rtol=1e-12)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_exact_batchnorm_sums_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)], res
