@@ -702,13 +702,22 @@ def make_optimizers(generator, discriminator, cfg=Config):
 def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg=Config, dp=None,
                skip_dead_d_wgrad=True):
     """One iteration of train_countergan's loop body (trainer.py:89-123) for a batch already on the GPU; `target_y`
-    (:94) and `mask` (:95) are passed in.  Returns device tensors; the reference's `.item()` calls are the caller's."""
+    (:94) and `mask` (:95) are passed in.  Returns device tensors; the reference's `.item()` calls are the caller's.
+
+    dp (parallel.GradSync): D's bucket is averaged in stream order (Adam(D) needs it at once); G's bucket + Adam(G) run on the
+    side stream and overlap with the NEXT iteration's D(real) forward — which is therefore issued before the generator forward
+    when data-parallel (it reads only x, y and D's weights; D has no BatchNorm, so the hoist changes no number)."""
+    d_real_logits = None
+    if dp is not None:
+        d_real_logits = discriminator(x, y)                                            # :103, hoisted above the wait
+        dp.wait(generator)                                                             # previous iteration's G all-reduce + Adam(G)
     raw_residual, masked_residual = generator(x, target_y, mask)                       # :96
     x_cf = clamp_add(x, masked_residual, -1.0, 1.0)                                    # :97
     mask_penalty_pre = abs_mean(raw_residual, mask, one_minus=True)                    # :99
     # Discriminator update
     opt_d.zero_grad()                                                                  # :102
-    d_real_logits = discriminator(x, y)                                                # :103
+    if d_real_logits is None:
+        d_real_logits = discriminator(x, y)                                            # :103
     d_fake_logits = discriminator(x_cf.detach(), target_y)                             # :104
     d_loss = bce(d_real_logits, 1.0) + bce(d_fake_logits, 0.0)                         # :106-107
     d_loss.backward()                                                                  # :111
@@ -716,8 +725,6 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
         dp.sync_now(discriminator)
     opt_d.step()                                                                       # :112
     # Generator update
-    if dp is not None:
-        dp.wait(generator)
     opt_g.zero_grad()                                                                  # :115
     if skip_dead_d_wgrad:
         for p in discriminator.parameters():
@@ -734,8 +741,9 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
             for p in discriminator.parameters():
                 p.requires_grad_(True)
     if dp is not None:
-        dp.sync_now(generator)
-    opt_g.step()                                                                       # :123
+        dp.sync_then(generator, opt_g.step)                                            # overlapped with the next D(real) forward
+    else:
+        opt_g.step()                                                                   # :123
     return {"d_loss": d_loss, "g_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg_l1": reg_l1, "mask_pen": mask_penalty_pre,
             "d_real_logits": d_real_logits, "d_fake_logits": d_fake_logits, "x_cf": x_cf}
 

@@ -1,72 +1,111 @@
 #!/usr/bin/env python3
-"""Step time of the tabular CounteRGAN training step (house_sales_kc_usa/trainer.py:241-316) on one MI355X — secondary
-measurement; the contract bench is bench.py (DCGAN).  Two modes: eager (one host launch per
-kernel) and --graph (the whole step — G fwd, D step, G step, both Adams — captured once in a HIP graph and replayed; the
-per-step draws are written into static buffers by three RNG launches outside the graph)."""
-import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import pcgan_amd
-from pcgan_amd import house as H, ops
+"""rows/sec of the tabular CounteRGAN training step (conditional_counteRGAN/house_sales_kc_usa/trainer.py:241-316) on one MI355X —
+BASELINE config 5 (batch 4096, single GPU: the path does not shard, "replicas only").
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=128)
-ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--warmup", type=int, default=20)
-ap.add_argument("--graph", action="store_true")
-ap.add_argument("--cpu-baseline", action="store_true", help="also time oracle/house_ref.py (PyTorch CPU) on the same batch size")
-args = ap.parse_args()
-dev = torch.device("cuda:0")
-G, D, C = H.build(dev, seed=0)
-opt_g, opt_d = H.make_optimizers(G, D)
-norm = H.cat_norm_maps(G, H.CONFIG, dev)
-rng = ops.DeviceRNG(1)
-B = args.batch
-x = torch.rand(B, 17, device=dev)
-y = torch.randint(0, 4, (B,), device=dev)
-t, mask, noise = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
+  python scripts/bench_house.py                  batch 4096, the whole step (G fwd, D step, G step, both Adams) replayed as ONE HIP graph
+  python scripts/bench_house.py --eager          one host launch per kernel
 
-def draws():
-    t2, m2, n2 = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
-    t.copy_(t2); mask.copy_(m2); noise.copy_(n2)
+One JSON line, same contract as bench.py.  The step is ~1 MFLOP per row on 17..256-wide layers: no MFMA claim.  `roofline` is
+stated against HBM with `bound: "launch/hbm"`: achieved = algorithmic bytes per step (the batch's inputs and draws once; every
+parameter read once per pass that uses it; Adam's 28 B per trained parameter; the per-row activations that backward needs, written
+once and read once) / step time — the step is launch-latency-bound, the fraction is small by construction and `launches_per_step`
+(from the committed rocprofv3 summary of this command) is the number that explains it."""
+import argparse
+import json
+import os
+import sys
 
-def step():
-    return H.train_step(G, D, C, opt_g, opt_d, x, y, t, mask, norm, gumbel=noise)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib as BL  # noqa: E402
+import torch  # noqa: E402
 
-if args.graph:
-    gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B)
-    gs.x.copy_(x); gs.y.copy_(y)
-    t, mask, noise = gs.target_y, gs.mask, gs.noise
-    def run():
-        global out
-        draws(); out = gs.replay()
-else:
-    def run():
-        global out
-        draws(); out = step()
-for _ in range(args.warmup):
-    run()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(args.steps):
-    run()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / args.steps
-line = (f"house-sales counteRGAN batch {B} {'graph' if args.graph else 'eager'}: {dt * 1e3:.3f} ms/step  {B / dt:.0f} rows/s  "
-        f"D_loss {out['D_loss'].item():.4f} G_loss {out['G_loss'].item():.4f}")
-if args.cpu_baseline:
-    from oracle import house_ref as HR
-    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    oG, oD, oC = HR.build(0)
-    o_g, o_d = HR.make_optimizers(oG, oD)
-    xb, yb, tb, mb, gb = HR.synthetic_batch(B, 0)
-    nm = HR.cat_norm_maps()
-    for _ in range(3):
-        HR.house_step(oG, oD, oC, o_g, o_d, xb, yb, tb, mb, gb, nm)
-    n = max(5, min(100, int(2.0 / max(dt, 1e-4) / 50)))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        HR.house_step(oG, oD, oC, o_g, o_d, xb, yb, tb, mb, gb, nm)
-    ct = (time.perf_counter() - t0) / n
-    line += f"  | oracle (PyTorch CPU, {torch.get_num_threads()} threads): {ct * 1e3:.3f} ms/step  {B / ct:.0f} rows/s"
-print(line)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    BL.add_common_args(ap, steps=200, warmup=20)
+    args = ap.parse_args()
+    if args.gpus != 1:
+        sys.exit("bench_house.py: the tabular step does not shard (BASELINE config 5 is single-GPU); run one process per replica")
+    R = BL.Ranks(args, os.path.abspath(__file__))
+    from pcgan_amd import house as H, ops
+    dev = R.dev
+    G, D, C = H.build(dev, seed=0)
+    opt_g, opt_d = H.make_optimizers(G, D)
+    norm = H.cat_norm_maps(G, H.CONFIG, dev)
+    rng = ops.DeviceRNG(1)
+    B = args.batch
+    x = rng.rand((B, H.CONFIG["input_dim"]), dev)
+    y = rng.randint(0, H.CONFIG["num_classes"], B, dev)
+    t, mask, noise = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
+
+    def draws():
+        t2, m2, n2 = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
+        t.copy_(t2); mask.copy_(m2); noise.copy_(n2)
+
+    gs = None
+    if not args.eager:
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B)
+        gs.x.copy_(x); gs.y.copy_(y)
+        t, mask, noise = gs.target_y, gs.mask, gs.noise
+
+    def run(i):
+        draws()
+        return gs.replay() if gs is not None else H.train_step(G, D, C, opt_g, opt_d, x, y, t, mask, norm, gumbel=noise)
+
+    for i in range(args.warmup):
+        run(i)
+    dt, out = R.timed(run, args.steps)
+    sec = dt / args.steps
+    losses = {"D_loss": float(out["D_loss"].item()), "G_loss": float(out["G_loss"].item())}
+    if not all(v == v and abs(v) < 1e6 for v in losses.values()):
+        sys.exit(f"non-finite losses: {losses}")
+
+    # algorithmic HBM bytes per step
+    nG, nD, nC = (sum(p.numel() for p in m.parameters()) for m in (G, D, C))
+    hid = int(H.CONFIG.get("hidden_dim", 256)) if isinstance(H.CONFIG, dict) else 256
+    nblk = len(getattr(G, "blocks", [])) or 5
+    per_row_saved = 4 * (2 * (17 + 4 + 17 + 38) + (2 * nblk + 1) * hid * 2 + 3 * 128)      # inputs/draws, G trunk activations (fwd write + bwd read), D/C hidden rows
+    algo_bytes = (4 * (3 * nD + 2 * nG + 2 * nC)          # parameters read: D in 3 passes, G fwd+bwd, frozen C fwd+bwd
+                  + 28 * (nG + nD)                        # Adam: p, g read; m, v read+write; p write
+                  + B * per_row_saved)
+    launches = None
+    try:
+        with open(os.path.join(BL.ROOT, "profiles", "r02_house_launches.json")) as f:
+            launches = json.load(f)["launches_per_step"]
+    except Exception:
+        pass
+    ach = algo_bytes / sec / 1e9
+    roofline = {"bound": "launch/hbm", "achieved": round(ach, 2), "peak": BL.PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / BL.PEAK_HBM_GBS, 5),
+                "traffic": None, "algorithmic_bytes_per_step": int(algo_bytes), "launches_per_step": launches,
+                "us_per_launch": None if not launches else round(sec * 1e6 / launches, 2),
+                "kernel": "whole step (fused generator segments, fused critic, grouped weight gradients, Adam x2)"}
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import house_ref as HR                   # the checker's restatement: CPU-baseline leg only
+        oG, oD, oC = HR.build(0)
+        o_g, o_d = HR.make_optimizers(oG, oD)
+        xb, yb, tb, mb, gb = HR.synthetic_batch(B, 0)
+        nm = HR.cat_norm_maps()
+        med, thr, avail = BL.cpu_median(lambda: HR.house_step(oG, oD, oC, o_g, o_d, xb, yb, tb, mb, gb, nm), steps=15, warmup=3,
+                                        threads=args.cpu_threads)
+        cpu = {"value": round(B / med, 1), "unit": "rows/sec", "cores": thr, "kind": "port", "cpu_model": BL.cpu_model(),
+               "host_cpus_visible": avail,
+               "sample": f"median of 15 steps at batch {B} (= the GPU run) after 3 warm-ups; PyTorch-CPU fp32 restatement of "
+                         f"house_sales_kc_usa/trainer.py:241-316 (oracle/house_ref.py)"}
+    BL.emit({
+        "metric": "rows/sec (G+D step) tabular CounteRGAN house_sales_kc_usa; launch/HBM bound",
+        "value": round(B / sec, 1), "unit": "rows/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"conditional_counteRGAN/house_sales_kc_usa tabular CounteRGAN (FiLM ResidualGenerator, spectral-norm "
+                               f"Discriminator, frozen NNClassifier), 17 features, batch {B}, full step incl. per-step device draws",
+                   "global_batch": B, "parallelism": "dp1"},
+        "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
+        "launch": "eager" if gs is None else "hip-graph replay (1 graph) + 3 RNG launches per step",
+    })
+    R.finish()
+
+
+if __name__ == "__main__":
+    main()

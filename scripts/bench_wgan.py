@@ -1,53 +1,106 @@
 #!/usr/bin/env python3
-"""Step time of the conditional WGAN-GP loop iteration (mnist_wgan_conditional.py:133-168) on one MI355X at the reference's
-full width (1024) — secondary measurement (BASELINE config: global batch 1024 = 256 per GPU on 4);
-the contract bench is bench.py (DCGAN).  Reports the critic update (every iteration) and the generator update (every n_critic-th)
-separately and their n_critic-weighted mean.
+"""images/sec of the conditional WGAN-GP loop iteration (conditional_gan/mnist/mnist_wgan_conditional.py:133-168) at the
+reference's full width (1024) — BASELINE config 3 (global batch 1024 = 256 per GPU on 4 MI355X).
 
-Nominal MACs per image (SURVEY.md section 8d convention: positions x k^2 x Cin x Cout): critic forward 70.2 M, generator forward
-195.9 M.  Critic update = 3 critic forwards + 1 generator forward + first-order backward of the real and fake passes (2 forward-
-equivalents each, less the layer-1 dgrad) + the interpolate pass's gradient sweep (1) + backward-of-backward (conv_fwd + wgrad up,
-wgrad + dgrad down: 4) ~ 12 x 70.2 + 195.9 = 1038 M MACs = 2.08 GFLOP.  Generator update = 3 x 195.9 + 2 x 70.2 = 728 M MACs."""
-import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import pcgan_amd
-from pcgan_amd import wgan as W, ops
+  python scripts/bench_wgan.py                 one GPU, batch 256
+  python scripts/bench_wgan.py --gpus 4        starts 4 ranks itself (or run it under torch.distributed.run)
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=256)
-ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--warmup", type=int, default=3)
-ap.add_argument("--width", type=int, default=1024)
-args = ap.parse_args()
-dev = torch.device("cuda:0")
-hp = W.Hyperparameter(critic_size=args.width, generator_size=args.width, critic_hidden_size=args.width, batchsize=args.batch)
-critic, generator = W.build(dev, hp)
-c_opt, g_opt = W.make_optimizers(critic, generator)
-rng = ops.DeviceRNG(1)
-B = args.batch
-x = rng.rand((B, 1, 28, 28), dev) * 2 - 1
-lab = ops.onehot(rng.randint(0, 10, B, dev), 10)
+A "step" is one loop iteration: the critic update (every iteration) + 1/n_critic of a generator update (the reference runs it
+every n_critic-th iteration, :157); both are timed separately and combined with that weight.  One JSON line, same contract as
+bench.py.  Nominal MACs per image (SURVEY.md §8d convention: positions x k^2 x Cin x Cout): critic forward 70.2 M, generator
+forward 195.9 M.  Critic update = 3 critic forwards + 1 generator forward + first-order backward of the real and fake passes
+(2 forward-equivalents each, less the layer-1 dgrad) + the interpolate pass's gradient sweep (1) + backward-of-backward (conv_fwd +
+wgrad up, wgrad + dgrad down: 4) ~ 12 x 70.2 + 195.9 = 1038 M MACs = 2.08 GFLOP.  Generator update = 3 x 195.9 + 2 x 70.2 = 728 M MACs."""
+import argparse
+import os
+import sys
 
-def cstep():
-    return W.critic_step(critic, generator, c_opt, hp, x, lab, rng.randn((B, hp.latent_size), dev), rng.rand((B, 1), dev))
-def gstep():
-    return W.generator_step(critic, generator, g_opt, ops.onehot(rng.randint(0, 10, B, dev), 10), rng.randn((B, hp.latent_size), dev))
-def timeit(fn):
-    for _ in range(args.warmup):
-        out = fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / args.steps, out
-tc, oc = timeit(cstep)
-tg, og = timeit(gstep)
-scale = (args.width / 1024.0) ** 2
-fc, fg = 2 * 1038e6 * scale * B, 2 * 728e6 * scale * B
-it = tc + tg / hp.n_critic
-print(f"WGAN-GP width {args.width} batch {B}: critic update {tc * 1e3:.2f} ms ({fc / tc / 1e12:.1f} TFLOP/s nominal), generator update "
-      f"{tg * 1e3:.2f} ms ({fg / tg / 1e12:.1f} TFLOP/s), loop iteration (n_critic={hp.n_critic}) {it * 1e3:.2f} ms = {B / it:.0f} img/s "
-      f"({(fc + fg / hp.n_critic) / it / 1e12:.1f} TFLOP/s = {(fc + fg / hp.n_critic) / it / 157.3e12 * 100:.1f}% of fp32-MFMA peak)  "
-      f"critic_loss {oc['critic_loss'].item():.4f} gp {oc['gradient_penalty'].item():.4f} g_loss {og['generator_loss'].item():.4f}")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _benchlib as BL  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--width", type=int, default=1024)
+    BL.add_common_args(ap, steps=20, warmup=3)
+    args = ap.parse_args()
+    R = BL.Ranks(args, os.path.abspath(__file__))
+    from pcgan_amd import wgan as W, ops
+    dev, dp = R.dev, R.dp
+    hp = W.Hyperparameter(critic_size=args.width, generator_size=args.width, critic_hidden_size=args.width, batchsize=args.batch)
+    critic, generator = W.build(dev, hp)
+    c_opt, g_opt = W.make_optimizers(critic, generator)
+    R.broadcast([critic, generator])
+    rng = ops.DeviceRNG(1 + R.rank)
+    B = args.batch
+    x = rng.rand((B, 1, 28, 28), dev).mul_(2.0).sub_(1.0)
+    lab = ops.onehot(rng.randint(0, 10, B, dev), 10)
+    records = []
+
+    def cstep(i):
+        return W.critic_step(critic, generator, c_opt, hp, x, lab, rng.randn((B, hp.latent_size), dev), rng.rand((B, 1), dev), dp=dp)
+
+    def gstep(i):
+        return W.generator_step(critic, generator, g_opt, ops.onehot(rng.randint(0, 10, B, dev), 10), rng.randn((B, hp.latent_size), dev), dp=dp)
+
+    def measure(fn):
+        for i in range(args.warmup):
+            fn(i)
+        mid = args.steps // 2
+
+        def one(i):
+            ops.set_conv_hook((lambda *r: records.append(r)) if i == mid else None)
+            return fn(i)
+        dt, out = R.timed(one, args.steps)
+        ops.set_conv_hook(None)
+        return dt / args.steps, out
+
+    tc, oc = measure(cstep)
+    tg, og = measure(gstep)
+    same = R.replicas_identical([critic, generator])
+    scale = (args.width / 1024.0) ** 2
+    fc, fg = 2 * 1038e6 * scale * B, 2 * 728e6 * scale * B
+    it = tc + tg / hp.n_critic
+    flops_it = fc + fg / hp.n_critic
+    losses = {"critic_loss": float(oc["critic_loss"].item()), "gradient_penalty": float(oc["gradient_penalty"].item()),
+              "generator_loss": float(og["generator_loss"].item())}
+    if not all(v == v and abs(v) < 1e6 for v in losses.values()):
+        sys.exit(f"non-finite losses: {losses}")
+    cpu = None
+    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
+        from oracle import wgan_ref as WR                 # the checker's restatement: CPU-baseline leg only
+        cb = 32                                           # full width on the CPU: ~2 s per critic update at 32 images
+        ohp = WR.Hyperparameter()
+        ohp.critic_size = ohp.generator_size = ohp.critic_hidden_size = args.width
+        ocr, og_ = WR.build(ohp, seed=1)
+        oc_opt, og_opt = WR.make_optimizers(ocr, og_)
+        xb, yb, zb, ab, y2, z2 = WR.synthetic_batch(ohp, cb, seed=0)
+        mc, thr, avail = BL.cpu_median(lambda: WR.critic_step(ocr, og_, oc_opt, ohp, xb, yb, zb, ab), steps=3, threads=args.cpu_threads)
+        mg, _, _ = BL.cpu_median(lambda: WR.generator_step(ocr, og_, og_opt, y2, z2), steps=3, threads=args.cpu_threads)
+        cpu = {"value": round(cb / (mc + mg / hp.n_critic), 2), "unit": "images/sec", "cores": thr, "kind": "port", "cpu_model": BL.cpu_model(),
+               "host_cpus_visible": avail,
+               "sample": f"median of 3 critic updates + 3 generator updates at batch {cb}, width {args.width} (GPU run: {B} per GPU), "
+                         f"1 warm-up each, combined with the 1/n_critic weight; PyTorch-CPU fp32 restatement of mnist_wgan_conditional.py:133-168"}
+    if R.rank == 0:
+        roof = BL.conv_family_roofline(records, it, 1, flops_it)
+        if roof:
+            roof["gemm_time_share"] = None     # events sample one critic and one generator update, not one weighted iteration
+        BL.emit({
+            "metric": "images/sec (loop iteration: critic update + 1/n_critic generator update) conditional WGAN-GP/mnist; % MFMA roofline",
+            "value": round(R.world * B / it, 1), "unit": "images/sec", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(it * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"conditional_gan/mnist WGAN-GP (Generator / Critic width {args.width}, gradient penalty via hand-derived "
+                                   f"backward of the backward), 28x28, batch {B} per GPU, n_critic {hp.n_critic}",
+                       "global_batch": R.world * B, "parallelism": f"dp{R.world}"},
+            "critic_update_ms": round(tc * 1e3, 3), "generator_update_ms": round(tg * 1e3, 3),
+            "roofline": roof, "cpu_baseline": cpu, "final_losses": losses,
+            "rccl_ranks": None if dp is None else dp.rccl_ranks(), "replicas_identical": same, "launch": "eager",
+        })
+    R.finish()
+
+
+if __name__ == "__main__":
+    main()

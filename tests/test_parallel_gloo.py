@@ -151,12 +151,38 @@ def _toy_step(rec, netG, netD, optD, optG, real, noise, dp):
     return netD.flat_grads
 
 
-def _segment_worker(rank, world, port, q):
+def _toy_countergan_step(rec, netG, netD, optD, optG, real, noise, dp):
+    """The exchange points of countergan.train_step (mnist/trainer.py:96-123) in its data-parallel order: D(real) forward hoisted
+    above wait(G), generator forward, D update (bucket averaged in stream order), G update (bucket + Adam overlapped)."""
+    L = rec.launch
+    scratch = {}
+    if dp is not None:
+        L(lambda: scratch.__setitem__("d_real", real.sum() * netD.flat_params))       # D(real) forward: reads only D
+        dp.wait(netG)
+    else:
+        L(lambda: scratch.__setitem__("d_real", real.sum() * netD.flat_params))
+    L(lambda: scratch.__setitem__("x_cf", noise.sum() * netG.flat_params[:netD.flat_params.numel()]))   # generator forward
+    L(lambda: netD.flat_grads.zero_())
+    L(lambda: netD.flat_grads.add_(scratch["d_real"]).add_(scratch["x_cf"]))          # d_loss.backward()
+    if dp is not None:
+        dp.sync_now(netD)
+    optD.step()
+    L(lambda: netG.flat_grads.zero_())
+    L(lambda: netG.flat_grads.add_(noise.sum() * netG.flat_params).add_(netD.flat_params.sum()))      # g_loss.backward()
+    if dp is not None:
+        dp.sync_then(netG, optG.step)
+    else:
+        optG.step()
+    return netD.flat_grads
+
+
+def _segment_worker(rank, world, port, q, toy="dcgan"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pcgan_amd.nn import GraphedStep
     from pcgan_amd.parallel import GradSync
+    _toy_step = globals()["_toy_step" if toy == "dcgan" else "_toy_countergan_step"]
 
     def build():
         rec = _Recorder()
@@ -192,6 +218,14 @@ def _segment_worker(rank, world, port, q):
     ok = ok and torch.equal(gG.flat_params, eG.flat_params) and torch.equal(gD.flat_params, eD.flat_params)
     ok = ok and torch.equal(gD.bn_running, eD.bn_running) and float(oG2.steps) == steps
 
+    if toy != "dcgan":      # the single-process closed form below is the DCGAN toy's; (a) == (b) and (d) cover this order
+        for t in (gG.flat_params, gD.flat_params):
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            ok = ok and all(torch.equal(gathered[0], x) for x in gathered)
+        q.put((rank, bool(ok)))
+        dist.destroy_process_group()
+        return
     # (c) one process, averaged gradients of all shards (what the replicas must equal)
     rec, sG, sD, oD3, oG3 = build()
     for _ in range(steps):
@@ -214,11 +248,15 @@ def _segment_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_segment_program_world2_gloo():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("toy", ["dcgan", "countergan"])
+def test_segment_program_world2_gloo(toy):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_segment_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_segment_worker, args=(r, 2, port, q, toy)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
