@@ -46,6 +46,10 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, true, true>(ktiles, acc, smem);
   float* out = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
+#ifdef PCG_ABL_NO_EPILOGUE   // timing-only ablation: keep one store so the accumulators stay live
+  if (acc[0][0][0] == 12345.678f) out[0] = acc[0][0][1];
+  return;
+#endif
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, blockIdx.y == 0 ? p.bias : nullptr, [&](int row) -> float* {
     const int m = m_block + row;
     return m < p.M ? out + (size_t)m * p.N + n_block : nullptr;

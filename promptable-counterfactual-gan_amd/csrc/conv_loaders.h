@@ -96,7 +96,7 @@ __device__ __forceinline__ float4 xf_apply(float4 v, float4 sc, float4 sh, float
 // ---- forward: A = im2col rows of x (K-major), B = OHWI weight rows (K-major) --------------------------------
 template <int ROWS_, bool XF = false>
 struct FwdALoader {
-  static constexpr bool KMAJOR = true;
+  static constexpr bool KMAJOR = true, XFORM = XF;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV], mask[NV];
@@ -158,7 +158,7 @@ struct FwdALoader {
 
 template <int ROWS_>
 struct FwdBLoader {
-  static constexpr bool KMAJOR = true;
+  static constexpr bool KMAJOR = true, XFORM = false;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV];
@@ -205,7 +205,7 @@ struct DgradTapIter {  // k-tiles run over (jh, jw, co-chunk)
 
 template <int ROWS_, bool XF = false>
 struct DgradALoader {
-  static constexpr bool KMAJOR = true;
+  static constexpr bool KMAJOR = true, XFORM = XF;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV], mask[NV];
@@ -260,7 +260,7 @@ struct DgradALoader {
 
 template <int ROWS_>
 struct DgradBLoader {
-  static constexpr bool KMAJOR = false;
+  static constexpr bool KMAJOR = false, XFORM = false;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
   rsrc_t rs;
@@ -295,7 +295,7 @@ struct DgradBLoader {
 // live in registers; XF = the operand is an activation to be read as act(v*sc + sh).
 template <int ROWS_, bool XF = false>
 struct WgradALoader {
-  static constexpr bool KMAJOR = false;
+  static constexpr bool KMAJOR = false, XFORM = XF;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
   rsrc_t rs;
@@ -342,7 +342,7 @@ struct WgradALoader {
 
 template <int ROWS_, bool XF = false>
 struct WgradBLoader {
-  static constexpr bool KMAJOR = false;
+  static constexpr bool KMAJOR = false, XFORM = XF;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
   rsrc_t rs;

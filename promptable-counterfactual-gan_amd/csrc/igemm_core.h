@@ -37,6 +37,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int IG_LOADERS = 256;            // threads that gather one k-tile (4 waves)
 constexpr int IG_THREADS = 512;            // 4 consumer + 4 producer waves
 constexpr int IG_BK = 32;
+#ifndef PCG_PREFETCH_DEPTH
+#define PCG_PREFETCH_DEPTH 2               // k-tiles of operand gathers in flight per producer thread (1: the r01 pipeline)
+#endif
 constexpr int IG_LDK = IG_BK + 4;          // K-major row stride: 144 B = 9*16 (aligned for b128, conflict-free)
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -108,6 +111,43 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
   static_assert(LA::ROWS == Cfg::BM && LB::ROWS == Cfg::BN, "loader/tile mismatch");
   float* As = smem;
   float* Bs = smem + 2 * IA::FLOATS;
+  // loaders that carry an input transform keep ONE pending tile of transform state: they run the depth-1 pipeline
+  if constexpr (PCG_PREFETCH_DEPTH == 2 && !LA::XFORM && !LB::XFORM) {
+  // Two k-tiles of gathers in flight.  One k-tile of MFMAs is 2048 (128x64 tile) .. 4096 cycles (128x128) = 1 .. 2 us, which is no
+  // more than a loaded HBM / L2 round trip: with a single tile in flight the producers reach the hand-over barrier late and the
+  // consumers wait.  (Measured r02: +2..4 % per kernel in isolation, nothing in the back-to-back step — the larger part of what idle
+  // producers gain in the ablation, +12 % on 128x128 tiles and +19 % on 128x64, is not gather latency.)  Register sets 0/1 alternate: at
+  // iteration kt the set holding tile kt+1 is written to LDS and immediately refilled with the gathers of tile kt+3.
+  float4 ra[2][IA::NV], rb[2][IB::NV];
+  if (ktiles > 0) {
+    la.load_next(ra[0]); lb.load_next(rb[0]);                       // tile 0
+    if (ktiles > 1) { la.load_next(ra[1]); lb.load_next(rb[1]); }   // tile 1
+    la.transform(ra[0]); lb.transform(rb[0]);
+    IA::store(As, ra[0], tid);
+    IB::store(Bs, rb[0], tid);
+    if (ktiles > 2) { la.load_next(ra[0]); lb.load_next(rb[0]); }   // tile 2
+  }
+  lds_barrier();  // barrier 0: stage 0 is ready
+  // invariant at the top of iteration kt: set (kt+1)&1 holds tile kt+1 (in flight or landed), set kt&1 holds tile kt+2
+  int kt = 0;
+  for (; kt + 1 < ktiles; kt += 2) {
+    // kt even: tile kt+1 is in set 1 -> stage 1; refill set 1 with tile kt+3
+    la.transform(ra[1]); lb.transform(rb[1]);
+    IA::store(As + IA::FLOATS, ra[1], tid);
+    IB::store(Bs + IB::FLOATS, rb[1], tid);
+    if (kt + 3 < ktiles) { la.load_next(ra[1]); lb.load_next(rb[1]); }
+    lds_barrier();
+    // kt+1 odd: tile kt+2 is in set 0 -> stage 0; refill set 0 with tile kt+4
+    if (kt + 2 < ktiles) {
+      la.transform(ra[0]); lb.transform(rb[0]);
+      IA::store(As, ra[0], tid);
+      IB::store(Bs, rb[0], tid);
+    }
+    if (kt + 4 < ktiles) { la.load_next(ra[0]); lb.load_next(rb[0]); }
+    lds_barrier();
+  }
+  if (kt < ktiles) lds_barrier();   // odd ktiles: the last iteration has nothing left to stage
+  } else {
   float4 ra[IA::NV], rb[IB::NV];
   if (ktiles > 0) {
     la.load_next(ra);
@@ -136,6 +176,7 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
 #endif
     lds_barrier();  // barrier kt+1: stage nxt handed to the consumers, stage nxt^1 handed back
     nxt ^= 1;
+  }
   }
 }
 

@@ -414,6 +414,21 @@ class _MaskMulFn(torch.autograd.Function):
         return ops.scale_mask_bwd(None, dsum, ctx.mask, 1.0, like=ctx.mask), None, None
 
 
+class _InjectGradFn(torch.autograd.Function):
+    """y = x; in backward: dx = dy + g.  Carries a gradient contribution that was computed ahead of time (the frozen classifier's
+    d(lambda_cls * CE)/d(x_cf), evaluated on the parallel branch of train_step) into autograd's sweep: one fused add instead of
+    autograd's own accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.g = g
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.axpby(1.0, dy.contiguous(), 1.0, ctx.g), None
+
+
 # ---- discriminator ------------------------------------------------------------------------------------------------------
 class _DFn(torch.autograd.Function):
     @staticmethod
@@ -711,10 +726,17 @@ def make_optimizers(generator, discriminator, config=CONFIG):
 
 
 def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config=CONFIG, gumbel=None,
-               ce=None, skip_dead_d_wgrad=True):
+               ce=None, skip_dead_d_wgrad=True, branch=None):
     """One iteration of train_countergan's loop body (trainer.py:241-316) for a batch already on the GPU.  The draws —
     `target_y` (:248-249), `mask` (:253-255) and the Gumbel noise inside G (gumbel=None: generator.rng) — are inputs.
-    Returns device tensors; the reference's `.item()` calls are the caller's."""
+    Returns device tensors; the reference's `.item()` calls are the caller's.
+
+    branch: a second HIP stream.  The step is a chain of ~100 tiny kernels (64 blocks each on a 256-CU chip), i.e. bound by the
+    length of its dependency chain; the frozen classifier's pass (trainer.py:301-302: forward, cross-entropy and — in backward —
+    the gradient with respect to x_cf; ~25 % of the chain) depends only on x_cf, so it is forked onto `branch` as soon as x_cf
+    exists and runs beside the whole critic update; it joins where g_loss is formed.  autograd runs a node's backward on the
+    stream its forward ran on, so the classifier's backward overlaps the critic's in the G step too.  Same kernels, same inputs:
+    results are bit-identical to the single-stream order; captured in a HIP graph the two streams become parallel branches."""
     nc = config["num_classes"]
     ce = ce if ce is not None else CrossEntropyLoss()
     target_onehot = ops.onehot(target_y, nc)                                                  # :250
@@ -722,12 +744,43 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
                                                 gumbel=gumbel)                                # :259-261
     residual_full = assemble_residual(generator, cont, samples, x, norm_vals)                 # :266-279
     masked_residual, x_cf = _MaskMulFn.apply(residual_full, mask, x)                          # :281-282
-    mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                          # :287
+    g_cls = dx_cls = am = None
+    if branch is None:
+        mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                      # :287
+    else:
+        # fork: the classifier term of the G step (:301-302) needs only x_cf and a frozen net, and its weight in g_loss is a
+        # constant — so its forward, the cross-entropy (value AND gradient in one launch) and its grad-input sweep all run here,
+        # beside the critic update; the resulting d(lambda_cls * g_cls)/d(x_cf) is injected into autograd's sweep below.
+        # (grad_scale = lambda_cls, grad_out = 1: the same product the autograd path forms from weighted_sum's backward.)
+        if classifier.training or any(p.requires_grad for p in classifier.parameters()):
+            raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
+        # Off the critical chain as well: the two L1 penalties (:287, :305 — forward here, so autograd runs their backward on the
+        # branch, beside the critic's), and the gradient buffers are zeroed up front (nothing writes them before the backward
+        # passes; the reference zeroes them right before each backward, :293, :314).
+        main = torch.cuda.current_stream()
+        branch.wait_stream(main)
+        with torch.cuda.stream(branch):
+            opt_d.zero_grad(); opt_g.zero_grad()
+            zeroed = torch.cuda.Event()
+            zeroed.record(branch)
+            mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                  # :287
+            am = abs_mean(masked_residual)                                                    # :305
+        residual_full.record_stream(branch); masked_residual.record_stream(branch); mask.record_stream(branch)
+        with torch.cuda.stream(branch), torch.no_grad():
+            logits_c, acts_c = classifier._run_forward(x_cf.detach().contiguous(), keep=True)
+            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
+                                                    grad_scale=float(config["lambda_cls"]))
+            dx_cls = classifier._run_backward(acts_c, dlog)
+            g_cls = g_cls.view(())
+        x_cf.record_stream(branch); target_y.record_stream(branch)
     # ---- D step
     d_real = discriminator(x, ops.onehot(y, nc))                                              # :290
     d_fake = discriminator(x_cf.detach(), target_onehot)                                      # :291
     d_loss = weighted_sum([mean(d_fake), mean(d_real)], [1.0, -1.0])                          # :292
-    opt_d.zero_grad()
+    if branch is None:
+        opt_d.zero_grad()
+    else:                            # the zero fills were issued on the branch: the backward passes must see them
+        torch.cuda.current_stream().wait_event(zeroed)
     d_loss.backward()
     opt_d.step()                                                                              # :293-295
     # ---- G step
@@ -735,23 +788,43 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
         for p in discriminator.parameters():
             p.requires_grad_(False)
     try:
-        d_fake_for_g = discriminator(x_cf, target_onehot)                                     # :298
+        if g_cls is None:
+            x_cf_g = x_cf
+        else:                                                                                 # join the classifier branch
+            torch.cuda.current_stream().wait_stream(branch)
+            g_cls.record_stream(torch.cuda.current_stream()); dx_cls.record_stream(torch.cuda.current_stream())
+            x_cf_g = _InjectGradFn.apply(x_cf, dx_cls)
+        d_fake_for_g = discriminator(x_cf_g, target_onehot)                                   # :298
         m_fake = mean(d_fake_for_g)
-        g_cls = ce(classifier(x_cf), target_y)                                                # :301-302
-        am = abs_mean(masked_residual)                                                        # :305  mean_b ||.||_1 = D * mean|.|
+        if g_cls is None:
+            g_cls = ce(classifier(x_cf), target_y)                                            # :301-302
+        if am is None:
+            am = abs_mean(masked_residual)                                                    # :305  mean_b ||.||_1 = D * mean|.|
+        else:
+            am.record_stream(torch.cuda.current_stream()); mask_penalty_pre.record_stream(torch.cuda.current_stream())
         d_feat = float(x.shape[1])
         g_loss = weighted_sum([m_fake, g_cls, am, mask_penalty_pre],
                               [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]])   # :299, :307-312
-        with torch.no_grad():                                                                 # logged values
-            g_adv = weighted_sum([m_fake], [-1.0])
-            g_reg = weighted_sum([am], [d_feat])
-        opt_g.zero_grad()
+        if branch is None:
+            with torch.no_grad():                                                             # logged values
+                g_adv = weighted_sum([m_fake], [-1.0])
+                g_reg = weighted_sum([am], [d_feat])
+            opt_g.zero_grad()
+        else:                                                                                 # logged values: beside the backward sweep
+            branch.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(branch), torch.no_grad():
+                g_adv = weighted_sum([m_fake], [-1.0])
+                g_reg = weighted_sum([am], [d_feat])
+            m_fake.record_stream(branch)
         g_loss.backward()                                                                     # :314-315
     finally:
         if skip_dead_d_wgrad:
             for p in discriminator.parameters():
                 p.requires_grad_(True)
     opt_g.step()                                                                              # :316
+    if branch is not None:
+        torch.cuda.current_stream().wait_stream(branch)                                       # final join (the logged values)
+        g_adv.record_stream(torch.cuda.current_stream()); g_reg.record_stream(torch.cuda.current_stream())
     return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
             "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
 
@@ -825,8 +898,9 @@ class GraphedTrainStep:
     Capture needs warm-up executions of real steps; the parameters, buffers and optimizer state are snapshotted before and
     restored after, so constructing this object does not advance training."""
 
-    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3):
+    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap=True):
         dev = norm_vals.device
+        self.branch = torch.cuda.Stream(device=dev) if overlap else None      # the classifier branch (train_step `branch`)
         D_in, T = config["input_dim"], generator.total_cat
         self.x = torch.zeros((batch, D_in), dtype=torch.float32, device=dev)
         self.y = torch.zeros((batch,), dtype=torch.int64, device=dev)
@@ -841,7 +915,7 @@ class GraphedTrainStep:
 
         def step():
             return train_step(generator, discriminator, classifier, opt_g, opt_d, self.x, self.y, self.target_y, self.mask, norm_vals,
-                              config, gumbel=self.noise)
+                              config, gumbel=self.noise, branch=self.branch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -962,16 +1036,18 @@ def train_classifier(X_train_all, X_test, y_train_all, y_test, scaler, config, d
     return model
 
 
-def draw_batch_randoms(rng, generator, y, config, device):
-    """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise)."""
+def draw_batch_randoms(rng, generator, y, config, device, out=None):
+    """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise).
+    out = (target_y, mask, noise): draw straight into these buffers (the static inputs of a GraphedTrainStep)."""
     B = y.shape[0]
-    target_y = rng.randint(0, config["num_classes"], B, device, exclude=y)
+    o_t, o_m, o_n = out if out is not None else (None, None, None)
+    target_y = rng.randint(0, config["num_classes"], B, device, exclude=y, out=o_t)
     imm = getattr(generator, "_imm_dev", None)
     if imm is None or imm.device != device:
         imm = torch.tensor(list(config.get("immutable_idx", [])), dtype=torch.int32, device=device)
         generator._imm_dev = imm
-    mask = rng.feature_mask(B, config["input_dim"], device, imm if imm.numel() else None)
-    return target_y, mask, rng.gumbel((B, generator.total_cat), device)
+    mask = rng.feature_mask(B, config["input_dim"], device, imm if imm.numel() else None, out=o_m)
+    return target_y, mask, rng.gumbel((B, generator.total_cat), device, out=o_n)
 
 
 def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):

@@ -853,8 +853,8 @@ class DeviceRNG:
               "pcg_patch_mask")
         return out
 
-    def randint(self, low, high, n, device, exclude=None):
-        out = torch.empty((n,), dtype=torch.int64, device=device)
+    def randint(self, low, high, n, device, exclude=None, out=None):
+        out = out if out is not None else torch.empty((n,), dtype=torch.int64, device=device)
         check(_lib.load().pcg_randint(_p(out), n, low, high, _p(exclude), self.seed, self._advance((n + 3) // 4), _stream()),
               "pcg_randint")
         return out
@@ -865,17 +865,17 @@ class DeviceRNG:
         check(_lib.load().pcg_randn(_p(out), n, mean, std, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_randn")
         return out
 
-    def gumbel(self, shape, device):
+    def gumbel(self, shape, device, out=None):
         """Gumbel(0,1) noise, the draw F.gumbel_softmax makes (house_sales_kc_usa/models/generator.py:90)."""
-        out = torch.empty(shape, dtype=torch.float32, device=device)
+        out = out if out is not None else torch.empty(shape, dtype=torch.float32, device=device)
         n = out.numel()
         check(_lib.load().pcg_rand_gumbel(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_gumbel")
         return out
 
-    def feature_mask(self, B, D, device, zero_cols=None):
+    def feature_mask(self, B, D, device, zero_cols=None, out=None):
         """Bernoulli(1/2) modifiable-feature mask with immutable columns zeroed (house_sales_kc_usa/trainer.py:253-255);
         zero_cols: int32 device tensor."""
-        out = torch.empty((B, D), dtype=torch.float32, device=device)
+        out = out if out is not None else torch.empty((B, D), dtype=torch.float32, device=device)
         nz = 0 if zero_cols is None else zero_cols.numel()
         check(_lib.load().pcg_feature_mask(_p(out), B, D, _p(zero_cols), nz, self.seed, self._advance((B * D + 3) // 4), _stream()),
               "pcg_feature_mask")

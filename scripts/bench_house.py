@@ -23,6 +23,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: single-stream graph (no parallel classifier branch)")
     BL.add_common_args(ap, steps=200, warmup=20)
     args = ap.parse_args()
     if args.gpus != 1:
@@ -39,13 +40,12 @@ def main():
     y = rng.randint(0, H.CONFIG["num_classes"], B, dev)
     t, mask, noise = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
 
-    def draws():
-        t2, m2, n2 = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
-        t.copy_(t2); mask.copy_(m2); noise.copy_(n2)
+    def draws():                      # straight into the step's (static) input buffers
+        H.draw_batch_randoms(rng, G, y, H.CONFIG, dev, out=(t, mask, noise))
 
     gs = None
     if not args.eager:
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B)
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap=not args.no_overlap)
         gs.x.copy_(x); gs.y.copy_(y)
         t, mask, noise = gs.target_y, gs.mask, gs.noise
 
@@ -102,7 +102,8 @@ def main():
                                f"Discriminator, frozen NNClassifier), 17 features, batch {B}, full step incl. per-step device draws",
                    "global_batch": B, "parallelism": "dp1"},
         "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
-        "launch": "eager" if gs is None else "hip-graph replay (1 graph) + 3 RNG launches per step",
+        "launch": "eager" if gs is None else ("hip-graph replay (1 graph" + (", classifier branch parallel to the critic update" if gs.branch is not None else "")
+                                            + ") + 3 RNG launches per step drawing into its input buffers"),
     })
     R.finish()
 
