@@ -414,6 +414,18 @@ class _MaskMulFn(torch.autograd.Function):
         return ops.scale_mask_bwd(None, dsum, ctx.mask, 1.0, like=ctx.mask), None, None
 
 
+_ones_cache = {}
+
+
+def _one(device):
+    """A cached scalar 1.0 on the device: `loss.backward(gradient=_one(dev))` spares autograd its ones_like fill launch."""
+    t = _ones_cache.get(device)
+    if t is None:
+        t = ops.fill(torch.empty((), dtype=torch.float32, device=device), 1.0)
+        _ones_cache[device] = t
+    return t
+
+
 class _InjectGradFn(torch.autograd.Function):
     """y = x; in backward: dx = dy + g.  Carries a gradient contribution that was computed ahead of time (the frozen classifier's
     d(lambda_cls * CE)/d(x_cf), evaluated on the parallel branch of train_step) into autograd's sweep: one fused add instead of
@@ -781,7 +793,7 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
         opt_d.zero_grad()
     else:                            # the zero fills were issued on the branch: the backward passes must see them
         torch.cuda.current_stream().wait_event(zeroed)
-    d_loss.backward()
+    d_loss.backward(gradient=_one(x.device))
     opt_d.step()                                                                              # :293-295
     # ---- G step
     if skip_dead_d_wgrad:            # the reference computes D's weight gradients here and never uses them (next zero_grad)
@@ -816,7 +828,7 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
                 g_adv = weighted_sum([m_fake], [-1.0])
                 g_reg = weighted_sum([am], [d_feat])
             m_fake.record_stream(branch)
-        g_loss.backward()                                                                     # :314-315
+        g_loss.backward(gradient=_one(x.device))                                              # :314-315
     finally:
         if skip_dead_d_wgrad:
             for p in discriminator.parameters():
