@@ -41,9 +41,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 
 def pmc_traffic():
     """HBM bytes per launch of the implicit-GEMM family from the committed rocprofv3 --pmc summary (FETCH_SIZE doubled
-    + WRITE_SIZE, collected in separate passes: profiles/r01_pmc_traffic.json), or None."""
+    + WRITE_SIZE, collected in separate passes: profiles/r02_pmc_traffic.json), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -292,7 +292,7 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
             "kernel": "fp32-MFMA implicit-GEMM conv family (igemm_mainloop: conv_fwd/dgrad/wgrad_kernel); wgrad spans include slab_reduce",
             "step_frac": round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "gemm_time_share": round(tot_t / (elapsed * len(sampled) / args.steps), 4),

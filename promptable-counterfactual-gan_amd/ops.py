@@ -109,13 +109,23 @@ def workspace2(nbytes, device):
     return _scratch(2, nbytes, device)
 
 
+_ticket_pool = {}
+
+
 def _ticket_buffer(device):
-    """Zero-initialised ticket counters of the linear weight-gradient kernels (they leave them zero), one set per stream."""
+    """Zero-initialised ticket counters of the linear weight-gradient kernels (they leave them zero), one set per stream.
+    New sets come from a small pool zeroed OUTSIDE any graph capture: a `torch.zeros` issued while a stream is capturing would
+    become a fill node that replays with every launch of the graph."""
     stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
     key = (device.type, device.index, stream, "tickets")
     tk = _ws_cache.get(key)
     if tk is None:
-        tk = torch.zeros(_lib.load().pcg_linear_wgrad_ticket_count(), dtype=torch.int32, device=device)   # setup: zeroed once
+        n = _lib.load().pcg_linear_wgrad_ticket_count()
+        pool = _ticket_pool.setdefault((device.type, device.index), [])
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not pool and not capturing:
+            pool.extend(torch.zeros((8, n), dtype=torch.int32, device=device).unbind(0))                  # setup: zeroed once
+        tk = pool.pop() if pool else torch.zeros(n, dtype=torch.int32, device=device)
         _ws_cache[key] = tk
     return tk
 

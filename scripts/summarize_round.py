@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Turn the output of scripts/collect_profiles.sh (gpurun_out/prof_<tag>/) into the tracked summaries under profiles/:
+
+  python scripts/summarize_round.py r02
+writes  <tag>_kernel_stats.md (DCGAN bench), <tag>_{countergan,wgan,house}_kernel_stats.md, <tag>_pmc_traffic.json,
+        <tag>_house_launches.json, <tag>_rocprofv3_kernel_stats.csv (raw, DCGAN) and copies the JSON lines (<tag>_*_line.json).
+FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide coalesced reads: doubled here, as MI355X_MICROARCH.md prescribes;
+WRITE_SIZE is exact.  Both are reported by rocprofv3 in KiB."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("pcg::(anonymous namespace)::", "").replace("void ", "")
+    for a, b in (("pcg::TileCfg<128, 128, 2, 2>", "128x128"), ("pcg::TileCfg<128, 64, 2, 2>", "128x64"), ("pcg::TileCfg<64, 128, 1, 4>", "64x128")):
+        name = name.replace(a, b)
+    return name.split("(")[0]
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def stats_md(sub, dest, title, steps):
+    path = find(sub, "*kernel_stats.csv")
+    if not path:
+        print("missing", sub)
+        return
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    calls = sum(int(r["Calls"]) for r in rows)
+    with open(os.path.join(out, dest), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {title}, round {tag}\n\n")
+        f.write(f"{steps} executed steps in the trace (capture warm-up + warm-up + timed; kernels inside a replayed HIP graph are traced like any other).\n\n")
+        f.write("| kernel | launches/step | avg µs | ms/step | % of GPU time |\n|---|---|---|---|---|\n")
+        for r in rows:
+            t = float(r["TotalDurationNs"])
+            if t / tot < 0.0005:
+                continue
+            f.write(f"| `{short(r['Name'])}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {t / 1e6 / steps:.3f} | {100 * t / tot:.1f} |\n")
+        f.write(f"\nGPU busy time: {tot / 1e6 / steps:.3f} ms/step, {calls / steps:.1f} launches/step\n")
+    return path, tot, calls
+
+
+r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline (DCGAN 64x64, batch 512)", 16)
+if r:
+    shutil.copy(r[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
+stats_md("countergan", f"{tag}_countergan_kernel_stats.md", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 (batch 1024)", 10)
+stats_md("wgan", f"{tag}_wgan_kernel_stats.md", "python3 scripts/bench_wgan.py --steps 10 --warmup 2 (12 critic updates + 12 generator updates; per-launch averages)", 24)
+
+# house: launches per step = dispatches between two consecutive randint_kernel launches in the steady state
+trace = find("house", "*kernel_trace.csv")
+if trace:
+    rows = sorted(csv.DictReader(open(trace)), key=lambda r_: int(r_["Start_Timestamp"]))
+    marks = [i for i, r_ in enumerate(rows) if "randint_kernel" in r_["Kernel_Name"]]
+    if len(marks) > 12:
+        a, b = marks[-11], marks[-1]
+        lps = (b - a) / 10.0
+        period = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 10.0 / 1e3
+        busy = sum(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]) for r_ in rows[a:b]) / 10.0 / 1e3
+        nat = sum(1 for r_ in rows[a:b] if "at::native" in r_["Kernel_Name"]) / 10.0
+        queues = sorted({r_["Queue_Id"] for r_ in rows[a:b]})
+        json.dump({"launches_per_step": lps, "step_period_us_under_profiler": period, "sum_of_kernel_durations_us": busy,
+                   "aten_kernels_per_step": nat, "hw_queues_used": len(queues),
+                   "how": "dispatches between consecutive randint_kernel launches (one per step), mean of the last 10 steps of "
+                          "rocprofv3 --kernel-trace -- python3 scripts/bench_house.py --steps 50 --warmup 10"},
+                  open(os.path.join(out, f"{tag}_house_launches.json"), "w"), indent=1)
+    stats_md("house", f"{tag}_house_kernel_stats.md", "python3 scripts/bench_house.py --steps 50 --warmup 10 (batch 4096, HIP-graph replay with the parallel classifier branch)", 63)
+
+# PMC traffic
+fe_p, wr_p = find("pmc_fetch", "*counter_collection.csv"), find("pmc_write", "*counter_collection.csv")
+if fe_p and wr_p:
+    def agg(path, counter):
+        d = collections.defaultdict(lambda: [0, 0.0])
+        for r_ in csv.DictReader(open(path)):
+            if r_["Counter_Name"] == counter:
+                k = short(r_["Kernel_Name"])
+                d[k][0] += 1
+                d[k][1] += float(r_["Counter_Value"])
+        return d
+    fe, wr = agg(fe_p, "FETCH_SIZE"), agg(wr_p, "WRITE_SIZE")
+    res = {}
+    for k in fe:
+        n = fe[k][0]
+        res[k] = {"launches": n, "fetch_bytes_per_launch": 2 * 1024 * fe[k][1] / n,
+                  "write_bytes_per_launch": 1024 * wr.get(k, [1, 0.0])[1] / max(wr.get(k, [1, 0.0])[0], 1)}
+    fam = [k for k in res if k.startswith("conv_")]
+    n = sum(res[k]["launches"] for k in fam)
+    res["_igemm_family"] = {
+        "launches": n,
+        "hbm_bytes_per_launch": sum(res[k]["launches"] * (res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]) for k in fam) / n,
+        "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes for FETCH_SIZE and WRITE_SIZE; bench.py --steps 2 --warmup 1"}
+    json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+
+for name in ("bench_line", "bench_line_dp1", "countergan_line", "wgan_line", "house_line"):
+    p = os.path.join(src, name + ".json")
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            open(os.path.join(out, f"{tag}_{name}.json"), "w").write(lines[-1])
+print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag)))
