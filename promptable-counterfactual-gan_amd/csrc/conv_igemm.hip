@@ -137,6 +137,40 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   });
 }
 
+// 64x192 tile of the weight gradient (Cout <= 64, N = KH*KW*Cin a multiple of 192): the same pipeline with the 192-column B loader
+using Cfg64x192 = TileCfg<64, 192, 2, 2>;
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad192_kernel(ConvP p, int ktiles_total, int ktiles_per_split, int tiles,
+                                                                      int slice_major) {
+  using Cfg = Cfg64x192;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint32_t tile, split;
+  if (slice_major) {
+    const uint32_t l = xcd_remap(blockIdx.x, gridDim.x);
+    split = l / (uint32_t)tiles; tile = l - split * (uint32_t)tiles;
+  } else {
+    tile = xcd_remap(blockIdx.x, gridDim.x); split = blockIdx.y;
+  }
+  const int mt = tile / p.tilesN, nt = tile % p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  const int kt_begin = split * ktiles_per_split;
+  int ktiles = ktiles_total - kt_begin;
+  if (ktiles > ktiles_per_split) ktiles = ktiles_per_split;
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    WgradALoader<Cfg::BM, false> la(p, m_block, kt_begin, tid);
+    WgradBLoader192 lb(p, n_block, kt_begin, tid);
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    return;
+  }
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_consume<Cfg, false, false>(ktiles, acc, smem);
+  float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
+  igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
+    const int m = m_block + row;
+    return m < p.M ? slab + (size_t)m * p.N + n_block : nullptr;
+  });
+}
+
 // col2im for the "one GEMM + scatter" form of the grad-input (see dgrad_as_gemm): dx[b,ih,iw,ci] = bias[ci] + sum over the taps
 // (kh,kw) that reach (ih,iw) of dcol[b,oh,ow][(kh,kw,ci)], taps added in (kh,kw) order.  Every dcol element is read once.
 __global__ void __launch_bounds__(256) col2im_kernel(const float4* __restrict__ dcol, float4* __restrict__ dx, const float* __restrict__ bias,
@@ -299,14 +333,17 @@ int launch_dgrad(const ConvP& p, const DgradPhases& ph, int nphases, int maxMp, 
   return p.in_sc ? launch_dgrad_x<Cfg, true>(p, ph, nphases, maxMp, s) : launch_dgrad_x<Cfg, false>(p, ph, nphases, maxMp, s);
 }
 
-struct WgradPlan { int splits, ktiles_total, ktiles_per_split, tiles; bool narrow; };
+struct WgradPlan { int splits, ktiles_total, ktiles_per_split, tiles; bool narrow, wide192; };
 
 WgradPlan plan_wgrad(const pcg_conv_geom* g) {
   WgradPlan w{};
   const int M = g->Cout, N = g->KH * g->KW * g->Cin;
   w.narrow = (M <= 64);
+  static const int t192_env = getenv("PCG_WGRAD_192") ? atoi(getenv("PCG_WGRAD_192")) : 1;   // A/B switch
+  // 64x192 tile: N = 576 (3x3, 64 channels) is 4.5 tiles of 128 columns — the fifth one is half empty, 11 % of the MFMAs
+  w.wide192 = w.narrow && t192_env && N % 192 == 0 && (N % 128) != 0;
   const int BM = w.narrow ? 64 : 128;
-  w.tiles = ceil_div(M, BM) * ceil_div(N, 128);
+  w.tiles = ceil_div(M, BM) * (w.wide192 ? N / 192 : ceil_div(N, 128));
   const int64_t K = (int64_t)g->B * g->OH * g->OW;
   w.ktiles_total = (int)ceil_div64(K, IG_BK);
   // fill the 512 block slots (2 per CU) in ONE round — 515 blocks would run as 512 + a second round of 3 — but keep
@@ -323,7 +360,7 @@ WgradPlan plan_wgrad(const pcg_conv_geom* g) {
     const int kps = ceil_div(w.ktiles_total, s), se = ceil_div(w.ktiles_total, kps);
     const int n = ceil_div(w.tiles * se, 256);
     *s_eff = se;
-    return (double)n * kps * (w.narrow ? 1.0 : 1.95) * (n == 1 ? 1.2 : 1.0) + (double)se * M * N * 8.0 / 4.0e6;
+    return (double)n * kps * (w.wide192 ? 1.5 : w.narrow ? 1.0 : 1.95) * (n == 1 ? 1.2 : 1.0) + (double)se * M * N * 8.0 / 4.0e6;
   };
   int se = 0;
   const double c0 = cost(splits, &se);
@@ -688,7 +725,23 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   static const int order_env = getenv("PCG_WGRAD_ORDER") ? atoi(getenv("PCG_WGRAD_ORDER")) : -1;   // A/B switch: 0 tile-major, 1 slice-major
   const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
   const int side = hx ? 1 : hy ? 2 : 0;
-  const int rc = wp.narrow ? launch_wgrad<TileCfg<64, 128, 1, 4>>(p, wp, slice_major, side, s) : launch_wgrad<Cfg128x128>(p, wp, slice_major, side, s);
+  int rc;
+  if (wp.wide192 && side == 0) {
+    p.tilesN = p.N / 192;
+    constexpr size_t smem = smem_bytes<Cfg64x192, false, false>();
+    static int once = set_smem(conv_wgrad192_kernel, smem);
+    if (once != PCG_OK) return once;
+    hipLaunchKernelGGL(conv_wgrad192_kernel, slice_major ? dim3((unsigned)wp.tiles * wp.splits) : dim3((unsigned)wp.tiles, wp.splits),
+                       dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
+    rc = launch_status("conv_wgrad192_kernel");
+  } else {
+    WgradPlan wq = wp;
+    if (wp.wide192) {     // an input transform is pending on an operand: the 128-column tiles carry it (re-plan without the 192 tile)
+      wq.wide192 = false;
+      wq.tiles = ceil_div(p.M, 64) * ceil_div(p.N, 128);
+    }
+    rc = wq.narrow ? launch_wgrad<TileCfg<64, 128, 1, 4>>(p, wq, slice_major, side, s) : launch_wgrad<Cfg128x128>(p, wq, slice_major, side, s);
+  }
   if (rc != PCG_OK) return rc;
   const size_t n = (size_t)p.M * p.N;
   return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s);

@@ -394,4 +394,51 @@ struct WgradBLoader {
   }
 };
 
+// 192-column variant (the 64x192 weight-gradient tile: N = KH*KW*Cin = 576 = 3 x 192 for the 3x3 64-channel layers, where 128-column
+// tiles leave the fifth tile half empty): three 64-column sub-images, see LdsImage.  A thread owns one column quad per sub-image
+// (three (tap, ci) pairs) and two k-rows (pixels) per k-tile, whose pixel decomposition is shared by the sub-images.
+struct WgradBLoader192 {
+  static constexpr bool KMAJOR = false, XFORM = false;
+  static constexpr int ROWS = 192, NV = 6;
+  rsrc_t rs;
+  int IH, IW, Cin, stride, K, q0, dh[3], dw[3], ci[3];
+  bool nok[3];
+  FastDiv dOW, dOH;
+
+  __device__ __forceinline__ WgradBLoader192(const ConvP& p, int n_block, int kt_begin, int tid) {
+    rs = make_rsrc(p.x, p.x_bytes);
+    IH = p.IH; IW = p.IW; Cin = p.Cin; stride = p.stride; K = p.B * p.OH * p.OW;
+    dOW = p.dOW; dOH = p.dOH;
+    const int c4 = tid & 15;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int n = n_block + 64 * s + 4 * c4;
+      nok[s] = n < p.N;
+      const int tap = nok[s] ? n / Cin : 0;
+      ci[s] = nok[s] ? n - tap * Cin : 0;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      dh[s] = kh - p.pad; dw[s] = kw - p.pad;
+    }
+    q0 = kt_begin * IG_BK + (tid >> 4);
+  }
+  __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + 16 * h;
+      uint32_t t, ow, b, oh;
+      dOW.divmod((uint32_t)q, t, ow);
+      dOH.divmod(t, b, oh);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ih = (int)oh * stride + dh[s], iw = (int)ow * stride + dw[s];
+        const bool ok = nok[s] && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+        const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci[s]) * 4);
+        v[2 * s + h] = buf_load4(rs, ok ? off : OOB_OFF);
+      }
+    }
+    q0 += IG_BK;
+  }
+  __device__ __forceinline__ void transform(float4 (&)[NV]) {}
+};
+
 }  // namespace pcg

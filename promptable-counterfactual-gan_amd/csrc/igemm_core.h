@@ -64,13 +64,23 @@ struct LdsImage {
 #pragma unroll
       for (int p = 0; p < NV; ++p)
         *reinterpret_cast<float4*>(lds + (r0 + 32 * p) * IG_LDK + 4 * kq) = v[p];
-    } else {
+    } else if constexpr (IG_LOADERS % (ROWS / 4) == 0) {
       constexpr int C4 = ROWS / 4;          // float4 per k-row
       constexpr int KR = IG_LOADERS / C4;   // k-rows per pass
       const int c4 = tid % C4, kr0 = tid / C4;
 #pragma unroll
       for (int p = 0; p < NV; ++p)
         *reinterpret_cast<float4*>(lds + (kr0 + KR * p) * LDM + 4 * c4) = v[p];
+    } else {
+      // ROWS = 192 (48 float4 per k-row do not divide the 256 loader threads): three 64-column sub-images side by side, each
+      // loaded like a 64-row image (16 float4 per k-row, 16 k-rows per pass, 2 passes); v[2*s + h] = sub-image s, k-rows 16h..16h+15
+      static_assert(ROWS % 64 == 0, "MN-major image: ROWS must divide the loader threads or be a multiple of 64");
+      const int c4 = tid & 15, kr0 = tid >> 4;
+#pragma unroll
+      for (int s = 0; s < ROWS / 64; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<float4*>(lds + (kr0 + 16 * h) * LDM + 64 * s + 4 * c4) = v[2 * s + h];
     }
   }
   // fragment for MFMA tile rows [row0, row0+32), k-group ks (8 k's): f[t] = T[row0+i][8ks+4h+t]
@@ -270,7 +280,8 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
                                                  float slope = 0.f, const EpiAux* epi = nullptr) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
-  constexpr int RPI = 64 / Q;              // rows per store instruction
+  constexpr int RPI = 64 / Q;              // rows per store instruction (Q = 24, the 64x192 tile: 2 rows, lanes 48..63 idle)
+  static_assert(Cfg::WTM % RPI == 0, "wave tile rows must be a multiple of the rows stored per instruction");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
   float* reg = smem + wave * (Cfg::WTM * LDW);
@@ -283,7 +294,7 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int cq = lane % Q, r0 = lane / Q;
   const int n = n_block + wn * Cfg::WTN + 4 * cq;
-  const bool nok = n < N;  // N % 4 == 0: a quad is entirely inside or outside
+  const bool nok = n < N && r0 < RPI;  // N % 4 == 0: a quad is entirely inside or outside; r0 >= RPI: surplus lanes (Q not a power of two)
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && nok) bv = *reinterpret_cast<const float4*>(bias + n);
   // column sums for the fused BatchNorm statistics / BatchNorm-backward sums: accumulated in fp64 (the reference's CPU path sums
