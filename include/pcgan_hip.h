@@ -216,6 +216,21 @@ int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C,
                        const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
                        int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
+/* The same two backward calls, additionally returning the column sums of the dx they write: dcol[c] (+)= sum_rows dx[row][c] — the
+ * bias gradient of the convolution in front of this BatchNorm (models/generator.py:11-14: Conv2d(bias=True) -> BatchNorm2d; the sum is
+ * analytically zero, the reference computes its rounding residue, so it is computed) taken while dx streams out of the apply pass
+ * instead of by a separate pcg_colsum pass over it (fp64 per thread, fixed-order block sums, fixed-order finalize).
+ * y == NULL with ReLU / LeakyReLU and beta given: the mask is recomputed (as pcg_bn_act_bwd_premask). */
+size_t pcg_bn_db_workspace_bytes(int64_t rows, int32_t C);
+int pcg_bn_act_bwd_db(const float* dy, const float* x, const float* y /*nullable*/, int64_t rows, int32_t C, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta /*nullable*/, int act, float slope, float dy_scale,
+                      float* dx, float* dgamma, float* dbeta, int accumulate, float* dcol, int accumulate_col, void* workspace,
+                      size_t workspace_bytes, pcg_stream_t stream);
+size_t pcg_bn_bwd_partial_db_workspace_bytes(int32_t C);
+int pcg_bn_bwd_partial_db(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                          const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                          int accumulate, float* dcol, int accumulate_col, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */
 int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream);

@@ -55,12 +55,13 @@ def _conv_fwd(conv, a, act=ACT_NONE, slope=0.0):
     return g, z
 
 
-def _conv_wgrad(net, conv, g, a, dz, need_p=True):
-    """Accumulate weight/bias gradients into net's flat buffer."""
+def _conv_wgrad(net, conv, g, a, dz, need_p=True, bias_done=False):
+    """Accumulate weight/bias gradients into net's flat buffer (bias_done: the bias gradient already came out of the BatchNorm
+    backward's apply pass — ops.bn_act_bwd / bn_bwd_partial with dcol=)."""
     if need_p and conv.weight.requires_grad:
         gw, acc = net._grad_view(conv.weight)
         ops.conv2d_wgrad(g, a, dz, ops.ohwi(gw), acc)
-        if conv.bias is not None:
+        if conv.bias is not None and not bias_done:
             gb, accb = net._grad_view(conv.bias)
             ops.colsum(dz.numel() // conv.out_channels, conv.out_channels, dz, gb, accb)
 
@@ -80,6 +81,7 @@ def _dgrad_act(g, dz, w, a_below, act, slope):
     return ops.act_bwd(d, a_below.view(d.shape), act, slope, out=d)
 
 
+FUSE_BIAS_COLSUM = True         # A/B switch: conv-bias gradients in front of a BatchNorm out of the BatchNorm backward's apply pass
 FUSE_BACKWARD_EPILOGUE = True   # A/B switch for the tests: activation derivative / BatchNorm-backward sums / skip-connection add in
                                 # the grad-input kernel's epilogue (ops.conv_bwd_data_fused, conv2d_dgrad_add) vs separate passes
 
@@ -302,18 +304,24 @@ class ResidualGenerator(FlatModule):
             C = blk.bn2.num_features
             dg2, acc = self._grad_view(blk.bn2.weight)
             db2, _ = self._grad_view(blk.bn2.bias)
-            dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1)
-            _conv_wgrad(self, blk.conv2, g2, a1, dz2)
+            # the conv biases in front of the BatchNorms: their gradient is the column sum of dz, taken in the apply pass
+            cb2, accb2 = self._grad_view(blk.conv2.bias) if (blk.conv2.bias is not None and FUSE_BIAS_COLSUM) else (None, False)
+            dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1,
+                                 dcol=cb2, accumulate_col=accb2)
+            _conv_wgrad(self, blk.conv2, g2, a1, dz2, bias_done=cb2 is not None)
             dg1, acc = self._grad_view(blk.bn1.weight)
             db1, _ = self._grad_view(blk.bn1.bias)
             res = (ops.conv_bwd_data_fused(g2, dz2, ops.ohwi(blk.conv2.weight.data), False, ACT_LRELU, slope, z_below=z1,
                                            bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data)) if FUSE_BACKWARD_EPILOGUE else None)
+            cb1, accb1 = self._grad_view(blk.conv1.bias) if (blk.conv1.bias is not None and FUSE_BIAS_COLSUM) else (None, False)
             if res is not None:      # LeakyReLU mask + BatchNorm-backward column sums came out of conv2's grad-input epilogue
-                dz1 = ops.bn_bwd_partial(res[0], z1, C, m1, s1, blk.bn1.weight.data, res[1], res[2], dg1, db1, acc, out=res[0])
+                dz1 = ops.bn_bwd_partial(res[0], z1, C, m1, s1, blk.bn1.weight.data, res[1], res[2], dg1, db1, acc, out=res[0],
+                                         dcol=cb1, accumulate_col=accb1)
             else:
                 da1 = ops.conv2d_dgrad(g2, dz2, ops.ohwi(blk.conv2.weight.data))
-                dz1 = ops.bn_act_bwd(da1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc, beta=blk.bn1.bias.data)
-            _conv_wgrad(self, blk.conv1, g1, h, dz1)
+                dz1 = ops.bn_act_bwd(da1, z1, None, C, m1, s1, blk.bn1.weight.data, ACT_LRELU, slope, dg1, db1, acc, beta=blk.bn1.bias.data,
+                                     dcol=cb1, accumulate_col=accb1)
+            _conv_wgrad(self, blk.conv1, g1, h, dz1, bias_done=cb1 is not None)
             if FUSE_BACKWARD_EPILOGUE:   # skip path + block path: the add happens in conv1's grad-input epilogue, in place
                 dh = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh)
             else:

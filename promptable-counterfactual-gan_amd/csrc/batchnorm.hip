@@ -411,10 +411,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, int act, float slope,
                                                                 float dy_scale, float4* __restrict__ dx, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta) {
+                                                                const float* __restrict__ beta, double* __restrict__ colpart) {
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
   float mu[4], is[4], k0[4], k1[4], k2[4], msc[4], msh[4];
+  // colpart != nullptr: also the column sums of the dx written here — the bias gradient of the convolution in front of this
+  // BatchNorm (analytically zero, numerically rounding residue: the reference computes it, so it is computed) without a
+  // separate pass over dx.  fp64 per thread (a thread's channel quad is fixed), fixed-order block sum, one partial row per block.
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
   const bool premask = act != PCG_ACT_NONE && y == nullptr;     // mask from the recomputed BatchNorm output: y is not read
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -436,14 +440,36 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
     return make_float4(gg[0], gg[1], gg[2], gg[3]);
   };
   const float4 ones = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto tally = [&](const float4& v) { cs[0] += (double)v.x; cs[1] += (double)v.y; cs[2] += (double)v.z; cs[3] += (double)v.w; };
   size_t i = gtid;
   for (; i + stride < n4; i += 2 * stride) {
     const float4 g0 = dy[i], g1 = dy[i + stride], x0 = x[i], x1 = x[i + stride];
     const float4 y0 = (has_act && !premask) ? y[i] : ones, y1 = (has_act && !premask) ? y[i + stride] : ones;
-    dx[i] = one(g0, x0, y0);
-    dx[i + stride] = one(g1, x1, y1);
+    const float4 o0 = one(g0, x0, y0), o1 = one(g1, x1, y1);
+    dx[i] = o0;
+    dx[i + stride] = o1;
+    if (colpart) { tally(o0); tally(o1); }
   }
-  if (i < n4) dx[i] = one(dy[i], x[i], (has_act && !premask) ? y[i] : ones);
+  if (i < n4) {
+    const float4 o = one(dy[i], x[i], (has_act && !premask) ? y[i] : ones);
+    dx[i] = o;
+    if (colpart) tally(o);
+  }
+  if (colpart) {   // kernel-uniform
+    __shared__ double red[4][256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[e][threadIdx.x] = cs[e];
+    __syncthreads();
+    const int nq = C >> 2;                    // threads q, q + nq, q + 2 nq, ... of a block own channel quad q (256 % nq == 0)
+    if ((int)threadIdx.x < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double sum = 0.0;
+        for (int t = threadIdx.x; t < 256; t += nq) sum += red[e][t];
+        colpart[(size_t)blockIdx.x * C + 4 * threadIdx.x + e] = sum;
+      }
+    }
+  }
 }
 
 bool fast_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
@@ -571,9 +597,13 @@ extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const f
   return launch_status("bn_apply_act_kernel");
 }
 
+constexpr int COL_MAX_BLOCKS = 4096;   // grid cap of the fast apply kernels = partial rows of their fused column sums
+static size_t colpart_bytes(int32_t C) { return (size_t)COL_MAX_BLOCKS * C * sizeof(double); }
+
 static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
                            const float* invstd, const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx,
-                           float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+                           float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream,
+                           float* dcol = nullptr, int accumulate_col = 0) {
   PCG_REQUIRE(dy && x && mean && invstd && dx && rows > 0 && C > 0, "pcg_bn_act_bwd: bad arguments");
   PCG_REQUIRE(y || act == PCG_ACT_NONE || (gamma && beta && (act == PCG_ACT_RELU || act == PCG_ACT_LRELU)),
               "pcg_bn_act_bwd: without y the activation must be ReLU / LeakyReLU and gamma, beta must be given");
@@ -587,6 +617,10 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   double* partial = (double*)workspace;
   double* scratch = partial + (size_t)cp.nblocks * 2 * C;
   float* coef = reinterpret_cast<float*>(scratch + 4 * (size_t)C);
+  // fused column sums of dx: partial rows behind everything else (only when the caller sized the workspace for them)
+  double* colpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + ((pcg_bn_workspace_bytes(rows, C) + 7) & ~(size_t)7));
+  PCG_REQUIRE(!dcol || workspace_bytes >= ((pcg_bn_workspace_bytes(rows, C) + 7) & ~(size_t)7) + colpart_bytes(C),
+              "pcg_bn_act_bwd_db: workspace smaller than pcg_bn_db_workspace_bytes");
   FnBnBwd fn{dy, x, y, mean, invstd, act, slope, dy_scale, gamma, beta};
   if (int e = launch_colreduce(fn, rows, C, cp, partial, s)) return e;
   const double* src = partial;
@@ -602,20 +636,36 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
                      1.0 / (double)rows_all, gamma, invstd, coef, dgamma, dbeta, accumulate, local);
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const size_t n = (size_t)rows * C;
+  const bool fused_col = dcol != nullptr;
   if (fast_channels(C) && aligned) {
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > COL_MAX_BLOCKS) blocks = COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
-                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx), gamma, beta);
+                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx), gamma, beta, fused_col ? colpart : nullptr);
+    if (fused_col) {
+      if (int e = launch_status("bn_bwd_apply_kernel")) return e;
+      hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads((int)blocks)), 0, s, (const double*)colpart,
+                         (int)blocks, C, dcol, accumulate_col);
+      return launch_status("colsum_finalize_kernel");
+    }
   } else if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
                        (const float*)coef, act, slope, dy_scale, dx, gamma, beta);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dy, x, y, n, C, mean, invstd,
                        (const float*)coef, act, slope, dy_scale, dx, gamma, beta);
-  return launch_status("bn_bwd_apply_kernel");
+  if (int e = launch_status("bn_bwd_apply_kernel")) return e;
+  if (dcol) {   // generic shapes: the separate reduction over the dx just written (the partial rows are free again)
+    const ColPlan cq = plan_cols(rows, C, al16(dx));
+    FnSum fs{dx};
+    if (int e = launch_colreduce(fs, rows, C, cq, partial, s)) return e;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cq.nblocks)), 0, s, (const double*)partial, cq.nblocks, C,
+                       dcol, accumulate_col);
+    return launch_status("colsum_finalize_kernel");
+  }
+  return PCG_OK;
 }
 
 extern "C" int pcg_bn_act_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
@@ -636,11 +686,17 @@ extern "C" int pcg_bn_act_bwd_premask(const float* dy, const float* x, int64_t r
 }
 
 extern "C" size_t pcg_bn_bwd_partial_workspace_bytes(int32_t C) { return (size_t)3 * C * sizeof(float); }
+extern "C" size_t pcg_bn_bwd_partial_db_workspace_bytes(int32_t C) {
+  return C > 0 ? (((size_t)3 * C * sizeof(float) + 7) & ~(size_t)7) + (size_t)4096 * C * sizeof(double) : 0;
+}
 
-extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                                  const float* gamma, const void* partial_, int32_t nparts, float* dx, float* dgamma, float* dbeta,
-                                  int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                               const float* gamma, const void* partial_, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                               int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream, float* dcol,
+                               int accumulate_col) {
   const double* partial = static_cast<const double*>(partial_);
+  PCG_REQUIRE(!dcol || workspace_bytes >= pcg_bn_bwd_partial_db_workspace_bytes(C),
+              "pcg_bn_bwd_partial_db: workspace smaller than pcg_bn_bwd_partial_db_workspace_bytes");
   PCG_REQUIRE(dm && x && mean && invstd && partial && dx && rows > 0 && C > 0 && nparts > 0, "pcg_bn_bwd_partial: bad arguments");
   PCG_REQUIRE(((uintptr_t)partial & 7) == 0, "pcg_bn_bwd_partial: the partial-sum buffer must be 8-byte aligned");
   if (!workspace || workspace_bytes < pcg_bn_bwd_partial_workspace_bytes(C)) {
@@ -666,20 +722,63 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
   if (int e = launch_status("bn_bwd_finalize_kernel")) return e;
   const bool aligned = al16(dm) && al16(x) && al16(dx);
   const size_t n = (size_t)rows * C;
+  double* colpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)3 * C * sizeof(float) + 7) & ~(size_t)7));
   if (fast_channels(C) && aligned) {
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > COL_MAX_BLOCKS) blocks = COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
                        reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, PCG_ACT_NONE,
-                       0.f, 1.f, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr);
+                       0.f, 1.f, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr, dcol ? colpart : nullptr);
+    if (int e = launch_status("bn_bwd_apply_kernel")) return e;
+    if (dcol) {
+      hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads((int)blocks)), 0, s, (const double*)colpart,
+                         (int)blocks, C, dcol, accumulate_col);
+      return launch_status("colsum_finalize_kernel");
+    }
+    return PCG_OK;
   } else if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
                        (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
                        (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
-  return launch_status("bn_bwd_apply_kernel");
+  if (int e = launch_status("bn_bwd_apply_kernel")) return e;
+  if (dcol) {
+    const ColPlan cq = plan_cols(rows, C, al16(dx));
+    FnSum fs{dx};
+    if (int e = launch_colreduce(fs, rows, C, cq, colpart, s)) return e;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(cq.nblocks)), 0, s, (const double*)colpart, cq.nblocks, C,
+                       dcol, accumulate_col);
+    return launch_status("colsum_finalize_kernel");
+  }
+  return PCG_OK;
+}
+
+extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                  const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                                  int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  return bn_bwd_partial_impl(dm, x, rows, C, mean, invstd, gamma, partial, nparts, dx, dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                             stream, nullptr, 0);
+}
+extern "C" int pcg_bn_bwd_partial_db(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                     const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
+                                     int accumulate, float* dcol, int accumulate_col, void* workspace, size_t workspace_bytes,
+                                     pcg_stream_t stream) {
+  PCG_REQUIRE(dcol != nullptr, "pcg_bn_bwd_partial_db: null column-sum output");
+  return bn_bwd_partial_impl(dm, x, rows, C, mean, invstd, gamma, partial, nparts, dx, dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                             stream, dcol, accumulate_col);
+}
+extern "C" size_t pcg_bn_db_workspace_bytes(int64_t rows, int32_t C) {
+  return rows > 0 && C > 0 ? ((pcg_bn_workspace_bytes(rows, C) + 7) & ~(size_t)7) + colpart_bytes(C) : 0;
+}
+extern "C" int pcg_bn_act_bwd_db(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int act, float slope, float dy_scale, float* dx,
+                                 float* dgamma, float* dbeta, int accumulate, float* dcol, int accumulate_col, void* workspace,
+                                 size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dcol != nullptr, "pcg_bn_act_bwd_db: null column-sum output");
+  return bn_act_bwd_impl(dy, x, y, rows, C, mean, invstd, gamma, beta, act, slope, dy_scale, dx, dgamma, dbeta, accumulate, workspace,
+                         workspace_bytes, stream, dcol, accumulate_col);
 }
 
 extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate, void* workspace,

@@ -282,15 +282,22 @@ def conv2d_dgrad_add(g, dy, w, addend, out=None):
     return dx
 
 
-def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None):
-    """BatchNorm backward from the column sums a fused grad-input epilogue left in `partial` (dm is already masked)."""
+def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None, dcol=None, accumulate_col=False):
+    """BatchNorm backward from the column sums a fused grad-input epilogue left in `partial` (dm is already masked).
+    dcol: also accumulate the column sums of the returned dx there (the bias gradient of the conv in front of the BatchNorm)."""
     _chk(dm, "dm"); _chk(x, "x")
     rows = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
     lib = _lib.load()
-    ws = workspace(lib.pcg_bn_bwd_partial_workspace_bytes(C), x.device)
-    check(lib.pcg_bn_bwd_partial(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
-                                 _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_bwd_partial")
+    if dcol is None:
+        ws = workspace(lib.pcg_bn_bwd_partial_workspace_bytes(C), x.device)
+        check(lib.pcg_bn_bwd_partial(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
+                                     _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_bwd_partial")
+    else:
+        ws = workspace(lib.pcg_bn_bwd_partial_db_workspace_bytes(C), x.device)
+        check(lib.pcg_bn_bwd_partial_db(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
+                                        _p(dbeta), int(bool(accumulate)), _p(dcol), int(bool(accumulate_col)), _p(ws), ws.numel(), _stream()),
+              "pcg_bn_bwd_partial_db")
     return dx
 
 
@@ -345,15 +352,26 @@ def bn_apply_act(x, C, mean, invstd_or_var, gamma, beta, act, slope=0.0, var_eps
     return y
 
 
-def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None, dy_scale=1.0, beta=None):
+def bn_act_bwd(dy, x, y, C, mean, invstd, gamma, act, slope, dgamma, dbeta, accumulate, out=None, dy_scale=1.0, beta=None, dcol=None,
+               accumulate_col=False):
     """BatchNorm(train) + activation backward.  y=None with ReLU / LeakyReLU and `beta` given: the mask is recomputed from x
-    (pcg_bn_act_bwd_premask) instead of read from the saved activation."""
+    (pcg_bn_act_bwd_premask) instead of read from the saved activation.  dcol: also accumulate the column sums of the returned dx
+    there (the bias gradient of the conv in front of the BatchNorm) — taken in the apply pass, no separate reduction."""
     _chk(dy, "dy"); _chk(x, "x")
     if y is not None:
         _chk(y, "y")
     rows = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
     lib = _lib.load()
+    if dcol is not None:
+        premask = y is None and act in (ACT_RELU, ACT_LRELU)
+        if premask and beta is None:
+            raise _lib.PcgError("bn_act_bwd: pass y, or beta to recompute the activation mask")
+        ws = workspace(lib.pcg_bn_db_workspace_bytes(rows, C), x.device)
+        check(lib.pcg_bn_act_bwd_db(_p(dy), _p(x), _p(y), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta if premask else None), act, slope,
+                                    dy_scale, _p(dx), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(dcol), int(bool(accumulate_col)),
+                                    _p(ws), ws.numel(), _stream()), "pcg_bn_act_bwd_db")
+        return dx
     ws = workspace(lib.pcg_bn_workspace_bytes(rows, C), x.device)
     if y is None and act in (ACT_RELU, ACT_LRELU):
         if beta is None:

@@ -330,3 +330,32 @@ def test_fused_backward_epilogues_equal_separate_passes(pcg):
         assert l2 <= 2e-5, f"{k}: rel-L2 {l2:.2e}"
         checked += 1
     assert checked >= 45
+
+
+def test_fused_bias_colsum_equals_separate_pass(pcg):
+    """countergan.FUSE_BIAS_COLSUM: the gradients of the conv biases in front of BatchNorm layers come out of the BatchNorm
+    backward's apply pass instead of a pcg_colsum pass over dz.  Everything else of the step is bit-identical; the bias gradients
+    themselves are rounding residue of an analytically zero sum (both forms accumulate in fp64: equal to ~1e-6 of |dz| sums)."""
+    K = pcg.countergan
+    x, y, t, m = (a.to(DEV) for a in CR.synthetic_batch(16, seed=5))
+    res = {}
+    try:
+        for fuse in (True, False):
+            K.FUSE_BIAS_COLSUM = fuse
+            (G, D, C), _ = _build(pcg, seed=2)
+            opt_g, opt_d, bce, ce = K.make_optimizers(G, D)
+            out = K.train_step(G, D, C, opt_g, opt_d, bce, ce, x, y, t, m)
+            res[fuse] = (out["g_loss"].item(), out["d_loss"].item(),
+                         {n: p.grad.clone() for n, p in G.named_parameters()}, {n: p.grad.clone() for n, p in D.named_parameters()})
+    finally:
+        K.FUSE_BIAS_COLSUM = True
+    assert res[True][:2] == res[False][:2]
+    for n, gref in res[False][2].items():
+        got = res[True][2][n]
+        if n.endswith("bias") and ".conv" in n and "resblocks" in n:
+            scale = max(float(res[False][2][n.replace("bias", "weight")].abs().max()), 1e-12)
+            assert float((got - gref).abs().max()) <= 1e-4 * scale + 1e-9, n     # residue of a zero sum: tiny next to the weight gradient
+        else:
+            assert torch.equal(got, gref), n
+    for n, gref in res[False][3].items():
+        assert torch.equal(res[True][3][n], gref), n

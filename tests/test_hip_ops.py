@@ -391,3 +391,26 @@ def test_input_transform_rejected_on_thin_layers(pcg):
     with pytest.raises(pcg.PcgError, match="MFMA path"):
         ops.conv2d_fwd(geom, torch.zeros(2, 8, 8, 64, device="cuda:0"), torch.zeros(1, 4, 4, 64, device="cuda:0"),
                        xf=ops.InputXform(coef, 1, 0.0))
+
+
+@pytest.mark.parametrize("rows,C,act", [(64 * 28 * 28, 64, 0), (16 * 16 * 16, 128, 2), (1000, 36, 2), (4 * 7 * 7, 20, 0)])
+def test_bn_backward_with_fused_bias_colsum(pcg, rows, C, act):
+    """pcg_bn_act_bwd_db / pcg_bn_bwd_partial_db: dx is what the plain calls return, bit for bit, and dcol (+)= the column sums of
+    that dx (fp64 accumulation, so equal to a float64 reduction of dx to fp32 rounding) — fast path (C/4 a power of two) and the
+    generic fallback."""
+    ops = pcg.ops
+    g = torch.Generator(device="cuda:0").manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g, device="cuda:0") * 1.3 + 0.2
+    dy = torch.randn(rows, C, generator=g, device="cuda:0") + 0.05
+    gam, bet = torch.rand(C, generator=g, device="cuda:0") + 0.5, torch.randn(C, generator=g, device="cuda:0") * 0.2
+    mean, invstd = ops.bn_train_stats(x, C, 1e-5, 0.1)
+    dg1, db1, dg2, db2 = (torch.zeros(C, device="cuda:0") for _ in range(4))
+    ref = ops.bn_act_bwd(dy, x, None, C, mean, invstd, gam, act, 0.2, dg1, db1, False, beta=bet, dy_scale=0.5)
+    dcol = torch.full((C,), 3.0, device="cuda:0")
+    got = ops.bn_act_bwd(dy, x, None, C, mean, invstd, gam, act, 0.2, dg2, db2, False, beta=bet, dy_scale=0.5, dcol=dcol, accumulate_col=True)
+    assert torch.equal(got, ref) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    want = ref.double().sum(0)
+    np.testing.assert_allclose((dcol - 3.0).cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-6 * float(ref.abs().sum(0).max()) + 1e-6)
+    dcol2 = torch.empty(C, device="cuda:0")
+    ops.bn_act_bwd(dy, x, None, C, mean, invstd, gam, act, 0.2, dg2, db2, False, beta=bet, dy_scale=0.5, dcol=dcol2, accumulate_col=False)
+    np.testing.assert_allclose(dcol2.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-6 * float(ref.abs().sum(0).max()) + 1e-6)
