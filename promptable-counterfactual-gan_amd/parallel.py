@@ -25,6 +25,9 @@ from . import _lib
 from ._lib import check
 
 
+_native_generation = 0      # how many library communicators this process has created (every rank counts the same way)
+
+
 def _cur_stream(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -59,8 +62,11 @@ class GradSync:
     def _init_native(self):
         lib = _lib.load()
         if lib.pcg_dp_world() == 0:
+            global _native_generation
             store = dist.distributed_c10d._get_default_store()
-            key = "pcgan_hip/rccl_unique_id"
+            # one key per communicator generation: a second communicator (after parallel.shutdown()) must not read the first one's id
+            key = f"pcgan_hip/rccl_unique_id/{_native_generation}"
+            _native_generation += 1
             if self.rank == 0:
                 buf = ctypes.create_string_buffer(128)
                 check(lib.pcg_dp_unique_id(buf), "pcg_dp_unique_id")
