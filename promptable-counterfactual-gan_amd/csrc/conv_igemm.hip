@@ -25,7 +25,7 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // XF (here and below): the activation operand carries an input transform (ConvP::in_sc) — a separate instantiation, so the
 // plain kernels pay nothing for it.
 template <class Cfg, bool XF>
-__global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_fwd_kernel(ConvP p) {
 }
 
 template <class Cfg, bool XF>
-__global__ void __launch_bounds__(IG_THREADS, 4) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
   // phases.interleave (all phases the same size, 1-D grid): the sub-pixel phases of one tile are neighbours in launch order and
@@ -208,7 +208,15 @@ __global__ void __launch_bounds__(256) col2im_kernel(const float4* __restrict__ 
 // host side
 // ------------------------------------------------------------------------------------------------
 using Cfg128x128 = TileCfg<128, 128, 2, 2>;
-using Cfg128x64 = TileCfg<128, 64, 2, 2>;
+#ifndef PCG_TILE64_SWZ
+#define PCG_TILE64_SWZ 1     // 128x64 tiles: swizzled unpadded LDS images, three workgroups per CU (0: the r01 layout, two per CU)
+#endif
+using Cfg128x64P = TileCfg<128, 64, 2, 2>;                 // padded images, two workgroups per CU, two k-tiles of gathers in flight
+#if PCG_TILE64_SWZ
+using Cfg128x64 = TileCfg<128, 64, 2, 2, true, 6, 1>;      // measured r02: 3x3 s1 64->64 forward 97.7 -> 101.1, grad-input 106.0 -> 111.5
+#else                                                      // TFLOP/s; the k4 s2 grad-input (four interleaved phases, K = 512) LOSES
+using Cfg128x64 = Cfg128x64P;                              // 9 % (105.7 -> 96.6) and therefore keeps the padded config
+#endif
 
 int check_geom(const pcg_conv_geom* g) {
   PCG_REQUIRE(g != nullptr, "conv geometry is null");
@@ -565,7 +573,8 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
     }
   PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
   hipStream_t st = (hipStream_t)stream;
-  if (int e = p.N > 64 ? launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st) : launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st)) return e;
+  if (int e = p.N > 64 ? launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st)
+                       : nph > 1 ? launch_dgrad<Cfg128x64P>(p, ph, nph, maxMp, st) : launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st)) return e;
   return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, stream);
 }
 

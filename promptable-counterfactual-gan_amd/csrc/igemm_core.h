@@ -42,24 +42,39 @@ constexpr int IG_BK = 32;
 #endif
 constexpr int IG_LDK = IG_BK + 4;          // K-major row stride: 144 B = 9*16 (aligned for b128, conflict-free)
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+// SWZ_: K-major LDS images without row padding, 16-byte chunks XOR-swizzled by the row (LdsImage): 128x64 tiles then need 49 KB
+//       instead of 55 KB and THREE workgroups fit a CU's 160 KB — while one of them is in its prologue / epilogue the SIMD still
+//       hosts two consumer waves (one wave alone does not keep the MFMA pipe full).  MINW_: waves per SIMD the register budget
+//       must allow (launch bounds); PF_: k-tiles of gathers in flight per producer thread (register sets).
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool SWZ_ = false, int MINW_ = 4, int PF_ = PCG_PREFETCH_DEPTH>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+  static constexpr bool SWZ = SWZ_;
+  static constexpr int MINW = MINW_, PF = PF_;
   static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   static constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 consumer waves per block");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");
 };
 
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, bool SWZ = false>
 struct LdsImage {
   static constexpr int LDM = ROWS + 4;
-  static constexpr int FLOATS = KMAJOR ? ROWS * IG_LDK : IG_BK * LDM;
+  // K-major row stride: 36 floats (padded, conflict-free as is) or 32 floats with the row's eight 16-byte chunks permuted by
+  // chunk ^ ((row >> 1) & 7): sixteen consecutive rows reading the same logical chunk (one quarter-wave of a ds_read_b128) then
+  // touch all 64 banks once (even rows: bank base 0, chunks 0..7 each once; odd rows: bank base 32, likewise)
+  static constexpr int LDKS = (KMAJOR && SWZ) ? IG_BK : IG_LDK;
+  static constexpr int FLOATS = KMAJOR ? ROWS * LDKS : IG_BK * LDM;
   static constexpr int NV = ROWS / 32;  // float4 per loader thread per k-tile (256 loader threads)
 
   // loader thread tid (0..255) -> (row, k-quad) for K-major; (k-row, column-quad) for MN-major
   __device__ static __forceinline__ void store(float* lds, const float4 (&v)[NV], int tid) {
-    if constexpr (KMAJOR) {
+    if constexpr (KMAJOR && SWZ) {
+      const int kq = tid & 7, r0 = tid >> 3;
+#pragma unroll
+      for (int p = 0; p < NV; ++p)     // (row >> 1) & 7 == (r0 >> 1) & 7: adding 32 * p does not touch bits 1..3 of the row
+        *reinterpret_cast<float4*>(lds + (r0 + 32 * p) * IG_BK + 4 * (kq ^ ((r0 >> 1) & 7))) = v[p];
+    } else if constexpr (KMAJOR) {
       const int kq = tid & 7, r0 = tid >> 3;
 #pragma unroll
       for (int p = 0; p < NV; ++p)
@@ -85,7 +100,11 @@ struct LdsImage {
   }
   // fragment for MFMA tile rows [row0, row0+32), k-group ks (8 k's): f[t] = T[row0+i][8ks+4h+t]
   __device__ static __forceinline__ void frag(const float* lds, int row0, int ks, int li, int lh, float (&f)[4]) {
-    if constexpr (KMAJOR) {
+    if constexpr (KMAJOR && SWZ) {
+      const int row = row0 + li;
+      const float4 q = *reinterpret_cast<const float4*>(lds + row * IG_BK + 4 * ((2 * ks + lh) ^ ((row >> 1) & 7)));
+      f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+    } else if constexpr (KMAJOR) {
       const float4 q = *reinterpret_cast<const float4*>(lds + (row0 + li) * IG_LDK + 8 * ks + 4 * lh);
       f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
     } else {
@@ -107,7 +126,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 template <class Cfg, bool AK, bool BK_>
 constexpr int igemm_smem_floats() {
-  return 2 * (LdsImage<Cfg::BM, AK>::FLOATS + LdsImage<Cfg::BN, BK_>::FLOATS);
+  return 2 * (LdsImage<Cfg::BM, AK, Cfg::SWZ>::FLOATS + LdsImage<Cfg::BN, BK_, Cfg::SWZ>::FLOATS);
 }
 
 // Loader concept (per-thread state of a producer thread, constructed with its loader-thread id 0..255):
@@ -116,13 +135,13 @@ constexpr int igemm_smem_floats() {
 //   __device__ void transform(float4 (&v)[ROWS/32]);   // applied to the registers of the last load_next before the ds_write
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float* smem, int tid) {
-  using IA = LdsImage<Cfg::BM, LA::KMAJOR>;
-  using IB = LdsImage<Cfg::BN, LB::KMAJOR>;
+  using IA = LdsImage<Cfg::BM, LA::KMAJOR, Cfg::SWZ>;
+  using IB = LdsImage<Cfg::BN, LB::KMAJOR, Cfg::SWZ>;
   static_assert(LA::ROWS == Cfg::BM && LB::ROWS == Cfg::BN, "loader/tile mismatch");
   float* As = smem;
   float* Bs = smem + 2 * IA::FLOATS;
   // loaders that carry an input transform keep ONE pending tile of transform state: they run the depth-1 pipeline
-  if constexpr (PCG_PREFETCH_DEPTH == 2 && !LA::XFORM && !LB::XFORM) {
+  if constexpr (Cfg::PF == 2 && !LA::XFORM && !LB::XFORM) {
   // Two k-tiles of gathers in flight.  One k-tile of MFMAs is 2048 (128x64 tile) .. 4096 cycles (128x128) = 1 .. 2 us, which is no
   // more than a loaded HBM / L2 round trip: with a single tile in flight the producers reach the hand-over barrier late and the
   // consumers wait.  (Measured r02: +2..4 % per kernel in isolation, nothing in the back-to-back step — the larger part of what idle
@@ -196,8 +215,8 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
 // the tile boundary.  s_setprio keeps MFMA issue ahead of the co-resident producers' vector instructions.
 template <class Cfg, bool AK, bool BK_>
 __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* smem) {
-  using IA = LdsImage<Cfg::BM, AK>;
-  using IB = LdsImage<Cfg::BN, BK_>;
+  using IA = LdsImage<Cfg::BM, AK, Cfg::SWZ>;
+  using IB = LdsImage<Cfg::BN, BK_, Cfg::SWZ>;
   constexpr int KG = IG_BK / 8;  // k-groups per tile
   const float* As = smem;
   const float* Bs = smem + 2 * IA::FLOATS;
