@@ -22,9 +22,11 @@ os.makedirs(out, exist_ok=True)
 
 
 def short(name):
+    import re
     name = name.replace("pcg::(anonymous namespace)::", "").replace("void ", "")
-    for a, b in (("pcg::TileCfg<128, 128, 2, 2>", "128x128"), ("pcg::TileCfg<128, 64, 2, 2>", "128x64"), ("pcg::TileCfg<64, 128, 1, 4>", "64x128")):
-        name = name.replace(a, b)
+    # TileCfg<BM, BN, WM, WN[, swizzled, min waves/SIMD, prefetch depth]> -> BMxBN (+ "/swz3" for the unpadded three-per-CU config)
+    name = re.sub(r"pcg::TileCfg<(\d+), (\d+), \d+, \d+(?:, (true|false), \d+, \d+)?>",
+                  lambda m: f"{m.group(1)}x{m.group(2)}" + ("/swz3" if m.group(3) == "true" else ""), name)
     return name.split("(")[0]
 
 
