@@ -30,9 +30,15 @@ def _conv_label(g, op):
     if g.Cin <= 3 or g.Cout <= 3:
         return f"thin_{op}"
     if op == "wgrad":
-        return "conv_wgrad_kernel<64x128>" if g.Cout <= 64 else "conv_wgrad_kernel<128x128>"
+        n = g.KH * g.KW * g.Cin
+        if g.Cout <= 64:
+            return "conv_wgrad192_kernel<64x192>" if (n % 192 == 0 and n % 128 != 0) else "conv_wgrad_kernel<64x128>"
+        return "conv_wgrad_kernel<128x128>"
     n = g.Cout if op == "fwd" else g.Cin
-    return f"conv_{op}_kernel<128x{'128' if n > 64 else '64'}>"
+    if n > 64:
+        return f"conv_{op}_kernel<128x128>"
+    swz = op == "fwd" or g.stride == 1          # three-per-CU swizzled config: forward and single-phase grad-input
+    return f"conv_{op}_kernel<128x64{'/swz3' if swz else ''}>"
 
 
 def _conv_flops(g):
