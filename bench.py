@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — images/sec of one full DCGAN G+D training step (mnist_dcgan.py:147-175) on MI355X.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL; weak scaling: 512 images per GPU)
 
@@ -10,7 +10,8 @@ GPU; the parent never touches the GPU) and relays rank 0's JSON line; under torc
 
 A "step" = D(real) fwd+bwd, G fwd, D(fake.detach()) fwd+bwd, Adam(D), D(fake) fwd, bwd through D into G, Adam(G)
 on a synthetic MNIST-shaped batch (U[-1,1) 64x64 images, N(0,1) noise) that is already resident in HBM.  fp32
-throughout (v_mfma_f32_32x32x2_f32 for the contractions).  Rank 0 prints ONE JSON line.
+throughout (v_mfma_f32_32x32x2_f32 for the contractions).  Rank 0 prints ONE JSON line.  Defaults: 50 timed steps after 5
+warm-up steps (a 0.55 s timed region: long enough for a utilisation sampler to see the GPU busy).
 
 roofline: the dominant kernels are the fp32-MFMA implicit-GEMM convolutions (conv_{fwd,dgrad,wgrad}_kernel).  Every
 launch of that family inside the timed region is bracketed by HIP events on the launch stream; `achieved` =
@@ -131,7 +132,7 @@ def params_digest(nets):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU (default: the BASELINE config, 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
