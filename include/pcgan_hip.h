@@ -161,6 +161,14 @@ int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w,
  * in the backward sweep (`x + 0.1*out`, conditional_counteRGAN/mnist/models/generator.py:20): no separate add pass.  MFMA layers. */
 int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, float* dx,
                          void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+/* pcg_conv2d_dgrad_add + the BatchNorm-backward column sums of the SUM for the next BatchNorm down the skip chain
+ * (`x + 0.1*bn2(conv2(...))`, models/generator.py:18-20: the gradient arriving at block i-1's bn2 is the sum block i's backward just
+ * formed): partial rows get sum(sum_scale*dx) and sum(sum_scale*dx*xhat) with xhat from z_next / mean / invstd of that BatchNorm;
+ * dx itself is stored unscaled.  Finish with pcg_bn_bwd_partial_db(dm = dx, dm_scale = sum_scale).  partial: the buffer of
+ * pcg_conv2d_dgrad_bn_workspace_bytes, pcg_conv2d_dgrad_bn_partial_rows rows. */
+int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* z_next,
+                               const float* mean, const float* invstd, float sum_scale, float* dx, void* partial, size_t partial_bytes,
+                               pcg_stream_t stream);
 int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g);
 int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */
@@ -227,9 +235,12 @@ int pcg_bn_act_bwd_db(const float* dy, const float* x, const float* y /*nullable
                       float* dx, float* dgamma, float* dbeta, int accumulate, float* dcol, int accumulate_col, void* workspace,
                       size_t workspace_bytes, pcg_stream_t stream);
 size_t pcg_bn_bwd_partial_db_workspace_bytes(int32_t C);
+/* dm_scale: the partial sums already include this factor, the apply pass multiplies dm by it (1: plain) — the 0.1 of a residual
+ * branch whose incoming gradient is the unscaled skip-path sum (pcg_conv2d_dgrad_add_bnsum).  dcol may be NULL. */
 int pcg_bn_bwd_partial_db(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                          const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
-                          int accumulate, float* dcol, int accumulate_col, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+                          const float* gamma, const void* partial, int32_t nparts, float dm_scale, float* dx, float* dgamma,
+                          float* dbeta, int accumulate, float* dcol /*nullable*/, int accumulate_col, void* workspace,
+                          size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */

@@ -14,6 +14,8 @@ The torch layer objects are kept as parameter containers (identical `state_dict(
 `adv_head.*`; `conv.{0,2,4}.*`, `fc.{1,4}.*`), forward/backward are one autograd node per network sequencing C-ABI
 calls on NHWC activations.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -81,6 +83,7 @@ def _dgrad_act(g, dz, w, a_below, act, slope):
     return ops.act_bwd(d, a_below.view(d.shape), act, slope, out=d)
 
 
+FUSE_SKIP_BNSUM = os.environ.get("PCG_SKIP_BNSUM", "1") != "0"   # A/B switch: bn2's backward column sums out of the previous block's skip-add grad-input epilogue
 FUSE_BIAS_COLSUM = True         # A/B switch: conv-bias gradients in front of a BatchNorm out of the BatchNorm backward's apply pass
 FUSE_BACKWARD_EPILOGUE = True   # A/B switch for the tests: activation derivative / BatchNorm-backward sums / skip-connection add in
                                 # the grad-input kernel's epilogue (ops.conv_bwd_data_fused, conv2d_dgrad_add) vs separate passes
@@ -300,14 +303,21 @@ class ResidualGenerator(FlatModule):
         d = _conv_bwd(self, self.conv_out, g_out, hm, dc, True, True)
         ops.act_bwd(d, hm, ACT_LRELU, slope, out=d)
         dh = _conv_bwd(self, self.conv_mid, g_mid, h_last, d, True, True)
-        for blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2) in zip(reversed(self.resblocks), reversed(blocks)):
+        order = list(zip(reversed(self.resblocks), reversed(blocks)))
+        pending = None      # (partial, nparts): bn2's backward sums of the gradient `dh`, left by the previous block's skip-add epilogue
+        for bi, (blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2)) in enumerate(order):
             C = blk.bn2.num_features
             dg2, acc = self._grad_view(blk.bn2.weight)
             db2, _ = self._grad_view(blk.bn2.bias)
             # the conv biases in front of the BatchNorms: their gradient is the column sum of dz, taken in the apply pass
             cb2, accb2 = self._grad_view(blk.conv2.bias) if (blk.conv2.bias is not None and FUSE_BIAS_COLSUM) else (None, False)
-            dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1,
-                                 dcol=cb2, accumulate_col=accb2)
+            if pending is not None:     # sums of 0.1*dh and 0.1*dh*xhat2 came with dh: no reduction pass over (dh, z2)
+                dz2 = ops.bn_bwd_partial(dh, z2, C, m2, s2, blk.bn2.weight.data, pending[0], pending[1], dg2, db2, acc, dcol=cb2,
+                                         accumulate_col=accb2, dm_scale=0.1)
+            else:
+                dz2 = ops.bn_act_bwd(dh, z2, None, C, m2, s2, blk.bn2.weight.data, ACT_NONE, 0.0, dg2, db2, acc, dy_scale=0.1,
+                                     dcol=cb2, accumulate_col=accb2)
+            pending = None
             _conv_wgrad(self, blk.conv2, g2, a1, dz2, bias_done=cb2 is not None)
             dg1, acc = self._grad_view(blk.bn1.weight)
             db1, _ = self._grad_view(blk.bn1.bias)
@@ -323,7 +333,13 @@ class ResidualGenerator(FlatModule):
                                      dcol=cb1, accumulate_col=accb1)
             _conv_wgrad(self, blk.conv1, g1, h, dz1, bias_done=cb1 is not None)
             if FUSE_BACKWARD_EPILOGUE:   # skip path + block path: the add happens in conv1's grad-input epilogue, in place
-                dh = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh)
+                nxt = order[bi + 1][1] if (bi + 1 < len(order) and FUSE_SKIP_BNSUM) else None
+                if nxt is not None:      # ... together with the BatchNorm-backward sums the NEXT block's bn2 needs from this sum
+                    dh, part, nparts = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh,
+                                                            bnsum=(nxt[7], nxt[8], nxt[9], 0.1))
+                    pending = (part, nparts)
+                else:
+                    dh = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh)
             else:
                 dconv = ops.conv2d_dgrad(g1, dz1, ops.ohwi(blk.conv1.weight.data))
                 dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)

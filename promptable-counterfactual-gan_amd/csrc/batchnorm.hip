@@ -693,7 +693,7 @@ extern "C" size_t pcg_bn_bwd_partial_db_workspace_bytes(int32_t C) {
 static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
                                const float* gamma, const void* partial_, int32_t nparts, float* dx, float* dgamma, float* dbeta,
                                int accumulate, void* workspace, size_t workspace_bytes, pcg_stream_t stream, float* dcol,
-                               int accumulate_col) {
+                               int accumulate_col, float dm_scale = 1.f) {
   const double* partial = static_cast<const double*>(partial_);
   PCG_REQUIRE(!dcol || workspace_bytes >= pcg_bn_bwd_partial_db_workspace_bytes(C),
               "pcg_bn_bwd_partial_db: workspace smaller than pcg_bn_bwd_partial_db_workspace_bytes");
@@ -729,7 +729,7 @@ static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, in
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
                        reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, PCG_ACT_NONE,
-                       0.f, 1.f, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr, dcol ? colpart : nullptr);
+                       0.f, dm_scale, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr, dcol ? colpart : nullptr);
     if (int e = launch_status("bn_bwd_apply_kernel")) return e;
     if (dcol) {
       hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads((int)blocks)), 0, s, (const double*)colpart,
@@ -739,10 +739,10 @@ static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, in
     return PCG_OK;
   } else if (C % 4 == 0 && aligned)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
-                       (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
+                       (const float*)coef, PCG_ACT_NONE, 0.f, dm_scale, dx, gamma, (const float*)nullptr);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), 0, s, dm, x, (const float*)nullptr, n, C, mean, invstd,
-                       (const float*)coef, PCG_ACT_NONE, 0.f, 1.f, dx, gamma, (const float*)nullptr);
+                       (const float*)coef, PCG_ACT_NONE, 0.f, dm_scale, dx, gamma, (const float*)nullptr);
   if (int e = launch_status("bn_bwd_apply_kernel")) return e;
   if (dcol) {
     const ColPlan cq = plan_cols(rows, C, al16(dx));
@@ -762,12 +762,11 @@ extern "C" int pcg_bn_bwd_partial(const float* dm, const float* x, int64_t rows,
                              stream, nullptr, 0);
 }
 extern "C" int pcg_bn_bwd_partial_db(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
-                                     const float* gamma, const void* partial, int32_t nparts, float* dx, float* dgamma, float* dbeta,
-                                     int accumulate, float* dcol, int accumulate_col, void* workspace, size_t workspace_bytes,
-                                     pcg_stream_t stream) {
-  PCG_REQUIRE(dcol != nullptr, "pcg_bn_bwd_partial_db: null column-sum output");
+                                     const float* gamma, const void* partial, int32_t nparts, float dm_scale, float* dx, float* dgamma,
+                                     float* dbeta, int accumulate, float* dcol, int accumulate_col, void* workspace,
+                                     size_t workspace_bytes, pcg_stream_t stream) {
   return bn_bwd_partial_impl(dm, x, rows, C, mean, invstd, gamma, partial, nparts, dx, dgamma, dbeta, accumulate, workspace, workspace_bytes,
-                             stream, dcol, accumulate_col);
+                             stream, dcol, accumulate_col, dm_scale);
 }
 extern "C" size_t pcg_bn_db_workspace_bytes(int64_t rows, int32_t C) {
   return rows > 0 && C > 0 ? ((pcg_bn_workspace_bytes(rows, C) + 7) & ~(size_t)7) + colpart_bytes(C) : 0;

@@ -650,6 +650,24 @@ extern "C" int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, con
   return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
 }
 
+extern "C" int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* z_next,
+                                          const float* mean, const float* invstd, float sum_scale, float* dx, void* partial,
+                                          size_t partial_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_ADDSUM;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_dgrad_add_bnsum", g, dx, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  const size_t need = pcg_conv2d_dgrad_bn_workspace_bytes(g);
+  PCG_REQUIRE(need > 0, "pcg_conv2d_dgrad_add_bnsum: layer not eligible (MFMA layers, stride <= 2, channel count %% 4 == 0)");
+  PCG_REQUIRE(z_next && mean && invstd && (((uintptr_t)z_next | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0,
+              "pcg_conv2d_dgrad_add_bnsum: z_next / mean / invstd must be non-null and 16-byte aligned");
+  if (!partial || partial_bytes < need) { set_error("pcg_conv2d_dgrad_add_bnsum: partial-sum buffer %zu B < required %zu B", partial_bytes, need); return PCG_ERR_WORKSPACE; }
+  e.neg = sum_scale;
+  e.delta2_bytes = (int64_t)((intptr_t)z_next - (intptr_t)dx);
+  e.mean = mean; e.invstd = invstd;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
+
 static int bnbwd_epi(const char* who, const pcg_conv_geom* g, const float* out, const float* z_below, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, int act, float slope, size_t need, void* partial, size_t partial_bytes,
                      EpiAux* e) {

@@ -285,11 +285,16 @@ constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 //              v *= (pre > 0 ? 1 : neg), xhat = (z - mean)*invstd; column sums of v and v*xhat go to the partial rows
 //              (-> dbeta, dgamma and the two means BatchNorm's backward needs): no separate reduction pass over (dy, z).
 //   EPI_ADD    aux = an addend of the output's shape (may BE the output: in-place accumulation).  v += aux   — skip connections
-enum { EPI_NONE = 0, EPI_MASK = 1, EPI_BNBWD = 2, EPI_ADD = 3 };
+//   EPI_ADDSUM EPI_ADD + the BatchNorm-backward column sums of the SUM for the next BatchNorm down the skip chain: aux2 = that layer's
+//              pre-BatchNorm output z (delta2_bytes), mean / invstd its statistics; no activation in between (x + 0.1*bn2(...), models/
+//              generator.py:20).  The partial rows get sum(scale*v) and sum(scale*v*xhat) (scale = neg: the 0.1 of the residual branch);
+//              the stored tile is the unscaled sum — the skip path needs it as it is.
+enum { EPI_NONE = 0, EPI_MASK = 1, EPI_BNBWD = 2, EPI_ADD = 3, EPI_ADDSUM = 4 };
 struct EpiAux {
   int mode;                 // EPI_*
-  float neg;                // slope of the negative side (0 ReLU, 0.2 LeakyReLU, 1 = no activation)
+  float neg;                // slope of the negative side (0 ReLU, 0.2 LeakyReLU, 1 = no activation); EPI_ADDSUM: the sum scale
   int64_t delta_bytes;      // (char*)aux - (char*)out
+  int64_t delta2_bytes;     // EPI_ADDSUM: (char*)z_next - (char*)out
   const float* mean; const float* invstd; const float* gamma; const float* beta;   // EPI_BNBWD, per output column
 };
 
@@ -352,6 +357,10 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       bn_fold(ga.x, be.x, mu.x, is.x, sc.x, sh.x); bn_fold(ga.y, be.y, mu.y, is.y, sc.y, sh.y);
       bn_fold(ga.z, be.z, mu.z, is.z, sc.z, sh.z); bn_fold(ga.w, be.w, mu.w, is.w, sc.w, sh.w);
     }
+    if (emode == EPI_ADDSUM && nok) {
+      mu = *reinterpret_cast<const float4*>(epi->mean + n);
+      is = *reinterpret_cast<const float4*>(epi->invstd + n);
+    }
     // all aux loads of the wave tile first (independent of the LDS reads), then the arithmetic
     float4 u[Cfg::WTM / RPI];
 #pragma unroll
@@ -360,6 +369,27 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       u[k] = (dst && nok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (emode == EPI_ADDSUM) {   // wave-uniform: its own loop (the second aux tensor is read next to each row's arithmetic)
+      const int64_t delta2 = epi->delta2_bytes;
+      const double sc2 = (double)neg;
+#pragma unroll
+      for (int k = 0; k < Cfg::WTM / RPI; ++k) {
+        const int row = r0 + RPI * k;
+        float* dst = row_base(wm * Cfg::WTM + row);
+        if (dst && nok) {
+          float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
+          const float4 z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta2);
+          v.x += u[k].x; v.y += u[k].y; v.z += u[k].z; v.w += u[k].w;
+          *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+          if (want_sums) {
+            const double d0 = sc2 * (double)v.x, d1 = sc2 * (double)v.y, d2 = sc2 * (double)v.z, d3 = sc2 * (double)v.w;
+            s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+            s2[0] = fma(d0, (double)((z.x - mu.x) * is.x), s2[0]); s2[1] = fma(d1, (double)((z.y - mu.y) * is.y), s2[1]);
+            s2[2] = fma(d2, (double)((z.z - mu.z) * is.z), s2[2]); s2[3] = fma(d3, (double)((z.w - mu.w) * is.w), s2[3]);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < Cfg::WTM / RPI; ++k) {
       const int row = r0 + RPI * k;
@@ -380,6 +410,7 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
           s2[2] = fma((double)v.z, (double)((u[k].z - mu.z) * is.z), s2[2]); s2[3] = fma((double)v.w, (double)((u[k].w - mu.w) * is.w), s2[3]);
         }
       }
+    }
     }
   }
   // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one fp64 partial row per

@@ -278,32 +278,50 @@ def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=Non
     return out, partial, nparts
 
 
-def conv2d_dgrad_add(g, dy, w, addend, out=None):
-    """dx = conv_dgrad(dy, w) + addend (out may be `addend`: in place) — the add of a skip connection in the grad-input epilogue."""
+def conv2d_dgrad_add(g, dy, w, addend, out=None, bnsum=None):
+    """dx = conv_dgrad(dy, w) + addend (out may be `addend`: in place) — the add of a skip connection in the grad-input epilogue.
+    bnsum = (z_next, mean, invstd, scale): also leave the BatchNorm-backward column sums of scale*dx for the BatchNorm whose
+    pre-normalisation output is z_next (the next one down the skip chain); returns (dx, partial, nparts) for bn_bwd_partial(dm_scale=scale)."""
     _chk(dy, "dy"); _chk(w, "w"); _chk(addend, "addend")
     assert addend.numel() == g.B * g.IH * g.IW * g.Cin
     dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
+    if bnsum is not None:
+        z_next, mean, invstd, scale = bnsum
+        _chk(z_next, "z_next")
+        assert z_next.numel() == dx.numel()
+        lib = _lib.load()
+        need = lib.pcg_conv2d_dgrad_bn_workspace_bytes(ctypes.byref(g))
+        if need == 0:
+            raise _lib.PcgError("conv2d_dgrad_add(bnsum=...): layer not eligible for the fused column sums")
+        nparts = lib.pcg_conv2d_dgrad_bn_partial_rows(ctypes.byref(g))
+        partial = torch.empty(need // 4, dtype=torch.float32, device=dy.device)
+        with _Timed(g, "dgrad"):
+            check(lib.pcg_conv2d_dgrad_add_bnsum(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(z_next), _p(mean), _p(invstd), float(scale),
+                                                 _p(dx), _p(partial), need, _stream()), "pcg_conv2d_dgrad_add_bnsum")
+        return dx, partial, nparts
     with _Timed(g, "dgrad"):
         check(_lib.load().pcg_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(dx), None, 0, _stream()), "pcg_conv2d_dgrad_add")
     return dx
 
 
-def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None, dcol=None, accumulate_col=False):
+def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta, accumulate, out=None, dcol=None, accumulate_col=False,
+                   dm_scale=1.0):
     """BatchNorm backward from the column sums a fused grad-input epilogue left in `partial` (dm is already masked).
-    dcol: also accumulate the column sums of the returned dx there (the bias gradient of the conv in front of the BatchNorm)."""
+    dcol: also accumulate the column sums of the returned dx there (the bias gradient of the conv in front of the BatchNorm).
+    dm_scale: the sums include this factor and the apply pass multiplies dm by it (conv2d_dgrad_add(bnsum=...))."""
     _chk(dm, "dm"); _chk(x, "x")
     rows = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
     lib = _lib.load()
-    if dcol is None:
+    if dcol is None and dm_scale == 1.0:
         ws = workspace(lib.pcg_bn_bwd_partial_workspace_bytes(C), x.device)
         check(lib.pcg_bn_bwd_partial(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
                                      _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "pcg_bn_bwd_partial")
     else:
         ws = workspace(lib.pcg_bn_bwd_partial_db_workspace_bytes(C), x.device)
-        check(lib.pcg_bn_bwd_partial_db(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), _p(dx), _p(dgamma),
-                                        _p(dbeta), int(bool(accumulate)), _p(dcol), int(bool(accumulate_col)), _p(ws), ws.numel(), _stream()),
-              "pcg_bn_bwd_partial_db")
+        check(lib.pcg_bn_bwd_partial_db(_p(dm), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), float(dm_scale),
+                                        _p(dx), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(dcol), int(bool(accumulate_col)), _p(ws),
+                                        ws.numel(), _stream()), "pcg_bn_bwd_partial_db")
     return dx
 
 
