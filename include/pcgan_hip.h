@@ -169,6 +169,15 @@ int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, const float* w
 int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* z_next,
                                const float* mean, const float* invstd, float sum_scale, float* dx, void* partial, size_t partial_bytes,
                                pcg_stream_t stream);
+/* The `fwd` forms of the skip-add epilogues (a ConvTranspose2d's grad-input; or a stride-1 Conv2d's grad-input run as a forward
+ * convolution of dy with the adjoint weight — pcg_conv_weight_adjoint: w[co][kh][kw][ci] -> w_adj[ci][KH-1-kh][KW-1-kw][co], geometry
+ * {B, OH, OW, Cout -> IH, IW, Cin, pad' = K-1-pad} — which makes both GEMM operands K-major). */
+int pcg_conv2d_fwd_add(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, float* y,
+                       void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+int pcg_conv2d_fwd_add_bnsum(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* z_next,
+                             const float* mean, const float* invstd, float sum_scale, float* y, void* partial, size_t partial_bytes,
+                             pcg_stream_t stream);
+int pcg_conv_weight_adjoint(const float* w, float* w_adj, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, pcg_stream_t stream);
 int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g);
 int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */

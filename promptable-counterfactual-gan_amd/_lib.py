@@ -110,6 +110,9 @@ PROTOTYPES = {
     "pcg_bn_bwd_partial_db_workspace_bytes": (_sz, [_c.c_int32]),
     "pcg_bn_bwd_partial_db": (_i, [_vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _c.c_int32, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad_add_bnsum": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_add": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcg_conv2d_fwd_add_bnsum": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
+    "pcg_conv_weight_adjoint": (_i, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pcg_dp_unique_id": (_i, [_vp]),
     "pcg_dp_init": (_i, [_vp, _i32, _i32]),
     "pcg_dp_world": (_i32, []),

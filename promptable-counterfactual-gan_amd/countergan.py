@@ -83,6 +83,7 @@ def _dgrad_act(g, dz, w, a_below, act, slope):
     return ops.act_bwd(d, a_below.view(d.shape), act, slope, out=d)
 
 
+S1_DGRAD_AS_FWD = os.environ.get("PCG_S1_DGRAD_AS_FWD", "1") != "0"   # A/B switch: stride-1 grad-inputs on the forward kernel (adjoint weight)
 FUSE_SKIP_BNSUM = os.environ.get("PCG_SKIP_BNSUM", "1") != "0"   # A/B switch: bn2's backward column sums out of the previous block's skip-add grad-input epilogue
 FUSE_BIAS_COLSUM = True         # A/B switch: conv-bias gradients in front of a BatchNorm out of the BatchNorm backward's apply pass
 FUSE_BACKWARD_EPILOGUE = True   # A/B switch for the tests: activation derivative / BatchNorm-backward sums / skip-connection add in
@@ -321,8 +322,14 @@ class ResidualGenerator(FlatModule):
             _conv_wgrad(self, blk.conv2, g2, a1, dz2, bias_done=cb2 is not None)
             dg1, acc = self._grad_view(blk.bn1.weight)
             db1, _ = self._grad_view(blk.bn1.bias)
-            res = (ops.conv_bwd_data_fused(g2, dz2, ops.ohwi(blk.conv2.weight.data), False, ACT_LRELU, slope, z_below=z1,
-                                           bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data)) if FUSE_BACKWARD_EPILOGUE else None)
+            # stride-1 layers: the grad-input runs on the FORWARD kernel with the adjoint weight (both operands K-major)
+            adj = FUSE_BACKWARD_EPILOGUE and S1_DGRAD_AS_FWD and g2.stride == 1 and ops.xform_ok(g2, "x")
+            if adj:
+                res = ops.conv_bwd_data_fused(ops.adjoint_geom(g2), dz2, ops.conv_weight_adjoint(ops.ohwi(blk.conv2.weight.data)), True,
+                                              ACT_LRELU, slope, z_below=z1, bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data))
+            else:
+                res = (ops.conv_bwd_data_fused(g2, dz2, ops.ohwi(blk.conv2.weight.data), False, ACT_LRELU, slope, z_below=z1,
+                                               bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data)) if FUSE_BACKWARD_EPILOGUE else None)
             cb1, accb1 = self._grad_view(blk.conv1.bias) if (blk.conv1.bias is not None and FUSE_BIAS_COLSUM) else (None, False)
             if res is not None:      # LeakyReLU mask + BatchNorm-backward column sums came out of conv2's grad-input epilogue
                 dz1 = ops.bn_bwd_partial(res[0], z1, C, m1, s1, blk.bn1.weight.data, res[1], res[2], dg1, db1, acc, out=res[0],
@@ -334,12 +341,14 @@ class ResidualGenerator(FlatModule):
             _conv_wgrad(self, blk.conv1, g1, h, dz1, bias_done=cb1 is not None)
             if FUSE_BACKWARD_EPILOGUE:   # skip path + block path: the add happens in conv1's grad-input epilogue, in place
                 nxt = order[bi + 1][1] if (bi + 1 < len(order) and FUSE_SKIP_BNSUM) else None
+                adj1 = S1_DGRAD_AS_FWD and g1.stride == 1 and ops.xform_ok(g1, "x")
+                ga, wa = ((ops.adjoint_geom(g1), ops.conv_weight_adjoint(ops.ohwi(blk.conv1.weight.data))) if adj1
+                          else (g1, ops.ohwi(blk.conv1.weight.data)))
                 if nxt is not None:      # ... together with the BatchNorm-backward sums the NEXT block's bn2 needs from this sum
-                    dh, part, nparts = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh,
-                                                            bnsum=(nxt[7], nxt[8], nxt[9], 0.1))
+                    dh, part, nparts = ops.conv2d_dgrad_add(ga, dz1, wa, dh, out=dh, bnsum=(nxt[7], nxt[8], nxt[9], 0.1), transposed=adj1)
                     pending = (part, nparts)
                 else:
-                    dh = ops.conv2d_dgrad_add(g1, dz1, ops.ohwi(blk.conv1.weight.data), dh, out=dh)
+                    dh = ops.conv2d_dgrad_add(ga, dz1, wa, dh, out=dh, transposed=adj1)
             else:
                 dconv = ops.conv2d_dgrad(g1, dz1, ops.ohwi(blk.conv1.weight.data))
                 dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)

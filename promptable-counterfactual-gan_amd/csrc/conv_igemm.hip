@@ -650,6 +650,54 @@ extern "C" int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, con
   return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
 }
 
+extern "C" int pcg_conv2d_fwd_add(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, float* y,
+                                  void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_ADD;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_fwd_add", g, y, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  return conv2d_fwd_impl(g, x, w, nullptr, y, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
+}
+extern "C" int pcg_conv2d_fwd_add_bnsum(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* z_next,
+                                        const float* mean, const float* invstd, float sum_scale, float* y, void* partial,
+                                        size_t partial_bytes, pcg_stream_t stream) {
+  EpiAux e{};
+  e.mode = EPI_ADDSUM;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common("pcg_conv2d_fwd_add_bnsum", g, y, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  const size_t need = pcg_conv2d_fwd_bn_workspace_bytes(g);
+  PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_add_bnsum: layer not eligible (MFMA layers, channel count %% 4 == 0)");
+  PCG_REQUIRE(z_next && mean && invstd && (((uintptr_t)z_next | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0,
+              "pcg_conv2d_fwd_add_bnsum: z_next / mean / invstd must be non-null and 16-byte aligned");
+  if (!partial || partial_bytes < need) { set_error("pcg_conv2d_fwd_add_bnsum: partial-sum buffer %zu B < required %zu B", partial_bytes, need); return PCG_ERR_WORKSPACE; }
+  e.neg = sum_scale;
+  e.delta2_bytes = (int64_t)((intptr_t)z_next - (intptr_t)y);
+  e.mean = mean; e.invstd = invstd;
+  return conv2d_fwd_impl(g, x, w, nullptr, y, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
+
+namespace pcg { namespace {
+// w[co][kh][kw][ci] -> w_adj[ci][KH-1-kh][KW-1-kw][co]: the OHWI weight of the adjoint (grad-input) convolution of a stride-1 layer
+__global__ void __launch_bounds__(256) weight_adjoint_kernel(const float* __restrict__ w, float* __restrict__ wa, int Cout, int KHW, int Cin) {
+  const int total = Cout * KHW * Cin;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+    const int co = o % Cout, t = o / Cout;           // o indexes w_adj: [ci][tap'][co]
+    const int tapr = t % KHW, ci = t / KHW;
+    wa[o] = w[((size_t)co * KHW + (KHW - 1 - tapr)) * Cin + ci];
+  }
+}
+} }
+// Stride-1 layers: the grad-input convolution is itself a forward convolution of dy with the 180-degree-rotated, channel-transposed
+// weight and padding K-1-pad.  Running it on the FORWARD kernel makes both operands K-major (one ds_read_b128 per fragment
+// instead of four ds_read_b32 for the transposed weight slices of the grad-input kernel): measured r02 on the 3x3 64->64 layers.
+extern "C" int pcg_conv_weight_adjoint(const float* w, float* w_adj, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, pcg_stream_t stream) {
+  PCG_REQUIRE(w && w_adj && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "pcg_conv_weight_adjoint: bad arguments");
+  const int total = Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(weight_adjoint_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, w_adj, Cout, KH * KW, Cin);
+  return launch_status("weight_adjoint_kernel");
+}
+
 extern "C" int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* z_next,
                                           const float* mean, const float* invstd, float sum_scale, float* dx, void* partial,
                                           size_t partial_bytes, pcg_stream_t stream) {

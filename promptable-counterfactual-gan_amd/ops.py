@@ -278,27 +278,50 @@ def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=Non
     return out, partial, nparts
 
 
-def conv2d_dgrad_add(g, dy, w, addend, out=None, bnsum=None):
+def conv_weight_adjoint(w):
+    """OHWI weight of the adjoint convolution of a stride-1 layer: w[co][kh][kw][ci] -> [ci][KH-1-kh][KW-1-kw][co]."""
+    _chk(w, "w")
+    Cout, KH, KW, Cin = w.shape
+    wa = torch.empty((Cin, KH, KW, Cout), dtype=torch.float32, device=w.device)
+    check(_lib.load().pcg_conv_weight_adjoint(_p(w), _p(wa), Cout, KH, KW, Cin, _stream()), "pcg_conv_weight_adjoint")
+    return wa
+
+
+def adjoint_geom(g):
+    """Geometry of the grad-input of a stride-1 convolution seen as a forward convolution of dy (see conv_weight_adjoint)."""
+    assert g.stride == 1
+    return conv_geom(g.B, g.OH, g.OW, g.Cout, g.Cin, g.KH, g.KW, 1, g.KH - 1 - g.pad)
+
+
+def conv2d_dgrad_add(g, dy, w, addend, out=None, bnsum=None, transposed=False):
     """dx = conv_dgrad(dy, w) + addend (out may be `addend`: in place) — the add of a skip connection in the grad-input epilogue.
     bnsum = (z_next, mean, invstd, scale): also leave the BatchNorm-backward column sums of scale*dx for the BatchNorm whose
-    pre-normalisation output is z_next (the next one down the skip chain); returns (dx, partial, nparts) for bn_bwd_partial(dm_scale=scale)."""
+    pre-normalisation output is z_next (the next one down the skip chain); returns (dx, partial, nparts) for bn_bwd_partial(dm_scale=scale).
+    transposed=True: the forward-kernel form (g, w describe a forward convolution whose input is `dy`: ConvTranspose2d layers, or a
+    stride-1 layer through adjoint_geom / conv_weight_adjoint)."""
     _chk(dy, "dy"); _chk(w, "w"); _chk(addend, "addend")
-    assert addend.numel() == g.B * g.IH * g.IW * g.Cin
-    dx = out if out is not None else torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=dy.device)
+    shape = (g.B, g.OH, g.OW, g.Cout) if transposed else (g.B, g.IH, g.IW, g.Cin)
+    assert addend.numel() == shape[0] * shape[1] * shape[2] * shape[3]
+    dx = out if out is not None else torch.empty(shape, dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
     if bnsum is not None:
         z_next, mean, invstd, scale = bnsum
         _chk(z_next, "z_next")
         assert z_next.numel() == dx.numel()
-        lib = _lib.load()
-        need = lib.pcg_conv2d_dgrad_bn_workspace_bytes(ctypes.byref(g))
+        need = (lib.pcg_conv2d_fwd_bn_workspace_bytes if transposed else lib.pcg_conv2d_dgrad_bn_workspace_bytes)(ctypes.byref(g))
         if need == 0:
             raise _lib.PcgError("conv2d_dgrad_add(bnsum=...): layer not eligible for the fused column sums")
-        nparts = lib.pcg_conv2d_dgrad_bn_partial_rows(ctypes.byref(g))
+        nparts = (lib.pcg_conv2d_fwd_bn_partial_rows if transposed else lib.pcg_conv2d_dgrad_bn_partial_rows)(ctypes.byref(g))
         partial = torch.empty(need // 4, dtype=torch.float32, device=dy.device)
-        with _Timed(g, "dgrad"):
-            check(lib.pcg_conv2d_dgrad_add_bnsum(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(z_next), _p(mean), _p(invstd), float(scale),
-                                                 _p(dx), _p(partial), need, _stream()), "pcg_conv2d_dgrad_add_bnsum")
+        fn = lib.pcg_conv2d_fwd_add_bnsum if transposed else lib.pcg_conv2d_dgrad_add_bnsum
+        with _Timed(g, "fwd" if transposed else "dgrad"):
+            check(fn(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(z_next), _p(mean), _p(invstd), float(scale),
+                     _p(dx), _p(partial), need, _stream()), "pcg_conv2d_*_add_bnsum")
         return dx, partial, nparts
+    if transposed:
+        with _Timed(g, "fwd"):
+            check(lib.pcg_conv2d_fwd_add(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(dx), None, 0, _stream()), "pcg_conv2d_fwd_add")
+        return dx
     with _Timed(g, "dgrad"):
         check(_lib.load().pcg_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(dx), None, 0, _stream()), "pcg_conv2d_dgrad_add")
     return dx

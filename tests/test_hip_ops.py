@@ -414,3 +414,28 @@ def test_bn_backward_with_fused_bias_colsum(pcg, rows, C, act):
     dcol2 = torch.empty(C, device="cuda:0")
     ops.bn_act_bwd(dy, x, None, C, mean, invstd, gam, act, 0.2, dg2, db2, False, beta=bet, dy_scale=0.5, dcol=dcol2, accumulate_col=False)
     np.testing.assert_allclose(dcol2.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-6 * float(ref.abs().sum(0).max()) + 1e-6)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,p", [(3, 64, 64, 28, 28, 3, 1), (2, 32, 48, 9, 7, 3, 1), (2, 64, 32, 8, 8, 1, 0), (2, 16, 24, 10, 10, 5, 2)])
+def test_stride1_grad_input_as_forward_conv_with_adjoint_weight(pcg, B, Cin, Cout, H, W, k, p):
+    """pcg_conv_weight_adjoint + the forward kernel on dy (geometry {OHxOW, Cout -> IHxIW, Cin, pad K-1-p}) is the grad-input of a
+    stride-1 convolution: compared with the grad-input kernel (same products, another summation order) and with float64."""
+    ops = pcg.ops
+    g = torch.Generator(device="cuda:0").manual_seed(B + Cin + k)
+    geom = ops.conv_geom(B, H, W, Cin, Cout, k, k, 1, p)
+    w = torch.randn(Cout, k, k, Cin, generator=g, device="cuda:0") / math.sqrt(Cout * k * k)
+    dy = torch.randn(B, geom.OH, geom.OW, Cout, generator=g, device="cuda:0")
+    wa = ops.conv_weight_adjoint(w)
+    assert torch.equal(wa, w.flip(1, 2).permute(3, 1, 2, 0).contiguous())
+    ga = ops.adjoint_geom(geom)
+    assert (ga.OH, ga.OW, ga.Cout) == (H, W, Cin)
+    got = ops.conv2d_fwd(ga, dy, wa)
+    ref = ops.conv2d_dgrad(geom, dy, w)
+    wt = w.permute(0, 3, 1, 2).double().cpu()
+    truth = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double().cpu(), wt, stride=1, padding=p).permute(0, 2, 3, 1)
+    tol = _tol(Cout * k * k, 1.0 / math.sqrt(Cout * k * k)) if "_tol" in globals() else 1e-4
+    assert float((got.cpu().double() - truth).abs().max()) <= max(tol, 2e-5)
+    assert float((got - ref).abs().max()) <= 2e-5
+    addend = torch.randn(B, H, W, Cin, generator=g, device="cuda:0")
+    assert torch.equal(ops.conv2d_dgrad_add(ga, dy, wa, addend, transposed=True), got + addend) or \
+        float((ops.conv2d_dgrad_add(ga, dy, wa, addend, transposed=True) - (got + addend)).abs().max()) <= 1e-6
