@@ -486,11 +486,16 @@ class Discriminator(FlatModule):
         return (getattr(self, "use_fused", True) and [l.out_features for l in lins] == [32, 64, 128, 1] and lins[0].in_features == 21
                 and x.shape[1] + target_onehot.shape[1] == 21)
 
-    def _run_forward(self, x, target_onehot, keep=True):
+    def _spectral_norm(self):
+        """Power iteration (training mode: updates u, v in place) + W / sigma of all four layers: one launch."""
         lins = self._linears()
-        # power iteration + W / sigma of all four layers: one launch
-        sn = ops.spectral_norm_fwd_batched([l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins],
-                                           1e-12, self.training)
+        return ops.spectral_norm_fwd_batched([l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins],
+                                             1e-12, self.training)
+
+    def _run_forward(self, x, target_onehot, keep=True, sn=None):
+        lins = self._linears()
+        if sn is None:
+            sn = self._spectral_norm()
         if self._fused_ok(x, target_onehot):
             # the four layers as ONE launch, one thread per row (csrc/house_critic_fused.hip)
             import ctypes
@@ -515,7 +520,9 @@ class Discriminator(FlatModule):
             a = z
         return a, (layers if keep else None)
 
-    def _fused_backward(self, saved, dout, need_x, need_p):
+    def _fused_backward(self, saved, dout, need_x, need_p, gtarget=None):
+        """gtarget: a flat buffer with the layout of flat_grads that receives this pass's parameter gradients (written, not
+        accumulated) instead of the module's gradient buffer — see FlatModule.grad_view_in."""
         from ._lib import load
         _, acts, sn = saved
         lins = self._linears()
@@ -531,17 +538,23 @@ class Discriminator(FlatModule):
             items, sn_items = [], []
             for lin, a, d, (w_bar, sigma, u, v) in zip(lins, acts, (d1, d2, d3, d4), sn):
                 dwb = torch.empty_like(w_bar)
-                gb, accb = self._grad_view(lin.bias)
+                if gtarget is None:
+                    gb, accb = self._grad_view(lin.bias)
+                    gw, acc = self._grad_view(lin.weight_orig)
+                else:
+                    gb, accb = self.grad_view_in(gtarget, lin.bias), False
+                    gw, acc = self.grad_view_in(gtarget, lin.weight_orig), False
                 items.append((d, a, lin.out_features, lin.in_features, dwb, gb, lin.out_features, lin.in_features, False, accb))
-                gw, acc = self._grad_view(lin.weight_orig)
                 sn_items.append((dwb, w_bar, u, v, sigma, gw, acc))
             ops.linear_wgrad_grouped(items, B, d4.device)                                    # all weight + bias gradients: one launch
             ops.spectral_norm_bwd_batched(sn_items)                                          # through W / sigma: one launch
         return dx
 
-    def _run_backward(self, layers, dout, need_x, need_p):
+    def _run_backward(self, layers, dout, need_x, need_p, gtarget=None):
         if layers[0] == "fused":
-            return self._fused_backward(layers, dout, need_x, need_p)
+            return self._fused_backward(layers, dout, need_x, need_p, gtarget)
+        if gtarget is not None:
+            raise PcgError("Discriminator: a separate gradient target needs the fused critic kernels")
         lins = self._linears()
         d = dout.contiguous()
         B = d.shape[0]
@@ -749,6 +762,9 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     exists and runs beside the whole critic update; it joins where g_loss is formed.  autograd runs a node's backward on the
     stream its forward ran on, so the classifier's backward overlaps the critic's in the G step too.  Same kernels, same inputs:
     results are bit-identical to the single-stream order; captured in a HIP graph the two streams become parallel branches."""
+    if branch is not None:
+        return _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel,
+                                  branch, skip_dead_d_wgrad)
     nc = config["num_classes"]
     ce = ce if ce is not None else CrossEntropyLoss()
     target_onehot = ops.onehot(target_y, nc)                                                  # :250
@@ -756,43 +772,12 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
                                                 gumbel=gumbel)                                # :259-261
     residual_full = assemble_residual(generator, cont, samples, x, norm_vals)                 # :266-279
     masked_residual, x_cf = _MaskMulFn.apply(residual_full, mask, x)                          # :281-282
-    g_cls = dx_cls = am = None
-    if branch is None:
-        mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                      # :287
-    else:
-        # fork: the classifier term of the G step (:301-302) needs only x_cf and a frozen net, and its weight in g_loss is a
-        # constant — so its forward, the cross-entropy (value AND gradient in one launch) and its grad-input sweep all run here,
-        # beside the critic update; the resulting d(lambda_cls * g_cls)/d(x_cf) is injected into autograd's sweep below.
-        # (grad_scale = lambda_cls, grad_out = 1: the same product the autograd path forms from weighted_sum's backward.)
-        if classifier.training or any(p.requires_grad for p in classifier.parameters()):
-            raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
-        # Off the critical chain as well: the two L1 penalties (:287, :305 — forward here, so autograd runs their backward on the
-        # branch, beside the critic's), and the gradient buffers are zeroed up front (nothing writes them before the backward
-        # passes; the reference zeroes them right before each backward, :293, :314).
-        main = torch.cuda.current_stream()
-        branch.wait_stream(main)
-        with torch.cuda.stream(branch):
-            opt_d.zero_grad(); opt_g.zero_grad()
-            zeroed = torch.cuda.Event()
-            zeroed.record(branch)
-            mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                  # :287
-            am = abs_mean(masked_residual)                                                    # :305
-        residual_full.record_stream(branch); masked_residual.record_stream(branch); mask.record_stream(branch)
-        with torch.cuda.stream(branch), torch.no_grad():
-            logits_c, acts_c = classifier._run_forward(x_cf.detach().contiguous(), keep=True)
-            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
-                                                    grad_scale=float(config["lambda_cls"]))
-            dx_cls = classifier._run_backward(acts_c, dlog)
-            g_cls = g_cls.view(())
-        x_cf.record_stream(branch); target_y.record_stream(branch)
+    mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                          # :287
     # ---- D step
     d_real = discriminator(x, ops.onehot(y, nc))                                              # :290
     d_fake = discriminator(x_cf.detach(), target_onehot)                                      # :291
     d_loss = weighted_sum([mean(d_fake), mean(d_real)], [1.0, -1.0])                          # :292
-    if branch is None:
-        opt_d.zero_grad()
-    else:                            # the zero fills were issued on the branch: the backward passes must see them
-        torch.cuda.current_stream().wait_event(zeroed)
+    opt_d.zero_grad()
     d_loss.backward(gradient=_one(x.device))
     opt_d.step()                                                                              # :293-295
     # ---- G step
@@ -800,43 +785,163 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
         for p in discriminator.parameters():
             p.requires_grad_(False)
     try:
-        if g_cls is None:
-            x_cf_g = x_cf
-        else:                                                                                 # join the classifier branch
-            torch.cuda.current_stream().wait_stream(branch)
-            g_cls.record_stream(torch.cuda.current_stream()); dx_cls.record_stream(torch.cuda.current_stream())
-            x_cf_g = _InjectGradFn.apply(x_cf, dx_cls)
-        d_fake_for_g = discriminator(x_cf_g, target_onehot)                                   # :298
+        d_fake_for_g = discriminator(x_cf, target_onehot)                                     # :298
         m_fake = mean(d_fake_for_g)
-        if g_cls is None:
-            g_cls = ce(classifier(x_cf), target_y)                                            # :301-302
-        if am is None:
-            am = abs_mean(masked_residual)                                                    # :305  mean_b ||.||_1 = D * mean|.|
-        else:
-            am.record_stream(torch.cuda.current_stream()); mask_penalty_pre.record_stream(torch.cuda.current_stream())
+        g_cls = ce(classifier(x_cf), target_y)                                                # :301-302
+        am = abs_mean(masked_residual)                                                        # :305  mean_b ||.||_1 = D * mean|.|
         d_feat = float(x.shape[1])
         g_loss = weighted_sum([m_fake, g_cls, am, mask_penalty_pre],
                               [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]])   # :299, :307-312
-        if branch is None:
-            with torch.no_grad():                                                             # logged values
-                g_adv = weighted_sum([m_fake], [-1.0])
-                g_reg = weighted_sum([am], [d_feat])
-            opt_g.zero_grad()
-        else:                                                                                 # logged values: beside the backward sweep
-            branch.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(branch), torch.no_grad():
-                g_adv = weighted_sum([m_fake], [-1.0])
-                g_reg = weighted_sum([am], [d_feat])
-            m_fake.record_stream(branch)
+        with torch.no_grad():                                                                 # logged values
+            g_adv = weighted_sum([m_fake], [-1.0])
+            g_reg = weighted_sum([am], [d_feat])
+        opt_g.zero_grad()
         g_loss.backward(gradient=_one(x.device))                                              # :314-315
     finally:
         if skip_dead_d_wgrad:
             for p in discriminator.parameters():
                 p.requires_grad_(True)
     opt_g.step()                                                                              # :316
-    if branch is not None:
-        torch.cuda.current_stream().wait_stream(branch)                                       # final join (the logged values)
-        g_adv.record_stream(torch.cuda.current_stream()); g_reg.record_stream(torch.cuda.current_stream())
+    return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
+            "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+
+
+_cot_cache = {}
+_alt_cache = {}
+
+
+def _alt_grads(net):
+    """A second, zero-initialised gradient buffer with the layout of net.flat_grads (kept per net: passes that target it WRITE
+    every parameter's gradient, the padding between parameters stays zero)."""
+    g = net.flat_grads
+    key = (id(net), g.data_ptr())
+    a = _alt_cache.get(key)
+    if a is None:
+        a = ops.fill(torch.empty_like(g), 0.0)
+        _alt_cache[key] = a
+    return a
+
+
+
+def _mean_cotangents(B, device):
+    """(+1/B, -1/B) as [B, 1] tensors: d(mean(out))/d(out) scaled by the Wasserstein losses' weights (+1 and -1, trainer.py:292, :299).
+    They are constants of the step, so the critic's backward can start the moment its forward is done — no loss kernels on the
+    chain.  Built once with the very kernels autograd would run (weighted_sum's backward, then mean's backward): same bits."""
+    key = (int(B), device)
+    c = _cot_cache.get(key)
+    if c is None:
+        like = torch.empty((B, 1), dtype=torch.float32, device=device)
+        gpos, gneg = ops.weighted_sum_bwd((1.0, -1.0), _one(device).view(1), (True, True))
+        c = (ops.mean_bwd(gpos.contiguous(), 1.0, like), ops.mean_bwd(gneg.contiguous(), 1.0, like))
+        _cot_cache[key] = c
+    return c
+
+
+def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
+                       skip_dead_d_wgrad):
+    """train_step scheduled for the length of its dependency chain (the step is ~90 kernels of 64 blocks each on a 256-CU chip):
+    what the reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager), with
+
+      * the frozen classifier's whole term (:301-302) — forward, cross-entropy value AND gradient in one launch (grad_scale =
+        lambda_cls, exactly the product autograd forms), grad-input sweep — on the `branch` stream beside the critic update;
+      * the two L1 penalties (:287, :305) forward on the branch, so autograd runs their backward there too; the gradient zero-fills
+        and every logged scalar (D_loss, G_loss, g_adv, g_reg) on the branch as well;
+      * the critic passes run directly (no autograd nodes): the cotangents of the Wasserstein means are the constants +-1/B
+        (_mean_cotangents), so each critic backward starts right behind its forward; the real and the fake pass accumulate into
+        the zeroed gradient buffers (a + b == b + a);
+      * the G step's two gradient contributions to x_cf (critic: -1/B through D; classifier: from the branch) are added once and
+        handed to autograd as the gradient of x_cf, next to the scalar lambda_reg*d*am + lambda_mask*pen.
+    Captured in a HIP graph the two streams are parallel branches."""
+    nc, dev, B = config["num_classes"], x.device, x.shape[0]
+    if classifier.training or any(p.requires_grad for p in classifier.parameters()):
+        raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
+    branch, branch2 = branch if isinstance(branch, (tuple, list)) else (branch, None)
+    main = torch.cuda.current_stream()
+    discriminator._ensure_flat()
+    cot_pos, cot_neg = _mean_cotangents(B, dev)
+    d_feat = float(x.shape[1])
+    target_onehot = ops.onehot(target_y, nc)                                                  # :250
+    cont, _, samples = generator.forward_packed(x, target_onehot, mask, temperature=config["gumbel_tau"], hard=False,
+                                                gumbel=gumbel)                                # :259-261
+    residual_full = assemble_residual(generator, cont, samples, x, norm_vals)                 # :266-279
+    masked_residual, x_cf = _MaskMulFn.apply(residual_full, mask, x)                          # :281-282
+    # ---- fork
+    branch.wait_stream(main)
+    with torch.cuda.stream(branch):
+        opt_d.zero_grad(); opt_g.zero_grad()
+        zeroed = torch.cuda.Event()
+        zeroed.record(branch)
+        mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                      # :287
+        am = abs_mean(masked_residual)                                                        # :305
+        with torch.no_grad():
+            logits_c, acts_c = classifier._run_forward(x_cf.detach().contiguous(), keep=True)                 # :301
+            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
+                                                    grad_scale=float(config["lambda_cls"]))                  # :302
+            dx_cls = classifier._run_backward(acts_c, dlog)
+            g_cls = g_cls.view(())
+    for t in (residual_full, masked_residual, mask, x_cf, target_y):
+        t.record_stream(branch)
+    # ---- D step (:290-295)
+    xd = x_cf.detach()
+    onehot_y = ops.onehot(y, nc)
+    with torch.no_grad():
+        if branch2 is None or not discriminator._fused_ok(x, onehot_y):
+            d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True)                 # :290
+            d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291
+            main.wait_event(zeroed)                                                           # the zero fills were issued on the branch
+            discriminator._run_backward(sv_f, cot_pos, False, True)                           # d(mean(d_fake) - mean(d_real))
+            discriminator._run_backward(sv_r, cot_neg, False, True)
+        else:
+            # (Opt-in, `GraphedTrainStep(overlap="critic")`: measured r02 without gain — 0.857 vs 0.856 ms — because the classifier
+            # branch is then the longest chain, and every cross-queue edge of the graph costs ~10 us; with the zero-fills moved onto
+            # this third stream as well the step went to 1.10 ms.)
+            # The real pass and the fake pass only share the spectral-norm state: the reference's two forward calls each run a
+            # power iteration, in this order (so the passes use different sigma and cannot be batched).  After the first one the
+            # WHOLE real pass — critic forward, backward, weight gradients, the backward through W/sigma — runs on a third
+            # stream into a second gradient buffer, beside the second power iteration and the fake pass; one add joins them
+            # ((0 + a) + b either way).
+            sn_r = discriminator._spectral_norm()                                             # power iteration of the D(real) call
+            alt = _alt_grads(discriminator)
+            branch2.wait_stream(main)                                                         # (behind the zero-fills it carries)
+            with torch.cuda.stream(branch2):
+                d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True, sn=sn_r)    # :290
+                discriminator._run_backward(sv_r, cot_neg, False, True, gtarget=alt)
+            for t in (x, onehot_y, cot_neg) + tuple(tt for grp in sn_r for tt in grp):
+                t.record_stream(branch2)
+            d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291 (its own power iteration)
+            main.wait_event(zeroed)
+            discriminator._run_backward(sv_f, cot_pos, False, True)
+            main.wait_stream(branch2)
+            d_real.record_stream(main)
+            ops.axpby(1.0, discriminator.flat_grads, 1.0, alt, out=discriminator.flat_grads)
+    opt_d.step()                                                                              # :295
+    # ---- G step (:298-316)
+    with torch.no_grad():
+        d_fake_for_g, sv_g = discriminator._run_forward(xd, target_onehot, keep=True)         # :298
+        fwd_done = torch.cuda.Event()
+        fwd_done.record(main)
+        dx_d = discriminator._run_backward(sv_g, cot_neg, True, not skip_dead_d_wgrad)        # d(-mean(D(x_cf)))/d(x_cf)
+    # the logged scalars: on the branch, as soon as the last critic forward is out
+    branch.wait_event(fwd_done)
+    with torch.cuda.stream(branch), torch.no_grad():
+        m_fake = ops.mean_fwd(d_fake_for_g.contiguous()).view(())
+        d_loss = ops.weighted_sum_fwd([ops.mean_fwd(d_fake.contiguous()), ops.mean_fwd(d_real.contiguous())], [1.0, -1.0]).view(())   # :292
+        g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am.detach(), mask_penalty_pre.detach()],
+                                      [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]]).view(())   # :307-312
+        g_adv = ops.weighted_sum_fwd([m_fake], [-1.0]).view(())
+        g_reg = ops.weighted_sum_fwd([am.detach()], [d_feat]).view(())
+    for t in (d_real, d_fake, d_fake_for_g):
+        t.record_stream(branch)
+    main.wait_stream(branch)                                                                  # join: dx_cls, am, mask_penalty_pre
+    for t in (dx_cls, am, mask_penalty_pre):
+        t.record_stream(main)
+    gx = ops.axpby(1.0, dx_d, 1.0, dx_cls)                                                    # gradient of g_loss w.r.t. x_cf
+    g_rest = weighted_sum([am, mask_penalty_pre], [config["lambda_reg"] * d_feat, config["lambda_mask"]])
+    torch.autograd.backward([g_rest, x_cf], [_one(dev), gx])                                  # :314-315
+    opt_g.step()                                                                              # :316
+    main.wait_stream(branch)                                                                  # final join
+    for t in (d_loss, g_loss, g_adv, g_reg, g_cls):
+        t.record_stream(main)
     return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
             "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
 
@@ -912,7 +1017,12 @@ class GraphedTrainStep:
 
     def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap=True):
         dev = norm_vals.device
-        self.branch = torch.cuda.Stream(device=dev) if overlap else None      # the classifier branch (train_step `branch`)
+        # train_step's parallel branch: the classifier term (+ penalties, zero-fills, logged sums); overlap="critic" adds a third
+        # stream for the critic's real pass (bit-identical, no gain measured: see _train_step_branch)
+        if overlap == "critic":
+            self.branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        else:
+            self.branch = torch.cuda.Stream(device=dev) if overlap else None
         D_in, T = config["input_dim"], generator.total_cat
         self.x = torch.zeros((batch, D_in), dtype=torch.float32, device=dev)
         self.y = torch.zeros((batch,), dtype=torch.int64, device=dev)

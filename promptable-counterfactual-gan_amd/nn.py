@@ -97,6 +97,14 @@ class FlatModule(nn.Module):
                 return gv, acc
         raise PcgError("parameter does not belong to this FlatModule")
 
+    def grad_view_in(self, buf, p):
+        """The view of parameter p's gradient inside `buf`, a flat buffer with the layout of flat_grads (a second gradient
+        accumulator: two backward passes that run on parallel streams write one buffer each and are added once)."""
+        for q, off, n in self._seg:
+            if q is p:
+                return self._views(self._flat, buf, p, off, n)[1]
+        raise PcgError("parameter does not belong to this FlatModule")
+
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffer in one launch and keep the .grad views (set_to_none is ignored: the
         views are the gradient storage; values after backward are identical either way)."""

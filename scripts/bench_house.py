@@ -102,7 +102,7 @@ def main():
                                f"Discriminator, frozen NNClassifier), 17 features, batch {B}, full step incl. per-step device draws",
                    "global_batch": B, "parallelism": "dp1"},
         "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
-        "launch": "eager" if gs is None else ("hip-graph replay (1 graph" + (", classifier branch parallel to the critic update" if gs.branch is not None else "")
+        "launch": "eager" if gs is None else ("hip-graph replay (1 graph" + (", classifier term on a parallel branch" if gs.branch is not None else "")
                                             + ") + 3 RNG launches per step drawing into its input buffers"),
     })
     R.finish()

@@ -379,9 +379,13 @@ def test_fused_critic_kernels_match_the_op_chain(pcg, hgold):
         _close(res[0][3][n], res[1][3][n], 1e-6, 1e-7, f"buffer {n}")
 
 
-def test_graphed_step_equals_eager(pcg, hgold):
+@pytest.mark.parametrize("overlap", [True, "critic", False])
+def test_graphed_step_equals_eager(pcg, hgold, overlap):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
-    it (warm-up + capture) does not advance the training state."""
+    it (warm-up + capture) does not advance the training state.  overlap=True: the schedule with the classifier term on a parallel
+    branch and the critic passes run directly with constant cotangents (house._train_step_branch); "critic": additionally the
+    critic's real pass on a third stream into a second gradient buffer; False: the reference-order single-stream step.  All three
+    are bit-identical to the eager autograd step."""
     H = pcg.house
     batches = [HR.synthetic_batch(128, seed=s) for s in (1, 2, 3)]
     states = []
@@ -389,7 +393,7 @@ def test_graphed_step_equals_eager(pcg, hgold):
         G, D, C = _load_golden_nets(pcg, hgold)
         opt_g, opt_d = H.make_optimizers(G, D)
         norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, 128) if graphed else None
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, 128, overlap=overlap) if graphed else None
         losses = []
         for (x, y, t, m, gumbel) in batches:
             noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
