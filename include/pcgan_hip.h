@@ -279,7 +279,9 @@ int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t step, pcg_stream_t stream);
 
 /* hipGraph-capturable form: the step count lives on the device (*step_counter_dev is incremented by the
- * call) and the bias corrections are computed there in fp64; hyper_scratch2_dev is 2 floats of scratch. */
+ * call) and the bias corrections are computed there in fp64, inside the update kernel itself: its last block to
+ * finish stores the new count.  hyper_scratch2_dev is 8 bytes the caller zero-initialises ONCE and then leaves
+ * alone (the last-block ticket; every call leaves it zero). */
 int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled_wd,
                              int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream);
@@ -539,6 +541,13 @@ int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t B, int32_t
                          const float* const* bias, float slope, float* a0, float* a1, float* a2, float* a3, float* out, pcg_stream_t stream);
 int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* const* w_bar, float slope, const float* a1, const float* a2,
                          const float* a3, float* d3, float* d2, float* d1, float* dx /*nullable*/, pcg_stream_t stream);
+
+/* The scalars the tabular trainer logs per step (house_sales_kc_usa/trainer.py:292, :299, :307-312, :318-330) in one launch:
+ * out5 = { D_loss = mean(d_fake) - mean(d_real), G_loss = -mean(d_fake_g) + lambda_cls*g_cls + w_reg*am + lambda_mask*pen,
+ *          g_adv = -mean(d_fake_g), g_reg = w_reg_log*am, mean(d_fake_g) } — the same reduction trees and fma chains as
+ * pcg_mean_fwd + pcg_weighted_sum_fwd (bit-identical values), n <= 16384 critic outputs. */
+int pcg_house_losses(const float* d_real, const float* d_fake, const float* d_fake_g, int64_t n, const float* g_cls, const float* am,
+                     const float* pen, float lambda_cls, float w_reg, float lambda_mask, float w_reg_log, float* out5, pcg_stream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per

@@ -4,9 +4,14 @@
 // weights of a segment sit in LDS and are read as broadcasts, the rows' input vectors are parked in LDS between layers.  The only
 // cross-row dependencies are the ten BatchNorm1d batch statistics, so the net is cut there: a segment ends by writing its
 // pre-BatchNorm activations plus per-block column sums, and the next segment starts by turning those sums into mean / invstd
-// (fixed order, fp64) — the kernel boundary is the grid barrier.  Forward = 12 launches (op chain: ~95), backward = 11 launches
-// + the weight-gradient reductions (op chain: ~190).  Hidden width 32, 5 residual blocks (the reference's configuration)
+// (fixed order, fp64) — the kernel boundary is the grid barrier.  (A persistent launch whose blocks meet at an arrival counter in
+// global memory was built and measured in round 2: a dependent launch inside a single-stream HIP graph costs 1.8 us on this part,
+// a 64-block grid barrier with agent-scope release / acquire 3.9 us, 9.5 us at 256 blocks — scripts/probes/grid_barrier_probe.hip —
+// and the persistent forward ran 181 us against 157 us.  What a segment costs is its chain of dependent cold global loads, so
+// every segment issues ALL its global loads before its first barrier.)  Forward = 12 launches (op chain: ~95), backward = 11
+// launches + the weight-gradient reductions (op chain: ~190).  Hidden width 32, 5 residual blocks (the reference's configuration)
 // are compile-time; other configurations use the op-chain path.
+#include <cstddef>
 #include <cstring>
 #include "pcg_common.h"
 
@@ -21,7 +26,7 @@ constexpr int MAXCOND = NCLS + DIN;          // cond = (one-hot target, mask)
 constexpr int MAXIN = DIN + MAXCOND;         // fc_in input = (x, cond)
 constexpr int MAXT = 96;          // packed categorical columns <= 96
 constexpr int MAXHEADS = 8;
-constexpr int FT = 64;            // threads per block = rows per block: one wave, so 4096 rows spread over 64 CUs
+constexpr int FT = 64;            // rows per block (lane = row); a block is four such waves: 4096 rows = 64 blocks of 256 threads
 
 struct GDesc {                    // element offsets into the flat parameter (and gradient) buffer + dimensions
   int fc_in_w, fc_in_b;
@@ -48,102 +53,6 @@ struct GBufs {
 
 struct BNState { float* running_mean[2 * NBLK]; float* running_var[2 * NBLK]; int64_t* nbt[2 * NBLK]; };
 
-// ---- small helpers ---------------------------------------------------------------------------------------------------------
-// Weight matrices are NOT staged: every lane of a wave needs the same element at the same time, so they are read from
-// global memory at wave-uniform addresses — scalar loads into SGPRs that feed v_fma directly (no LDS traffic, no VGPRs).
-// Staging them in LDS and reading broadcasts was measured slower (60-86 us vs 34-64 us per segment at B = 4096).
-__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += FT) dst[i] = src[i];
-}
-
-// Matrix-vector products of one segment, per lane (= per batch row).  A fully unrolled 32x32 product is 1024 FMAs of straight-
-// line code per layer — measured, the segment kernels then spend their time FETCHING INSTRUCTIONS (every line of a 50-100 KB
-// kernel is a cold miss executed once).  Instead the loop over the input index stays rolled: the weight matrix is staged
-// transposed in LDS ([i][j], so one input index needs 32 contiguous weights = 8 broadcast ds_read_b128), the lane's input
-// vector is parked in LDS ([i][lane], conflict-free), and the 32 accumulators live in registers.  ~40 instructions per
-// input index, a few hundred bytes of code per layer.
-//   out[j] = b[j] + sum_i W[j][i] in[i]          W row-major [HH][K] in global memory
-template <int K>
-__device__ __forceinline__ void lin_to32(float* lds, const float* __restrict__ W, const float* __restrict__ b, const float (&in)[K],
-                                         float (&out)[HH]) {
-  float* Wt = lds; float* bl = lds + K * HH; float* V = bl + HH;
-  __syncthreads();                                           // the scratch area is free again
-  for (int e = threadIdx.x; e < K * HH; e += FT) { const int j = e / K, i = e - j * K; Wt[i * HH + j] = W[e]; }
-  if (threadIdx.x < HH) bl[threadIdx.x] = b[threadIdx.x];
-#pragma unroll
-  for (int i = 0; i < K; ++i) V[i * FT + threadIdx.x] = in[i];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < HH; ++j) out[j] = bl[j];
-#pragma unroll 1
-  for (int i = 0; i < K; ++i) {
-    const float a = V[i * FT + threadIdx.x];
-    const float* w = Wt + i * HH;
-#pragma unroll
-    for (int j = 0; j < HH; ++j) out[j] = fmaf(w[j], a, out[j]);
-  }
-}
-template <int KMAX>
-__device__ __forceinline__ void lin_to32_rt(float* lds, const float* __restrict__ W, const float* __restrict__ b, const float (&in)[KMAX], int,
-                                            float (&out)[HH]) {
-  lin_to32<KMAX>(lds, W, b, in, out);
-}
-// per-block column sums of v[0..31] and w[0..31] over the block's rows -> part[2][HH] of this block (fixed order)
-__device__ __forceinline__ void block_colsums(const float (&v)[HH], const float (&w)[HH], float* red /* [FT][HH+1] */,
-                                              float* red2 /* [8][HH] */, float* part) {
-  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < HH; ++j) red[threadIdx.x * (HH + 1) + j] = pass == 0 ? v[j] : w[j];
-    __syncthreads();
-    float s = 0.f;
-    for (int r = 0; r < 32; ++r) s += red[(g * 32 + r) * (HH + 1) + c];     // FT / 32 row groups
-    red2[g * HH + c] = s;
-    __syncthreads();
-    if (threadIdx.x < HH) {
-      float t = 0.f;
-      for (int q = 0; q < FT / 32; ++q) t += red2[q * HH + threadIdx.x];
-      part[pass * HH + threadIdx.x] = t;
-    }
-  }
-  __syncthreads();
-}
-
-// mean / invstd of a BatchNorm from the per-block partials (fp64, block order); block 0 also maintains the module's buffers
-__device__ __forceinline__ void bn_finalize(const float* P, int nblocks, int B, float eps, float momentum, float* s_mean, float* s_inv,
-                                            float* save, float* rmean, float* rvar, int64_t* nbt) {
-  // all 64 lanes: lane (c, half) adds the partials of blocks half, half+2, ... of column c (8 loads in flight), then the two
-  // halves are combined in a fixed order
-  __shared__ double fin[2][2][HH];
-  if (threadIdx.x < FT) {   // (the four-wave kernels call this with 256 threads: the first wave does the work)
-    const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
-    double s0 = 0.0, q0 = 0.0;
-#pragma unroll 8
-    for (int b = half; b < nblocks; b += 2) { s0 += (double)P[(size_t)b * 2 * HH + c]; q0 += (double)P[(size_t)b * 2 * HH + HH + c]; }
-    fin[half][0][c] = s0; fin[half][1][c] = q0;
-  }
-  __syncthreads();
-  if (threadIdx.x < HH) {
-    const double s = fin[0][0][threadIdx.x] + fin[1][0][threadIdx.x], q = fin[0][1][threadIdx.x] + fin[1][1][threadIdx.x];
-    const double mean = s / B;
-    double var = q / B - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float inv = (float)(1.0 / sqrt(var + (double)eps));
-    s_mean[threadIdx.x] = (float)mean; s_inv[threadIdx.x] = inv;
-    if (blockIdx.x == 0) {
-      save[threadIdx.x] = (float)mean; save[HH + threadIdx.x] = inv;
-      if (rmean) {
-        const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
-        rmean[threadIdx.x] = (float)((1.0 - momentum) * rmean[threadIdx.x] + momentum * mean);
-        rvar[threadIdx.x] = (float)((1.0 - momentum) * rvar[threadIdx.x] + momentum * unb);
-        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 __device__ __forceinline__ void load32(const float* p, size_t row, bool on, float (&v)[HH]) {
 #pragma unroll
   for (int j = 0; j < HH; j += 4) {
@@ -157,74 +66,77 @@ __device__ __forceinline__ void store32(float* p, size_t row, bool on, const flo
   for (int j = 0; j < HH; j += 4) *reinterpret_cast<float4*>(p + row * HH + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
 }
 
-// LDS layout shared by the kernels (floats)
-struct alignas(16) Smem {
-  float red[FT * (HH + 1)];
-  float red2[(FT / 32) * HH];
-  float gamma[HH], beta[HH], mean[HH], inv[HH];
-  float sums[2 * HH];
-  float lin[MAXIN * HH + HH + MAXIN * FT];     // scratch of lin_to32: transposed weights, bias, the lanes' input vectors
-};
-
-// ---- forward ---------------------------------------------------------------------------------------------------------------
-// kind 0: fc_in + ReLU -> h0; z1_0 = fc1_0(h0), partial statistics
-__global__ void __launch_bounds__(FT) g_fwd_first_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
-  __shared__ Smem s;
-  constexpr int K = MAXIN;
-  const int row = blockIdx.x * FT + threadIdx.x;
-  const bool on = row < a.B;
-  float inp[MAXIN];
-#pragma unroll
-  for (int i = 0; i < DIN; ++i) inp[i] = on ? a.x[(size_t)row * DIN + i] : 0.f;
-#pragma unroll
-  for (int i = 0; i < NCLS; ++i) inp[DIN + i] = on ? a.onehot[(size_t)row * NCLS + i] : 0.f;
-#pragma unroll
-  for (int i = 0; i < DIN; ++i) inp[DIN + NCLS + i] = on ? a.mask[(size_t)row * DIN + i] : 0.f;
-  if (on) {
-#pragma unroll
-    for (int i = 0; i < K; ++i) a.inp[(size_t)row * K + i] = inp[i];
-  }
-  float h[HH], z[HH], zz[HH];
-  lin_to32_rt<MAXIN>(s.lin, PRM + d.fc_in_w, PRM + d.fc_in_b, inp, K, h);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
-  store32(a.H, row, on, h);
-  lin_to32<HH>(s.lin, PRM + d.fc1_w[0], PRM + d.fc1_b[0], h, z);
-  store32(a.Z1, row, on, z);
-#pragma unroll
-  for (int j = 0; j < HH; ++j) { z[j] = on ? z[j] : 0.f; zz[j] = z[j] * z[j]; }
-  block_colsums(z, zz, s.red, s.red2, a.P + (size_t)blockIdx.x * 2 * HH);
-}
-
-// ---- forward, four waves per 64 rows --------------------------------------------------------------------------------------------
-// One thread per row (above) runs 4096 rows as 64 waves on 1024 SIMDs.  Here a block is the same 64 rows (lane = row) and four
-// waves, each owning 8 of the 32 channels: its quarter of every matrix-vector product (weights staged transposed in LDS by all 256
-// threads and read as broadcasts, the rows' input vectors parked in LDS), of the BatchNorm / FiLM / residual arithmetic and of the
-// per-block column sums (wave butterfly, fixed order).  Used for kinds A and B of the forward except the last block's heads.
-constexpr int NQ = 4, HQ = HH / NQ;
+// ---- layout of a block ---------------------------------------------------------------------------------------------------------
+// A block is 64 rows (lane = row) and four waves, each owning 8 of the 32 channels: its quarter of every matrix-vector product
+// (weights staged transposed in LDS by all 256 threads and read as broadcasts — rolled loops over the input index: fully unrolled
+// 32x32 products made the kernels instruction-fetch bound —, the rows' input vectors parked in LDS), of the BatchNorm / FiLM /
+// residual arithmetic and of the per-block column sums (wave butterfly, fixed order).  One thread per row alone ran 4096 rows as
+// 64 waves on a chip with 1024 SIMDs.
+//
+// What a segment costs is latency, not work: a launch boundary is ~2 us, but every DEPENDENT global load behind it is a cold miss
+// (~1-2 us), and the first version had four or five of them in a row (statistics -> barrier -> weights -> barrier -> rows ->
+// barrier -> next weights).  So each segment starts with ONE burst: every weight image, the rows' operands, the BatchNorm
+// partials and whatever block 0 will update are requested into registers before the first barrier; the rest runs out of LDS.
+constexpr int NQ = 4, HQ = HH / NQ, NT = FT * NQ;
+constexpr int NPART = NT / HH;              // 8 threads per column add the per-block partial statistics
 struct alignas(16) Smem4 {
   float gamma[HH], beta[HH], mean[HH], inv[HH];
-  float Wt[2][HH * HH];        // transposed weight images [i][j]: FiLM gamma + beta (21 x 32 each), or one 32 x 32 Linear
-  float bl[2][HH];
-  float V[HH * FT], V2[HH * FT];   // parked input vectors [i][row]
+  float gamma1[HH], beta1[HH];     // backward kind B: bn1's affine pair next to bn2's
+  float sm[4][HH];                 // backward: saved mean / invstd of the (up to two) BatchNorms a segment touches
+  float Wt[3][MAXIN * HH];         // weight images: FiLM gamma + beta (21 x 32 each, transposed [i][j]) and one 32 x 32 Linear; fc_in is 38 x 32
+  float bl[3][HH];
+  float V[MAXIN * FT], V2[HH * FT];   // parked input vectors [i][row]
   float sums[2 * HH];              // backward: mean(dz), mean(dz * xhat) of the BatchNorm in flight
+  double fin[NPART][2][HH];        // partial statistics on their way to the 32 finishing threads
 };
+
+// -- the burst: global -> registers ------------------------------------------------------------------------------------------
 template <int K>
-__device__ __forceinline__ void stage_t4(float* Wt, float* bl, const float* __restrict__ W, const float* __restrict__ b) {
-  for (int e = threadIdx.x; e < K * HH; e += FT * NQ) { const int j = e / K, i = e - j * K; Wt[i * HH + j] = W[e]; }
-  if (threadIdx.x < HH) bl[threadIdx.x] = b[threadIdx.x];
+struct WRegs { float v[(K * HH + NT - 1) / NT]; float b; };
+template <int K>
+__device__ __forceinline__ void wload(WRegs<K>& r, const float* __restrict__ W, const float* __restrict__ b) {
+#pragma unroll
+  for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) r.v[t] = W[min((int)threadIdx.x + t * NT, K * HH - 1)];   // clamped, not guarded: a guard is a branch per load
+  r.b = b ? b[threadIdx.x & (HH - 1)] : 0.f;
 }
-template <int K>
-__device__ __forceinline__ void lin_q(const float* Wt, const float* bl, const float* V, int lane, int q, float (&out)[HQ]) {
+// registers -> LDS, transposed ([i][j]: the forward product reads 8 consecutive outputs of one input) or as stored ([j][i])
+template <int K, bool TRANSPOSE>
+__device__ __forceinline__ void wstore(float* Wl, float* bl, const WRegs<K>& r) {
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) out[j] = bl[q * HQ + j];
-#pragma unroll 1
-  for (int i = 0; i < K; ++i) {
-    const float a = V[i * FT + lane];
-    const float* w = Wt + i * HH + q * HQ;
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) out[j] = fmaf(w[j], a, out[j]);
+  for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < K * HH) {
+      if (TRANSPOSE) { const int j = e / K, i = e - j * K; Wl[i * HH + j] = r.v[t]; }
+      else Wl[e] = r.v[t];
+    }
   }
+  if (bl && threadIdx.x < HH) bl[threadIdx.x] = r.b;
+}
+// per-block partial sums [nblocks][2][HH] -> this thread's share (column c = tid & 31, blocks part, part + 8, ...: fixed order, fp64)
+struct PRegs { double s, q; };
+__device__ __forceinline__ void pload(PRegs& r, const float* __restrict__ P, int nblocks) {
+  const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5;
+  double s = 0.0, q = 0.0;
+#pragma unroll 8
+  for (int b = part; b < nblocks; b += NPART) { s += (double)P[(size_t)b * 2 * HH + c]; q += (double)P[(size_t)b * 2 * HH + HH + c]; }
+  r.s = s; r.q = q;
+}
+__device__ __forceinline__ void pstore(Smem4& s, const PRegs& r) {
+  const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5;
+  s.fin[part][0][c] = r.s; s.fin[part][1][c] = r.q;
+}
+struct CondRegs { float v[(MAXCOND + NQ - 1) / NQ]; };
+// cond = (one-hot target, mask): wave q brings in elements q, q+4, ... of its rows
+__device__ __forceinline__ void cload(CondRegs& r, const float* __restrict__ onehot, const float* __restrict__ mask, size_t row, bool on, int q) {
+#pragma unroll
+  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) {
+    const int i = min(q + t * NQ, MAXCOND - 1);     // (row is clamped by the caller: rows past the batch read the last row and are masked later)
+    r.v[t] = i < NCLS ? onehot[row * NCLS + i] : mask[row * DIN + (i - NCLS)];
+  }
+}
+__device__ __forceinline__ void cstore(float* V, const CondRegs& r, int lane, int q) {
+#pragma unroll
+  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = q + t * NQ; if (i < MAXCOND) V[i * FT + lane] = r.v[t]; }
 }
 __device__ __forceinline__ void load8(const float* p, size_t row, int q, bool on, float (&v)[HQ]) {
 #pragma unroll
@@ -242,41 +154,177 @@ __device__ __forceinline__ void park8(float* V, int lane, int q, const float (&v
 #pragma unroll
   for (int j = 0; j < HQ; ++j) V[(q * HQ + j) * FT + lane] = v[j];
 }
-// cond = (one-hot target, mask): wave q brings in elements q, q+4, ... of its rows
-__device__ __forceinline__ void park_cond(float* V, const float* __restrict__ onehot, const float* __restrict__ mask, size_t row, bool on,
-                                          int lane, int q) {
-  for (int i = q; i < MAXCOND; i += NQ)
-    V[i * FT + lane] = !on ? 0.f : (i < NCLS ? onehot[row * NCLS + i] : mask[row * DIN + (i - NCLS)]);
-}
-// column sums of v and v*v over the block's 64 rows for this wave's 8 channels -> part[2][HH] (butterfly: a fixed order)
-__device__ __forceinline__ void wave_colsums(const float (&v)[HQ], bool on, int lane, int q, float* part) {
+// The loop over the input index is unrolled by a few steps only: rolled, every step waits out its own LDS reads (~110 cycles for
+// 8 FMAs — measured 2.2 us for the two 21-step FiLM products of a segment); fully unrolled, the kernels were instruction-fetch bound.
+template <int K>
+__device__ __forceinline__ void lin_q(const float* Wt, const float* bl, const float* V, int lane, int q, float (&out)[HQ]) {
+  constexpr int UNR = K % 4 == 0 ? 4 : (K % 3 == 0 ? 3 : (K % 2 == 0 ? 2 : 1));
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    float s1 = on ? v[j] : 0.f, s2 = s1 * s1;
+  for (int j = 0; j < HQ; ++j) out[j] = bl[q * HQ + j];
+#pragma unroll 1
+  for (int i0 = 0; i0 < K; i0 += UNR) {
+    float a[UNR], w[UNR][HQ];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-    if (lane == 0) { part[q * HQ + j] = s1; part[HH + q * HQ + j] = s2; }
+    for (int u = 0; u < UNR; ++u) {
+      a[u] = V[(i0 + u) * FT + lane];
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) w[u][j] = Wt[(i0 + u) * HH + q * HQ + j];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) out[j] = fmaf(w[u][j], a[u], out[j]);
   }
 }
+// two products over the same input (the FiLM gamma and beta Linears over cond): one walk
+template <int K>
+__device__ __forceinline__ void lin_q2(const float* Wa, const float* ba, const float* Wb, const float* bb, const float* V, int lane, int q,
+                                       float (&oa)[HQ], float (&ob)[HQ]) {
+  constexpr int UNR = K % 3 == 0 ? 3 : (K % 2 == 0 ? 2 : 1);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) { oa[j] = ba[q * HQ + j]; ob[j] = bb[q * HQ + j]; }
+#pragma unroll 1
+  for (int i0 = 0; i0 < K; i0 += UNR) {
+    float a[UNR], wa[UNR][HQ], wb[UNR][HQ];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      a[u] = V[(i0 + u) * FT + lane];
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) { wa[u][j] = Wa[(i0 + u) * HH + q * HQ + j]; wb[u][j] = Wb[(i0 + u) * HH + q * HQ + j]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) { oa[j] = fmaf(wa[u][j], a[u], oa[j]); ob[j] = fmaf(wb[u][j], a[u], ob[j]); }
+  }
+}
+// Sums over the wave's 64 lanes of 8 values per lane, as a halving butterfly: at distance 32 a lane keeps four of its channels and
+// hands the other four to its partner, at 16 two, at 8 one; three plain steps finish.  10 exchanges instead of 48 (a full butterfly
+// per channel measured 2.2 us per segment: the exchanges are LDS-crossbar round trips), a fixed order.  The total of channel c
+// ends in lane 8 * c.
+__device__ __forceinline__ float wave_sum8(const float (&v)[HQ], int lane) {
+  static_assert(HQ == 8, "three halving steps");
+  float r4[4], r2[2], r1;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float keep = b5 ? v[j + 4] : v[j], send = b5 ? v[j] : v[j + 4]; r4[j] = keep + __shfl_xor(send, 32); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const float keep = b4 ? r4[j + 2] : r4[j], send = b4 ? r4[j] : r4[j + 2]; r2[j] = keep + __shfl_xor(send, 16); }
+  { const float keep = b3 ? r2[1] : r2[0], send = b3 ? r2[0] : r2[1]; r1 = keep + __shfl_xor(send, 8); }
+  r1 += __shfl_xor(r1, 4); r1 += __shfl_xor(r1, 2); r1 += __shfl_xor(r1, 1);
+  return r1;
+}
+// column sums of v and v*v over the block's 64 rows for this wave's 8 channels -> part[2][HH]
+__device__ __forceinline__ void wave_colsums(const float (&v)[HQ], bool on, int lane, int q, float* part) {
+  float a[HQ], b[HQ];
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) { a[j] = on ? v[j] : 0.f; b[j] = a[j] * a[j]; }
+  const float s1 = wave_sum8(a, lane), s2 = wave_sum8(b, lane);
+  if ((lane & 7) == 0) { part[q * HQ + (lane >> 3)] = s1; part[HH + q * HQ + (lane >> 3)] = s2; }
+}
 
-// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
-__global__ void __launch_bounds__(FT * NQ) g_fwd_a4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+// mean / invstd of a BatchNorm from the partial statistics parked in s.fin; block 0 also maintains the module's buffers (their old
+// values came in with the burst: rm_old / rv_old, valid in threads < 32 of block 0)
+__device__ __forceinline__ void bn_finish(Smem4& s, int B, float eps, float momentum, float* save, float* rmean, float* rvar, int64_t* nbt,
+                                          float rm_old, float rv_old) {
+  __syncthreads();                                   // s.fin and the LDS images of the burst are complete
+  if (threadIdx.x < HH) {
+    double sm = 0.0, q = 0.0;
+#pragma unroll
+    for (int p = 0; p < NPART; ++p) { sm += s.fin[p][0][threadIdx.x]; q += s.fin[p][1][threadIdx.x]; }
+    const double mean = sm / B;
+    double var = q / B - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    s.mean[threadIdx.x] = (float)mean; s.inv[threadIdx.x] = inv;
+    if (blockIdx.x == 0) {
+      save[threadIdx.x] = (float)mean; save[HH + threadIdx.x] = inv;
+      if (rmean) {
+        const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
+        rmean[threadIdx.x] = (float)((1.0 - momentum) * rm_old + momentum * mean);
+        rvar[threadIdx.x] = (float)((1.0 - momentum) * rv_old + momentum * unb);
+        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------------------
+// entry segment: inp = (x, onehot, mask); h0 = relu(fc_in(inp)); z1_0 = fc1_0(h0), partial statistics
+__global__ void __launch_bounds__(NT) g_fwd_first4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
   __shared__ Smem4 s;
-  const int li = 2 * k;
-  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
-              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
-  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn1_b[k] + threadIdx.x]; }
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
-  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
-  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
+  WRegs<MAXIN> w_in; WRegs<HH> w_fc1;
+  wload<MAXIN>(w_in, PRM + d.fc_in_w, PRM + d.fc_in_b);
+  wload<HH>(w_fc1, PRM + d.fc1_w[0], PRM + d.fc1_b[0]);
+  float in[(MAXIN + NQ - 1) / NQ];                   // wave q brings in inputs q, q+4, ... of its rows
+#pragma unroll
+  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
+    const int i = q + t * NQ;
+    in[t] = (!on || i >= MAXIN) ? 0.f
+          : (i < DIN ? a.x[row * DIN + i] : (i < DIN + NCLS ? a.onehot[row * NCLS + (i - DIN)] : a.mask[row * DIN + (i - DIN - NCLS)]));
+  }
+  wstore<MAXIN, true>(s.Wt[0], s.bl[0], w_in);
+  wstore<HH, true>(s.Wt[1], s.bl[1], w_fc1);
+#pragma unroll
+  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
+    const int i = q + t * NQ;
+    if (i < MAXIN) { s.V[i * FT + lane] = in[t]; if (on) a.inp[row * MAXIN + i] = in[t]; }
+  }
   __syncthreads();
-  float gam[HQ], bet[HQ], z[HQ], a1[HQ];
-  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
-  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  float h[HQ], z[HQ];
+  lin_q<MAXIN>(s.Wt[0], s.bl[0], s.V, lane, q, h);
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
+  store8(a.H, row, q, on, h);
+  park8(s.V2, lane, q, h);
+  __syncthreads();
+  lin_q<HH>(s.Wt[1], s.bl[1], s.V2, lane, q, z);
+  store8(a.Z1, row, q, on, z);
+  wave_colsums(z, on, lane, q, a.P + (size_t)blockIdx.x * 2 * HH);
+}
+
+// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
+// (the offsets and pointers of ONE segment travel by value — FSeg / BSeg / CSeg — so they arrive with the kernel arguments instead
+// of as a chain of dependent scalar loads indexed by k)
+struct FSeg { int fg_w, fg_b, fb_w, fb_b, fc_w, fc_b, bn_g, bn_b; float* rmean; float* rvar; int64_t* nbt; int k, li, more; };
+__global__ void __launch_bounds__(NT) g_fwd_a4_kernel(const float* __restrict__ PRM, GBufs a, FSeg f) {
+  __shared__ Smem4 s;
+  const int li = f.li, k = f.k;
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const bool on = row < (size_t)a.B;
+  // ---- the burst
+  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc2; CondRegs cr; PRegs pr;
+  float z[HQ], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
+  PCG_T(0);
+  wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
+  wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
+  wload<HH>(w_fc2, PRM + f.fc_w, PRM + f.fc_b);
+  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
   load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+  if (threadIdx.x < HH) {
+    g_bn = PRM[f.bn_g + threadIdx.x]; b_bn = PRM[f.bn_b + threadIdx.x];
+    if (f.rmean) { rm_old = f.rmean[threadIdx.x]; rv_old = f.rvar[threadIdx.x]; }     // every block: no block-0 detour in the burst
+  }
+  pload(pr, a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks);
+  PCG_T(1);
+  // ---- into LDS
+  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
+  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
+  wstore<HH, true>(s.Wt[2], s.bl[2], w_fc2);
+  cstore(s.V, cr, lane, q);
+  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = g_bn; s.beta[threadIdx.x] = b_bn; }
+  pstore(s, pr);
+  PCG_T(2);
+  bn_finish(s, a.B, a.eps, a.momentum, a.SM + (size_t)li * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
+  PCG_T(3);
+  float gam[HQ], bet[HQ], a1[HQ];
+  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
+  PCG_T(4);
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
@@ -285,35 +333,47 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_a4_kernel(const float* __restri
     a1[j] = f > 0.f ? f : 0.f;
   }
   park8(s.V2, lane, q, a1);
-  __syncthreads();                                   // FiLM images read by every wave; a1 complete
-  stage_t4<HH>(s.Wt[0], s.bl[0], PRM + d.fc2_w[k], PRM + d.fc2_b[k]);
-  __syncthreads();
+  __syncthreads();                                   // a1 complete
+  PCG_T(5);
   float z2[HQ];
-  lin_q<HH>(s.Wt[0], s.bl[0], s.V2, lane, q, z2);
+  lin_q<HH>(s.Wt[2], s.bl[2], s.V2, lane, q, z2);
+  PCG_T(6);
   store8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z2);
   wave_colsums(z2, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+  PCG_T(7);
 }
 
 // kind B (block k): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); z1_{k+1} = fc1_{k+1}(h), partial statistics (after the last
 // block the output heads follow instead: g_heads4_kernel)
-__global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, BNState bs, int k) {
+__global__ void __launch_bounds__(NT) g_fwd_b4_kernel(const float* __restrict__ PRM, GBufs a, FSeg f) {
   __shared__ Smem4 s;
-  const int li = 2 * k + 1;
-  bn_finalize(a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks, a.B, a.eps, a.momentum, s.mean, s.inv, a.SM + (size_t)li * 2 * HH,
-              bs.running_mean[li], bs.running_var[li], bs.nbt[li]);
-  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = PRM[d.bn2_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn2_b[k] + threadIdx.x]; }
+  const int li = f.li, k = f.k;
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
-  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
-  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
-  __syncthreads();
-  float gam[HQ], bet[HQ], z[HQ], h[HQ];
-  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
-  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  const bool more = f.more != 0;                     // kernel-uniform: a next block follows (f.fc_* = its fc1)
+  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc1; CondRegs cr; PRegs pr;
+  float z[HQ], h[HQ], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
+  wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
+  wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
+  if (more) wload<HH>(w_fc1, PRM + f.fc_w, PRM + f.fc_b);
+  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
   load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
   load8(a.H + (size_t)k * a.B * HH, row, q, on, h);
+  if (threadIdx.x < HH) {
+    g_bn = PRM[f.bn_g + threadIdx.x]; b_bn = PRM[f.bn_b + threadIdx.x];
+    if (f.rmean) { rm_old = f.rmean[threadIdx.x]; rv_old = f.rvar[threadIdx.x]; }
+  }
+  pload(pr, a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks);
+  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
+  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
+  if (more) wstore<HH, true>(s.Wt[2], s.bl[2], w_fc1);
+  cstore(s.V, cr, lane, q);
+  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = g_bn; s.beta[threadIdx.x] = b_bn; }
+  pstore(s, pr);
+  bn_finish(s, a.B, a.eps, a.momentum, a.SM + (size_t)li * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
+  float gam[HQ], bet[HQ];
+  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
@@ -321,64 +381,128 @@ __global__ void __launch_bounds__(FT * NQ) g_fwd_b4_kernel(const float* __restri
     h[j] += fmaf(gam[j], n, bet[j]);
   }
   store8(a.H + (size_t)(k + 1) * a.B * HH, row, q, on, h);
-  if (k == NBLK - 1) return;                         // block-uniform
+  if (!more) return;
   park8(s.V2, lane, q, h);
   __syncthreads();
-  stage_t4<HH>(s.Wt[0], s.bl[0], PRM + d.fc1_w[k + 1], PRM + d.fc1_b[k + 1]);
-  __syncthreads();
   float z1[HQ];
-  lin_q<HH>(s.Wt[0], s.bl[0], s.V2, lane, q, z1);
+  lin_q<HH>(s.Wt[2], s.bl[2], s.V2, lane, q, z1);
   store8(a.Z1 + (size_t)(k + 1) * a.B * HH, row, q, on, z1);
   wave_colsums(z1, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
-// Output heads on four waves: the continuous residual head and the categorical heads (logits, Gumbel-softmax samples) are dealt to
-// the waves by the host (largest first onto the least loaded wave); every wave reads the 32-vector of its rows and walks its heads
-// exactly as the one-wave kernel does.
+// ---- output heads ----------------------------------------------------------------------------------------------------------------
+// The continuous residual head and the categorical heads (logits, Gumbel-softmax samples) are dealt to the four waves by the host
+// (largest first onto the least loaded wave); every wave holds the 32-vector of its rows in registers and walks its heads.  All
+// head weights sit in LDS as stored ([column][32]: a wave works on one column at a time, so the reads are broadcasts); the block's
+// noise rows come in as one coalesced tile, logits and samples leave the same way (a lane-per-row access to a [B][70] tensor
+// touches 64 cache lines per instruction).
 struct HeadOwner { signed char owner[MAXHEADS + 1]; };   // [nheads] = the continuous head
-__global__ void __launch_bounds__(FT * NQ) g_heads4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, HeadOwner ho) {
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  if (row >= (size_t)a.B) return;
-  float h[HH];
-  load32(a.H + (size_t)NBLK * a.B * HH, row, true, h);
-  const int T = d.seg[d.nheads];
-  if (ho.owner[d.nheads] == q) {
-    for (int c = 0; c < d.ncont; ++c) {
-      float acc = PRM[d.cont_b + c];
+constexpr int MAXCOLS = MAXT + HH;          // packed categorical columns + continuous columns
+constexpr int TP = MAXT + 1;                // row pitch of the LDS tiles (odd: lane-per-row accesses are conflict-free)
+struct alignas(16) SmemHeads {
+  float W[MAXCOLS * HH];
+  float b[MAXCOLS];
+  float lg[FT * TP];                        // logits; backward: d_logits in, dl out
+  float ns[FT * TP];                        // noise -> (logit + noise) / tau -> soft sample; backward: soft
+  float ds[FT * TP];                        // backward: d_samples
+  float ct[FT * (HH + 1)];                  // continuous head
+};
+// flat-parameter offset of element (column c, input i) of the packed head matrix; -1 outside
+__device__ __forceinline__ int head_src(const GDesc& d, int c, int i, int T) {
+  if (c >= T) return c < T + d.ncont ? d.cont_w + (c - T) * HH + i : -1;
+  int src = -1;
 #pragma unroll
-      for (int i = 0; i < HH; ++i) acc = fmaf(PRM[d.cont_w + c * HH + i], h[i], acc);
-      a.cont[row * d.ncont + c] = acc * a.res_scale;
+  for (int hd = 0; hd < MAXHEADS; ++hd)
+    if (hd < d.nheads && c >= d.seg[hd] && c < d.seg[hd + 1]) src = d.head_w[hd] + (c - d.seg[hd]) * HH + i;
+  return src;
+}
+__device__ __forceinline__ int head_bias_src(const GDesc& d, int c, int T) {
+  if (c >= T) return c < T + d.ncont ? d.cont_b + (c - T) : -1;
+  int src = -1;
+#pragma unroll
+  for (int hd = 0; hd < MAXHEADS; ++hd)
+    if (hd < d.nheads && c >= d.seg[hd] && c < d.seg[hd + 1]) src = d.head_b[hd] + (c - d.seg[hd]);
+  return src;
+}
+constexpr int HW_PER = MAXCOLS * HH / NT;   // 16 weight elements per thread
+constexpr int TILE_PER = (FT * MAXT + NT - 1) / NT;   // 24 tile elements per thread
+// coalesced [rows][T] global tile <-> LDS tile [FT][TP]
+__device__ __forceinline__ void tile_load(float (&r)[TILE_PER], const float* __restrict__ g, size_t row0, int rows, int T) {
+#pragma unroll
+  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; r[t] = (g && e < rows * T) ? g[row0 * T + e] : 0.f; }
+}
+__device__ __forceinline__ void tile_park(float* L, const float (&r)[TILE_PER], int rows, int T) {
+#pragma unroll
+  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; if (e < rows * T) { const int rr = e / T; L[rr * TP + (e - rr * T)] = r[t]; } }
+}
+__device__ __forceinline__ void tile_out(float* __restrict__ g, const float* L, size_t row0, int rows, int T) {
+#pragma unroll
+  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; if (e < rows * T) { const int rr = e / T; g[row0 * T + e] = L[rr * TP + (e - rr * T)]; } }
+}
+
+__global__ void __launch_bounds__(NT) g_heads4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, HeadOwner ho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
+  SmemHeads& s = *reinterpret_cast<SmemHeads*>(heads_lds);
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const size_t row0 = (size_t)blockIdx.x * FT, row = row0 + lane;
+  const bool on = row < (size_t)a.B;
+  const int rows = min(FT, a.B - (int)row0);
+  const int T = d.seg[d.nheads];
+  // ---- the burst
+  float wr[HW_PER], br = 0.f, nr[TILE_PER], h[HH];
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; const int src = head_src(d, e >> 5, e & 31, T); wr[t] = src >= 0 ? PRM[src] : 0.f; }
+  if (threadIdx.x < MAXCOLS) { const int src = head_bias_src(d, threadIdx.x, T); br = src >= 0 ? PRM[src] : 0.f; }
+  tile_load(nr, a.noise, row0, rows, T);
+  load32(a.H + (size_t)NBLK * a.B * HH, row, on, h);
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) s.W[threadIdx.x + t * NT] = wr[t];
+  if (threadIdx.x < MAXCOLS) s.b[threadIdx.x] = br;
+  tile_park(s.ns, nr, rows, T);
+  __syncthreads();
+  if (ho.owner[d.nheads] == q) {                     // wave-uniform
+    for (int c = 0; c < d.ncont; ++c) {
+      float acc = s.b[T + c];
+      const float* w = s.W + (T + c) * HH;
+#pragma unroll
+      for (int i = 0; i < HH; ++i) acc = fmaf(w[i], h[i], acc);
+      s.ct[lane * (HH + 1) + c] = acc * a.res_scale;
     }
   }
   const float inv_tau = 1.f / a.tau;
   for (int hd = 0; hd < d.nheads; ++hd) {
     if (ho.owner[hd] != q) continue;               // wave-uniform
     const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-    const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
-    const float* __restrict__ bh = PRM + d.head_b[hd] - c0;
+    float* lg = s.lg + lane * TP; float* ns = s.ns + lane * TP;
     float mx = -INFINITY;
     for (int c = c0; c < c1; ++c) {
-      float acc = bh[c];
+      float acc = s.b[c];
+      const float* w = s.W + c * HH;
 #pragma unroll
-      for (int i = 0; i < HH; ++i) acc = fmaf(Wh[c * HH + i], h[i], acc);
-      a.logits[row * T + c] = acc;
-      mx = fmaxf(mx, (acc + a.noise[row * T + c]) * inv_tau);
+      for (int i = 0; i < HH; ++i) acc = fmaf(w[i], h[i], acc);
+      lg[c] = acc;
+      const float t = (acc + ns[c]) * inv_tau;
+      ns[c] = t;
+      mx = fmaxf(mx, t);
     }
     float se = 0.f;
-    for (int c = c0; c < c1; ++c) se += expf((a.logits[row * T + c] + a.noise[row * T + c]) * inv_tau - mx);
+    for (int c = c0; c < c1; ++c) se += expf(ns[c] - mx);
     const float inv = 1.f / se;
     float best = -1.f; int arg = c0;
     for (int c = c0; c < c1; ++c) {
-      const float p = expf((a.logits[row * T + c] + a.noise[row * T + c]) * inv_tau - mx) * inv;
-      a.soft[row * T + c] = p;
+      const float p = expf(ns[c] - mx) * inv;
+      ns[c] = p;
       if (p > best) { best = p; arg = c; }
     }
-    if (a.hard) for (int c = c0; c < c1; ++c) a.hard[row * T + c] = c == arg ? 1.f : 0.f;
+    if (a.hard && on) for (int c = c0; c < c1; ++c) a.hard[row * T + c] = c == arg ? 1.f : 0.f;
   }
+  __syncthreads();
+  tile_out(a.logits, s.lg, row0, rows, T);
+  tile_out(a.soft, s.ns, row0, rows, T);
+  for (int e = threadIdx.x; e < rows * d.ncont; e += NT) { const int rr = e / d.ncont; a.cont[row0 * d.ncont + e] = s.ct[rr * (HH + 1) + (e - rr * d.ncont)]; }
 }
 
-// ---- backward --------------------------------------------------------------------------------------------------------------
+// ---- backward ------------------------------------------------------------------------------------------------------------------
 struct GBwd {
   float* grads;                           // flat gradient buffer (BatchNorm gamma/beta gradients are written here)
   const float* onehot; const float* mask;
@@ -395,70 +519,57 @@ struct GBwd {
   float tau, res_scale;
 };
 
-// sums of one BatchNorm backward from the partials; block 0 writes dgamma / dbeta
-__device__ __forceinline__ void bnb_finalize(float* sums, const GBwd& a, int li, int g_off, int b_off) {
-  __shared__ double fin[2][2][HH];
-  if (threadIdx.x < FT) {   // (the four-wave kernels call this with 256 threads: the first wave does the work)
-    const float* Q = a.Q + (size_t)li * a.nblocks * 2 * HH;
-    const int c = threadIdx.x & 31, half = threadIdx.x >> 5;
-    double t1 = 0.0, t2 = 0.0;
-#pragma unroll 8
-    for (int b = half; b < a.nblocks; b += 2) { t1 += (double)Q[(size_t)b * 2 * HH + c]; t2 += (double)Q[(size_t)b * 2 * HH + HH + c]; }
-    fin[half][0][c] = t1; fin[half][1][c] = t2;
-  }
+// sums of one BatchNorm backward from the partials parked in s.fin -> s.sums (means); block 0 writes dgamma / dbeta (their old
+// values, for the accumulate case, came in with the burst)
+__device__ __forceinline__ void bnb_finish(Smem4& s, const GBwd& a, int g_off, int b_off, float gg_old, float gb_old) {
   __syncthreads();
   if (threadIdx.x < HH) {
-    const double s1 = fin[0][0][threadIdx.x] + fin[1][0][threadIdx.x], s2 = fin[0][1][threadIdx.x] + fin[1][1][threadIdx.x];
-    sums[threadIdx.x] = (float)(s1 / a.B); sums[HH + threadIdx.x] = (float)(s2 / a.B);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < NPART; ++p) { s1 += s.fin[p][0][threadIdx.x]; s2 += s.fin[p][1][threadIdx.x]; }
+    s.sums[threadIdx.x] = (float)(s1 / a.B); s.sums[HH + threadIdx.x] = (float)(s2 / a.B);
     if (blockIdx.x == 0) {
-      float* gg = a.grads + g_off + threadIdx.x; float* gb = a.grads + b_off + threadIdx.x;
-      *gg = a.accumulate ? *gg + (float)s2 : (float)s2;
-      *gb = a.accumulate ? *gb + (float)s1 : (float)s1;
+      a.grads[g_off + threadIdx.x] = a.accumulate ? gg_old + (float)s2 : (float)s2;
+      a.grads[b_off + threadIdx.x] = a.accumulate ? gb_old + (float)s1 : (float)s1;
     }
   }
   __syncthreads();
 }
 
-// ---- backward, four waves per 64 rows (same split as the forward: wave q owns channels 8q .. 8q+7) -------------------------------
 // out[8] = sum_j Wl[j][8q + .] * V[j][row]      (Wl = the Linear's weight as stored, [out j][in i]: gradient w.r.t. its input)
 __device__ __forceinline__ void lin_tq(const float* Wl, const float* V, int lane, int q, float (&out)[HQ]) {
 #pragma unroll
   for (int i = 0; i < HQ; ++i) out[i] = 0.f;
 #pragma unroll 1
-  for (int j = 0; j < HH; ++j) {
-    const float a = V[j * FT + lane];
-    const float* w = Wl + j * HH + q * HQ;
+  for (int j0 = 0; j0 < HH; j0 += 4) {
+    float a[4], w[4][HQ];
 #pragma unroll
-    for (int i = 0; i < HQ; ++i) out[i] = fmaf(w[i], a, out[i]);
+    for (int u = 0; u < 4; ++u) {
+      a[u] = V[(j0 + u) * FT + lane];
+#pragma unroll
+      for (int i = 0; i < HQ; ++i) w[u][i] = Wl[(j0 + u) * HH + q * HQ + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < HQ; ++i) out[i] = fmaf(w[u][i], a[u], out[i]);
   }
-}
-__device__ __forceinline__ void stage_asis4(float* Wl, const float* __restrict__ W) {
-  for (int e = threadIdx.x; e < HH * HH; e += FT * NQ) Wl[e] = W[e];
 }
 // column sums of v and w over the block's 64 rows for this wave's 8 channels -> part[2][HH]
 __device__ __forceinline__ void wave_colsums2(const float (&v)[HQ], const float (&w)[HQ], int lane, int q, float* part) {
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    float s1 = v[j], s2 = w[j];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-    if (lane == 0) { part[q * HQ + j] = s1; part[HH + q * HQ + j] = s2; }
-  }
+  const float s1 = wave_sum8(v, lane), s2 = wave_sum8(w, lane);
+  if ((lane & 7) == 0) { part[q * HQ + (lane >> 3)] = s1; part[HH + q * HQ + (lane >> 3)] = s2; }
 }
-// part "a" of block k: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2).  Uses s.V / s.Wt[1] (free at every call site).
-__device__ __forceinline__ void bwd_part_a4(const float* __restrict__ PRM, Smem4& s, const GBwd& a, const GDesc& d, int k, size_t row, bool on,
-                                            int lane, int q, const float (&dh)[HQ]) {
-  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
-  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fg_w[k], PRM + d.fg_b[k]);
-  __syncthreads();
-  float gam[HQ], z[HQ], v[HQ], w[HQ];
-  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, gam);
-  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
-  const float* sm = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+// part "a" of block k: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2).  Its operands came in with the caller's burst: the FiLM gamma
+// image in s.Wt[wslot] / s.bl[wslot], cond parked in s.V, z = z2_k rows, the saved statistics of bn2_k in s.sm[smslot], s.sm[smslot+1].
+__device__ __forceinline__ void bwd_part_a4(Smem4& s, const GBwd& a, int k, bool on, int lane, int q, const float (&dh)[HQ], const float (&z)[HQ],
+                                            int wslot, int smslot) {
+  float gam[HQ], v[HQ], w[HQ];
+  lin_q<MAXCOND>(s.Wt[wslot], s.bl[wslot], s.V, lane, q, gam);
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
-    const float xh = (z[j] - sm[c]) * sm[HH + c];
+    const float xh = (z[j] - s.sm[smslot][c]) * s.sm[smslot + 1][c];
     v[j] = on ? dh[j] * gam[j] : 0.f;
     w[j] = v[j] * xh;
   }
@@ -466,99 +577,158 @@ __device__ __forceinline__ void bwd_part_a4(const float* __restrict__ PRM, Smem4
 }
 
 // first backward kernel: gradients of the heads (dealt to the waves like the forward) -> dh entering the last block; part a
-__global__ void __launch_bounds__(FT * NQ) g_bwd_first4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, HeadOwner ho) {
-  __shared__ Smem4 s;
-  __shared__ float part[NQ][HH][FT];        // per-wave partial dh
+__global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, HeadOwner ho) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
+  SmemHeads& hs = *reinterpret_cast<SmemHeads*>(heads_lds);
+  Smem4& s = *reinterpret_cast<Smem4*>(heads_lds + sizeof(SmemHeads));
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
+  const size_t row0 = (size_t)blockIdx.x * FT, row = row0 + lane;
   const bool on = row < (size_t)a.B;
+  const int rows = min(FT, a.B - (int)row0);
   const int T = d.seg[d.nheads];
+  constexpr int k = NBLK - 1;
+  // ---- the burst: head weights, the three [rows][T] tiles, d_cont; for part a: FiLM gamma of the last block, cond, z2, saved statistics
+  float wr[HW_PER], t_dl[TILE_PER], t_ds[TILE_PER], t_y[TILE_PER], z[HQ], smr = 0.f;
+  WRegs<MAXCOND> w_g; CondRegs cr;
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; const int src = head_src(d, e >> 5, e & 31, T); wr[t] = src >= 0 ? PRM[src] : 0.f; }
+  tile_load(t_dl, a.d_logits, row0, rows, T);
+  tile_load(t_ds, a.d_samples, row0, rows, T);
+  tile_load(t_y, a.soft, row0, rows, T);
+  float dcr[(FT * HH + NT - 1) / NT];
+#pragma unroll
+  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) { const int e = threadIdx.x + t * NT; dcr[t] = (a.d_cont && e < rows * d.ncont) ? a.d_cont[row0 * d.ncont + e] : 0.f; }
+  wload<MAXCOND>(w_g, PRM + d.fg_w[k], PRM + d.fg_b[k]);
+  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
+  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
+  if (threadIdx.x < 2 * HH) smr = a.SM[(size_t)(2 * k + 1) * 2 * HH + threadIdx.x];
+  // ---- into LDS
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) hs.W[threadIdx.x + t * NT] = wr[t];
+  tile_park(hs.lg, t_dl, rows, T);
+  tile_park(hs.ds, t_ds, rows, T);
+  tile_park(hs.ns, t_y, rows, T);
+#pragma unroll
+  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < rows * d.ncont) {
+      const int rr = e / d.ncont;
+      const float dc = dcr[t] * a.res_scale;           // 0 without a cotangent
+      hs.ct[rr * (HH + 1) + (e - rr * d.ncont)] = dc;
+      a.DC[row0 * d.ncont + e] = dc;
+    }
+  }
+  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_g);
+  cstore(s.V, cr, lane, q);
+  if (threadIdx.x < 2 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
+  __syncthreads();
   float dh[HH];
 #pragma unroll
   for (int i = 0; i < HH; ++i) dh[i] = 0.f;
   if (on) {
     if (ho.owner[d.nheads] == q) {
       for (int c = 0; c < d.ncont; ++c) {
-        const float dc = a.d_cont ? a.d_cont[row * d.ncont + c] * a.res_scale : 0.f;
-        a.DC[row * d.ncont + c] = dc;
+        const float dc = hs.ct[lane * (HH + 1) + c];       // d_cont * res_scale (0 without a cotangent)
+        const float* w = hs.W + (T + c) * HH;
 #pragma unroll
-        for (int i = 0; i < HH; ++i) dh[i] = fmaf(PRM[d.cont_w + c * HH + i], dc, dh[i]);
+        for (int i = 0; i < HH; ++i) dh[i] = fmaf(w[i], dc, dh[i]);
       }
     }
     const float inv_tau = 1.f / a.tau;
+    float* dlr = hs.lg + lane * TP; const float* dsr = hs.ds + lane * TP; const float* yr = hs.ns + lane * TP;
     for (int hd = 0; hd < d.nheads; ++hd) {
       if (ho.owner[hd] != q) continue;             // wave-uniform
       const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-      const float* __restrict__ Wh = PRM + d.head_w[hd] - c0 * HH;
       float dot = 0.f;
       if (a.d_samples)
-        for (int c = c0; c < c1; ++c) dot = fmaf(a.d_samples[row * T + c], a.soft[row * T + c], dot);
+        for (int c = c0; c < c1; ++c) dot = fmaf(dsr[c], yr[c], dot);
       for (int c = c0; c < c1; ++c) {
-        float dl = a.d_logits ? a.d_logits[row * T + c] : 0.f;
-        if (a.d_samples) { const float y = a.soft[row * T + c]; dl += y * (a.d_samples[row * T + c] - dot) * inv_tau; }
-        a.DL[row * T + c] = dl;
+        float dl = a.d_logits ? dlr[c] : 0.f;
+        if (a.d_samples) { const float y = yr[c]; dl += y * (dsr[c] - dot) * inv_tau; }
+        dlr[c] = dl;
+        const float* w = hs.W + c * HH;
 #pragma unroll
-        for (int i = 0; i < HH; ++i) dh[i] = fmaf(Wh[c * HH + i], dl, dh[i]);
+        for (int i = 0; i < HH; ++i) dh[i] = fmaf(w[i], dl, dh[i]);
       }
     }
   }
+  // per-wave partial dh -> this wave's 8 channels: through the (now free) d_samples tile, [q][i][lane]
+  __syncthreads();
+  static_assert(offsetof(SmemHeads, ct) == offsetof(SmemHeads, ds) + sizeof(float) * FT * TP && FT * TP + FT * (HH + 1) >= NQ * HH * FT,
+                "the per-wave partials reuse the d_samples tile and the continuous-head tile behind it");
+  float* part = hs.ds;                               // NQ * HH * FT floats: spills into hs.ct behind it — both free now
 #pragma unroll
-  for (int i = 0; i < HH; ++i) part[q][i][lane] = dh[i];
+  for (int i = 0; i < HH; ++i) part[(q * HH + i) * FT + lane] = dh[i];
   __syncthreads();
   float d8[HQ];
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
-    d8[j] = (part[0][c][lane] + part[1][c][lane]) + (part[2][c][lane] + part[3][c][lane]);
+    d8[j] = (part[(0 * HH + c) * FT + lane] + part[(1 * HH + c) * FT + lane]) + (part[(2 * HH + c) * FT + lane] + part[(3 * HH + c) * FT + lane]);
   }
-  store8(a.DH + (size_t)(NBLK - 1) * a.B * HH, row, q, on, d8);
-  bwd_part_a4(PRM, s, a, d, NBLK - 1, row, on, lane, q, d8);
+  store8(a.DH + (size_t)k * a.B * HH, row, q, on, d8);
+  tile_out(a.DL, hs.lg, row0, rows, T);
+  bwd_part_a4(s, a, k, on, lane, q, d8, z, 1, 0);
 }
 
 // kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
-__global__ void __launch_bounds__(FT * NQ) g_bwd_b4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+struct BSeg { int fg_w, fg_b, fb_w, fb_b, fc2_w, bn2_g, bn2_b, bn1_g, bn1_b, k; };
+__global__ void __launch_bounds__(NT) g_bwd_b4_kernel(const float* __restrict__ PRM, GBwd a, BSeg f) {
   __shared__ Smem4 s;
-  bnb_finalize(s.sums, a, 2 * k + 1, d.bn2_g[k], d.bn2_b[k]);
-  if (threadIdx.x < HH) {
-    s.gamma[threadIdx.x] = PRM[d.bn2_g[k] + threadIdx.x]; s.beta[threadIdx.x] = PRM[d.bn2_b[k] + threadIdx.x];
-    s.mean[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x]; s.inv[threadIdx.x] = PRM[d.bn1_b[k] + threadIdx.x];   // bn1's gamma / beta (names reused)
-  }
+  const int k = f.k;
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  park_cond(s.V, a.onehot, a.mask, row, on, lane, q);
-  stage_t4<MAXCOND>(s.Wt[0], s.bl[0], PRM + d.fg_w[k], PRM + d.fg_b[k]);
-  stage_t4<MAXCOND>(s.Wt[1], s.bl[1], PRM + d.fb_w[k], PRM + d.fb_b[k]);
-  __syncthreads();
-  float gam[HQ], bet[HQ], z[HQ], dh[HQ], dz2[HQ], da1[HQ], dgam[HQ];
-  lin_q<MAXCOND>(s.Wt[0], s.bl[0], s.V, lane, q, gam);
-  lin_q<MAXCOND>(s.Wt[1], s.bl[1], s.V, lane, q, bet);
+  // ---- the burst
+  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc2; CondRegs cr; PRegs pr;
+  float dh[HQ], z2[HQ], z1[HQ], aff = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
+  wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
+  wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
+  wload<HH>(w_fc2, PRM + f.fc2_w, nullptr);
+  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
   load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
-  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
-  const float* sm2 = a.SM + (size_t)(2 * k + 1) * 2 * HH;
+  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z2);
+  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z1);
+  if (threadIdx.x < 4 * HH) {                        // bn2 gamma, beta, bn1 gamma, beta -> s.gamma, s.beta, s.gamma1, s.beta1 (contiguous)
+    const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    aff = PRM[(w == 0 ? f.bn2_g : w == 1 ? f.bn2_b : w == 2 ? f.bn1_g : f.bn1_b) + c];
+    smr = a.SM[(size_t)(2 * k) * 2 * HH + threadIdx.x];        // sm[0..1] = bn1's mean / invstd, sm[2..3] = bn2's
+  }
+  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn2_g + threadIdx.x]; gb_old = a.grads[f.bn2_b + threadIdx.x]; }   // every block
+  pload(pr, a.Q + (size_t)(2 * k + 1) * a.nblocks * 2 * HH, a.nblocks);
+  // ---- into LDS
+  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
+  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
+  wstore<HH, false>(s.Wt[2], nullptr, w_fc2);
+  cstore(s.V, cr, lane, q);
+  if (threadIdx.x < 4 * HH) {
+    const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    (w == 0 ? s.gamma : w == 1 ? s.beta : w == 2 ? s.gamma1 : s.beta1)[c] = aff;
+    s.sm[w][c] = smr;
+  }
+  pstore(s, pr);
+  bnb_finish(s, a, f.bn2_g, f.bn2_b, gg_old, gb_old);
+  float gam[HQ], bet[HQ], dz2[HQ], da1[HQ], dgam[HQ];
+  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
-    const float xh = (z[j] - sm2[c]) * sm2[HH + c];
+    const float xh = (z2[j] - s.sm[2][c]) * s.sm[3][c];
     const float n2 = fmaf(xh, s.gamma[c], s.beta[c]);
     const float dn2 = dh[j] * gam[j];
-    dz2[j] = s.gamma[c] * sm2[HH + c] * (dn2 - s.sums[c] - xh * s.sums[HH + c]);
+    dz2[j] = s.gamma[c] * s.sm[3][c] * (dn2 - s.sums[c] - xh * s.sums[HH + c]);
     dgam[j] = dh[j] * n2;
   }
   store8(a.DZ2 + (size_t)k * a.B * HH, row, q, on, dz2);
   park8(s.V2, lane, q, dz2);
-  __syncthreads();                                   // FiLM images read by every wave; dz2 complete
-  stage_asis4(s.Wt[0], PRM + d.fc2_w[k]);
-  __syncthreads();
-  lin_tq(s.Wt[0], s.V2, lane, q, da1);
-  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
-  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+  __syncthreads();                                   // dz2 complete
+  lin_tq(s.Wt[2], s.V2, lane, q, da1);
   float a1[HQ], v[HQ], w[HQ], dbet[HQ];
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
-    const float xh = (z[j] - sm1[c]) * sm1[HH + c];
-    const float n1 = fmaf(xh, s.mean[c], s.inv[c]);
+    const float xh = (z1[j] - s.sm[0][c]) * s.sm[1][c];
+    const float n1 = fmaf(xh, s.gamma1[c], s.beta1[c]);
     const float f = fmaf(gam[j], n1, bet[j]);
     a1[j] = f > 0.f ? f : 0.f;
     const float df1 = f > 0.f ? da1[j] : 0.f;
@@ -575,41 +745,62 @@ __global__ void __launch_bounds__(FT * NQ) g_bwd_b4_kernel(const float* __restri
 }
 
 // kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
-__global__ void __launch_bounds__(FT * NQ) g_bwd_c4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, int k) {
+struct CSeg { int fc1_w, bn1_g, bn1_b, fgp_w, fgp_b, k; };     // fgp_*: FiLM gamma of block k-1
+__global__ void __launch_bounds__(NT) g_bwd_c4_kernel(const float* __restrict__ PRM, GBwd a, CSeg f) {
   __shared__ Smem4 s;
-  bnb_finalize(s.sums, a, 2 * k, d.bn1_g[k], d.bn1_b[k]);
-  if (threadIdx.x < HH) s.gamma[threadIdx.x] = PRM[d.bn1_g[k] + threadIdx.x];
-  stage_asis4(s.Wt[0], PRM + d.fc1_w[k]);
-  __syncthreads();
+  const int k = f.k;
   const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
   const size_t row = (size_t)blockIdx.x * FT + lane;
   const bool on = row < (size_t)a.B;
-  float z[HQ], dn1[HQ], dz1[HQ], dh[HQ], t[HQ];
-  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+  const bool more = k > 0;                           // kernel-uniform
+  const int kp = more ? k - 1 : 0;
+  // ---- the burst (with the operands of part a of block k-1, or h0 for the fc_in ReLU)
+  WRegs<HH> w_fc1; WRegs<MAXCOND> w_g; CondRegs cr; PRegs pr;
+  float z1[HQ], dn1[HQ], dh[HQ], zp[HQ], g1 = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
+  wload<HH>(w_fc1, PRM + f.fc1_w, nullptr);
+  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z1);
   load8(a.DN1, row, q, on, dn1);
-  const float* sm1 = a.SM + (size_t)(2 * k) * 2 * HH;
+  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
+  load8(more ? a.Z2 + (size_t)kp * a.B * HH : a.H, row, q, on, zp);     // z2 of block k-1, or h0
+  if (more) {
+    wload<MAXCOND>(w_g, PRM + f.fgp_w, PRM + f.fgp_b);
+    cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
+  }
+  if (threadIdx.x < HH) g1 = PRM[f.bn1_g + threadIdx.x];
+  if (threadIdx.x < 4 * HH) {                        // sm[0..1]: bn1_k; sm[2..3]: bn2_{k-1} (unused for k = 0)
+    const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    const int li = w < 2 ? 2 * k : 2 * kp + 1;
+    smr = a.SM[(size_t)li * 2 * HH + (w & 1) * HH + c];
+  }
+  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn1_g + threadIdx.x]; gb_old = a.grads[f.bn1_b + threadIdx.x]; }   // every block
+  pload(pr, a.Q + (size_t)(2 * k) * a.nblocks * 2 * HH, a.nblocks);
+  // ---- into LDS
+  wstore<HH, false>(s.Wt[0], nullptr, w_fc1);
+  if (more) { wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_g); cstore(s.V, cr, lane, q); }
+  if (threadIdx.x < HH) s.gamma[threadIdx.x] = g1;
+  if (threadIdx.x < 4 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
+  pstore(s, pr);
+  bnb_finish(s, a, f.bn1_g, f.bn1_b, gg_old, gb_old);
+  float dz1[HQ], t[HQ];
 #pragma unroll
   for (int j = 0; j < HQ; ++j) {
     const int c = q * HQ + j;
-    const float xh = (z[j] - sm1[c]) * sm1[HH + c];
-    dz1[j] = s.gamma[c] * sm1[HH + c] * (dn1[j] - s.sums[c] - xh * s.sums[HH + c]);
+    const float xh = (z1[j] - s.sm[0][c]) * s.sm[1][c];
+    dz1[j] = s.gamma[c] * s.sm[1][c] * (dn1[j] - s.sums[c] - xh * s.sums[HH + c]);
   }
   store8(a.DZ1 + (size_t)k * a.B * HH, row, q, on, dz1);
   park8(s.V2, lane, q, dz1);
   __syncthreads();
   lin_tq(s.Wt[0], s.V2, lane, q, t);
-  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
 #pragma unroll
   for (int j = 0; j < HQ; ++j) dh[j] += t[j];
-  if (k > 0) {                                       // block-uniform
-    store8(a.DH + (size_t)(k - 1) * a.B * HH, row, q, on, dh);
-    bwd_part_a4(PRM, s, a, d, k - 1, row, on, lane, q, dh);
+  if (more) {
+    store8(a.DH + (size_t)kp * a.B * HH, row, q, on, dh);
+    bwd_part_a4(s, a, kp, on, lane, q, dh, zp, 1, 2);
     return;
   }
-  float h0[HQ];
-  load8(a.H, row, q, on, h0);
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) dh[j] = h0[j] > 0.f ? dh[j] : 0.f;
+  for (int j = 0; j < HQ; ++j) dh[j] = zp[j] > 0.f ? dh[j] : 0.f;
   store8(a.DZIN, row, q, on, dh);
 }
 
@@ -617,6 +808,12 @@ __global__ void __launch_bounds__(FT * NQ) g_bwd_c4_kernel(const float* __restri
 }  // namespace pcg
 
 using namespace pcg;
+
+static int set_heads_lds(const void* fn, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e)); return PCG_ERR_LAUNCH; }
+  return PCG_OK;
+}
 
 // output heads (and the continuous head, index nheads) dealt to the four waves: largest first onto the least loaded wave
 static HeadOwner deal_heads(const GDesc& d) {
@@ -658,17 +855,23 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
   BNState bs{};
   for (int i = 0; i < 2 * NBLK; ++i) { bs.running_mean[i] = args->running_mean[i]; bs.running_var[i] = args->running_var[i]; bs.nbt[i] = args->num_batches_tracked[i]; }
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(a.nblocks), block(FT);
-  hipLaunchKernelGGL(g_fwd_first_kernel, grid, block, 0, s, args->params, a, d);
-  if (int e = launch_status("g_fwd_first_kernel")) return e;
-  const dim3 block4(FT * NQ);
+  const dim3 grid(a.nblocks), block4(FT * NQ);
+  static int once = set_heads_lds(reinterpret_cast<const void*>(g_heads4_kernel), sizeof(SmemHeads));
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL(g_fwd_first4_kernel, grid, block4, 0, s, args->params, a, d);
+  if (int e = launch_status("g_fwd_first4_kernel")) return e;
   for (int k = 0; k < NBLK; ++k) {
-    hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    const bool more = k < NBLK - 1;
+    const FSeg fa{d.fg_w[k], d.fg_b[k], d.fb_w[k], d.fb_b[k], d.fc2_w[k], d.fc2_b[k], d.bn1_g[k], d.bn1_b[k],
+                  bs.running_mean[2 * k], bs.running_var[2 * k], bs.nbt[2 * k], k, 2 * k, 1};
+    const FSeg fb{d.fg_w[k], d.fg_b[k], d.fb_w[k], d.fb_b[k], more ? d.fc1_w[k + 1] : 0, more ? d.fc1_b[k + 1] : 0, d.bn2_g[k], d.bn2_b[k],
+                  bs.running_mean[2 * k + 1], bs.running_var[2 * k + 1], bs.nbt[2 * k + 1], k, 2 * k + 1, more ? 1 : 0};
+    hipLaunchKernelGGL(g_fwd_a4_kernel, grid, block4, 0, s, args->params, a, fa);
     if (int e = launch_status("g_fwd_a4_kernel")) return e;
-    hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, d, bs, k);
+    hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, fb);
     if (int e = launch_status("g_fwd_b4_kernel")) return e;
   }
-  hipLaunchKernelGGL(g_heads4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
+  hipLaunchKernelGGL(g_heads4_kernel, grid, block4, sizeof(SmemHeads), s, args->params, a, d, deal_heads(d));
   if (int e = launch_status("g_heads4_kernel")) return e;
   return PCG_OK;
 }
@@ -690,12 +893,16 @@ extern "C" int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_b
   a.tau = args->tau; a.res_scale = args->res_scale;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.nblocks), block4(FT * NQ);
-  hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, 0, s, args->params, a, d, deal_heads(d));
+  static int once = set_heads_lds(reinterpret_cast<const void*>(g_bwd_first4_kernel), sizeof(SmemHeads) + sizeof(Smem4));
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, sizeof(SmemHeads) + sizeof(Smem4), s, args->params, a, d, deal_heads(d));
   if (int e = launch_status("g_bwd_first4_kernel")) return e;
   for (int k = NBLK - 1; k >= 0; --k) {
-    hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    const BSeg fb{d.fg_w[k], d.fg_b[k], d.fb_w[k], d.fb_b[k], d.fc2_w[k], d.bn2_g[k], d.bn2_b[k], d.bn1_g[k], d.bn1_b[k], k};
+    const CSeg fc{d.fc1_w[k], d.bn1_g[k], d.bn1_b[k], k > 0 ? d.fg_w[k - 1] : 0, k > 0 ? d.fg_b[k - 1] : 0, k};
+    hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, fb);
     if (int e = launch_status("g_bwd_b4_kernel")) return e;
-    hipLaunchKernelGGL(g_bwd_c4_kernel, grid, block4, 0, s, args->params, a, d, k);
+    hipLaunchKernelGGL(g_bwd_c4_kernel, grid, block4, 0, s, args->params, a, fc);
     if (int e = launch_status("g_bwd_c4_kernel")) return e;
   }
   return PCG_OK;

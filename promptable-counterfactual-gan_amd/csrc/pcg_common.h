@@ -5,6 +5,15 @@
 #include <stddef.h>
 #include "../../include/pcgan_hip.h"
 
+// Phase timestamps inside a kernel (scripts/probes/seg_timing_probe.hip builds the kernel sources with -DPCG_SEG_TIMING and
+// provides pcg_dbg_ts); compiled out of the library.
+#ifdef PCG_SEG_TIMING
+extern __device__ unsigned long long* pcg_dbg_ts;
+#define PCG_T(i) do { if (threadIdx.x == 0 && pcg_dbg_ts) pcg_dbg_ts[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define PCG_T(i) do { } while (0)
+#endif
+
 namespace pcg {
 
 // ---- error reporting (thread-local text behind pcg_last_error()) -------------------------------

@@ -97,15 +97,6 @@ __global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict
 // hyper[0] = lr / (1 - beta1^step) ; hyper[1] = sqrt(1 - beta2^step)
 struct AdamHyper { float step_size, bc2_sqrt; };
 
-__global__ void adam_tick_kernel(int64_t* step_counter, double lr, double beta1, double beta2, AdamHyper* out) {
-  const int64_t t = step_counter[0] + 1;
-  step_counter[0] = t;
-  const double bc1 = 1.0 - pow(beta1, (double)t);
-  const double bc2 = 1.0 - pow(beta2, (double)t);
-  out->step_size = (float)(lr / bc1);
-  out->bc2_sqrt = (float)sqrt(bc2);
-}
-
 struct AdamConst { float lr, w1, one_minus_w1, beta2, one_minus_beta2, eps, wd; int decoupled; };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamConst& k, float step_size,
@@ -123,11 +114,24 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);
 }
 
+// Capturable stepping without a separate "tick" launch: the step counter lives on the device; every thread reads it at entry and
+// forms the bias corrections for step t itself (two pow() in double: noise next to the memory pass), and the LAST block to finish
+// (atomic ticket) writes t back — every block has read the old value by then, whatever the grid size.
+//   mode 0: hy is given by value;  1: t = step + 1, the last block stores it;  2: t = step (a preceding launch already ticked)
+struct AdamTick { int64_t* step; int* ticket; double lr, beta1, beta2; int mode; };
+
 template <int VEC>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n, AdamConst k,
-                                                   AdamHyper hy, const AdamHyper* hy_dev) {
-  if (hy_dev) hy = *hy_dev;
+                                                   AdamHyper hy, AdamTick tk) {
+  int64_t t = 0;
+  if (tk.mode) {
+    t = tk.step[0] + (tk.mode == 1 ? 1 : 0);
+    const double bc1 = 1.0 - pow(tk.beta1, (double)t);
+    const double bc2 = 1.0 - pow(tk.beta2, (double)t);
+    hy.step_size = (float)(tk.lr / bc1);
+    hy.bc2_sqrt = (float)sqrt(bc2);
+  }
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     if constexpr (VEC == 4) {
@@ -146,6 +150,15 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
       float p = param[i], mm = m[i], vv = v[i];
       adam_one(p, grad[i], mm, vv, k, hy.step_size, hy.bc2_sqrt);
       param[i] = p; m[i] = mm; v[i] = vv;
+    }
+  }
+  if (tk.mode == 1) {          // kernel-uniform
+    __syncthreads();           // every thread of this block has read the counter
+    if (threadIdx.x == 0) {             // (no fence: nothing but the counter itself travels between blocks, and it is only written here)
+      if (atomicAdd(tk.ticket, 1) == (int)gridDim.x - 1) {
+        tk.step[0] = t;
+        *tk.ticket = 0;
+      }
     }
   }
 }
@@ -169,18 +182,21 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p,
 }
 
 int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                double wd, int decoupled, AdamHyper hy, const AdamHyper* hy_dev, hipStream_t s) {
+                double wd, int decoupled, AdamHyper hy, int64_t* step_dev, int* ticket_dev, hipStream_t s) {
   const bool al = al16(param) && al16(grad) && al16(m) && al16(v);
   const AdamConst k{(float)lr, (float)(1.0 - beta1), (float)(1.0 - (1.0 - beta1)), (float)beta2, (float)(1.0 - beta2), (float)eps,
                     (float)wd, decoupled};
   // 16-byte lanes over the bulk, a scalar launch for the 1..3 trailing elements (a flat buffer that ends in a bias of one element —
   // the WGAN-GP critic's Linear(1024, 1) — used to send all 25 M parameters down the scalar kernel)
   const int64_t bulk = al ? (n & ~(int64_t)3) : 0;
-  if (bulk)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)bulk / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, k, hy, hy_dev);
+  AdamTick tk{step_dev, ticket_dev, lr, beta1, beta2, step_dev ? 1 : 0};
+  if (bulk) {
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)bulk / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, k, hy, tk);
+    if (tk.mode) tk.mode = 2;      // the trailing launch uses the counter the bulk launch's last block stored
+  }
   if (n > bulk)
     hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)(n - bulk))), dim3(256), 0, s, param + bulk, grad + bulk, m + bulk, v + bulk,
-                       (size_t)(n - bulk), k, hy, hy_dev);
+                       (size_t)(n - bulk), k, hy, tk);
   return launch_status("adam_kernel");
 }
 
@@ -233,7 +249,7 @@ extern "C" int pcg_adam_step(float* param, const float* grad, float* exp_avg, fl
   hy.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
   hy.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
   return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, nullptr,
-                     (hipStream_t)stream);
+                     nullptr, (hipStream_t)stream);
 }
 
 extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
@@ -242,11 +258,10 @@ extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* 
   PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_counter_dev && hyper_scratch2_dev,
               "pcg_adam_step_capturable: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  AdamHyper* hd = reinterpret_cast<AdamHyper*>(hyper_scratch2_dev);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step_counter_dev, lr, beta1, beta2, hd);
-  if (int e = launch_status("adam_tick_kernel")) return e;
+  // hyper_scratch2_dev: 8 zero-initialised bytes — the ticket of the last-block tick (left zero by every launch)
   AdamHyper hy{0.f, 1.f};
-  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, hd, s);
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, step_counter_dev,
+                     reinterpret_cast<int*>(hyper_scratch2_dev), s);
 }
 
 extern "C" int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream) {

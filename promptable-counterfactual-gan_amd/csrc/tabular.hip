@@ -75,6 +75,57 @@ __global__ void __launch_bounds__(256) gemm_kernel(int transA, int transB, int M
   }
 }
 
+// Skinny-N GEMM: C[M][N <= 32] (+)= A[M][K] opB (+ bias).  The 64x64 tile above gives such a problem one block per 64 rows (M = 4096,
+// N = 17, K = 256 — the frozen classifier's grad-input to the 17 features: 64 blocks on 256 CUs, 16 latency-bound k-steps, 48 us).
+// Here opB (K x N) sits in LDS whole, a block owns 16 rows (256 blocks at M = 4096) and a thread two columns of one row.
+constexpr int SK_R = 16, SK_LDB = 33;
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(int transB, int M, int N, int K, const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                          const float* __restrict__ bias, int accumulate, int act_on, float neg) {
+  extern __shared__ float sk_lds[];
+  float* Bs = sk_lds;                 // [K][33]
+  float* As = sk_lds + K * SK_LDB;    // [16][K + 1]
+  for (int e = threadIdx.x; e < K * N; e += 256) {
+    const int k = transB ? e % K : e / N, n = transB ? e / K : e % N;
+    Bs[k * SK_LDB + n] = transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n];
+  }
+  const int m0 = blockIdx.x * SK_R;
+  for (int e = threadIdx.x; e < SK_R * K; e += 256) {
+    const int r = e / K, k = e - r * K, m = m0 + r;
+    As[r * (K + 1) + k] = m < M ? A[(size_t)m * lda + k] : 0.f;
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const float* a = As + r * (K + 1);
+  float acc0 = 0.f, acc1 = 0.f;
+  const bool two = c + 16 < N;
+  for (int k = 0; k < K; ++k) {
+    const float av = a[k];
+    acc0 = fmaf(av, Bs[k * SK_LDB + c], acc0);
+    acc1 = fmaf(av, Bs[k * SK_LDB + c + 16], acc1);      // columns >= N of Bs are never written: the product is discarded below
+  }
+  const int m = m0 + r;
+  if (m >= M) return;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = c + 16 * j;
+    if (n >= N || (j == 1 && !two)) continue;
+    float v = (j ? acc1 : acc0) + (bias ? bias[n] : 0.f);
+    float* cp = C + (size_t)m * ldc + n;
+    if (accumulate) v += *cp;
+    if (act_on) v = act_neg_scale(v, neg);
+    *cp = v;
+  }
+}
+static bool launch_skinny(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          const float* bias, int accumulate, int act_on, float neg, hipStream_t s) {
+  if (transA || N > 32 || N < 2 || K > 320 || M < 512) return false;
+  const size_t lds = ((size_t)K * SK_LDB + (size_t)SK_R * (K + 1)) * sizeof(float);     // <= 63 KB at K = 320
+  hipLaunchKernelGGL(gemm_skinny_kernel, dim3((M + SK_R - 1) / SK_R), dim3(256), lds, s, transB, M, N, K, A, lda, B, ldb, C, ldc, bias,
+                     accumulate, act_on, neg);
+  return true;
+}
+
 // dW[O][I] (+)= dy^T x, db[O] (+)= column sums of dy, reducing over the B rows: the batch is split into S slabs across
 // blockIdx.z; every slab writes its partial tile, and the block that takes the last ticket of a tile adds the S partials in
 // slab order (deterministic, no float atomics).  x is seen with a virtual column of ones at index I, whose "weight gradient"
@@ -142,15 +193,18 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ dy, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-        if (m < O && n < NP) mine[(size_t)m * NP + n] = acc[i][j];
+        if (m < O && n < NP) __hip_atomic_store(mine + (size_t)m * NP + n, acc[i][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    __syncthreads();                              // all partial stores of this block are issued (vector stores go to L2)
+    // The partials travel between blocks (other XCDs, other L2s) as agent-scope relaxed atomics: stores that write through, loads
+    // that do not hit a stale line.  No agent-scope fence: a release / acquire pair here is a whole-L2 write-back and invalidate PER
+    // BLOCK, and a launch has ~1000 blocks taking tickets — measured, that serialised to 43-65 us per launch for ~10 us of work.
+    // Order: every thread's stores are complete (vmcnt 0) before the barrier, the ticket is taken behind the barrier.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
     if (threadIdx.x == 0) {
-      // release: write this XCD's L2 back so the partials are visible device-wide; acquire: drop stale lines before the
-      // last block reads the other slabs.  One fence pair per block (thread 0, after the barrier), not one per thread.
-      const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = t == S - 1;
-      if (s_last) *ticket = 0;
+      if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
@@ -165,11 +219,11 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ dy, 
       for (; z + 16 <= S; z += 16) {       // 16 slabs in flight per output (the tail of the launch is this one block's latency chain)
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(z + j) * O * NP];
+        for (int j = 0; j < 16; ++j) v[j] = __hip_atomic_load(src + (size_t)(z + j) * O * NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int j = 0; j < 16; ++j) sum += v[j];
       }
-      for (; z < S; ++z) sum += src[(size_t)z * O * NP];
+      for (; z < S; ++z) sum += __hip_atomic_load(src + (size_t)z * O * NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (n < I) {
         float* p = dW + (size_t)m * I + n;
         *p = accW ? *p + sum : sum;
@@ -363,6 +417,42 @@ __global__ void __launch_bounds__(1024) mean_small_kernel(const float* __restric
   }
   if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
 }
+// The logged scalars of the tabular step in ONE launch: the three critic-output means (each with mean_small_kernel's exact reduction
+// tree) and the weighted combinations the trainer forms from them (each with weighted_sum_fwd_kernel's fma chain, in its term order):
+//   out[0] = D_loss = mean(d_fake) - mean(d_real)                                  (trainer.py:292)
+//   out[1] = G_loss = -mean(d_fake_g) + l_cls*g_cls + l_reg*am + l_mask*pen        (:299, :307-312)
+//   out[2] = g_adv  = -mean(d_fake_g)       out[3] = g_reg = w_reg_log * am        out[4] = mean(d_fake_g)
+__global__ void __launch_bounds__(1024) house_losses_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake,
+                                                            const float* __restrict__ d_fake_g, size_t n, double inv_n,
+                                                            const float* __restrict__ g_cls, const float* __restrict__ am,
+                                                            const float* __restrict__ pen, float l_cls, float l_reg, float l_mask,
+                                                            float w_reg_log, float* __restrict__ out) {
+  __shared__ double red[1024];
+  __shared__ float means[3];
+  const float* vec[3] = {d_real, d_fake, d_fake_g};
+#pragma unroll 1
+  for (int v = 0; v < 3; ++v) {
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += vec[v][i];
+    red[threadIdx.x] = (double)acc;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) means[v] = (float)(red[0] * inv_n);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float m_real = means[0], m_fake = means[1], m_g = means[2];
+    out[0] = fmaf(-1.f, m_real, fmaf(1.f, m_fake, 0.f));
+    out[1] = fmaf(l_mask, pen[0], fmaf(l_reg, am[0], fmaf(l_cls, g_cls[0], fmaf(-1.f, m_g, 0.f))));
+    out[2] = fmaf(-1.f, m_g, 0.f);
+    out[3] = fmaf(w_reg_log, am[0], 0.f);
+    out[4] = m_g;
+  }
+}
+
 __global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ gout, float scale, size_t n, float* __restrict__ dx) {
   const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = g;
@@ -559,6 +649,8 @@ extern "C" int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_
   PCG_REQUIRE(act_is_cheap(act), "pcg_gemm_act: only ReLU / LeakyReLU are fused (activation %d)", act);
   if (launch_rowdot(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope), (hipStream_t)stream))
     return launch_status("rowdot_kernel");
+  if (launch_skinny(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope), (hipStream_t)stream))
+    return launch_status("gemm_skinny_kernel");
   hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), 0, (hipStream_t)stream, transA, transB, M, N, K,
                      A, lda, B, ldb, C, ldc, bias, accumulate, act != PCG_ACT_NONE, act_neg_of(act, slope));
   return launch_status("gemm_kernel");
@@ -751,6 +843,16 @@ extern "C" int pcg_mean_fwd(const float* x, int64_t n, float* out, void* workspa
   if (int e = launch_status("mean_partial_kernel")) return e;
   hipLaunchKernelGGL(mean_finish_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, MEAN_BLOCKS, 1.0 / (double)n, out);
   return launch_status("mean_finish_kernel");
+}
+
+extern "C" int pcg_house_losses(const float* d_real, const float* d_fake, const float* d_fake_g, int64_t n, const float* g_cls,
+                                const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask, float w_reg_log,
+                                float* out5, pcg_stream_t stream) {
+  PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
+              "pcg_house_losses: bad arguments (critic outputs of at most 16384 rows)");
+  hipLaunchKernelGGL(house_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n,
+                     g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5);
+  return launch_status("house_losses_kernel");
 }
 
 extern "C" int pcg_mean_bwd(const float* grad_out_dev, float grad_scale, int64_t n, float* dx, pcg_stream_t stream) {

@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError, load as _lib_load
 from .countergan import CrossEntropyLoss, abs_mean, grad_norm  # noqa: F401  (same loss kernels)
 from .nn import FlatModule, affine_fwd, linear_dgrad as _lin_dgrad, linear_fwd as _lin_fwd, linear_wgrad as _lin_wgrad, mean, weighted_sum  # noqa: F401
 from .optim import Adam
@@ -857,6 +857,8 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
     branch, branch2 = branch if isinstance(branch, (tuple, list)) else (branch, None)
     main = torch.cuda.current_stream()
+    if isinstance(branch, str):        # "inline": this schedule's kernels, all on the current stream (no fork: every wait is a no-op)
+        branch = main
     discriminator._ensure_flat()
     cot_pos, cot_neg = _mean_cotangents(B, dev)
     d_feat = float(x.shape[1])
@@ -924,12 +926,20 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     # the logged scalars: on the branch, as soon as the last critic forward is out
     branch.wait_event(fwd_done)
     with torch.cuda.stream(branch), torch.no_grad():
-        m_fake = ops.mean_fwd(d_fake_for_g.contiguous()).view(())
-        d_loss = ops.weighted_sum_fwd([ops.mean_fwd(d_fake.contiguous()), ops.mean_fwd(d_real.contiguous())], [1.0, -1.0]).view(())   # :292
-        g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am.detach(), mask_penalty_pre.detach()],
-                                      [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]]).view(())   # :307-312
-        g_adv = ops.weighted_sum_fwd([m_fake], [-1.0]).view(())
-        g_reg = ops.weighted_sum_fwd([am.detach()], [d_feat]).view(())
+        if B <= 16 * 1024:       # all five in one launch (same reduction trees and fma chains: the same bits)
+            out5 = torch.empty(5, dtype=torch.float32, device=dev)
+            ops.check(_lib_load().pcg_house_losses(ops._p(d_real), ops._p(d_fake), ops._p(d_fake_for_g), B, ops._p(g_cls), ops._p(am.detach()),
+                                                   ops._p(mask_penalty_pre.detach()), float(config["lambda_cls"]),
+                                                   float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat, ops._p(out5),
+                                                   ops._stream()), "pcg_house_losses")
+            d_loss, g_loss, g_adv, g_reg = out5[0], out5[1], out5[2], out5[3]                 # :292, :307-312
+        else:
+            m_fake = ops.mean_fwd(d_fake_for_g.contiguous()).view(())
+            d_loss = ops.weighted_sum_fwd([ops.mean_fwd(d_fake.contiguous()), ops.mean_fwd(d_real.contiguous())], [1.0, -1.0]).view(())
+            g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am.detach(), mask_penalty_pre.detach()],
+                                          [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]]).view(())
+            g_adv = ops.weighted_sum_fwd([m_fake], [-1.0]).view(())
+            g_reg = ops.weighted_sum_fwd([am.detach()], [d_feat]).view(())
     for t in (d_real, d_fake, d_fake_for_g):
         t.record_stream(branch)
     main.wait_stream(branch)                                                                  # join: dx_cls, am, mask_penalty_pre
@@ -1021,6 +1031,8 @@ class GraphedTrainStep:
         # stream for the critic's real pass (bit-identical, no gain measured: see _train_step_branch)
         if overlap == "critic":
             self.branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        elif overlap == "inline":
+            self.branch = "inline"
         else:
             self.branch = torch.cuda.Stream(device=dev) if overlap else None
         D_in, T = config["input_dim"], generator.total_cat
