@@ -364,9 +364,10 @@ size_t pcg_linear_wgrad_workspace_bytes(int32_t B, int32_t O, int32_t I);
 int32_t pcg_linear_wgrad_ticket_count(void);
 int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int32_t B, int32_t O, int32_t I, float* dW, float* db,
                      int accumulate_w, int accumulate_b, void* workspace, size_t workspace_bytes, int32_t* tickets, pcg_stream_t stream);
-/* The same for up to 40 items that reduce over the SAME B rows, in one launch — the 35 Linear layers of the tabular generator's
- * backward.  An item is ONE 64x64 output tile (tile_x over the I + 1 columns incl. the bias column, tile_y over the O rows) of a
- * layer: small layers are a single item (tile 0, 0); a 128x64 layer is four.  tickets: int32[>= n_items], zero before first use. */
+/* The same for up to 40 LAYERS that reduce over the SAME B rows, in one launch on the matrix cores — the 29 Linear layers of the
+ * tabular generator's backward.  The library cuts every layer into 32x32 output tiles (at most 64 per call) and the rows into
+ * slabs; tile_x / tile_y are reserved (0).  tickets: int32[>= 64], zero before first use, left zero.
+ * pcg_linear_wgrad_grouped_slabs: partial results per layer the workspace holds. */
 typedef struct pcg_wgrad_item {
   const float* dy; const float* x; float* dW; float* db /*nullable*/;
   int32_t ldy, ldx, O, I, accumulate_w, accumulate_b, tile_x, tile_y;
@@ -548,6 +549,30 @@ int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* c
  * pcg_mean_fwd + pcg_weighted_sum_fwd (bit-identical values), n <= 16384 critic outputs. */
 int pcg_house_losses(const float* d_real, const float* d_fake, const float* d_fake_g, int64_t n, const float* g_cls, const float* am,
                      const float* pen, float lambda_cls, float w_reg, float lambda_mask, float w_reg_log, float* out5, pcg_stream_t stream);
+
+/* The residual block of the tabular step (house_sales_kc_usa/trainer.py:266-287, :305) in one launch each way.
+ * Forward: residual_full (as pcg_assemble_residual_fwd), masked = residual_full * mask, x_cf = x + masked, and the penalties
+ * pen = mean|residual_full * (1 - mask)|, am = mean|masked| — bit-identical to pcg_assemble_residual_fwd + pcg_scale_mask_fwd +
+ * pcg_axpby + 2 x pcg_abs_mean_fwd (same element arithmetic, same partition and trees of the sums).  col_src (HOST int32[D]):
+ * >= 0 the index of a continuous column in cont, -(s + 1) categorical head s.  partial512: 512 floats of scratch; ticket: one
+ * int32, zero before first use, left zero.
+ * Backward: the gradient of  lambda_mask * pen + w_reg * am + <gx_a + gx_b, x_cf>  with respect to (cont, samples) — w_pen =
+ * lambda_mask, w_am = lambda_reg * D as the trainer weighs them; gx_a, gx_b: the two addends of dLoss/dx_cf (critic, classifier).
+ * Bit-identical to the chain pcg_axpby, pcg_weighted_sum_bwd, 2 x pcg_abs_mean_bwd, pcg_axpby, pcg_scale_mask_bwd, add,
+ * pcg_assemble_residual_bwd. */
+int pcg_house_residual_fwd(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
+                           const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
+                           float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out, pcg_stream_t stream);
+int pcg_house_residual_bwd(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b, float w_pen,
+                           float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S, int32_t T,
+                           const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont, float* dsamples,
+                           pcg_stream_t stream);
+/* The three per-iteration draws of the tabular trainer in one launch — target class != y (trainer.py:248-249, as pcg_randint with
+ * exclude), feature mask (:253-255, as pcg_feature_mask), Gumbel noise [B][T] (generator.py:90, as pcg_rand_gumbel) — each from its
+ * own counter offset: the values the three separate calls produce. */
+int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
+                    const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
+                    uint64_t seed, pcg_stream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per

@@ -6,6 +6,7 @@
 //   * latent noise           mnist_dcgan.py:156 torch.randn(b_size, z_dim, 1, 1)
 // The streams differ from torch's generators (RNG parity is by supplied tensors — SURVEY.md §7 "RNG parity"); what is
 // tested is the distribution: exact patch counts, uniform marginals, N(0,1) moments, determinism in (seed, offset).
+#include <algorithm>
 #include "pcg_common.h"
 
 namespace pcg {
@@ -71,10 +72,12 @@ __global__ void __launch_bounds__(256) patch_mask_kernel(float* __restrict__ out
   }
 }
 
-__global__ void __launch_bounds__(256) randint_kernel(int64_t* __restrict__ out, int64_t n, int32_t lo, int32_t hi,
-                                                      const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset) {
+// (the bodies are device functions over the counter index i — four values each — so that a fused launch draws exactly what the
+// separate launches draw)
+__device__ __forceinline__ void randint_quad(int64_t i, int64_t* __restrict__ out, int64_t n, int32_t lo, int32_t hi,
+                                             const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset) {
   const uint32_t span = (uint32_t)(hi - lo);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+  {
     const U4 r = draw(seed, offset, (uint64_t)i);
     const uint32_t v[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -91,6 +94,11 @@ __global__ void __launch_bounds__(256) randint_kernel(int64_t* __restrict__ out,
       }
     }
   }
+}
+__global__ void __launch_bounds__(256) randint_kernel(int64_t* __restrict__ out, int64_t n, int32_t lo, int32_t hi,
+                                                      const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256)
+    randint_quad(i, out, n, lo, hi, exclude, seed, offset);
 }
 
 __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, float mean, float std, uint64_t seed,
@@ -115,22 +123,22 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
 // single log but an infinity under -log(-log(u)))
 __device__ __forceinline__ float u01_open(uint32_t v) { return ((float)(v >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
-__global__ void __launch_bounds__(256) gumbel_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
-    const U4 r = draw(seed, offset, (uint64_t)i);
-    const uint32_t v[4] = {r.x, r.y, r.z, r.w};
+__device__ __forceinline__ void gumbel_quad(int64_t i, float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  const U4 r = draw(seed, offset, (uint64_t)i);
+  const uint32_t v[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t j = i * 4 + e;
-      if (j < n) out[j] = -logf(-logf(u01_open(v[e])));
-    }
+  for (int e = 0; e < 4; ++e) {
+    const int64_t j = i * 4 + e;
+    if (j < n) out[j] = -logf(-logf(u01_open(v[e])));
   }
 }
+__global__ void __launch_bounds__(256) gumbel_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) gumbel_quad(i, out, n, seed, offset);
+}
 
-__global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ out, int B, int D, const int* __restrict__ zero_cols, int nz,
-                                                           uint64_t seed, uint64_t offset) {
-  const int64_t n = (int64_t)B * D;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
+__device__ __forceinline__ void feature_mask_quad(int64_t i, float* __restrict__ out, int64_t n, int D, const int* __restrict__ zero_cols, int nz,
+                                                  uint64_t seed, uint64_t offset) {
+  {
     const U4 r = draw(seed, offset, (uint64_t)i);
     const uint32_t v[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -143,6 +151,23 @@ __global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ o
       out[j] = on ? 1.f : 0.f;
     }
   }
+}
+__global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ out, int B, int D, const int* __restrict__ zero_cols, int nz,
+                                                           uint64_t seed, uint64_t offset) {
+  const int64_t n = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256)
+    feature_mask_quad(i, out, n, D, zero_cols, nz, seed, offset);
+}
+// the three per-iteration draws of the tabular trainer (trainer.py:248-255, generator.py:90) in one launch
+__global__ void __launch_bounds__(256) house_draws_kernel(int64_t* __restrict__ target, int B, int32_t lo, int32_t hi, const int64_t* __restrict__ y,
+                                                          uint64_t off_t, float* __restrict__ mask, int D, const int* __restrict__ zero_cols, int nz,
+                                                          uint64_t off_m, float* __restrict__ noise, int64_t n_noise, uint64_t off_n, uint64_t seed) {
+  const int64_t nm = (int64_t)B * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n_noise + 3) / 4; i += (int64_t)gridDim.x * 256) gumbel_quad(i, noise, n_noise, seed, off_n);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (nm + 3) / 4; i += (int64_t)gridDim.x * 256)
+    feature_mask_quad(i, mask, nm, D, zero_cols, nz, seed, off_m);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ((int64_t)B + 3) / 4; i += (int64_t)gridDim.x * 256)
+    randint_quad(i, target, B, lo, hi, y, seed, off_t);
 }
 
 __global__ void __launch_bounds__(256) uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
@@ -217,6 +242,17 @@ extern "C" int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t*
   hipLaunchKernelGGL(feature_mask_kernel, dim3(grid_for(((int64_t)B * D + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, B, D, zero_cols,
                      n_zero_cols, seed, offset);
   return launch_status("feature_mask_kernel");
+}
+
+extern "C" int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
+                               const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
+                               uint64_t seed, pcg_stream_t stream) {
+  PCG_REQUIRE(target_y && y && mask && noise && B > 0 && num_classes > 1 && D > 0 && T > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0),
+              "pcg_house_draws: bad arguments");
+  const int64_t quads = std::max(((int64_t)B * T + 3) / 4, ((int64_t)B * D + 3) / 4);
+  hipLaunchKernelGGL(house_draws_kernel, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, target_y, B, 0, num_classes, y, offset_target, mask, D,
+                     zero_cols, n_zero_cols, offset_mask, noise, (int64_t)B * T, offset_noise, seed);
+  return launch_status("house_draws_kernel");
 }
 
 extern "C" int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream) {

@@ -5,6 +5,7 @@
 // normalisation, one-hot, column concat/split, mean.  Round-1 status: correct and graph-capturable, but one launch per
 // op — the layer chain is launch-latency bound; the MI355X-shaped answer is one persistent fused kernel.
 // Reference call sites are cited next to each prototype in include/pcgan_hip.h.
+#include <algorithm>
 #include "pcg_common.h"
 
 namespace pcg {
@@ -256,19 +257,104 @@ __global__ void __launch_bounds__(256) linear_wgrad_kernel(const float* __restri
                     blockIdx.y, blockIdx.z);
 }
 
-// Many small layers of one backward pass in ONE launch (a step of the tabular generator has 35 of them): blockIdx.y picks the
-// layer, blockIdx.x the row slab.  Every layer here is a single 64x64 output tile (O <= 64, I + 1 <= 64).
-constexpr int WG_MAX_ITEMS = 40;
-struct WgradGroup {
-  const float* dy[WG_MAX_ITEMS]; const float* x[WG_MAX_ITEMS]; float* dW[WG_MAX_ITEMS]; float* db[WG_MAX_ITEMS];
-  int ldy[WG_MAX_ITEMS], ldx[WG_MAX_ITEMS], O[WG_MAX_ITEMS], I[WG_MAX_ITEMS], poff[WG_MAX_ITEMS];
-  unsigned char accW[WG_MAX_ITEMS], accB[WG_MAX_ITEMS], tx[WG_MAX_ITEMS], ty[WG_MAX_ITEMS];
+// Many small layers of one backward pass in ONE launch (a step of the tabular generator has 29 of them, 35 tiles), on the matrix
+// cores: dW[O][I] = dy^T x is a [O x rows] x [rows x I] product whose operands are ALREADY in MFMA layout in global memory — for
+// v_mfma_f32_32x32x2_f32 lane (li, lh) supplies A[m = li][k = lh] = dy[row + lh][m0 + li] and B[k = lh][n = li] = x[row + lh][n0 + li]:
+// two coalesced 128-byte reads per half-wave, no LDS staging.  A WAVE owns (32x32 output tile, slab of rows); the four waves of a
+// block add their tiles through LDS in wave order, blocks leave one partial each, and the block that takes the last ticket of a
+// tile adds the partials in block order (deterministic, no float atomics; the partials travel as agent-scope relaxed atomics, see
+// linear_wgrad_body).  The bias gradient is the column sum of dy: accumulated on the side by the tile_x = 0 waves.
+// (The first version ran these layers through the 64x64 VALU tile above: a 32x33 layer keeps 72 of 256 threads busy, and the launch
+// was VALU-bound on padding — 31-65 us for 0.3 GFLOP.)
+constexpr int WM_MAX_ITEMS = 40, WM_MAX_TILES = 64, WM_T = 32, WM_NP = WM_T + 1;
+struct WgradMfmaGroup {
+  const float* dy[WM_MAX_ITEMS]; const float* x[WM_MAX_ITEMS]; float* dW[WM_MAX_ITEMS]; float* db[WM_MAX_ITEMS];
+  int ldy[WM_MAX_ITEMS], ldx[WM_MAX_ITEMS], O[WM_MAX_ITEMS], I[WM_MAX_ITEMS], poff[WM_MAX_ITEMS];
+  unsigned char accW[WM_MAX_ITEMS], accB[WM_MAX_ITEMS];
+  unsigned char t_item[WM_MAX_TILES], t_x[WM_MAX_TILES], t_y[WM_MAX_TILES];
 };
-__global__ void __launch_bounds__(256) linear_wgrad_grouped_kernel(WgradGroup g, int B, int S, int chunk, float* __restrict__ partial,
-                                                                   int* __restrict__ tickets) {
-  const int it = blockIdx.y;
-  linear_wgrad_body(g.dy[it], g.ldy[it], g.x[it], g.ldx[it], B, g.O[it], g.I[it], g.dW[it], g.db[it], g.accW[it], g.accB[it], S, chunk,
-                    partial + g.poff[it], tickets + it, g.tx[it], g.ty[it], blockIdx.x);
+typedef float wm_acc_t __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g, int B, int Sb, int chunk, float* __restrict__ partial,
+                                                                int* __restrict__ tickets) {
+  __shared__ float red[4][WM_T * WM_NP];
+  __shared__ int s_last;
+  const int tile = blockIdx.y, sb = blockIdx.x;
+  const int it = g.t_item[tile], m0 = g.t_y[tile] * WM_T, n0 = g.t_x[tile] * WM_T;
+  const int O = g.O[it], I = g.I[it], ldy = g.ldy[it], ldx = g.ldx[it];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int kbeg = (sb * 4 + wave) * chunk, kend = min(B, kbeg + chunk);
+  const bool va = m0 + li < O, vb = n0 + li < I;
+  const float* pa = g.dy[it] + min(m0 + li, O - 1);          // clamped, not guarded: out-of-tile lanes read a valid element and drop it
+  const float* pb = g.x[it] + min(n0 + li, I - 1);
+  wm_acc_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int r = kbeg; r < kend; r += 32) {                  // 16 MFMA steps of two rows; all 32 loads of a group in flight together
+    float av[16], bv[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int row = r + 2 * st + lh, rc = min(row, kend - 1);
+      const float a = pa[(size_t)rc * ldy], b = pb[(size_t)rc * ldx];
+      av[st] = (row < kend && va) ? a : 0.f;
+      bv[st] = (row < kend && vb) ? b : 0.f;
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc, 0, 0, 0);
+      bsum += av[st];
+    }
+  }
+  bsum += __shfl_xor(bsum, 32);                              // rows of both k-halves: lanes lh = 0 hold column m0 + li of db
+  // the four waves' tiles -> LDS, added in wave order
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * lh) * WM_NP + li] = acc[r];
+  if (lh == 0) red[wave][li * WM_NP + WM_T] = bsum;
+  __syncthreads();
+  const int NP = I + 1;
+  const bool bias_tile = n0 == 0 && g.db[it] != nullptr;
+  float* mine = partial + g.poff[it] + (size_t)sb * O * NP;
+  for (int e = threadIdx.x; e < WM_T * WM_NP; e += 256) {
+    const int m = e / WM_NP, n = e - m * WM_NP;
+    const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    const int gm = m0 + m, gn = n < WM_T ? n0 + n : I;       // n == 32: the bias column, stored at column I of the partial rows
+    const bool ok = gm < O && (n < WM_T ? gn < I : bias_tile);
+    if (!ok) continue;
+    if (Sb == 1) {
+      if (n < WM_T) { float* q = g.dW[it] + (size_t)gm * I + gn; *q = g.accW[it] ? *q + v : v; }
+      else { float* q = g.db[it] + gm; *q = g.accB[it] ? *q + v : v; }
+    } else {
+      __hip_atomic_store(mine + (size_t)gm * NP + gn, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (Sb == 1) return;                                       // kernel-uniform
+  __builtin_amdgcn_s_waitcnt(0);                             // this thread's partial stores are complete ...
+  __syncthreads();                                           // ... every thread's are
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == Sb - 1;
+    if (s_last) __hip_atomic_store(tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const float* base = partial + g.poff[it];
+  for (int e = threadIdx.x; e < WM_T * WM_NP; e += 256) {
+    const int m = e / WM_NP, n = e - m * WM_NP;
+    const int gm = m0 + m, gn = n < WM_T ? n0 + n : I;
+    const bool ok = gm < O && (n < WM_T ? gn < I : bias_tile);
+    if (!ok) continue;
+    const float* src = base + (size_t)gm * NP + gn;
+    float sum = 0.f;
+    int z = 0;
+    for (; z + 8 <= Sb; z += 8) {                            // eight partials in flight per output, added in block order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(src + (size_t)(z + j) * O * NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; z < Sb; ++z) sum += __hip_atomic_load(src + (size_t)z * O * NP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n < WM_T) { float* q = g.dW[it] + (size_t)gm * I + gn; *q = g.accW[it] ? *q + sum : sum; }
+    else { float* q = g.db[it] + gm; *q = g.accB[it] ? *q + sum : sum; }
+  }
 }
 
 __global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
@@ -379,6 +465,117 @@ __global__ void __launch_bounds__(256) assemble_bwd_kernel(const float* __restri
       const int s = j - ncont;
       const float d = dres[(size_t)b * D + cat_idx[s]];
       for (int c = seg[s]; c < seg[s + 1]; ++c) dsamples[(size_t)b * T + c] = d * norm[c];
+    }
+  }
+}
+
+// ---- the residual block of the tabular step (trainer.py:266-287, :305) in two launches -------------------------------------------
+// forward: residual_full (assemble), masked_residual = residual_full * mask, x_cf = x + masked_residual, and the two penalties
+// mean|residual_full * (1 - mask)|, mean|masked_residual| — what pcg_assemble_residual_fwd + pcg_scale_mask_fwd + pcg_axpby +
+// 2 x pcg_abs_mean_fwd compute in seven launches, with the same element arithmetic, the same partition of the sums over threads and
+// the same reduction trees (so the same bits).  Contraction is off: every product and sum below was a rounded result in its own
+// kernel.  col_src[col] >= 0: continuous column (index into cont); < 0: categorical head -(s + 1).
+struct ResCols { int src[32]; };
+template <bool SMALL>       // SMALL: one block of 1024 threads (n <= 16 K, as pcg_abs_mean_fwd); else 256 blocks of 256 + last-block finish
+__global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
+    const float* __restrict__ cont, int ncont, const float* __restrict__ samples, const int* __restrict__ seg, int T, const float* __restrict__ norm,
+    const float* __restrict__ x, const float* __restrict__ mask, ResCols cols, int D, size_t n, double inv_n, float* __restrict__ res,
+    float* __restrict__ masked, float* __restrict__ x_cf, float* __restrict__ partial, int* __restrict__ ticket, float* __restrict__ pen_out,
+    float* __restrict__ am_out) {
+#pragma clang fp contract(off)
+  constexpr int NTH = SMALL ? 1024 : 256;
+  __shared__ double redd[2][NTH];
+  __shared__ float redf[2][SMALL ? 1 : 256];
+  __shared__ int s_last;
+  float acc_pen = 0.f, acc_am = 0.f;
+  for (size_t i = (size_t)blockIdx.x * NTH + threadIdx.x; i < n; i += (size_t)gridDim.x * NTH) {
+    const size_t b = i / (size_t)D;
+    const int col = (int)(i - b * (size_t)D), src = cols.src[col];
+    float r;
+    if (src >= 0) {
+      r = cont[b * ncont + src];
+    } else {
+      const int sg = -src - 1;
+      float acc = 0.f;
+      for (int c = seg[sg]; c < seg[sg + 1]; ++c) acc = fmaf(samples[b * T + c], norm[c], acc);
+      r = acc - x[i];
+    }
+    const float mk = mask[i];
+    const float msk = r * mk;                          // (1.0 * r) * mask
+    res[i] = r; masked[i] = msk;
+    x_cf[i] = x[i] + msk;                              // 1.0 * x + 1.0 * masked
+    acc_pen += fabsf(r * (1.f - mk));
+    acc_am += fabsf(msk);                              // |masked * 1.0|
+  }
+  if (SMALL) {
+    redd[0][threadIdx.x] = (double)acc_pen; redd[1][threadIdx.x] = (double)acc_am;
+    __syncthreads();
+    for (int k = NTH / 2; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) { redd[0][threadIdx.x] += redd[0][threadIdx.x + k]; redd[1][threadIdx.x] += redd[1][threadIdx.x + k]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { pen_out[0] = (float)(redd[0][0] * inv_n); am_out[0] = (float)(redd[1][0] * inv_n); }
+    return;
+  } else {
+    redf[0][threadIdx.x] = acc_pen; redf[1][threadIdx.x] = acc_am;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) { redf[0][threadIdx.x] += redf[0][threadIdx.x + k]; redf[1][threadIdx.x] += redf[1][threadIdx.x + k]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(partial + blockIdx.x, redf[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + 256 + blockIdx.x, redf[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);
+      const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == (int)gridDim.x - 1;
+      if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the finish of abs_mean_finish_kernel (256 partials, one per thread, fp64 tree) for both sums
+    redd[0][threadIdx.x] = 0.0 + (double)__hip_atomic_load(partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    redd[1][threadIdx.x] = 0.0 + (double)__hip_atomic_load(partial + 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) { redd[0][threadIdx.x] += redd[0][threadIdx.x + k]; redd[1][threadIdx.x] += redd[1][threadIdx.x + k]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { pen_out[0] = (float)(redd[0][0] * inv_n); am_out[0] = (float)(redd[1][0] * inv_n); }
+  }
+}
+// backward of the same block, given the gradient of the G loss with respect to x_cf as two addends (critic, classifier):
+//   d_res = lambda_mask * d mean|res (1-mask)| + mask * (w_reg * d mean|masked| + (gx_a + gx_b)),   then assemble's backward —
+// pcg_axpby + pcg_weighted_sum_bwd + 2 x pcg_abs_mean_bwd + pcg_axpby + pcg_scale_mask_bwd + autograd's add + pcg_assemble_residual_bwd
+// in one launch, one rounded operation per step as there.  One thread per (row, source column) like assemble_bwd.
+__global__ void __launch_bounds__(256) house_residual_bwd_kernel(const float* __restrict__ res, const float* __restrict__ masked,
+                                                                 const float* __restrict__ mask, const float* __restrict__ gx_a,
+                                                                 const float* __restrict__ gx_b, float w_pen, float w_am, size_t n, int ncont,
+                                                                 const int* __restrict__ cont_idx, const int* __restrict__ seg, int S, int T,
+                                                                 const int* __restrict__ cat_idx, const float* __restrict__ norm, int D, int B,
+                                                                 float* __restrict__ dcont, float* __restrict__ dsamples) {
+#pragma clang fp contract(off)
+  const float g_pen = (w_pen * 1.f) * 1.f / (float)n, g_am = (w_am * 1.f) * 1.f / (float)n;   // weighted_sum_bwd (grad_out = 1), then abs_mean_bwd's g
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * (ncont + S); i += gridDim.x * 256) {
+    const int b = i / (ncont + S), j = i - b * (ncont + S);
+    const int col = j < ncont ? cont_idx[j] : cat_idx[j - ncont];
+    const size_t e = (size_t)b * D + col;
+    const float mk = mask[e];
+    const float w1 = 1.f - mk, v1 = res[e] * w1;
+    const float sg1 = v1 > 0.f ? 1.f : (v1 < 0.f ? -1.f : 0.f);
+    const float d_pen = 0.f + g_pen * sg1 * w1;
+    const float v2 = masked[e] * 1.f;
+    const float sg2 = v2 > 0.f ? 1.f : (v2 < 0.f ? -1.f : 0.f);
+    const float d_am = 0.f + g_am * sg2 * 1.f;
+    const float gx = 1.f * gx_a[e] + 1.f * gx_b[e];
+    const float dsum = 1.f * d_am + 1.f * gx;
+    const float d_mm = 1.f * (0.f + dsum * mk);
+    const float d = d_pen + d_mm;
+    if (j < ncont) {
+      dcont[(size_t)b * ncont + j] = d;
+    } else {
+      const int sgm = j - ncont;
+      for (int c = seg[sgm]; c < seg[sgm + 1]; ++c) dsamples[(size_t)b * T + c] = d * norm[c];
     }
   }
 }
@@ -726,39 +923,55 @@ extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, in
   return launch_status("linear_wgrad_kernel");
 }
 
-extern "C" int32_t pcg_linear_wgrad_grouped_slabs(int32_t B) { return B > 0 ? plan_linear_wgrad(B, 32, 32).S : 0; }   // single-tile plan: depends on B only
+// grouped plan: rows per wave ~128 (64 MFMA steps), slabs in blocks of four waves, at most 16 blocks per tile
+namespace {
+struct WgradMfmaPlan { int Sb, chunk; };
+WgradMfmaPlan plan_wgrad_mfma(int B) {
+  int S = (B + 127) / 128;
+  S = (S + 3) / 4 * 4;
+  if (S > 64) S = 64;
+  int chunk = (B + S - 1) / S;
+  chunk = (chunk + 31) / 32 * 32;
+  return {S / 4, chunk};
+}
+}  // namespace
+
+extern "C" int32_t pcg_linear_wgrad_grouped_slabs(int32_t B) { return B > 0 ? plan_wgrad_mfma(B).Sb : 0; }
 
 extern "C" size_t pcg_linear_wgrad_grouped_workspace_bytes(int32_t B, const pcg_wgrad_item* items, int32_t n_items) {
   if (B <= 0 || n_items <= 0 || !items) return 0;
-  const WgradPlan p = plan_linear_wgrad(B, 32, 32);
+  const WgradMfmaPlan p = plan_wgrad_mfma(B);
   size_t total = 0;
-  for (int i = 0; i < n_items; ++i) total += (size_t)p.S * items[i].O * (items[i].I + 1);
-  return total * sizeof(float);
+  for (int i = 0; i < n_items; ++i) total += (size_t)p.Sb * items[i].O * (items[i].I + 1);
+  return total * sizeof(float) + 16;
 }
 
 extern "C" int pcg_linear_wgrad_grouped(const pcg_wgrad_item* items, int32_t n_items, int32_t B, void* workspace, size_t workspace_bytes,
                                         int32_t* tickets, pcg_stream_t stream) {
-  PCG_REQUIRE(items && n_items > 0 && n_items <= WG_MAX_ITEMS && B > 0 && tickets, "pcg_linear_wgrad_grouped: bad arguments (at most %d items)", WG_MAX_ITEMS);
-  const WgradPlan p = plan_linear_wgrad(B, 32, 32);
+  PCG_REQUIRE(items && n_items > 0 && n_items <= WM_MAX_ITEMS && B > 0 && tickets, "pcg_linear_wgrad_grouped: bad arguments (at most %d layers)", WM_MAX_ITEMS);
+  const WgradMfmaPlan p = plan_wgrad_mfma(B);
   if (!workspace || workspace_bytes < pcg_linear_wgrad_grouped_workspace_bytes(B, items, n_items)) {
     set_error("pcg_linear_wgrad_grouped: workspace too small"); return PCG_ERR_WORKSPACE;
   }
-  WgradGroup g{};
+  WgradMfmaGroup g{};
   size_t off = 0;
+  int nt = 0;
   for (int i = 0; i < n_items; ++i) {
     const pcg_wgrad_item& it = items[i];
-    PCG_REQUIRE(it.dy && it.x && it.dW && it.O > 0 && it.I > 0 && it.ldy >= it.O && it.ldx >= it.I && it.tile_x >= 0 && it.tile_y >= 0 &&
-                    it.tile_x * GT <= it.I && it.tile_y * GT < it.O && it.tile_x < 256 && it.tile_y < 256,
-                "pcg_linear_wgrad_grouped: item %d: bad layer / tile", i);
+    PCG_REQUIRE(it.dy && it.x && it.dW && it.O > 0 && it.I > 0 && it.ldy >= it.O && it.ldx >= it.I, "pcg_linear_wgrad_grouped: layer %d: bad arguments", i);
     g.dy[i] = it.dy; g.x[i] = it.x; g.dW[i] = it.dW; g.db[i] = it.db; g.ldy[i] = it.ldy; g.ldx[i] = it.ldx; g.O[i] = it.O; g.I[i] = it.I;
-    g.accW[i] = it.accumulate_w != 0; g.accB[i] = it.accumulate_b != 0; g.tx[i] = (unsigned char)it.tile_x; g.ty[i] = (unsigned char)it.tile_y;
+    g.accW[i] = it.accumulate_w != 0; g.accB[i] = it.accumulate_b != 0;
     PCG_REQUIRE(off < (1u << 30), "pcg_linear_wgrad_grouped: workspace offset overflow");
     g.poff[i] = (int)off;
-    off += (size_t)p.S * it.O * (it.I + 1);
+    off += (size_t)p.Sb * it.O * (it.I + 1);
+    for (int ty = 0; ty < (it.O + WM_T - 1) / WM_T; ++ty)
+      for (int tx = 0; tx < (it.I + WM_T - 1) / WM_T; ++tx) {
+        PCG_REQUIRE(nt < WM_MAX_TILES, "pcg_linear_wgrad_grouped: more than %d 32x32 output tiles in one call", WM_MAX_TILES);
+        g.t_item[nt] = (unsigned char)i; g.t_x[nt] = (unsigned char)tx; g.t_y[nt] = (unsigned char)ty; ++nt;
+      }
   }
-  hipLaunchKernelGGL(linear_wgrad_grouped_kernel, dim3(p.S, n_items), dim3(256), 0, (hipStream_t)stream, g, B, p.S, p.chunk,
-                     (float*)workspace, tickets);
-  return launch_status("linear_wgrad_grouped_kernel");
+  hipLaunchKernelGGL(linear_wgrad_mfma_kernel, dim3(p.Sb, nt), dim3(256), 0, (hipStream_t)stream, g, B, p.Sb, p.chunk, (float*)workspace, tickets);
+  return launch_status("linear_wgrad_mfma_kernel");
 }
 
 extern "C" int pcg_onehot(const int64_t* idx, int32_t B, int32_t K, float* out, pcg_stream_t stream) {
@@ -878,4 +1091,35 @@ extern "C" int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, in
   hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dw_bar, w_bar, out_features, in_features, u, v,
                      sigma, dw_orig, accumulate);
   return launch_status("spectral_norm_bwd_kernel");
+}
+
+extern "C" int pcg_house_residual_fwd(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
+                                      const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
+                                      float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out, pcg_stream_t stream) {
+  PCG_REQUIRE(cont && samples && seg_dev && norm && x && mask && col_src && res && masked && x_cf && partial512 && ticket && pen_out && am_out &&
+                  B > 0 && D > 0 && D <= 32 && T > 0 && ncont >= 0, "pcg_house_residual_fwd: bad arguments (at most 32 feature columns)");
+  ResCols cols{};
+  for (int c = 0; c < D; ++c) cols.src[c] = col_src[c];
+  const size_t n = (size_t)B * D;
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 16 * 1024) {
+    hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, cont, ncont, samples, seg_dev, T, norm, x, mask, cols, D, n,
+                       1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
+  } else {
+    hipLaunchKernelGGL(house_residual_fwd_kernel<false>, dim3(256), dim3(256), 0, s, cont, ncont, samples, seg_dev, T, norm, x, mask, cols, D, n,
+                       1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
+  }
+  return launch_status("house_residual_fwd_kernel");
+}
+
+extern "C" int pcg_house_residual_bwd(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b, float w_pen,
+                                      float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S, int32_t T,
+                                      const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont, float* dsamples,
+                                      pcg_stream_t stream) {
+  PCG_REQUIRE(res && masked && mask && gx_a && gx_b && cont_idx_dev && seg_dev && cat_idx_dev && norm && dcont && dsamples && B > 0 && D > 0 &&
+                  S >= 0 && T > 0 && ncont >= 0 && ncont + S > 0, "pcg_house_residual_bwd: bad arguments");
+  const size_t work = (size_t)B * (ncont + S);
+  hipLaunchKernelGGL(house_residual_bwd_kernel, dim3((unsigned)std::min<size_t>((work + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, masked,
+                     mask, gx_a, gx_b, w_pen, w_am, (size_t)B * D, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples);
+  return launch_status("house_residual_bwd_kernel");
 }

@@ -227,6 +227,17 @@ class ResidualGenerator(FlatModule):
             self._idx_dev = (mk(self.seg), mk(self.cat_idx), mk(self.continuous_idx))
         return self._idx_dev
 
+    def col_src(self):
+        """Per feature column, where residual_full takes it from: the index of a continuous output (>= 0) or -(head + 1)."""
+        src = [None] * self.input_dim
+        for j, c in enumerate(self.continuous_idx):
+            src[c] = j
+        for s_, c in enumerate(self.cat_idx):
+            src[c] = -(s_ + 1)
+        if any(v is None for v in src):
+            raise PcgError("ResidualGenerator: continuous_idx and categorical_info must cover every feature column")
+        return src
+
     def pack_noise(self, gumbel):
         """dict idx -> [B, n]  ->  packed [B, T] (setup-time helper for tests / supplied draws)."""
         return torch.cat([gumbel[i] for i in self.cat_idx], dim=1).contiguous()
@@ -859,29 +870,33 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     main = torch.cuda.current_stream()
     if isinstance(branch, str):        # "inline": this schedule's kernels, all on the current stream (no fork: every wait is a no-op)
         branch = main
-    discriminator._ensure_flat()
+    discriminator._ensure_flat(); generator._ensure_flat()
     cot_pos, cot_neg = _mean_cotangents(B, dev)
     d_feat = float(x.shape[1])
+    if not x.is_cuda:
+        raise PcgError(f"train_step: input is on {x.device}; libpcgan_hip has no CPU path")
+    seg, cat_idx, cont_idx = generator.index_tables(dev)
+    x, mask = x.contiguous(), mask.contiguous()
     target_onehot = ops.onehot(target_y, nc)                                                  # :250
-    cont, _, samples = generator.forward_packed(x, target_onehot, mask, temperature=config["gumbel_tau"], hard=False,
-                                                gumbel=gumbel)                                # :259-261
-    residual_full = assemble_residual(generator, cont, samples, x, norm_vals)                 # :266-279
-    masked_residual, x_cf = _MaskMulFn.apply(residual_full, mask, x)                          # :281-282
+    with torch.no_grad():            # no autograd graph anywhere in this schedule: every backward below is called directly
+        cont, _, samples, g_saved = generator._run_forward(x, target_onehot, mask, generator._noise(gumbel, B, dev),
+                                                           float(config["gumbel_tau"]), False)            # :259-261
+        # residual assembly, mask, x_cf and both L1 penalties (:266-287, :305): one launch
+        residual_full, masked_residual, x_cf, mask_penalty_pre, am = ops.house_residual_fwd(
+            cont.contiguous(), samples.contiguous(), seg, norm_vals, x, mask, generator.col_src())
+    # the zero-fills of the two gradient buffers are not launched: every parameter of both nets receives a gradient in this step,
+    # so the first writer overwrites (0 + g == g)
+    discriminator.drop_grads(); generator.drop_grads()
     # ---- fork
     branch.wait_stream(main)
     with torch.cuda.stream(branch):
-        opt_d.zero_grad(); opt_g.zero_grad()
-        zeroed = torch.cuda.Event()
-        zeroed.record(branch)
-        mask_penalty_pre = abs_mean(residual_full, mask, one_minus=True)                      # :287
-        am = abs_mean(masked_residual)                                                        # :305
         with torch.no_grad():
             logits_c, acts_c = classifier._run_forward(x_cf.detach().contiguous(), keep=True)                 # :301
             g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
                                                     grad_scale=float(config["lambda_cls"]))                  # :302
             dx_cls = classifier._run_backward(acts_c, dlog)
             g_cls = g_cls.view(())
-    for t in (residual_full, masked_residual, mask, x_cf, target_y):
+    for t in (x_cf, target_y):
         t.record_stream(branch)
     # ---- D step (:290-295)
     xd = x_cf.detach()
@@ -890,7 +905,6 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         if branch2 is None or not discriminator._fused_ok(x, onehot_y):
             d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True)                 # :290
             d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291
-            main.wait_event(zeroed)                                                           # the zero fills were issued on the branch
             discriminator._run_backward(sv_f, cot_pos, False, True)                           # d(mean(d_fake) - mean(d_real))
             discriminator._run_backward(sv_r, cot_neg, False, True)
         else:
@@ -911,7 +925,6 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
             for t in (x, onehot_y, cot_neg) + tuple(tt for grp in sn_r for tt in grp):
                 t.record_stream(branch2)
             d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291 (its own power iteration)
-            main.wait_event(zeroed)
             discriminator._run_backward(sv_f, cot_pos, False, True)
             main.wait_stream(branch2)
             d_real.record_stream(main)
@@ -928,26 +941,28 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     with torch.cuda.stream(branch), torch.no_grad():
         if B <= 16 * 1024:       # all five in one launch (same reduction trees and fma chains: the same bits)
             out5 = torch.empty(5, dtype=torch.float32, device=dev)
-            ops.check(_lib_load().pcg_house_losses(ops._p(d_real), ops._p(d_fake), ops._p(d_fake_for_g), B, ops._p(g_cls), ops._p(am.detach()),
-                                                   ops._p(mask_penalty_pre.detach()), float(config["lambda_cls"]),
+            ops.check(_lib_load().pcg_house_losses(ops._p(d_real), ops._p(d_fake), ops._p(d_fake_for_g), B, ops._p(g_cls), ops._p(am),
+                                                   ops._p(mask_penalty_pre), float(config["lambda_cls"]),
                                                    float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat, ops._p(out5),
                                                    ops._stream()), "pcg_house_losses")
             d_loss, g_loss, g_adv, g_reg = out5[0], out5[1], out5[2], out5[3]                 # :292, :307-312
         else:
             m_fake = ops.mean_fwd(d_fake_for_g.contiguous()).view(())
             d_loss = ops.weighted_sum_fwd([ops.mean_fwd(d_fake.contiguous()), ops.mean_fwd(d_real.contiguous())], [1.0, -1.0]).view(())
-            g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am.detach(), mask_penalty_pre.detach()],
+            g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am, mask_penalty_pre],
                                           [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]]).view(())
             g_adv = ops.weighted_sum_fwd([m_fake], [-1.0]).view(())
-            g_reg = ops.weighted_sum_fwd([am.detach()], [d_feat]).view(())
+            g_reg = ops.weighted_sum_fwd([am], [d_feat]).view(())
     for t in (d_real, d_fake, d_fake_for_g):
         t.record_stream(branch)
-    main.wait_stream(branch)                                                                  # join: dx_cls, am, mask_penalty_pre
-    for t in (dx_cls, am, mask_penalty_pre):
-        t.record_stream(main)
-    gx = ops.axpby(1.0, dx_d, 1.0, dx_cls)                                                    # gradient of g_loss w.r.t. x_cf
-    g_rest = weighted_sum([am, mask_penalty_pre], [config["lambda_reg"] * d_feat, config["lambda_mask"]])
-    torch.autograd.backward([g_rest, x_cf], [_one(dev), gx])                                  # :314-315
+    main.wait_stream(branch)                                                                  # join: dx_cls
+    dx_cls.record_stream(main)
+    with torch.no_grad():
+        # :314-315 from dLoss/dx_cf = dx_d + dx_cls and the two penalty weights down to the generator's outputs: one launch
+        d_cont, d_samples = ops.house_residual_bwd(residual_full, masked_residual, mask, dx_d.contiguous(), dx_cls.contiguous(),
+                                                   config["lambda_mask"], config["lambda_reg"] * d_feat, len(generator.continuous_idx), cont_idx,
+                                                   seg, generator.total_cat, cat_idx, norm_vals)
+        generator._run_backward(g_saved, d_cont, None, d_samples)
     opt_g.step()                                                                              # :316
     main.wait_stream(branch)                                                                  # final join
     for t in (d_loss, g_loss, g_adv, g_reg, g_cls):
@@ -1174,14 +1189,15 @@ def draw_batch_randoms(rng, generator, y, config, device, out=None):
     """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise).
     out = (target_y, mask, noise): draw straight into these buffers (the static inputs of a GraphedTrainStep)."""
     B = y.shape[0]
-    o_t, o_m, o_n = out if out is not None else (None, None, None)
-    target_y = rng.randint(0, config["num_classes"], B, device, exclude=y, out=o_t)
     imm = getattr(generator, "_imm_dev", None)
     if imm is None or imm.device != device:
         imm = torch.tensor(list(config.get("immutable_idx", [])), dtype=torch.int32, device=device)
         generator._imm_dev = imm
-    mask = rng.feature_mask(B, config["input_dim"], device, imm if imm.numel() else None, out=o_m)
-    return target_y, mask, rng.gumbel((B, generator.total_cat), device, out=o_n)
+    if out is None:
+        out = (torch.empty((B,), dtype=torch.int64, device=device), torch.empty((B, config["input_dim"]), dtype=torch.float32, device=device),
+               torch.empty((B, generator.total_cat), dtype=torch.float32, device=device))
+    # one launch; the values of randint(exclude=y), feature_mask, gumbel called in this order
+    return rng.house_draws(y.contiguous(), config["num_classes"], config["input_dim"], generator.total_cat, imm if imm.numel() else None, out)
 
 
 def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):

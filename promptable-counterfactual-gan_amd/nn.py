@@ -105,6 +105,14 @@ class FlatModule(nn.Module):
                 return self._views(self._flat, buf, p, off, n)[1]
         raise PcgError("parameter does not belong to this FlatModule")
 
+    def drop_grads(self):
+        """Forget the gradients without touching memory: the next backward OVERWRITES (p.grad is None = 'no gradient yet', see
+        _grad_view) instead of adding to a zero-filled buffer — 0 + g == g, one fill launch less.  Only for steps in which every
+        parameter receives a gradient (the padding between parameters stays as allocated: zero)."""
+        self._ensure_flat()
+        for p, _, _ in self._seg:
+            p.grad = None
+
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffer in one launch and keep the .grad views (set_to_none is ignored: the
         views are the gradient storage; values after backward are identical either way)."""

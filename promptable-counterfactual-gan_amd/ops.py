@@ -632,21 +632,15 @@ def linear_wgrad(dy, x, B, O, I, dW, db=None, ldy=None, ldx=None, accumulate_w=F
 
 def linear_wgrad_grouped(items, B, device):
     """items: list of (dy, x, O, I, dW, db or None, ldy, ldx, accumulate_w, accumulate_b) — layers that reduce over the same B rows,
-    all in one launch; a layer wider than one 64x64 tile is expanded into one item per tile."""
+    all in one launch (the library tiles them for the matrix cores)."""
     lib = _lib.load()
-    tiles = []
-    for it in items:
-        O, I = it[2], it[3]
-        for ty in range((O + 63) // 64):
-            for tx in range((I + 1 + 63) // 64):
-                tiles.append(it + (tx, ty))
-    n = len(tiles)
+    n = len(items)
     arr = (_lib.WgradItem * n)()
-    for k, (dy, x, O, I, dW, db, ldy, ldx, aw, ab, tx, ty) in enumerate(tiles):
+    for k, (dy, x, O, I, dW, db, ldy, ldx, aw, ab) in enumerate(items):
         arr[k].dy, arr[k].x, arr[k].dW, arr[k].db = dy.data_ptr(), x.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else None)
         arr[k].ldy, arr[k].ldx, arr[k].O, arr[k].I = ldy, ldx, O, I
         arr[k].accumulate_w, arr[k].accumulate_b = int(bool(aw)), int(bool(ab))
-        arr[k].tile_x, arr[k].tile_y = tx, ty
+        arr[k].tile_x, arr[k].tile_y = 0, 0
     tk = _ticket_buffer(device)
     nbytes = lib.pcg_linear_wgrad_grouped_workspace_bytes(B, arr, n)
     ws = workspace2(nbytes, device)
@@ -719,6 +713,38 @@ def assemble_residual_fwd(cont, cont_idx, samples, seg_offsets, cat_idx, norm_va
                                                 samples.shape[1], _p(cat_idx), _p(norm_vals), _p(x), D, B, _p(res), _stream()),
           "pcg_assemble_residual_fwd")
     return res
+
+
+def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src):
+    """(residual_full, masked_residual, x_cf, mask_penalty, am) of the tabular step in one launch: assemble_residual_fwd +
+    scale_mask_fwd + axpby + 2 x abs_mean_fwd, bit for bit.  col_src: host list, per feature column the continuous index (>= 0) or
+    -(head + 1)."""
+    import ctypes
+    _chk(cont, "cont"); _chk(samples, "samples"); _chk(x, "x"); _chk(mask, "mask"); _chk(norm_vals, "norm_vals")
+    B, D = x.shape
+    res, masked, x_cf = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    scal = torch.empty(2, dtype=torch.float32, device=x.device)
+    part = torch.empty(512, dtype=torch.float32, device=x.device)
+    tk = _ticket_buffer(x.device)
+    src = (ctypes.c_int32 * D)(*[int(v) for v in col_src])
+    check(_lib.load().pcg_house_residual_fwd(_p(cont), cont.shape[1], _p(samples), _p(seg_offsets), samples.shape[1], _p(norm_vals), _p(x), _p(mask),
+                                             src, D, B, _p(res), _p(masked), _p(x_cf), _p(part), tk.data_ptr() + 4 * 1024, _p(scal),
+                                             scal.data_ptr() + 4, _stream()), "pcg_house_residual_fwd")
+    return res, masked, x_cf, scal[0], scal[1]
+
+
+def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
+    """(d_cont, d_samples): the tabular step's backward from dLoss/dx_cf = gx_a + gx_b and the two penalty weights down to the
+    generator's outputs, in one launch (see pcg_house_residual_bwd)."""
+    for t, nme in ((res, "res"), (masked, "masked"), (mask, "mask"), (gx_a, "gx_a"), (gx_b, "gx_b")):
+        _chk(t, nme)
+    B, D = res.shape
+    dcont = torch.empty((B, ncont), dtype=torch.float32, device=res.device)
+    dsamples = torch.empty((B, T), dtype=torch.float32, device=res.device)
+    check(_lib.load().pcg_house_residual_bwd(_p(res), _p(masked), _p(mask), _p(gx_a), _p(gx_b), float(w_pen), float(w_am), ncont, _p(cont_idx),
+                                             _p(seg_offsets), cat_idx.numel(), T, _p(cat_idx), _p(norm_vals), D, B, _p(dcont), _p(dsamples),
+                                             _stream()), "pcg_house_residual_bwd")
+    return dcont, dsamples
 
 
 def assemble_residual_bwd(dres, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
@@ -946,6 +972,19 @@ class DeviceRNG:
         n = out.numel()
         check(_lib.load().pcg_rand_gumbel(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_gumbel")
         return out
+
+    def house_draws(self, y, num_classes, D, T, zero_cols, out):
+        """target class != y, feature mask, Gumbel noise [B, T] in ONE launch, drawn into out = (target_y, mask, noise): the values
+        randint(exclude=y), feature_mask, gumbel give when called in this order (same counter offsets)."""
+        o_t, o_m, o_n = out
+        B = y.shape[0]
+        off_t = self._advance((B + 3) // 4)
+        off_m = self._advance((B * D + 3) // 4)
+        off_n = self._advance((B * T + 3) // 4)
+        nz = 0 if zero_cols is None else zero_cols.numel()
+        check(_lib.load().pcg_house_draws(_p(o_t), B, num_classes, _p(y), off_t, _p(o_m), D, _p(zero_cols), nz, off_m, _p(o_n), T, off_n, self.seed,
+                                          _stream()), "pcg_house_draws")
+        return o_t, o_m, o_n
 
     def feature_mask(self, B, D, device, zero_cols=None, out=None):
         """Bernoulli(1/2) modifiable-feature mask with immutable columns zeroed (house_sales_kc_usa/trainer.py:253-255);

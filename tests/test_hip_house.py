@@ -234,9 +234,20 @@ def test_golden_reference_train_loop_batch(pcg, hgold):
     assert abs(out["reg"].item() - logged(r"reg=([0-9.]+)")) <= 2e-6 and abs(out["mask_pen"].item() - logged(r"mask_pen=([0-9.]+)")) <= 7e-6
     assert abs(out["D_loss"].item() - logged(r"\] D: (-?[0-9.]+)")) <= 7e-5 and abs(out["G_loss"].item() - logged(r", G: (-?[0-9.]+)")) <= 7e-5
     lr = H.CONFIG["lr_G"]
+    # The G gradients pass through the critic AFTER its Adam step, and Adam's first step is ~lr * sign(g): a critic weight whose
+    # gradient is at the fp32 noise level lands 2*lr apart under a different (equally valid) summation order, which moves the G
+    # gradients by ~1e-4 of their scale.  The floor is measured, not assumed: the oracle on this batch in float32 and in float64.
+    noise = {}
+    for dt in (torch.float32, torch.float64):
+        oG, oD, oC = _oracle_nets(hgold, dt)
+        o_g, o_d = HR.make_optimizers(oG, oD)
+        HR.house_step(oG, oD, oC, o_g, o_d, x.cpu().to(dt), y.cpu(), t.cpu(), m.cpu().to(dt), {f: v.to(dt) for f, v in gumbel.items()},
+                      {f: v.to(dt) for f, v in HR.cat_norm_maps().items()})
+        noise[dt] = {n: p.grad.double().clone() for n, p in oG.named_parameters()}
     for n, p in G.named_parameters():
         ref = hgold[f"grad.G.{n}"]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-4, atol=2e-6 + 2e-5 * np.abs(ref).max(), err_msg=f"grad {n}")
+        floor = 3 * float((noise[torch.float32][n] - noise[torch.float64][n]).abs().max())
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-4, atol=max(2e-6 + 2e-5 * np.abs(ref).max(), floor), err_msg=f"grad {n}")
     for k, v in G.state_dict().items():
         gk = f"grad.G.{k}"
         if gk in hgold and np.abs(hgold[gk]).max() < 1e-6:
@@ -260,9 +271,11 @@ def test_golden_reference_train_loop_batch(pcg, hgold):
         if k.endswith("weight_u") or k.endswith("weight_v"):
             _close(v, ref, 1e-4, 1e-5, k)                     # three power iterations per step (D(real), D(fake), D(fake) for G)
         else:
-            # Adam's first step moves every weight by ~lr*sign(g): entries whose gradient is at noise level may flip
+            # Adam's first step moves every weight by ~lr*sign(g): entries whose gradient is at noise level may flip (the Wasserstein
+            # critic's gradient is a difference of two batch means: a few entries per layer cancel to fp32 noise, and which way they
+            # fall depends on the summation order — here MFMA accumulation vs the oracle's sequential sums)
             d = (v.cpu() - ref).abs()
-            assert float(d.max()) <= 2.2 * H.CONFIG["lr_D"] and int((d > 2e-5).sum()) <= max(2, 0.01 * d.numel()), (k, float(d.max()))
+            assert float(d.max()) <= 2.2 * H.CONFIG["lr_D"] and int((d > 2e-5).sum()) <= max(2, 0.03 * d.numel()), (k, float(d.max()), int((d > 2e-5).sum()))
 
 
 @pytest.mark.parametrize("batch", [256])
@@ -353,6 +366,44 @@ def test_fused_generator_kernels_match_the_op_chain(pcg, hgold):
         _close(res[0][3][n], res[1][3][n], 1e-4, 2e-5 * float(res[1][3][n].abs().max()) + 2e-6 * scale, f"grad {n}")
     for n in res[0][4]:
         _close(res[0][4][n], res[1][4][n], 1e-5, 1e-6, f"buffer {n}")
+
+
+@pytest.mark.parametrize("rows", [4096, 300])
+def test_fused_residual_block_equals_the_op_chain_bitwise(pcg, hgold, rows):
+    """pcg_house_residual_fwd / _bwd (one launch each) against the seven + nine single-op launches they replace, through autograd:
+    residual_full, masked residual, x_cf, both penalties, and the gradients reaching the generator's outputs — bit for bit, at a
+    size on either side of abs_mean's one-block / 256-block switch.  pcg_house_draws against the three separate draws."""
+    H, ops = pcg.house, pcg.ops
+    G, _, _ = _load_golden_nets(pcg, hgold)
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(rows)
+    B, D, T, nc = rows, 17, G.total_cat, len(G.continuous_idx)
+    x, mask = _dev(torch.rand(B, D, generator=g)), _dev((torch.rand(B, D, generator=g) > 0.4).float())
+    cont = _dev(torch.randn(B, nc, generator=g) * 0.1).requires_grad_(True)
+    samples = _dev(torch.softmax(torch.randn(B, T, generator=g), 1)).requires_grad_(True)
+    gx_a, gx_b = _dev(torch.randn(B, D, generator=g) * 1e-3), _dev(torch.randn(B, D, generator=g) * 1e-3)
+    norm = H.cat_norm_maps(G, H.CONFIG, dev)
+    seg, cat_idx, cont_idx = G.index_tables(dev)
+    lam_mask, w_reg = 1.0, 1.0 * D
+    # the op chain, as train_step (reference order) composes it
+    res = H.assemble_residual(G, cont, samples, x, norm)
+    masked, x_cf = H._MaskMulFn.apply(res, mask, x)
+    pen, am = H.abs_mean(res, mask, one_minus=True), H.abs_mean(masked)
+    rest = H.weighted_sum([am, pen], [w_reg, lam_mask])
+    torch.autograd.backward([rest, x_cf], [H._one(dev), ops.axpby(1.0, gx_a, 1.0, gx_b)])
+    # fused
+    with torch.no_grad():
+        r2, m2, xc2, pen2, am2 = ops.house_residual_fwd(cont.detach(), samples.detach(), seg, norm, x, mask, G.col_src())
+        dc2, ds2 = ops.house_residual_bwd(r2, m2, mask, gx_a, gx_b, lam_mask, w_reg, nc, cont_idx, seg, T, cat_idx, norm)
+    for a, b, what in ((res, r2, "residual_full"), (masked, m2, "masked"), (x_cf, xc2, "x_cf"), (pen, pen2, "mask penalty"), (am, am2, "am"),
+                       (cont.grad, dc2, "d_cont"), (samples.grad, ds2, "d_samples")):
+        assert torch.equal(a.detach().reshape(-1), b.reshape(-1)), what
+    y = _dev(torch.randint(0, 4, (B,), generator=g))
+    imm = torch.tensor(H.CONFIG["immutable_idx"], dtype=torch.int32, device=dev)
+    r1, r2 = ops.DeviceRNG(seed=11), ops.DeviceRNG(seed=11)
+    t1 = r1.randint(0, 4, B, dev, exclude=y); k1 = r1.feature_mask(B, D, dev, imm); n1 = r1.gumbel((B, T), dev)
+    t2, k2, n2 = H.draw_batch_randoms(r2, G, y, H.CONFIG, dev)
+    assert torch.equal(t1, t2) and torch.equal(k1, k2) and torch.equal(n1, n2) and r1.offset == r2.offset
 
 
 def test_fused_critic_kernels_match_the_op_chain(pcg, hgold):
