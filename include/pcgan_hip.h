@@ -419,6 +419,21 @@ int pcg_spectral_norm_fwd_batched(int32_t n, const float* const* w_orig, const i
 int pcg_spectral_norm_bwd_batched(int32_t n, const float* const* dw_bar, const float* const* w_bar, const int32_t* out_features,
                                   const int32_t* in_features, const float* const* u, const float* const* v, const float* const* sigma,
                                   float* const* dw_orig, const int32_t* accumulate, pcg_stream_t stream);
+/* `reps` successive training-mode calls of every layer in one launch (each one power iteration from the previous call's u, v, as the
+ * module's forward does: D(real) then D(fake)); the output arrays hold reps * n entries, call-major (call r of layer l: r * n + l).
+ * At most 8 layers x calls. */
+int pcg_spectral_norm_fwd_batched_reps(int32_t n, int32_t reps, const float* const* w_orig, const int32_t* out_features,
+                                       const int32_t* in_features, float* const* u, float* const* v, float eps, int power_iteration,
+                                       float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
+                                       pcg_stream_t stream);
+/* The backward of `passes` calls of the same n layers, applied one after the other into the same dw_orig[l] (the first writes or
+ * accumulates as accumulate[l] says, the others add — what chained launches compute); per-call arrays hold passes * n entries,
+ * pass-major.  Then, where db_dst[l] is given, db_dst[l] += db_src[l] over out_features[l] values (the bias gradient of a later pass,
+ * reduced into its own buffer because one grouped weight-gradient launch cannot order two writers of the same vector). */
+int pcg_spectral_norm_bwd_batched_seq(int32_t n, int32_t passes, const float* const* dw_bar, const float* const* w_bar,
+                                      const int32_t* out_features, const int32_t* in_features, const float* const* u, const float* const* v,
+                                      const float* const* sigma, float* const* dw_orig, const int32_t* accumulate, float* const* db_dst /*nullable*/,
+                                      const float* const* db_src /*nullable*/, pcg_stream_t stream);
 int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, int32_t out_features, int32_t in_features, const float* u,
                           const float* v, const float* sigma, float* dw_orig, int accumulate, pcg_stream_t stream);
 
@@ -542,6 +557,15 @@ int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t B, int32_t
                          const float* const* bias, float slope, float* a0, float* a1, float* a2, float* a3, float* out, pcg_stream_t stream);
 int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* const* w_bar, float slope, const float* a1, const float* a2,
                          const float* a3, float* d3, float* d2, float* d1, float* dx /*nullable*/, pcg_stream_t stream);
+/* The same for n_pass (1 or 2) independent passes in ONE launch each way — D(real) and D(fake) of the critic step (trainer.py:290-291),
+ * which share the module but not the spectral-norm weights (two successive power iterations): every per-pass pointer becomes an
+ * array of n_pass, w_bar has n_pass * 4 entries (pass-major).  Per pass the arithmetic is that of the one-pass calls. */
+int pcg_house_critic_fwd_n(int32_t n_pass, const float* const* x, const float* const* onehot, int32_t B, int32_t D, int32_t NC,
+                           const float* const* w_bar, const float* const* bias, float slope, float* const* a0, float* const* a1,
+                           float* const* a2, float* const* a3, float* const* out, pcg_stream_t stream);
+int pcg_house_critic_bwd_n(int32_t n_pass, const float* const* dout, int32_t B, int32_t D, const float* const* w_bar, float slope,
+                           const float* const* a1, const float* const* a2, const float* const* a3, float* const* d3, float* const* d2,
+                           float* const* d1, float* const* dx /*entries nullable*/, pcg_stream_t stream);
 
 /* The scalars the tabular trainer logs per step (house_sales_kc_usa/trainer.py:292, :299, :307-312, :318-330) in one launch:
  * out5 = { D_loss = mean(d_fake) - mean(d_real), G_loss = -mean(d_fake_g) + lambda_cls*g_cls + w_reg*am + lambda_mask*pen,

@@ -18,6 +18,13 @@ constexpr int V_FLOATS = C3 * CT;
 constexpr int C_LDS = C2 * C3 + C3 + 2 * V_FLOATS + NW * CT;
 
 struct CW { const float* w[4]; const float* b[4]; };
+// Up to two passes of the critic in one launch (blockIdx.y): D(real) and D(fake) of the critic step share nothing but the module —
+// each has its own spectral-norm weights (two successive power iterations), inputs and outputs.
+constexpr int CP = 2;
+struct CFwdPass { const float* x; const float* onehot; CW p; float* a0; float* a1; float* a2; float* a3; float* out; };
+struct CFwdArgs { CFwdPass ps[CP]; };
+struct CBwdPass { const float* dout; CW p; const float* a1; const float* a2; const float* a3; float* d3o; float* d2o; float* d1o; float* dx; };
+struct CBwdArgs { CBwdPass ps[CP]; };
 
 // One thread per (row, quarter): a block is 64 rows x 4 waves.  A row per THREAD alone (the first version) ran 4096 rows as 64
 // waves on a chip with 1024 SIMDs, each a serial chain over all 32..128 outputs of a layer; splitting the output columns over
@@ -73,9 +80,12 @@ __device__ __forceinline__ void finish_cols(float (&v)[NO], float slope, float* 
   for (int j = 0; j < NO; ++j) Vnext[(j0 + j) * CT + row] = v[j];
 }
 
-__global__ void __launch_bounds__(CT * NW) critic_fwd_kernel(const float* __restrict__ x, int D, const float* __restrict__ onehot, int NC, int B,
-                                                             CW p, float slope, float* __restrict__ a0, float* __restrict__ a1,
-                                                             float* __restrict__ a2, float* __restrict__ a3, float* __restrict__ out) {
+__global__ void __launch_bounds__(CT * NW) critic_fwd_kernel(CFwdArgs args, int D, int NC, int B, float slope) {
+  const CFwdPass& ps = args.ps[blockIdx.y];
+  const float* __restrict__ x = ps.x; const float* __restrict__ onehot = ps.onehot;
+  const CW& p = ps.p;
+  float* __restrict__ a0 = ps.a0; float* __restrict__ a1 = ps.a1; float* __restrict__ a2 = ps.a2; float* __restrict__ a3 = ps.a3;
+  float* __restrict__ out = ps.out;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wl = lds; float* bl = lds + C2 * C3; float* Va = bl + C3; float* Vb = Va + V_FLOATS; float* part = Vb + V_FLOATS;
   const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
@@ -125,10 +135,12 @@ __global__ void __launch_bounds__(CT * NW) critic_fwd_kernel(const float* __rest
 }
 
 // pre-activation gradients d3, d2, d1 (operands of the weight gradients) and, optionally, the gradient of the first D inputs
-__global__ void __launch_bounds__(CT * NW) critic_bwd_kernel(const float* __restrict__ dout, int B, CW p, float slope, const float* __restrict__ a1,
-                                                             const float* __restrict__ a2, const float* __restrict__ a3,
-                                                             float* __restrict__ d3o, float* __restrict__ d2o, float* __restrict__ d1o,
-                                                             float* __restrict__ dx, int D) {
+__global__ void __launch_bounds__(CT * NW) critic_bwd_kernel(CBwdArgs args, int B, float slope, int D) {
+  const CBwdPass& ps = args.ps[blockIdx.y];
+  const float* __restrict__ dout = ps.dout;
+  const CW& p = ps.p;
+  const float* __restrict__ a1 = ps.a1; const float* __restrict__ a2 = ps.a2; const float* __restrict__ a3 = ps.a3;
+  float* __restrict__ d3o = ps.d3o; float* __restrict__ d2o = ps.d2o; float* __restrict__ d1o = ps.d1o; float* __restrict__ dx = ps.dx;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wl = lds; float* Va = lds + C2 * C3 + C3; float* Vb = Va + V_FLOATS;
   const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
@@ -225,28 +237,55 @@ int set_lds(const void* fn) {
 
 using namespace pcg;
 
+extern "C" int pcg_house_critic_fwd_n(int32_t n_pass, const float* const* x, const float* const* onehot, int32_t B, int32_t D, int32_t NC,
+                                      const float* const* w_bar /*[n_pass*4]*/, const float* const* bias /*[4]*/, float slope, float* const* a0,
+                                      float* const* a1, float* const* a2, float* const* a3, float* const* out, pcg_stream_t stream) {
+  PCG_REQUIRE(n_pass >= 1 && n_pass <= CP && x && onehot && w_bar && bias && a0 && a1 && a2 && a3 && out && B > 0,
+              "pcg_house_critic_fwd_n: bad arguments (1 or 2 passes)");
+  PCG_REQUIRE(D + NC == C0 && D > 0 && NC > 0, "pcg_house_critic_fwd_n: built for input_dim + num_classes = %d and hidden width %d", C0, C1);
+  CFwdArgs args{};
+  for (int q = 0; q < n_pass; ++q) {
+    CFwdPass& ps = args.ps[q];
+    PCG_REQUIRE(x[q] && onehot[q] && a0[q] && a1[q] && a2[q] && a3[q] && out[q], "pcg_house_critic_fwd_n: pass %d: null buffer", q);
+    ps.x = x[q]; ps.onehot = onehot[q]; ps.a0 = a0[q]; ps.a1 = a1[q]; ps.a2 = a2[q]; ps.a3 = a3[q]; ps.out = out[q];
+    for (int l = 0; l < 4; ++l) {
+      PCG_REQUIRE(w_bar[q * 4 + l] && bias[l], "pcg_house_critic_fwd_n: pass %d: null layer %d", q, l);
+      ps.p.w[l] = w_bar[q * 4 + l]; ps.p.b[l] = bias[l];
+    }
+  }
+  static int once = set_lds(reinterpret_cast<const void*>(critic_fwd_kernel));
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + CT - 1) / CT, n_pass), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, args, D, NC, B, slope);
+  return launch_status("critic_fwd_kernel");
+}
+
 extern "C" int pcg_house_critic_fwd(const float* x, const float* onehot, int32_t B, int32_t D, int32_t NC, const float* const* w_bar,
                                     const float* const* bias, float slope, float* a0, float* a1, float* a2, float* a3, float* out,
                                     pcg_stream_t stream) {
-  PCG_REQUIRE(x && onehot && w_bar && bias && a0 && a1 && a2 && a3 && out && B > 0, "pcg_house_critic_fwd: bad arguments");
-  PCG_REQUIRE(D + NC == C0 && D > 0 && NC > 0, "pcg_house_critic_fwd: built for input_dim + num_classes = %d and hidden width %d", C0, C1);
-  CW p{};
-  for (int l = 0; l < 4; ++l) { PCG_REQUIRE(w_bar[l] && bias[l], "pcg_house_critic_fwd: null layer %d", l); p.w[l] = w_bar[l]; p.b[l] = bias[l]; }
-  static int once = set_lds(reinterpret_cast<const void*>(critic_fwd_kernel));
+  PCG_REQUIRE(w_bar && bias, "pcg_house_critic_fwd: bad arguments");
+  return pcg_house_critic_fwd_n(1, &x, &onehot, B, D, NC, w_bar, bias, slope, &a0, &a1, &a2, &a3, &out, stream);
+}
+
+extern "C" int pcg_house_critic_bwd_n(int32_t n_pass, const float* const* dout, int32_t B, int32_t D, const float* const* w_bar /*[n_pass*4]*/,
+                                      float slope, const float* const* a1, const float* const* a2, const float* const* a3, float* const* d3,
+                                      float* const* d2, float* const* d1, float* const* dx /*entries nullable*/, pcg_stream_t stream) {
+  PCG_REQUIRE(n_pass >= 1 && n_pass <= CP && dout && w_bar && a1 && a2 && a3 && d3 && d2 && d1 && dx && B > 0 && D > 0 && D <= C0,
+              "pcg_house_critic_bwd_n: bad arguments (1 or 2 passes)");
+  CBwdArgs args{};
+  for (int q = 0; q < n_pass; ++q) {
+    CBwdPass& ps = args.ps[q];
+    PCG_REQUIRE(dout[q] && a1[q] && a2[q] && a3[q] && d3[q] && d2[q] && d1[q], "pcg_house_critic_bwd_n: pass %d: null buffer", q);
+    ps.dout = dout[q]; ps.a1 = a1[q]; ps.a2 = a2[q]; ps.a3 = a3[q]; ps.d3o = d3[q]; ps.d2o = d2[q]; ps.d1o = d1[q]; ps.dx = dx[q];
+    for (int l = 0; l < 4; ++l) { PCG_REQUIRE(w_bar[q * 4 + l], "pcg_house_critic_bwd_n: pass %d: null layer %d", q, l); ps.p.w[l] = w_bar[q * 4 + l]; }
+  }
+  static int once = set_lds(reinterpret_cast<const void*>(critic_bwd_kernel));
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + CT - 1) / CT), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, x, D, onehot, NC, B, p,
-                     slope, a0, a1, a2, a3, out);
-  return launch_status("critic_fwd_kernel");
+  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + CT - 1) / CT, n_pass), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, args, B, slope, D);
+  return launch_status("critic_bwd_kernel");
 }
 
 extern "C" int pcg_house_critic_bwd(const float* dout, int32_t B, int32_t D, const float* const* w_bar, float slope, const float* a1,
                                     const float* a2, const float* a3, float* d3, float* d2, float* d1, float* dx, pcg_stream_t stream) {
-  PCG_REQUIRE(dout && w_bar && a1 && a2 && a3 && d3 && d2 && d1 && B > 0 && D > 0 && D <= C0, "pcg_house_critic_bwd: bad arguments");
-  CW p{};
-  for (int l = 0; l < 4; ++l) { PCG_REQUIRE(w_bar[l], "pcg_house_critic_bwd: null layer %d", l); p.w[l] = w_bar[l]; }
-  static int once = set_lds(reinterpret_cast<const void*>(critic_bwd_kernel));
-  if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + CT - 1) / CT), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, dout, B, p, slope, a1, a2,
-                     a3, d3, d2, d1, dx, D);
-  return launch_status("critic_bwd_kernel");
+  PCG_REQUIRE(w_bar, "pcg_house_critic_bwd: bad arguments");
+  return pcg_house_critic_bwd_n(1, &dout, B, D, w_bar, slope, &a1, &a2, &a3, &d3, &d2, &d1, &dx, stream);
 }

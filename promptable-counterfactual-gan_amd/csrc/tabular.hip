@@ -672,9 +672,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // matrix-vector products read it from there; matrices beyond 48 KB take the global-memory form.
 constexpr int SN_LDS_FLOATS = 12288;
 __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__ W, int O, int I, float* __restrict__ u,
-                                                       float* __restrict__ v, float eps, int power_iter, float* __restrict__ Wbar,
-                                                       float* __restrict__ sigma_out, float* __restrict__ u_used,
-                                                       float* __restrict__ v_used) {
+                                                       float* __restrict__ v, float eps, int power_iter, float* const* Wbar_r,
+                                                       float* const* sigma_r, float* const* uu_r, float* const* vu_r, int reps, int rstride) {
   __shared__ float red[256];
   __shared__ float su[256], sv[256];   // O, I <= 256 (host-checked)
   __shared__ float sW[SN_LDS_FLOATS];
@@ -687,6 +686,11 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   __syncthreads();
   const float* M = in_lds ? sW : W;
   const int lm = in_lds ? ld : I;
+  // reps > 1: that many successive training-mode calls (each one power iteration from the previous call's u, v, as the module's
+  // forward does) in one launch — the matrix is staged once; call r writes its W / sigma, sigma and the u, v it used to set r.
+  for (int rp = 0; rp < reps; ++rp) {
+  float* __restrict__ Wbar = Wbar_r[rp * rstride]; float* __restrict__ sigma_out = sigma_r[rp * rstride];
+  float* __restrict__ u_used = uu_r[rp * rstride]; float* __restrict__ v_used = vu_r[rp * rstride];
   if (power_iter) {
     float t = 0.f;
     if ((int)threadIdx.x < I) { for (int o = 0; o < O; ++o) t = fmaf(M[(size_t)o * lm + threadIdx.x], su[o], t); }
@@ -712,12 +716,14 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
     const int o = e / I, i = e - o * I;
     Wbar[e] = (in_lds ? sW[o * ld + i] : W[e]) * inv;
   }
+  }
 }
 __global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
                                                                 float* __restrict__ v, float eps, int power_iter,
                                                                 float* __restrict__ Wbar, float* __restrict__ sigma_out,
                                                                 float* __restrict__ u_used, float* __restrict__ v_used) {
-  spectral_norm_fwd_body(W, O, I, u, v, eps, power_iter, Wbar, sigma_out, u_used, v_used);
+  float* wb[1] = {Wbar}; float* sg[1] = {sigma_out}; float* uu[1] = {u_used}; float* vu[1] = {v_used};
+  spectral_norm_fwd_body(W, O, I, u, v, eps, power_iter, wb, sg, uu, vu, 1, 0);
 }
 // dW (+)= (dWbar - (sum dWbar*Wbar) u v^T) / sigma
 __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O, int I,
@@ -749,16 +755,25 @@ __global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __r
 }
 
 // all spectral-norm layers of a net in one launch (one block per layer): the critic has four
-constexpr int SN_MAX = 8;
+constexpr int SN_MAX = 8;      // entries: layers x (reps | passes)
 struct SnFwdBatch { const float* W[SN_MAX]; float* u[SN_MAX]; float* v[SN_MAX]; float* Wbar[SN_MAX]; float* sigma[SN_MAX]; float* uu[SN_MAX]; float* vu[SN_MAX]; int O[SN_MAX], I[SN_MAX]; };
 struct SnBwdBatch { const float* dWbar[SN_MAX]; const float* Wbar[SN_MAX]; const float* u[SN_MAX]; const float* v[SN_MAX]; const float* sigma[SN_MAX]; float* dW[SN_MAX]; int O[SN_MAX], I[SN_MAX], acc[SN_MAX]; };
-__global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBatch b, float eps, int power_iter) {
-  const int l = blockIdx.x;
-  spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar[l], b.sigma[l], b.uu[l], b.vu[l]);
+__global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBatch b, float eps, int power_iter, int n, int reps) {
+  const int l = blockIdx.x;       // outputs of call r of layer l: entry r * n + l
+  spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n);
 }
-__global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBatch b) {
+// passes > 1: the backward of that many calls of the same layer (entry q * n + l), one after the other into the same dW — the first
+// writes or accumulates as its flag says, the others add, exactly as chained launches would; then db_dst[l] += db_src[l] (the bias
+// gradient of a later pass, reduced into its own buffer by the grouped weight-gradient launch, which cannot order two writers)
+struct SnBwdExtra { float* db_dst[SN_MAX]; const float* db_src[SN_MAX]; };
+__global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBatch b, SnBwdExtra x, int n, int passes) {
   const int l = blockIdx.x;
-  spectral_norm_bwd_body(b.dWbar[l], b.Wbar[l], b.O[l], b.I[l], b.u[l], b.v[l], b.sigma[l], b.dW[l], b.acc[l]);
+  for (int q = 0; q < passes; ++q) {
+    const int e = q * n + l;
+    spectral_norm_bwd_body(b.dWbar[e], b.Wbar[e], b.O[l], b.I[l], b.u[e], b.v[e], b.sigma[e], b.dW[l], q == 0 ? b.acc[l] : 1);
+  }
+  if (x.db_dst[l])
+    for (int i = threadIdx.x; i < b.O[l]; i += 256) x.db_dst[l][i] += x.db_src[l][i];
 }
 
 }  // namespace
@@ -853,36 +868,59 @@ extern "C" int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_
   return launch_status("gemm_kernel");
 }
 
+extern "C" int pcg_spectral_norm_fwd_batched_reps(int32_t n, int32_t reps, const float* const* w_orig, const int32_t* out_features,
+                                                  const int32_t* in_features, float* const* u, float* const* v, float eps, int power_iteration,
+                                                  float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
+                                                  pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && reps >= 1 && n * reps <= SN_MAX && w_orig && out_features && in_features && u && v && w_bar && sigma && u_used && v_used,
+              "pcg_spectral_norm_fwd_batched: bad arguments (at most %d layers x calls)", SN_MAX);
+  PCG_REQUIRE(reps == 1 || power_iteration, "pcg_spectral_norm_fwd_batched_reps: several calls only differ in training mode");
+  SnFwdBatch b{};
+  for (int l = 0; l < n; ++l) {
+    PCG_REQUIRE(w_orig[l] && u[l] && v[l] && out_features[l] > 0 && out_features[l] <= 256 && in_features[l] > 0 && in_features[l] <= 256,
+                "pcg_spectral_norm_fwd_batched: layer %d: bad arguments", l);
+    b.W[l] = w_orig[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.O[l] = out_features[l]; b.I[l] = in_features[l];
+  }
+  for (int e = 0; e < n * reps; ++e) {
+    PCG_REQUIRE(w_bar[e] && sigma[e], "pcg_spectral_norm_fwd_batched: output set %d: null buffer", e);
+    b.Wbar[e] = w_bar[e]; b.sigma[e] = sigma[e]; b.uu[e] = u_used[e]; b.vu[e] = v_used[e];
+  }
+  hipLaunchKernelGGL(spectral_norm_fwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b, eps, power_iteration, n, reps);
+  return launch_status("spectral_norm_fwd_batched_kernel");
+}
+
 extern "C" int pcg_spectral_norm_fwd_batched(int32_t n, const float* const* w_orig, const int32_t* out_features, const int32_t* in_features,
                                              float* const* u, float* const* v, float eps, int power_iteration, float* const* w_bar,
                                              float* const* sigma, float* const* u_used, float* const* v_used, pcg_stream_t stream) {
-  PCG_REQUIRE(n > 0 && n <= SN_MAX && w_orig && out_features && in_features && u && v && w_bar && sigma && u_used && v_used,
-              "pcg_spectral_norm_fwd_batched: bad arguments (at most %d layers)", SN_MAX);
-  SnFwdBatch b{};
+  return pcg_spectral_norm_fwd_batched_reps(n, 1, w_orig, out_features, in_features, u, v, eps, power_iteration, w_bar, sigma, u_used, v_used, stream);
+}
+
+extern "C" int pcg_spectral_norm_bwd_batched_seq(int32_t n, int32_t passes, const float* const* dw_bar, const float* const* w_bar,
+                                                 const int32_t* out_features, const int32_t* in_features, const float* const* u,
+                                                 const float* const* v, const float* const* sigma, float* const* dw_orig, const int32_t* accumulate,
+                                                 float* const* db_dst, const float* const* db_src, pcg_stream_t stream) {
+  PCG_REQUIRE(n > 0 && passes >= 1 && n * passes <= SN_MAX && dw_bar && w_bar && out_features && in_features && u && v && sigma && dw_orig && accumulate,
+              "pcg_spectral_norm_bwd_batched: bad arguments (at most %d layers x passes)", SN_MAX);
+  SnBwdBatch b{};
+  SnBwdExtra x{};
   for (int l = 0; l < n; ++l) {
-    PCG_REQUIRE(w_orig[l] && u[l] && v[l] && w_bar[l] && sigma[l] && out_features[l] > 0 && out_features[l] <= 256 && in_features[l] > 0 &&
-                    in_features[l] <= 256, "pcg_spectral_norm_fwd_batched: layer %d: bad arguments", l);
-    b.W[l] = w_orig[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.Wbar[l] = w_bar[l]; b.sigma[l] = sigma[l]; b.uu[l] = u_used[l]; b.vu[l] = v_used[l];
-    b.O[l] = out_features[l]; b.I[l] = in_features[l];
+    PCG_REQUIRE(dw_orig[l] && out_features[l] > 0 && out_features[l] <= 256 && in_features[l] > 0 && in_features[l] <= 256,
+                "pcg_spectral_norm_bwd_batched: layer %d: bad arguments", l);
+    b.dW[l] = dw_orig[l]; b.O[l] = out_features[l]; b.I[l] = in_features[l]; b.acc[l] = accumulate[l];
+    if (db_dst && db_dst[l]) { PCG_REQUIRE(db_src && db_src[l], "pcg_spectral_norm_bwd_batched_seq: layer %d: db_src missing", l); x.db_dst[l] = db_dst[l]; x.db_src[l] = db_src[l]; }
   }
-  hipLaunchKernelGGL(spectral_norm_fwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b, eps, power_iteration);
-  return launch_status("spectral_norm_fwd_batched_kernel");
+  for (int e = 0; e < n * passes; ++e) {
+    PCG_REQUIRE(dw_bar[e] && w_bar[e] && u[e] && v[e] && sigma[e], "pcg_spectral_norm_bwd_batched: entry %d: null buffer", e);
+    b.dWbar[e] = dw_bar[e]; b.Wbar[e] = w_bar[e]; b.u[e] = u[e]; b.v[e] = v[e]; b.sigma[e] = sigma[e];
+  }
+  hipLaunchKernelGGL(spectral_norm_bwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b, x, n, passes);
+  return launch_status("spectral_norm_bwd_batched_kernel");
 }
 
 extern "C" int pcg_spectral_norm_bwd_batched(int32_t n, const float* const* dw_bar, const float* const* w_bar, const int32_t* out_features,
                                              const int32_t* in_features, const float* const* u, const float* const* v,
                                              const float* const* sigma, float* const* dw_orig, const int32_t* accumulate, pcg_stream_t stream) {
-  PCG_REQUIRE(n > 0 && n <= SN_MAX && dw_bar && w_bar && out_features && in_features && u && v && sigma && dw_orig && accumulate,
-              "pcg_spectral_norm_bwd_batched: bad arguments");
-  SnBwdBatch b{};
-  for (int l = 0; l < n; ++l) {
-    PCG_REQUIRE(dw_bar[l] && w_bar[l] && u[l] && v[l] && sigma[l] && dw_orig[l] && out_features[l] > 0 && out_features[l] <= 256 &&
-                    in_features[l] > 0 && in_features[l] <= 256, "pcg_spectral_norm_bwd_batched: layer %d: bad arguments", l);
-    b.dWbar[l] = dw_bar[l]; b.Wbar[l] = w_bar[l]; b.u[l] = u[l]; b.v[l] = v[l]; b.sigma[l] = sigma[l]; b.dW[l] = dw_orig[l];
-    b.O[l] = out_features[l]; b.I[l] = in_features[l]; b.acc[l] = accumulate[l];
-  }
-  hipLaunchKernelGGL(spectral_norm_bwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b);
-  return launch_status("spectral_norm_bwd_batched_kernel");
+  return pcg_spectral_norm_bwd_batched_seq(n, 1, dw_bar, w_bar, out_features, in_features, u, v, sigma, dw_orig, accumulate, nullptr, nullptr, stream);
 }
 
 namespace {

@@ -531,6 +531,51 @@ class Discriminator(FlatModule):
             a = z
         return a, (layers if keep else None)
 
+    def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b):
+        """The critic step's two passes as one: D(a) then D(b) — two successive power iterations, as two forward calls make them —
+        and the backward of cot_b . D(b) followed by that of cot_a . D(a) into the gradient buffer (the order the chained calls
+        of train_step use), in FIVE launches instead of ten: both power iterations, both forwards, both backwards, all sixteen
+        weight / bias reductions, both passes through W / sigma.  Per element the arithmetic of the chained calls (same bits).
+        Returns (D(a), D(b))."""
+        import ctypes
+        from ._lib import load
+        lins = self._linears()
+        sn_a, sn_b = ops.spectral_norm_fwd_batched_reps([l.weight_orig.data for l in lins], [l.weight_u for l in lins],
+                                                        [l.weight_v for l in lins], 1e-12, 2)
+        B = x_a.shape[0]
+        dev = x_a.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        ins = [(x_a.contiguous(), onehot_a.contiguous()), (x_b.contiguous(), onehot_b.contiguous())]
+        acts = [[torch.empty((B, n), **f32) for n in (21, 32, 64, 128)] for _ in range(2)]
+        outs = [torch.empty((B, 1), **f32) for _ in range(2)]
+        wb = [t[0] for t in sn_a] + [t[0] for t in sn_b]
+        pa = ops._ptr_array
+        ops.check(load().pcg_house_critic_fwd_n(2, pa([i[0] for i in ins]), pa([i[1] for i in ins]), B, x_a.shape[1], onehot_a.shape[1], pa(wb),
+                                                pa([l.bias.data for l in lins]), 0.2, pa([a[0] for a in acts]), pa([a[1] for a in acts]),
+                                                pa([a[2] for a in acts]), pa([a[3] for a in acts]), pa(outs), ops._stream()),
+                  "pcg_house_critic_fwd_n")
+        d4 = [cot_a.contiguous(), cot_b.contiguous()]
+        d3, d2, d1 = ([torch.empty((B, n), **f32) for _ in range(2)] for n in (128, 64, 32))
+        null2 = (ctypes.c_void_p * 2)(None, None)
+        ops.check(load().pcg_house_critic_bwd_n(2, pa(d4), B, self.input_dim, pa(wb), 0.2, pa([a[1] for a in acts]), pa([a[2] for a in acts]),
+                                                pa([a[3] for a in acts]), pa(d3), pa(d2), pa(d1), null2, ops._stream()), "pcg_house_critic_bwd_n")
+        # pass b is the first writer of the gradient buffer, pass a adds (bias: through its own buffer, added behind the b pass)
+        items, seq_b, seq_a, dws, accs, bias_adds = [], [], [], [], [], []
+        for li, lin in enumerate(lins):
+            gb, accb = self._grad_view(lin.bias)
+            gw, acc = self._grad_view(lin.weight_orig)
+            dw_b, dw_a = torch.empty_like(sn_b[li][0]), torch.empty_like(sn_a[li][0])
+            gb_a = torch.empty_like(gb)
+            O, I = lin.out_features, lin.in_features
+            items.append(((d1, d2, d3, d4)[li][1], acts[1][li], O, I, dw_b, gb, O, I, False, accb))
+            items.append(((d1, d2, d3, d4)[li][0], acts[0][li], O, I, dw_a, gb_a, O, I, False, False))
+            seq_b.append((dw_b, sn_b[li][0], sn_b[li][2], sn_b[li][3], sn_b[li][1]))
+            seq_a.append((dw_a, sn_a[li][0], sn_a[li][2], sn_a[li][3], sn_a[li][1]))
+            dws.append(gw); accs.append(acc); bias_adds.append((gb, gb_a))
+        ops.linear_wgrad_grouped(items, B, dev)
+        ops.spectral_norm_bwd_batched_seq([seq_b, seq_a], dws, accs, bias_adds)
+        return outs[0], outs[1]
+
     def _fused_backward(self, saved, dout, need_x, need_p, gtarget=None):
         """gtarget: a flat buffer with the layout of flat_grads that receives this pass's parameter gradients (written, not
         accumulated) instead of the module's gradient buffer — see FlatModule.grad_view_in."""
@@ -902,7 +947,9 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     xd = x_cf.detach()
     onehot_y = ops.onehot(y, nc)
     with torch.no_grad():
-        if branch2 is None or not discriminator._fused_ok(x, onehot_y):
+        if branch2 is None and discriminator._fused_ok(x, onehot_y) and all(p.requires_grad for p in discriminator.parameters()):
+            d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos)       # :290-294, five launches
+        elif branch2 is None or not discriminator._fused_ok(x, onehot_y):
             d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True)                 # :290
             d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291
             discriminator._run_backward(sv_f, cot_pos, False, True)                           # d(mean(d_fake) - mean(d_real))

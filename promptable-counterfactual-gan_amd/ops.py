@@ -801,6 +801,38 @@ def spectral_norm_fwd_batched(w_origs, us, vs, eps, power_iteration):
     return outs
 
 
+def spectral_norm_fwd_batched_reps(w_origs, us, vs, eps, reps):
+    """`reps` successive training-mode calls in one launch: [[(w_bar, sigma, u_used, v_used)] per layer] per call."""
+    n = len(w_origs)
+    outs = [[(torch.empty_like(w), torch.empty(1, dtype=torch.float32, device=w.device), torch.empty_like(u), torch.empty_like(v))
+             for w, u, v in zip(w_origs, us, vs)] for _ in range(reps)]
+    flat = [o for call in outs for o in call]
+    I32 = ctypes.c_int32 * n
+    check(_lib.load().pcg_spectral_norm_fwd_batched_reps(n, reps, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]),
+                                                         I32(*[w.shape[1] for w in w_origs]), _ptr_array(us), _ptr_array(vs), float(eps), 1,
+                                                         _ptr_array([o[0] for o in flat]), _ptr_array([o[1] for o in flat]),
+                                                         _ptr_array([o[2] for o in flat]), _ptr_array([o[3] for o in flat]), _stream()),
+          "pcg_spectral_norm_fwd_batched_reps")
+    return outs
+
+
+def spectral_norm_bwd_batched_seq(passes, dw_origs, accumulate, bias_adds=None):
+    """passes: [[(dw_bar, w_bar, u, v, sigma)] per layer] per call, applied in this order into dw_origs[l]; bias_adds: per layer
+    (dst, src) or None — dst += src afterwards."""
+    n = len(dw_origs)
+    flat = [e for call in passes for e in call]
+    I32 = ctypes.c_int32 * n
+    null = ctypes.c_void_p * n
+    dst = null(*[(b[0].data_ptr() if b is not None else None) for b in (bias_adds or [None] * n)])
+    src = null(*[(b[1].data_ptr() if b is not None else None) for b in (bias_adds or [None] * n)])
+    check(_lib.load().pcg_spectral_norm_bwd_batched_seq(n, len(passes), _ptr_array([e[0] for e in flat]), _ptr_array([e[1] for e in flat]),
+                                                        I32(*[w.shape[0] for w in dw_origs]), I32(*[w.shape[1] for w in dw_origs]),
+                                                        _ptr_array([e[2] for e in flat]), _ptr_array([e[3] for e in flat]),
+                                                        _ptr_array([e[4] for e in flat]), _ptr_array(dw_origs),
+                                                        I32(*[int(bool(a)) for a in accumulate]), dst, src, _stream()),
+          "pcg_spectral_norm_bwd_batched_seq")
+
+
 def spectral_norm_bwd_batched(items):
     """items: [(dw_bar, w_bar, u, v, sigma, dw_orig, accumulate)] — all layers in one launch."""
     n = len(items)
