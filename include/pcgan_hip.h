@@ -567,6 +567,19 @@ int pcg_house_critic_bwd_n(int32_t n_pass, const float* const* dout, int32_t B, 
                            const float* const* a1, const float* const* a2, const float* const* a3, float* const* d3, float* const* d2,
                            float* const* d1, float* const* dx /*entries nullable*/, pcg_stream_t stream);
 
+/* The frozen tabular classifier of the counterfactual loss (house_sales_kc_usa/models/nn_classifier.py:4-32 in eval mode, each
+ * BatchNorm1d folded into the following Linear by the caller: Linear 17->256, 256->256, 256->128, 128->64 + LeakyReLU(0.1), Linear
+ * 64->4) as one launch each way on the matrix cores, 32 rows per block, activations in LDS between layers.
+ *   forward:  w_kmajor[l], l = 0..3: the folded weight TRANSPOSED, [K_l][N_l] row-major, layer 0 zero-padded to K = 18;
+ *             w_kmajor[4]: the last layer as stored [4][64]; bias[l]; writes the post-activation outputs a1 [B][256], a2 [B][256],
+ *             a3 [B][128], a4 [B][64] (the backward's masks) and logits [B][4].
+ *   backward: w_stored[l]: the folded weights as stored [N_l][K_l]; dx [B][17] = d(logits . dlogits)/dx.  (trainer.py:301-302;
+ *             the parameters are frozen, main.py:27-30: no weight gradients.) */
+int pcg_house_classifier_fwd(const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2,
+                             float* a3, float* a4, float* logits, pcg_stream_t stream);
+int pcg_house_classifier_bwd(const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2, const float* a3,
+                             const float* a4, float* dx, pcg_stream_t stream);
+
 /* The scalars the tabular trainer logs per step (house_sales_kc_usa/trainer.py:292, :299, :307-312, :318-330) in one launch:
  * out5 = { D_loss = mean(d_fake) - mean(d_real), G_loss = -mean(d_fake_g) + lambda_cls*g_cls + w_reg*am + lambda_mask*pen,
  *          g_adv = -mean(d_fake_g), g_reg = w_reg_log*am, mean(d_fake_g) } — the same reduction trees and fma chains as

@@ -189,6 +189,8 @@ PROTOTYPES = {
     "pcg_house_critic_bwd_n": (_i, [_i32, _vp, _i32, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_spectral_norm_fwd_batched_reps": (_i, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "pcg_spectral_norm_bwd_batched_seq": (_i, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_house_classifier_fwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_house_classifier_bwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_linear_wgrad_grouped_slabs": (_i32, [_i32]),
     "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _c.POINTER(WgradItem), _i32]),
     "pcg_house_critic_fwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

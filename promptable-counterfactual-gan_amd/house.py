@@ -700,7 +700,24 @@ class NNClassifier(FlatModule):
                     s = m.weight.double() / torch.sqrt(m.running_var.double() + m.eps)
                     scale, shift = s, m.bias.double() - m.running_mean.double() * s
         self._packed = (key, packed)
+        self._kmajor = None
         return packed
+
+    def _fused_ok(self, x):
+        dims = [m.in_features for m in self.net if isinstance(m, nn.Linear)] + [self.net[-1].out_features]
+        return getattr(self, "use_fused", True) and x.is_cuda and x.shape[1] == 17 and dims == [17, 256, 256, 128, 64, 4]
+
+    def _pack_kmajor(self):
+        """Per layer the folded weight transposed ([K][N]: the forward's B operand is then a coalesced read), layer 0 padded with a
+        zero row to an even reduction length; the last layer stays as stored.  Built once per pack."""
+        packed = self._pack()
+        if getattr(self, "_kmajor", None) is None:
+            with torch.no_grad():
+                km = [w.t().contiguous() for w, _ in packed[:4]]
+                km[0] = torch.cat([km[0], torch.zeros((1, km[0].shape[1]), dtype=km[0].dtype, device=km[0].device)], 0).contiguous()
+                km.append(packed[4][0])
+            self._kmajor = km
+        return self._kmajor
 
     def train(self, mode=True):
         # the optimizer kernel updates parameters in place without touching torch's version counters: drop the packed eval
@@ -780,6 +797,16 @@ class NNClassifier(FlatModule):
         packed = self._pack()
         a = x.contiguous()
         B = a.shape[0]
+        if self._fused_ok(a):
+            # the five layers as ONE launch on the matrix cores (csrc/house_classifier_fused.hip)
+            from ._lib import load
+            f32 = dict(dtype=torch.float32, device=a.device)
+            acts = [torch.empty((B, n), **f32) for n in (256, 256, 128, 64)]
+            logits = torch.empty((B, 4), **f32)
+            ops.check(load().pcg_house_classifier_fwd(ops._p(a), B, ops._ptr_array(self._pack_kmajor()), ops._ptr_array([b for _, b in packed]),
+                                                      ops._p(acts[0]), ops._p(acts[1]), ops._p(acts[2]), ops._p(acts[3]), ops._p(logits),
+                                                      ops._stream()), "pcg_house_classifier_fwd")
+            return logits, (acts if keep else None)
         acts = []
         for i, (w, b) in enumerate(packed):
             z = affine_fwd(a, w, b, act=ACT_LRELU if i + 1 < len(packed) else ACT_NONE, slope=0.1)
@@ -793,6 +820,12 @@ class NNClassifier(FlatModule):
         packed = self._pack()
         d = dlogits.contiguous()
         B = d.shape[0]
+        if d.is_cuda and len(acts) == 4 and [t.shape[1] for t in acts] == [256, 256, 128, 64] and getattr(self, "use_fused", True) and d.shape[1] == 4:
+            from ._lib import load
+            dx = torch.empty((B, 17), dtype=torch.float32, device=d.device)
+            ops.check(load().pcg_house_classifier_bwd(ops._p(d), B, ops._ptr_array([w for w, _ in packed]), ops._p(acts[0]), ops._p(acts[1]),
+                                                      ops._p(acts[2]), ops._p(acts[3]), ops._p(dx), ops._stream()), "pcg_house_classifier_bwd")
+            return dx
         for i in range(len(packed) - 1, -1, -1):
             if i + 1 < len(packed):
                 d = ops.act_bwd(d, acts[i], ACT_LRELU, 0.1, out=d)

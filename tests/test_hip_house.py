@@ -430,6 +430,45 @@ def test_fused_critic_kernels_match_the_op_chain(pcg, hgold):
         _close(res[0][3][n], res[1][3][n], 1e-6, 1e-7, f"buffer {n}")
 
 
+@pytest.mark.parametrize("rows", [300, 4096, 5])
+def test_fused_classifier_kernels_match_the_op_chain(pcg, hgold, rows):
+    """csrc/house_classifier_fused.hip (the frozen classifier's five layers as one MFMA launch forward, one backward) against the
+    per-layer GEMM path and against float64 torch on the folded weights: logits and the input gradient of a cross-entropy on
+    them.  Same arithmetic up to summation order: 2e-5 of scale; ragged last block, a batch smaller than a block."""
+    H, ops = pcg.house, pcg.ops
+    _, _, C = _load_golden_nets(pcg, hgold)
+    g = torch.Generator().manual_seed(rows)
+    with torch.no_grad():       # trained-looking BatchNorm statistics, so that the folding matters
+        for m in C.net:
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(_dev(torch.randn(m.num_features, generator=g) * 0.1)); m.running_var.copy_(_dev(torch.rand(m.num_features, generator=g) + 0.5))
+    x = _dev(torch.rand(rows, 17, generator=g)); t = _dev(torch.randint(0, 4, (rows,), generator=g))
+    res = []
+    for fused in (True, False):
+        C.use_fused = fused
+        with torch.no_grad():
+            logits, acts = C._run_forward(x, keep=True)
+            loss, dlog = ops.cross_entropy_fwd_bwd(logits.contiguous(), t, need_loss=True, need_grad=True, grad_scale=2.0)
+            dx = C._run_backward(acts, dlog)
+        res.append((logits.clone(), dx.clone(), [a.clone() for a in acts]))
+    C.use_fused = True
+    # float64 truth from the folded weights
+    a = x.double().cpu()
+    packed = [(w.double().cpu(), b.double().cpu()) for w, b in C._pack()]
+    a.requires_grad_(True)
+    h = a
+    for i, (w, b) in enumerate(packed):
+        h = h @ w.T + b
+        if i + 1 < len(packed):
+            h = F.leaky_relu(h, 0.1)
+    (2.0 * F.cross_entropy(h, t.cpu())).backward()
+    for k, (lg, dx, acts) in enumerate(res):
+        _close(lg, h.detach(), 2e-5, 2e-5 * float(h.detach().abs().max()), f"logits fused={k == 0}")
+        _close(dx, a.grad, 1e-4, 2e-5 * float(a.grad.abs().max()), f"dx fused={k == 0}")
+    for u, v in zip(res[0][2], res[1][2]):
+        _close(u, v, 2e-5, 2e-5 * float(v.abs().max()), "saved activation")
+
+
 @pytest.mark.parametrize("overlap", [True, "critic", False])
 def test_graphed_step_equals_eager(pcg, hgold, overlap):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
