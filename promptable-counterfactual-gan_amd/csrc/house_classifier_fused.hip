@@ -165,9 +165,19 @@ __global__ void __launch_bounds__(256) classifier_fwd_kernel(const float* __rest
   const size_t row0 = (size_t)blockIdx.x * CL_R;
   const int rows = min(CL_R, B - (int)row0);
   // the block's input rows, k-major, with the zero row that pads the reduction to 18
-  for (int e = threadIdx.x; e < CL_R * CL_INP; e += 256) {
-    const int m = e / CL_INP, k = e - m * CL_INP;
-    s.X[0][k * CL_P + m] = (m < rows && k < CL_IN) ? x[(row0 + m) * CL_IN + k] : 0.f;
+  {
+    constexpr int PER = (CL_R * CL_INP + 255) / 256;
+    float xv[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int e = threadIdx.x + t * 256, m = min(e / CL_INP, rows - 1), k = min(e - (e / CL_INP) * CL_INP, CL_IN - 1);
+      xv[t] = x[(row0 + m) * CL_IN + k];
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int e = threadIdx.x + t * 256;
+      if (e < CL_R * CL_INP) { const int m = e / CL_INP, k = e - m * CL_INP; s.X[0][k * CL_P + m] = (m < rows && k < CL_IN) ? xv[t] : 0.f; }
+    }
   }
   __syncthreads();
   cl_dense_fwd<CL_INP, CL_H1, true>(s.X[0], s.X[1], w.wt[0], w.b[0], a1, row0, rows, wave, li, lh);
@@ -198,16 +208,27 @@ __global__ void __launch_bounds__(256) classifier_bwd_kernel(const float* __rest
   const size_t row0 = (size_t)blockIdx.x * CL_R;
   const int rows = min(CL_R, B - (int)row0);
   // d4[m][k] = (sum_c dlogits[m][c] W5[c][k]) * LeakyReLU'(a4[m][k]): 2048 outputs, eight per thread
-  for (int e = threadIdx.x; e < CL_R * CL_H4; e += 256) {
-    const int m = e / CL_H4, k = e - m * CL_H4;
-    float v = 0.f;
-    if (m < rows) {
+  {
+    constexpr int PER = CL_R * CL_H4 / 256;                 // element tid + 256 t of [32][64]: column tid % 64 for every t
+    const int k = threadIdx.x & (CL_H4 - 1);
+    float w5[CL_OUT], dl[PER][CL_OUT], av[PER];
+#pragma unroll
+    for (int c = 0; c < CL_OUT; ++c) w5[c] = w.w[4][c * CL_H4 + k];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {                          // all loads first: a load-use loop pays one memory latency per trip
+      const int m = min((int)(threadIdx.x + t * 256) / CL_H4, rows - 1);
+#pragma unroll
+      for (int c = 0; c < CL_OUT; ++c) dl[t][c] = dlogits[(row0 + m) * CL_OUT + c];
+      av[t] = a4[(row0 + m) * CL_H4 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int m = (threadIdx.x + t * 256) / CL_H4;
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < CL_OUT; ++c) acc = fmaf(dlogits[(row0 + m) * CL_OUT + c], w.w[4][c * CL_H4 + k], acc);
-      v = acc * (a4[(row0 + m) * CL_H4 + k] > 0.f ? 1.f : CL_SLOPE);
+      for (int c = 0; c < CL_OUT; ++c) acc = fmaf(dl[t][c], w5[c], acc);
+      s.X[0][k * CL_P + m] = m < rows ? acc * (av[t] > 0.f ? 1.f : CL_SLOPE) : 0.f;
     }
-    s.X[0][k * CL_P + m] = v;
   }
   __syncthreads();
   cl_dense_bwd<CL_H4, CL_H3>(s.X[0], s.X[1], w.w[3], a3, row0, rows, wave, li, lh);

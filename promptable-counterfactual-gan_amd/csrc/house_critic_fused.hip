@@ -1,21 +1,15 @@
 // house_critic_fused.hip — the tabular spectral-norm critic (house_sales_kc_usa/models/discriminator.py:5-20:
-// Linear 21->32, 32->64, 64->128 with LeakyReLU(0.2), Linear 128->1) as ONE forward and ONE backward kernel: a block owns 64 batch
-// rows (lane = row) and four waves that each compute a quarter of every layer's output columns (rolled loops over the input index,
-// weights staged in LDS and read as broadcasts, the rows' input vectors parked in LDS, accumulators in registers).  The weights are the spectral-normalised W / sigma that
-// pcg_spectral_norm_fwd_batched produced; the weight gradients are reduced afterwards by pcg_linear_wgrad_grouped from the
-// per-layer pre-activation gradients this backward writes.  Widths are the reference configuration (input 17 + 4 classes,
-// hidden 32): compile-time.
+// Linear 21->32, 32->64, 64->128 with LeakyReLU(0.2), Linear 128->1) as ONE forward and ONE backward kernel on the matrix cores: a
+// block owns 32 batch rows, the four waves split the 32-column output tiles of a layer (or, where a layer is a single tile, its
+// reduction).  The weights are the spectral-normalised W / sigma that pcg_spectral_norm_fwd_batched produced; the weight gradients
+// are reduced afterwards by pcg_linear_wgrad_grouped from the per-layer pre-activation gradients this backward writes.  Widths are
+// the reference configuration (input 17 + 4 classes, hidden 32): compile-time.
 #include "pcg_common.h"
 
 namespace pcg {
 namespace {
 
-constexpr int CT = 64;                                  // rows per block (lane = row)
-constexpr int NW = 4;                                   // waves per block: wave q owns a quarter of every layer's output columns
 constexpr int C0 = 21, C1 = 32, C2 = 64, C3 = 128;      // layer widths (input_dim + num_classes, hidden, 2*hidden, 4*hidden)
-// LDS (floats): weight image of the largest layer + bias + two parked-vector buffers (ping-pong between layers) + 4 x 64 partials
-constexpr int V_FLOATS = C3 * CT;
-constexpr int C_LDS = C2 * C3 + C3 + 2 * V_FLOATS + NW * CT;
 
 struct CW { const float* w[4]; const float* b[4]; };
 // Up to two passes of the critic in one launch (blockIdx.y): D(real) and D(fake) of the critic step share nothing but the module —
@@ -26,208 +20,250 @@ struct CFwdArgs { CFwdPass ps[CP]; };
 struct CBwdPass { const float* dout; CW p; const float* a1; const float* a2; const float* a3; float* d3o; float* d2o; float* d1o; float* dx; };
 struct CBwdArgs { CBwdPass ps[CP]; };
 
-// One thread per (row, quarter): a block is 64 rows x 4 waves.  A row per THREAD alone (the first version) ran 4096 rows as 64
-// waves on a chip with 1024 SIMDs, each a serial chain over all 32..128 outputs of a layer; splitting the output columns over
-// four waves quadruples the wave count at the same total work, and the weights are staged by 256 threads instead of 64.
-// Layer inputs travel through LDS ("parked" [K][CT]: conflict-free, lane = row), weights are broadcast reads.
+// ---- the layers on the matrix cores ------------------------------------------------------------------------------------------------
+// A block owns 32 rows and runs the net on v_mfma_f32_32x32x2_f32 (exact fp32), everything in LDS:
+//   * all three weight matrices are staged once, AS STORED ([out][in]) with a row pitch of in + 1 floats (odd): the forward's B
+//     operand B[k][n] = W[n][k] is then a column walk (bank = n * pitch + k: conflict-free), the backward's B[n][j] = W[n][j] a row
+//     walk — one image serves both directions, and the staging is a coalesced burst at kernel entry;
+//   * activations / gradients sit k-major, X[k][row] with pitch 33: the A operand of a k-step is two rows of 32 floats.
+// The first version gave a thread (row, quarter of the output columns) and read the weights as LDS broadcasts: every k-step cost each
+// wave 8 ds_read_b128 for 32 FMAs per lane, and four waves shared one LDS — 24 us per pass, LDS-bandwidth bound.
+constexpr int MR = 32, MP = MR + 1;                       // rows per block, k-row pitch
+constexpr int C0P = 22;                                   // input width padded to an even reduction length (column 21 is zero)
+constexpr int P1 = C0P + 1, P2 = C1 + 1, P3 = C2 + 1;     // weight row pitches (odd)
+typedef float cm_acc_t __attribute__((ext_vector_type(16)));
+struct alignas(16) CritSmem {
+  float W1[C1 * P1], W2[C2 * P2], W3[C3 * P3];            // 736 + 2112 + 8320 floats
+  float w4[C3], b1[C1], b2[C2], b3[C3];
+  float X[2][C3 * MP];                                    // activation ping-pong, k-major
+  float part[4][MR * MP];                                 // split-reduction partial tiles
+};
+__device__ __forceinline__ int cm_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+// global [N][K] -> LDS [N][pitch] (pad columns zeroed), coalesced.  Two steps — every load of the kernel's staging is requested
+// before the first LDS store (a load-then-store loop waits out one memory latency per trip: 33 trips for the widest matrix).
+template <int N, int K>
+struct CmRegs { float v[(N * K + 255) / 256]; };
+template <int N, int K>
+__device__ __forceinline__ void cm_load(CmRegs<N, K>& r, const float* __restrict__ W) {
+#pragma unroll
+  for (int t = 0; t < (N * K + 255) / 256; ++t) r.v[t] = W[min((int)threadIdx.x + t * 256, N * K - 1)];
+}
+template <int N, int K, int PITCH>
+__device__ __forceinline__ void cm_store(float* Wl, const CmRegs<N, K>& r) {
+#pragma unroll
+  for (int t = 0; t < (N * K + 255) / 256; ++t) {
+    const int e = threadIdx.x + t * 256;
+    if (e < N * K) { const int n = e / K, k = e - n * K; Wl[n * PITCH + k] = r.v[t]; }
+  }
+  for (int e = threadIdx.x; e < N * (PITCH - K); e += 256) { const int n = e / (PITCH - K), k = K + (e - n * (PITCH - K)); Wl[n * PITCH + k] = 0.f; }
+}
+// acc (+)= X[32 rows][k in k0 .. k0 + 2*steps) * B, B[k][n] = Wl[(n0 + n) * PITCH + k]      (forward: W as stored is [n][k])
+template <int PITCH>
+__device__ __forceinline__ void cm_mma_fwd(cm_acc_t& acc, const float* X, const float* Wl, int n0, int k0, int steps, int li, int lh) {
+#pragma unroll 4
+  for (int st = 0; st < steps; ++st) {
+    const int k = k0 + 2 * st + lh;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[k * MP + li], Wl[(n0 + li) * PITCH + k], acc, 0, 0, 0);
+  }
+}
+// acc (+)= D[32 rows][n in n0 .. n0 + 2*steps) * B, B[n][j] = Wl[n * PITCH + j0 + j]           (backward: dX = dY W)
+template <int PITCH>
+__device__ __forceinline__ void cm_mma_bwd(cm_acc_t& acc, const float* D, const float* Wl, int j0, int n0, int steps, int li, int lh) {
+#pragma unroll 4
+  for (int st = 0; st < steps; ++st) {
+    const int n = n0 + 2 * st + lh;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(D[n * MP + li], Wl[n * PITCH + j0 + li], acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ cm_acc_t cm_zero() { cm_acc_t z; for (int r = 0; r < 16; ++r) z[r] = 0.f; return z; }
 
-// stage W ([N][K] row-major in global) transposed as Wt[i][j] (forward) / as is (backward), and the bias
-template <int K, int N, bool TRANSPOSE>
-__device__ __forceinline__ void stage_w(float* Wl, float* bl, const float* __restrict__ W, const float* __restrict__ b) {
-  for (int e = threadIdx.x; e < K * N; e += CT * NW) {
-    if (TRANSPOSE) { const int j = e / K, i = e - j * K; Wl[i * N + j] = W[e]; }
-    else Wl[e] = W[e];
-  }
-  if (b) for (int j = threadIdx.x; j < N; j += CT * NW) bl[j] = b[j];
-}
-// out[NO] = b[j0..] + sum_{i<K} Wt[i][j0 + .] * V[i][row]
-template <int K, int N, int NO>
-__device__ __forceinline__ void lin_cols(const float* Wt, const float* bl, const float* V, int row, int j0, float (&out)[NO]) {
-#pragma unroll
-  for (int j = 0; j < NO; ++j) out[j] = bl[j0 + j];
-#pragma unroll 1
-  for (int i = 0; i < K; ++i) {
-    const float a = V[i * CT + row];
-    const float* w = Wt + i * N + j0;
-#pragma unroll
-    for (int j = 0; j < NO; ++j) out[j] = fmaf(w[j], a, out[j]);
-  }
-}
-// out[KO] = sum_{j<N} Wl[j][i0 + .] * V[j][row]            (gradient with respect to the layer's inputs i0..i0+KO)
-template <int K, int N, int KO>
-__device__ __forceinline__ void lin_rows_t(const float* Wl, const float* V, int row, int i0, float (&out)[KO]) {
-#pragma unroll
-  for (int i = 0; i < KO; ++i) out[i] = 0.f;
-#pragma unroll 1
-  for (int j = 0; j < N; ++j) {
-    const float a = V[j * CT + row];
-    const float* w = Wl + j * K + i0;
-#pragma unroll
-    for (int i = 0; i < KO; ++i) out[i] = fmaf(w[i], a, out[i]);
-  }
-}
-// LeakyReLU, store the thread's NO columns of its row, park them for the next layer
-template <int N, int NO>
-__device__ __forceinline__ void finish_cols(float (&v)[NO], float slope, float* __restrict__ gl, size_t grow, bool on, float* Vnext, int row,
-                                            int j0) {
-#pragma unroll
-  for (int j = 0; j < NO; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-  if (on) {
-#pragma unroll
-    for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(gl + grow * N + j0 + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-  }
-#pragma unroll
-  for (int j = 0; j < NO; ++j) Vnext[(j0 + j) * CT + row] = v[j];
-}
-
-__global__ void __launch_bounds__(CT * NW) critic_fwd_kernel(CFwdArgs args, int D, int NC, int B, float slope) {
+__global__ void __launch_bounds__(256) critic_fwd_kernel(CFwdArgs args, int D, int NC, int B, float slope) {
   const CFwdPass& ps = args.ps[blockIdx.y];
-  const float* __restrict__ x = ps.x; const float* __restrict__ onehot = ps.onehot;
-  const CW& p = ps.p;
-  float* __restrict__ a0 = ps.a0; float* __restrict__ a1 = ps.a1; float* __restrict__ a2 = ps.a2; float* __restrict__ a3 = ps.a3;
-  float* __restrict__ out = ps.out;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Wl = lds; float* bl = lds + C2 * C3; float* Va = bl + C3; float* Vb = Va + V_FLOATS; float* part = Vb + V_FLOATS;
-  const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * CT + lane;
-  const bool on = row < (size_t)B;
-  // torch.cat([x, target_onehot], 1) (:19): wave q brings in inputs q, q+4, ... of its rows, stores them to a0 and parks them
-  for (int i = q; i < C0; i += NW) {
-    const float v = !on ? 0.f : (i < D ? x[row * D + i] : onehot[row * NC + (i - D)]);   // D + NC == C0 (host-checked)
-    if (on) a0[row * C0 + i] = v;
-    Va[i * CT + lane] = v;
-  }
-  stage_w<C0, C1, true>(Wl, bl, p.w[0], p.b[0]);
-  __syncthreads();
-  {
-    float h[C1 / NW];
-    lin_cols<C0, C1, C1 / NW>(Wl, bl, Va, lane, q * (C1 / NW), h);
-    finish_cols<C1, C1 / NW>(h, slope, a1, row, on, Vb, lane, q * (C1 / NW));
-  }
-  __syncthreads();
-  stage_w<C1, C2, true>(Wl, bl, p.w[1], p.b[1]);
-  __syncthreads();
-  {
-    float h[C2 / NW];
-    lin_cols<C1, C2, C2 / NW>(Wl, bl, Vb, lane, q * (C2 / NW), h);
-    finish_cols<C2, C2 / NW>(h, slope, a2, row, on, Va, lane, q * (C2 / NW));
-  }
-  __syncthreads();
-  stage_w<C2, C3, true>(Wl, bl, p.w[2], p.b[2]);
-  __syncthreads();
-  float acc = 0.f;
-  {
-    constexpr int NO = C3 / NW;
-    float h[NO];
-    lin_cols<C2, C3, NO>(Wl, bl, Va, lane, q * NO, h);
+  extern __shared__ __attribute__((aligned(16))) unsigned char crit_lds[];
+  CritSmem& s = *reinterpret_cast<CritSmem*>(crit_lds);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const size_t row0 = (size_t)blockIdx.x * MR;
+  const int rows = min(MR, B - (int)row0);
+  // ---- one burst: the three weight images, biases, the last layer's row, the block's input rows
+  CmRegs<C1, C0> r1; CmRegs<C2, C1> r2; CmRegs<C3, C2> r3;
+  cm_load<C1, C0>(r1, ps.p.w[0]); cm_load<C2, C1>(r2, ps.p.w[1]); cm_load<C3, C2>(r3, ps.p.w[2]);
+  const int tq = threadIdx.x & (C3 - 1);
+  const float w4v = ps.p.w[3][tq], b3v = ps.p.b[2][tq], b2v = ps.p.b[1][tq & (C2 - 1)], b1v = ps.p.b[0][tq & (C1 - 1)];
+  float xin[(MR * C0P + 255) / 256];                       // torch.cat([x, target_onehot], 1) (:19): elements tid, tid + 256, ...
 #pragma unroll
-    for (int j = 0; j < NO; ++j) h[j] = h[j] > 0.f ? h[j] : h[j] * slope;
-    if (on) {
+  for (int t = 0; t < (MR * C0P + 255) / 256; ++t) {
+    const int e = threadIdx.x + t * 256, m = min(e / C0P, rows - 1), k = min(e - (e / C0P) * C0P, C0 - 1);
+    xin[t] = k < D ? ps.x[(row0 + m) * D + k] : ps.onehot[(row0 + m) * NC + (k - D)];
+  }
+  cm_store<C1, C0, P1>(s.W1, r1); cm_store<C2, C1, P2>(s.W2, r2); cm_store<C3, C2, P3>(s.W3, r3);
+  if (threadIdx.x < C3) { s.w4[threadIdx.x] = w4v; s.b3[threadIdx.x] = b3v; }
+  if (threadIdx.x < C2) s.b2[threadIdx.x] = b2v;
+  if (threadIdx.x < C1) s.b1[threadIdx.x] = b1v;
 #pragma unroll
-      for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(a3 + row * C3 + q * NO + j) = make_float4(h[j], h[j + 1], h[j + 2], h[j + 3]);
+  for (int t = 0; t < (MR * C0P + 255) / 256; ++t) {
+    const int e = threadIdx.x + t * 256;
+    if (e < MR * C0P) {
+      const int m = e / C0P, k = e - m * C0P;
+      const float v = (m < rows && k < C0) ? xin[t] : 0.f;   // + the zero pad row k = 21
+      if (m < rows && k < C0) ps.a0[(row0 + m) * C0 + k] = v;
+      s.X[0][k * MP + m] = v;
     }
-#pragma unroll
-    for (int j = 0; j < NO; ++j) acc = fmaf(p.w[3][q * NO + j], h[j], acc);     // Linear(128 -> 1): this wave's quarter of the dot
   }
-  part[q * CT + lane] = acc;
   __syncthreads();
-  if (q == 0 && on) out[row] = p.b[3][0] + ((part[lane] + part[CT + lane]) + (part[2 * CT + lane] + part[3 * CT + lane]));
+  // layer 1: 22 -> 32, one tile: wave 0
+  if (wave == 0) {
+    cm_acc_t acc; const float bv = s.b1[li];
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    cm_mma_fwd<P1>(acc, s.X[0], s.W1, 0, 0, C0P / 2, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = cm_row(r, lh);
+      const float v = acc[r] > 0.f ? acc[r] : acc[r] * slope;
+      s.X[1][li * MP + m] = v;
+      if (m < rows) ps.a1[(row0 + m) * C1 + li] = v;
+    }
+  }
+  __syncthreads();
+  // layer 2: 32 -> 64, two tiles: waves 0, 1
+  if (wave < 2) {
+    const int n0 = wave * 32;
+    cm_acc_t acc; const float bv = s.b2[n0 + li];
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    cm_mma_fwd<P2>(acc, s.X[1], s.W2, n0, 0, C1 / 2, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = cm_row(r, lh);
+      const float v = acc[r] > 0.f ? acc[r] : acc[r] * slope;
+      s.X[0][(n0 + li) * MP + m] = v;
+      if (m < rows) ps.a2[(row0 + m) * C2 + n0 + li] = v;
+    }
+  }
+  __syncthreads();
+  // layer 3: 64 -> 128, four tiles: one per wave
+  {
+    const int n0 = wave * 32;
+    cm_acc_t acc; const float bv = s.b3[n0 + li];
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    cm_mma_fwd<P3>(acc, s.X[0], s.W3, n0, 0, C2 / 2, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = cm_row(r, lh);
+      const float v = acc[r] > 0.f ? acc[r] : acc[r] * slope;
+      s.X[1][(n0 + li) * MP + m] = v;
+      if (m < rows) ps.a3[(row0 + m) * C3 + n0 + li] = v;
+    }
+  }
+  __syncthreads();
+  // Linear(128 -> 1): eight threads per row take 16 inputs each (ascending), then a fixed-order sum of the eight
+  {
+    const int m = threadIdx.x >> 3, sgm = threadIdx.x & 7;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(s.w4[sgm * 16 + k], s.X[1][(sgm * 16 + k) * MP + m], acc);
+    s.part[0][m * 8 + sgm] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < MR && threadIdx.x < rows) {
+    const float* q = s.part[0] + threadIdx.x * 8;
+    ps.out[row0 + threadIdx.x] = ps.p.b[3][0] + (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])));
+  }
 }
 
 // pre-activation gradients d3, d2, d1 (operands of the weight gradients) and, optionally, the gradient of the first D inputs
-__global__ void __launch_bounds__(CT * NW) critic_bwd_kernel(CBwdArgs args, int B, float slope, int D) {
+__global__ void __launch_bounds__(256) critic_bwd_kernel(CBwdArgs args, int B, float slope, int D) {
   const CBwdPass& ps = args.ps[blockIdx.y];
-  const float* __restrict__ dout = ps.dout;
-  const CW& p = ps.p;
-  const float* __restrict__ a1 = ps.a1; const float* __restrict__ a2 = ps.a2; const float* __restrict__ a3 = ps.a3;
-  float* __restrict__ d3o = ps.d3o; float* __restrict__ d2o = ps.d2o; float* __restrict__ d1o = ps.d1o; float* __restrict__ dx = ps.dx;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Wl = lds; float* Va = lds + C2 * C3 + C3; float* Vb = Va + V_FLOATS;
-  const int lane = threadIdx.x & (CT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * CT + lane;
-  const bool on = row < (size_t)B;
-  const float g = on ? dout[row] : 0.f;
-  {
-    constexpr int NO = C3 / NW;        // d3 = dout * w4 * LeakyReLU'(a3): this wave's quarter
-    float d[NO];
+  extern __shared__ __attribute__((aligned(16))) unsigned char crit_lds[];
+  CritSmem& s = *reinterpret_cast<CritSmem*>(crit_lds);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const size_t row0 = (size_t)blockIdx.x * MR;
+  const int rows = min(MR, B - (int)row0);
+  // ---- one burst: the weight images, the last layer's row, and the operands of d3 (a3 rows, dout)
+  CmRegs<C1, C0> r1; CmRegs<C2, C1> r2; CmRegs<C3, C2> r3;
+  cm_load<C1, C0>(r1, ps.p.w[0]); cm_load<C2, C1>(r2, ps.p.w[1]); cm_load<C3, C2>(r3, ps.p.w[2]);
+  const int k3 = threadIdx.x & (C3 - 1);                   // this thread's column of every d3 element it makes (256 % 128 == 0)
+  const float w4v = ps.p.w[3][k3];
+  float a3v[MR * C3 / 256], dov[MR * C3 / 256];
 #pragma unroll
-    for (int j = 0; j < NO; j += 4) {
-      const float4 a = on ? *reinterpret_cast<const float4*>(a3 + row * C3 + q * NO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      d[j] = g * p.w[3][q * NO + j] * (a.x > 0.f ? 1.f : slope);         d[j + 1] = g * p.w[3][q * NO + j + 1] * (a.y > 0.f ? 1.f : slope);
-      d[j + 2] = g * p.w[3][q * NO + j + 2] * (a.z > 0.f ? 1.f : slope); d[j + 3] = g * p.w[3][q * NO + j + 3] * (a.w > 0.f ? 1.f : slope);
-    }
-    if (on) {
-#pragma unroll
-      for (int j = 0; j < NO; j += 4) *reinterpret_cast<float4*>(d3o + row * C3 + q * NO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
-    }
-#pragma unroll
-    for (int j = 0; j < NO; ++j) Va[(q * NO + j) * CT + lane] = d[j];
+  for (int t = 0; t < MR * C3 / 256; ++t) {
+    const int m = min((int)(threadIdx.x + t * 256) / C3, rows - 1);
+    a3v[t] = ps.a3[(row0 + m) * C3 + k3]; dov[t] = ps.dout[row0 + m];
   }
-  stage_w<C2, C3, false>(Wl, nullptr, p.w[2], nullptr);
-  __syncthreads();
-  {
-    constexpr int KO = C2 / NW;
-    float d[KO];
-    lin_rows_t<C2, C3, KO>(Wl, Va, lane, q * KO, d);
+  float a2v[MR * C2 / 256], a1v[MR * C1 / 256];              // the masks of the later layers: element tid + 256 t of [32][64], [32][32]
 #pragma unroll
-    for (int j = 0; j < KO; j += 4) {
-      const float4 a = on ? *reinterpret_cast<const float4*>(a2 + row * C2 + q * KO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      d[j] *= a.x > 0.f ? 1.f : slope; d[j + 1] *= a.y > 0.f ? 1.f : slope; d[j + 2] *= a.z > 0.f ? 1.f : slope; d[j + 3] *= a.w > 0.f ? 1.f : slope;
+  for (int t = 0; t < MR * C2 / 256; ++t) a2v[t] = ps.a2[(row0 + min((int)(threadIdx.x + t * 256) / C2, rows - 1)) * C2 + (threadIdx.x & (C2 - 1))];
+#pragma unroll
+  for (int t = 0; t < MR * C1 / 256; ++t) a1v[t] = ps.a1[(row0 + min((int)(threadIdx.x + t * 256) / C1, rows - 1)) * C1 + (threadIdx.x & (C1 - 1))];
+  cm_store<C1, C0, P1>(s.W1, r1); cm_store<C2, C1, P2>(s.W2, r2); cm_store<C3, C2, P3>(s.W3, r3);
+  // d3 = dout * w4 * LeakyReLU'(a3): 32 x 128, sixteen per thread; coalesced rows of a3 in, d3 out
+#pragma unroll
+  for (int t = 0; t < MR * C3 / 256; ++t) {
+    const int m = (threadIdx.x + t * 256) / C3;
+    float v = 0.f;
+    if (m < rows) {
+      v = dov[t] * w4v * (a3v[t] > 0.f ? 1.f : slope);
+      ps.d3o[(row0 + m) * C3 + k3] = v;
     }
-    if (on) {
-#pragma unroll
-      for (int j = 0; j < KO; j += 4) *reinterpret_cast<float4*>(d2o + row * C2 + q * KO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
-    }
-#pragma unroll
-    for (int j = 0; j < KO; ++j) Vb[(q * KO + j) * CT + lane] = d[j];
+    s.X[0][k3 * MP + m] = v;
   }
   __syncthreads();
-  stage_w<C1, C2, false>(Wl, nullptr, p.w[1], nullptr);
-  __syncthreads();
+  // d2 = (d3 W3) * LeakyReLU'(a2): reduction 128, two output tiles: wave (tile, half of the reduction); halves added in order
   {
-    constexpr int KO = C1 / NW;
-    float d[KO];
-    lin_rows_t<C1, C2, KO>(Wl, Vb, lane, q * KO, d);
+    const int tile = wave & 1, half = wave >> 1, j0 = tile * 32;
+    cm_acc_t acc = cm_zero();
+    cm_mma_bwd<P3>(acc, s.X[0], s.W3, j0, half * (C3 / 2), C3 / 4, li, lh);
 #pragma unroll
-    for (int j = 0; j < KO; j += 4) {
-      const float4 a = on ? *reinterpret_cast<const float4*>(a1 + row * C1 + q * KO + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      d[j] *= a.x > 0.f ? 1.f : slope; d[j + 1] *= a.y > 0.f ? 1.f : slope; d[j + 2] *= a.z > 0.f ? 1.f : slope; d[j + 3] *= a.w > 0.f ? 1.f : slope;
-    }
-    if (on) {
-#pragma unroll
-      for (int j = 0; j < KO; j += 4) *reinterpret_cast<float4*>(d1o + row * C1 + q * KO + j) = make_float4(d[j], d[j + 1], d[j + 2], d[j + 3]);
-    }
-#pragma unroll
-    for (int j = 0; j < KO; ++j) Va[(q * KO + j) * CT + lane] = d[j];
+    for (int r = 0; r < 16; ++r) s.part[wave][li * MP + cm_row(r, lh)] = acc[r];
   }
-  if (dx) {   // block-uniform
-    __syncthreads();
-    stage_w<C0, C1, false>(Wl, nullptr, p.w[0], nullptr);
-    __syncthreads();
-    constexpr int KO = (C0 + NW - 1) / NW;            // 6, 6, 6, 3 of the 21 input columns
-    float d[KO];
-    // the last wave's window is clipped: it reads weights of columns < C0 only through the guarded store below, LDS reads stay in
-    // the staged image (K*N floats) because i0 + KO <= C0 + 3 < 2*C0 and j*K + i0 + i < N*K for j < N-1; the last row is guarded
-    const int i0 = q * KO;
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < KO; ++i) d[i] = 0.f;
-#pragma unroll 1
-    for (int j = 0; j < C1; ++j) {
-      const float a = Va[j * CT + lane];
-      const float* w = Wl + j * C0 + i0;
-#pragma unroll
-      for (int i = 0; i < KO; ++i) d[i] = fmaf(i0 + i < C0 ? w[i] : 0.f, a, d[i]);
+  for (int t = 0; t < MR * C2 / 256; ++t) {
+    const int e = threadIdx.x + t * 256;
+    const int m = e / C2, j = e - m * C2, tile = j >> 5, jj = j & 31;
+    float v = 0.f;
+    if (m < rows) {
+      v = (s.part[tile][jj * MP + m] + s.part[2 + tile][jj * MP + m]) * (a2v[t] > 0.f ? 1.f : slope);
+      ps.d2o[(row0 + m) * C2 + j] = v;
     }
-    if (on) {
+    s.X[1][j * MP + m] = v;
+  }
+  __syncthreads();
+  // d1 = (d2 W2) * LeakyReLU'(a1): reduction 64, one tile: a quarter of the reduction per wave, added in wave order
+  {
+    cm_acc_t acc = cm_zero();
+    cm_mma_bwd<P2>(acc, s.X[1], s.W2, 0, wave * (C2 / 4), C2 / 8, li, lh);
 #pragma unroll
-      for (int i = 0; i < KO; ++i)
-        if (i0 + i < D) dx[row * D + i0 + i] = d[i];
+    for (int r = 0; r < 16; ++r) s.part[wave][li * MP + cm_row(r, lh)] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MR * C1 / 256; ++t) {
+    const int e = threadIdx.x + t * 256;
+    const int m = e / C1, j = e - m * C1;
+    float v = 0.f;
+    if (m < rows) {
+      v = (((s.part[0][j * MP + m] + s.part[1][j * MP + m]) + s.part[2][j * MP + m]) + s.part[3][j * MP + m]) * (a1v[t] > 0.f ? 1.f : slope);
+      ps.d1o[(row0 + m) * C1 + j] = v;
     }
+    s.X[0][j * MP + m] = v;
+  }
+  if (!ps.dx) return;                                        // block-uniform
+  __syncthreads();
+  // dx = d1 W1 (first D of the 21 input columns): reduction 32, one tile, a quarter per wave
+  {
+    cm_acc_t acc = cm_zero();
+    cm_mma_bwd<P1>(acc, s.X[0], s.W1, 0, wave * (C1 / 4), C1 / 8, li, lh);      // columns >= 22 of the tile read pad / the next row: dropped below
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s.part[wave][li * MP + cm_row(r, lh)] = acc[r];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < MR * D; e += 256) {
+    const int m = e / D, i = e - m * D;
+    if (m < rows) ps.dx[(row0 + m) * D + i] = ((s.part[0][i * MP + m] + s.part[1][i * MP + m]) + s.part[2][i * MP + m]) + s.part[3][i * MP + m];
   }
 }
 
 int set_lds(const void* fn) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C_LDS * sizeof(float)));
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CritSmem));
   if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e)); return PCG_ERR_LAUNCH; }
   return PCG_OK;
 }
@@ -255,7 +291,7 @@ extern "C" int pcg_house_critic_fwd_n(int32_t n_pass, const float* const* x, con
   }
   static int once = set_lds(reinterpret_cast<const void*>(critic_fwd_kernel));
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + CT - 1) / CT, n_pass), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, args, D, NC, B, slope);
+  hipLaunchKernelGGL(critic_fwd_kernel, dim3((B + MR - 1) / MR, n_pass), dim3(256), sizeof(CritSmem), (hipStream_t)stream, args, D, NC, B, slope);
   return launch_status("critic_fwd_kernel");
 }
 
@@ -280,7 +316,7 @@ extern "C" int pcg_house_critic_bwd_n(int32_t n_pass, const float* const* dout, 
   }
   static int once = set_lds(reinterpret_cast<const void*>(critic_bwd_kernel));
   if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + CT - 1) / CT, n_pass), dim3(CT * NW), C_LDS * sizeof(float), (hipStream_t)stream, args, B, slope, D);
+  hipLaunchKernelGGL(critic_bwd_kernel, dim3((B + MR - 1) / MR, n_pass), dim3(256), sizeof(CritSmem), (hipStream_t)stream, args, B, slope, D);
   return launch_status("critic_bwd_kernel");
 }
 

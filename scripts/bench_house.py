@@ -23,7 +23,8 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--no-overlap", action="store_true", help="A/B: single-stream graph (no parallel classifier branch)")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: the reference-order autograd step as a single-stream graph")
+    ap.add_argument("--inline", action="store_true", help="A/B: the scheduled step's kernels on ONE stream (no parallel classifier branch)")
     BL.add_common_args(ap, steps=200, warmup=20)
     args = ap.parse_args()
     if args.gpus != 1:
@@ -45,7 +46,7 @@ def main():
 
     gs = None
     if not args.eager:
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap=not args.no_overlap)
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap="inline" if args.inline else (not args.no_overlap))
         gs.x.copy_(x); gs.y.copy_(y)
         t, mask, noise = gs.target_y, gs.mask, gs.noise
 
@@ -79,7 +80,7 @@ def main():
     roofline = {"bound": "launch/hbm", "achieved": round(ach, 2), "peak": BL.PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / BL.PEAK_HBM_GBS, 5),
                 "traffic": None, "algorithmic_bytes_per_step": int(algo_bytes), "launches_per_step": launches,
                 "us_per_launch": None if not launches else round(sec * 1e6 / launches, 2),
-                "kernel": "whole step (fused generator segments, fused critic, grouped weight gradients, Adam x2)"}
+                "kernel": "whole step (fused generator segments, fused critic pair, MFMA classifier and weight gradients, Adam x2)"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import house_ref as HR                   # the checker's restatement: CPU-baseline leg only
@@ -102,8 +103,10 @@ def main():
                                f"Discriminator, frozen NNClassifier), 17 features, batch {B}, full step incl. per-step device draws",
                    "global_batch": B, "parallelism": "dp1"},
         "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
-        "launch": "eager" if gs is None else ("hip-graph replay (1 graph" + (", classifier term on a parallel branch" if gs.branch is not None else "")
-                                            + ") + 3 RNG launches per step drawing into its input buffers"),
+        "launch": "eager" if gs is None else ("hip-graph replay (1 graph"
+                                            + (", scheduled step on one stream" if gs.branch == "inline" else
+                                               ", classifier term on a parallel branch" if gs.branch is not None else ", reference-order step")
+                                            + ") + 1 RNG launch per step drawing into its input buffers"),
     })
     R.finish()
 

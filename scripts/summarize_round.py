@@ -62,11 +62,11 @@ if r:
 stats_md("countergan", f"{tag}_countergan_kernel_stats.md", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 (batch 1024)", 10)
 stats_md("wgan", f"{tag}_wgan_kernel_stats.md", "python3 scripts/bench_wgan.py --steps 10 --warmup 2 (12 critic updates + 12 generator updates; per-launch averages)", 24)
 
-# house: launches per step = dispatches between two consecutive randint_kernel launches in the steady state
+# house: launches per step = dispatches between two consecutive house_draws_kernel launches in the steady state
 trace = find("house", "*kernel_trace.csv")
 if trace:
     rows = sorted(csv.DictReader(open(trace)), key=lambda r_: int(r_["Start_Timestamp"]))
-    marks = [i for i, r_ in enumerate(rows) if "randint_kernel" in r_["Kernel_Name"]]
+    marks = [i for i, r_ in enumerate(rows) if "house_draws_kernel" in r_["Kernel_Name"]]
     if len(marks) > 12:
         a, b = marks[-11], marks[-1]
         lps = (b - a) / 10.0
@@ -76,7 +76,7 @@ if trace:
         queues = sorted({r_["Queue_Id"] for r_ in rows[a:b]})
         json.dump({"launches_per_step": lps, "step_period_us_under_profiler": period, "sum_of_kernel_durations_us": busy,
                    "aten_kernels_per_step": nat, "hw_queues_used": len(queues),
-                   "how": "dispatches between consecutive randint_kernel launches (one per step), mean of the last 10 steps of "
+                   "how": "dispatches between consecutive house_draws_kernel launches (one per step), mean of the last 10 steps of "
                           "rocprofv3 --kernel-trace -- python3 scripts/bench_house.py --steps 50 --warmup 10"},
                   open(os.path.join(out, f"{tag}_house_launches.json"), "w"), indent=1)
     stats_md("house", f"{tag}_house_kernel_stats.md", "python3 scripts/bench_house.py --steps 50 --warmup 10 (batch 4096, HIP-graph replay with the parallel classifier branch)", 63)
