@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
                                                                 int* __restrict__ tickets) {
   __shared__ float red[4][WM_T * WM_NP];
   __shared__ int s_last;
+  PCG_T(0);
   const int tile = blockIdx.y, sb = blockIdx.x;
   const int it = g.t_item[tile], m0 = g.t_y[tile] * WM_T, n0 = g.t_x[tile] * WM_T;
   const int O = g.O[it], I = g.I[it], ldy = g.ldy[it], ldx = g.ldx[it];
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
   const float* pb = g.x[it] + min(n0 + li, I - 1);
   wm_acc_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  PCG_T(1);
   for (int r = kbeg; r < kend; r += 32) {                  // 16 MFMA steps of two rows; all 32 loads of a group in flight together
     float av[16], bv[16];
 #pragma unroll
@@ -303,12 +305,14 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
       bsum += av[st];
     }
   }
+  PCG_T(2);
   bsum += __shfl_xor(bsum, 32);                              // rows of both k-halves: lanes lh = 0 hold column m0 + li of db
   // the four waves' tiles -> LDS, added in wave order
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * lh) * WM_NP + li] = acc[r];
   if (lh == 0) red[wave][li * WM_NP + WM_T] = bsum;
   __syncthreads();
+  PCG_T(3);
   const int NP = I + 1;
   const bool bias_tile = n0 == 0 && g.db[it] != nullptr;
   float* mine = partial + g.poff[it] + (size_t)sb * O * NP;
@@ -326,14 +330,17 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
     }
   }
   if (Sb == 1) return;                                       // kernel-uniform
+  PCG_T(4);
   __builtin_amdgcn_s_waitcnt(0);                             // this thread's partial stores are complete ...
   __syncthreads();                                           // ... every thread's are
+  PCG_T(5);
   if (threadIdx.x == 0) {
     const int t = __hip_atomic_fetch_add(tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == Sb - 1;
     if (s_last) __hip_atomic_store(tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  PCG_T(6);
   if (!s_last) return;
   const float* base = partial + g.poff[it];
   for (int e = threadIdx.x; e < WM_T * WM_NP; e += 256) {
@@ -355,6 +362,7 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
     if (n < WM_T) { float* q = g.dW[it] + (size_t)gm * I + gn; *q = g.accW[it] ? *q + sum : sum; }
     else { float* q = g.db[it] + gm; *q = g.accB[it] ? *q + sum : sum; }
   }
+  PCG_T(7);
 }
 
 __global__ void __launch_bounds__(256) onehot_kernel(const int64_t* __restrict__ idx, int B, int K, float* __restrict__ out) {
@@ -679,10 +687,26 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   __shared__ float sW[SN_LDS_FLOATS];
   const int ld = (I & 1) ? I : I + 1;
   const bool in_lds = O * ld <= SN_LDS_FLOATS;      // block-uniform
-  for (int i = threadIdx.x; i < O; i += 256) su[i] = u[i];
-  for (int i = threadIdx.x; i < I; i += 256) sv[i] = v[i];
-  if (in_lds)
-    for (int e = threadIdx.x; e < O * I; e += 256) { const int o = e / I, i = e - o * I; sW[o * ld + i] = W[e]; }
+  // one burst: u, v and the whole matrix are requested before the first LDS store (a load-then-store loop pays one memory latency
+  // per trip: 32 trips for the 128 x 64 layer)
+  {
+    constexpr int PER = SN_LDS_FLOATS / 256;                // 48 elements per thread at most
+    const float uv = u[min((int)threadIdx.x, O - 1)], vv = v[min((int)threadIdx.x, I - 1)];      // O, I <= 256
+    float wr[PER];
+    if (in_lds) {
+#pragma unroll
+      for (int t = 0; t < PER; ++t) wr[t] = W[min((int)threadIdx.x + t * 256, O * I - 1)];
+    }
+    if ((int)threadIdx.x < O) su[threadIdx.x] = uv;
+    if ((int)threadIdx.x < I) sv[threadIdx.x] = vv;
+    if (in_lds) {
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int e = threadIdx.x + t * 256;
+        if (e < O * I) { const int o = e / I, i = e - o * I; sW[o * ld + i] = wr[t]; }
+      }
+    }
+  }
   __syncthreads();
   const float* M = in_lds ? sW : W;
   const int lm = in_lds ? ld : I;
@@ -729,7 +753,35 @@ __global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __r
 __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O, int I,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
+  // no contraction: "dW + g" must round g first, so that accumulating here and adding a separately written g later (the two-buffer
+  // schedule of the tabular step) give the same bits
+#pragma clang fp contract(off)
   __shared__ float red[256];
+  if (O * I <= 32 * 256) {       // (block-uniform) every operand of the layer in ONE burst: 32 elements per thread at most
+    __shared__ float su[256], sv[256];
+    constexpr int PER = 32;
+    float a[PER], b[PER], w0[PER];
+    const float uv = u[min((int)threadIdx.x, O - 1)], vv = v[min((int)threadIdx.x, I - 1)], sg = sigma[0];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int e = min((int)threadIdx.x + 256 * j, O * I - 1); a[j] = dWbar[e]; b[j] = Wbar[e]; w0[j] = accumulate ? dW[e] : 0.f; }
+    su[threadIdx.x] = uv; sv[threadIdx.x] = vv;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) t = (int)threadIdx.x + 256 * j < O * I ? fmaf(a[j], b[j], t) : t;      // element order, as the loops below
+    const float dot = block_sum(t, red);
+    const float inv = 1.f / sg;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < O * I) {
+        const int o = e / I, i = e - o * I;
+        const float g = (a[j] - dot * su[o] * sv[i]) * inv;
+        dW[e] = accumulate ? w0[j] + g : g;
+      }
+    }
+    __syncthreads();             // su / sv / red are reused by the next pass of a sequence
+    return;
+  }
   float t = 0.f;
   int e0 = threadIdx.x;
   for (; e0 + 7 * 256 < O * I; e0 += 8 * 256) {      // 16 independent loads in flight, products added in element order
