@@ -87,6 +87,27 @@ def cpu_baseline(batch=BATCH_PER_GPU, steps=3, threads=None):
                       f"restatement of mnist_dcgan.py:147-175 (oracle/dcgan_ref.py), {torch.get_num_threads()} threads"}
 
 
+_json_fd = None
+
+
+def claim_stdout():
+    """Keep the process's stdout for the ONE JSON line: the real fd 1 is saved and fd 1 is pointed at stderr, so that anything a
+    library prints there (RCCL writes a version banner to stdout when a communicator is created) cannot land in front of it."""
+    global _json_fd
+    if _json_fd is None:
+        sys.stdout.flush()
+        _json_fd = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(line):
+    text = (json.dumps(line) + "\n").encode()
+    if _json_fd is None:
+        sys.stdout.write(text.decode()); sys.stdout.flush()
+    else:
+        os.write(_json_fd, text)
+
+
 def launch_ranks(n, argv, script=None):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as CHILD processes — one per GPU, the
     environment torch.distributed.run would give them — before anything in this process touches the GPU, relay rank 0's stdout
@@ -149,6 +170,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus, sys.argv[1:])      # does not return
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -321,7 +343,7 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",
         }
-        print(json.dumps(line), flush=True)
+        emit_json(line)
     if dp is not None:
         from pcgan_amd.parallel import shutdown
         torch.cuda.synchronize()

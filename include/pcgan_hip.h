@@ -280,8 +280,8 @@ int pcg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 
 /* hipGraph-capturable form: the step count lives on the device (*step_counter_dev is incremented by the
  * call) and the bias corrections are computed there in fp64, inside the update kernel itself: its last block to
- * finish stores the new count.  hyper_scratch2_dev is 8 bytes the caller zero-initialises ONCE and then leaves
- * alone (the last-block ticket; every call leaves it zero). */
+ * finish stores the new count and the corrections of the next step.  hyper_scratch2_dev is 48 bytes (8-byte aligned)
+ * the caller zero-initialises ONCE and then leaves alone. */
 int pcg_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled_wd,
                              int64_t* step_counter_dev, float* hyper_scratch2_dev, pcg_stream_t stream);

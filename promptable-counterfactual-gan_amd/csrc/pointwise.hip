@@ -118,7 +118,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 // forms the bias corrections for step t itself (two pow() in double: noise next to the memory pass), and the LAST block to finish
 // (atomic ticket) writes t back — every block has read the old value by then, whatever the grid size.
 //   mode 0: hy is given by value;  1: t = step + 1, the last block stores it;  2: t = step (a preceding launch already ticked)
-struct AdamTick { int64_t* step; int* ticket; double lr, beta1, beta2; int mode; };
+// The two pow() cost every WAVE ~1 us of straight-line fp64 code (measured: the DCGAN update went from 18 to 44 us per launch), so
+// the last block also leaves the corrections of the NEXT step in the scratch block, tagged with the step and the betas they are
+// for; a launch that finds its own step there just loads them.  First step, a changed beta, a restored counter: the tag misses and
+// the launch computes them itself.
+struct AdamCache { int ticket; float bc2_sqrt; double bc1, beta1, beta2; long long t_for; };   // 40 bytes of the caller's scratch, zero at first use
+struct AdamTick { int64_t* step; AdamCache* cache; double lr, beta1, beta2; int mode; };
 
 template <int VEC>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
@@ -127,10 +132,15 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
   int64_t t = 0;
   if (tk.mode) {
     t = tk.step[0] + (tk.mode == 1 ? 1 : 0);
-    const double bc1 = 1.0 - pow(tk.beta1, (double)t);
-    const double bc2 = 1.0 - pow(tk.beta2, (double)t);
+    const AdamCache c = *tk.cache;
+    double bc1;
+    if (c.t_for == t && c.beta1 == tk.beta1 && c.beta2 == tk.beta2) {       // kernel-uniform
+      bc1 = c.bc1; hy.bc2_sqrt = c.bc2_sqrt;
+    } else {
+      bc1 = 1.0 - pow(tk.beta1, (double)t);
+      hy.bc2_sqrt = (float)sqrt(1.0 - pow(tk.beta2, (double)t));
+    }
     hy.step_size = (float)(tk.lr / bc1);
-    hy.bc2_sqrt = (float)sqrt(bc2);
   }
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
@@ -155,9 +165,12 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
   if (tk.mode == 1) {          // kernel-uniform
     __syncthreads();           // every thread of this block has read the counter
     if (threadIdx.x == 0) {             // (no fence: nothing but the counter itself travels between blocks, and it is only written here)
-      if (atomicAdd(tk.ticket, 1) == (int)gridDim.x - 1) {
+      if (atomicAdd(&tk.cache->ticket, 1) == (int)gridDim.x - 1) {      // every block has read the counter and the cache by now
         tk.step[0] = t;
-        *tk.ticket = 0;
+        tk.cache->ticket = 0;
+        tk.cache->bc1 = 1.0 - pow(tk.beta1, (double)(t + 1));
+        tk.cache->bc2_sqrt = (float)sqrt(1.0 - pow(tk.beta2, (double)(t + 1)));
+        tk.cache->beta1 = tk.beta1; tk.cache->beta2 = tk.beta2; tk.cache->t_for = t + 1;
       }
     }
   }
@@ -182,14 +195,14 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p,
 }
 
 int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                double wd, int decoupled, AdamHyper hy, int64_t* step_dev, int* ticket_dev, hipStream_t s) {
+                double wd, int decoupled, AdamHyper hy, int64_t* step_dev, AdamCache* cache_dev, hipStream_t s) {
   const bool al = al16(param) && al16(grad) && al16(m) && al16(v);
   const AdamConst k{(float)lr, (float)(1.0 - beta1), (float)(1.0 - (1.0 - beta1)), (float)beta2, (float)(1.0 - beta2), (float)eps,
                     (float)wd, decoupled};
   // 16-byte lanes over the bulk, a scalar launch for the 1..3 trailing elements (a flat buffer that ends in a bias of one element —
   // the WGAN-GP critic's Linear(1024, 1) — used to send all 25 M parameters down the scalar kernel)
   const int64_t bulk = al ? (n & ~(int64_t)3) : 0;
-  AdamTick tk{step_dev, ticket_dev, lr, beta1, beta2, step_dev ? 1 : 0};
+  AdamTick tk{step_dev, cache_dev, lr, beta1, beta2, step_dev ? 1 : 0};
   if (bulk) {
     hipLaunchKernelGGL(adam_kernel<4>, dim3(ew_blocks((size_t)bulk / 4)), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, k, hy, tk);
     if (tk.mode) tk.mode = 2;      // the trailing launch uses the counter the bulk launch's last block stored
@@ -258,10 +271,11 @@ extern "C" int pcg_adam_step_capturable(float* param, const float* grad, float* 
   PCG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_counter_dev && hyper_scratch2_dev,
               "pcg_adam_step_capturable: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  // hyper_scratch2_dev: 8 zero-initialised bytes — the ticket of the last-block tick (left zero by every launch)
+  // hyper_scratch2_dev: 48 bytes, zero at first use: the last-block ticket and the cached corrections of the next step
+  PCG_REQUIRE((reinterpret_cast<uintptr_t>(hyper_scratch2_dev) & 7) == 0, "pcg_adam_step_capturable: the scratch block must be 8-byte aligned");
   AdamHyper hy{0.f, 1.f};
   return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, hy, step_counter_dev,
-                     reinterpret_cast<int*>(hyper_scratch2_dev), s);
+                     reinterpret_cast<AdamCache*>(hyper_scratch2_dev), s);
 }
 
 extern "C" int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream) {

@@ -1151,9 +1151,17 @@ class GraphedTrainStep:
             for _ in range(max(1, warmup)):
                 step()
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = step()
+        import gc
+        gc.collect()                 # no finalizer may run while the stream captures (see nn._HipGraphCapture.begin)
+        gc_on = gc.isenabled()
+        gc.disable()
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = step()
+        finally:
+            if gc_on:
+                gc.enable()
         for n, (fp, bufs) in zip(nets, saved):
             n.flat_params.copy_(fp)
             for b, b0 in zip(n.buffers(), bufs):

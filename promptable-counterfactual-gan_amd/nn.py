@@ -606,6 +606,12 @@ class _HipGraphCapture:
         torch.cuda.current_stream().wait_stream(side)
 
     def begin(self):
+        # Python's cyclic collector must not run while a stream captures: freeing a graph, an event or a cached block from a finalizer
+        # is a HIP call the capture forbids, and an error raised inside a finalizer aborts the process.  Collect now, hold it off.
+        import gc
+        gc.collect()
+        self._gc_was_on = gc.isenabled()
+        gc.disable()
         self._g = torch.cuda.CUDAGraph()
         # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
         self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
@@ -613,7 +619,12 @@ class _HipGraphCapture:
         self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
 
     def end(self):
-        self._ctx.__exit__(None, None, None)
+        try:
+            self._ctx.__exit__(None, None, None)
+        finally:
+            if getattr(self, "_gc_was_on", False):
+                import gc
+                gc.enable()
         if self._pool is None:
             self._pool = self._g.pool()
         return self._g             # .replay()

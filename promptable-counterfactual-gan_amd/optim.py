@@ -77,7 +77,7 @@ class Adam(torch.optim.Optimizer):
                     "exp_avg": ops.fill(torch.empty(n, dtype=torch.float32, device=dev), 0.0),
                     "exp_avg_sq": ops.fill(torch.empty(n, dtype=torch.float32, device=dev), 0.0),
                     "step": torch.zeros(1, dtype=torch.int64, device=dev),
-                    "hyper": torch.zeros(2, dtype=torch.float32, device=dev),
+                    "hyper": torch.zeros(12, dtype=torch.float32, device=dev),       # 48 bytes of kernel-side scratch (ticket + cached corrections)
                 }
                 built.append(st)
             self._segments.append(built)

@@ -35,6 +35,7 @@ class Ranks:
     def __init__(self, args, script):
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             _contract.launch_ranks(args.gpus, sys.argv[1:], script=script)      # does not return
+        _contract.claim_stdout()
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -139,7 +140,7 @@ def cpu_median(step_fn, steps=3, warmup=1, threads=None):
 
 
 def emit(line):
-    print(json.dumps(line), flush=True)
+    _contract.emit_json(line)
 
 
 cpu_model = _contract.cpu_model

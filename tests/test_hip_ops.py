@@ -226,7 +226,7 @@ def test_adam(pcg, betas, wd, decoupled, n):
     d = dev()
     pd = torch.from_numpy(p.copy()).to(d); md = torch.zeros(n, device=d); vd = torch.zeros(n, device=d)
     pd2 = pd.clone(); md2 = torch.zeros(n, device=d); vd2 = torch.zeros(n, device=d)
-    step_dev = torch.zeros(1, dtype=torch.int64, device=d); hyper = torch.zeros(2, device=d)
+    step_dev = torch.zeros(1, dtype=torch.int64, device=d); hyper = torch.zeros(12, device=d)
     for step in range(1, 5):
         g = rng.standard_normal(n).astype(np.float32)
         gd = torch.from_numpy(g).to(d)
