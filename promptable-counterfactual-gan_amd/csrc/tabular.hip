@@ -675,8 +675,40 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   __syncthreads();
   return r;
 }
+// sum over the block's 256 threads: wave butterflies + four partials in a fixed order (two barriers instead of nine)
+__device__ __forceinline__ float block_sum4(float v, float* red4) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+  __syncthreads();
+  return r;
+}
+// y[j] = sum_k A(j, k) x[k] for j < NJ with ALL 256 threads: 256 / P2 threads per output (P2 = NJ rounded up to a power of two), each
+// a contiguous share of k, the shares added in order through LDS.  TRANS: A(j, k) = M[k][j] (W^T u), else M[j][k] (W v).  The result
+// is valid in threads < NJ.  (One thread per output left 64-128 threads walking 64-128 dependent FMAs each, three times per call.)
+template <bool TRANS>
+__device__ __forceinline__ float sn_matvec(const float* M, int lm, const float* x, int NJ, int NK, float* ps) {
+  int p2 = 1;
+  while (p2 < NJ) p2 <<= 1;                               // <= 256 (host-checked)
+  const int parts = 256 / p2, j = threadIdx.x & (p2 - 1), part = threadIdx.x / p2;
+  const int chunk = (NK + parts - 1) / parts, k0 = part * chunk, k1 = min(NK, k0 + chunk);
+  float acc = 0.f;
+  if (j < NJ) {
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc = fmaf(TRANS ? M[k * lm + j] : M[j * lm + k], x[k], acc);
+  }
+  ps[threadIdx.x] = acc;
+  __syncthreads();
+  float r = 0.f;
+  if ((int)threadIdx.x < p2)
+    for (int q = 0; q < parts; ++q) r += ps[q * p2 + threadIdx.x];
+  __syncthreads();
+  return r;
+}
 // training: v <- normalize(W^T u); u <- normalize(W v)  (in place);  sigma = u . (W v);  Wbar = W / sigma
-// The matrix is staged once in LDS (row stride made odd: the row-wise products then hit 32 different banks) and the three
+// The matrix is staged once in LDS (row stride made odd: the row-wise products then hit 32 different banks) and the
 // matrix-vector products read it from there; matrices beyond 48 KB take the global-memory form.
 constexpr int SN_LDS_FLOATS = 12288;
 __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__ W, int O, int I, float* __restrict__ u,
@@ -687,31 +719,61 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   __shared__ float sW[SN_LDS_FLOATS];
   const int ld = (I & 1) ? I : I + 1;
   const bool in_lds = O * ld <= SN_LDS_FLOATS;      // block-uniform
-  // one burst: u, v and the whole matrix are requested before the first LDS store (a load-then-store loop pays one memory latency
-  // per trip: 32 trips for the 128 x 64 layer)
-  {
+  if (in_lds) {
+    // one burst: u, v and the whole matrix are requested before the first LDS store (a load-then-store loop pays one memory
+    // latency per trip: 32 trips for the 128 x 64 layer); the register copy of the matrix also feeds the W / sigma writes
     constexpr int PER = SN_LDS_FLOATS / 256;                // 48 elements per thread at most
     const float uv = u[min((int)threadIdx.x, O - 1)], vv = v[min((int)threadIdx.x, I - 1)];      // O, I <= 256
     float wr[PER];
-    if (in_lds) {
 #pragma unroll
-      for (int t = 0; t < PER; ++t) wr[t] = W[min((int)threadIdx.x + t * 256, O * I - 1)];
-    }
+    for (int t = 0; t < PER; ++t) wr[t] = W[min((int)threadIdx.x + t * 256, O * I - 1)];
     if ((int)threadIdx.x < O) su[threadIdx.x] = uv;
     if ((int)threadIdx.x < I) sv[threadIdx.x] = vv;
-    if (in_lds) {
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int e = threadIdx.x + t * 256;
+      if (e < O * I) { const int o = e / I, i = e - o * I; sW[o * ld + i] = wr[t]; }
+    }
+    __syncthreads();
+    // reps > 1: that many successive training-mode calls (each one power iteration from the previous call's u, v, as the module's
+    // forward does) in one launch — the matrix is staged once; call r writes its W / sigma, sigma and the u, v it used to set r.
+    for (int rp = 0; rp < reps; ++rp) {
+      float* __restrict__ Wbar = Wbar_r[rp * rstride]; float* __restrict__ sigma_out = sigma_r[rp * rstride];
+      float* __restrict__ u_used = uu_r[rp * rstride]; float* __restrict__ v_used = vu_r[rp * rstride];
+      float w;
+      if (power_iter) {
+        const float t = sn_matvec<true>(sW, ld, su, I, O, red);
+        const float nv = sqrtf(block_sum4((int)threadIdx.x < I ? t * t : 0.f, red));
+        if ((int)threadIdx.x < I) sv[threadIdx.x] = t / fmaxf(nv, eps);
+        __syncthreads();
+        w = sn_matvec<false>(sW, ld, sv, O, I, red);
+        const float nu = sqrtf(block_sum4((int)threadIdx.x < O ? w * w : 0.f, red));
+        if ((int)threadIdx.x < O) su[threadIdx.x] = w / fmaxf(nu, eps);
+        __syncthreads();
+        if ((int)threadIdx.x < O) u[threadIdx.x] = su[threadIdx.x];
+        if ((int)threadIdx.x < I) v[threadIdx.x] = sv[threadIdx.x];
+      } else {
+        w = sn_matvec<false>(sW, ld, sv, O, I, red);
+      }
+      if (u_used && (int)threadIdx.x < O) u_used[threadIdx.x] = su[threadIdx.x];
+      if (v_used && (int)threadIdx.x < I) v_used[threadIdx.x] = sv[threadIdx.x];
+      const float sigma = block_sum4((int)threadIdx.x < O ? w * su[threadIdx.x] : 0.f, red);     // u . (W v): W v is `w` (v unchanged since)
+      if (threadIdx.x == 0) sigma_out[0] = sigma;
+      const float inv = 1.f / sigma;
 #pragma unroll
       for (int t = 0; t < PER; ++t) {
         const int e = threadIdx.x + t * 256;
-        if (e < O * I) { const int o = e / I, i = e - o * I; sW[o * ld + i] = wr[t]; }
+        if (e < O * I) Wbar[e] = wr[t] * inv;
       }
     }
+    return;
   }
+  // matrices beyond the LDS image: the global-memory form, one thread per output
+  for (int i = threadIdx.x; i < O; i += 256) su[i] = u[i];
+  for (int i = threadIdx.x; i < I; i += 256) sv[i] = v[i];
   __syncthreads();
-  const float* M = in_lds ? sW : W;
-  const int lm = in_lds ? ld : I;
-  // reps > 1: that many successive training-mode calls (each one power iteration from the previous call's u, v, as the module's
-  // forward does) in one launch — the matrix is staged once; call r writes its W / sigma, sigma and the u, v it used to set r.
+  const float* M = W;
+  const int lm = I;
   for (int rp = 0; rp < reps; ++rp) {
   float* __restrict__ Wbar = Wbar_r[rp * rstride]; float* __restrict__ sigma_out = sigma_r[rp * rstride];
   float* __restrict__ u_used = uu_r[rp * rstride]; float* __restrict__ v_used = vu_r[rp * rstride];
@@ -736,10 +798,7 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   const float sigma = block_sum((int)threadIdx.x < O ? wv : 0.f, red);
   if (threadIdx.x == 0) sigma_out[0] = sigma;
   const float inv = 1.f / sigma;
-  for (int e = threadIdx.x; e < O * I; e += 256) {
-    const int o = e / I, i = e - o * I;
-    Wbar[e] = (in_lds ? sW[o * ld + i] : W[e]) * inv;
-  }
+  for (int e = threadIdx.x; e < O * I; e += 256) Wbar[e] = W[e] * inv;
   }
 }
 __global__ void __launch_bounds__(256) spectral_norm_fwd_kernel(const float* __restrict__ W, int O, int I, float* __restrict__ u,
