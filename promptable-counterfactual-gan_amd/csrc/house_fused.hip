@@ -391,115 +391,184 @@ __global__ void __launch_bounds__(NT) g_fwd_b4_kernel(const float* __restrict__ 
 }
 
 // ---- output heads ----------------------------------------------------------------------------------------------------------------
-// The continuous residual head and the categorical heads (logits, Gumbel-softmax samples) are dealt to the four waves by the host
-// (largest first onto the least loaded wave); every wave holds the 32-vector of its rows in registers and walks its heads.  All
-// head weights sit in LDS as stored ([column][32]: a wave works on one column at a time, so the reads are broadcasts); the block's
-// noise rows come in as one coalesced tile, logits and samples leave the same way (a lane-per-row access to a [B][70] tensor
-// touches 64 cache lines per instruction).
-struct HeadOwner { signed char owner[MAXHEADS + 1]; };   // [nheads] = the continuous head
-constexpr int MAXCOLS = MAXT + HH;          // packed categorical columns + continuous columns
+// The continuous residual head and the categorical heads as ONE product on the matrix cores — out[64 rows][T + ncont columns] =
+// h_5 W^T + b over the packed weight rows of all heads — followed by the per-(row, head) Gumbel-softmax.
+//   * the weight rows are staged as stored ([column][32]) with a pitch of 33 floats: B[k][n] = W[n][k] is a column walk, bank =
+//     n + k (conflict-free); h_5 comes in k-major ([k][row], pitch 65); logits and noise sit in [row][column] tiles of pitch 97;
+//   * waves 0-2 own one 32-column tile each (both 32-row tiles: two accumulators), 16 MFMA steps per tile;
+//   * the softmax of a (row, head) is shared by TWO lanes (the head's columns split in two, max and sum exchanged at distance 32),
+//     so a wave covers 32 rows of a head and the widest head (30 columns) costs 15 column visits per pass, not 30; the host deals
+//     the 2 x nheads (head, row-half) units to the four waves by cost.
+// The first version (a lane per row walking its heads, weights as LDS broadcasts) was bound by LDS bandwidth in the dot products
+// (9.7 us) and by the 30-wide head's serial softmax on one wave (7 us): 24 us per launch.
+struct HeadOwner { signed char owner[2 * MAXHEADS]; };   // [2 * head + row-half] -> wave
+constexpr int NCOLT = 3, MAXCOLS = NCOLT * 32;          // packed categorical + continuous columns <= 96 (host-checked)
 constexpr int TP = MAXT + 1;                // row pitch of the LDS tiles (odd: lane-per-row accesses are conflict-free)
+constexpr int WPH = HH + 1, HPK = FT + 1;   // pitches of the staged weight rows and of k-major h_5
+typedef float hd_acc_t __attribute__((ext_vector_type(16)));
 struct alignas(16) SmemHeads {
-  float W[MAXCOLS * HH];
+  float W[MAXCOLS * WPH];                   // head weight rows as stored; backward: the same (B[k = column][n = input])
   float b[MAXCOLS];
-  float lg[FT * TP];                        // logits; backward: d_logits in, dl out
+  float Hk[HH * HPK];                       // forward: h_5 k-major; backward: the four partial dh tiles reuse this and ct
+  float lg[FT * TP];                        // logits; backward: d_logits in, dl out (+ the continuous head's gradient in columns T ..)
   float ns[FT * TP];                        // noise -> (logit + noise) / tau -> soft sample; backward: soft
   float ds[FT * TP];                        // backward: d_samples
   float ct[FT * (HH + 1)];                  // continuous head
 };
-// flat-parameter offset of element (column c, input i) of the packed head matrix; -1 outside
-__device__ __forceinline__ int head_src(const GDesc& d, int c, int i, int T) {
-  if (c >= T) return c < T + d.ncont ? d.cont_w + (c - T) * HH + i : -1;
-  int src = -1;
+__device__ __forceinline__ int hd_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+// flat-parameter offsets of output column c (categorical columns 0 .. T-1, then the continuous head); -1 past the last column
+struct ColSrc { int w, b; };
+__device__ __forceinline__ ColSrc col_src(const GDesc& d, int c, int T) {
+  ColSrc r;
+  if (c >= T) { const bool ok = c < T + d.ncont; r.w = ok ? d.cont_w + (c - T) * HH : -1; r.b = ok ? d.cont_b + (c - T) : -1; return r; }
+  int w = d.head_w[0], b = d.head_b[0], c0 = 0;
 #pragma unroll
-  for (int hd = 0; hd < MAXHEADS; ++hd)
-    if (hd < d.nheads && c >= d.seg[hd] && c < d.seg[hd + 1]) src = d.head_w[hd] + (c - d.seg[hd]) * HH + i;
-  return src;
+  for (int k = 1; k < MAXHEADS; ++k)
+    if (k < d.nheads && c >= d.seg[k]) { w = d.head_w[k]; b = d.head_b[k]; c0 = d.seg[k]; }
+  r.w = w + (c - c0) * HH; r.b = b + (c - c0);
+  return r;
 }
-__device__ __forceinline__ int head_bias_src(const GDesc& d, int c, int T) {
-  if (c >= T) return c < T + d.ncont ? d.cont_b + (c - T) : -1;
-  int src = -1;
-#pragma unroll
-  for (int hd = 0; hd < MAXHEADS; ++hd)
-    if (hd < d.nheads && c >= d.seg[hd] && c < d.seg[hd + 1]) src = d.head_b[hd] + (c - d.seg[hd]);
-  return src;
-}
-constexpr int HW_PER = MAXCOLS * HH / NT;   // 16 weight elements per thread
+constexpr int HW_PER = MAXCOLS * HH / NT;   // 12 weight elements per thread
 constexpr int TILE_PER = (FT * MAXT + NT - 1) / NT;   // 24 tile elements per thread
-// coalesced [rows][T] global tile <-> LDS tile [FT][TP]
+// coalesced [rows][T] global tile <-> LDS tile [FT][TP]; element e = tid + 256 t sits at (e / T, e % T), walked incrementally (a
+// division by the runtime T per element was a sixth of the kernel)
+struct TileWalk { int rr, cc, dr, dc; };
+__device__ __forceinline__ TileWalk tile_walk(int T) {
+  TileWalk w; w.rr = (int)threadIdx.x / T; w.cc = (int)threadIdx.x - w.rr * T; w.dr = NT / T; w.dc = NT - w.dr * T; return w;
+}
+__device__ __forceinline__ void tile_step(TileWalk& w, int T) { w.rr += w.dr; w.cc += w.dc; if (w.cc >= T) { w.cc -= T; w.rr += 1; } }
 __device__ __forceinline__ void tile_load(float (&r)[TILE_PER], const float* __restrict__ g, size_t row0, int rows, int T) {
 #pragma unroll
-  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; r[t] = (g && e < rows * T) ? g[row0 * T + e] : 0.f; }
+  for (int t = 0; t < TILE_PER; ++t) r[t] = g ? g[row0 * T + min((int)threadIdx.x + t * NT, rows * T - 1)] : 0.f;
 }
 __device__ __forceinline__ void tile_park(float* L, const float (&r)[TILE_PER], int rows, int T) {
+  TileWalk w = tile_walk(T);
 #pragma unroll
-  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; if (e < rows * T) { const int rr = e / T; L[rr * TP + (e - rr * T)] = r[t]; } }
+  for (int t = 0; t < TILE_PER; ++t) { if (w.rr < rows) L[w.rr * TP + w.cc] = r[t]; tile_step(w, T); }
 }
 __device__ __forceinline__ void tile_out(float* __restrict__ g, const float* L, size_t row0, int rows, int T) {
+  TileWalk w = tile_walk(T);
 #pragma unroll
-  for (int t = 0; t < TILE_PER; ++t) { const int e = threadIdx.x + t * NT; if (e < rows * T) { const int rr = e / T; g[row0 * T + e] = L[rr * TP + (e - rr * T)]; } }
+  for (int t = 0; t < TILE_PER; ++t) { if (w.rr < rows) g[row0 * T + threadIdx.x + t * NT] = L[w.rr * TP + w.cc]; tile_step(w, T); }
+}
+// the packed weight rows (and biases) of all heads: global -> registers -> LDS [column][33]
+__device__ __forceinline__ void heads_wload(float (&wr)[HW_PER], float& br, const float* __restrict__ PRM, const GDesc& d, int T) {
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) {
+    const int e = threadIdx.x + t * NT;
+    const ColSrc cs = col_src(d, e >> 5, T);
+    const float v = PRM[max(cs.w, 0) + (e & 31)];
+    wr[t] = cs.w >= 0 ? v : 0.f;
+  }
+  br = 0.f;
+  if (threadIdx.x < MAXCOLS) { const ColSrc cs = col_src(d, threadIdx.x, T); const float v = PRM[max(cs.b, 0)]; br = cs.b >= 0 ? v : 0.f; }
+}
+__device__ __forceinline__ void heads_wstore(SmemHeads& s, const float (&wr)[HW_PER], float br) {
+#pragma unroll
+  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; s.W[(e >> 5) * WPH + (e & 31)] = wr[t]; }
+  if (threadIdx.x < MAXCOLS) s.b[threadIdx.x] = br;
 }
 
 __global__ void __launch_bounds__(NT) g_heads4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, HeadOwner ho) {
   extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
   SmemHeads& s = *reinterpret_cast<SmemHeads*>(heads_lds);
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row0 = (size_t)blockIdx.x * FT, row = row0 + lane;
-  const bool on = row < (size_t)a.B;
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const size_t row0 = (size_t)blockIdx.x * FT;
   const int rows = min(FT, a.B - (int)row0);
   const int T = d.seg[d.nheads];
-  // ---- the burst
-  float wr[HW_PER], br = 0.f, nr[TILE_PER], h[HH];
-#pragma unroll
-  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; const int src = head_src(d, e >> 5, e & 31, T); wr[t] = src >= 0 ? PRM[src] : 0.f; }
-  if (threadIdx.x < MAXCOLS) { const int src = head_bias_src(d, threadIdx.x, T); br = src >= 0 ? PRM[src] : 0.f; }
+  // ---- the burst: weight rows, biases, the noise tile, h_5 (element tid + 256 t of the block's [64][32] slice)
+  float wr[HW_PER], br, nr[TILE_PER], hv[FT * HH / NT];
+  PCG_T(8);
+  heads_wload(wr, br, PRM, d, T);
   tile_load(nr, a.noise, row0, rows, T);
-  load32(a.H + (size_t)NBLK * a.B * HH, row, on, h);
+  const float* h5 = a.H + (size_t)NBLK * a.B * HH + row0 * HH;
 #pragma unroll
-  for (int t = 0; t < HW_PER; ++t) s.W[threadIdx.x + t * NT] = wr[t];
-  if (threadIdx.x < MAXCOLS) s.b[threadIdx.x] = br;
+  for (int t = 0; t < FT * HH / NT; ++t) hv[t] = h5[min((int)threadIdx.x + t * NT, rows * HH - 1)];
+  PCG_T(9);
+  heads_wstore(s, wr, br);
   tile_park(s.ns, nr, rows, T);
-  __syncthreads();
-  if (ho.owner[d.nheads] == q) {                     // wave-uniform
-    for (int c = 0; c < d.ncont; ++c) {
-      float acc = s.b[T + c];
-      const float* w = s.W + (T + c) * HH;
 #pragma unroll
-      for (int i = 0; i < HH; ++i) acc = fmaf(w[i], h[i], acc);
-      s.ct[lane * (HH + 1) + c] = acc * a.res_scale;
-    }
-  }
+  for (int t = 0; t < FT * HH / NT; ++t) { const int e = threadIdx.x + t * NT; s.Hk[(e & 31) * HPK + (e >> 5)] = hv[t]; }
+  __syncthreads();
+  PCG_T(10);
+  // ---- out = h_5 W^T + b: waves 0-2 own a 32-column tile each, both row tiles
   const float inv_tau = 1.f / a.tau;
-  for (int hd = 0; hd < d.nheads; ++hd) {
-    if (ho.owner[hd] != q) continue;               // wave-uniform
-    const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-    float* lg = s.lg + lane * TP; float* ns = s.ns + lane * TP;
-    float mx = -INFINITY;
-    for (int c = c0; c < c1; ++c) {
-      float acc = s.b[c];
-      const float* w = s.W + c * HH;
+  if (q < NCOLT) {
+    hd_acc_t acc[2];
+    const int n0 = q * 32;
+    const float bv = s.b[n0 + li];
 #pragma unroll
-      for (int i = 0; i < HH; ++i) acc = fmaf(w[i], h[i], acc);
-      lg[c] = acc;
-      const float t = (acc + ns[c]) * inv_tau;
-      ns[c] = t;
-      mx = fmaxf(mx, t);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = bv;
+#pragma unroll 4
+    for (int st = 0; st < HH / 2; ++st) {
+      const int k = 2 * st + lh;
+      const float bw = s.W[(n0 + li) * WPH + k];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Hk[k * HPK + li], bw, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Hk[k * HPK + 32 + li], bw, acc[1], 0, 0, 0);
     }
-    float se = 0.f;
-    for (int c = c0; c < c1; ++c) se += expf(ns[c] - mx);
-    const float inv = 1.f / se;
-    float best = -1.f; int arg = c0;
-    for (int c = c0; c < c1; ++c) {
-      const float p = expf(ns[c] - mx) * inv;
-      ns[c] = p;
-      if (p > best) { best = p; arg = c; }
-    }
-    if (a.hard && on) for (int c = c0; c < c1; ++c) a.hard[row * T + c] = c == arg ? 1.f : 0.f;
+    const int col = n0 + li, colc = min(col, T - 1);
+    float nz[2][16];                                   // the noise under this lane's 32 outputs: all reads first, then the writes
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nz[rt][r] = s.ns[(rt * 32 + hd_row(r, lh)) * TP + colc];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = rt * 32 + hd_row(r, lh);
+        const float v = acc[rt][r];
+        if (col < T) { s.lg[m * TP + col] = v; s.ns[m * TP + col] = (v + nz[rt][r]) * inv_tau; }
+        else if (col < T + d.ncont) s.ct[m * (HH + 1) + (col - T)] = v * a.res_scale;
+      }
   }
   __syncthreads();
+  PCG_T(11);
+  // ---- Gumbel-softmax per (row, head): two lanes per pair, (head, 32-row half) units dealt to the waves
+  for (int un = 0; un < 2 * d.nheads; ++un) {
+    if (ho.owner[un] != q) continue;               // wave-uniform
+    const int hd = un >> 1, m = (un & 1) * 32 + li;
+    const int c0 = d.seg[hd], c1 = d.seg[hd + 1], cm = c0 + (c1 - c0 + 1) / 2;
+    const int cb = lh ? cm : c0, ce = lh ? c1 : cm;
+    float* ns = s.ns + m * TP;
+    // this lane's columns (at most 16) come into registers once, four independent LDS reads at a time
+    constexpr int MAXHALF = 16;
+    float tv[MAXHALF];
+#pragma unroll
+    for (int j = 0; j < MAXHALF; ++j) tv[j] = cb + j < ce ? ns[cb + j] : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXHALF; ++j) mx = fmaxf(mx, tv[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXHALF; ++j) { tv[j] = cb + j < ce ? expf(tv[j] - mx) : 0.f; se += tv[j]; }
+    se += __shfl_xor(se, 32);
+    const float inv = 1.f / se;
+    float best = -1.f; int arg = cb;
+#pragma unroll
+    for (int j = 0; j < MAXHALF; ++j) {
+      if (cb + j < ce) {
+        const float p = tv[j] * inv;
+        ns[cb + j] = p;
+        if (p > best) { best = p; arg = cb + j; }
+      }
+    }
+    if (a.hard) {                                    // kernel-uniform; first maximum, as y_soft.max(dim)[1]
+      const float ob = __shfl_xor(best, 32); const int oa = __shfl_xor(arg, 32);
+      if (ob > best || (ob == best && oa < arg)) arg = oa;
+      if (m < rows) for (int c = cb; c < ce; ++c) a.hard[(row0 + m) * T + c] = c == arg ? 1.f : 0.f;
+    }
+  }
+  PCG_T(12);
+  __syncthreads();
+  PCG_T(13);
   tile_out(a.logits, s.lg, row0, rows, T);
   tile_out(a.soft, s.ns, row0, rows, T);
   for (int e = threadIdx.x; e < rows * d.ncont; e += NT) { const int rr = e / d.ncont; a.cont[row0 * d.ncont + e] = s.ct[rr * (HH + 1) + (e - rr * d.ncont)]; }
+  PCG_T(14);
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------------------
@@ -576,35 +645,37 @@ __device__ __forceinline__ void bwd_part_a4(Smem4& s, const GBwd& a, int k, bool
   wave_colsums2(v, w, lane, q, a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
-// first backward kernel: gradients of the heads (dealt to the waves like the forward) -> dh entering the last block; part a
+// first backward kernel: the Gumbel-softmax backward of every (row, head) — two lanes per pair, units dealt like the forward —, then
+// dh = G W on the matrix cores (G: the rows' gradients at all T + ncont output columns, W: the packed weight rows as stored: the
+// gradient entering the last block), then part a of that block
 __global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, HeadOwner ho) {
   extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
   SmemHeads& hs = *reinterpret_cast<SmemHeads*>(heads_lds);
   Smem4& s = *reinterpret_cast<Smem4*>(heads_lds + sizeof(SmemHeads));
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const size_t row0 = (size_t)blockIdx.x * FT, row = row0 + lane;
   const bool on = row < (size_t)a.B;
   const int rows = min(FT, a.B - (int)row0);
-  const int T = d.seg[d.nheads];
+  const int T = d.seg[d.nheads], ncols = T + d.ncont;
   constexpr int k = NBLK - 1;
-  // ---- the burst: head weights, the three [rows][T] tiles, d_cont; for part a: FiLM gamma of the last block, cond, z2, saved statistics
-  float wr[HW_PER], t_dl[TILE_PER], t_ds[TILE_PER], t_y[TILE_PER], z[HQ], smr = 0.f;
+  // ---- the burst: head weight rows, the three [rows][T] tiles, d_cont; for part a: FiLM gamma of the last block, cond, z2, saved statistics
+  float wr[HW_PER], br, t_dl[TILE_PER], t_ds[TILE_PER], t_y[TILE_PER], z[HQ], smr = 0.f;
   WRegs<MAXCOND> w_g; CondRegs cr;
-#pragma unroll
-  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; const int src = head_src(d, e >> 5, e & 31, T); wr[t] = src >= 0 ? PRM[src] : 0.f; }
+  heads_wload(wr, br, PRM, d, T);
   tile_load(t_dl, a.d_logits, row0, rows, T);
   tile_load(t_ds, a.d_samples, row0, rows, T);
   tile_load(t_y, a.soft, row0, rows, T);
   float dcr[(FT * HH + NT - 1) / NT];
 #pragma unroll
-  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) { const int e = threadIdx.x + t * NT; dcr[t] = (a.d_cont && e < rows * d.ncont) ? a.d_cont[row0 * d.ncont + e] : 0.f; }
+  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) dcr[t] = a.d_cont ? a.d_cont[row0 * d.ncont + min((int)threadIdx.x + t * NT, max(rows * d.ncont - 1, 0))] : 0.f;
   wload<MAXCOND>(w_g, PRM + d.fg_w[k], PRM + d.fg_b[k]);
   cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
   load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
   if (threadIdx.x < 2 * HH) smr = a.SM[(size_t)(2 * k + 1) * 2 * HH + threadIdx.x];
-  // ---- into LDS
-#pragma unroll
-  for (int t = 0; t < HW_PER; ++t) hs.W[threadIdx.x + t * NT] = wr[t];
+  // ---- into LDS.  G (in hs.lg) must be finite and zero outside the live rows / columns: it is an MFMA operand
+  heads_wstore(hs, wr, br);
+  for (int e = threadIdx.x; e < FT * TP; e += NT) hs.lg[e] = 0.f;
+  __syncthreads();
   tile_park(hs.lg, t_dl, rows, T);
   tile_park(hs.ds, t_ds, rows, T);
   tile_park(hs.ns, t_y, rows, T);
@@ -614,7 +685,7 @@ __global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restric
     if (e < rows * d.ncont) {
       const int rr = e / d.ncont;
       const float dc = dcr[t] * a.res_scale;           // 0 without a cotangent
-      hs.ct[rr * (HH + 1) + (e - rr * d.ncont)] = dc;
+      hs.lg[rr * TP + T + (e - rr * d.ncont)] = dc;    // the continuous head's columns of G
       a.DC[row0 * d.ncont + e] = dc;
     }
   }
@@ -622,53 +693,72 @@ __global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restric
   cstore(s.V, cr, lane, q);
   if (threadIdx.x < 2 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
   __syncthreads();
-  float dh[HH];
-#pragma unroll
-  for (int i = 0; i < HH; ++i) dh[i] = 0.f;
-  if (on) {
-    if (ho.owner[d.nheads] == q) {
-      for (int c = 0; c < d.ncont; ++c) {
-        const float dc = hs.ct[lane * (HH + 1) + c];       // d_cont * res_scale (0 without a cotangent)
-        const float* w = hs.W + (T + c) * HH;
-#pragma unroll
-        for (int i = 0; i < HH; ++i) dh[i] = fmaf(w[i], dc, dh[i]);
-      }
-    }
+  // ---- dl of every (row, head), left in G
+  {
     const float inv_tau = 1.f / a.tau;
-    float* dlr = hs.lg + lane * TP; const float* dsr = hs.ds + lane * TP; const float* yr = hs.ns + lane * TP;
-    for (int hd = 0; hd < d.nheads; ++hd) {
-      if (ho.owner[hd] != q) continue;             // wave-uniform
-      const int c0 = d.seg[hd], c1 = d.seg[hd + 1];
-      float dot = 0.f;
-      if (a.d_samples)
-        for (int c = c0; c < c1; ++c) dot = fmaf(dsr[c], yr[c], dot);
-      for (int c = c0; c < c1; ++c) {
-        float dl = a.d_logits ? dlr[c] : 0.f;
-        if (a.d_samples) { const float y = yr[c]; dl += y * (dsr[c] - dot) * inv_tau; }
-        dlr[c] = dl;
-        const float* w = hs.W + c * HH;
+    for (int un = 0; un < 2 * d.nheads; ++un) {
+      if (ho.owner[un] != q) continue;             // wave-uniform
+      const int hd = un >> 1, m = (un & 1) * 32 + li;
+      if (m >= rows) continue;                     // (both lanes of a pair: the exchange below stays paired)
+      const int c0 = d.seg[hd], c1 = d.seg[hd + 1], cm = c0 + (c1 - c0 + 1) / 2;
+      const int cb = lh ? cm : c0, ce = lh ? c1 : cm;
+      float* dlr = hs.lg + m * TP; const float* dsr = hs.ds + m * TP; const float* yr = hs.ns + m * TP;
+      constexpr int MAXHALF = 16;                      // this lane's columns in registers: independent LDS reads, then the arithmetic
+      float dsv[MAXHALF], yv[MAXHALF], dlv[MAXHALF];
 #pragma unroll
-        for (int i = 0; i < HH; ++i) dh[i] = fmaf(w[i], dl, dh[i]);
+      for (int j = 0; j < MAXHALF; ++j) {
+        const bool in = cb + j < ce;
+        dsv[j] = in ? dsr[cb + j] : 0.f; yv[j] = in ? yr[cb + j] : 0.f; dlv[j] = in ? dlr[cb + j] : 0.f;
+      }
+      float dot = 0.f;
+      if (a.d_samples) {
+#pragma unroll
+        for (int j = 0; j < MAXHALF; ++j) dot = fmaf(dsv[j], yv[j], dot);
+        dot += __shfl_xor(dot, 32);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXHALF; ++j) {
+        if (cb + j < ce) {
+          float dl = a.d_logits ? dlv[j] : 0.f;
+          if (a.d_samples) dl += yv[j] * (dsv[j] - dot) * inv_tau;
+          dlr[cb + j] = dl;
+        }
       }
     }
   }
-  // per-wave partial dh -> this wave's 8 channels: through the (now free) d_samples tile, [q][i][lane]
   __syncthreads();
-  static_assert(offsetof(SmemHeads, ct) == offsetof(SmemHeads, ds) + sizeof(float) * FT * TP && FT * TP + FT * (HH + 1) >= NQ * HH * FT,
-                "the per-wave partials reuse the d_samples tile and the continuous-head tile behind it");
-  float* part = hs.ds;                               // NQ * HH * FT floats: spills into hs.ct behind it — both free now
+  // ---- dh[64 rows][32] = G[64][96] W[96][32]: wave (row tile, half of the 48 reduction steps); the halves added below in order
+  static_assert(FT * TP >= 4 * 32 * WPH, "four partial tiles fit the d_samples tile");
+  float* part = hs.ds;                               // four 32 x 33 partial tiles: the d_samples tile is free now
+  {
+    const int rt = q & 1, kh = q >> 1;
+    hd_acc_t acc;
 #pragma unroll
-  for (int i = 0; i < HH; ++i) part[(q * HH + i) * FT + lane] = dh[i];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int st = 0; st < MAXCOLS / 4; ++st) {
+      const int c = kh * (MAXCOLS / 2) + 2 * st + lh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hs.lg[(rt * 32 + li) * TP + c], hs.W[c * WPH + li], acc, 0, 0, 0);
+    }
+    __syncthreads();                                 // every wave is done reading G before d_samples' space is reused
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[q * (32 * WPH) + li * WPH + hd_row(r, lh)] = acc[r];      // [wave][channel][row in tile]
+  }
   __syncthreads();
   float d8[HQ];
+  {
+    const int rt = lane >> 5, m = lane & 31;         // this thread's row (lane = row) lives in row tile rt
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    d8[j] = (part[(0 * HH + c) * FT + lane] + part[(1 * HH + c) * FT + lane]) + (part[(2 * HH + c) * FT + lane] + part[(3 * HH + c) * FT + lane]);
+    for (int j = 0; j < HQ; ++j) {
+      const int c = q * HQ + j;
+      d8[j] = part[rt * (32 * WPH) + c * WPH + m] + part[(2 + rt) * (32 * WPH) + c * WPH + m];
+    }
   }
   store8(a.DH + (size_t)k * a.B * HH, row, q, on, d8);
+  // DL = the first T columns of G
   tile_out(a.DL, hs.lg, row0, rows, T);
   bwd_part_a4(s, a, k, on, lane, q, d8, z, 1, 0);
+  (void)ncols;
 }
 
 // kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
@@ -815,21 +905,27 @@ static int set_heads_lds(const void* fn, size_t bytes) {
   return PCG_OK;
 }
 
-// output heads (and the continuous head, index nheads) dealt to the four waves: largest first onto the least loaded wave
+static bool heads_at_most_32_wide(const GDesc& d) {      // a lane keeps its half of a head's columns (<= 16) in registers
+  for (int h = 0; h < d.nheads; ++h)
+    if (d.seg[h + 1] - d.seg[h] > 32) return false;
+  return true;
+}
+// the (head, 32-row half) units of the Gumbel-softmax dealt to the four waves: cost = columns per lane (two lanes share a pair),
+// largest first onto the least loaded wave
 static HeadOwner deal_heads(const GDesc& d) {
   HeadOwner ho{};
-  int size[MAXHEADS + 1], load[NQ] = {0, 0, 0, 0};
-  bool done[MAXHEADS + 1] = {};
-  for (int h = 0; h < d.nheads; ++h) size[h] = d.seg[h + 1] - d.seg[h];
-  size[d.nheads] = d.ncont;
-  for (int it = 0; it <= d.nheads; ++it) {
+  int cost[2 * MAXHEADS], load[NQ] = {0, 0, 0, 0};
+  bool done[2 * MAXHEADS] = {};
+  const int nu = 2 * d.nheads;
+  for (int u = 0; u < nu; ++u) cost[u] = (d.seg[u / 2 + 1] - d.seg[u / 2] + 1) / 2;
+  for (int it = 0; it < nu; ++it) {
     int best = -1;
-    for (int j = 0; j <= d.nheads; ++j)
-      if (!done[j] && (best < 0 || size[j] > size[best])) best = j;
+    for (int j = 0; j < nu; ++j)
+      if (!done[j] && (best < 0 || cost[j] > cost[best])) best = j;
     int w = 0;
     for (int j = 1; j < NQ; ++j)
       if (load[j] < load[w]) w = j;
-    done[best] = true; ho.owner[best] = (signed char)w; load[w] += size[best];
+    done[best] = true; ho.owner[best] = (signed char)w; load[w] += cost[best];
   }
   return ho;
 }
@@ -842,8 +938,8 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
   std::memcpy(&d, desc, sizeof(d));
   PCG_REQUIRE(desc->hidden == 32 && desc->nblocks == 5, "pcg_house_g_fwd: built for hidden width 32 and 5 residual blocks");
   PCG_REQUIRE(d.D == DIN && d.NC == NCLS && d.nheads >= 0 && d.nheads <= MAXHEADS && d.ncont >= 0 &&
-                  d.ncont <= HH && d.seg[d.nheads] <= MAXT,
-              "pcg_house_g_fwd: built for input_dim 17, 4 classes, <= 8 heads / 96 packed categories");
+                  d.ncont <= HH && d.seg[d.nheads] <= MAXT && d.seg[d.nheads] + d.ncont <= MAXCOLS && heads_at_most_32_wide(d),
+              "pcg_house_g_fwd: built for input_dim 17, 4 classes, <= 8 heads, <= 96 packed categorical + continuous output columns");
   PCG_REQUIRE(args->B > 0 && args->params && args->x && args->onehot && args->mask && args->noise && args->inp && args->H && args->Z1 &&
                   args->Z2 && args->P && args->SM && args->cont && args->logits && args->soft,
               "pcg_house_g_fwd: null buffer");

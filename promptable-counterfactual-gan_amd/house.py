@@ -115,6 +115,7 @@ class ResidualGenerator(FlatModule):
         bn = self.blocks[0].bn1 if len(self.blocks) else None
         return (self.use_fused and self.hidden_dim == 32 and len(self.blocks) == 5 and self.training and bn is not None
                 and self.input_dim == 17 and self.num_classes == 4 and self.total_cat <= 96 and len(self.cat_idx) <= 8
+                and self.total_cat + len(self.continuous_idx) <= 96 and all(b_ - a_ <= 32 for a_, b_ in zip(self.seg, self.seg[1:]))
                 and len(self.continuous_idx) <= 32 and all(b_.bn1.momentum == bn.momentum and b_.bn2.eps == bn.eps for b_ in self.blocks))
 
     def _fused_desc(self):

@@ -49,7 +49,7 @@ int main() {
     for (int i = 1; i < 8; ++i) printf("  %s %.2f", names[i], (h[b * 16 + i] - h[b * 16 + i - 1]) * 0.01);
     printf("\n");
   }
-  const char* hn[7] = {"entry", "burst issued", "parked + barrier", "cont head", "categorical heads (wave 0)", "barrier", "tiles out"};
+  const char* hn[7] = {"entry", "burst issued", "parked + barrier", "matrix product (wave 0)", "softmax (wave 0)", "barrier", "tiles out"};
   t0 = ~0ull; t1 = 0;
   for (int b = 0; b < 64; ++b) { if (h[b * 16 + 8] < t0) t0 = h[b * 16 + 8]; if (h[b * 16 + 14] > t1) t1 = h[b * 16 + 14]; }
   printf("g_heads4: first block entry -> last block exit: %.2f us\n", (t1 - t0) * 0.01);
