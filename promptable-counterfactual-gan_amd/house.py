@@ -929,19 +929,19 @@ def _mean_cotangents(B, device):
 
 def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
                        skip_dead_d_wgrad):
-    """train_step scheduled for the length of its dependency chain (the step is ~90 kernels of 64 blocks each on a 256-CU chip):
-    what the reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager), with
+    """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 44 launches here): what the
+    reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager vs the reference-order autograd step), with
 
+      * no autograd graph: every backward is called directly, in the order autograd would run it;
+      * residual assembly, mask, x_cf and both L1 penalties (:266-287, :305) in one launch, and the whole way back from
+        dLoss/dx_cf (critic: -1/B through D; classifier: from the branch) to the generator's outputs in one (:314-315);
       * the frozen classifier's whole term (:301-302) — forward, cross-entropy value AND gradient in one launch (grad_scale =
-        lambda_cls, exactly the product autograd forms), grad-input sweep — on the `branch` stream beside the critic update;
-      * the two L1 penalties (:287, :305) forward on the branch, so autograd runs their backward there too; the gradient zero-fills
-        and every logged scalar (D_loss, G_loss, g_adv, g_reg) on the branch as well;
-      * the critic passes run directly (no autograd nodes): the cotangents of the Wasserstein means are the constants +-1/B
-        (_mean_cotangents), so each critic backward starts right behind its forward; the real and the fake pass accumulate into
-        the zeroed gradient buffers (a + b == b + a);
-      * the G step's two gradient contributions to x_cf (critic: -1/B through D; classifier: from the branch) are added once and
-        handed to autograd as the gradient of x_cf, next to the scalar lambda_reg*d*am + lambda_mask*pen.
-    Captured in a HIP graph the two streams are parallel branches."""
+        lambda_cls, exactly the product autograd forms), grad-input sweep — on the `branch` stream beside the critic update,
+        the logged scalars (D_loss, G_loss, g_adv, g_reg) there too;
+      * the critic step's two passes as one (Discriminator._run_pair): the cotangents of the Wasserstein means are the constants
+        +-1/B (_mean_cotangents), the fake pass is the first writer of the gradient buffer, the real pass adds;
+      * no gradient zero-fills: every parameter of both nets receives a gradient, the first writer overwrites (0 + g == g).
+    Captured in a HIP graph the two streams are parallel branches; branch="inline": the same kernels on one stream."""
     nc, dev, B = config["num_classes"], x.device, x.shape[0]
     if classifier.training or any(p.requires_grad for p in classifier.parameters()):
         raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
@@ -1114,17 +1114,20 @@ def compute_metrics_per_target(generator, classifier, X, y, config, gumbel_per_c
 
 
 class GraphedTrainStep:
-    """The whole training step — G forward, critic step, G step, both Adam updates, ~400 small kernels — captured once in a
-    HIP graph and replayed with one host call: this path is launch-latency bound, and the graph
-    removes the per-kernel host cost.  Inputs live in static device buffers (`x, y, target_y, mask, noise`): write the next
+    """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 44 as scheduled by
+    train_step(branch=...) — captured once in a HIP graph and replayed with one host call: this path is latency bound (SURVEY.md
+    section 8a row a15), and the graph removes the per-kernel host cost.  overlap=True (default): the frozen classifier's term on a
+    parallel branch; "inline": the same schedule on one stream (a multi-branch graph is launched node by node by the host, a
+    single-stream one is not: 0.28 vs 0.03 ms of host time per replay, wall 0.437 vs 0.451 ms at batch 4096); "critic": a third
+    stream for the critic's real pass (no gain); False: the reference-order autograd step.  All bit-identical.  Inputs live in static device buffers (`x, y, target_y, mask, noise`): write the next
     batch into them (`load(...)`, or draw straight into them) and call `replay()`; outputs are the static tensors in `out`.
     Capture needs warm-up executions of real steps; the parameters, buffers and optimizer state are snapshotted before and
     restored after, so constructing this object does not advance training."""
 
     def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap=True):
         dev = norm_vals.device
-        # train_step's parallel branch: the classifier term (+ penalties, zero-fills, logged sums); overlap="critic" adds a third
-        # stream for the critic's real pass (bit-identical, no gain measured: see _train_step_branch)
+        # train_step's parallel branch: the classifier term and the logged sums; overlap="critic" adds a third stream for the
+        # critic's real pass (bit-identical, no gain measured: see _train_step_branch)
         if overlap == "critic":
             self.branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         elif overlap == "inline":
