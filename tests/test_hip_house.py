@@ -500,6 +500,31 @@ def test_graphed_step_equals_eager(pcg, hgold, overlap):
         assert torch.equal(states[0][0][k], states[1][0][k]), k
 
 
+def test_scheduled_step_equals_reference_order_without_the_fused_kernels(pcg, hgold):
+    """train_step(branch=...) — no autograd graph, fused residual block, manual critic passes — must also hold when the nets fall
+    back to their per-op paths (configurations the fused kernels are not built for): same state as the reference-order autograd
+    step, bit for bit."""
+    H = pcg.house
+    states = []
+    for sched in (False, True):
+        G, D, C = _load_golden_nets(pcg, hgold)
+        G.use_fused = D.use_fused = C.use_fused = False
+        opt_g, opt_d = H.make_optimizers(G, D)
+        norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
+        losses = []
+        for seed in (4, 5):
+            x, y, t, m, gumbel = HR.synthetic_batch(96, seed=seed)
+            noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
+            out = H.train_step(G, D, C, opt_g, opt_d, _dev(x), _dev(y), _dev(t), _dev(m), norm, gumbel=noise,
+                               branch=torch.cuda.Stream() if sched else None)
+            torch.cuda.synchronize()
+            losses.append((out["D_loss"].item(), out["G_loss"].item(), out["g_cls"].item(), out["reg"].item()))
+        states.append(({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}}, losses))
+    assert states[0][1] == states[1][1], (states[0][1], states[1][1])
+    for k in states[0][0]:
+        assert torch.equal(states[0][0][k], states[1][0][k]), k
+
+
 def test_trained_checkpoints_eval_forward(pcg, golden_dir):
     """The checkpoints the reference ships, eval mode, hard Gumbel-softmax (eval_utils.py:76-77), reference-module outputs."""
     H = pcg.house
