@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) assemble_bwd_kernel(const float* __restri
 struct ResCols { int src[32]; };
 template <bool SMALL>       // SMALL: one block of 1024 threads (n <= 16 K, as pcg_abs_mean_fwd); else 256 blocks of 256 + last-block finish
 __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
-    const float* __restrict__ cont, int ncont, const float* __restrict__ samples, const int* __restrict__ seg, int T, const float* __restrict__ norm,
+    const float* __restrict__ cont, int ncont, const float* __restrict__ samples, const int* __restrict__ seg, int nseg, int T, const float* __restrict__ norm,
     const float* __restrict__ x, const float* __restrict__ mask, ResCols cols, int D, size_t n, double inv_n, float* __restrict__ res,
     float* __restrict__ masked, float* __restrict__ x_cf, float* __restrict__ partial, int* __restrict__ ticket, float* __restrict__ pen_out,
     float* __restrict__ am_out) {
@@ -495,6 +495,9 @@ __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
   __shared__ double redd[2][NTH];
   __shared__ float redf[2][SMALL ? 1 : 256];
   __shared__ int s_last;
+  __shared__ int s_seg[34];                                // head boundaries: read once, not per element (a dependent load in front of the dot)
+  if (threadIdx.x <= (unsigned)nseg) s_seg[threadIdx.x] = seg[threadIdx.x];
+  __syncthreads();
   float acc_pen = 0.f, acc_am = 0.f;
   for (size_t i = (size_t)blockIdx.x * NTH + threadIdx.x; i < n; i += (size_t)gridDim.x * NTH) {
     const size_t b = i / (size_t)D;
@@ -505,8 +508,18 @@ __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
     } else {
       const int sg = -src - 1;
       float acc = 0.f;
-      for (int c = seg[sg]; c < seg[sg + 1]; ++c) acc = fmaf(samples[b * T + c], norm[c], acc);
-      r = acc - x[i];
+      int c = s_seg[sg];
+      const int ce = s_seg[sg + 1];
+      const float xv = x[i];
+      for (; c + 8 <= ce; c += 8) {                      // eight (sample, value) pairs requested together, added in column order
+        float sv[8], nv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sv[j] = samples[b * T + c + j]; nv[j] = norm[c + j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(sv[j], nv[j], acc);
+      }
+      for (; c < ce; ++c) acc = fmaf(samples[b * T + c], norm[c], acc);
+      r = acc - xv;
     }
     const float mk = mask[i];
     const float msk = r * mk;                          // (1.0 * r) * mask
@@ -1248,14 +1261,16 @@ extern "C" int pcg_house_residual_fwd(const float* cont, int32_t ncont, const fl
   PCG_REQUIRE(cont && samples && seg_dev && norm && x && mask && col_src && res && masked && x_cf && partial512 && ticket && pen_out && am_out &&
                   B > 0 && D > 0 && D <= 32 && T > 0 && ncont >= 0, "pcg_house_residual_fwd: bad arguments (at most 32 feature columns)");
   ResCols cols{};
-  for (int c = 0; c < D; ++c) cols.src[c] = col_src[c];
+  int nseg = 0;                                            // number of categorical heads = the largest -(src) among the columns
+  for (int c = 0; c < D; ++c) { cols.src[c] = col_src[c]; if (col_src[c] < 0 && -col_src[c] > nseg) nseg = -col_src[c]; }
+  PCG_REQUIRE(nseg <= 32, "pcg_house_residual_fwd: at most 32 categorical heads");
   const size_t n = (size_t)B * D;
   hipStream_t s = (hipStream_t)stream;
   if (n <= 16 * 1024) {
-    hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, cont, ncont, samples, seg_dev, T, norm, x, mask, cols, D, n,
+    hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, cont, ncont, samples, seg_dev, nseg, T, norm, x, mask, cols, D, n,
                        1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
   } else {
-    hipLaunchKernelGGL(house_residual_fwd_kernel<false>, dim3(256), dim3(256), 0, s, cont, ncont, samples, seg_dev, T, norm, x, mask, cols, D, n,
+    hipLaunchKernelGGL(house_residual_fwd_kernel<false>, dim3(256), dim3(256), 0, s, cont, ncont, samples, seg_dev, nseg, T, norm, x, mask, cols, D, n,
                        1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
   }
   return launch_status("house_residual_fwd_kernel");
