@@ -606,10 +606,11 @@ int pcg_house_residual_bwd(const float* res, const float* masked, const float* m
                            pcg_stream_t stream);
 /* The three per-iteration draws of the tabular trainer in one launch — target class != y (trainer.py:248-249, as pcg_randint with
  * exclude), feature mask (:253-255, as pcg_feature_mask), Gumbel noise [B][T] (generator.py:90, as pcg_rand_gumbel) — each from its
- * own counter offset: the values the three separate calls produce. */
+ * own counter offset: the values the three separate calls produce.  onehot_target / onehot_y (nullable, [B][num_classes]): the float
+ * one-hot rows of the drawn targets and of y (trainer.py:250, :290), written by the same launch. */
 int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
                     const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
-                    uint64_t seed, pcg_stream_t stream);
+                    uint64_t seed, float* onehot_target, float* onehot_y, pcg_stream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per

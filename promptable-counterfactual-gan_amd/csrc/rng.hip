@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(256) patch_mask_kernel(float* __restrict__ out
 // (the bodies are device functions over the counter index i — four values each — so that a fused launch draws exactly what the
 // separate launches draw)
 __device__ __forceinline__ void randint_quad(int64_t i, int64_t* __restrict__ out, int64_t n, int32_t lo, int32_t hi,
-                                             const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset) {
+                                             const int64_t* __restrict__ exclude, uint64_t seed, uint64_t offset,
+                                             float* __restrict__ onehot = nullptr) {
   const uint32_t span = (uint32_t)(hi - lo);
   {
     const U4 r = draw(seed, offset, (uint64_t)i);
@@ -88,7 +89,9 @@ __device__ __forceinline__ void randint_quad(int64_t i, int64_t* __restrict__ ou
                       // exclude[j] maps to the next class (cyclically) — P(exclude+1) = 2/span, 1/span for the others, never exclude
         const uint32_t k = (uint32_t)(((uint64_t)v[e] * (uint64_t)span) >> 32);
         const int64_t ex = exclude[j] - lo;
-        out[j] = lo + (int64_t)((int64_t)k == ex ? (k + 1u) % span : k);
+        const uint32_t kk = (int64_t)k == ex ? (k + 1u) % span : k;
+        out[j] = lo + (int64_t)kk;
+        if (onehot) for (uint32_t q = 0; q < span; ++q) onehot[j * span + q] = q == kk ? 1.f : 0.f;      // F.one_hot(target).float() (trainer.py:250)
       } else {
         out[j] = lo + (int64_t)(((uint64_t)v[e] * (uint64_t)span) >> 32);
       }
@@ -161,13 +164,21 @@ __global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ o
 // the three per-iteration draws of the tabular trainer (trainer.py:248-255, generator.py:90) in one launch
 __global__ void __launch_bounds__(256) house_draws_kernel(int64_t* __restrict__ target, int B, int32_t lo, int32_t hi, const int64_t* __restrict__ y,
                                                           uint64_t off_t, float* __restrict__ mask, int D, const int* __restrict__ zero_cols, int nz,
-                                                          uint64_t off_m, float* __restrict__ noise, int64_t n_noise, uint64_t off_n, uint64_t seed) {
+                                                          uint64_t off_m, float* __restrict__ noise, int64_t n_noise, uint64_t off_n, uint64_t seed,
+                                                          float* __restrict__ onehot_t, float* __restrict__ onehot_y) {
   const int64_t nm = (int64_t)B * D;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n_noise + 3) / 4; i += (int64_t)gridDim.x * 256) gumbel_quad(i, noise, n_noise, seed, off_n);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (nm + 3) / 4; i += (int64_t)gridDim.x * 256)
     feature_mask_quad(i, mask, nm, D, zero_cols, nz, seed, off_m);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ((int64_t)B + 3) / 4; i += (int64_t)gridDim.x * 256)
-    randint_quad(i, target, B, lo, hi, y, seed, off_t);
+    randint_quad(i, target, B, lo, hi, y, seed, off_t, onehot_t);
+  if (onehot_y) {                                            // F.one_hot(y).float() (trainer.py:290) rides along: y is an input
+    const int nc = hi - lo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * nc; i += (int64_t)gridDim.x * 256) {
+      const int64_t b = i / nc; const int q = (int)(i - b * nc);
+      onehot_y[i] = y[b] - lo == q ? 1.f : 0.f;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
@@ -246,12 +257,12 @@ extern "C" int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t*
 
 extern "C" int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
                                const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
-                               uint64_t seed, pcg_stream_t stream) {
+                               uint64_t seed, float* onehot_target, float* onehot_y, pcg_stream_t stream) {
   PCG_REQUIRE(target_y && y && mask && noise && B > 0 && num_classes > 1 && D > 0 && T > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0),
               "pcg_house_draws: bad arguments");
   const int64_t quads = std::max(((int64_t)B * T + 3) / 4, ((int64_t)B * D + 3) / 4);
   hipLaunchKernelGGL(house_draws_kernel, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, target_y, B, 0, num_classes, y, offset_target, mask, D,
-                     zero_cols, n_zero_cols, offset_mask, noise, (int64_t)B * T, offset_noise, seed);
+                     zero_cols, n_zero_cols, offset_mask, noise, (int64_t)B * T, offset_noise, seed, onehot_target, onehot_y);
   return launch_status("house_draws_kernel");
 }
 

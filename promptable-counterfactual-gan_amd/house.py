@@ -841,7 +841,7 @@ def make_optimizers(generator, discriminator, config=CONFIG):
 
 
 def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config=CONFIG, gumbel=None,
-               ce=None, skip_dead_d_wgrad=True, branch=None):
+               ce=None, skip_dead_d_wgrad=True, branch=None, onehots=None):
     """One iteration of train_countergan's loop body (trainer.py:241-316) for a batch already on the GPU.  The draws —
     `target_y` (:248-249), `mask` (:253-255) and the Gumbel noise inside G (gumbel=None: generator.rng) — are inputs.
     Returns device tensors; the reference's `.item()` calls are the caller's.
@@ -854,7 +854,7 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     results are bit-identical to the single-stream order; captured in a HIP graph the two streams become parallel branches."""
     if branch is not None:
         return _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel,
-                                  branch, skip_dead_d_wgrad)
+                                  branch, skip_dead_d_wgrad, onehots)
     nc = config["num_classes"]
     ce = ce if ce is not None else CrossEntropyLoss()
     target_onehot = ops.onehot(target_y, nc)                                                  # :250
@@ -928,7 +928,7 @@ def _mean_cotangents(B, device):
 
 
 def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
-                       skip_dead_d_wgrad):
+                       skip_dead_d_wgrad, onehots=None):
     """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 44 launches here): what the
     reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager vs the reference-order autograd step), with
 
@@ -956,7 +956,8 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         raise PcgError(f"train_step: input is on {x.device}; libpcgan_hip has no CPU path")
     seg, cat_idx, cont_idx = generator.index_tables(dev)
     x, mask = x.contiguous(), mask.contiguous()
-    target_onehot = ops.onehot(target_y, nc)                                                  # :250
+    # onehots = (one_hot(target_y), one_hot(y)) already made (draw_batch_randoms writes them with the draws): two launches less
+    target_onehot = onehots[0] if onehots is not None else ops.onehot(target_y, nc)            # :250
     with torch.no_grad():            # no autograd graph anywhere in this schedule: every backward below is called directly
         cont, _, samples, g_saved = generator._run_forward(x, target_onehot, mask, generator._noise(gumbel, B, dev),
                                                            float(config["gumbel_tau"]), False)            # :259-261
@@ -979,7 +980,7 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         t.record_stream(branch)
     # ---- D step (:290-295)
     xd = x_cf.detach()
-    onehot_y = ops.onehot(y, nc)
+    onehot_y = onehots[1] if onehots is not None else ops.onehot(y, nc)
     with torch.no_grad():
         if branch2 is None and discriminator._fused_ok(x, onehot_y) and all(p.requires_grad for p in discriminator.parameters()):
             d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos)       # :290-294, five launches
@@ -1146,9 +1147,16 @@ class GraphedTrainStep:
         saved = [(n.flat_params.clone(), [b.clone() for b in n.buffers()]) for n in nets]
         osnap = [o.snapshot() for o in (opt_g, opt_d)]
 
+        nc = config["num_classes"]
+        # one-hot rows of target_y and y: static inputs of the scheduled step (draw_batch_randoms(onehots=self.onehots) fills them with
+        # the draws; load() computes them)
+        self.onehots = (torch.zeros((batch, nc), dtype=torch.float32, device=dev), torch.zeros((batch, nc), dtype=torch.float32, device=dev))
+        ops.onehot(self.target_y, nc, out=self.onehots[0]); ops.onehot(self.y, nc, out=self.onehots[1])
+
         def step():
             return train_step(generator, discriminator, classifier, opt_g, opt_d, self.x, self.y, self.target_y, self.mask, norm_vals,
-                              config, gumbel=self.noise, branch=self.branch)
+                              config, gumbel=self.noise, branch=self.branch, onehots=self.onehots if self.branch is not None else None)
+        self._nc = nc
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -1175,6 +1183,7 @@ class GraphedTrainStep:
 
     def load(self, x, y, target_y, mask, noise):
         self.x.copy_(x); self.y.copy_(y); self.target_y.copy_(target_y); self.mask.copy_(mask); self.noise.copy_(noise)
+        ops.onehot(self.target_y, self._nc, out=self.onehots[0]); ops.onehot(self.y, self._nc, out=self.onehots[1])
 
     def replay(self):
         self.graph.replay()
@@ -1277,7 +1286,7 @@ def train_classifier(X_train_all, X_test, y_train_all, y_test, scaler, config, d
     return model
 
 
-def draw_batch_randoms(rng, generator, y, config, device, out=None):
+def draw_batch_randoms(rng, generator, y, config, device, out=None, onehots=None):
     """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise).
     out = (target_y, mask, noise): draw straight into these buffers (the static inputs of a GraphedTrainStep)."""
     B = y.shape[0]
@@ -1289,7 +1298,8 @@ def draw_batch_randoms(rng, generator, y, config, device, out=None):
         out = (torch.empty((B,), dtype=torch.int64, device=device), torch.empty((B, config["input_dim"]), dtype=torch.float32, device=device),
                torch.empty((B, generator.total_cat), dtype=torch.float32, device=device))
     # one launch; the values of randint(exclude=y), feature_mask, gumbel called in this order
-    return rng.house_draws(y.contiguous(), config["num_classes"], config["input_dim"], generator.total_cat, imm if imm.numel() else None, out)
+    return rng.house_draws(y.contiguous(), config["num_classes"], config["input_dim"], generator.total_cat, imm if imm.numel() else None, out,
+                           onehots=onehots)
 
 
 def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):

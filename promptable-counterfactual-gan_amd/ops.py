@@ -647,9 +647,10 @@ def linear_wgrad_grouped(items, B, device):
     check(lib.pcg_linear_wgrad_grouped(arr, n, B, _p(ws), nbytes, _p(tk), _stream()), "pcg_linear_wgrad_grouped")
 
 
-def onehot(idx, K):
+def onehot(idx, K, out=None):
     _chk_idx(idx, K)
-    out = torch.empty((idx.numel(), K), dtype=torch.float32, device=idx.device)
+    if out is None:
+        out = torch.empty((idx.numel(), K), dtype=torch.float32, device=idx.device)
     check(_lib.load().pcg_onehot(_p(idx), idx.numel(), K, _p(out), _stream()), "pcg_onehot")
     return out
 
@@ -1005,17 +1006,19 @@ class DeviceRNG:
         check(_lib.load().pcg_rand_gumbel(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_gumbel")
         return out
 
-    def house_draws(self, y, num_classes, D, T, zero_cols, out):
+    def house_draws(self, y, num_classes, D, T, zero_cols, out, onehots=None):
         """target class != y, feature mask, Gumbel noise [B, T] in ONE launch, drawn into out = (target_y, mask, noise): the values
-        randint(exclude=y), feature_mask, gumbel give when called in this order (same counter offsets)."""
+        randint(exclude=y), feature_mask, gumbel give when called in this order (same counter offsets).  onehots = (onehot(target_y),
+        onehot(y)) float [B, num_classes] buffers: filled by the same launch."""
         o_t, o_m, o_n = out
         B = y.shape[0]
         off_t = self._advance((B + 3) // 4)
         off_m = self._advance((B * D + 3) // 4)
         off_n = self._advance((B * T + 3) // 4)
         nz = 0 if zero_cols is None else zero_cols.numel()
+        oh_t, oh_y = onehots if onehots is not None else (None, None)
         check(_lib.load().pcg_house_draws(_p(o_t), B, num_classes, _p(y), off_t, _p(o_m), D, _p(zero_cols), nz, off_m, _p(o_n), T, off_n, self.seed,
-                                          _stream()), "pcg_house_draws")
+                                          _p(oh_t), _p(oh_y), _stream()), "pcg_house_draws")
         return o_t, o_m, o_n
 
     def feature_mask(self, B, D, device, zero_cols=None, out=None):

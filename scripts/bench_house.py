@@ -41,14 +41,18 @@ def main():
     y = rng.randint(0, H.CONFIG["num_classes"], B, dev)
     t, mask, noise = H.draw_batch_randoms(rng, G, y, H.CONFIG, dev)
 
-    def draws():                      # straight into the step's (static) input buffers
-        H.draw_batch_randoms(rng, G, y, H.CONFIG, dev, out=(t, mask, noise))
+    onehots = None
+
+    def draws():                      # straight into the step's (static) input buffers, the one-hot rows with them
+        H.draw_batch_randoms(rng, G, y, H.CONFIG, dev, out=(t, mask, noise), onehots=onehots)
 
     gs = None
     if not args.eager:
         gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap="inline" if args.inline else (not args.no_overlap))
         gs.x.copy_(x); gs.y.copy_(y)
         t, mask, noise = gs.target_y, gs.mask, gs.noise
+        y = gs.y                       # the graph's own label buffer: the draws kernel reads it for the one-hot rows
+        onehots = gs.onehots if gs.branch is not None else None
 
     def run(i):
         draws()

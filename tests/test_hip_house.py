@@ -402,8 +402,10 @@ def test_fused_residual_block_equals_the_op_chain_bitwise(pcg, hgold, rows):
     imm = torch.tensor(H.CONFIG["immutable_idx"], dtype=torch.int32, device=dev)
     r1, r2 = ops.DeviceRNG(seed=11), ops.DeviceRNG(seed=11)
     t1 = r1.randint(0, 4, B, dev, exclude=y); k1 = r1.feature_mask(B, D, dev, imm); n1 = r1.gumbel((B, T), dev)
-    t2, k2, n2 = H.draw_batch_randoms(r2, G, y, H.CONFIG, dev)
+    oh = (torch.empty((B, 4), device=dev), torch.empty((B, 4), device=dev))
+    t2, k2, n2 = H.draw_batch_randoms(r2, G, y, H.CONFIG, dev, onehots=oh)
     assert torch.equal(t1, t2) and torch.equal(k1, k2) and torch.equal(n1, n2) and r1.offset == r2.offset
+    assert torch.equal(oh[0], ops.onehot(t1, 4)) and torch.equal(oh[1], ops.onehot(y, 4))
 
 
 def test_fused_critic_kernels_match_the_op_chain(pcg, hgold):
