@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="enqueue every step kernel by kernel instead of replaying the captured HIP graph(s)")
     ap.add_argument("--event-every", type=int, default=8, help="one timed step per this many (at most 3 in total) runs eagerly with HIP events around the conv launches")
     ap.add_argument("--sync-bn", action="store_true", help="exact global-batch BatchNorm across the ranks (SURVEY.md 8e option ii); implies --eager")
+    ap.add_argument("--wgrad-stream", action="store_true", help="A/B: weight gradients on a second HIP stream beside the grad-input kernels")
     ap.add_argument("--torch-collectives", action="store_true", help="A/B: gradient exchange on torch.distributed's RCCL communicator instead of the library's (pcg_dp_*)")
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: min(16, visible cores))")
     args = ap.parse_args()
@@ -204,6 +205,8 @@ def main():
     netG, netD = D.build(None, device="cpu")
     netG.to(dev); netD.to(dev)
     crit, optD, optG = D.make_optimizers(netG, netD)
+    if args.wgrad_stream:
+        netG.wgrad_stream = netD.wgrad_stream = torch.cuda.Stream()
     if dp is not None:
         netG.flat_params, netD.flat_params  # flatten
         broadcast_parameters(netG, dp=dp); broadcast_parameters(netD, dp=dp)

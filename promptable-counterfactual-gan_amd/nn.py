@@ -11,6 +11,8 @@ second one: the fused Adam step is a single launch over the flat buffer and the 
 single RCCL call on the flat gradient bucket.  Backward accumulates straight into the flat gradient buffer
 (`p.grad` are views of it), which is autograd's `.grad` accumulation contract without extra add kernels.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -374,9 +376,20 @@ class SequentialConvNet(FlatModule):
             a, H, W = (y if xf is None else z), OH, OW
         return a, saved
 
+    wgrad_stream = None      # opt-in A/B: a second HIP stream for the weight gradients (they and the grad-input of a layer both need only dz)
+
     def _run_backward(self, saved, dy, need_x, need_p):
         if not dy.is_contiguous():
             dy = dy.contiguous()
+        side = self.wgrad_stream
+        main = torch.cuda.current_stream() if side is not None else None
+        try:
+            return self._run_backward_impl(saved, dy, need_x, need_p, side, main)
+        finally:
+            if side is not None:
+                main.wait_stream(side)
+
+    def _run_backward_impl(self, saved, dy, need_x, need_p, side, main):
         d = dy
         own = False  # never write into autograd's incoming grad tensor; deeper gradients are ours to overwrite
         nblk = len(self._blocks)
@@ -415,13 +428,17 @@ class SequentialConvNet(FlatModule):
             if need_p and c.weight.requires_grad:
                 gw, acc = self._grad_view(c.weight)
                 gw = _w_ohwi(gw)
-                if not b.transposed:      # `a` may be the layer below's pre-BatchNorm output read through its transform
-                    ops.conv2d_wgrad(g, a, dz, gw, acc, xf_x=xf_in)
-                else:
-                    ops.conv2d_wgrad(g, dz, a, gw, acc, xf_dy=xf_in)
-                if c.bias is not None and c.bias.requires_grad:
-                    gb, accb = self._grad_view(c.bias)
-                    ops.colsum(dz.numel() // C, C, dz, gb, accb)
+                if side is not None:
+                    side.wait_stream(main)                       # dz is complete
+                    dz.record_stream(side); a.record_stream(side)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    if not b.transposed:      # `a` may be the layer below's pre-BatchNorm output read through its transform
+                        ops.conv2d_wgrad(g, a, dz, gw, acc, xf_x=xf_in)
+                    else:
+                        ops.conv2d_wgrad(g, dz, a, gw, acc, xf_dy=xf_in)
+                    if c.bias is not None and c.bias.requires_grad:
+                        gb, accb = self._grad_view(c.bias)
+                        ops.colsum(dz.numel() // C, C, dz, gb, accb)
             last = idx == 0
             if last and not need_x:
                 return None
