@@ -98,6 +98,44 @@ def test_linear_wgrad_slab_split(pcg):
         assert torch.equal(dW, outs[0][0])
 
 
+@pytest.mark.parametrize("B", [64, 1000, 4096])
+def test_grouped_weight_gradient_on_the_matrix_cores(pcg, B):
+    """pcg_linear_wgrad_grouped: the generator's 29 layers (strided operands, shared inputs, ragged widths 2..38) and a 128x64 layer
+    (eight 32x32 tiles) in ONE launch against float64; batches on either side of the one-block / eight-partials-per-tile switch and a
+    ragged one; accumulate on top of existing values; two runs are bit-identical (fixed reduction order, no float atomics)."""
+    ops = pcg.ops
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(B)
+    rnd = lambda *sh: _dev(torch.randn(*sh, generator=g) * 0.01)
+    T, K = 70, 38
+    inp = _dev(torch.rand(B, K, generator=g)); cond = inp[:, 17:]
+    Hs = _dev(torch.rand(6, B, 32, generator=g)); A1 = _dev(torch.rand(5, B, 32, generator=g))
+    DZIN, DZ1, DZ2, DG, DB, DC, DL = rnd(B, 32), rnd(5, B, 32), rnd(5, B, 32), rnd(5, B, 32), rnd(5, B, 32), rnd(B, 10), rnd(B, T)
+    big_dy, big_x = rnd(B, 128), _dev(torch.rand(B, 64, generator=g))
+    seg = [0, 9, 39, 45, 47, 52, 57, 70]
+    spec = [(DZIN, inp, 32, 38, None, None)]
+    for k in range(5):
+        spec += [(DZ1[k], Hs[k], 32, 32, None, None), (DZ2[k], A1[k], 32, 32, None, None), (DG[k], cond, 32, 21, None, K), (DB[k], cond, 32, 21, None, K)]
+    spec.append((DC, Hs[5], 10, 32, None, None))
+    spec += [(DL[:, seg[s_]:], Hs[5], seg[s_ + 1] - seg[s_], 32, T, None) for s_ in range(7)]
+    spec.append((big_dy, big_x, 128, 64, None, None))
+
+    def run():
+        items = []
+        for dy, x, O, I, ldy, ldx in spec:
+            dW = torch.full((O, I), 0.5, device=dev); db = torch.full((O,), -0.25, device=dev)
+            items.append((dy, x, O, I, dW, db, ldy or O, ldx or I, True, True))
+        ops.linear_wgrad_grouped(items, B, dev)
+        return items
+    a, b = run(), run()
+    for (dy, x, O, I, ldy, ldx), ia, ib in zip(spec, a, b):
+        rw = dy[:, :O].double().T @ x[:, :I].double() + 0.5
+        rb = dy[:, :O].double().sum(0) - 0.25
+        _close(ia[4], rw, 0, 2e-6 * float((rw - 0.5).abs().max()) + 1e-7, f"dW {O}x{I}")
+        _close(ia[5], rb, 0, 2e-6 * float((rb + 0.25).abs().max()) + 1e-7, f"db {O}")
+        assert torch.equal(ia[4], ib[4]) and torch.equal(ia[5], ib[5])
+
+
 def test_tabular_elementwise_ops(pcg):
     ops = pcg.ops
     g = torch.Generator().manual_seed(2)
@@ -471,21 +509,21 @@ def test_fused_classifier_kernels_match_the_op_chain(pcg, hgold, rows):
         _close(u, v, 2e-5, 2e-5 * float(v.abs().max()), "saved activation")
 
 
-@pytest.mark.parametrize("overlap", [True, "critic", False])
-def test_graphed_step_equals_eager(pcg, hgold, overlap):
+@pytest.mark.parametrize("overlap,batch", [(True, 128), ("critic", 128), (False, 128), ("inline", 128), (True, 4096)])
+def test_graphed_step_equals_eager(pcg, hgold, overlap, batch):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
     it (warm-up + capture) does not advance the training state.  overlap=True: the schedule with the classifier term on a parallel
     branch and the critic passes run directly with constant cotangents (house._train_step_branch); "critic": additionally the
     critic's real pass on a third stream into a second gradient buffer; False: the reference-order single-stream step.  All three
     are bit-identical to the eager autograd step."""
     H = pcg.house
-    batches = [HR.synthetic_batch(128, seed=s) for s in (1, 2, 3)]
+    batches = [HR.synthetic_batch(batch, seed=s) for s in (1, 2, 3)]     # 4096: the multi-block forms of every reduction (the bench batch)
     states = []
     for graphed in (False, True):
         G, D, C = _load_golden_nets(pcg, hgold)
         opt_g, opt_d = H.make_optimizers(G, D)
         norm = H.cat_norm_maps(G, H.CONFIG, torch.device(DEV))
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, 128, overlap=overlap) if graphed else None
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, batch, overlap=overlap) if graphed else None
         losses = []
         for (x, y, t, m, gumbel) in batches:
             noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
