@@ -438,21 +438,6 @@ def _one(device):
     return t
 
 
-class _InjectGradFn(torch.autograd.Function):
-    """y = x; in backward: dx = dy + g.  Carries a gradient contribution that was computed ahead of time (the frozen classifier's
-    d(lambda_cls * CE)/d(x_cf), evaluated on the parallel branch of train_step) into autograd's sweep: one fused add instead of
-    autograd's own accumulation kernel."""
-
-    @staticmethod
-    def forward(ctx, x, g):
-        ctx.g = g
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dy):
-        return ops.axpby(1.0, dy.contiguous(), 1.0, ctx.g), None
-
-
 # ---- discriminator ------------------------------------------------------------------------------------------------------
 class _DFn(torch.autograd.Function):
     @staticmethod
