@@ -569,8 +569,8 @@ int pcg_house_critic_bwd_n(int32_t n_pass, const float* const* dout, int32_t B, 
 
 /* The frozen tabular classifier of the counterfactual loss (house_sales_kc_usa/models/nn_classifier.py:4-32 in eval mode, each
  * BatchNorm1d folded into the following Linear by the caller: Linear 17->256, 256->256, 256->128, 128->64 + LeakyReLU(0.1), Linear
- * 64->4) as one launch each way on the matrix cores, 32 rows per block, activations in LDS between layers.
- *   forward:  w_kmajor[l], l = 0..3: the folded weight TRANSPOSED, [K_l][N_l] row-major, layer 0 zero-padded to K = 18;
+ * 64->4) as one launch each way on the matrix cores, 16 rows per block, activations in LDS between layers.
+ *   forward:  w_kmajor[l], l = 0..3: the folded weight TRANSPOSED, [K_l][N_l] row-major, layer 0 zero-padded to K = 20;
  *             w_kmajor[4]: the last layer as stored [4][64]; bias[l]; writes the post-activation outputs a1 [B][256], a2 [B][256],
  *             a3 [B][128], a4 [B][64] (the backward's masks) and logits [B][4].
  *   backward: w_stored[l]: the folded weights as stored [N_l][K_l]; dx [B][17] = d(logits . dlogits)/dx.  (trainer.py:301-302;

@@ -695,12 +695,12 @@ class NNClassifier(FlatModule):
 
     def _pack_kmajor(self):
         """Per layer the folded weight transposed ([K][N]: the forward's B operand is then a coalesced read), layer 0 padded with a
-        zero row to an even reduction length; the last layer stays as stored.  Built once per pack."""
+        zero rows to a multiple of the MFMA's reduction depth (17 -> 20); the last layer stays as stored.  Built once per pack."""
         packed = self._pack()
         if getattr(self, "_kmajor", None) is None:
             with torch.no_grad():
                 km = [w.t().contiguous() for w, _ in packed[:4]]
-                km[0] = torch.cat([km[0], torch.zeros((1, km[0].shape[1]), dtype=km[0].dtype, device=km[0].device)], 0).contiguous()
+                km[0] = torch.cat([km[0], torch.zeros((3, km[0].shape[1]), dtype=km[0].dtype, device=km[0].device)], 0).contiguous()   # K 17 -> 20
                 km.append(packed[4][0])
             self._kmajor = km
         return self._kmajor
@@ -1102,15 +1102,16 @@ def compute_metrics_per_target(generator, classifier, X, y, config, gumbel_per_c
 class GraphedTrainStep:
     """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 44 as scheduled by
     train_step(branch=...) — captured once in a HIP graph and replayed with one host call: this path is latency bound (SURVEY.md
-    section 8a row a15), and the graph removes the per-kernel host cost.  overlap=True (default): the frozen classifier's term on a
-    parallel branch; "inline": the same schedule on one stream (a multi-branch graph is launched node by node by the host, a
-    single-stream one is not: 0.28 vs 0.03 ms of host time per replay, wall 0.437 vs 0.451 ms at batch 4096); "critic": a third
-    stream for the critic's real pass (no gain); False: the reference-order autograd step.  All bit-identical.  Inputs live in static device buffers (`x, y, target_y, mask, noise`): write the next
+    section 8a row a15), and the graph removes the per-kernel host cost.  overlap="inline" (default): the scheduled step on one
+    stream; True: the frozen classifier's term on a parallel graph branch (a graph with branches is launched node by node by the
+    host, a chain is not: 0.28 vs 0.03 ms of host time per replay; wall 0.434 vs 0.422 ms at batch 4096 once the classifier term
+    itself was down to 47 us); "critic": a third stream for the critic's real pass (no gain); False: the reference-order autograd
+    step.  All bit-identical.  Inputs live in static device buffers (`x, y, target_y, mask, noise`): write the next
     batch into them (`load(...)`, or draw straight into them) and call `replay()`; outputs are the static tensors in `out`.
     Capture needs warm-up executions of real steps; the parameters, buffers and optimizer state are snapshotted before and
     restored after, so constructing this object does not advance training."""
 
-    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap=True):
+    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap="inline"):
         dev = norm_vals.device
         # train_step's parallel branch: the classifier term and the logged sums; overlap="critic" adds a third stream for the
         # critic's real pass (bit-identical, no gain measured: see _train_step_branch)

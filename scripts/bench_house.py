@@ -2,7 +2,8 @@
 """rows/sec of the tabular CounteRGAN training step (conditional_counteRGAN/house_sales_kc_usa/trainer.py:241-316) on one MI355X —
 BASELINE config 5 (batch 4096, single GPU: the path does not shard, "replicas only").
 
-  python scripts/bench_house.py                  batch 4096, the whole step (G fwd, D step, G step, both Adams) replayed as ONE HIP graph
+  python scripts/bench_house.py                  batch 4096, the whole step (G fwd, D step, G step, both Adams) replayed as ONE single-stream HIP graph
+  python scripts/bench_house.py --overlap        A/B: the classifier term on a parallel graph branch
   python scripts/bench_house.py --eager          one host launch per kernel
 
 One JSON line, same contract as bench.py.  The step is ~1 MFLOP per row on 17..256-wide layers: no MFMA claim.  `roofline` is
@@ -24,7 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-overlap", action="store_true", help="A/B: the reference-order autograd step as a single-stream graph")
-    ap.add_argument("--inline", action="store_true", help="A/B: the scheduled step's kernels on ONE stream (no parallel classifier branch)")
+    ap.add_argument("--overlap", action="store_true", help="A/B: the frozen classifier's term on a parallel graph branch (two streams)")
+    ap.add_argument("--inline", action="store_true", help="(default) the scheduled step's kernels on ONE stream")
     BL.add_common_args(ap, steps=200, warmup=20)
     args = ap.parse_args()
     if args.gpus != 1:
@@ -48,7 +50,7 @@ def main():
 
     gs = None
     if not args.eager:
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap="inline" if args.inline else (not args.no_overlap))
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap=False if args.no_overlap else (True if args.overlap else "inline"))
         gs.x.copy_(x); gs.y.copy_(y)
         t, mask, noise = gs.target_y, gs.mask, gs.noise
         y = gs.y                       # the graph's own label buffer: the draws kernel reads it for the one-hot rows

@@ -79,7 +79,7 @@ if trace:
                    "how": "dispatches between consecutive house_draws_kernel launches (one per step), mean of the last 10 steps of "
                           "rocprofv3 --kernel-trace -- python3 scripts/bench_house.py --steps 50 --warmup 10"},
                   open(os.path.join(out, f"{tag}_house_launches.json"), "w"), indent=1)
-    stats_md("house", f"{tag}_house_kernel_stats.md", "python3 scripts/bench_house.py --steps 50 --warmup 10 (batch 4096, HIP-graph replay with the parallel classifier branch)", 63)
+    stats_md("house", f"{tag}_house_kernel_stats.md", "python3 scripts/bench_house.py --steps 50 --warmup 10 (batch 4096, single-stream HIP-graph replay of the scheduled step)", 63)
 
 # PMC traffic
 fe_p, wr_p = find("pmc_fetch", "*counter_collection.csv"), find("pmc_write", "*counter_collection.csv")
