@@ -291,103 +291,246 @@ __global__ void __launch_bounds__(NT) g_fwd_first4_kernel(const float* __restric
 // (the offsets and pointers of ONE segment travel by value — FSeg / BSeg / CSeg — so they arrive with the kernel arguments instead
 // of as a chain of dependent scalar loads indexed by k)
 struct FSeg { int fg_w, fg_b, fb_w, fb_b, fc_w, fc_b, bn_g, bn_b; float* rmean; float* rvar; int64_t* nbt; int k, li, more; };
+
+// ---- the forward segments on the matrix cores -------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: lane (li = lane % 16, lq = lane / 16) supplies A[m = li][k = lq], B[k = lq][n = li]; accumulator register r
+// holds D[m = 4 lq + r][n = li].  Wave w owns rows 16 w .. 16 w + 15 of the block and BOTH 16-channel tiles: its FiLM products
+// (cond x gamma / beta weights, K = 21 padded to 24), the BatchNorm / FiLM / ReLU arithmetic on the accumulator layout, and the next
+// Linear (K = 32) — no cross-wave dependency until the column sums.  The lane-per-row form read the weights as LDS broadcasts: 8
+// ds_read_b128 per 32 FMAs per lane, four waves on one LDS — 2.3 us of a 7 us segment in the three products alone.
+constexpr int MK_C = 24;                    // cond width padded to the MFMA's reduction depth
+constexpr int PWM = 36;                     // weight row pitch in LDS (as stored [out][in]): banks 4 li + lq
+constexpr int PRM_ = 68;                    // pitch of a k-major [k][64 rows] image
+typedef float m16_t __attribute__((ext_vector_type(4)));
+struct alignas(16) SmemM {
+  float gamma[HH], beta[HH], mean[HH], inv[HH];
+  float Wg[HH * PWM], Wb[HH * PWM], Wf[HH * PWM];   // FiLM gamma / beta weights (21 columns used), the segment's Linear (32)
+  float bg[HH], bb[HH], bf[HH];
+  float C[MK_C * PRM_];                     // cond, k-major (rows 21 .. 23 zero)
+  float A[HH * PRM_];                       // the Linear's input, k-major
+  float ws[NQ][2][HH];                      // per-wave column sums
+  double fin[NPART][2][HH];
+};
+// registers -> LDS as stored with pitch PWM, pad columns zero
+template <int K>
+__device__ __forceinline__ void wstore_m(float* Wl, float* bl, const WRegs<K>& r) {
+#pragma unroll
+  for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < K * HH) { const int j = e / K, i = e - j * K; Wl[j * PWM + i] = r.v[t]; }
+  }
+  for (int e = threadIdx.x; e < HH * (PWM - K); e += NT) { const int j = e / (PWM - K); Wl[j * PWM + K + (e - j * (PWM - K))] = 0.f; }
+  if (threadIdx.x < HH) bl[threadIdx.x] = r.b;
+}
+// acc[ct] += A[16 rows of this wave][k] * W[ct * 16 + n][k] over KSTEPS steps of 4; A k-major in LDS (pitch PRM_), W as stored (pitch PWM)
+template <int KSTEPS>
+__device__ __forceinline__ void mma16(m16_t (&acc)[2], const float* A, const float* W, int wave, int li, int lq) {
+#pragma unroll
+  for (int st = 0; st < KSTEPS; ++st) {
+    const float av = A[(4 * st + lq) * PRM_ + wave * 16 + li];
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, W[li * PWM + 4 * st + lq], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, W[(16 + li) * PWM + 4 * st + lq], acc[1], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void bn_finish_m(SmemM& s, int B, float eps, float momentum, float* save, float* rmean, float* rvar, int64_t* nbt,
+                                            float rm_old, float rv_old) {
+  __syncthreads();                                   // s.fin and the LDS images of the burst are complete
+  if (threadIdx.x < HH) {
+    double sm = 0.0, q = 0.0;
+#pragma unroll
+    for (int p = 0; p < NPART; ++p) { sm += s.fin[p][0][threadIdx.x]; q += s.fin[p][1][threadIdx.x]; }
+    const double mean = sm / B;
+    double var = q / B - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    s.mean[threadIdx.x] = (float)mean; s.inv[threadIdx.x] = inv;
+    if (blockIdx.x == 0) {
+      save[threadIdx.x] = (float)mean; save[HH + threadIdx.x] = inv;
+      if (rmean) {
+        const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
+        rmean[threadIdx.x] = (float)((1.0 - momentum) * rm_old + momentum * mean);
+        rvar[threadIdx.x] = (float)((1.0 - momentum) * rv_old + momentum * unb);
+        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
+      }
+    }
+  }
+  __syncthreads();
+}
+// column sums of v and v*v over the block's 64 rows from the accumulator layout (lane: rows 4 lq + r of its wave, column ct * 16 + li):
+// in-lane over r, across lq at distances 16 and 32, the four waves through LDS in wave order
+__device__ __forceinline__ void colsums_m(SmemM& s, const m16_t (&v)[2], const bool (&ok)[4], int wave, int li, int lq, float* part) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float x = ok[r] ? v[ct][r] : 0.f; s1 += x; s2 += x * x; }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lq == 0) { s.ws[wave][0][ct * 16 + li] = s1; s.ws[wave][1][ct * 16 + li] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * HH) {
+    const int st = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    part[st * HH + c] = (s.ws[0][st][c] + s.ws[1][st][c]) + (s.ws[2][st][c] + s.ws[3][st][c]);
+  }
+}
+
+// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
 __global__ void __launch_bounds__(NT) g_fwd_a4_kernel(const float* __restrict__ PRM, GBufs a, FSeg f) {
-  __shared__ Smem4 s;
-  const int li = f.li, k = f.k;
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  const bool on = row < (size_t)a.B;
+  __shared__ SmemM s;
+  const int lyr = f.li, k = f.k;
+  const int lane = threadIdx.x & (FT - 1), wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t rowL = (size_t)blockIdx.x * FT + lane;            // the lane-per-row view (cond loads)
+  const size_t rowA = (size_t)blockIdx.x * FT + wave * 16 + 4 * lq;   // this lane's first accumulator row
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = rowA + r < (size_t)a.B;
   // ---- the burst
-  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc2; CondRegs cr; PRegs pr;
-  float z[HQ], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
+  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc; CondRegs cr; PRegs pr;
+  float z[2][4], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
   PCG_T(0);
   wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
   wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
-  wload<HH>(w_fc2, PRM + f.fc_w, PRM + f.fc_b);
-  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
-  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z);
+  wload<HH>(w_fc, PRM + f.fc_w, PRM + f.fc_b);
+  cload(cr, a.onehot, a.mask, min(rowL, (size_t)a.B - 1), rowL < (size_t)a.B, wave);
+  const float* Zk = a.Z1 + (size_t)k * a.B * HH;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[ct][r] = Zk[min(rowA + r, (size_t)a.B - 1) * HH + ct * 16 + li];
   if (threadIdx.x < HH) {
     g_bn = PRM[f.bn_g + threadIdx.x]; b_bn = PRM[f.bn_b + threadIdx.x];
     if (f.rmean) { rm_old = f.rmean[threadIdx.x]; rv_old = f.rvar[threadIdx.x]; }     // every block: no block-0 detour in the burst
   }
-  pload(pr, a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks);
+  pload(pr, a.P + (size_t)lyr * a.nblocks * 2 * HH, a.nblocks);
   PCG_T(1);
   // ---- into LDS
-  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
-  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
-  wstore<HH, true>(s.Wt[2], s.bl[2], w_fc2);
-  cstore(s.V, cr, lane, q);
+  wstore_m<MAXCOND>(s.Wg, s.bg, w_g);
+  wstore_m<MAXCOND>(s.Wb, s.bb, w_b);
+  wstore_m<HH>(s.Wf, s.bf, w_fc);
+#pragma unroll
+  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = wave + t * NQ; if (i < MAXCOND) s.C[i * PRM_ + lane] = cr.v[t]; }
+  if (wave < MK_C - MAXCOND) s.C[(MAXCOND + wave) * PRM_ + lane] = 0.f;
   if (threadIdx.x < HH) { s.gamma[threadIdx.x] = g_bn; s.beta[threadIdx.x] = b_bn; }
-  pstore(s, pr);
+  { const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5; s.fin[part][0][c] = pr.s; s.fin[part][1][c] = pr.q; }
   PCG_T(2);
-  bn_finish(s, a.B, a.eps, a.momentum, a.SM + (size_t)li * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
+  bn_finish_m(s, a.B, a.eps, a.momentum, a.SM + (size_t)lyr * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
   PCG_T(3);
-  float gam[HQ], bet[HQ], a1[HQ];
-  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
+  // FiLM: gamma and beta of this wave's 16 rows x 32 channels
+  m16_t gam[2], bet[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gam[ct][r] = s.bg[ct * 16 + li]; bet[ct][r] = s.bb[ct * 16 + li]; }
+  mma16<MK_C / 4>(gam, s.C, s.Wg, wave, li, lq);
+  mma16<MK_C / 4>(bet, s.C, s.Wb, wave, li, lq);
   PCG_T(4);
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float n = fmaf((z[j] - s.mean[c]) * s.inv[c], s.gamma[c], s.beta[c]);
-    const float f = fmaf(gam[j], n, bet[j]);
-    a1[j] = f > 0.f ? f : 0.f;
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = ct * 16 + li;
+    const float mu = s.mean[c], iv = s.inv[c], ga = s.gamma[c], be = s.beta[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float n = fmaf((z[ct][r] - mu) * iv, ga, be);
+      const float fv = fmaf(gam[ct][r], n, bet[ct][r]);
+      s.A[c * PRM_ + wave * 16 + 4 * lq + r] = fv > 0.f ? fv : 0.f;
+    }
   }
-  park8(s.V2, lane, q, a1);
-  __syncthreads();                                   // a1 complete
+  __syncthreads();                                   // a1 parked (each wave reads back only its own rows; the barrier orders the LDS traffic)
   PCG_T(5);
-  float z2[HQ];
-  lin_q<HH>(s.Wt[2], s.bl[2], s.V2, lane, q, z2);
+  m16_t z2[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z2[ct][r] = s.bf[ct * 16 + li];
+  mma16<HH / 4>(z2, s.A, s.Wf, wave, li, lq);
   PCG_T(6);
-  store8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z2);
-  wave_colsums(z2, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+  float* Z2k = a.Z2 + (size_t)k * a.B * HH;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[r]) Z2k[(rowA + r) * HH + ct * 16 + li] = z2[ct][r];
+  colsums_m(s, z2, ok, wave, li, lq, a.P + ((size_t)(lyr + 1) * a.nblocks + blockIdx.x) * 2 * HH);
   PCG_T(7);
 }
 
 // kind B (block k): bn2 statistics -> h_{k+1} = h_k + film(bn2(z2)); z1_{k+1} = fc1_{k+1}(h), partial statistics (after the last
 // block the output heads follow instead: g_heads4_kernel)
 __global__ void __launch_bounds__(NT) g_fwd_b4_kernel(const float* __restrict__ PRM, GBufs a, FSeg f) {
-  __shared__ Smem4 s;
-  const int li = f.li, k = f.k;
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  const bool on = row < (size_t)a.B;
+  __shared__ SmemM s;
+  const int lyr = f.li, k = f.k;
+  const int lane = threadIdx.x & (FT - 1), wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t rowL = (size_t)blockIdx.x * FT + lane;
+  const size_t rowA = (size_t)blockIdx.x * FT + wave * 16 + 4 * lq;
   const bool more = f.more != 0;                     // kernel-uniform: a next block follows (f.fc_* = its fc1)
-  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc1; CondRegs cr; PRegs pr;
-  float z[HQ], h[HQ], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = rowA + r < (size_t)a.B;
+  WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc; CondRegs cr; PRegs pr;
+  float z[2][4], h[2][4], g_bn = 0.f, b_bn = 0.f, rm_old = 0.f, rv_old = 0.f;
   wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
   wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
-  if (more) wload<HH>(w_fc1, PRM + f.fc_w, PRM + f.fc_b);
-  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
-  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
-  load8(a.H + (size_t)k * a.B * HH, row, q, on, h);
+  if (more) wload<HH>(w_fc, PRM + f.fc_w, PRM + f.fc_b);
+  cload(cr, a.onehot, a.mask, min(rowL, (size_t)a.B - 1), rowL < (size_t)a.B, wave);
+  const float* Zk = a.Z2 + (size_t)k * a.B * HH;
+  const float* Hk = a.H + (size_t)k * a.B * HH;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = min(rowA + r, (size_t)a.B - 1) * HH + ct * 16 + li;
+      z[ct][r] = Zk[o]; h[ct][r] = Hk[o];
+    }
   if (threadIdx.x < HH) {
     g_bn = PRM[f.bn_g + threadIdx.x]; b_bn = PRM[f.bn_b + threadIdx.x];
     if (f.rmean) { rm_old = f.rmean[threadIdx.x]; rv_old = f.rvar[threadIdx.x]; }
   }
-  pload(pr, a.P + (size_t)li * a.nblocks * 2 * HH, a.nblocks);
-  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
-  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
-  if (more) wstore<HH, true>(s.Wt[2], s.bl[2], w_fc1);
-  cstore(s.V, cr, lane, q);
-  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = g_bn; s.beta[threadIdx.x] = b_bn; }
-  pstore(s, pr);
-  bn_finish(s, a.B, a.eps, a.momentum, a.SM + (size_t)li * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
-  float gam[HQ], bet[HQ];
-  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
+  pload(pr, a.P + (size_t)lyr * a.nblocks * 2 * HH, a.nblocks);
+  wstore_m<MAXCOND>(s.Wg, s.bg, w_g);
+  wstore_m<MAXCOND>(s.Wb, s.bb, w_b);
+  if (more) wstore_m<HH>(s.Wf, s.bf, w_fc);
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float n = fmaf((z[j] - s.mean[c]) * s.inv[c], s.gamma[c], s.beta[c]);
-    h[j] += fmaf(gam[j], n, bet[j]);
+  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = wave + t * NQ; if (i < MAXCOND) s.C[i * PRM_ + lane] = cr.v[t]; }
+  if (wave < MK_C - MAXCOND) s.C[(MAXCOND + wave) * PRM_ + lane] = 0.f;
+  if (threadIdx.x < HH) { s.gamma[threadIdx.x] = g_bn; s.beta[threadIdx.x] = b_bn; }
+  { const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5; s.fin[part][0][c] = pr.s; s.fin[part][1][c] = pr.q; }
+  bn_finish_m(s, a.B, a.eps, a.momentum, a.SM + (size_t)lyr * 2 * HH, f.rmean, f.rvar, f.nbt, rm_old, rv_old);
+  m16_t gam[2], bet[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gam[ct][r] = s.bg[ct * 16 + li]; bet[ct][r] = s.bb[ct * 16 + li]; }
+  mma16<MK_C / 4>(gam, s.C, s.Wg, wave, li, lq);
+  mma16<MK_C / 4>(bet, s.C, s.Wb, wave, li, lq);
+  float* Hn = a.H + (size_t)(k + 1) * a.B * HH;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = ct * 16 + li;
+    const float mu = s.mean[c], iv = s.inv[c], ga = s.gamma[c], be = s.beta[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float n = fmaf((z[ct][r] - mu) * iv, ga, be);
+      const float hv = h[ct][r] + fmaf(gam[ct][r], n, bet[ct][r]);
+      if (ok[r]) Hn[(rowA + r) * HH + c] = hv;
+      if (more) s.A[c * PRM_ + wave * 16 + 4 * lq + r] = hv;
+    }
   }
-  store8(a.H + (size_t)(k + 1) * a.B * HH, row, q, on, h);
   if (!more) return;
-  park8(s.V2, lane, q, h);
   __syncthreads();
-  float z1[HQ];
-  lin_q<HH>(s.Wt[2], s.bl[2], s.V2, lane, q, z1);
-  store8(a.Z1 + (size_t)(k + 1) * a.B * HH, row, q, on, z1);
-  wave_colsums(z1, on, lane, q, a.P + ((size_t)(li + 1) * a.nblocks + blockIdx.x) * 2 * HH);
+  m16_t z1[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z1[ct][r] = s.bf[ct * 16 + li];
+  mma16<HH / 4>(z1, s.A, s.Wf, wave, li, lq);
+  float* Z1n = a.Z1 + (size_t)(k + 1) * a.B * HH;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[r]) Z1n[(rowA + r) * HH + ct * 16 + li] = z1[ct][r];
+  colsums_m(s, z1, ok, wave, li, lq, a.P + ((size_t)(lyr + 1) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
 // ---- output heads ----------------------------------------------------------------------------------------------------------------
