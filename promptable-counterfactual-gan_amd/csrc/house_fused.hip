@@ -904,137 +904,271 @@ __global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restric
   (void)ncols;
 }
 
+// ---- backward segments on the matrix cores (same ownership as the forward: wave w has rows 16 w .. 16 w + 15, both channel tiles) ---
+struct alignas(16) SmemMB {
+  float aff[4][HH];                         // bn2 gamma, bn2 beta, bn1 gamma, bn1 beta
+  float sm[4][HH];                          // saved mean / invstd: [0..1] bn1 of the block, [2..3] bn2 (kind C: bn2 of block k - 1)
+  float sums[2 * HH];                       // mean(dz), mean(dz * xhat) of the BatchNorm in flight
+  float Wg[HH * PWM], Wb[HH * PWM], Wf[HH * PWM];
+  float bg[HH], bb[HH];
+  float C[MK_C * PRM_];
+  float A[HH * PRM_];
+  float ws[NQ][2][HH];
+  double fin[NPART][2][HH];
+};
+// acc[ct][row][i = ct * 16 + n] += D[row][j] * W[j][i] over j = 0 .. 31: D k-major (index j) in LDS, W as stored [j][i]
+__device__ __forceinline__ void mma16_t(m16_t (&acc)[2], const float* D, const float* W, int wave, int li, int lq) {
+#pragma unroll
+  for (int st = 0; st < HH / 4; ++st) {
+    const float dv = D[(4 * st + lq) * PRM_ + wave * 16 + li];
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W[(4 * st + lq) * PWM + li], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, W[(4 * st + lq) * PWM + 16 + li], acc[1], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mma16_c(m16_t (&acc)[2], const float* C, const float* W, int wave, int li, int lq) {    // cond x FiLM weights
+#pragma unroll
+  for (int st = 0; st < MK_C / 4; ++st) {
+    const float av = C[(4 * st + lq) * PRM_ + wave * 16 + li];
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, W[li * PWM + 4 * st + lq], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, W[(16 + li) * PWM + 4 * st + lq], acc[1], 0, 0, 0);
+  }
+}
+// sums of one BatchNorm backward from the partials parked in s.fin -> s.sums (means); block 0 writes dgamma / dbeta
+__device__ __forceinline__ void bnb_finish_m(SmemMB& s, const GBwd& a, int g_off, int b_off, float gg_old, float gb_old) {
+  __syncthreads();
+  if (threadIdx.x < HH) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < NPART; ++p) { s1 += s.fin[p][0][threadIdx.x]; s2 += s.fin[p][1][threadIdx.x]; }
+    s.sums[threadIdx.x] = (float)(s1 / a.B); s.sums[HH + threadIdx.x] = (float)(s2 / a.B);
+    if (blockIdx.x == 0) {
+      a.grads[g_off + threadIdx.x] = a.accumulate ? gg_old + (float)s2 : (float)s2;
+      a.grads[b_off + threadIdx.x] = a.accumulate ? gb_old + (float)s1 : (float)s1;
+    }
+  }
+  __syncthreads();
+}
+// column sums of v and w over the block's 64 rows from the accumulator layout -> part[2][HH] (callers zero the rows past the batch)
+__device__ __forceinline__ void colsums2_m(SmemMB& s, const m16_t (&v)[2], const m16_t (&w)[2], int wave, int li, int lq, float* part) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float s1 = (v[ct][0] + v[ct][1]) + (v[ct][2] + v[ct][3]), s2 = (w[ct][0] + w[ct][1]) + (w[ct][2] + w[ct][3]);
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lq == 0) { s.ws[wave][0][ct * 16 + li] = s1; s.ws[wave][1][ct * 16 + li] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * HH) {
+    const int st = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    part[st * HH + c] = (s.ws[0][st][c] + s.ws[1][st][c]) + (s.ws[2][st][c] + s.ws[3][st][c]);
+  }
+}
+template <int K>
+__device__ __forceinline__ void wstore_mb(float* Wl, float* bl, const WRegs<K>& r) {
+#pragma unroll
+  for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < K * HH) { const int j = e / K, i = e - j * K; Wl[j * PWM + i] = r.v[t]; }
+  }
+  for (int e = threadIdx.x; e < HH * (PWM - K); e += NT) { const int j = e / (PWM - K); Wl[j * PWM + K + (e - j * (PWM - K))] = 0.f; }
+  if (bl && threadIdx.x < HH) bl[threadIdx.x] = r.b;
+}
+__device__ __forceinline__ void acc_rows_load(float (&v)[2][4], const float* __restrict__ p, size_t rowA, int B, int li) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[ct][r] = p[min(rowA + r, (size_t)B - 1) * HH + ct * 16 + li];
+}
+__device__ __forceinline__ void acc_rows_store(float* __restrict__ p, const m16_t (&v)[2], size_t rowA, const bool (&ok)[4], int li) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[r]) p[(rowA + r) * HH + ct * 16 + li] = v[ct][r];
+}
+
 // kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
 struct BSeg { int fg_w, fg_b, fb_w, fb_b, fc2_w, bn2_g, bn2_b, bn1_g, bn1_b, k; };
 __global__ void __launch_bounds__(NT) g_bwd_b4_kernel(const float* __restrict__ PRM, GBwd a, BSeg f) {
-  __shared__ Smem4 s;
+  __shared__ SmemMB s;
   const int k = f.k;
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  const bool on = row < (size_t)a.B;
+  const int lane = threadIdx.x & (FT - 1), wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t rowL = (size_t)blockIdx.x * FT + lane;
+  const size_t rowA = (size_t)blockIdx.x * FT + wave * 16 + 4 * lq;
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = rowA + r < (size_t)a.B;
   // ---- the burst
   WRegs<MAXCOND> w_g, w_b; WRegs<HH> w_fc2; CondRegs cr; PRegs pr;
-  float dh[HQ], z2[HQ], z1[HQ], aff = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
+  float dh[2][4], z2[2][4], z1[2][4], affv = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
   wload<MAXCOND>(w_g, PRM + f.fg_w, PRM + f.fg_b);
   wload<MAXCOND>(w_b, PRM + f.fb_w, PRM + f.fb_b);
   wload<HH>(w_fc2, PRM + f.fc2_w, nullptr);
-  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
-  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
-  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z2);
-  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z1);
-  if (threadIdx.x < 4 * HH) {                        // bn2 gamma, beta, bn1 gamma, beta -> s.gamma, s.beta, s.gamma1, s.beta1 (contiguous)
-    const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
-    aff = PRM[(w == 0 ? f.bn2_g : w == 1 ? f.bn2_b : w == 2 ? f.bn1_g : f.bn1_b) + c];
-    smr = a.SM[(size_t)(2 * k) * 2 * HH + threadIdx.x];        // sm[0..1] = bn1's mean / invstd, sm[2..3] = bn2's
-  }
-  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn2_g + threadIdx.x]; gb_old = a.grads[f.bn2_b + threadIdx.x]; }   // every block
-  pload(pr, a.Q + (size_t)(2 * k + 1) * a.nblocks * 2 * HH, a.nblocks);
-  // ---- into LDS
-  wstore<MAXCOND, true>(s.Wt[0], s.bl[0], w_g);
-  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_b);
-  wstore<HH, false>(s.Wt[2], nullptr, w_fc2);
-  cstore(s.V, cr, lane, q);
+  cload(cr, a.onehot, a.mask, min(rowL, (size_t)a.B - 1), rowL < (size_t)a.B, wave);
+  acc_rows_load(dh, a.DH + (size_t)k * a.B * HH, rowA, a.B, li);
+  acc_rows_load(z2, a.Z2 + (size_t)k * a.B * HH, rowA, a.B, li);
+  acc_rows_load(z1, a.Z1 + (size_t)k * a.B * HH, rowA, a.B, li);
   if (threadIdx.x < 4 * HH) {
     const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
-    (w == 0 ? s.gamma : w == 1 ? s.beta : w == 2 ? s.gamma1 : s.beta1)[c] = aff;
-    s.sm[w][c] = smr;
+    affv = PRM[(w == 0 ? f.bn2_g : w == 1 ? f.bn2_b : w == 2 ? f.bn1_g : f.bn1_b) + c];
+    smr = a.SM[(size_t)(2 * k) * 2 * HH + threadIdx.x];        // sm[0..1] = bn1's mean / invstd, sm[2..3] = bn2's
   }
-  pstore(s, pr);
-  bnb_finish(s, a, f.bn2_g, f.bn2_b, gg_old, gb_old);
-  float gam[HQ], bet[HQ], dz2[HQ], da1[HQ], dgam[HQ];
-  lin_q2<MAXCOND>(s.Wt[0], s.bl[0], s.Wt[1], s.bl[1], s.V, lane, q, gam, bet);
+  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn2_g + threadIdx.x]; gb_old = a.grads[f.bn2_b + threadIdx.x]; }
+  pload(pr, a.Q + (size_t)(2 * k + 1) * a.nblocks * 2 * HH, a.nblocks);
+  // ---- into LDS
+  wstore_mb<MAXCOND>(s.Wg, s.bg, w_g);
+  wstore_mb<MAXCOND>(s.Wb, s.bb, w_b);
+  wstore_mb<HH>(s.Wf, nullptr, w_fc2);
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float xh = (z2[j] - s.sm[2][c]) * s.sm[3][c];
-    const float n2 = fmaf(xh, s.gamma[c], s.beta[c]);
-    const float dn2 = dh[j] * gam[j];
-    dz2[j] = s.gamma[c] * s.sm[3][c] * (dn2 - s.sums[c] - xh * s.sums[HH + c]);
-    dgam[j] = dh[j] * n2;
-  }
-  store8(a.DZ2 + (size_t)k * a.B * HH, row, q, on, dz2);
-  park8(s.V2, lane, q, dz2);
-  __syncthreads();                                   // dz2 complete
-  lin_tq(s.Wt[2], s.V2, lane, q, da1);
-  float a1[HQ], v[HQ], w[HQ], dbet[HQ];
+  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = wave + t * NQ; if (i < MAXCOND) s.C[i * PRM_ + lane] = cr.v[t]; }
+  if (wave < MK_C - MAXCOND) s.C[(MAXCOND + wave) * PRM_ + lane] = 0.f;
+  if (threadIdx.x < 4 * HH) { s.aff[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = affv; s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr; }
+  { const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5; s.fin[part][0][c] = pr.s; s.fin[part][1][c] = pr.q; }
+  bnb_finish_m(s, a, f.bn2_g, f.bn2_b, gg_old, gb_old);
+  m16_t gam[2], bet[2], dz2[2], dgam[2];
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float xh = (z1[j] - s.sm[0][c]) * s.sm[1][c];
-    const float n1 = fmaf(xh, s.gamma1[c], s.beta1[c]);
-    const float f = fmaf(gam[j], n1, bet[j]);
-    a1[j] = f > 0.f ? f : 0.f;
-    const float df1 = f > 0.f ? da1[j] : 0.f;
-    dgam[j] = fmaf(df1, n1, dgam[j]);
-    dbet[j] = dh[j] + df1;
-    v[j] = on ? df1 * gam[j] : 0.f;          // dn1
-    w[j] = v[j] * xh;
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gam[ct][r] = s.bg[ct * 16 + li]; bet[ct][r] = s.bb[ct * 16 + li]; }
+  mma16_c(gam, s.C, s.Wg, wave, li, lq);
+  mma16_c(bet, s.C, s.Wb, wave, li, lq);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = ct * 16 + li;
+    const float g2 = s.aff[0][c], b2 = s.aff[1][c], m2 = s.sm[2][c], i2 = s.sm[3][c], su = s.sums[c], sx = s.sums[HH + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (z2[ct][r] - m2) * i2;
+      const float n2 = fmaf(xh, g2, b2);
+      const float dn2 = dh[ct][r] * gam[ct][r];
+      dz2[ct][r] = g2 * i2 * (dn2 - su - xh * sx);
+      dgam[ct][r] = dh[ct][r] * n2;
+      s.A[c * PRM_ + wave * 16 + 4 * lq + r] = dz2[ct][r];
+    }
   }
-  store8(a.A1 + (size_t)k * a.B * HH, row, q, on, a1);
-  store8(a.DG + (size_t)k * a.B * HH, row, q, on, dgam);
-  store8(a.DB + (size_t)k * a.B * HH, row, q, on, dbet);
-  store8(a.DN1, row, q, on, v);
-  wave_colsums2(v, w, lane, q, a.Q + ((size_t)(2 * k) * a.nblocks + blockIdx.x) * 2 * HH);
+  acc_rows_store(a.DZ2 + (size_t)k * a.B * HH, dz2, rowA, ok, li);
+  __syncthreads();                                   // dz2 parked
+  m16_t da1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  mma16_t(da1, s.A, s.Wf, wave, li, lq);
+  m16_t a1[2], v[2], w[2], dbet[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = ct * 16 + li;
+    const float g1 = s.aff[2][c], b1 = s.aff[3][c], m1 = s.sm[0][c], i1 = s.sm[1][c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (z1[ct][r] - m1) * i1;
+      const float n1 = fmaf(xh, g1, b1);
+      const float fv = fmaf(gam[ct][r], n1, bet[ct][r]);
+      a1[ct][r] = fv > 0.f ? fv : 0.f;
+      const float df1 = fv > 0.f ? da1[ct][r] : 0.f;
+      dgam[ct][r] = fmaf(df1, n1, dgam[ct][r]);
+      dbet[ct][r] = dh[ct][r] + df1;
+      v[ct][r] = ok[r] ? df1 * gam[ct][r] : 0.f;          // dn1
+      w[ct][r] = v[ct][r] * xh;
+    }
+  }
+  acc_rows_store(a.A1 + (size_t)k * a.B * HH, a1, rowA, ok, li);
+  acc_rows_store(a.DG + (size_t)k * a.B * HH, dgam, rowA, ok, li);
+  acc_rows_store(a.DB + (size_t)k * a.B * HH, dbet, rowA, ok, li);
+  acc_rows_store(a.DN1, v, rowA, ok, li);
+  colsums2_m(s, v, w, wave, li, lq, a.Q + ((size_t)(2 * k) * a.nblocks + blockIdx.x) * 2 * HH);
 }
 
 // kind C (block k): bn1 backward -> dz1; dh_{k-1} = dh_k + fc1^T dz1; then part a of block k-1, or the fc_in ReLU for k = 0
 struct CSeg { int fc1_w, bn1_g, bn1_b, fgp_w, fgp_b, k; };     // fgp_*: FiLM gamma of block k-1
 __global__ void __launch_bounds__(NT) g_bwd_c4_kernel(const float* __restrict__ PRM, GBwd a, CSeg f) {
-  __shared__ Smem4 s;
+  __shared__ SmemMB s;
   const int k = f.k;
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  const bool on = row < (size_t)a.B;
+  const int lane = threadIdx.x & (FT - 1), wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t rowL = (size_t)blockIdx.x * FT + lane;
+  const size_t rowA = (size_t)blockIdx.x * FT + wave * 16 + 4 * lq;
   const bool more = k > 0;                           // kernel-uniform
   const int kp = more ? k - 1 : 0;
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = rowA + r < (size_t)a.B;
   // ---- the burst (with the operands of part a of block k-1, or h0 for the fc_in ReLU)
   WRegs<HH> w_fc1; WRegs<MAXCOND> w_g; CondRegs cr; PRegs pr;
-  float z1[HQ], dn1[HQ], dh[HQ], zp[HQ], g1 = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
+  float z1[2][4], dn1[2][4], dhv[2][4], zp[2][4], g1 = 0.f, smr = 0.f, gg_old = 0.f, gb_old = 0.f;
   wload<HH>(w_fc1, PRM + f.fc1_w, nullptr);
-  load8(a.Z1 + (size_t)k * a.B * HH, row, q, on, z1);
-  load8(a.DN1, row, q, on, dn1);
-  load8(a.DH + (size_t)k * a.B * HH, row, q, on, dh);
-  load8(more ? a.Z2 + (size_t)kp * a.B * HH : a.H, row, q, on, zp);     // z2 of block k-1, or h0
+  acc_rows_load(z1, a.Z1 + (size_t)k * a.B * HH, rowA, a.B, li);
+  acc_rows_load(dn1, a.DN1, rowA, a.B, li);
+  acc_rows_load(dhv, a.DH + (size_t)k * a.B * HH, rowA, a.B, li);
+  acc_rows_load(zp, more ? a.Z2 + (size_t)kp * a.B * HH : a.H, rowA, a.B, li);     // z2 of block k-1, or h0
   if (more) {
     wload<MAXCOND>(w_g, PRM + f.fgp_w, PRM + f.fgp_b);
-    cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
+    cload(cr, a.onehot, a.mask, min(rowL, (size_t)a.B - 1), rowL < (size_t)a.B, wave);
   }
   if (threadIdx.x < HH) g1 = PRM[f.bn1_g + threadIdx.x];
   if (threadIdx.x < 4 * HH) {                        // sm[0..1]: bn1_k; sm[2..3]: bn2_{k-1} (unused for k = 0)
     const int w = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
-    const int li = w < 2 ? 2 * k : 2 * kp + 1;
-    smr = a.SM[(size_t)li * 2 * HH + (w & 1) * HH + c];
+    const int lyr = w < 2 ? 2 * k : 2 * kp + 1;
+    smr = a.SM[(size_t)lyr * 2 * HH + (w & 1) * HH + c];
   }
-  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn1_g + threadIdx.x]; gb_old = a.grads[f.bn1_b + threadIdx.x]; }   // every block
+  if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn1_g + threadIdx.x]; gb_old = a.grads[f.bn1_b + threadIdx.x]; }
   pload(pr, a.Q + (size_t)(2 * k) * a.nblocks * 2 * HH, a.nblocks);
   // ---- into LDS
-  wstore<HH, false>(s.Wt[0], nullptr, w_fc1);
-  if (more) { wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_g); cstore(s.V, cr, lane, q); }
-  if (threadIdx.x < HH) s.gamma[threadIdx.x] = g1;
-  if (threadIdx.x < 4 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
-  pstore(s, pr);
-  bnb_finish(s, a, f.bn1_g, f.bn1_b, gg_old, gb_old);
-  float dz1[HQ], t[HQ];
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float xh = (z1[j] - s.sm[0][c]) * s.sm[1][c];
-    dz1[j] = s.gamma[c] * s.sm[1][c] * (dn1[j] - s.sums[c] - xh * s.sums[HH + c]);
-  }
-  store8(a.DZ1 + (size_t)k * a.B * HH, row, q, on, dz1);
-  park8(s.V2, lane, q, dz1);
-  __syncthreads();
-  lin_tq(s.Wt[0], s.V2, lane, q, t);
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) dh[j] += t[j];
+  wstore_mb<HH>(s.Wf, nullptr, w_fc1);
   if (more) {
-    store8(a.DH + (size_t)kp * a.B * HH, row, q, on, dh);
-    bwd_part_a4(s, a, kp, on, lane, q, dh, zp, 1, 2);
+    wstore_mb<MAXCOND>(s.Wg, s.bg, w_g);
+#pragma unroll
+    for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = wave + t * NQ; if (i < MAXCOND) s.C[i * PRM_ + lane] = cr.v[t]; }
+    if (wave < MK_C - MAXCOND) s.C[(MAXCOND + wave) * PRM_ + lane] = 0.f;
+  }
+  if (threadIdx.x < HH) s.aff[2][threadIdx.x] = g1;
+  if (threadIdx.x < 4 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
+  { const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5; s.fin[part][0][c] = pr.s; s.fin[part][1][c] = pr.q; }
+  bnb_finish_m(s, a, f.bn1_g, f.bn1_b, gg_old, gb_old);
+  m16_t dz1[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = ct * 16 + li;
+    const float ga = s.aff[2][c], m1 = s.sm[0][c], i1 = s.sm[1][c], su = s.sums[c], sx = s.sums[HH + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xh = (z1[ct][r] - m1) * i1;
+      dz1[ct][r] = ga * i1 * (dn1[ct][r] - su - xh * sx);
+      s.A[c * PRM_ + wave * 16 + 4 * lq + r] = dz1[ct][r];
+    }
+  }
+  acc_rows_store(a.DZ1 + (size_t)k * a.B * HH, dz1, rowA, ok, li);
+  __syncthreads();
+  m16_t t[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  mma16_t(t, s.A, s.Wf, wave, li, lq);
+  m16_t dh[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[ct][r] = dhv[ct][r] + t[ct][r];
+  if (more) {                                        // kernel-uniform
+    acc_rows_store(a.DH + (size_t)kp * a.B * HH, dh, rowA, ok, li);
+    // part "a" of block k-1: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2)
+    m16_t gam[2], v[2], w[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gam[ct][r] = s.bg[ct * 16 + li];
+    mma16_c(gam, s.C, s.Wg, wave, li, lq);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = ct * 16 + li;
+      const float m2 = s.sm[2][c], i2 = s.sm[3][c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xh = (zp[ct][r] - m2) * i2;
+        v[ct][r] = ok[r] ? dh[ct][r] * gam[ct][r] : 0.f;
+        w[ct][r] = v[ct][r] * xh;
+      }
+    }
+    colsums2_m(s, v, w, wave, li, lq, a.Q + ((size_t)(2 * kp + 1) * a.nblocks + blockIdx.x) * 2 * HH);
     return;
   }
 #pragma unroll
-  for (int j = 0; j < HQ; ++j) dh[j] = zp[j] > 0.f ? dh[j] : 0.f;
-  store8(a.DZIN, row, q, on, dh);
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[ct][r] = zp[ct][r] > 0.f ? dh[ct][r] : 0.f;
+  acc_rows_store(a.DZIN, dh, rowA, ok, li);
 }
 
 }  // namespace
