@@ -252,44 +252,6 @@ __device__ __forceinline__ void bn_finish(Smem4& s, int B, float eps, float mome
 
 // ---- forward -------------------------------------------------------------------------------------------------------------------
 // entry segment: inp = (x, onehot, mask); h0 = relu(fc_in(inp)); z1_0 = fc1_0(h0), partial statistics
-__global__ void __launch_bounds__(NT) g_fwd_first4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
-  __shared__ Smem4 s;
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6;
-  const size_t row = (size_t)blockIdx.x * FT + lane;
-  const bool on = row < (size_t)a.B;
-  WRegs<MAXIN> w_in; WRegs<HH> w_fc1;
-  wload<MAXIN>(w_in, PRM + d.fc_in_w, PRM + d.fc_in_b);
-  wload<HH>(w_fc1, PRM + d.fc1_w[0], PRM + d.fc1_b[0]);
-  float in[(MAXIN + NQ - 1) / NQ];                   // wave q brings in inputs q, q+4, ... of its rows
-#pragma unroll
-  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
-    const int i = q + t * NQ;
-    in[t] = (!on || i >= MAXIN) ? 0.f
-          : (i < DIN ? a.x[row * DIN + i] : (i < DIN + NCLS ? a.onehot[row * NCLS + (i - DIN)] : a.mask[row * DIN + (i - DIN - NCLS)]));
-  }
-  wstore<MAXIN, true>(s.Wt[0], s.bl[0], w_in);
-  wstore<HH, true>(s.Wt[1], s.bl[1], w_fc1);
-#pragma unroll
-  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
-    const int i = q + t * NQ;
-    if (i < MAXIN) { s.V[i * FT + lane] = in[t]; if (on) a.inp[row * MAXIN + i] = in[t]; }
-  }
-  __syncthreads();
-  float h[HQ], z[HQ];
-  lin_q<MAXIN>(s.Wt[0], s.bl[0], s.V, lane, q, h);
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
-  store8(a.H, row, q, on, h);
-  park8(s.V2, lane, q, h);
-  __syncthreads();
-  lin_q<HH>(s.Wt[1], s.bl[1], s.V2, lane, q, z);
-  store8(a.Z1, row, q, on, z);
-  wave_colsums(z, on, lane, q, a.P + (size_t)blockIdx.x * 2 * HH);
-}
-
-// kind A (block k): bn1 statistics -> a1 = relu(film(bn1(z1))) ; z2 = fc2(a1), partial statistics
-// (the offsets and pointers of ONE segment travel by value — FSeg / BSeg / CSeg — so they arrive with the kernel arguments instead
-// of as a chain of dependent scalar loads indexed by k)
 struct FSeg { int fg_w, fg_b, fb_w, fb_b, fc_w, fc_b, bn_g, bn_b; float* rmean; float* rvar; int64_t* nbt; int k, li, more; };
 
 // ---- the forward segments on the matrix cores -------------------------------------------------------------------------------------
@@ -372,6 +334,97 @@ __device__ __forceinline__ void colsums_m(SmemM& s, const m16_t (&v)[2], const b
   if (threadIdx.x < 2 * HH) {
     const int st = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
     part[st * HH + c] = (s.ws[0][st][c] + s.ws[1][st][c]) + (s.ws[2][st][c] + s.ws[3][st][c]);
+  }
+}
+
+// entry segment: inp = (x, onehot, mask); h0 = relu(fc_in(inp)); z1_0 = fc1_0(h0), partial statistics — on the matrix cores like the
+// other segments (K = 38 padded to 40 for fc_in)
+constexpr int MK_IN = 40, PWI = 44;         // padded input width, fc_in's weight row pitch in LDS
+struct alignas(16) SmemF {
+  float Wi[HH * PWI], Wf[HH * PWM], bi[HH], bf[HH];
+  float IN[MK_IN * PRM_];
+  float A[HH * PRM_];
+  float ws[NQ][2][HH];
+};
+__global__ void __launch_bounds__(NT) g_fwd_first4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
+  __shared__ SmemF s;
+  const int lane = threadIdx.x & (FT - 1), wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t rowL = (size_t)blockIdx.x * FT + lane;
+  const bool onL = rowL < (size_t)a.B;
+  const size_t rowA = (size_t)blockIdx.x * FT + wave * 16 + 4 * lq;
+  bool ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok[r] = rowA + r < (size_t)a.B;
+  WRegs<MAXIN> w_in; WRegs<HH> w_fc1;
+  wload<MAXIN>(w_in, PRM + d.fc_in_w, PRM + d.fc_in_b);
+  wload<HH>(w_fc1, PRM + d.fc1_w[0], PRM + d.fc1_b[0]);
+  float in[(MAXIN + NQ - 1) / NQ];                   // wave q brings in inputs q, q+4, ... of its rows (lane = row)
+  const size_t rc = min(rowL, (size_t)a.B - 1);
+#pragma unroll
+  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
+    const int i = min(wave + t * NQ, MAXIN - 1);
+    in[t] = i < DIN ? a.x[rc * DIN + i] : (i < DIN + NCLS ? a.onehot[rc * NCLS + (i - DIN)] : a.mask[rc * DIN + (i - DIN - NCLS)]);
+  }
+#pragma unroll
+  for (int t = 0; t < (MAXIN * HH + NT - 1) / NT; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < MAXIN * HH) { const int j = e / MAXIN, i = e - j * MAXIN; s.Wi[j * PWI + i] = w_in.v[t]; }
+  }
+  for (int e = threadIdx.x; e < HH * (PWI - MAXIN); e += NT) { const int j = e / (PWI - MAXIN); s.Wi[j * PWI + MAXIN + (e - j * (PWI - MAXIN))] = 0.f; }
+  if (threadIdx.x < HH) s.bi[threadIdx.x] = w_in.b;
+  wstore_m<HH>(s.Wf, s.bf, w_fc1);
+#pragma unroll
+  for (int t = 0; t < (MAXIN + NQ - 1) / NQ; ++t) {
+    const int i = wave + t * NQ;
+    if (i < MAXIN) { const float v = onL ? in[t] : 0.f; s.IN[i * PRM_ + lane] = v; if (onL) a.inp[rowL * MAXIN + i] = v; }
+  }
+  if (wave < MK_IN - MAXIN) s.IN[(MAXIN + wave) * PRM_ + lane] = 0.f;
+  __syncthreads();
+  m16_t h[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[ct][r] = s.bi[ct * 16 + li];
+#pragma unroll
+  for (int st = 0; st < MK_IN / 4; ++st) {
+    const float av = s.IN[(4 * st + lq) * PRM_ + wave * 16 + li];
+    h[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s.Wi[li * PWI + 4 * st + lq], h[0], 0, 0, 0);
+    h[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s.Wi[(16 + li) * PWI + 4 * st + lq], h[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      h[ct][r] = h[ct][r] > 0.f ? h[ct][r] : 0.f;
+      if (ok[r]) a.H[(rowA + r) * HH + ct * 16 + li] = h[ct][r];
+      s.A[(ct * 16 + li) * PRM_ + wave * 16 + 4 * lq + r] = h[ct][r];
+    }
+  __syncthreads();
+  m16_t z[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[ct][r] = s.bf[ct * 16 + li];
+  mma16<HH / 4>(z, s.A, s.Wf, wave, li, lq);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[r]) a.Z1[(rowA + r) * HH + ct * 16 + li] = z[ct][r];
+  // column sums (as colsums_m, on this kernel's own LDS block)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float x = ok[r] ? z[ct][r] : 0.f; s1 += x; s2 += x * x; }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lq == 0) { s.ws[wave][0][ct * 16 + li] = s1; s.ws[wave][1][ct * 16 + li] = s2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * HH) {
+    const int st = threadIdx.x >> 5, c = threadIdx.x & (HH - 1);
+    a.P[(size_t)blockIdx.x * 2 * HH + st * HH + c] = (s.ws[0][st][c] + s.ws[1][st][c]) + (s.ws[2][st][c] + s.ws[3][st][c]);
   }
 }
 
