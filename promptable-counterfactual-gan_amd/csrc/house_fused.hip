@@ -121,10 +121,6 @@ __device__ __forceinline__ void pload(PRegs& r, const float* __restrict__ P, int
   for (int b = part; b < nblocks; b += NPART) { s += (double)P[(size_t)b * 2 * HH + c]; q += (double)P[(size_t)b * 2 * HH + HH + c]; }
   r.s = s; r.q = q;
 }
-__device__ __forceinline__ void pstore(Smem4& s, const PRegs& r) {
-  const int c = threadIdx.x & (HH - 1), part = threadIdx.x >> 5;
-  s.fin[part][0][c] = r.s; s.fin[part][1][c] = r.q;
-}
 struct CondRegs { float v[(MAXCOND + NQ - 1) / NQ]; };
 // cond = (one-hot target, mask): wave q brings in elements q, q+4, ... of its rows
 __device__ __forceinline__ void cload(CondRegs& r, const float* __restrict__ onehot, const float* __restrict__ mask, size_t row, bool on, int q) {
@@ -150,10 +146,6 @@ __device__ __forceinline__ void store8(float* p, size_t row, int q, bool on, con
 #pragma unroll
   for (int j = 0; j < HQ; j += 4) *reinterpret_cast<float4*>(p + row * HH + q * HQ + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
 }
-__device__ __forceinline__ void park8(float* V, int lane, int q, const float (&v)[HQ]) {
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) V[(q * HQ + j) * FT + lane] = v[j];
-}
 // The loop over the input index is unrolled by a few steps only: rolled, every step waits out its own LDS reads (~110 cycles for
 // 8 FMAs — measured 2.2 us for the two 21-step FiLM products of a segment); fully unrolled, the kernels were instruction-fetch bound.
 template <int K>
@@ -176,28 +168,6 @@ __device__ __forceinline__ void lin_q(const float* Wt, const float* bl, const fl
       for (int j = 0; j < HQ; ++j) out[j] = fmaf(w[u][j], a[u], out[j]);
   }
 }
-// two products over the same input (the FiLM gamma and beta Linears over cond): one walk
-template <int K>
-__device__ __forceinline__ void lin_q2(const float* Wa, const float* ba, const float* Wb, const float* bb, const float* V, int lane, int q,
-                                       float (&oa)[HQ], float (&ob)[HQ]) {
-  constexpr int UNR = K % 3 == 0 ? 3 : (K % 2 == 0 ? 2 : 1);
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) { oa[j] = ba[q * HQ + j]; ob[j] = bb[q * HQ + j]; }
-#pragma unroll 1
-  for (int i0 = 0; i0 < K; i0 += UNR) {
-    float a[UNR], wa[UNR][HQ], wb[UNR][HQ];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      a[u] = V[(i0 + u) * FT + lane];
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) { wa[u][j] = Wa[(i0 + u) * HH + q * HQ + j]; wb[u][j] = Wb[(i0 + u) * HH + q * HQ + j]; }
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) { oa[j] = fmaf(wa[u][j], a[u], oa[j]); ob[j] = fmaf(wb[u][j], a[u], ob[j]); }
-  }
-}
 // Sums over the wave's 64 lanes of 8 values per lane, as a halving butterfly: at distance 32 a lane keeps four of its channels and
 // hands the other four to its partner, at 16 two, at 8 one; three plain steps finish.  10 exchanges instead of 48 (a full butterfly
 // per channel measured 2.2 us per segment: the exchanges are LDS-crossbar round trips), a fixed order.  The total of channel c
@@ -214,42 +184,6 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[HQ], int lane) {
   r1 += __shfl_xor(r1, 4); r1 += __shfl_xor(r1, 2); r1 += __shfl_xor(r1, 1);
   return r1;
 }
-// column sums of v and v*v over the block's 64 rows for this wave's 8 channels -> part[2][HH]
-__device__ __forceinline__ void wave_colsums(const float (&v)[HQ], bool on, int lane, int q, float* part) {
-  float a[HQ], b[HQ];
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) { a[j] = on ? v[j] : 0.f; b[j] = a[j] * a[j]; }
-  const float s1 = wave_sum8(a, lane), s2 = wave_sum8(b, lane);
-  if ((lane & 7) == 0) { part[q * HQ + (lane >> 3)] = s1; part[HH + q * HQ + (lane >> 3)] = s2; }
-}
-
-// mean / invstd of a BatchNorm from the partial statistics parked in s.fin; block 0 also maintains the module's buffers (their old
-// values came in with the burst: rm_old / rv_old, valid in threads < 32 of block 0)
-__device__ __forceinline__ void bn_finish(Smem4& s, int B, float eps, float momentum, float* save, float* rmean, float* rvar, int64_t* nbt,
-                                          float rm_old, float rv_old) {
-  __syncthreads();                                   // s.fin and the LDS images of the burst are complete
-  if (threadIdx.x < HH) {
-    double sm = 0.0, q = 0.0;
-#pragma unroll
-    for (int p = 0; p < NPART; ++p) { sm += s.fin[p][0][threadIdx.x]; q += s.fin[p][1][threadIdx.x]; }
-    const double mean = sm / B;
-    double var = q / B - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float inv = (float)(1.0 / sqrt(var + (double)eps));
-    s.mean[threadIdx.x] = (float)mean; s.inv[threadIdx.x] = inv;
-    if (blockIdx.x == 0) {
-      save[threadIdx.x] = (float)mean; save[HH + threadIdx.x] = inv;
-      if (rmean) {
-        const double unb = B > 1 ? var * (double)B / (double)(B - 1) : var;
-        rmean[threadIdx.x] = (float)((1.0 - momentum) * rm_old + momentum * mean);
-        rvar[threadIdx.x] = (float)((1.0 - momentum) * rv_old + momentum * unb);
-        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // ---- forward -------------------------------------------------------------------------------------------------------------------
 // entry segment: inp = (x, onehot, mask); h0 = relu(fc_in(inp)); z1_0 = fc1_0(h0), partial statistics
 struct FSeg { int fg_w, fg_b, fb_w, fb_b, fc_w, fc_b, bn_g, bn_b; float* rmean; float* rvar; int64_t* nbt; int k, li, more; };
@@ -784,42 +718,6 @@ struct GBwd {
   float tau, res_scale;
 };
 
-// sums of one BatchNorm backward from the partials parked in s.fin -> s.sums (means); block 0 writes dgamma / dbeta (their old
-// values, for the accumulate case, came in with the burst)
-__device__ __forceinline__ void bnb_finish(Smem4& s, const GBwd& a, int g_off, int b_off, float gg_old, float gb_old) {
-  __syncthreads();
-  if (threadIdx.x < HH) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int p = 0; p < NPART; ++p) { s1 += s.fin[p][0][threadIdx.x]; s2 += s.fin[p][1][threadIdx.x]; }
-    s.sums[threadIdx.x] = (float)(s1 / a.B); s.sums[HH + threadIdx.x] = (float)(s2 / a.B);
-    if (blockIdx.x == 0) {
-      a.grads[g_off + threadIdx.x] = a.accumulate ? gg_old + (float)s2 : (float)s2;
-      a.grads[b_off + threadIdx.x] = a.accumulate ? gb_old + (float)s1 : (float)s1;
-    }
-  }
-  __syncthreads();
-}
-
-// out[8] = sum_j Wl[j][8q + .] * V[j][row]      (Wl = the Linear's weight as stored, [out j][in i]: gradient w.r.t. its input)
-__device__ __forceinline__ void lin_tq(const float* Wl, const float* V, int lane, int q, float (&out)[HQ]) {
-#pragma unroll
-  for (int i = 0; i < HQ; ++i) out[i] = 0.f;
-#pragma unroll 1
-  for (int j0 = 0; j0 < HH; j0 += 4) {
-    float a[4], w[4][HQ];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u] = V[(j0 + u) * FT + lane];
-#pragma unroll
-      for (int i = 0; i < HQ; ++i) w[u][i] = Wl[(j0 + u) * HH + q * HQ + i];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int i = 0; i < HQ; ++i) out[i] = fmaf(w[u][i], a[u], out[i]);
-  }
-}
 // column sums of v and w over the block's 64 rows for this wave's 8 channels -> part[2][HH]
 __device__ __forceinline__ void wave_colsums2(const float (&v)[HQ], const float (&w)[HQ], int lane, int q, float* part) {
   const float s1 = wave_sum8(v, lane), s2 = wave_sum8(w, lane);
