@@ -9,7 +9,8 @@
     optimizers :118-119                            make_optimizers (AdamW lr 1e-4, betas (0, 0.9))
     critic update :133-155                         critic_step       (gradient penalty :146-150 = gradient_penalty / interpolate)
     generator update :157-168                      generator_step
-    loop :129-168                                  train (draws on the device)
+    loop :129-168                                  train (draws on the device; graphed=True replays GraphedSteps)
+    -                                              GraphedSteps: both updates captured once as HIP graphs, one host call each
 
 The gradient penalty needs the gradient of the critic output with respect to its input image as a DIFFERENTIABLE quantity
 (`autograd.grad(..., create_graph=True)`, :149) and then `critic_loss.backward()` (:154) differentiates through it.  The
@@ -25,7 +26,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import ACT_LRELU, PcgError
-from .nn import FlatModule, SequentialConvNet, _compile, linear_dgrad, linear_fwd, linear_wgrad, mean
+from .nn import FlatModule, GraphedStep, SequentialConvNet, _compile, linear_dgrad, linear_fwd, linear_wgrad, mean
 from .optim import AdamW
 
 
@@ -435,10 +436,54 @@ def generator_step(critic, generator, generator_optimizer, fake_class_labels, no
     return {"generator_loss": generator_loss}
 
 
-def train(critic, generator, dataloader, hp, device, rng=None, epochs=None):
+class GraphedSteps:
+    """The two updates of the loop body (:133-155, :157-168) captured once each as HIP graphs (nn.GraphedStep) and replayed with
+    one host call per update: at 256 images per GPU an update is ~70 / ~115 kernel launches of 5-200 us, and launched one by one
+    the host leaves the GPU idle for a quarter of the iteration.  The draws stay outside the graphs (a captured Philox draw would
+    replay the same numbers): the caller passes noise / alpha / labels exactly as to critic_step / generator_step and they are
+    copied into the static inputs the graphs read.  Results are bit-identical to the eager calls (same kernels, same order).
+
+        gs = GraphedSteps(critic, generator, c_opt, g_opt, hp, B, device)
+        out = gs.critic_step(images, onehot, noise, alpha);  out = gs.generator_step(fake_onehot, noise)
+
+    Data-parallel: pass the parallel.GradSync as `dp`; each graph is cut at its gradient exchange (nn.GraphedStep)."""
+
+    def __init__(self, critic, generator, critic_optimizer, generator_optimizer, hp, B, device, dp=None, warmup=2):
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+        self.B = int(B)
+        self._c_in = {"images": z(B, 1, 28, 28), "labels": z(B, hp.num_classes), "noise": z(B, hp.latent_size), "alpha": z(B, 1)}
+        self._g_in = {"labels": z(B, hp.num_classes), "noise": z(B, hp.latent_size)}
+        ops.fill(self._c_in["alpha"], 0.5)
+        for d in (self._c_in, self._g_in):                       # one-hot rows: the warm-up steps run on well-formed inputs
+            d["labels"][:, 0] = 1.0
+        ci, gi = self._c_in, self._g_in
+        mods, opts = [critic, generator], [critic_optimizer, generator_optimizer]
+        cfn = lambda d=None: critic_step_batched(critic, generator, critic_optimizer, hp, ci["images"], ci["labels"], ci["noise"], ci["alpha"], dp=d)
+        gfn = lambda d=None: generator_step(critic, generator, generator_optimizer, gi["labels"], gi["noise"], dp=d)
+        self._critic = GraphedStep(cfn, ci, mods, opts, warmup=warmup, dp=dp)
+        self._generator = GraphedStep(gfn, gi, mods, opts, warmup=warmup, dp=dp)
+
+    def _check(self, t):
+        if t.shape[0] != self.B:
+            raise PcgError(f"GraphedSteps was captured for batches of {self.B} rows, got {t.shape[0]} (run the ragged last batch eagerly)")
+
+    def critic_step(self, real_images, real_class_labels, noise, alpha):
+        self._check(real_images)
+        self._critic.load(images=real_images, labels=real_class_labels, noise=noise, alpha=alpha)
+        return self._critic.replay()
+
+    def generator_step(self, fake_class_labels, noise):
+        self._check(fake_class_labels)
+        self._generator.load(labels=fake_class_labels, noise=noise)
+        return self._generator.replay()
+
+
+def train(critic, generator, dataloader, hp, device, rng=None, epochs=None, graphed=False):
     """:129-189 without the plotting tail: `dataloader` yields (images [B,1,28,28], class indices [B]); one-hot rows come from
-    an identity table (:123,133); noise / alpha / fake labels are drawn on the device."""
+    an identity table (:123,133); noise / alpha / fake labels are drawn on the device.  graphed=True: full batches of hp.batchsize
+    rows replay GraphedSteps (same numbers); a ragged last batch runs eagerly."""
     critic_optimizer, generator_optimizer = make_optimizers(critic, generator)
+    gs = GraphedSteps(critic, generator, critic_optimizer, generator_optimizer, hp, hp.batchsize, device) if graphed else None
     rng = rng if rng is not None else ops.DeviceRNG(seed=1)
     history = []
     generator_loss = None
@@ -449,12 +494,15 @@ def train(critic, generator, dataloader, hp, device, rng=None, epochs=None):
             images, labels = images.to(device), labels.to(device)
             B = images.shape[0]
             onehot = ops.onehot(labels, hp.num_classes)                                  # all_labels[data[1]] (:133)
-            out = critic_step(critic, generator, critic_optimizer, hp, images, onehot, rng.randn((B, hp.latent_size), device),
-                              rng.rand((B, 1), device))
+            replay = gs is not None and B == gs.B
+            noise, alpha = rng.randn((B, hp.latent_size), device), rng.rand((B, 1), device)
+            out = (gs.critic_step(images, onehot, noise, alpha) if replay else
+                   critic_step(critic, generator, critic_optimizer, hp, images, onehot, noise, alpha))
             if batch_idx % hp.n_critic == 0:                                             # :157
                 fake_labels = ops.onehot(rng.randint(0, hp.num_classes, B, device), hp.num_classes)   # :161
-                generator_loss = generator_step(critic, generator, generator_optimizer, fake_labels,
-                                                rng.randn((B, hp.latent_size), device))["generator_loss"]
+                noise = rng.randn((B, hp.latent_size), device)
+                generator_loss = (gs.generator_step(fake_labels, noise) if replay else
+                                  generator_step(critic, generator, generator_optimizer, fake_labels, noise))["generator_loss"]
             d_sum += out["critic_loss"].item(); g_sum += generator_loss.item()           # :177-178
             n += 1
         history.append((d_sum / max(n, 1), g_sum / max(n, 1)))

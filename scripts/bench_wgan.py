@@ -39,20 +39,29 @@ def main():
     lab = ops.onehot(rng.randint(0, 10, B, dev), 10)
     records = []
 
-    def cstep(i):
-        return W.critic_step(critic, generator, c_opt, hp, x, lab, rng.randn((B, hp.latent_size), dev), rng.rand((B, 1), dev), dp=dp)
+    gs = None if args.eager else W.GraphedSteps(critic, generator, c_opt, g_opt, hp, B, dev, dp=dp)
 
-    def gstep(i):
-        return W.generator_step(critic, generator, g_opt, ops.onehot(rng.randint(0, 10, B, dev), 10), rng.randn((B, hp.latent_size), dev), dp=dp)
+    # the draws of an iteration (noise :141, alpha :146, fake labels :161, noise :162) are launched eagerly in front of each replay
+    def cstep(i, eager=False):
+        noise, alpha = rng.randn((B, hp.latent_size), dev), rng.rand((B, 1), dev)
+        if gs is None or eager:
+            return W.critic_step(critic, generator, c_opt, hp, x, lab, noise, alpha, dp=dp)
+        return gs.critic_step(x, lab, noise, alpha)
+
+    def gstep(i, eager=False):
+        fake, noise = ops.onehot(rng.randint(0, 10, B, dev), 10), rng.randn((B, hp.latent_size), dev)
+        if gs is None or eager:
+            return W.generator_step(critic, generator, g_opt, fake, noise, dp=dp)
+        return gs.generator_step(fake, noise)
 
     def measure(fn):
         for i in range(args.warmup):
             fn(i)
         mid = args.steps // 2
 
-        def one(i):
+        def one(i):                                       # one timed update runs eagerly with HIP events around every conv launch
             ops.set_conv_hook((lambda *r: records.append(r)) if i == mid else None)
-            return fn(i)
+            return fn(i, eager=(i == mid))
         dt, out = R.timed(one, args.steps)
         ops.set_conv_hook(None)
         return dt / args.steps, out
@@ -97,7 +106,8 @@ def main():
                        "global_batch": R.world * B, "parallelism": f"dp{R.world}"},
             "critic_update_ms": round(tc * 1e3, 3), "generator_update_ms": round(tg * 1e3, 3),
             "roofline": roof, "cpu_baseline": cpu, "final_losses": losses,
-            "rccl_ranks": None if dp is None else dp.rccl_ranks(), "replicas_identical": same, "launch": "eager",
+            "rccl_ranks": None if dp is None else dp.rccl_ranks(), "replicas_identical": same,
+            "launch": "eager" if gs is None else "hip-graph replay (one graph per update); 1 of the timed updates of each kind eager with HIP events",
         })
     R.finish()
 

@@ -245,3 +245,51 @@ def test_train_loop_on_device_draws(pcg):
     assert any(not torch.equal(before[k], v) for k, v in generator.state_dict().items())
     a = ops.DeviceRNG(9).rand((4096,), torch.device(DEV))
     assert 0.0 <= float(a.min()) and float(a.max()) < 1.0 and abs(float(a.mean()) - 0.5) < 0.02
+
+
+def test_graphed_updates_equal_the_eager_updates_bitwise(pcg):
+    """wgan.GraphedSteps (both updates replayed from HIP graphs) against critic_step / generator_step launched kernel by kernel:
+    same parameters, optimizer state and logged losses after every update of three loop iterations; then train(graphed=True)
+    against train(graphed=False) on the same batches and the same device draws, ragged last batch included."""
+    W, ops = pcg.wgan, pcg.ops
+    dev = torch.device(DEV)
+    hp = W.Hyperparameter(critic_size=32, generator_size=32, critic_hidden_size=32, batchsize=16, n_critic=2)
+    B = hp.batchsize
+
+    def fresh():
+        critic, generator = W.build(dev, hp, seed=5)
+        return (critic, generator) + W.make_optimizers(critic, generator)
+
+    ce, ge, coe, goe = fresh()
+    cg, gg, cog, gog = fresh()
+    gs = W.GraphedSteps(cg, gg, cog, gog, hp, B, dev)
+    for m_e, m_g in ((ce, cg), (ge, gg)):                         # building the graphs does not advance training
+        for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+            assert torch.equal(a, b), k
+    rng = ops.DeviceRNG(11)
+    for it in range(3):
+        x = rng.rand((B, 1, 28, 28), dev).mul_(2.0).sub_(1.0)
+        lab = ops.onehot(rng.randint(0, 10, B, dev), 10)
+        noise, alpha = rng.randn((B, hp.latent_size), dev), rng.rand((B, 1), dev)
+        oe = W.critic_step(ce, ge, coe, hp, x, lab, noise, alpha)
+        og = gs.critic_step(x, lab, noise, alpha)
+        for k in ("critic_loss", "loss_real", "loss_fake", "gradient_penalty", "gradients", "fake_image"):
+            assert torch.equal(oe[k], og[k]), (it, k)
+        fake, noise = ops.onehot(rng.randint(0, 10, B, dev), 10), rng.randn((B, hp.latent_size), dev)
+        le = W.generator_step(ce, ge, goe, fake, noise)["generator_loss"]
+        lg = gs.generator_step(fake, noise)["generator_loss"]
+        assert torch.equal(le, lg), it
+        for m_e, m_g in ((ce, cg), (ge, gg)):
+            for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+                assert torch.equal(a, b), (it, k)
+    with pytest.raises(pcg.PcgError):
+        gs.critic_step(x[:5], lab[:5], noise[:5], alpha[:5])
+    # the loop
+    data = [(torch.rand(n, 1, 28, 28) * 2 - 1, torch.randint(0, 10, (n,))) for n in (B, B, B, 5)]
+    c1, g1 = W.build(dev, hp, seed=2)
+    c2, g2 = W.build(dev, hp, seed=2)
+    h1 = W.train(c1, g1, data, hp, dev, rng=ops.DeviceRNG(3), epochs=2)
+    h2 = W.train(c2, g2, data, hp, dev, rng=ops.DeviceRNG(3), epochs=2, graphed=True)
+    assert h1 == h2
+    for (k, a), (_, b) in zip(g1.state_dict().items(), g2.state_dict().items()):
+        assert torch.equal(a, b), k
