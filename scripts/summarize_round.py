@@ -60,7 +60,7 @@ r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --w
 if r:
     shutil.copy(r[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
 stats_md("countergan", f"{tag}_countergan_kernel_stats.md", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 (batch 1024)", 10)
-stats_md("wgan", f"{tag}_wgan_kernel_stats.md", "python3 scripts/bench_wgan.py --steps 10 --warmup 2 (12 critic updates + 12 generator updates; per-launch averages)", 24)
+stats_md("wgan", f"{tag}_wgan_kernel_stats.md", "python3 scripts/bench_wgan.py --steps 10 --warmup 2 (14 critic updates + 14 generator updates executed: 2 capture warm-ups, 2 warm-ups, 10 timed of each kind; a \"step\" in the table is the average update)", 28)
 
 # house: launches per step = dispatches between two consecutive house_draws_kernel launches in the steady state
 trace = find("house", "*kernel_trace.csv")
