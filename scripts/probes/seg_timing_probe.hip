@@ -43,7 +43,7 @@ int main() {
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int b = 0; b < 64; ++b) { if (h[b * 16] < t0) t0 = h[b * 16]; if (h[b * 16 + 7] > t1) t1 = h[b * 16 + 7]; }
   printf("g_fwd_a4 (k = 4), 10 ns ticks; first block entry -> last block exit: %.2f us\n", (t1 - t0) * 0.01);
-  const char* names[8] = {"entry", "burst issued", "in LDS (loads back)", "bn_finish", "FiLM lin_q x2", "a1 parked + barrier", "fc2 lin_q", "store + colsums"};
+  const char* names[8] = {"entry", "burst issued", "in LDS (loads back)", "bn_finish", "FiLM products (MFMA) x2", "a1 parked + barrier", "fc2 product (MFMA)", "store + colsums"};
   for (int b : {0, 1, 31, 63}) {
     printf("block %2d: entry at +%.2f us;", b, (h[b * 16] - t0) * 0.01);
     for (int i = 1; i < 8; ++i) printf("  %s %.2f", names[i], (h[b * 16 + i] - h[b * 16 + i - 1]) * 0.01);
