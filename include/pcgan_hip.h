@@ -533,7 +533,8 @@ typedef struct pcg_house_g_bwd_args {
   float *DG, *DB;                            /* out [5][B][32]: gradients at the FiLM gamma / beta Linear outputs */
   float* DZIN;                               /* out [B][32]: gradient at fc_in's output */
   float *DL, *DC;                            /* out [B][T], [B][ncont]: gradients at the head outputs */
-  float* Q;                                  /* scratch [10][ceil(B/64)][2][32] */
+  float* Q;                                  /* scratch [9 * ceil(B/64) + ceil(B/16)][2][32]: per-block partial sums of the ten BatchNorm backwards
+                                                (64-row blocks; the last bn2's come from the 16-row head kernel) */
   int32_t B, accumulate;
   float tau, res_scale;
 } pcg_house_g_bwd_args;

@@ -1,7 +1,7 @@
 // house_fused.hip — the tabular ResidualGenerator (house_sales_kc_usa/models/generator.py:38-92) as a chain of "segment"
-// kernels.  Every tensor of this net is [B][32] and every weight matrix is at most 38 wide: a block owns 64 batch rows (lane = row)
-// and four waves that each carry 8 of the 32 channels in registers (the entry segment still gives a thread the whole row); the
-// weights of a segment sit in LDS and are read as broadcasts, the rows' input vectors are parked in LDS between layers.  The only
+// kernels.  Every tensor of this net is [B][32] and every weight matrix is at most 38 wide: a block owns 64 batch rows and four
+// waves, every product runs on v_mfma_f32_16x16x4_f32 (exact fp32) with the activations parked k-major in LDS and the weights
+// staged as stored, and the BatchNorm / FiLM / ReLU arithmetic is done on the accumulator layout.  The only
 // cross-row dependencies are the ten BatchNorm1d batch statistics, so the net is cut there: a segment ends by writing its
 // pre-BatchNorm activations plus per-block column sums, and the next segment starts by turning those sums into mean / invstd
 // (fixed order, fp64) — the kernel boundary is the grid barrier.  (A persistent launch whose blocks meet at an arrival counter in
@@ -53,42 +53,16 @@ struct GBufs {
 
 struct BNState { float* running_mean[2 * NBLK]; float* running_var[2 * NBLK]; int64_t* nbt[2 * NBLK]; };
 
-__device__ __forceinline__ void load32(const float* p, size_t row, bool on, float (&v)[HH]) {
-#pragma unroll
-  for (int j = 0; j < HH; j += 4) {
-    float4 q = on ? *reinterpret_cast<const float4*>(p + row * HH + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-  }
-}
-__device__ __forceinline__ void store32(float* p, size_t row, bool on, const float (&v)[HH]) {
-  if (!on) return;
-#pragma unroll
-  for (int j = 0; j < HH; j += 4) *reinterpret_cast<float4*>(p + row * HH + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-}
-
 // ---- layout of a block ---------------------------------------------------------------------------------------------------------
-// A block is 64 rows (lane = row) and four waves, each owning 8 of the 32 channels: its quarter of every matrix-vector product
-// (weights staged transposed in LDS by all 256 threads and read as broadcasts — rolled loops over the input index: fully unrolled
-// 32x32 products made the kernels instruction-fetch bound —, the rows' input vectors parked in LDS), of the BatchNorm / FiLM /
-// residual arithmetic and of the per-block column sums (wave butterfly, fixed order).  One thread per row alone ran 4096 rows as
-// 64 waves on a chip with 1024 SIMDs.
+// A segment block is 64 rows and four waves (256 threads); wave w owns rows 16 w .. 16 w + 15 and both 16-channel tiles of every
+// product (v_mfma_f32_16x16x4_f32, see "the forward segments on the matrix cores" below).  The two head kernels use 16-row blocks.
 //
 // What a segment costs is latency, not work: a launch boundary is ~2 us, but every DEPENDENT global load behind it is a cold miss
 // (~1-2 us), and the first version had four or five of them in a row (statistics -> barrier -> weights -> barrier -> rows ->
 // barrier -> next weights).  So each segment starts with ONE burst: every weight image, the rows' operands, the BatchNorm
 // partials and whatever block 0 will update are requested into registers before the first barrier; the rest runs out of LDS.
-constexpr int NQ = 4, HQ = HH / NQ, NT = FT * NQ;
+constexpr int NQ = 4, NT = FT * NQ;
 constexpr int NPART = NT / HH;              // 8 threads per column add the per-block partial statistics
-struct alignas(16) Smem4 {
-  float gamma[HH], beta[HH], mean[HH], inv[HH];
-  float gamma1[HH], beta1[HH];     // backward kind B: bn1's affine pair next to bn2's
-  float sm[4][HH];                 // backward: saved mean / invstd of the (up to two) BatchNorms a segment touches
-  float Wt[3][MAXIN * HH];         // weight images: FiLM gamma + beta (21 x 32 each, transposed [i][j]) and one 32 x 32 Linear; fc_in is 38 x 32
-  float bl[3][HH];
-  float V[MAXIN * FT], V2[HH * FT];   // parked input vectors [i][row]
-  float sums[2 * HH];              // backward: mean(dz), mean(dz * xhat) of the BatchNorm in flight
-  double fin[NPART][2][HH];        // partial statistics on their way to the 32 finishing threads
-};
 
 // -- the burst: global -> registers ------------------------------------------------------------------------------------------
 template <int K>
@@ -98,19 +72,6 @@ __device__ __forceinline__ void wload(WRegs<K>& r, const float* __restrict__ W, 
 #pragma unroll
   for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) r.v[t] = W[min((int)threadIdx.x + t * NT, K * HH - 1)];   // clamped, not guarded: a guard is a branch per load
   r.b = b ? b[threadIdx.x & (HH - 1)] : 0.f;
-}
-// registers -> LDS, transposed ([i][j]: the forward product reads 8 consecutive outputs of one input) or as stored ([j][i])
-template <int K, bool TRANSPOSE>
-__device__ __forceinline__ void wstore(float* Wl, float* bl, const WRegs<K>& r) {
-#pragma unroll
-  for (int t = 0; t < (K * HH + NT - 1) / NT; ++t) {
-    const int e = threadIdx.x + t * NT;
-    if (e < K * HH) {
-      if (TRANSPOSE) { const int j = e / K, i = e - j * K; Wl[i * HH + j] = r.v[t]; }
-      else Wl[e] = r.v[t];
-    }
-  }
-  if (bl && threadIdx.x < HH) bl[threadIdx.x] = r.b;
 }
 // per-block partial sums [nblocks][2][HH] -> this thread's share (column c = tid & 31, blocks part, part + 8, ...: fixed order, fp64)
 struct PRegs { double s, q; };
@@ -129,60 +90,6 @@ __device__ __forceinline__ void cload(CondRegs& r, const float* __restrict__ one
     const int i = min(q + t * NQ, MAXCOND - 1);     // (row is clamped by the caller: rows past the batch read the last row and are masked later)
     r.v[t] = i < NCLS ? onehot[row * NCLS + i] : mask[row * DIN + (i - NCLS)];
   }
-}
-__device__ __forceinline__ void cstore(float* V, const CondRegs& r, int lane, int q) {
-#pragma unroll
-  for (int t = 0; t < (MAXCOND + NQ - 1) / NQ; ++t) { const int i = q + t * NQ; if (i < MAXCOND) V[i * FT + lane] = r.v[t]; }
-}
-__device__ __forceinline__ void load8(const float* p, size_t row, int q, bool on, float (&v)[HQ]) {
-#pragma unroll
-  for (int j = 0; j < HQ; j += 4) {
-    const float4 t = on ? *reinterpret_cast<const float4*>(p + row * HH + q * HQ + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
-  }
-}
-__device__ __forceinline__ void store8(float* p, size_t row, int q, bool on, const float (&v)[HQ]) {
-  if (!on) return;
-#pragma unroll
-  for (int j = 0; j < HQ; j += 4) *reinterpret_cast<float4*>(p + row * HH + q * HQ + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-}
-// The loop over the input index is unrolled by a few steps only: rolled, every step waits out its own LDS reads (~110 cycles for
-// 8 FMAs — measured 2.2 us for the two 21-step FiLM products of a segment); fully unrolled, the kernels were instruction-fetch bound.
-template <int K>
-__device__ __forceinline__ void lin_q(const float* Wt, const float* bl, const float* V, int lane, int q, float (&out)[HQ]) {
-  constexpr int UNR = K % 4 == 0 ? 4 : (K % 3 == 0 ? 3 : (K % 2 == 0 ? 2 : 1));
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) out[j] = bl[q * HQ + j];
-#pragma unroll 1
-  for (int i0 = 0; i0 < K; i0 += UNR) {
-    float a[UNR], w[UNR][HQ];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      a[u] = V[(i0 + u) * FT + lane];
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) w[u][j] = Wt[(i0 + u) * HH + q * HQ + j];
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) out[j] = fmaf(w[u][j], a[u], out[j]);
-  }
-}
-// Sums over the wave's 64 lanes of 8 values per lane, as a halving butterfly: at distance 32 a lane keeps four of its channels and
-// hands the other four to its partner, at 16 two, at 8 one; three plain steps finish.  10 exchanges instead of 48 (a full butterfly
-// per channel measured 2.2 us per segment: the exchanges are LDS-crossbar round trips), a fixed order.  The total of channel c
-// ends in lane 8 * c.
-__device__ __forceinline__ float wave_sum8(const float (&v)[HQ], int lane) {
-  static_assert(HQ == 8, "three halving steps");
-  float r4[4], r2[2], r1;
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const float keep = b5 ? v[j + 4] : v[j], send = b5 ? v[j] : v[j + 4]; r4[j] = keep + __shfl_xor(send, 32); }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const float keep = b4 ? r4[j + 2] : r4[j], send = b4 ? r4[j] : r4[j + 2]; r2[j] = keep + __shfl_xor(send, 16); }
-  { const float keep = b3 ? r2[1] : r2[0], send = b3 ? r2[0] : r2[1]; r1 = keep + __shfl_xor(send, 8); }
-  r1 += __shfl_xor(r1, 4); r1 += __shfl_xor(r1, 2); r1 += __shfl_xor(r1, 1);
-  return r1;
 }
 // ---- forward -------------------------------------------------------------------------------------------------------------------
 // entry segment: inp = (x, onehot, mask); h0 = relu(fc_in(inp)); z1_0 = fc1_0(h0), partial statistics
@@ -521,31 +428,34 @@ __global__ void __launch_bounds__(NT) g_fwd_b4_kernel(const float* __restrict__ 
 }
 
 // ---- output heads ----------------------------------------------------------------------------------------------------------------
-// The continuous residual head and the categorical heads as ONE product on the matrix cores — out[64 rows][T + ncont columns] =
-// h_5 W^T + b over the packed weight rows of all heads — followed by the per-(row, head) Gumbel-softmax.
-//   * the weight rows are staged as stored ([column][32]) with a pitch of 33 floats: B[k][n] = W[n][k] is a column walk, bank =
-//     n + k (conflict-free); h_5 comes in k-major ([k][row], pitch 65); logits and noise sit in [row][column] tiles of pitch 97;
-//   * waves 0-2 own one 32-column tile each (both 32-row tiles: two accumulators), 16 MFMA steps per tile;
-//   * the softmax of a (row, head) is shared by TWO lanes (the head's columns split in two, max and sum exchanged at distance 32),
-//     so a wave covers 32 rows of a head and the widest head (30 columns) costs 15 column visits per pass, not 30; the host deals
-//     the 2 x nheads (head, row-half) units to the four waves by cost.
-// The first version (a lane per row walking its heads, weights as LDS broadcasts) was bound by LDS bandwidth in the dot products
-// (9.7 us) and by the 30-wide head's serial softmax on one wave (7 us): 24 us per launch.
-struct HeadOwner { signed char owner[2 * MAXHEADS]; };   // [2 * head + row-half] -> wave
-constexpr int NCOLT = 3, MAXCOLS = NCOLT * 32;          // packed categorical + continuous columns <= 96 (host-checked)
-constexpr int TP = MAXT + 1;                // row pitch of the LDS tiles (odd: lane-per-row accesses are conflict-free)
-constexpr int WPH = HH + 1, HPK = FT + 1;   // pitches of the staged weight rows and of k-major h_5
-typedef float hd_acc_t __attribute__((ext_vector_type(16)));
+// The continuous residual head and the categorical heads as ONE product on the matrix cores — out[rows][T + ncont columns] =
+// h_5 W^T + b over the packed weight rows of all heads — followed by the per-(row, head) Gumbel-softmax.  A block owns HR = 16 rows
+// (4096 rows = 256 blocks: the 64-row form of this kernel kept 64 of the 256 CUs busy for 19 us — 3.5 us of products, 5 us of
+// softmax rounds, 3.5 us of tile stores per block — where a 16-row block does a quarter of each):
+//   * the weight rows are staged as stored ([column][32], pitch 36: B[k][n] = W[n][k], banks 4 li + lq); h_5 comes in k-major
+//     ([k][16 rows]); logits, noise and the backward's cotangents sit in [16][T] tiles of pitch 100 (36 mod 64: a 16-row column
+//     walk of the MFMA's A operand is conflict-free);
+//   * wave q owns the 16-column tiles q and q + 4 (v_mfma_f32_16x16x4_f32, 8 steps per tile);
+//   * the softmax of a (row, head) is shared by TWO lanes (the head's columns split in two, max and sum exchanged at distance 32):
+//     16 rows x 7 heads x 2 lanes fit the block's 256 threads in one round, the widest head (30 columns) costs 15 column visits.
+// (The first version — a lane per row walking its heads, weights as LDS broadcasts — was bound by LDS bandwidth in the dot products
+// and by the 30-wide head's serial softmax on one wave: 24 us per launch.)
+constexpr int HR = 16;                      // rows per block of the two head kernels
+constexpr int MAXCOLS = 96;                 // packed categorical + continuous columns (host-checked)
+constexpr int TP = 100;                     // row pitch of the [HR][T] LDS tiles
 struct alignas(16) SmemHeads {
-  float W[MAXCOLS * WPH];                   // head weight rows as stored; backward: the same (B[k = column][n = input])
+  float W[MAXCOLS * PWM];                   // head weight rows as stored; the backward reads the same image as B[k = column][n = input]
   float b[MAXCOLS];
-  float Hk[HH * HPK];                       // forward: h_5 k-major; backward: the four partial dh tiles reuse this and ct
-  float lg[FT * TP];                        // logits; backward: d_logits in, dl out (+ the continuous head's gradient in columns T ..)
-  float ns[FT * TP];                        // noise -> (logit + noise) / tau -> soft sample; backward: soft
-  float ds[FT * TP];                        // backward: d_samples
-  float ct[FT * (HH + 1)];                  // continuous head
+  float Hk[HH * HR];                        // forward: h_5 k-major
+  float lg[HR * TP];                        // logits; backward: d_logits in, dl out (+ the continuous head's gradient in columns T ..)
+  float ns[HR * TP];                        // noise -> (logit + noise) / tau -> soft sample; backward: soft
+  float ds[HR * TP];                        // backward: d_samples
+  float ct[HR * (HH + 1)];                  // continuous head
+  float Wg[HH * PWM], bg[HH];               // backward: FiLM gamma of the last block (part a)
+  float C[MK_C * HR];                       // backward: cond, k-major
+  float sm[2][HH];                          // backward: saved mean / invstd of the last bn2
+  int seg[MAXHEADS + 1];
 };
-__device__ __forceinline__ int hd_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 // flat-parameter offsets of output column c (categorical columns 0 .. T-1, then the continuous head); -1 past the last column
 struct ColSrc { int w, b; };
 __device__ __forceinline__ ColSrc col_src(const GDesc& d, int c, int T) {
@@ -559,8 +469,8 @@ __device__ __forceinline__ ColSrc col_src(const GDesc& d, int c, int T) {
   return r;
 }
 constexpr int HW_PER = MAXCOLS * HH / NT;   // 12 weight elements per thread
-constexpr int TILE_PER = (FT * MAXT + NT - 1) / NT;   // 24 tile elements per thread
-// coalesced [rows][T] global tile <-> LDS tile [FT][TP]; element e = tid + 256 t sits at (e / T, e % T), walked incrementally (a
+constexpr int TILE_PER = (HR * MAXT + NT - 1) / NT;   // 6 tile elements per thread
+// coalesced [rows][T] global tile <-> LDS tile [HR][TP]; element e = tid + 256 t sits at (e / T, e % T), walked incrementally (a
 // division by the runtime T per element was a sixth of the kernel)
 struct TileWalk { int rr, cc, dr, dc; };
 __device__ __forceinline__ TileWalk tile_walk(int T) {
@@ -581,7 +491,7 @@ __device__ __forceinline__ void tile_out(float* __restrict__ g, const float* L, 
 #pragma unroll
   for (int t = 0; t < TILE_PER; ++t) { if (w.rr < rows) g[row0 * T + threadIdx.x + t * NT] = L[w.rr * TP + w.cc]; tile_step(w, T); }
 }
-// the packed weight rows (and biases) of all heads: global -> registers -> LDS [column][33]
+// the packed weight rows (and biases) of all heads: global -> registers -> LDS [column][36]
 __device__ __forceinline__ void heads_wload(float (&wr)[HW_PER], float& br, const float* __restrict__ PRM, const GDesc& d, int T) {
 #pragma unroll
   for (int t = 0; t < HW_PER; ++t) {
@@ -593,77 +503,74 @@ __device__ __forceinline__ void heads_wload(float (&wr)[HW_PER], float& br, cons
   br = 0.f;
   if (threadIdx.x < MAXCOLS) { const ColSrc cs = col_src(d, threadIdx.x, T); const float v = PRM[max(cs.b, 0)]; br = cs.b >= 0 ? v : 0.f; }
 }
-__device__ __forceinline__ void heads_wstore(SmemHeads& s, const float (&wr)[HW_PER], float br) {
+__device__ __forceinline__ void heads_wstore(SmemHeads& s, const float (&wr)[HW_PER], float br, const GDesc& d) {
 #pragma unroll
-  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; s.W[(e >> 5) * WPH + (e & 31)] = wr[t]; }
+  for (int t = 0; t < HW_PER; ++t) { const int e = threadIdx.x + t * NT; s.W[(e >> 5) * PWM + (e & 31)] = wr[t]; }
   if (threadIdx.x < MAXCOLS) s.b[threadIdx.x] = br;
+  if (threadIdx.x <= MAXHEADS) s.seg[threadIdx.x] = d.seg[min((int)threadIdx.x, d.nheads)];
+}
+// the (row, head) pair a lane works on in a softmax round: pair = base + lane % 32 -> head = pair / 16, row = pair % 16; lanes l and
+// l + 32 share the pair and take the lower / upper half of the head's columns [cb, ce).  Past the last pair (or past the batch): no columns.
+struct PairCols { int m, cb, ce; };
+__device__ __forceinline__ PairCols pair_cols(const SmemHeads& s, int base, int lane, int nheads, int rows) {
+  const int p = base + (lane & 31), hd = min(p >> 4, max(nheads - 1, 0)), lh = lane >> 5;
+  PairCols r; r.m = p & (HR - 1);
+  const int c0 = s.seg[hd], c1 = s.seg[hd + 1], cm = c0 + (c1 - c0 + 1) / 2;
+  const bool live = p < HR * nheads && r.m < rows;
+  r.cb = live ? (lh ? cm : c0) : 0; r.ce = live ? (lh ? c1 : cm) : 0;
+  return r;
 }
 
-__global__ void __launch_bounds__(NT) g_heads4_kernel(const float* __restrict__ PRM, GBufs a, GDesc d, HeadOwner ho) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
-  SmemHeads& s = *reinterpret_cast<SmemHeads*>(heads_lds);
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const size_t row0 = (size_t)blockIdx.x * FT;
-  const int rows = min(FT, a.B - (int)row0);
-  const int T = d.seg[d.nheads];
-  // ---- the burst: weight rows, biases, the noise tile, h_5 (element tid + 256 t of the block's [64][32] slice)
-  float wr[HW_PER], br, nr[TILE_PER], hv[FT * HH / NT];
+__global__ void __launch_bounds__(NT) g_heads16_kernel(const float* __restrict__ PRM, GBufs a, GDesc d) {
+  __shared__ SmemHeads s;
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t row0 = (size_t)blockIdx.x * HR;
+  const int rows = min(HR, a.B - (int)row0);
+  const int T = d.seg[d.nheads], ncols = T + d.ncont;
+  // ---- the burst: weight rows, biases, the noise tile, h_5 (element tid + 256 t of the block's [16][32] slice)
+  float wr[HW_PER], br, nr[TILE_PER], hv[HR * HH / NT];
   PCG_T(8);
   heads_wload(wr, br, PRM, d, T);
   tile_load(nr, a.noise, row0, rows, T);
   const float* h5 = a.H + (size_t)NBLK * a.B * HH + row0 * HH;
 #pragma unroll
-  for (int t = 0; t < FT * HH / NT; ++t) hv[t] = h5[min((int)threadIdx.x + t * NT, rows * HH - 1)];
+  for (int t = 0; t < HR * HH / NT; ++t) hv[t] = h5[min((int)threadIdx.x + t * NT, rows * HH - 1)];
   PCG_T(9);
-  heads_wstore(s, wr, br);
+  heads_wstore(s, wr, br, d);
   tile_park(s.ns, nr, rows, T);
 #pragma unroll
-  for (int t = 0; t < FT * HH / NT; ++t) { const int e = threadIdx.x + t * NT; s.Hk[(e & 31) * HPK + (e >> 5)] = hv[t]; }
+  for (int t = 0; t < HR * HH / NT; ++t) { const int e = threadIdx.x + t * NT; s.Hk[(e & 31) * HR + (e >> 5)] = hv[t]; }
   __syncthreads();
   PCG_T(10);
-  // ---- out = h_5 W^T + b: waves 0-2 own a 32-column tile each, both row tiles
+  // ---- out = h_5 W^T + b: wave q owns the 16-column tiles q, q + 4
   const float inv_tau = 1.f / a.tau;
-  if (q < NCOLT) {
-    hd_acc_t acc[2];
-    const int n0 = q * 32;
-    const float bv = s.b[n0 + li];
+  for (int ct = q; ct * 16 < ncols; ct += NQ) {      // wave-uniform
+    const int col = ct * 16 + li;
+    const float bv = s.b[col];
+    m16_t acc = {bv, bv, bv, bv};
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int st = 0; st < HH / 4; ++st)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.Hk[(4 * st + lq) * HR + li], s.W[col * PWM + 4 * st + lq], acc, 0, 0, 0);
+    const int colc = min(col, max(T - 1, 0));
+    float nz[4];                                       // the noise under this lane's outputs: all reads first, then the writes
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][r] = bv;
-#pragma unroll 4
-    for (int st = 0; st < HH / 2; ++st) {
-      const int k = 2 * st + lh;
-      const float bw = s.W[(n0 + li) * WPH + k];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Hk[k * HPK + li], bw, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Hk[k * HPK + 32 + li], bw, acc[1], 0, 0, 0);
+    for (int r = 0; r < 4; ++r) nz[r] = s.ns[(4 * lq + r) * TP + colc];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * lq + r;
+      const float v = acc[r];
+      if (col < T) { s.lg[m * TP + col] = v; s.ns[m * TP + col] = (v + nz[r]) * inv_tau; }
+      else if (col < ncols) s.ct[m * (HH + 1) + (col - T)] = v * a.res_scale;
     }
-    const int col = n0 + li, colc = min(col, T - 1);
-    float nz[2][16];                                   // the noise under this lane's 32 outputs: all reads first, then the writes
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) nz[rt][r] = s.ns[(rt * 32 + hd_row(r, lh)) * TP + colc];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = rt * 32 + hd_row(r, lh);
-        const float v = acc[rt][r];
-        if (col < T) { s.lg[m * TP + col] = v; s.ns[m * TP + col] = (v + nz[rt][r]) * inv_tau; }
-        else if (col < T + d.ncont) s.ct[m * (HH + 1) + (col - T)] = v * a.res_scale;
-      }
   }
   __syncthreads();
   PCG_T(11);
-  // ---- Gumbel-softmax per (row, head): two lanes per pair, (head, 32-row half) units dealt to the waves
-  for (int un = 0; un < 2 * d.nheads; ++un) {
-    if (ho.owner[un] != q) continue;               // wave-uniform
-    const int hd = un >> 1, m = (un & 1) * 32 + li;
-    const int c0 = d.seg[hd], c1 = d.seg[hd + 1], cm = c0 + (c1 - c0 + 1) / 2;
-    const int cb = lh ? cm : c0, ce = lh ? c1 : cm;
+  // ---- Gumbel-softmax per (row, head): two lanes per pair, 128 pairs per round
+  for (int base = q * 32; base < HR * d.nheads; base += NQ * 32) {     // wave-uniform
+    const PairCols pc = pair_cols(s, base, lane, d.nheads, rows);
+    const int cb = pc.cb, ce = pc.ce, m = pc.m;
     float* ns = s.ns + m * TP;
-    // this lane's columns (at most 16) come into registers once, four independent LDS reads at a time
+    // this lane's columns (at most 16) come into registers once, independent LDS reads
     constexpr int MAXHALF = 16;
     float tv[MAXHALF];
 #pragma unroll
@@ -717,143 +624,6 @@ struct GBwd {
   int B, nblocks, accumulate;
   float tau, res_scale;
 };
-
-// column sums of v and w over the block's 64 rows for this wave's 8 channels -> part[2][HH]
-__device__ __forceinline__ void wave_colsums2(const float (&v)[HQ], const float (&w)[HQ], int lane, int q, float* part) {
-  const float s1 = wave_sum8(v, lane), s2 = wave_sum8(w, lane);
-  if ((lane & 7) == 0) { part[q * HQ + (lane >> 3)] = s1; part[HH + q * HQ + (lane >> 3)] = s2; }
-}
-// part "a" of block k: dn2 = dh * gam; partial sums (dn2, dn2 * xhat2).  Its operands came in with the caller's burst: the FiLM gamma
-// image in s.Wt[wslot] / s.bl[wslot], cond parked in s.V, z = z2_k rows, the saved statistics of bn2_k in s.sm[smslot], s.sm[smslot+1].
-__device__ __forceinline__ void bwd_part_a4(Smem4& s, const GBwd& a, int k, bool on, int lane, int q, const float (&dh)[HQ], const float (&z)[HQ],
-                                            int wslot, int smslot) {
-  float gam[HQ], v[HQ], w[HQ];
-  lin_q<MAXCOND>(s.Wt[wslot], s.bl[wslot], s.V, lane, q, gam);
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    const int c = q * HQ + j;
-    const float xh = (z[j] - s.sm[smslot][c]) * s.sm[smslot + 1][c];
-    v[j] = on ? dh[j] * gam[j] : 0.f;
-    w[j] = v[j] * xh;
-  }
-  wave_colsums2(v, w, lane, q, a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH);
-}
-
-// first backward kernel: the Gumbel-softmax backward of every (row, head) — two lanes per pair, units dealt like the forward —, then
-// dh = G W on the matrix cores (G: the rows' gradients at all T + ncont output columns, W: the packed weight rows as stored: the
-// gradient entering the last block), then part a of that block
-__global__ void __launch_bounds__(NT) g_bwd_first4_kernel(const float* __restrict__ PRM, GBwd a, GDesc d, HeadOwner ho) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char heads_lds[];
-  SmemHeads& hs = *reinterpret_cast<SmemHeads*>(heads_lds);
-  Smem4& s = *reinterpret_cast<Smem4*>(heads_lds + sizeof(SmemHeads));
-  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-  const size_t row0 = (size_t)blockIdx.x * FT, row = row0 + lane;
-  const bool on = row < (size_t)a.B;
-  const int rows = min(FT, a.B - (int)row0);
-  const int T = d.seg[d.nheads], ncols = T + d.ncont;
-  constexpr int k = NBLK - 1;
-  // ---- the burst: head weight rows, the three [rows][T] tiles, d_cont; for part a: FiLM gamma of the last block, cond, z2, saved statistics
-  float wr[HW_PER], br, t_dl[TILE_PER], t_ds[TILE_PER], t_y[TILE_PER], z[HQ], smr = 0.f;
-  WRegs<MAXCOND> w_g; CondRegs cr;
-  heads_wload(wr, br, PRM, d, T);
-  tile_load(t_dl, a.d_logits, row0, rows, T);
-  tile_load(t_ds, a.d_samples, row0, rows, T);
-  tile_load(t_y, a.soft, row0, rows, T);
-  float dcr[(FT * HH + NT - 1) / NT];
-#pragma unroll
-  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) dcr[t] = a.d_cont ? a.d_cont[row0 * d.ncont + min((int)threadIdx.x + t * NT, max(rows * d.ncont - 1, 0))] : 0.f;
-  wload<MAXCOND>(w_g, PRM + d.fg_w[k], PRM + d.fg_b[k]);
-  cload(cr, a.onehot, a.mask, min(row, (size_t)a.B - 1), on, q);
-  load8(a.Z2 + (size_t)k * a.B * HH, row, q, on, z);
-  if (threadIdx.x < 2 * HH) smr = a.SM[(size_t)(2 * k + 1) * 2 * HH + threadIdx.x];
-  // ---- into LDS.  G (in hs.lg) must be finite and zero outside the live rows / columns: it is an MFMA operand
-  heads_wstore(hs, wr, br);
-  for (int e = threadIdx.x; e < FT * TP; e += NT) hs.lg[e] = 0.f;
-  __syncthreads();
-  tile_park(hs.lg, t_dl, rows, T);
-  tile_park(hs.ds, t_ds, rows, T);
-  tile_park(hs.ns, t_y, rows, T);
-#pragma unroll
-  for (int t = 0; t < (FT * HH + NT - 1) / NT; ++t) {
-    const int e = threadIdx.x + t * NT;
-    if (e < rows * d.ncont) {
-      const int rr = e / d.ncont;
-      const float dc = dcr[t] * a.res_scale;           // 0 without a cotangent
-      hs.lg[rr * TP + T + (e - rr * d.ncont)] = dc;    // the continuous head's columns of G
-      a.DC[row0 * d.ncont + e] = dc;
-    }
-  }
-  wstore<MAXCOND, true>(s.Wt[1], s.bl[1], w_g);
-  cstore(s.V, cr, lane, q);
-  if (threadIdx.x < 2 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
-  __syncthreads();
-  // ---- dl of every (row, head), left in G
-  {
-    const float inv_tau = 1.f / a.tau;
-    for (int un = 0; un < 2 * d.nheads; ++un) {
-      if (ho.owner[un] != q) continue;             // wave-uniform
-      const int hd = un >> 1, m = (un & 1) * 32 + li;
-      if (m >= rows) continue;                     // (both lanes of a pair: the exchange below stays paired)
-      const int c0 = d.seg[hd], c1 = d.seg[hd + 1], cm = c0 + (c1 - c0 + 1) / 2;
-      const int cb = lh ? cm : c0, ce = lh ? c1 : cm;
-      float* dlr = hs.lg + m * TP; const float* dsr = hs.ds + m * TP; const float* yr = hs.ns + m * TP;
-      constexpr int MAXHALF = 16;                      // this lane's columns in registers: independent LDS reads, then the arithmetic
-      float dsv[MAXHALF], yv[MAXHALF], dlv[MAXHALF];
-#pragma unroll
-      for (int j = 0; j < MAXHALF; ++j) {
-        const bool in = cb + j < ce;
-        dsv[j] = in ? dsr[cb + j] : 0.f; yv[j] = in ? yr[cb + j] : 0.f; dlv[j] = in ? dlr[cb + j] : 0.f;
-      }
-      float dot = 0.f;
-      if (a.d_samples) {
-#pragma unroll
-        for (int j = 0; j < MAXHALF; ++j) dot = fmaf(dsv[j], yv[j], dot);
-        dot += __shfl_xor(dot, 32);
-      }
-#pragma unroll
-      for (int j = 0; j < MAXHALF; ++j) {
-        if (cb + j < ce) {
-          float dl = a.d_logits ? dlv[j] : 0.f;
-          if (a.d_samples) dl += yv[j] * (dsv[j] - dot) * inv_tau;
-          dlr[cb + j] = dl;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- dh[64 rows][32] = G[64][96] W[96][32]: wave (row tile, half of the 48 reduction steps); the halves added below in order
-  static_assert(FT * TP >= 4 * 32 * WPH, "four partial tiles fit the d_samples tile");
-  float* part = hs.ds;                               // four 32 x 33 partial tiles: the d_samples tile is free now
-  {
-    const int rt = q & 1, kh = q >> 1;
-    hd_acc_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int st = 0; st < MAXCOLS / 4; ++st) {
-      const int c = kh * (MAXCOLS / 2) + 2 * st + lh;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hs.lg[(rt * 32 + li) * TP + c], hs.W[c * WPH + li], acc, 0, 0, 0);
-    }
-    __syncthreads();                                 // every wave is done reading G before d_samples' space is reused
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[q * (32 * WPH) + li * WPH + hd_row(r, lh)] = acc[r];      // [wave][channel][row in tile]
-  }
-  __syncthreads();
-  float d8[HQ];
-  {
-    const int rt = lane >> 5, m = lane & 31;         // this thread's row (lane = row) lives in row tile rt
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) {
-      const int c = q * HQ + j;
-      d8[j] = part[rt * (32 * WPH) + c * WPH + m] + part[(2 + rt) * (32 * WPH) + c * WPH + m];
-    }
-  }
-  store8(a.DH + (size_t)k * a.B * HH, row, q, on, d8);
-  // DL = the first T columns of G
-  tile_out(a.DL, hs.lg, row0, rows, T);
-  bwd_part_a4(s, a, k, on, lane, q, d8, z, 1, 0);
-  (void)ncols;
-}
 
 // ---- backward segments on the matrix cores (same ownership as the forward: wave w has rows 16 w .. 16 w + 15, both channel tiles) ---
 struct alignas(16) SmemMB {
@@ -938,8 +708,128 @@ __device__ __forceinline__ void acc_rows_store(float* __restrict__ p, const m16_
       if (ok[r]) p[(rowA + r) * HH + ct * 16 + li] = v[ct][r];
 }
 
+// first backward kernel (16 rows per block, like the forward's head kernel): the Gumbel-softmax backward of every (row, head) — two
+// lanes per pair —, then dh = G W on the matrix cores (G: the rows' gradients at all T + ncont output columns, K = 96; W: the packed
+// weight rows as stored: the gradient entering the last block; waves 0 / 1 own one 16-channel tile each), then part "a" of that
+// block: dn2 = dh * gam (FiLM gamma product on the matrix cores), partial sums (dn2, dn2 * xhat2) per 16-ROW block — the last
+// bn2's slot of Q holds ceil(B / 16) partial rows (BSeg.qrows)
+__global__ void __launch_bounds__(NT) g_bwd_first16_kernel(const float* __restrict__ PRM, GBwd a, GDesc d) {
+  __shared__ SmemHeads s;
+  const int lane = threadIdx.x & (FT - 1), q = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const size_t row0 = (size_t)blockIdx.x * HR, rowA = row0 + 4 * lq;
+  const int rows = min(HR, a.B - (int)row0);
+  const int T = d.seg[d.nheads];
+  constexpr int k = NBLK - 1;
+  const int cch = (q & 1) * 16 + li;                 // this lane's channel in the dh product (waves 0 / 1)
+  // ---- the burst: head weight rows, the three [rows][T] tiles, d_cont; for part a: FiLM gamma of the last block, cond, z2, saved statistics
+  float wr[HW_PER], br, t_dl[TILE_PER], t_ds[TILE_PER], t_y[TILE_PER], z[4], smr = 0.f;
+  WRegs<MAXCOND> w_g;
+  constexpr int DC_PER = (HR * HH + NT - 1) / NT, C_PER = (MK_C * HR + NT - 1) / NT;
+  float dcr[DC_PER], cv[C_PER];
+  heads_wload(wr, br, PRM, d, T);
+  tile_load(t_dl, a.d_logits, row0, rows, T);
+  tile_load(t_ds, a.d_samples, row0, rows, T);
+  tile_load(t_y, a.soft, row0, rows, T);
+#pragma unroll
+  for (int t = 0; t < DC_PER; ++t) dcr[t] = a.d_cont ? a.d_cont[row0 * d.ncont + min((int)threadIdx.x + t * NT, max(rows * d.ncont - 1, 0))] : 0.f;
+  wload<MAXCOND>(w_g, PRM + d.fg_w[k], PRM + d.fg_b[k]);
+#pragma unroll
+  for (int t = 0; t < C_PER; ++t) {                    // cond = (one-hot target, mask), element (i, row) = (e / 16, e % 16)
+    const int e = threadIdx.x + t * NT, i = min(e >> 4, MAXCOND - 1);
+    const size_t rw = min(row0 + (e & (HR - 1)), (size_t)a.B - 1);
+    cv[t] = i < NCLS ? a.onehot[rw * NCLS + i] : a.mask[rw * DIN + (i - NCLS)];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) z[r] = a.Z2[(size_t)k * a.B * HH + min(rowA + r, (size_t)a.B - 1) * HH + cch];
+  if (threadIdx.x < 2 * HH) smr = a.SM[(size_t)(2 * k + 1) * 2 * HH + threadIdx.x];
+  // ---- into LDS.  G (in s.lg) must be finite and zero outside the live rows / columns: it is an MFMA operand
+  heads_wstore(s, wr, br, d);
+  for (int e = threadIdx.x; e < HR * TP; e += NT) s.lg[e] = 0.f;
+  __syncthreads();
+  tile_park(s.lg, t_dl, rows, T);
+  tile_park(s.ds, t_ds, rows, T);
+  tile_park(s.ns, t_y, rows, T);
+#pragma unroll
+  for (int t = 0; t < DC_PER; ++t) {
+    const int e = threadIdx.x + t * NT;
+    if (e < rows * d.ncont) {
+      const int rr = e / d.ncont;
+      const float dc = dcr[t] * a.res_scale;           // 0 without a cotangent
+      s.lg[rr * TP + T + (e - rr * d.ncont)] = dc;     // the continuous head's columns of G
+      a.DC[row0 * d.ncont + e] = dc;
+    }
+  }
+  wstore_mb<MAXCOND>(s.Wg, s.bg, w_g);
+#pragma unroll
+  for (int t = 0; t < C_PER; ++t) { const int e = threadIdx.x + t * NT; if (e < MK_C * HR) s.C[e] = e < MAXCOND * HR ? cv[t] : 0.f; }
+  if (threadIdx.x < 2 * HH) s.sm[threadIdx.x >> 5][threadIdx.x & (HH - 1)] = smr;
+  __syncthreads();
+  // ---- dl of every (row, head), left in G
+  {
+    const float inv_tau = 1.f / a.tau;
+    for (int base = q * 32; base < HR * d.nheads; base += NQ * 32) {   // wave-uniform
+      const PairCols pc = pair_cols(s, base, lane, d.nheads, rows);
+      const int cb = pc.cb, ce = pc.ce;
+      float* dlr = s.lg + pc.m * TP; const float* dsr = s.ds + pc.m * TP; const float* yr = s.ns + pc.m * TP;
+      constexpr int MAXHALF = 16;                      // this lane's columns in registers: independent LDS reads, then the arithmetic
+      float dsv[MAXHALF], yv[MAXHALF], dlv[MAXHALF];
+#pragma unroll
+      for (int j = 0; j < MAXHALF; ++j) {
+        const bool in = cb + j < ce;
+        dsv[j] = in ? dsr[cb + j] : 0.f; yv[j] = in ? yr[cb + j] : 0.f; dlv[j] = in ? dlr[cb + j] : 0.f;
+      }
+      float dot = 0.f;
+      if (a.d_samples) {
+#pragma unroll
+        for (int j = 0; j < MAXHALF; ++j) dot = fmaf(dsv[j], yv[j], dot);
+        dot += __shfl_xor(dot, 32);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXHALF; ++j) {
+        if (cb + j < ce) {
+          float dl = a.d_logits ? dlv[j] : 0.f;
+          if (a.d_samples) dl += yv[j] * (dsv[j] - dot) * inv_tau;
+          dlr[cb + j] = dl;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (q < 2) {                                         // wave-uniform
+    // ---- dh[16 rows][16 channels of this wave] = G[16][96] W[96][32]
+    m16_t dh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int st = 0; st < MAXCOLS / 4; ++st)
+      dh = __builtin_amdgcn_mfma_f32_16x16x4f32(s.lg[li * TP + 4 * st + lq], s.W[(4 * st + lq) * PWM + cch], dh, 0, 0, 0);
+    // ---- part a: gam = cond Wg^T + bg; dn2 = dh * gam; column sums of (dn2, dn2 * xhat2) over the block's rows
+    const float bgv = s.bg[cch];
+    m16_t gam = {bgv, bgv, bgv, bgv};
+#pragma unroll
+    for (int st = 0; st < MK_C / 4; ++st)
+      gam = __builtin_amdgcn_mfma_f32_16x16x4f32(s.C[(4 * st + lq) * HR + li], s.Wg[cch * PWM + 4 * st + lq], gam, 0, 0, 0);
+    const float m2 = s.sm[0][cch], i2 = s.sm[1][cch];
+    float v[4], w[4];
+    float* DHk = a.DH + (size_t)k * a.B * HH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = rowA + r < (size_t)a.B;
+      if (ok) DHk[(rowA + r) * HH + cch] = dh[r];
+      const float xh = (z[r] - m2) * i2;
+      v[r] = ok ? dh[r] * gam[r] : 0.f;
+      w[r] = v[r] * xh;
+    }
+    float s1 = (v[0] + v[1]) + (v[2] + v[3]), s2 = (w[0] + w[1]) + (w[2] + w[3]);
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    float* part = a.Q + ((size_t)(2 * k + 1) * a.nblocks + blockIdx.x) * 2 * HH;
+    if (lq == 0) { part[cch] = s1; part[HH + cch] = s2; }
+  }
+  // DL = the first T columns of G
+  tile_out(a.DL, s.lg, row0, rows, T);
+}
+
 // kind B (block k): bn2 backward -> dz2; through fc2 and the ReLU / FiLM -> dn1 and its partial sums; FiLM output gradients
-struct BSeg { int fg_w, fg_b, fb_w, fb_b, fc2_w, bn2_g, bn2_b, bn1_g, bn1_b, k; };
+struct BSeg { int fg_w, fg_b, fb_w, fb_b, fc2_w, bn2_g, bn2_b, bn1_g, bn1_b, k, qrows; };   // qrows: partial rows in bn2's slot of Q
 __global__ void __launch_bounds__(NT) g_bwd_b4_kernel(const float* __restrict__ PRM, GBwd a, BSeg f) {
   __shared__ SmemMB s;
   const int k = f.k;
@@ -965,7 +855,7 @@ __global__ void __launch_bounds__(NT) g_bwd_b4_kernel(const float* __restrict__ 
     smr = a.SM[(size_t)(2 * k) * 2 * HH + threadIdx.x];        // sm[0..1] = bn1's mean / invstd, sm[2..3] = bn2's
   }
   if (threadIdx.x < HH && a.accumulate) { gg_old = a.grads[f.bn2_g + threadIdx.x]; gb_old = a.grads[f.bn2_b + threadIdx.x]; }
-  pload(pr, a.Q + (size_t)(2 * k + 1) * a.nblocks * 2 * HH, a.nblocks);
+  pload(pr, a.Q + (size_t)(2 * k + 1) * a.nblocks * 2 * HH, f.qrows);
   // ---- into LDS
   wstore_mb<MAXCOND>(s.Wg, s.bg, w_g);
   wstore_mb<MAXCOND>(s.Wb, s.bb, w_b);
@@ -1127,35 +1017,10 @@ __global__ void __launch_bounds__(NT) g_bwd_c4_kernel(const float* __restrict__ 
 
 using namespace pcg;
 
-static int set_heads_lds(const void* fn, size_t bytes) {
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) { set_error("hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(e)); return PCG_ERR_LAUNCH; }
-  return PCG_OK;
-}
-
 static bool heads_at_most_32_wide(const GDesc& d) {      // a lane keeps its half of a head's columns (<= 16) in registers
   for (int h = 0; h < d.nheads; ++h)
     if (d.seg[h + 1] - d.seg[h] > 32) return false;
   return true;
-}
-// the (head, 32-row half) units of the Gumbel-softmax dealt to the four waves: cost = columns per lane (two lanes share a pair),
-// largest first onto the least loaded wave
-static HeadOwner deal_heads(const GDesc& d) {
-  HeadOwner ho{};
-  int cost[2 * MAXHEADS], load[NQ] = {0, 0, 0, 0};
-  bool done[2 * MAXHEADS] = {};
-  const int nu = 2 * d.nheads;
-  for (int u = 0; u < nu; ++u) cost[u] = (d.seg[u / 2 + 1] - d.seg[u / 2] + 1) / 2;
-  for (int it = 0; it < nu; ++it) {
-    int best = -1;
-    for (int j = 0; j < nu; ++j)
-      if (!done[j] && (best < 0 || cost[j] > cost[best])) best = j;
-    int w = 0;
-    for (int j = 1; j < NQ; ++j)
-      if (load[j] < load[w]) w = j;
-    done[best] = true; ho.owner[best] = (signed char)w; load[w] += cost[best];
-  }
-  return ho;
 }
 
 // C-side mirrors of the argument blocks (plain arrays of offsets / pointers: see include/pcgan_hip.h)
@@ -1180,8 +1045,6 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
   for (int i = 0; i < 2 * NBLK; ++i) { bs.running_mean[i] = args->running_mean[i]; bs.running_var[i] = args->running_var[i]; bs.nbt[i] = args->num_batches_tracked[i]; }
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.nblocks), block4(FT * NQ);
-  static int once = set_heads_lds(reinterpret_cast<const void*>(g_heads4_kernel), sizeof(SmemHeads));
-  if (once != PCG_OK) return once;
   hipLaunchKernelGGL(g_fwd_first4_kernel, grid, block4, 0, s, args->params, a, d);
   if (int e = launch_status("g_fwd_first4_kernel")) return e;
   for (int k = 0; k < NBLK; ++k) {
@@ -1195,8 +1058,8 @@ extern "C" int pcg_house_g_fwd(const pcg_house_g_desc* desc, const pcg_house_g_f
     hipLaunchKernelGGL(g_fwd_b4_kernel, grid, block4, 0, s, args->params, a, fb);
     if (int e = launch_status("g_fwd_b4_kernel")) return e;
   }
-  hipLaunchKernelGGL(g_heads4_kernel, grid, block4, sizeof(SmemHeads), s, args->params, a, d, deal_heads(d));
-  if (int e = launch_status("g_heads4_kernel")) return e;
+  hipLaunchKernelGGL(g_heads16_kernel, dim3((a.B + HR - 1) / HR), block4, 0, s, args->params, a, d);
+  if (int e = launch_status("g_heads16_kernel")) return e;
   return PCG_OK;
 }
 
@@ -1217,12 +1080,11 @@ extern "C" int pcg_house_g_bwd(const pcg_house_g_desc* desc, const pcg_house_g_b
   a.tau = args->tau; a.res_scale = args->res_scale;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(a.nblocks), block4(FT * NQ);
-  static int once = set_heads_lds(reinterpret_cast<const void*>(g_bwd_first4_kernel), sizeof(SmemHeads) + sizeof(Smem4));
-  if (once != PCG_OK) return once;
-  hipLaunchKernelGGL(g_bwd_first4_kernel, grid, block4, sizeof(SmemHeads) + sizeof(Smem4), s, args->params, a, d, deal_heads(d));
-  if (int e = launch_status("g_bwd_first4_kernel")) return e;
+  const int nblk16 = (a.B + HR - 1) / HR;
+  hipLaunchKernelGGL(g_bwd_first16_kernel, dim3(nblk16), block4, 0, s, args->params, a, d);
+  if (int e = launch_status("g_bwd_first16_kernel")) return e;
   for (int k = NBLK - 1; k >= 0; --k) {
-    const BSeg fb{d.fg_w[k], d.fg_b[k], d.fb_w[k], d.fb_b[k], d.fc2_w[k], d.bn2_g[k], d.bn2_b[k], d.bn1_g[k], d.bn1_b[k], k};
+    const BSeg fb{d.fg_w[k], d.fg_b[k], d.fb_w[k], d.fb_b[k], d.fc2_w[k], d.bn2_g[k], d.bn2_b[k], d.bn1_g[k], d.bn1_b[k], k, k == NBLK - 1 ? nblk16 : a.nblocks};
     const CSeg fc{d.fc1_w[k], d.bn1_g[k], d.bn1_b[k], k > 0 ? d.fg_w[k - 1] : 0, k > 0 ? d.fg_b[k - 1] : 0, k};
     hipLaunchKernelGGL(g_bwd_b4_kernel, grid, block4, 0, s, args->params, a, fb);
     if (int e = launch_status("g_bwd_b4_kernel")) return e;

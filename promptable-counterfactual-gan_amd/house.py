@@ -182,7 +182,7 @@ class ResidualGenerator(FlatModule):
         f32 = dict(dtype=torch.float32, device=onehot.device)
         g = {n: torch.empty((5, B, 32), **f32) for n in ("DH", "DZ1", "DZ2", "A1", "DG", "DB")}
         g.update({"DN1": torch.empty((B, 32), **f32), "DZIN": torch.empty((B, 32), **f32), "DL": torch.empty((B, T), **f32),
-                  "DC": torch.empty((B, nc), **f32), "Q": torch.empty((10, nb, 2, 32), **f32)})
+                  "DC": torch.empty((B, nc), **f32), "Q": torch.empty((9 * nb + (B + 15) // 16, 2, 32), **f32)})
         # BatchNorm gamma / beta gradients are written by the kernels; all of them share the accumulate state of the net
         _, acc = self._grad_view(self.blocks[0].bn1.weight)
         for blk in self.blocks:
