@@ -290,17 +290,18 @@ __global__ void __launch_bounds__(256) linear_wgrad_mfma_kernel(WgradMfmaGroup g
   wm_acc_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
   PCG_T(1);
-  for (int r = kbeg; r < kend; r += 32) {                  // 16 MFMA steps of two rows; all 32 loads of a group in flight together
-    float av[16], bv[16];
+  constexpr int GS = 32;                                     // MFMA steps (of two rows) per group: all 64 loads of a group in flight together
+  for (int r = kbeg; r < kend; r += 2 * GS) {
+    float av[GS], bv[GS];
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
+    for (int st = 0; st < GS; ++st) {
       const int row = r + 2 * st + lh, rc = min(row, kend - 1);
       const float a = pa[(size_t)rc * ldy], b = pb[(size_t)rc * ldx];
       av[st] = (row < kend && va) ? a : 0.f;
       bv[st] = (row < kend && vb) ? b : 0.f;
     }
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
+    for (int st = 0; st < GS; ++st) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc, 0, 0, 0);
       bsum += av[st];
     }
@@ -1085,11 +1086,14 @@ extern "C" int pcg_linear_wgrad(const float* dy, int32_t ldy, const float* x, in
   return launch_status("linear_wgrad_kernel");
 }
 
-// grouped plan: rows per wave ~128 (64 MFMA steps), slabs in blocks of four waves, at most 16 blocks per tile
+// grouped plan: rows per wave ~64 (32 MFMA steps, all 64 loads requested before the first MFMA: what a wave costs is the latency
+// of its load groups, so more, shorter waves win until the last block's sum over the partials grows — step time with 128 rows per
+// wave in four groups of 32 loads 0.380 ms, 64 rows in two groups 0.367, 32 rows 0.374, 64 rows in ONE group 0.361), slabs in
+// blocks of four waves, at most 16 blocks per tile
 namespace {
 struct WgradMfmaPlan { int Sb, chunk; };
 WgradMfmaPlan plan_wgrad_mfma(int B) {
-  int S = (B + 127) / 128;
+  int S = (B + 63) / 64;
   S = (S + 3) / 4 * 4;
   if (S > 64) S = 64;
   int chunk = (B + S - 1) / S;
