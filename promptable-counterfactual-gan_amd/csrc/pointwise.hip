@@ -128,7 +128,7 @@ struct AdamTick { int64_t* step; AdamCache* cache; double lr, beta1, beta2; int 
 
 template <int VEC>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
-                                                   float* __restrict__ m, float* __restrict__ v, size_t n, AdamConst k,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, int tail, AdamConst k,
                                                    AdamHyper hy, AdamTick tk) {
   int64_t t = 0;
   if (tk.mode) {
@@ -162,6 +162,12 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, co
       adam_one(p, grad[i], mm, vv, k, hy.step_size, hy.bc2_sqrt);
       param[i] = p; m[i] = mm; v[i] = vv;
     }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {       // the 1..3 elements behind the 16-byte lanes
+    const size_t i = n + threadIdx.x;
+    float p = param[i], mm = m[i], vv = v[i];
+    adam_one(p, grad[i], mm, vv, k, hy.step_size, hy.bc2_sqrt);
+    param[i] = p; m[i] = mm; v[i] = vv;
   }
   if (tk.mode == 1) {          // kernel-uniform
     __syncthreads();           // every thread of this block has read the counter
@@ -200,8 +206,8 @@ int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, 
   const bool al = al16(param) && al16(grad) && al16(m) && al16(v);
   const AdamConst k{(float)lr, (float)(1.0 - beta1), (float)(1.0 - (1.0 - beta1)), (float)beta2, (float)(1.0 - beta2), (float)eps,
                     (float)wd, decoupled};
-  // 16-byte lanes over the bulk, a scalar launch for the 1..3 trailing elements (a flat buffer that ends in a bias of one element —
-  // the WGAN-GP critic's Linear(1024, 1) — used to send all 25 M parameters down the scalar kernel)
+  // 16-byte lanes over the bulk, the 1..3 trailing elements on three threads of block 0 (a flat buffer that ends in a bias of one
+  // element — the WGAN-GP critic's Linear(1024, 1) — used to send all 25 M parameters down the scalar kernel)
   const int64_t bulk = al ? (n & ~(int64_t)3) : 0;
   AdamTick tk{step_dev, cache_dev, lr, beta1, beta2, step_dev ? 1 : 0};
   if (bulk) {
@@ -212,12 +218,12 @@ int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, 
       static const unsigned cap = [] { const char* e = getenv("PCG_ADAM_TICK_BLOCKS"); return e ? (unsigned)atoi(e) : 256u; }();
       if (blocks > cap) blocks = cap;
     }
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, k, hy, tk);
-    if (tk.mode) tk.mode = 2;      // the trailing launch uses the counter the bulk launch's last block stored
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, param, grad, m, v, (size_t)bulk, (int)(n - bulk), k, hy, tk);
+  } else {
+    unsigned blocks = ew_blocks((size_t)n);
+    if (tk.mode && blocks > 256u) blocks = 256u;
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, param, grad, m, v, (size_t)n, 0, k, hy, tk);
   }
-  if (n > bulk)
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(ew_blocks((size_t)(n - bulk))), dim3(256), 0, s, param + bulk, grad + bulk, m + bulk, v + bulk,
-                       (size_t)(n - bulk), k, hy, tk);
   return launch_status("adam_kernel");
 }
 
