@@ -380,23 +380,30 @@ def test_skip_dead_d_wgrad_is_equivalent(pcg, hgold):
         assert torch.equal(states[0][k], states[1][k]), k
 
 
-def test_fused_generator_kernels_match_the_op_chain(pcg, hgold):
-    """csrc/house_fused.hip (11 + 11 launches, one thread per row) against the per-op path on the same inputs: the three
-    outputs, every parameter gradient, the BatchNorm buffers.  Same arithmetic up to summation order: 2e-5 of scale."""
+@pytest.mark.parametrize("rows,hard", [(300, False), (7, False), (1000, True), (4096, False)])
+def test_fused_generator_kernels_match_the_op_chain(pcg, hgold, rows, hard):
+    """csrc/house_fused.hip (12 + 11 launches on the matrix cores: 64-row segment blocks, 16-row head blocks) against the per-op
+    path on the same inputs: the three outputs, every parameter gradient, the BatchNorm buffers.  Same arithmetic up to summation
+    order: 2e-5 of scale.  300 / 1000 rows end in ragged 64- and 16-row blocks, 7 rows is one partial block of either kind;
+    hard: the straight-through one-hot samples (first maximum) must be the same one-hot rows."""
     H = pcg.house
-    x, y, t, m, gumbel = HR.synthetic_batch(300, seed=5)            # 300 rows: a full block of 256 + a ragged one
+    x, y, t, m, gumbel = HR.synthetic_batch(rows, seed=5)
     res = []
     for fused in (True, False):
         G, _, _ = _load_golden_nets(pcg, hgold)
         G.use_fused = fused
         noise = G.pack_noise({f: _dev(v) for f, v in gumbel.items()})
-        cont, logits, samples = G.forward_packed(_dev(x), pcg.ops.onehot(_dev(t), 4), _dev(m), temperature=0.5, gumbel=noise)
+        cont, logits, samples = G.forward_packed(_dev(x), pcg.ops.onehot(_dev(t), 4), _dev(m), temperature=0.5, hard=hard, gumbel=noise)
         g = torch.Generator().manual_seed(1)
         dc, dl, ds = (torch.randn(v.shape, generator=g) for v in (cont, logits, samples))
-        (cont * _dev(dc)).sum().backward(retain_graph=True) if False else None
         torch.autograd.backward([cont, logits, samples], [_dev(dc), _dev(dl), _dev(ds)])
         res.append((cont.detach(), logits.detach(), samples.detach(), {n: p.grad.clone() for n, p in G.named_parameters()},
                     {n: b.clone() for n, b in G.named_buffers()}))
+    if hard:     # one-hot rows: equal wherever the two largest probabilities of a head are not within rounding of each other
+        same = (res[0][2] == res[1][2]).all(dim=1).float().mean().item()
+        assert same >= 0.995, same
+        assert bool(((res[0][2] == 0) | (res[0][2] == 1)).all())
+        res = [(r[0], r[1], r[1]) + r[3:] for r in res]            # (the samples were compared above)
     for a, b in zip(res[0][:3], res[1][:3]):
         _close(a, b, 2e-5, 2e-5 * float(b.abs().max()))
     scale = max(float(v.abs().max()) for v in res[1][3].values())
