@@ -605,6 +605,25 @@ int pcg_house_residual_bwd(const float* res, const float* masked, const float* m
                            float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S, int32_t T,
                            const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont, float* dsamples,
                            pcg_stream_t stream);
+/* "Riders": two launches of the tabular step that do not depend on each other issued as ONE launch whose blocks split between the
+ * two kernel bodies (a HIP graph with parallel branches is launched node by node by the host; one launch is not).  Same bodies, same
+ * bits as the separate calls.
+ *   pcg_house_residual_fwd_sn      = pcg_house_residual_fwd + pcg_spectral_norm_fwd_batched_reps (training mode: the critic step's
+ *                                    power iterations only need the critic's weights; trainer.py:266-287 beside models/discriminator.py:9-16)
+ *   pcg_house_residual_bwd_losses  = pcg_house_residual_bwd + pcg_house_losses (the logged scalars do not feed the backward;
+ *                                    trainer.py:314 beside :292, :307-312) */
+int pcg_house_residual_fwd_sn(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
+                              const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
+                              float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out,
+                              int32_t n_layers, int32_t reps, const float* const* w_orig, const int32_t* out_features,
+                              const int32_t* in_features, float* const* u, float* const* v, float eps, float* const* w_bar,
+                              float* const* sigma, float* const* u_used, float* const* v_used, pcg_stream_t stream);
+int pcg_house_residual_bwd_losses(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b,
+                                  float w_pen, float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S,
+                                  int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont,
+                                  float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g, int32_t n,
+                                  const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask,
+                                  float w_reg_log, float* out5, pcg_stream_t stream);
 /* The three per-iteration draws of the tabular trainer in one launch — target class != y (trainer.py:248-249, as pcg_randint with
  * exclude), feature mask (:253-255, as pcg_feature_mask), Gumbel noise [B][T] (generator.py:90, as pcg_rand_gumbel) — each from its
  * own counter offset: the values the three separate calls produce.  onehot_target / onehot_y (nullable, [B][num_classes]): the float

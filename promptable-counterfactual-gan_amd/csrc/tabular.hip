@@ -485,13 +485,21 @@ __global__ void __launch_bounds__(256) assemble_bwd_kernel(const float* __restri
 // the same reduction trees (so the same bits).  Contraction is off: every product and sum below was a rounded result in its own
 // kernel.  col_src[col] >= 0: continuous column (index into cont); < 0: categorical head -(s + 1).
 struct ResCols { int src[32]; };
-template <bool SMALL>       // SMALL: one block of 1024 threads (n <= 16 K, as pcg_abs_mean_fwd); else 256 blocks of 256 + last-block finish
-__global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
-    const float* __restrict__ cont, int ncont, const float* __restrict__ samples, const int* __restrict__ seg, int nseg, int T, const float* __restrict__ norm,
-    const float* __restrict__ x, const float* __restrict__ mask, ResCols cols, int D, size_t n, double inv_n, float* __restrict__ res,
-    float* __restrict__ masked, float* __restrict__ x_cf, float* __restrict__ partial, int* __restrict__ ticket, float* __restrict__ pen_out,
-    float* __restrict__ am_out) {
+struct ResFwdArgs {
+  const float* cont; int ncont; const float* samples; const int* seg; int nseg, T; const float* norm; const float* x; const float* mask;
+  ResCols cols; int D; size_t n; double inv_n; float* res; float* masked; float* x_cf; float* partial; int* ticket; float* pen_out; float* am_out;
+};
+// SMALL: one block of 1024 threads (n <= 16 K, as pcg_abs_mean_fwd); else nb blocks of 256 (block index bid) + last-block finish
+template <bool SMALL>
+__device__ __forceinline__ void house_residual_fwd_body(const ResFwdArgs& a, int bid, int nb) {
 #pragma clang fp contract(off)
+  const float* __restrict__ cont = a.cont; const float* __restrict__ samples = a.samples; const int* __restrict__ seg = a.seg;
+  const float* __restrict__ norm = a.norm; const float* __restrict__ x = a.x; const float* __restrict__ mask = a.mask;
+  float* __restrict__ res = a.res; float* __restrict__ masked = a.masked; float* __restrict__ x_cf = a.x_cf; float* __restrict__ partial = a.partial;
+  int* __restrict__ ticket = a.ticket; float* __restrict__ pen_out = a.pen_out; float* __restrict__ am_out = a.am_out;
+  const int ncont = a.ncont, nseg = a.nseg, T = a.T, D = a.D;
+  const size_t n = a.n; const double inv_n = a.inv_n;
+  const ResCols& cols = a.cols;
   constexpr int NTH = SMALL ? 1024 : 256;
   __shared__ double redd[2][NTH];
   __shared__ float redf[2][SMALL ? 1 : 256];
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
   if (threadIdx.x <= (unsigned)nseg) s_seg[threadIdx.x] = seg[threadIdx.x];
   __syncthreads();
   float acc_pen = 0.f, acc_am = 0.f;
-  for (size_t i = (size_t)blockIdx.x * NTH + threadIdx.x; i < n; i += (size_t)gridDim.x * NTH) {
+  for (size_t i = (size_t)bid * NTH + threadIdx.x; i < n; i += (size_t)nb * NTH) {
     const size_t b = i / (size_t)D;
     const int col = (int)(i - b * (size_t)D), src = cols.src[col];
     float r;
@@ -546,11 +554,11 @@ __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      __hip_atomic_store(partial + blockIdx.x, redf[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(partial + 256 + blockIdx.x, redf[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + bid, redf[0][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + 256 + bid, redf[1][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);
       const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = t == (int)gridDim.x - 1;
+      s_last = t == nb - 1;
       if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -566,19 +574,28 @@ __global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(
     if (threadIdx.x == 0) { pen_out[0] = (float)(redd[0][0] * inv_n); am_out[0] = (float)(redd[1][0] * inv_n); }
   }
 }
+template <bool SMALL>
+__global__ void __launch_bounds__(SMALL ? 1024 : 256) house_residual_fwd_kernel(ResFwdArgs a) {
+  house_residual_fwd_body<SMALL>(a, blockIdx.x, gridDim.x);
+}
 // backward of the same block, given the gradient of the G loss with respect to x_cf as two addends (critic, classifier):
 //   d_res = lambda_mask * d mean|res (1-mask)| + mask * (w_reg * d mean|masked| + (gx_a + gx_b)),   then assemble's backward —
 // pcg_axpby + pcg_weighted_sum_bwd + 2 x pcg_abs_mean_bwd + pcg_axpby + pcg_scale_mask_bwd + autograd's add + pcg_assemble_residual_bwd
 // in one launch, one rounded operation per step as there.  One thread per (row, source column) like assemble_bwd.
-__global__ void __launch_bounds__(256) house_residual_bwd_kernel(const float* __restrict__ res, const float* __restrict__ masked,
-                                                                 const float* __restrict__ mask, const float* __restrict__ gx_a,
-                                                                 const float* __restrict__ gx_b, float w_pen, float w_am, size_t n, int ncont,
-                                                                 const int* __restrict__ cont_idx, const int* __restrict__ seg, int S, int T,
-                                                                 const int* __restrict__ cat_idx, const float* __restrict__ norm, int D, int B,
-                                                                 float* __restrict__ dcont, float* __restrict__ dsamples) {
+struct ResBwdArgs {
+  const float* res; const float* masked; const float* mask; const float* gx_a; const float* gx_b; float w_pen, w_am; size_t n; int ncont;
+  const int* cont_idx; const int* seg; int S, T; const int* cat_idx; const float* norm; int D, B; float* dcont; float* dsamples;
+};
+// (elementwise: any partition of the (row, source column) pairs over threads gives the same bits) block bid of nb blocks of nth threads
+__device__ __forceinline__ void house_residual_bwd_body(const ResBwdArgs& a, int bid, int nb, int nth) {
 #pragma clang fp contract(off)
+  const float* __restrict__ res = a.res; const float* __restrict__ masked = a.masked; const float* __restrict__ mask = a.mask;
+  const float* __restrict__ gx_a = a.gx_a; const float* __restrict__ gx_b = a.gx_b; const int* __restrict__ cont_idx = a.cont_idx;
+  const int* __restrict__ seg = a.seg; const int* __restrict__ cat_idx = a.cat_idx; const float* __restrict__ norm = a.norm;
+  float* __restrict__ dcont = a.dcont; float* __restrict__ dsamples = a.dsamples;
+  const float w_pen = a.w_pen, w_am = a.w_am; const size_t n = a.n; const int ncont = a.ncont, S = a.S, T = a.T, D = a.D, B = a.B;
   const float g_pen = (w_pen * 1.f) * 1.f / (float)n, g_am = (w_am * 1.f) * 1.f / (float)n;   // weighted_sum_bwd (grad_out = 1), then abs_mean_bwd's g
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * (ncont + S); i += gridDim.x * 256) {
+  for (int i = bid * nth + threadIdx.x; i < B * (ncont + S); i += nb * nth) {
     const int b = i / (ncont + S), j = i - b * (ncont + S);
     const int col = j < ncont ? cont_idx[j] : cat_idx[j - ncont];
     const size_t e = (size_t)b * D + col;
@@ -601,6 +618,8 @@ __global__ void __launch_bounds__(256) house_residual_bwd_kernel(const float* __
     }
   }
 }
+
+__global__ void __launch_bounds__(256) house_residual_bwd_kernel(ResBwdArgs a) { house_residual_bwd_body(a, blockIdx.x, gridDim.x, 256); }
 
 // mean(x): per-block partials + fixed-order finish; bwd: dx = g * scale / n
 constexpr int MEAN_BLOCKS = 64;
@@ -641,11 +660,14 @@ __global__ void __launch_bounds__(1024) mean_small_kernel(const float* __restric
 //   out[0] = D_loss = mean(d_fake) - mean(d_real)                                  (trainer.py:292)
 //   out[1] = G_loss = -mean(d_fake_g) + l_cls*g_cls + l_reg*am + l_mask*pen        (:299, :307-312)
 //   out[2] = g_adv  = -mean(d_fake_g)       out[3] = g_reg = w_reg_log * am        out[4] = mean(d_fake_g)
-__global__ void __launch_bounds__(1024) house_losses_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake,
-                                                            const float* __restrict__ d_fake_g, size_t n, double inv_n,
-                                                            const float* __restrict__ g_cls, const float* __restrict__ am,
-                                                            const float* __restrict__ pen, float l_cls, float l_reg, float l_mask,
-                                                            float w_reg_log, float* __restrict__ out) {
+struct LossArgs {
+  const float* d_real; const float* d_fake; const float* d_fake_g; size_t n; double inv_n; const float* g_cls; const float* am; const float* pen;
+  float l_cls, l_reg, l_mask, w_reg_log; float* out;
+};
+__device__ __forceinline__ void house_losses_body(const LossArgs& a) {       // one block of 1024 threads
+  const float* __restrict__ d_real = a.d_real; const float* __restrict__ d_fake = a.d_fake; const float* __restrict__ d_fake_g = a.d_fake_g;
+  const float* __restrict__ g_cls = a.g_cls; const float* __restrict__ am = a.am; const float* __restrict__ pen = a.pen; float* __restrict__ out = a.out;
+  const size_t n = a.n; const double inv_n = a.inv_n; const float l_cls = a.l_cls, l_reg = a.l_reg, l_mask = a.l_mask, w_reg_log = a.w_reg_log;
   __shared__ double red[1024];
   __shared__ float means[3];
   const float* vec[3] = {d_real, d_fake, d_fake_g};
@@ -672,6 +694,14 @@ __global__ void __launch_bounds__(1024) house_losses_kernel(const float* __restr
   }
 }
 
+__global__ void __launch_bounds__(1024) house_losses_kernel(LossArgs a) { house_losses_body(a); }
+// Riders: two launches of the tabular step that do not depend on each other as ONE launch whose blocks split between the two bodies
+// (a graph with parallel branches is launched node by node by the host; one launch is not).  Block 0: the logged scalars (needs the
+// last critic forward); blocks 1 ..: the way back from dLoss/dx_cf to the generator's outputs.  Same bodies, same bits.
+__global__ void __launch_bounds__(1024) house_residual_bwd_losses_kernel(ResBwdArgs r, LossArgs l) {
+  if (blockIdx.x == 0) house_losses_body(l);
+  else house_residual_bwd_body(r, blockIdx.x - 1, gridDim.x - 1, 1024);
+}
 __global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ gout, float scale, size_t n, float* __restrict__ dx) {
   const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = g;
@@ -887,6 +917,14 @@ __global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBat
   const int l = blockIdx.x;       // outputs of call r of layer l: entry r * n + l
   spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n);
 }
+// Rider: the critic step's power iterations only need the critic's weights, so they ride with the residual block's forward —
+// blocks 0 .. 255 the residual block (its ticket counts those 256), blocks 256 .. one matrix each.  Same bodies, same bits.
+constexpr int RES_BLOCKS = 256;
+__global__ void __launch_bounds__(256) house_residual_fwd_sn_kernel(ResFwdArgs a, SnFwdBatch b, float eps, int power_iter, int n, int reps) {
+  if (blockIdx.x < RES_BLOCKS) { house_residual_fwd_body<false>(a, blockIdx.x, RES_BLOCKS); return; }
+  const int l = blockIdx.x - RES_BLOCKS;
+  spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n);
+}
 // passes > 1: the backward of that many calls of the same layer (entry q * n + l), one after the other into the same dW — the first
 // writes or accumulates as its flag says, the others add, exactly as chained launches would; then db_dst[l] += db_src[l] (the bias
 // gradient of a later pass, reduced into its own buffer by the grouped weight-gradient launch, which cannot order two writers)
@@ -993,14 +1031,13 @@ extern "C" int pcg_gemm_act(int transA, int transB, int32_t M, int32_t N, int32_
   return launch_status("gemm_kernel");
 }
 
-extern "C" int pcg_spectral_norm_fwd_batched_reps(int32_t n, int32_t reps, const float* const* w_orig, const int32_t* out_features,
-                                                  const int32_t* in_features, float* const* u, float* const* v, float eps, int power_iteration,
-                                                  float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
-                                                  pcg_stream_t stream) {
+namespace {
+int fill_sn_fwd_batch(SnFwdBatch& b, int32_t n, int32_t reps, const float* const* w_orig, const int32_t* out_features, const int32_t* in_features,
+                      float* const* u, float* const* v, int power_iteration, float* const* w_bar, float* const* sigma, float* const* u_used,
+                      float* const* v_used) {
   PCG_REQUIRE(n > 0 && reps >= 1 && n * reps <= SN_MAX && w_orig && out_features && in_features && u && v && w_bar && sigma && u_used && v_used,
               "pcg_spectral_norm_fwd_batched: bad arguments (at most %d layers x calls)", SN_MAX);
   PCG_REQUIRE(reps == 1 || power_iteration, "pcg_spectral_norm_fwd_batched_reps: several calls only differ in training mode");
-  SnFwdBatch b{};
   for (int l = 0; l < n; ++l) {
     PCG_REQUIRE(w_orig[l] && u[l] && v[l] && out_features[l] > 0 && out_features[l] <= 256 && in_features[l] > 0 && in_features[l] <= 256,
                 "pcg_spectral_norm_fwd_batched: layer %d: bad arguments", l);
@@ -1010,6 +1047,16 @@ extern "C" int pcg_spectral_norm_fwd_batched_reps(int32_t n, int32_t reps, const
     PCG_REQUIRE(w_bar[e] && sigma[e], "pcg_spectral_norm_fwd_batched: output set %d: null buffer", e);
     b.Wbar[e] = w_bar[e]; b.sigma[e] = sigma[e]; b.uu[e] = u_used[e]; b.vu[e] = v_used[e];
   }
+  return PCG_OK;
+}
+}  // namespace
+
+extern "C" int pcg_spectral_norm_fwd_batched_reps(int32_t n, int32_t reps, const float* const* w_orig, const int32_t* out_features,
+                                                  const int32_t* in_features, float* const* u, float* const* v, float eps, int power_iteration,
+                                                  float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
+                                                  pcg_stream_t stream) {
+  SnFwdBatch b{};
+  if (int e = fill_sn_fwd_batch(b, n, reps, w_orig, out_features, in_features, u, v, power_iteration, w_bar, sigma, u_used, v_used)) return e;
   hipLaunchKernelGGL(spectral_norm_fwd_batched_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, b, eps, power_iteration, n, reps);
   return launch_status("spectral_norm_fwd_batched_kernel");
 }
@@ -1229,8 +1276,8 @@ extern "C" int pcg_house_losses(const float* d_real, const float* d_fake, const 
                                 float* out5, pcg_stream_t stream) {
   PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
               "pcg_house_losses: bad arguments (critic outputs of at most 16384 rows)");
-  hipLaunchKernelGGL(house_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n,
-                     g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5);
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5};
+  hipLaunchKernelGGL(house_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, la);
   return launch_status("house_losses_kernel");
 }
 
@@ -1259,35 +1306,88 @@ extern "C" int pcg_spectral_norm_bwd(const float* dw_bar, const float* w_bar, in
   return launch_status("spectral_norm_bwd_kernel");
 }
 
+namespace {
+int fill_res_fwd_args(ResFwdArgs& a, const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
+                      const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked, float* x_cf,
+                      float* partial512, int32_t* ticket, float* pen_out, float* am_out) {
+  PCG_REQUIRE(cont && samples && seg_dev && norm && x && mask && col_src && res && masked && x_cf && partial512 && ticket && pen_out && am_out &&
+                  B > 0 && D > 0 && D <= 32 && T > 0 && ncont >= 0, "pcg_house_residual_fwd: bad arguments (at most 32 feature columns)");
+  int nseg = 0;                                            // number of categorical heads = the largest -(src) among the columns
+  for (int c = 0; c < D; ++c) { a.cols.src[c] = col_src[c]; if (col_src[c] < 0 && -col_src[c] > nseg) nseg = -col_src[c]; }
+  PCG_REQUIRE(nseg <= 32, "pcg_house_residual_fwd: at most 32 categorical heads");
+  a.cont = cont; a.ncont = ncont; a.samples = samples; a.seg = seg_dev; a.nseg = nseg; a.T = T; a.norm = norm; a.x = x; a.mask = mask; a.D = D;
+  a.n = (size_t)B * D; a.inv_n = 1.0 / (double)a.n; a.res = res; a.masked = masked; a.x_cf = x_cf; a.partial = partial512; a.ticket = ticket;
+  a.pen_out = pen_out; a.am_out = am_out;
+  return PCG_OK;
+}
+int fill_res_bwd_args(ResBwdArgs& a, const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b, float w_pen,
+                      float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S, int32_t T,
+                      const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont, float* dsamples) {
+  PCG_REQUIRE(res && masked && mask && gx_a && gx_b && cont_idx_dev && seg_dev && cat_idx_dev && norm && dcont && dsamples && B > 0 && D > 0 &&
+                  S >= 0 && T > 0 && ncont >= 0 && ncont + S > 0, "pcg_house_residual_bwd: bad arguments");
+  a = ResBwdArgs{res, masked, mask, gx_a, gx_b, w_pen, w_am, (size_t)B * D, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples};
+  return PCG_OK;
+}
+}  // namespace
+
 extern "C" int pcg_house_residual_fwd(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
                                       const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
                                       float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out, pcg_stream_t stream) {
-  PCG_REQUIRE(cont && samples && seg_dev && norm && x && mask && col_src && res && masked && x_cf && partial512 && ticket && pen_out && am_out &&
-                  B > 0 && D > 0 && D <= 32 && T > 0 && ncont >= 0, "pcg_house_residual_fwd: bad arguments (at most 32 feature columns)");
-  ResCols cols{};
-  int nseg = 0;                                            // number of categorical heads = the largest -(src) among the columns
-  for (int c = 0; c < D; ++c) { cols.src[c] = col_src[c]; if (col_src[c] < 0 && -col_src[c] > nseg) nseg = -col_src[c]; }
-  PCG_REQUIRE(nseg <= 32, "pcg_house_residual_fwd: at most 32 categorical heads");
-  const size_t n = (size_t)B * D;
+  ResFwdArgs a{};
+  if (int e = fill_res_fwd_args(a, cont, ncont, samples, seg_dev, T, norm, x, mask, col_src, D, B, res, masked, x_cf, partial512, ticket, pen_out, am_out)) return e;
   hipStream_t s = (hipStream_t)stream;
-  if (n <= 16 * 1024) {
-    hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, cont, ncont, samples, seg_dev, nseg, T, norm, x, mask, cols, D, n,
-                       1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
-  } else {
-    hipLaunchKernelGGL(house_residual_fwd_kernel<false>, dim3(256), dim3(256), 0, s, cont, ncont, samples, seg_dev, nseg, T, norm, x, mask, cols, D, n,
-                       1.0 / (double)n, res, masked, x_cf, partial512, ticket, pen_out, am_out);
-  }
+  if (a.n <= 16 * 1024) hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL(house_residual_fwd_kernel<false>, dim3(RES_BLOCKS), dim3(256), 0, s, a);
   return launch_status("house_residual_fwd_kernel");
+}
+
+// pcg_house_residual_fwd + pcg_spectral_norm_fwd_batched_reps (training mode) as ONE launch: the two do not depend on each other
+extern "C" int pcg_house_residual_fwd_sn(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
+                                         const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
+                                         float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out,
+                                         int32_t n_layers, int32_t reps, const float* const* w_orig, const int32_t* out_features,
+                                         const int32_t* in_features, float* const* u, float* const* v, float eps, float* const* w_bar,
+                                         float* const* sigma, float* const* u_used, float* const* v_used, pcg_stream_t stream) {
+  ResFwdArgs a{};
+  if (int e = fill_res_fwd_args(a, cont, ncont, samples, seg_dev, T, norm, x, mask, col_src, D, B, res, masked, x_cf, partial512, ticket, pen_out, am_out)) return e;
+  SnFwdBatch b{};
+  if (int e = fill_sn_fwd_batch(b, n_layers, reps, w_orig, out_features, in_features, u, v, 1, w_bar, sigma, u_used, v_used)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (a.n <= 16 * 1024) {                                  // the one-block form of the residual kernel: two launches
+    hipLaunchKernelGGL(house_residual_fwd_kernel<true>, dim3(1), dim3(1024), 0, s, a);
+    if (int e = launch_status("house_residual_fwd_kernel")) return e;
+    hipLaunchKernelGGL(spectral_norm_fwd_batched_kernel, dim3(n_layers), dim3(256), 0, s, b, eps, 1, n_layers, reps);
+    return launch_status("spectral_norm_fwd_batched_kernel");
+  }
+  hipLaunchKernelGGL(house_residual_fwd_sn_kernel, dim3(RES_BLOCKS + n_layers), dim3(256), 0, s, a, b, eps, 1, n_layers, reps);
+  return launch_status("house_residual_fwd_sn_kernel");
 }
 
 extern "C" int pcg_house_residual_bwd(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b, float w_pen,
                                       float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S, int32_t T,
                                       const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont, float* dsamples,
                                       pcg_stream_t stream) {
-  PCG_REQUIRE(res && masked && mask && gx_a && gx_b && cont_idx_dev && seg_dev && cat_idx_dev && norm && dcont && dsamples && B > 0 && D > 0 &&
-                  S >= 0 && T > 0 && ncont >= 0 && ncont + S > 0, "pcg_house_residual_bwd: bad arguments");
+  ResBwdArgs a{};
+  if (int e = fill_res_bwd_args(a, res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples)) return e;
   const size_t work = (size_t)B * (ncont + S);
-  hipLaunchKernelGGL(house_residual_bwd_kernel, dim3((unsigned)std::min<size_t>((work + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, res, masked,
-                     mask, gx_a, gx_b, w_pen, w_am, (size_t)B * D, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples);
+  hipLaunchKernelGGL(house_residual_bwd_kernel, dim3((unsigned)std::min<size_t>((work + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status("house_residual_bwd_kernel");
+}
+
+// pcg_house_residual_bwd + pcg_house_losses as ONE launch (the logged scalars do not feed the backward)
+extern "C" int pcg_house_residual_bwd_losses(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b,
+                                             float w_pen, float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev, int32_t S,
+                                             int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont,
+                                             float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g, int32_t n,
+                                             const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask,
+                                             float w_reg_log, float* out5, pcg_stream_t stream) {
+  ResBwdArgs a{};
+  if (int e = fill_res_bwd_args(a, res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples)) return e;
+  PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
+              "pcg_house_residual_bwd_losses: bad arguments (critic outputs of at most 16384 rows)");
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5};
+  const size_t work = (size_t)B * (ncont + S);
+  hipLaunchKernelGGL(house_residual_bwd_losses_kernel, dim3(1 + (unsigned)std::min<size_t>((work + 1023) / 1024, 4096)), dim3(1024), 0,
+                     (hipStream_t)stream, a, la);
+  return launch_status("house_residual_bwd_losses_kernel");
 }

@@ -517,17 +517,22 @@ class Discriminator(FlatModule):
             a = z
         return a, (layers if keep else None)
 
-    def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b):
+    def _sn_operands(self):
+        """(w_origs, us, vs, eps) of the spectrally normalised Linears: what a power iteration of this critic reads and updates."""
+        lins = self._linears()
+        return [l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins], 1e-12
+
+    def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b, sn=None):
         """The critic step's two passes as one: D(a) then D(b) — two successive power iterations, as two forward calls make them —
         and the backward of cot_b . D(b) followed by that of cot_a . D(a) into the gradient buffer (the order the chained calls
         of train_step use), in FIVE launches instead of ten: both power iterations, both forwards, both backwards, all sixteen
         weight / bias reductions, both passes through W / sigma.  Per element the arithmetic of the chained calls (same bits).
-        Returns (D(a), D(b))."""
+        Returns (D(a), D(b)).  `sn`: the result of the two power iterations when the caller has already launched them."""
         import ctypes
         from ._lib import load
         lins = self._linears()
-        sn_a, sn_b = ops.spectral_norm_fwd_batched_reps([l.weight_orig.data for l in lins], [l.weight_u for l in lins],
-                                                        [l.weight_v for l in lins], 1e-12, 2)
+        # sn: the two power iterations already made (they rode with the residual block's launch, ops.house_residual_fwd(sn=...))
+        sn_a, sn_b = sn if sn is not None else ops.spectral_norm_fwd_batched_reps(*self._sn_operands(), 2)
         B = x_a.shape[0]
         dev = x_a.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -946,9 +951,14 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     with torch.no_grad():            # no autograd graph anywhere in this schedule: every backward below is called directly
         cont, _, samples, g_saved = generator._run_forward(x, target_onehot, mask, generator._noise(gumbel, B, dev),
                                                            float(config["gumbel_tau"]), False)            # :259-261
-        # residual assembly, mask, x_cf and both L1 penalties (:266-287, :305): one launch
-        residual_full, masked_residual, x_cf, mask_penalty_pre, am = ops.house_residual_fwd(
-            cont.contiguous(), samples.contiguous(), seg, norm_vals, x, mask, generator.col_src())
+        # residual assembly, mask, x_cf and both L1 penalties (:266-287, :305): one launch — and the critic step's two power
+        # iterations ride in it (they only read the critic's weights: one launch less on the chain)
+        onehot_y = onehots[1] if onehots is not None else ops.onehot(y, nc)
+        pair = branch2 is None and discriminator._fused_ok(x, onehot_y) and all(p.requires_grad for p in discriminator.parameters())
+        rf = ops.house_residual_fwd(cont.contiguous(), samples.contiguous(), seg, norm_vals, x, mask, generator.col_src(),
+                                    sn=discriminator._sn_operands() + (2,) if pair else None)
+        residual_full, masked_residual, x_cf, mask_penalty_pre, am = rf[:5]
+        sn_pair = rf[5] if pair else None
     # the zero-fills of the two gradient buffers are not launched: every parameter of both nets receives a gradient in this step,
     # so the first writer overwrites (0 + g == g)
     discriminator.drop_grads(); generator.drop_grads()
@@ -965,10 +975,9 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         t.record_stream(branch)
     # ---- D step (:290-295)
     xd = x_cf.detach()
-    onehot_y = onehots[1] if onehots is not None else ops.onehot(y, nc)
     with torch.no_grad():
-        if branch2 is None and discriminator._fused_ok(x, onehot_y) and all(p.requires_grad for p in discriminator.parameters()):
-            d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos)       # :290-294, five launches
+        if pair:
+            d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos, sn=sn_pair)   # :290-294, four launches
         elif branch2 is None or not discriminator._fused_ok(x, onehot_y):
             d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True)                 # :290
             d_fake, sv_f = discriminator._run_forward(xd, target_onehot, keep=True)           # :291
@@ -1000,35 +1009,34 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     # ---- G step (:298-316)
     with torch.no_grad():
         d_fake_for_g, sv_g = discriminator._run_forward(xd, target_onehot, keep=True)         # :298
-        fwd_done = torch.cuda.Event()
-        fwd_done.record(main)
+        ride = B <= 16 * 1024  # the five logged scalars ride in the launch of the residual block's backward (same trees, same bits)
+        if not ride:
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(main)
         dx_d = discriminator._run_backward(sv_g, cot_neg, True, not skip_dead_d_wgrad)        # d(-mean(D(x_cf)))/d(x_cf)
-    # the logged scalars: on the branch, as soon as the last critic forward is out
-    branch.wait_event(fwd_done)
-    with torch.cuda.stream(branch), torch.no_grad():
-        if B <= 16 * 1024:       # all five in one launch (same reduction trees and fma chains: the same bits)
-            out5 = torch.empty(5, dtype=torch.float32, device=dev)
-            ops.check(_lib_load().pcg_house_losses(ops._p(d_real), ops._p(d_fake), ops._p(d_fake_for_g), B, ops._p(g_cls), ops._p(am),
-                                                   ops._p(mask_penalty_pre), float(config["lambda_cls"]),
-                                                   float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat, ops._p(out5),
-                                                   ops._stream()), "pcg_house_losses")
-            d_loss, g_loss, g_adv, g_reg = out5[0], out5[1], out5[2], out5[3]                 # :292, :307-312
-        else:
+    if not ride:               # on the branch, as soon as the last critic forward is out
+        branch.wait_event(fwd_done)
+        with torch.cuda.stream(branch), torch.no_grad():
             m_fake = ops.mean_fwd(d_fake_for_g.contiguous()).view(())
             d_loss = ops.weighted_sum_fwd([ops.mean_fwd(d_fake.contiguous()), ops.mean_fwd(d_real.contiguous())], [1.0, -1.0]).view(())
             g_loss = ops.weighted_sum_fwd([m_fake, g_cls, am, mask_penalty_pre],
                                           [-1.0, config["lambda_cls"], config["lambda_reg"] * d_feat, config["lambda_mask"]]).view(())
             g_adv = ops.weighted_sum_fwd([m_fake], [-1.0]).view(())
             g_reg = ops.weighted_sum_fwd([am], [d_feat]).view(())
-    for t in (d_real, d_fake, d_fake_for_g):
-        t.record_stream(branch)
-    main.wait_stream(branch)                                                                  # join: dx_cls
-    dx_cls.record_stream(main)
+        for t in (d_real, d_fake, d_fake_for_g):
+            t.record_stream(branch)
+    main.wait_stream(branch)                                                                  # join: dx_cls (and g_cls)
+    dx_cls.record_stream(main); g_cls.record_stream(main)
     with torch.no_grad():
         # :314-315 from dLoss/dx_cf = dx_d + dx_cls and the two penalty weights down to the generator's outputs: one launch
-        d_cont, d_samples = ops.house_residual_bwd(residual_full, masked_residual, mask, dx_d.contiguous(), dx_cls.contiguous(),
-                                                   config["lambda_mask"], config["lambda_reg"] * d_feat, len(generator.continuous_idx), cont_idx,
-                                                   seg, generator.total_cat, cat_idx, norm_vals)
+        rb = ops.house_residual_bwd(residual_full, masked_residual, mask, dx_d.contiguous(), dx_cls.contiguous(),
+                                    config["lambda_mask"], config["lambda_reg"] * d_feat, len(generator.continuous_idx), cont_idx,
+                                    seg, generator.total_cat, cat_idx, norm_vals,
+                                    losses=(d_real, d_fake, d_fake_for_g, g_cls, am, mask_penalty_pre, float(config["lambda_cls"]),
+                                            float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat) if ride else None)
+        d_cont, d_samples = rb[:2]
+        if ride:
+            d_loss, g_loss, g_adv, g_reg = rb[2][0], rb[2][1], rb[2][2], rb[2][3]             # :292, :307-312
         generator._run_backward(g_saved, d_cont, None, d_samples)
     opt_g.step()                                                                              # :316
     main.wait_stream(branch)                                                                  # final join

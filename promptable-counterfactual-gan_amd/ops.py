@@ -716,10 +716,11 @@ def assemble_residual_fwd(cont, cont_idx, samples, seg_offsets, cat_idx, norm_va
     return res
 
 
-def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src):
+def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src, sn=None):
     """(residual_full, masked_residual, x_cf, mask_penalty, am) of the tabular step in one launch: assemble_residual_fwd +
     scale_mask_fwd + axpby + 2 x abs_mean_fwd, bit for bit.  col_src: host list, per feature column the continuous index (>= 0) or
-    -(head + 1)."""
+    -(head + 1).  sn = (w_origs, us, vs, eps, reps): spectral_norm_fwd_batched_reps of these matrices rides in the same launch (the
+    two do not depend on each other); its result is appended to the returned tuple."""
     import ctypes
     _chk(cont, "cont"); _chk(samples, "samples"); _chk(x, "x"); _chk(mask, "mask"); _chk(norm_vals, "norm_vals")
     B, D = x.shape
@@ -728,24 +729,43 @@ def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src):
     part = torch.empty(512, dtype=torch.float32, device=x.device)
     tk = _ticket_buffer(x.device)
     src = (ctypes.c_int32 * D)(*[int(v) for v in col_src])
-    check(_lib.load().pcg_house_residual_fwd(_p(cont), cont.shape[1], _p(samples), _p(seg_offsets), samples.shape[1], _p(norm_vals), _p(x), _p(mask),
-                                             src, D, B, _p(res), _p(masked), _p(x_cf), _p(part), tk.data_ptr() + 4 * 1024, _p(scal),
-                                             scal.data_ptr() + 4, _stream()), "pcg_house_residual_fwd")
-    return res, masked, x_cf, scal[0], scal[1]
+    args = (_p(cont), cont.shape[1], _p(samples), _p(seg_offsets), samples.shape[1], _p(norm_vals), _p(x), _p(mask), src, D, B, _p(res),
+            _p(masked), _p(x_cf), _p(part), tk.data_ptr() + 4 * 1024, _p(scal), scal.data_ptr() + 4)
+    if sn is None:
+        check(_lib.load().pcg_house_residual_fwd(*args, _stream()), "pcg_house_residual_fwd")
+        return res, masked, x_cf, scal[0], scal[1]
+    w_origs, us, vs, eps, reps = sn
+    n = len(w_origs)
+    outs, flat = _sn_outputs(w_origs, us, vs, reps)
+    I32 = ctypes.c_int32 * n
+    check(_lib.load().pcg_house_residual_fwd_sn(*args, n, reps, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]),
+                                                I32(*[w.shape[1] for w in w_origs]), _ptr_array(us), _ptr_array(vs), float(eps),
+                                                _ptr_array([o[0] for o in flat]), _ptr_array([o[1] for o in flat]),
+                                                _ptr_array([o[2] for o in flat]), _ptr_array([o[3] for o in flat]), _stream()),
+          "pcg_house_residual_fwd_sn")
+    return res, masked, x_cf, scal[0], scal[1], outs
 
 
-def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
+def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals, losses=None):
     """(d_cont, d_samples): the tabular step's backward from dLoss/dx_cf = gx_a + gx_b and the two penalty weights down to the
-    generator's outputs, in one launch (see pcg_house_residual_bwd)."""
+    generator's outputs, in one launch (see pcg_house_residual_bwd).  losses = (d_real, d_fake, d_fake_g, g_cls, am, pen, lambda_cls,
+    w_reg, lambda_mask, w_reg_log): pcg_house_losses rides in the same launch; its five scalars are appended to the returned tuple."""
     for t, nme in ((res, "res"), (masked, "masked"), (mask, "mask"), (gx_a, "gx_a"), (gx_b, "gx_b")):
         _chk(t, nme)
     B, D = res.shape
     dcont = torch.empty((B, ncont), dtype=torch.float32, device=res.device)
     dsamples = torch.empty((B, T), dtype=torch.float32, device=res.device)
-    check(_lib.load().pcg_house_residual_bwd(_p(res), _p(masked), _p(mask), _p(gx_a), _p(gx_b), float(w_pen), float(w_am), ncont, _p(cont_idx),
-                                             _p(seg_offsets), cat_idx.numel(), T, _p(cat_idx), _p(norm_vals), D, B, _p(dcont), _p(dsamples),
-                                             _stream()), "pcg_house_residual_bwd")
-    return dcont, dsamples
+    args = (_p(res), _p(masked), _p(mask), _p(gx_a), _p(gx_b), float(w_pen), float(w_am), ncont, _p(cont_idx), _p(seg_offsets), cat_idx.numel(),
+            T, _p(cat_idx), _p(norm_vals), D, B, _p(dcont), _p(dsamples))
+    if losses is None:
+        check(_lib.load().pcg_house_residual_bwd(*args, _stream()), "pcg_house_residual_bwd")
+        return dcont, dsamples
+    d_real, d_fake, d_fake_g, g_cls, am, pen, l_cls, w_reg, l_mask, w_reg_log = losses
+    out5 = torch.empty(5, dtype=torch.float32, device=res.device)
+    check(_lib.load().pcg_house_residual_bwd_losses(*args, _p(d_real), _p(d_fake), _p(d_fake_g), d_real.numel(), _p(g_cls), _p(am), _p(pen),
+                                                    float(l_cls), float(w_reg), float(l_mask), float(w_reg_log), _p(out5), _stream()),
+          "pcg_house_residual_bwd_losses")
+    return dcont, dsamples, out5
 
 
 def assemble_residual_bwd(dres, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
@@ -802,12 +822,16 @@ def spectral_norm_fwd_batched(w_origs, us, vs, eps, power_iteration):
     return outs
 
 
+def _sn_outputs(w_origs, us, vs, reps):
+    outs = [[(torch.empty_like(w), torch.empty(1, dtype=torch.float32, device=w.device), torch.empty_like(u), torch.empty_like(v))
+             for w, u, v in zip(w_origs, us, vs)] for _ in range(reps)]
+    return outs, [o for call in outs for o in call]
+
+
 def spectral_norm_fwd_batched_reps(w_origs, us, vs, eps, reps):
     """`reps` successive training-mode calls in one launch: [[(w_bar, sigma, u_used, v_used)] per layer] per call."""
     n = len(w_origs)
-    outs = [[(torch.empty_like(w), torch.empty(1, dtype=torch.float32, device=w.device), torch.empty_like(u), torch.empty_like(v))
-             for w, u, v in zip(w_origs, us, vs)] for _ in range(reps)]
-    flat = [o for call in outs for o in call]
+    outs, flat = _sn_outputs(w_origs, us, vs, reps)
     I32 = ctypes.c_int32 * n
     check(_lib.load().pcg_spectral_norm_fwd_batched_reps(n, reps, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]),
                                                          I32(*[w.shape[1] for w in w_origs]), _ptr_array(us), _ptr_array(vs), float(eps), 1,
