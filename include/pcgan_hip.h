@@ -611,7 +611,11 @@ int pcg_house_residual_bwd(const float* res, const float* masked, const float* m
  *   pcg_house_residual_fwd_sn      = pcg_house_residual_fwd + pcg_spectral_norm_fwd_batched_reps (training mode: the critic step's
  *                                    power iterations only need the critic's weights; trainer.py:266-287 beside models/discriminator.py:9-16)
  *   pcg_house_residual_bwd_losses  = pcg_house_residual_bwd + pcg_house_losses (the logged scalars do not feed the backward;
- *                                    trainer.py:314 beside :292, :307-312) */
+ *                                    trainer.py:314 beside :292, :307-312)
+ *   pcg_house_classifier_fwd_snbwd = pcg_house_classifier_fwd + pcg_spectral_norm_bwd_batched_seq, and
+ *   pcg_house_classifier_bwd_snfwd = pcg_house_classifier_bwd + pcg_spectral_norm_fwd_batched_reps (training mode): the frozen
+ *                                    classifier's term (trainer.py:301-302) does not depend on the critic update (:290-295), so its
+ *                                    two launches carry the critic's spectral-norm work that is on the chain at the same time */
 int pcg_house_residual_fwd_sn(const float* cont, int32_t ncont, const float* samples, const int32_t* seg_dev, int32_t T, const float* norm,
                               const float* x, const float* mask, const int32_t* col_src, int32_t D, int32_t B, float* res, float* masked,
                               float* x_cf, float* partial512, int32_t* ticket, float* pen_out, float* am_out,
@@ -624,6 +628,16 @@ int pcg_house_residual_bwd_losses(const float* res, const float* masked, const f
                                   float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g, int32_t n,
                                   const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask,
                                   float w_reg_log, float* out5, pcg_stream_t stream);
+int pcg_house_classifier_fwd_snbwd(const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2,
+                                   float* a3, float* a4, float* logits, int32_t n, int32_t passes, const float* const* dw_bar,
+                                   const float* const* w_bar, const int32_t* out_features, const int32_t* in_features,
+                                   const float* const* u, const float* const* v, const float* const* sigma, float* const* dw_orig,
+                                   const int32_t* accumulate, float* const* db_dst, const float* const* db_src, pcg_stream_t stream);
+int pcg_house_classifier_bwd_snfwd(const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2,
+                                   const float* a3, const float* a4, float* dx, int32_t n, int32_t reps, const float* const* w_orig,
+                                   const int32_t* out_features, const int32_t* in_features, float* const* u, float* const* v, float eps,
+                                   float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
+                                   pcg_stream_t stream);
 /* The three per-iteration draws of the tabular trainer in one launch — target class != y (trainer.py:248-249, as pcg_randint with
  * exclude), feature mask (:253-255, as pcg_feature_mask), Gumbel noise [B][T] (generator.py:90, as pcg_rand_gumbel) — each from its
  * own counter offset: the values the three separate calls produce.  onehot_target / onehot_y (nullable, [B][num_classes]): the float

@@ -195,6 +195,10 @@ PROTOTYPES = {
     "pcg_spectral_norm_bwd_batched_seq": (_i, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_classifier_fwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_classifier_bwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_house_classifier_fwd_snbwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _vp]),
+    "pcg_house_classifier_bwd_snfwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp,
+                                            _vp]),
     "pcg_linear_wgrad_grouped_slabs": (_i32, [_i32]),
     "pcg_linear_wgrad_grouped_workspace_bytes": (_sz, [_i32, _c.POINTER(WgradItem), _i32]),
     "pcg_house_critic_fwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,7 @@
 //     256 -> 17 tail) split their reduction over the spare waves and the partial tiles are added through LDS in a fixed order.
 // The op chain this replaces is 5 GEMM + 4 LeakyReLU-backward + 5 GEMM launches of 64-128 blocks each (~170 us at batch 4096).
 #include "pcg_common.h"
+#include "spectral_norm_body.h"
 
 namespace pcg {
 namespace {
@@ -200,12 +201,15 @@ struct alignas(16) ClsSmem {
   float part[CL_NW * CL_R * CL_P];         // partial tiles of the split reductions, [wave][column][row]
 };
 
-__global__ void __launch_bounds__(CL_NT) classifier_fwd_kernel(const float* __restrict__ x, int B, ClsFwdW w, float* __restrict__ a1,
-                                                               float* __restrict__ a2, float* __restrict__ a3, float* __restrict__ a4,
-                                                               float* __restrict__ logits) {
-  __shared__ ClsSmem s;
+struct ClsFwdArgs { const float* x; int B; ClsFwdW w; float* a1; float* a2; float* a3; float* a4; float* logits; };
+struct ClsBwdArgs { const float* dlogits; int B; ClsBwdW w; const float* a1; const float* a2; const float* a3; const float* a4; float* dx; };
+
+__device__ __forceinline__ void classifier_fwd_body(const ClsFwdArgs& c, ClsSmem& s, int bid) {
+  const float* __restrict__ x = c.x; float* __restrict__ a1 = c.a1; float* __restrict__ a2 = c.a2; float* __restrict__ a3 = c.a3;
+  float* __restrict__ a4 = c.a4; float* __restrict__ logits = c.logits;
+  const int B = c.B; const ClsFwdW& w = c.w;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-  const size_t row0 = (size_t)blockIdx.x * CL_R;
+  const size_t row0 = (size_t)bid * CL_R;
   const int rows = min(CL_R, B - (int)row0);
   PCG_T(0);
   // the block's input rows, k-major, with the zero rows that pad the reduction to 20
@@ -240,12 +244,12 @@ __global__ void __launch_bounds__(CL_NT) classifier_fwd_kernel(const float* __re
   PCG_T(6);
 }
 
-__global__ void __launch_bounds__(CL_NT) classifier_bwd_kernel(const float* __restrict__ dlogits, int B, ClsBwdW w, const float* __restrict__ a1,
-                                                               const float* __restrict__ a2, const float* __restrict__ a3,
-                                                               const float* __restrict__ a4, float* __restrict__ dx) {
-  __shared__ ClsSmem s;
+__device__ __forceinline__ void classifier_bwd_body(const ClsBwdArgs& c, ClsSmem& s, int bid) {
+  const float* __restrict__ dlogits = c.dlogits; const float* __restrict__ a1 = c.a1; const float* __restrict__ a2 = c.a2;
+  const float* __restrict__ a3 = c.a3; const float* __restrict__ a4 = c.a4; float* __restrict__ dx = c.dx;
+  const int B = c.B; const ClsBwdW& w = c.w;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-  const size_t row0 = (size_t)blockIdx.x * CL_R;
+  const size_t row0 = (size_t)bid * CL_R;
   const int rows = min(CL_R, B - (int)row0);
   // d4[m][k] = (sum_c dlogits[m][c] W5[c][k]) * LeakyReLU'(a4[m][k]): 1024 outputs, two per thread
   {
@@ -310,25 +314,103 @@ __global__ void __launch_bounds__(CL_NT) classifier_bwd_kernel(const float* __re
   }
 }
 
+__global__ void __launch_bounds__(CL_NT) classifier_fwd_kernel(ClsFwdArgs c) {
+  __shared__ ClsSmem s;
+  classifier_fwd_body(c, s, blockIdx.x);
+}
+__global__ void __launch_bounds__(CL_NT) classifier_bwd_kernel(ClsBwdArgs c) {
+  __shared__ ClsSmem s;
+  classifier_bwd_body(c, s, blockIdx.x);
+}
+
+// Riders (see pcg_house_residual_fwd_sn): the frozen classifier's term of the generator loss does not depend on the critic update, so
+// its two launches carry the critic's spectral-norm work that sits on the chain at the same time — the first n blocks one matrix
+// each (256 of the 512 threads; the other four waves end at once, and a block barrier only waits for the waves that are left), the
+// blocks behind them the classifier body.  The two bodies share the block's LDS.  Same bodies, same bits as the separate launches.
+// The rider's blocks come FIRST in the grid: a classifier block is eight waves of 138 registers, so a CU holds one, and blocks behind
+// the 256 of a full batch would only start when one of those ends (measured: the launch then takes the SUM of the two bodies); a
+// rider block that started first leaves room for a classifier block beside its four live waves.
+constexpr size_t CL_RIDER_LDS = sizeof(ClsSmem) > sizeof(SnFwdLds) ? sizeof(ClsSmem) : sizeof(SnFwdLds);
+__global__ void __launch_bounds__(CL_NT) classifier_fwd_snbwd_kernel(ClsFwdArgs c, SnBwdBatch b, SnBwdExtra x, int n, int passes) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CL_RIDER_LDS];
+  if ((int)blockIdx.x >= n) { classifier_fwd_body(c, *reinterpret_cast<ClsSmem*>(lds), blockIdx.x - n); return; }
+  if (threadIdx.x >= 256) return;
+  spectral_norm_bwd_seq_body<true>(b, x, n, passes, blockIdx.x, *reinterpret_cast<SnBwdLds*>(lds));
+}
+__global__ void __launch_bounds__(CL_NT) classifier_bwd_snfwd_kernel(ClsBwdArgs c, SnFwdBatch b, float eps, int n, int reps) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CL_RIDER_LDS];
+  if ((int)blockIdx.x >= n) { classifier_bwd_body(c, *reinterpret_cast<ClsSmem*>(lds), blockIdx.x - n); return; }
+  if (threadIdx.x >= 256) return;
+  const int l = blockIdx.x;
+  spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, 1, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n,
+                         *reinterpret_cast<SnFwdLds*>(lds));
+}
+
 }  // namespace
 }  // namespace pcg
 
 using namespace pcg;
 
+namespace {
+int fill_cls_fwd(ClsFwdArgs& c, const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2, float* a3,
+                 float* a4, float* logits) {
+  PCG_REQUIRE(x && B > 0 && w_kmajor && bias && a1 && a2 && a3 && a4 && logits, "pcg_house_classifier_fwd: bad arguments");
+  for (int l = 0; l < 5; ++l) { PCG_REQUIRE(w_kmajor[l] && bias[l], "pcg_house_classifier_fwd: null layer %d", l); c.w.wt[l] = w_kmajor[l]; c.w.b[l] = bias[l]; }
+  c.x = x; c.B = B; c.a1 = a1; c.a2 = a2; c.a3 = a3; c.a4 = a4; c.logits = logits;
+  return PCG_OK;
+}
+int fill_cls_bwd(ClsBwdArgs& c, const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2, const float* a3,
+                 const float* a4, float* dx) {
+  PCG_REQUIRE(dlogits && B > 0 && w_stored && a1 && a2 && a3 && a4 && dx, "pcg_house_classifier_bwd: bad arguments");
+  for (int l = 0; l < 5; ++l) { PCG_REQUIRE(w_stored[l], "pcg_house_classifier_bwd: null layer %d", l); c.w.w[l] = w_stored[l]; }
+  c.dlogits = dlogits; c.B = B; c.a1 = a1; c.a2 = a2; c.a3 = a3; c.a4 = a4; c.dx = dx;
+  return PCG_OK;
+}
+}  // namespace
+
 extern "C" int pcg_house_classifier_fwd(const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2,
                                         float* a3, float* a4, float* logits, pcg_stream_t stream) {
-  PCG_REQUIRE(x && B > 0 && w_kmajor && bias && a1 && a2 && a3 && a4 && logits, "pcg_house_classifier_fwd: bad arguments");
-  ClsFwdW w{};
-  for (int l = 0; l < 5; ++l) { PCG_REQUIRE(w_kmajor[l] && bias[l], "pcg_house_classifier_fwd: null layer %d", l); w.wt[l] = w_kmajor[l]; w.b[l] = bias[l]; }
-  hipLaunchKernelGGL(classifier_fwd_kernel, dim3((B + CL_R - 1) / CL_R), dim3(CL_NT), 0, (hipStream_t)stream, x, B, w, a1, a2, a3, a4, logits);
+  ClsFwdArgs c{};
+  if (int e = fill_cls_fwd(c, x, B, w_kmajor, bias, a1, a2, a3, a4, logits)) return e;
+  hipLaunchKernelGGL(classifier_fwd_kernel, dim3((B + CL_R - 1) / CL_R), dim3(CL_NT), 0, (hipStream_t)stream, c);
   return launch_status("classifier_fwd_kernel");
 }
 
 extern "C" int pcg_house_classifier_bwd(const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2,
                                         const float* a3, const float* a4, float* dx, pcg_stream_t stream) {
-  PCG_REQUIRE(dlogits && B > 0 && w_stored && a1 && a2 && a3 && a4 && dx, "pcg_house_classifier_bwd: bad arguments");
-  ClsBwdW w{};
-  for (int l = 0; l < 5; ++l) { PCG_REQUIRE(w_stored[l], "pcg_house_classifier_bwd: null layer %d", l); w.w[l] = w_stored[l]; }
-  hipLaunchKernelGGL(classifier_bwd_kernel, dim3((B + CL_R - 1) / CL_R), dim3(CL_NT), 0, (hipStream_t)stream, dlogits, B, w, a1, a2, a3, a4, dx);
+  ClsBwdArgs c{};
+  if (int e = fill_cls_bwd(c, dlogits, B, w_stored, a1, a2, a3, a4, dx)) return e;
+  hipLaunchKernelGGL(classifier_bwd_kernel, dim3((B + CL_R - 1) / CL_R), dim3(CL_NT), 0, (hipStream_t)stream, c);
   return launch_status("classifier_bwd_kernel");
+}
+
+// pcg_house_classifier_fwd + pcg_spectral_norm_bwd_batched_seq as ONE launch
+extern "C" int pcg_house_classifier_fwd_snbwd(const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2,
+                                              float* a3, float* a4, float* logits, int32_t n, int32_t passes, const float* const* dw_bar,
+                                              const float* const* w_bar, const int32_t* out_features, const int32_t* in_features,
+                                              const float* const* u, const float* const* v, const float* const* sigma, float* const* dw_orig,
+                                              const int32_t* accumulate, float* const* db_dst, const float* const* db_src, pcg_stream_t stream) {
+  ClsFwdArgs c{};
+  if (int e = fill_cls_fwd(c, x, B, w_kmajor, bias, a1, a2, a3, a4, logits)) return e;
+  SnBwdBatch b{};
+  SnBwdExtra xx{};
+  if (int e = fill_sn_bwd_batch(b, xx, n, passes, dw_bar, w_bar, out_features, in_features, u, v, sigma, dw_orig, accumulate, db_dst, db_src)) return e;
+  const int ncls = (B + CL_R - 1) / CL_R;
+  hipLaunchKernelGGL(classifier_fwd_snbwd_kernel, dim3(ncls + n), dim3(CL_NT), 0, (hipStream_t)stream, c, b, xx, n, passes);
+  return launch_status("classifier_fwd_snbwd_kernel");
+}
+
+// pcg_house_classifier_bwd + pcg_spectral_norm_fwd_batched_reps (training mode) as ONE launch
+extern "C" int pcg_house_classifier_bwd_snfwd(const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2,
+                                              const float* a3, const float* a4, float* dx, int32_t n, int32_t reps, const float* const* w_orig,
+                                              const int32_t* out_features, const int32_t* in_features, float* const* u, float* const* v, float eps,
+                                              float* const* w_bar, float* const* sigma, float* const* u_used, float* const* v_used,
+                                              pcg_stream_t stream) {
+  ClsBwdArgs c{};
+  if (int e = fill_cls_bwd(c, dlogits, B, w_stored, a1, a2, a3, a4, dx)) return e;
+  SnFwdBatch b{};
+  if (int e = fill_sn_fwd_batch(b, n, reps, w_orig, out_features, in_features, u, v, 1, w_bar, sigma, u_used, v_used)) return e;
+  const int ncls = (B + CL_R - 1) / CL_R;
+  hipLaunchKernelGGL(classifier_bwd_snfwd_kernel, dim3(ncls + n), dim3(CL_NT), 0, (hipStream_t)stream, c, b, eps, n, reps);
+  return launch_status("classifier_bwd_snfwd_kernel");
 }

@@ -148,6 +148,9 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   }
 }
 // dW (+)= (dWbar - (sum dWbar*Wbar) u v^T) / sigma
+// LOWREG: skip the one-burst form (96 loads in flight with their addresses are 360 registers; a rider inside a 512-thread launch has
+// 256 per wave) — the loops below compute the same expressions in the same order: the same bits
+template <bool LOWREG>
 __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O, int I,
                                                        const float* __restrict__ u, const float* __restrict__ v,
                                                        const float* __restrict__ sigma, float* __restrict__ dW, int accumulate, SnBwdLds& lds) {
@@ -155,7 +158,7 @@ __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__
   // schedule of the tabular step) give the same bits
 #pragma clang fp contract(off)
   float* red = lds.red;
-  if (O * I <= 32 * 256) {       // (block-uniform) every operand of the layer in ONE burst: 32 elements per thread at most
+  if (!LOWREG && O * I <= 32 * 256) {       // (block-uniform) every operand of the layer in ONE burst: 32 elements per thread at most
     float* su = lds.su; float* sv = lds.sv;
     constexpr int PER = 32;
     float a[PER], b[PER], w0[PER];
@@ -206,10 +209,12 @@ struct SnBwdBatch { const float* dWbar[SN_MAX]; const float* Wbar[SN_MAX]; const
 // writes or accumulates as its flag says, the others add, exactly as chained launches would; then db_dst[l] += db_src[l] (the bias
 // gradient of a later pass, reduced into its own buffer by the grouped weight-gradient launch, which cannot order two writers)
 struct SnBwdExtra { float* db_dst[SN_MAX]; const float* db_src[SN_MAX]; };
+template <bool LOWREG>
 __device__ __forceinline__ void spectral_norm_bwd_seq_body(const SnBwdBatch& b, const SnBwdExtra& x, int n, int passes, int l, SnBwdLds& lds) {
   for (int q = 0; q < passes; ++q) {
     const int e = q * n + l;
-    spectral_norm_bwd_body(b.dWbar[e], b.Wbar[e], b.O[l], b.I[l], b.u[e], b.v[e], b.sigma[e], b.dW[l], q == 0 ? b.acc[l] : 1, lds);
+    spectral_norm_bwd_body<LOWREG>(b.dWbar[e], b.Wbar[e], b.O[l], b.I[l], b.u[e], b.v[e], b.sigma[e], b.dW[l], q == 0 ? b.acc[l] : 1, lds);
+    if (LOWREG) __syncthreads();       // (the burst form ends with this barrier: red is reused by the next pass)
   }
   if (x.db_dst[l])
     for (int i = threadIdx.x; i < b.O[l]; i += 256) x.db_dst[l][i] += x.db_src[l][i];

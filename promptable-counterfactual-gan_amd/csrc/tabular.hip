@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(256) spectral_norm_bwd_kernel(const float* __r
                                                                 int I, const float* __restrict__ u, const float* __restrict__ v,
                                                                 const float* __restrict__ sigma, float* __restrict__ dW, int accumulate) {
   __shared__ SnBwdLds lds;
-  spectral_norm_bwd_body(dWbar, Wbar, O, I, u, v, sigma, dW, accumulate, lds);
+  spectral_norm_bwd_body<false>(dWbar, Wbar, O, I, u, v, sigma, dW, accumulate, lds);
 }
 
 __global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBatch b, float eps, int power_iter, int n, int reps) {
@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(256) house_residual_fwd_sn_kernel(ResFwdArgs a
 }
 __global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBatch b, SnBwdExtra x, int n, int passes) {
   __shared__ SnBwdLds lds;
-  spectral_norm_bwd_seq_body(b, x, n, passes, blockIdx.x, lds);
+  spectral_norm_bwd_seq_body<false>(b, x, n, passes, blockIdx.x, lds);
 }
 
 }  // namespace

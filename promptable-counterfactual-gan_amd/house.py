@@ -522,12 +522,13 @@ class Discriminator(FlatModule):
         lins = self._linears()
         return [l.weight_orig.data for l in lins], [l.weight_u for l in lins], [l.weight_v for l in lins], 1e-12
 
-    def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b, sn=None):
+    def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b, sn=None, defer_sn_bwd=False):
         """The critic step's two passes as one: D(a) then D(b) — two successive power iterations, as two forward calls make them —
         and the backward of cot_b . D(b) followed by that of cot_a . D(a) into the gradient buffer (the order the chained calls
         of train_step use), in FIVE launches instead of ten: both power iterations, both forwards, both backwards, all sixteen
         weight / bias reductions, both passes through W / sigma.  Per element the arithmetic of the chained calls (same bits).
-        Returns (D(a), D(b)).  `sn`: the result of the two power iterations when the caller has already launched them."""
+        Returns (D(a), D(b)).  `sn`: the result of the two power iterations when the caller has already launched them;
+        defer_sn_bwd: leave the last launch (the backward through W / sigma) to the caller, as a rider."""
         import ctypes
         from ._lib import load
         lins = self._linears()
@@ -564,6 +565,8 @@ class Discriminator(FlatModule):
             seq_a.append((dw_a, sn_a[li][0], sn_a[li][2], sn_a[li][3], sn_a[li][1]))
             dws.append(gw); accs.append(acc); bias_adds.append((gb, gb_a))
         ops.linear_wgrad_grouped(items, B, dev)
+        if defer_sn_bwd:      # the caller launches the backward through W / sigma as a rider: (D(a), D(b), its arguments, what they point to)
+            return outs[0], outs[1], ops.sn_bwd_seq_args([seq_b, seq_a], dws, accs, bias_adds), (seq_b, seq_a, dws, bias_adds)
         ops.spectral_norm_bwd_batched_seq([seq_b, seq_a], dws, accs, bias_adds)
         return outs[0], outs[1]
 
@@ -784,19 +787,26 @@ class NNClassifier(FlatModule):
             if idx > 0:
                 d = _lin_dgrad(lin.weight.data, d, B)
 
-    def _run_forward(self, x, keep=True):
+    def _run_forward(self, x, keep=True, sn_bwd_rider=None):
+        """sn_bwd_rider: the argument list of a spectral-norm backward (ops.sn_bwd_seq_args) that rides in the fused forward launch
+        (the scheduled tabular step: the critic's spectral-norm backward is independent of this classifier)."""
         packed = self._pack()
         a = x.contiguous()
         B = a.shape[0]
+        if sn_bwd_rider is not None and not self._fused_ok(a):
+            raise PcgError("NNClassifier: a rider needs the fused forward launch")
         if self._fused_ok(a):
             # the five layers as ONE launch on the matrix cores (csrc/house_classifier_fused.hip)
             from ._lib import load
             f32 = dict(dtype=torch.float32, device=a.device)
             acts = [torch.empty((B, n), **f32) for n in (256, 256, 128, 64)]
             logits = torch.empty((B, 4), **f32)
-            ops.check(load().pcg_house_classifier_fwd(ops._p(a), B, ops._ptr_array(self._pack_kmajor()), ops._ptr_array([b for _, b in packed]),
-                                                      ops._p(acts[0]), ops._p(acts[1]), ops._p(acts[2]), ops._p(acts[3]), ops._p(logits),
-                                                      ops._stream()), "pcg_house_classifier_fwd")
+            cargs = (ops._p(a), B, ops._ptr_array(self._pack_kmajor()), ops._ptr_array([b for _, b in packed]), ops._p(acts[0]), ops._p(acts[1]),
+                     ops._p(acts[2]), ops._p(acts[3]), ops._p(logits))
+            if sn_bwd_rider is None:
+                ops.check(load().pcg_house_classifier_fwd(*cargs, ops._stream()), "pcg_house_classifier_fwd")
+            else:
+                ops.check(load().pcg_house_classifier_fwd_snbwd(*cargs, *sn_bwd_rider, ops._stream()), "pcg_house_classifier_fwd_snbwd")
             return logits, (acts if keep else None)
         acts = []
         for i, (w, b) in enumerate(packed):
@@ -807,16 +817,25 @@ class NNClassifier(FlatModule):
             a = z
         return a, (acts if keep else None)
 
-    def _run_backward(self, acts, dlogits):
+    def _run_backward(self, acts, dlogits, sn_fwd_rider=None):
+        """sn_fwd_rider = (w_origs, us, vs, eps, reps): that training-mode spectral normalisation rides in the fused backward launch;
+        the return value is then (dx, its outputs)."""
         packed = self._pack()
         d = dlogits.contiguous()
         B = d.shape[0]
-        if d.is_cuda and len(acts) == 4 and [t.shape[1] for t in acts] == [256, 256, 128, 64] and getattr(self, "use_fused", True) and d.shape[1] == 4:
+        fused = d.is_cuda and len(acts) == 4 and [t.shape[1] for t in acts] == [256, 256, 128, 64] and getattr(self, "use_fused", True) and d.shape[1] == 4
+        if sn_fwd_rider is not None and not fused:
+            raise PcgError("NNClassifier: a rider needs the fused backward launch")
+        if fused:
             from ._lib import load
             dx = torch.empty((B, 17), dtype=torch.float32, device=d.device)
-            ops.check(load().pcg_house_classifier_bwd(ops._p(d), B, ops._ptr_array([w for w, _ in packed]), ops._p(acts[0]), ops._p(acts[1]),
-                                                      ops._p(acts[2]), ops._p(acts[3]), ops._p(dx), ops._stream()), "pcg_house_classifier_bwd")
-            return dx
+            cargs = (ops._p(d), B, ops._ptr_array([w for w, _ in packed]), ops._p(acts[0]), ops._p(acts[1]), ops._p(acts[2]), ops._p(acts[3]), ops._p(dx))
+            if sn_fwd_rider is None:
+                ops.check(load().pcg_house_classifier_bwd(*cargs, ops._stream()), "pcg_house_classifier_bwd")
+                return dx
+            outs, sn_args = ops.sn_fwd_reps_args(*sn_fwd_rider)
+            ops.check(load().pcg_house_classifier_bwd_snfwd(*cargs, *sn_args, ops._stream()), "pcg_house_classifier_bwd_snfwd")
+            return dx, outs
         for i in range(len(packed) - 1, -1, -1):
             if i + 1 < len(packed):
                 d = ops.act_bwd(d, acts[i], ACT_LRELU, 0.1, out=d)
@@ -962,21 +981,32 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     # the zero-fills of the two gradient buffers are not launched: every parameter of both nets receives a gradient in this step,
     # so the first writer overwrites (0 + g == g)
     discriminator.drop_grads(); generator.drop_grads()
-    # ---- fork
-    branch.wait_stream(main)
-    with torch.cuda.stream(branch):
-        with torch.no_grad():
-            logits_c, acts_c = classifier._run_forward(x_cf.detach().contiguous(), keep=True)                 # :301
-            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
-                                                    grad_scale=float(config["lambda_cls"]))                  # :302
-            dx_cls = classifier._run_backward(acts_c, dlog)
-            g_cls = g_cls.view(())
-    for t in (x_cf, target_y):
-        t.record_stream(branch)
+    # One stream and the fused critic pair: the classifier's two launches carry the critic's spectral-norm work that is on the chain
+    # at the same time (riders) — its forward the backward through W / sigma of the critic step, its backward the power iteration
+    # of the generator step's critic call.  Otherwise the classifier's term runs on the branch beside the critic update.
+    xc = x_cf.detach().contiguous()
+    riders = pair and branch is main and classifier._fused_ok(xc)
+    if not riders:
+        # ---- fork
+        branch.wait_stream(main)
+        with torch.cuda.stream(branch):
+            with torch.no_grad():
+                logits_c, acts_c = classifier._run_forward(xc, keep=True)                                         # :301
+                g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
+                                                        grad_scale=float(config["lambda_cls"]))                  # :302
+                dx_cls = classifier._run_backward(acts_c, dlog)
+                g_cls = g_cls.view(())
+        for t in (x_cf, target_y):
+            t.record_stream(branch)
     # ---- D step (:290-295)
     xd = x_cf.detach()
     with torch.no_grad():
-        if pair:
+        if riders:
+            d_real, d_fake, snb_args, snb_keep = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos, sn=sn_pair,
+                                                                         defer_sn_bwd=True)                   # :290-294, three launches
+            logits_c, acts_c = classifier._run_forward(xc, keep=True, sn_bwd_rider=snb_args)                  # :301 + the fourth
+            del snb_keep
+        elif pair:
             d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos, sn=sn_pair)   # :290-294, four launches
         elif branch2 is None or not discriminator._fused_ok(x, onehot_y):
             d_real, sv_r = discriminator._run_forward(x, onehot_y, keep=True)                 # :290
@@ -1008,7 +1038,14 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     opt_d.step()                                                                              # :295
     # ---- G step (:298-316)
     with torch.no_grad():
-        d_fake_for_g, sv_g = discriminator._run_forward(xd, target_onehot, keep=True)         # :298
+        sn_g = None
+        if riders:
+            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
+                                                    grad_scale=float(config["lambda_cls"]))                  # :302
+            g_cls = g_cls.view(())
+            dx_cls, sn_out = classifier._run_backward(acts_c, dlog, sn_fwd_rider=discriminator._sn_operands() + (1,))
+            sn_g = sn_out[0]                                                                  # the power iteration of the :298 call
+        d_fake_for_g, sv_g = discriminator._run_forward(xd, target_onehot, keep=True, sn=sn_g)   # :298
         ride = B <= 16 * 1024  # the five logged scalars ride in the launch of the residual block's backward (same trees, same bits)
         if not ride:
             fwd_done = torch.cuda.Event()

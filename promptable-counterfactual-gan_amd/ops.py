@@ -734,15 +734,8 @@ def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src, 
     if sn is None:
         check(_lib.load().pcg_house_residual_fwd(*args, _stream()), "pcg_house_residual_fwd")
         return res, masked, x_cf, scal[0], scal[1]
-    w_origs, us, vs, eps, reps = sn
-    n = len(w_origs)
-    outs, flat = _sn_outputs(w_origs, us, vs, reps)
-    I32 = ctypes.c_int32 * n
-    check(_lib.load().pcg_house_residual_fwd_sn(*args, n, reps, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]),
-                                                I32(*[w.shape[1] for w in w_origs]), _ptr_array(us), _ptr_array(vs), float(eps),
-                                                _ptr_array([o[0] for o in flat]), _ptr_array([o[1] for o in flat]),
-                                                _ptr_array([o[2] for o in flat]), _ptr_array([o[3] for o in flat]), _stream()),
-          "pcg_house_residual_fwd_sn")
+    outs, sn_args = sn_fwd_reps_args(*sn)
+    check(_lib.load().pcg_house_residual_fwd_sn(*args, *sn_args, _stream()), "pcg_house_residual_fwd_sn")
     return res, masked, x_cf, scal[0], scal[1], outs
 
 
@@ -841,20 +834,35 @@ def spectral_norm_fwd_batched_reps(w_origs, us, vs, eps, reps):
     return outs
 
 
-def spectral_norm_bwd_batched_seq(passes, dw_origs, accumulate, bias_adds=None):
-    """passes: [[(dw_bar, w_bar, u, v, sigma)] per layer] per call, applied in this order into dw_origs[l]; bias_adds: per layer
-    (dst, src) or None — dst += src afterwards."""
+def sn_bwd_seq_args(passes, dw_origs, accumulate, bias_adds=None):
+    """The argument list of pcg_spectral_norm_bwd_batched_seq (without the stream), for the launch itself or for a rider launch that
+    carries it (pcg_house_classifier_fwd_snbwd).  The tensors must stay alive until the launch."""
     n = len(dw_origs)
     flat = [e for call in passes for e in call]
     I32 = ctypes.c_int32 * n
     null = ctypes.c_void_p * n
     dst = null(*[(b[0].data_ptr() if b is not None else None) for b in (bias_adds or [None] * n)])
     src = null(*[(b[1].data_ptr() if b is not None else None) for b in (bias_adds or [None] * n)])
-    check(_lib.load().pcg_spectral_norm_bwd_batched_seq(n, len(passes), _ptr_array([e[0] for e in flat]), _ptr_array([e[1] for e in flat]),
-                                                        I32(*[w.shape[0] for w in dw_origs]), I32(*[w.shape[1] for w in dw_origs]),
-                                                        _ptr_array([e[2] for e in flat]), _ptr_array([e[3] for e in flat]),
-                                                        _ptr_array([e[4] for e in flat]), _ptr_array(dw_origs),
-                                                        I32(*[int(bool(a)) for a in accumulate]), dst, src, _stream()),
+    return (n, len(passes), _ptr_array([e[0] for e in flat]), _ptr_array([e[1] for e in flat]), I32(*[w.shape[0] for w in dw_origs]),
+            I32(*[w.shape[1] for w in dw_origs]), _ptr_array([e[2] for e in flat]), _ptr_array([e[3] for e in flat]),
+            _ptr_array([e[4] for e in flat]), _ptr_array(dw_origs), I32(*[int(bool(a)) for a in accumulate]), dst, src)
+
+
+def sn_fwd_reps_args(w_origs, us, vs, eps, reps):
+    """(outputs, argument list) of a training-mode pcg_spectral_norm_fwd_batched_reps as a rider launch passes them (no
+    power_iteration flag, no stream)."""
+    n = len(w_origs)
+    outs, flat = _sn_outputs(w_origs, us, vs, reps)
+    I32 = ctypes.c_int32 * n
+    return outs, (n, reps, _ptr_array(w_origs), I32(*[w.shape[0] for w in w_origs]), I32(*[w.shape[1] for w in w_origs]), _ptr_array(us),
+                  _ptr_array(vs), float(eps), _ptr_array([o[0] for o in flat]), _ptr_array([o[1] for o in flat]),
+                  _ptr_array([o[2] for o in flat]), _ptr_array([o[3] for o in flat]))
+
+
+def spectral_norm_bwd_batched_seq(passes, dw_origs, accumulate, bias_adds=None):
+    """passes: [[(dw_bar, w_bar, u, v, sigma)] per layer] per call, applied in this order into dw_origs[l]; bias_adds: per layer
+    (dst, src) or None — dst += src afterwards."""
+    check(_lib.load().pcg_spectral_norm_bwd_batched_seq(*sn_bwd_seq_args(passes, dw_origs, accumulate, bias_adds), _stream()),
           "pcg_spectral_norm_bwd_batched_seq")
 
 
