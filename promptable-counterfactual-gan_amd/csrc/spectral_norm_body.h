@@ -148,8 +148,9 @@ __device__ __forceinline__ void spectral_norm_fwd_body(const float* __restrict__
   }
 }
 // dW (+)= (dWbar - (sum dWbar*Wbar) u v^T) / sigma
-// LOWREG: skip the one-burst form (96 loads in flight with their addresses are 360 registers; a rider inside a 512-thread launch has
-// 256 per wave) — the loops below compute the same expressions in the same order: the same bits
+// LOWREG: the burst in chunks of 16 elements per thread, the operands of the second sweep loaded again (96 loads in flight with their
+// addresses are 360 registers; a rider inside a 512-thread launch has 256 per wave) — the same expressions in the same order: the
+// same bits (the plain loops at the bottom are the same arithmetic too, but one memory latency per trip: 36 us for two passes)
 template <bool LOWREG>
 __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__ dWbar, const float* __restrict__ Wbar, int O, int I,
                                                        const float* __restrict__ u, const float* __restrict__ v,
@@ -183,6 +184,40 @@ __device__ __forceinline__ void spectral_norm_bwd_body(const float* __restrict__
     __syncthreads();             // su / sv / red are reused by the next pass of a sequence
     return;
   }
+  if (LOWREG && O * I <= 32 * 256) {
+    float* su = lds.su; float* sv = lds.sv;
+    constexpr int CH = 16, NCH = 32 / CH;
+    const float uv = u[min((int)threadIdx.x, O - 1)], vv = v[min((int)threadIdx.x, I - 1)], sg = sigma[0];
+    float t = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      float a[CH], b[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { const int e = min((int)threadIdx.x + 256 * (c * CH + j), O * I - 1); a[j] = dWbar[e]; b[j] = Wbar[e]; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) t = (int)threadIdx.x + 256 * (c * CH + j) < O * I ? fmaf(a[j], b[j], t) : t;
+    }
+    su[threadIdx.x] = uv; sv[threadIdx.x] = vv;
+    const float dot = block_sum(t, red);
+    const float inv = 1.f / sg;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      float a[CH], w0[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { const int e = min((int)threadIdx.x + 256 * (c * CH + j), O * I - 1); a[j] = dWbar[e]; w0[j] = accumulate ? dW[e] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int e = threadIdx.x + 256 * (c * CH + j);
+        if (e < O * I) {
+          const int o = e / I, i = e - o * I;
+          const float g = (a[j] - dot * su[o] * sv[i]) * inv;
+          dW[e] = accumulate ? w0[j] + g : g;
+        }
+      }
+    }
+    __syncthreads();
+    return;
+  }
   float t = 0.f;
   int e0 = threadIdx.x;
   for (; e0 + 7 * 256 < O * I; e0 += 8 * 256) {      // 16 independent loads in flight, products added in element order
@@ -214,7 +249,6 @@ __device__ __forceinline__ void spectral_norm_bwd_seq_body(const SnBwdBatch& b, 
   for (int q = 0; q < passes; ++q) {
     const int e = q * n + l;
     spectral_norm_bwd_body<LOWREG>(b.dWbar[e], b.Wbar[e], b.O[l], b.I[l], b.u[e], b.v[e], b.sigma[e], b.dW[l], q == 0 ? b.acc[l] : 1, lds);
-    if (LOWREG) __syncthreads();       // (the burst form ends with this barrier: red is reused by the next pass)
   }
   if (x.db_dst[l])
     for (int i = threadIdx.x; i < b.O[l]; i += 256) x.db_dst[l][i] += x.db_src[l][i];
