@@ -525,7 +525,8 @@ class Discriminator(FlatModule):
     def _run_pair(self, x_a, onehot_a, cot_a, x_b, onehot_b, cot_b, sn=None, defer_sn_bwd=False):
         """The critic step's two passes as one: D(a) then D(b) — two successive power iterations, as two forward calls make them —
         and the backward of cot_b . D(b) followed by that of cot_a . D(a) into the gradient buffer (the order the chained calls
-        of train_step use), in FIVE launches instead of ten: both power iterations, both forwards, both backwards, all sixteen
+        of train_step use), in FIVE launches instead of ten (four when the caller made the power iterations, three when it also
+        takes the last one as a rider): both power iterations, both forwards, both backwards, all sixteen
         weight / bias reductions, both passes through W / sigma.  Per element the arithmetic of the chained calls (same bits).
         Returns (D(a), D(b)).  `sn`: the result of the two power iterations when the caller has already launched them;
         defer_sn_bwd: leave the last launch (the backward through W / sigma) to the caller, as a rider."""
@@ -938,7 +939,7 @@ def _mean_cotangents(B, device):
 
 def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
                        skip_dead_d_wgrad, onehots=None):
-    """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 44 launches here): what the
+    """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 37 launches on one stream): what the
     reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager vs the reference-order autograd step), with
 
       * no autograd graph: every backward is called directly, in the order autograd would run it;
@@ -949,8 +950,11 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         the logged scalars (D_loss, G_loss, g_adv, g_reg) there too;
       * the critic step's two passes as one (Discriminator._run_pair): the cotangents of the Wasserstein means are the constants
         +-1/B (_mean_cotangents), the fake pass is the first writer of the gradient buffer, the real pass adds;
-      * no gradient zero-fills: every parameter of both nets receives a gradient, the first writer overwrites (0 + g == g).
-    Captured in a HIP graph the two streams are parallel branches; branch="inline": the same kernels on one stream."""
+      * no gradient zero-fills: every parameter of both nets receives a gradient, the first writer overwrites (0 + g == g);
+      * riders (one launch whose blocks split between two independent kernel bodies): the critic step's two power iterations in the
+        residual block's forward launch, the logged scalars in its backward launch; on ONE stream also the critic's backward through
+        W / sigma in the classifier's forward launch and the power iteration of the generator step's critic call in its backward launch.
+    Captured in a HIP graph the two streams are parallel branches; branch="inline": everything on one stream (the default)."""
     nc, dev, B = config["num_classes"], x.device, x.shape[0]
     if classifier.training or any(p.requires_grad for p in classifier.parameters()):
         raise PcgError("train_step(branch=...): the classifier must be frozen and in eval mode (main.py:27-30)")
@@ -1145,7 +1149,7 @@ def compute_metrics_per_target(generator, classifier, X, y, config, gumbel_per_c
 
 
 class GraphedTrainStep:
-    """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 44 as scheduled by
+    """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 37 as scheduled by
     train_step(branch=...) — captured once in a HIP graph and replayed with one host call: this path is latency bound (SURVEY.md
     section 8a row a15), and the graph removes the per-kernel host cost.  overlap="inline" (default): the scheduled step on one
     stream; True: the frozen classifier's term on a parallel graph branch (a graph with branches is launched node by node by the
