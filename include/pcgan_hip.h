@@ -627,12 +627,17 @@ int pcg_house_residual_bwd_losses(const float* res, const float* masked, const f
                                   int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont,
                                   float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g, int32_t n,
                                   const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask,
-                                  float w_reg_log, float* out5, pcg_stream_t stream);
+                                  float w_reg_log, const float* ce_row_loss, int32_t n_ce, float* out6, pcg_stream_t stream);
+/* ce_target != NULL: the forward also evaluates the cross-entropy of its logits against ce_target (trainer.py:302) — per row the
+ * term lse - z[target] into ce_row_loss[B] and ce_grad_scale / B * (softmax - onehot) into ce_dlogits[B][4], the expressions of
+ * pcg_cross_entropy_fwd_bwd; pcg_house_residual_bwd_losses(ce_row_loss, n_ce = B) then forms the mean in that kernel's summation
+ * order (out6[5], and uses it for G_loss instead of *g_cls): the same bits as the separate cross-entropy launch. */
 int pcg_house_classifier_fwd_snbwd(const float* x, int32_t B, const float* const* w_kmajor, const float* const* bias, float* a1, float* a2,
                                    float* a3, float* a4, float* logits, int32_t n, int32_t passes, const float* const* dw_bar,
                                    const float* const* w_bar, const int32_t* out_features, const int32_t* in_features,
                                    const float* const* u, const float* const* v, const float* const* sigma, float* const* dw_orig,
-                                   const int32_t* accumulate, float* const* db_dst, const float* const* db_src, pcg_stream_t stream);
+                                   const int32_t* accumulate, float* const* db_dst, const float* const* db_src,
+                                   const int64_t* ce_target, float ce_grad_scale, float* ce_dlogits, float* ce_row_loss, pcg_stream_t stream);
 int pcg_house_classifier_bwd_snfwd(const float* dlogits, int32_t B, const float* const* w_stored, const float* a1, const float* a2,
                                    const float* a3, const float* a4, float* dx, int32_t n, int32_t reps, const float* const* w_orig,
                                    const int32_t* out_features, const int32_t* in_features, float* const* u, float* const* v, float eps,

@@ -187,7 +187,7 @@ PROTOTYPES = {
     "pcg_house_residual_fwd_sn": (_i, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _c.POINTER(_i32), _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_residual_bwd_losses": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp,
-                                           _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp]),
+                                           _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _i32, _vp, _vp]),
     "pcg_house_draws": (_i, [_vp, _i32, _i32, _vp, _c.c_uint64, _vp, _i32, _vp, _i32, _c.c_uint64, _vp, _i32, _c.c_uint64, _c.c_uint64, _vp, _vp, _vp]),
     "pcg_house_critic_fwd_n": (_i, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_critic_bwd_n": (_i, [_i32, _vp, _i32, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -196,7 +196,7 @@ PROTOTYPES = {
     "pcg_house_classifier_fwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_classifier_bwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_classifier_fwd_snbwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                            _vp, _vp, _vp]),
+                                            _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "pcg_house_classifier_bwd_snfwd": (_i, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp,
                                             _vp]),
     "pcg_linear_wgrad_grouped_slabs": (_i32, [_i32]),

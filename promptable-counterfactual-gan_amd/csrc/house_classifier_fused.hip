@@ -14,6 +14,7 @@
 //   * the eight waves split the 32-column output tiles of a layer (one each at width 256); layers with fewer tiles (128, 64 wide, the
 //     256 -> 17 tail) split their reduction over the spare waves and the partial tiles are added through LDS in a fixed order.
 // The op chain this replaces is 5 GEMM + 4 LeakyReLU-backward + 5 GEMM launches of 64-128 blocks each (~170 us at batch 4096).
+#include <cstdint>
 #include "pcg_common.h"
 #include "spectral_norm_body.h"
 
@@ -201,7 +202,10 @@ struct alignas(16) ClsSmem {
   float part[CL_NW * CL_R * CL_P];         // partial tiles of the split reductions, [wave][column][row]
 };
 
-struct ClsFwdArgs { const float* x; int B; ClsFwdW w; float* a1; float* a2; float* a3; float* a4; float* logits; };
+struct ClsFwdArgs {
+  const float* x; int B; ClsFwdW w; float* a1; float* a2; float* a3; float* a4; float* logits;
+  const int64_t* target; float ce_scale; float* dlogits; float* rowloss;       // target != nullptr: the cross-entropy tail (below)
+};
 struct ClsBwdArgs { const float* dlogits; int B; ClsBwdW w; const float* a1; const float* a2; const float* a3; const float* a4; float* dx; };
 
 __device__ __forceinline__ void classifier_fwd_body(const ClsFwdArgs& c, ClsSmem& s, int bid) {
@@ -234,14 +238,37 @@ __device__ __forceinline__ void classifier_fwd_body(const ClsFwdArgs& c, ClsSmem
   PCG_T(5);
   // Linear(64 -> 4): 64 outputs, one per thread of the first wave
   if (threadIdx.x < CL_R * CL_OUT) {
-    const int m = threadIdx.x >> 2, c = threadIdx.x & 3;
-    float acc = w.b[4][c];
-    const float* wr = w.wt[4] + c * CL_H4;
+    const int m = threadIdx.x >> 2, col = threadIdx.x & 3;
+    float acc = w.b[4][col];
+    const float* wr = w.wt[4] + col * CL_H4;
 #pragma unroll 8
     for (int k = 0; k < CL_H4; ++k) acc = fmaf(s.X[0][k * CL_P + m], wr[k], acc);
-    if (m < rows) logits[(row0 + m) * CL_OUT + c] = acc;
+    if (m < rows) logits[(row0 + m) * CL_OUT + col] = acc;
+    if (c.target) s.part[threadIdx.x] = acc;
   }
   PCG_T(6);
+  // Cross-entropy tail (trainer.py:302, reduction mean): one thread per row with cross_entropy_kernel's expressions — the row's loss
+  // term lse - z[t] goes to rowloss (the launch that logs the scalars adds them in that kernel's order) and the gradient
+  // ce_scale / B * (softmax - onehot) to dlogits.  The same bits as pcg_cross_entropy_fwd_bwd on these logits.
+  if (c.target) {                                      // kernel-uniform
+    __syncthreads();
+    if (threadIdx.x < CL_R && (int)threadIdx.x < rows) {
+      const int m = threadIdx.x;
+      const float r[4] = {s.part[4 * m], s.part[4 * m + 1], s.part[4 * m + 2], s.part[4 * m + 3]};
+      const float g = c.ce_scale * 1.f / (float)B;
+      float mx = r[0];
+      for (int k = 1; k < 4; ++k) mx = fmaxf(mx, r[k]);
+      float se = 0.f;
+      for (int k = 0; k < 4; ++k) se += expf(r[k] - mx);
+      const float lse = mx + logf(se);
+      const int64_t tv = c.target[row0 + m];
+      const int t = tv < 0 ? 0 : (tv >= 4 ? 3 : (int)tv);
+      c.rowloss[row0 + m] = lse - r[t];
+      float o[4];
+      for (int k = 0; k < 4; ++k) o[k] = g * (expf(r[k] - lse) - (k == t ? 1.f : 0.f));
+      *reinterpret_cast<float4*>(c.dlogits + (row0 + m) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
 }
 
 __device__ __forceinline__ void classifier_bwd_body(const ClsBwdArgs& c, ClsSmem& s, int bid) {
@@ -389,9 +416,16 @@ extern "C" int pcg_house_classifier_fwd_snbwd(const float* x, int32_t B, const f
                                               float* a3, float* a4, float* logits, int32_t n, int32_t passes, const float* const* dw_bar,
                                               const float* const* w_bar, const int32_t* out_features, const int32_t* in_features,
                                               const float* const* u, const float* const* v, const float* const* sigma, float* const* dw_orig,
-                                              const int32_t* accumulate, float* const* db_dst, const float* const* db_src, pcg_stream_t stream) {
+                                              const int32_t* accumulate, float* const* db_dst, const float* const* db_src,
+                                              const int64_t* ce_target, float ce_grad_scale, float* ce_dlogits, float* ce_row_loss,
+                                              pcg_stream_t stream) {
   ClsFwdArgs c{};
   if (int e = fill_cls_fwd(c, x, B, w_kmajor, bias, a1, a2, a3, a4, logits)) return e;
+  if (ce_target) {
+    PCG_REQUIRE(ce_dlogits && ce_row_loss && (reinterpret_cast<uintptr_t>(ce_dlogits) & 15) == 0,
+                "pcg_house_classifier_fwd_snbwd: the cross-entropy tail needs dlogits (16-byte aligned) and row_loss");
+    c.target = ce_target; c.ce_scale = ce_grad_scale; c.dlogits = ce_dlogits; c.rowloss = ce_row_loss;
+  }
   SnBwdBatch b{};
   SnBwdExtra xx{};
   if (int e = fill_sn_bwd_batch(b, xx, n, passes, dw_bar, w_bar, out_features, in_features, u, v, sigma, dw_orig, accumulate, db_dst, db_src)) return e;

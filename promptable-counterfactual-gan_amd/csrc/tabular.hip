@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(1024) mean_small_kernel(const float* __restric
 struct LossArgs {
   const float* d_real; const float* d_fake; const float* d_fake_g; size_t n; double inv_n; const float* g_cls; const float* am; const float* pen;
   float l_cls, l_reg, l_mask, w_reg_log; float* out;
+  const float* rowloss; int n_ce;       // rowloss != nullptr: g_cls = the mean of these cross-entropy row terms, summed as cross_entropy_kernel does (out[5])
 };
 __device__ __forceinline__ void house_losses_body(const LossArgs& a) {       // one block of 1024 threads
   const float* __restrict__ d_real = a.d_real; const float* __restrict__ d_fake = a.d_fake; const float* __restrict__ d_fake_g = a.d_fake_g;
@@ -685,10 +686,27 @@ __device__ __forceinline__ void house_losses_body(const LossArgs& a) {       // 
     if (threadIdx.x == 0) means[v] = (float)(red[0] * inv_n);
     __syncthreads();
   }
+  __shared__ float ce_red[1024];
+  float gcls = 0.f;
+  if (a.rowloss) {                                     // kernel-uniform: cross_entropy_kernel's partition (1024 threads above 1024 rows, else 256) and tree
+    const int nt = a.n_ce > 1024 ? 1024 : 256;
+    float acc = 0.f;
+    if ((int)threadIdx.x < nt)
+      for (int b = threadIdx.x; b < a.n_ce; b += nt) acc += a.rowloss[b];
+    ce_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+      if ((int)threadIdx.x < sft) ce_red[threadIdx.x] += ce_red[threadIdx.x + sft];
+      __syncthreads();
+    }
+    gcls = ce_red[0] / (float)a.n_ce;
+  }
   if (threadIdx.x == 0) {
     const float m_real = means[0], m_fake = means[1], m_g = means[2];
+    if (!a.rowloss) gcls = g_cls[0];
+    else out[5] = gcls;
     out[0] = fmaf(-1.f, m_real, fmaf(1.f, m_fake, 0.f));
-    out[1] = fmaf(l_mask, pen[0], fmaf(l_reg, am[0], fmaf(l_cls, g_cls[0], fmaf(-1.f, m_g, 0.f))));
+    out[1] = fmaf(l_mask, pen[0], fmaf(l_reg, am[0], fmaf(l_cls, gcls, fmaf(-1.f, m_g, 0.f))));
     out[2] = fmaf(-1.f, m_g, 0.f);
     out[3] = fmaf(w_reg_log, am[0], 0.f);
     out[4] = m_g;
@@ -1048,7 +1066,7 @@ extern "C" int pcg_house_losses(const float* d_real, const float* d_fake, const 
                                 float* out5, pcg_stream_t stream) {
   PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
               "pcg_house_losses: bad arguments (critic outputs of at most 16384 rows)");
-  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5};
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5, nullptr, 0};
   hipLaunchKernelGGL(house_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, la);
   return launch_status("house_losses_kernel");
 }
@@ -1152,12 +1170,12 @@ extern "C" int pcg_house_residual_bwd_losses(const float* res, const float* mask
                                              int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B, float* dcont,
                                              float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g, int32_t n,
                                              const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg, float lambda_mask,
-                                             float w_reg_log, float* out5, pcg_stream_t stream) {
+                                             float w_reg_log, const float* ce_row_loss, int32_t n_ce, float* out6, pcg_stream_t stream) {
   ResBwdArgs a{};
   if (int e = fill_res_bwd_args(a, res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples)) return e;
-  PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
+  PCG_REQUIRE(d_real && d_fake && d_fake_g && (g_cls || ce_row_loss) && am && pen && out6 && n > 0 && n <= 16 * 1024 && (!ce_row_loss || n_ce > 0),
               "pcg_house_residual_bwd_losses: bad arguments (critic outputs of at most 16384 rows)");
-  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5};
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out6, ce_row_loss, n_ce};
   const size_t work = (size_t)B * (ncont + S);
   hipLaunchKernelGGL(house_residual_bwd_losses_kernel, dim3(1 + (unsigned)std::min<size_t>((work + 1023) / 1024, 4096)), dim3(1024), 0,
                      (hipStream_t)stream, a, la);

@@ -788,9 +788,10 @@ class NNClassifier(FlatModule):
             if idx > 0:
                 d = _lin_dgrad(lin.weight.data, d, B)
 
-    def _run_forward(self, x, keep=True, sn_bwd_rider=None):
+    def _run_forward(self, x, keep=True, sn_bwd_rider=None, ce=None):
         """sn_bwd_rider: the argument list of a spectral-norm backward (ops.sn_bwd_seq_args) that rides in the fused forward launch
-        (the scheduled tabular step: the critic's spectral-norm backward is independent of this classifier)."""
+        (the scheduled tabular step: the critic's spectral-norm backward is independent of this classifier).  ce = (target, grad_scale)
+        with a rider: the launch also leaves the cross-entropy's gradient and row terms; returns (logits, acts, dlogits, row_loss)."""
         packed = self._pack()
         a = x.contiguous()
         B = a.shape[0]
@@ -806,8 +807,14 @@ class NNClassifier(FlatModule):
                      ops._p(acts[2]), ops._p(acts[3]), ops._p(logits))
             if sn_bwd_rider is None:
                 ops.check(load().pcg_house_classifier_fwd(*cargs, ops._stream()), "pcg_house_classifier_fwd")
+            elif ce is None:
+                ops.check(load().pcg_house_classifier_fwd_snbwd(*cargs, *sn_bwd_rider, None, 0.0, None, None, ops._stream()),
+                          "pcg_house_classifier_fwd_snbwd")
             else:
-                ops.check(load().pcg_house_classifier_fwd_snbwd(*cargs, *sn_bwd_rider, ops._stream()), "pcg_house_classifier_fwd_snbwd")
+                dlog, row_loss = torch.empty((B, 4), **f32), torch.empty((B,), **f32)
+                ops.check(load().pcg_house_classifier_fwd_snbwd(*cargs, *sn_bwd_rider, ops._p(ce[0]), float(ce[1]), ops._p(dlog), ops._p(row_loss),
+                                                                ops._stream()), "pcg_house_classifier_fwd_snbwd")
+                return logits, (acts if keep else None), dlog, row_loss
             return logits, (acts if keep else None)
         acts = []
         for i, (w, b) in enumerate(packed):
@@ -1008,7 +1015,11 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         if riders:
             d_real, d_fake, snb_args, snb_keep = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos, sn=sn_pair,
                                                                          defer_sn_bwd=True)                   # :290-294, three launches
-            logits_c, acts_c = classifier._run_forward(xc, keep=True, sn_bwd_rider=snb_args)                  # :301 + the fourth
+            # :301 + the fourth; with the logged scalars riding below, the cross-entropy (:302) is the tail of this launch too
+            ce_tail = B <= 16 * 1024
+            cf = classifier._run_forward(xc, keep=True, sn_bwd_rider=snb_args,
+                                         ce=(target_y, float(config["lambda_cls"])) if ce_tail else None)
+            logits_c, acts_c = cf[:2]
             del snb_keep
         elif pair:
             d_real, d_fake = discriminator._run_pair(x, onehot_y, cot_neg, xd, target_onehot, cot_pos, sn=sn_pair)   # :290-294, four launches
@@ -1044,9 +1055,12 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     with torch.no_grad():
         sn_g = None
         if riders:
-            g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
-                                                    grad_scale=float(config["lambda_cls"]))                  # :302
-            g_cls = g_cls.view(())
+            if ce_tail:
+                dlog, g_cls = cf[2], cf[3]        # g_cls: still the row terms; the launch that logs the scalars forms their mean
+            else:
+                g_cls, dlog = ops.cross_entropy_fwd_bwd(logits_c.contiguous(), target_y, need_loss=True, need_grad=True,
+                                                        grad_scale=float(config["lambda_cls"]))              # :302
+                g_cls = g_cls.view(())
             dx_cls, sn_out = classifier._run_backward(acts_c, dlog, sn_fwd_rider=discriminator._sn_operands() + (1,))
             sn_g = sn_out[0]                                                                  # the power iteration of the :298 call
         d_fake_for_g, sv_g = discriminator._run_forward(xd, target_onehot, keep=True, sn=sn_g)   # :298
@@ -1078,6 +1092,8 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         d_cont, d_samples = rb[:2]
         if ride:
             d_loss, g_loss, g_adv, g_reg = rb[2][0], rb[2][1], rb[2][2], rb[2][3]             # :292, :307-312
+            if g_cls.numel() > 1:
+                g_cls = rb[2][5]
         generator._run_backward(g_saved, d_cont, None, d_samples)
     opt_g.step()                                                                              # :316
     main.wait_stream(branch)                                                                  # final join

@@ -742,7 +742,9 @@ def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src, 
 def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals, losses=None):
     """(d_cont, d_samples): the tabular step's backward from dLoss/dx_cf = gx_a + gx_b and the two penalty weights down to the
     generator's outputs, in one launch (see pcg_house_residual_bwd).  losses = (d_real, d_fake, d_fake_g, g_cls, am, pen, lambda_cls,
-    w_reg, lambda_mask, w_reg_log): pcg_house_losses rides in the same launch; its five scalars are appended to the returned tuple."""
+    w_reg, lambda_mask, w_reg_log): pcg_house_losses rides in the same launch; its scalars (six floats: the five of pcg_house_losses
+    and g_cls) are appended to the returned tuple.  g_cls: the cross-entropy value (a device scalar), or the [B] row terms the fused
+    classifier forward left (then their mean is formed here, in the cross-entropy kernel's order)."""
     for t, nme in ((res, "res"), (masked, "masked"), (mask, "mask"), (gx_a, "gx_a"), (gx_b, "gx_b")):
         _chk(t, nme)
     B, D = res.shape
@@ -754,11 +756,13 @@ def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_i
         check(_lib.load().pcg_house_residual_bwd(*args, _stream()), "pcg_house_residual_bwd")
         return dcont, dsamples
     d_real, d_fake, d_fake_g, g_cls, am, pen, l_cls, w_reg, l_mask, w_reg_log = losses
-    out5 = torch.empty(5, dtype=torch.float32, device=res.device)
-    check(_lib.load().pcg_house_residual_bwd_losses(*args, _p(d_real), _p(d_fake), _p(d_fake_g), d_real.numel(), _p(g_cls), _p(am), _p(pen),
-                                                    float(l_cls), float(w_reg), float(l_mask), float(w_reg_log), _p(out5), _stream()),
+    out6 = torch.empty(6, dtype=torch.float32, device=res.device)
+    rows = g_cls.numel() > 1
+    check(_lib.load().pcg_house_residual_bwd_losses(*args, _p(d_real), _p(d_fake), _p(d_fake_g), d_real.numel(), None if rows else _p(g_cls),
+                                                    _p(am), _p(pen), float(l_cls), float(w_reg), float(l_mask), float(w_reg_log),
+                                                    _p(g_cls) if rows else None, g_cls.numel() if rows else 0, _p(out6), _stream()),
           "pcg_house_residual_bwd_losses")
-    return dcont, dsamples, out5
+    return dcont, dsamples, out6
 
 
 def assemble_residual_bwd(dres, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
