@@ -946,7 +946,7 @@ def _mean_cotangents(B, device):
 
 def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
                        skip_dead_d_wgrad, onehots=None):
-    """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 37 launches on one stream): what the
+    """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 36 launches on one stream): what the
     reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager vs the reference-order autograd step), with
 
       * no autograd graph: every backward is called directly, in the order autograd would run it;
@@ -960,7 +960,8 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
       * no gradient zero-fills: every parameter of both nets receives a gradient, the first writer overwrites (0 + g == g);
       * riders (one launch whose blocks split between two independent kernel bodies): the critic step's two power iterations in the
         residual block's forward launch, the logged scalars in its backward launch; on ONE stream also the critic's backward through
-        W / sigma in the classifier's forward launch and the power iteration of the generator step's critic call in its backward launch.
+        W / sigma in the classifier's forward launch (whose tail is the cross-entropy) and the power iteration of the generator step's
+        critic call in its backward launch.
     Captured in a HIP graph the two streams are parallel branches; branch="inline": everything on one stream (the default)."""
     nc, dev, B = config["num_classes"], x.device, x.shape[0]
     if classifier.training or any(p.requires_grad for p in classifier.parameters()):
@@ -1165,7 +1166,7 @@ def compute_metrics_per_target(generator, classifier, X, y, config, gumbel_per_c
 
 
 class GraphedTrainStep:
-    """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 37 as scheduled by
+    """The whole training step — G forward, critic step, G step, both Adam updates: ~400 kernels as an op chain, 36 as scheduled by
     train_step(branch=...) — captured once in a HIP graph and replayed with one host call: this path is latency bound (SURVEY.md
     section 8a row a15), and the graph removes the per-kernel host cost.  overlap="inline" (default): the scheduled step on one
     stream; True: the frozen classifier's term on a parallel graph branch (a graph with branches is launched node by node by the

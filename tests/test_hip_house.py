@@ -516,13 +516,15 @@ def test_fused_classifier_kernels_match_the_op_chain(pcg, hgold, rows):
         _close(u, v, 2e-5, 2e-5 * float(v.abs().max()), "saved activation")
 
 
-@pytest.mark.parametrize("overlap,batch", [(True, 128), ("critic", 128), (False, 128), ("inline", 128), (True, 4096)])
+@pytest.mark.parametrize("overlap,batch", [(True, 128), ("critic", 128), (False, 128), ("inline", 128), (True, 4096), ("inline", 4096), ("inline", 1000)])
 def test_graphed_step_equals_eager(pcg, hgold, overlap, batch):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
     it (warm-up + capture) does not advance the training state.  overlap=True: the schedule with the classifier term on a parallel
     branch and the critic passes run directly with constant cotangents (house._train_step_branch); "critic": additionally the
-    critic's real pass on a third stream into a second gradient buffer; False: the reference-order single-stream step.  All three
-    are bit-identical to the eager autograd step."""
+    critic's real pass on a third stream into a second gradient buffer; False: the reference-order single-stream step; "inline"
+    (the default): the schedule on one stream, with the rider launches (spectral-norm work inside the residual block's and the
+    classifier's launches, the logged scalars inside the residual block's backward, the cross-entropy as the tail of the classifier's
+    forward).  All are bit-identical to the eager autograd step — parameters, buffers, D_loss, G_loss and g_cls."""
     H = pcg.house
     batches = [HR.synthetic_batch(batch, seed=s) for s in (1, 2, 3)]     # 4096: the multi-block forms of every reduction (the bench batch)
     states = []
@@ -539,7 +541,7 @@ def test_graphed_step_equals_eager(pcg, hgold, overlap, batch):
                 out = gs.replay()
             else:
                 out = H.train_step(G, D, C, opt_g, opt_d, _dev(x), _dev(y), _dev(t), _dev(m), norm, gumbel=noise)
-            losses.append((out["D_loss"].item(), out["G_loss"].item()))
+            losses.append((out["D_loss"].item(), out["G_loss"].item(), out["g_cls"].item(), out["reg"].item()))
         states.append(({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}},
                        losses))
     assert states[0][1] == states[1][1], (states[0][1], states[1][1])
