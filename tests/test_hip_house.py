@@ -516,7 +516,7 @@ def test_fused_classifier_kernels_match_the_op_chain(pcg, hgold, rows):
         _close(u, v, 2e-5, 2e-5 * float(v.abs().max()), "saved activation")
 
 
-@pytest.mark.parametrize("overlap,batch", [(True, 128), ("critic", 128), (False, 128), ("inline", 128), (True, 4096), ("inline", 4096), ("inline", 1000)])
+@pytest.mark.parametrize("overlap,batch", [(True, 128), ("critic", 128), (False, 128), ("inline", 128), (True, 4096), ("inline", 4096), ("inline", 1000), ("inline", 20000)])
 def test_graphed_step_equals_eager(pcg, hgold, overlap, batch):
     """GraphedTrainStep (one HIP-graph replay per step) leaves the nets exactly where the eager step does, and constructing
     it (warm-up + capture) does not advance the training state.  overlap=True: the schedule with the classifier term on a parallel
@@ -526,7 +526,8 @@ def test_graphed_step_equals_eager(pcg, hgold, overlap, batch):
     classifier's launches, the logged scalars inside the residual block's backward, the cross-entropy as the tail of the classifier's
     forward).  All are bit-identical to the eager autograd step — parameters, buffers, D_loss, G_loss and g_cls."""
     H = pcg.house
-    batches = [HR.synthetic_batch(batch, seed=s) for s in (1, 2, 3)]     # 4096: the multi-block forms of every reduction (the bench batch)
+    # 4096: the multi-block forms of every reduction (the bench batch); 20000: past the one-block forms of the logged scalars / cross-entropy tail
+    batches = [HR.synthetic_batch(batch, seed=s) for s in (1, 2, 3)]
     states = []
     for graphed in (False, True):
         G, D, C = _load_golden_nets(pcg, hgold)
