@@ -985,7 +985,9 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
         # residual assembly, mask, x_cf and both L1 penalties (:266-287, :305): one launch — and the critic step's two power
         # iterations ride in it (they only read the critic's weights: one launch less on the chain)
         onehot_y = onehots[1] if onehots is not None else ops.onehot(y, nc)
-        pair = branch2 is None and discriminator._fused_ok(x, onehot_y) and all(p.requires_grad for p in discriminator.parameters())
+        # (training mode: every critic call of the step makes a power iteration — the batched / riding forms assume it)
+        pair = (branch2 is None and discriminator.training and discriminator._fused_ok(x, onehot_y) and
+                all(p.requires_grad for p in discriminator.parameters()))
         rf = ops.house_residual_fwd(cont.contiguous(), samples.contiguous(), seg, norm_vals, x, mask, generator.col_src(),
                                     sn=discriminator._sn_operands() + (2,) if pair else None)
         residual_full, masked_residual, x_cf, mask_penalty_pre, am = rf[:5]
