@@ -650,6 +650,13 @@ int pcg_house_classifier_bwd_snfwd(const float* dlogits, int32_t B, const float*
 int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
                     const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
                     uint64_t seed, float* onehot_target, float* onehot_y, pcg_stream_t stream);
+/* The same launch with the Philox offsets taken from a DEVICE counter: counter[0] = the running offset (the three draws take
+ * consecutive ranges of (B+3)/4, (B*D+3)/4, (B*T+3)/4 counter values from it, as the host-side bookkeeping of the call above hands
+ * them out), counter[1] = a ticket (zero before first use, left zero); the launch advances counter[0] itself.  Captured in a HIP
+ * graph it draws fresh numbers on every replay — the values successive pcg_house_draws calls would produce. */
+int pcg_house_draws_counter(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, float* mask, int32_t D,
+                            const int32_t* zero_cols, int32_t n_zero_cols, float* noise, int32_t T, uint64_t seed, float* onehot_target,
+                            float* onehot_y, uint64_t* counter, pcg_stream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per

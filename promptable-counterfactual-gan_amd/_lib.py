@@ -189,6 +189,7 @@ PROTOTYPES = {
     "pcg_house_residual_bwd_losses": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp,
                                            _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _i32, _vp, _vp]),
     "pcg_house_draws": (_i, [_vp, _i32, _i32, _vp, _c.c_uint64, _vp, _i32, _vp, _i32, _c.c_uint64, _vp, _i32, _c.c_uint64, _c.c_uint64, _vp, _vp, _vp]),
+    "pcg_house_draws_counter": (_i, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _c.c_uint64, _vp, _vp, _vp, _vp]),
     "pcg_house_critic_fwd_n": (_i, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_critic_bwd_n": (_i, [_i32, _vp, _i32, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_spectral_norm_fwd_batched_reps": (_i, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),

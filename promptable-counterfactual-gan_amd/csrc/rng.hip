@@ -162,11 +162,19 @@ __global__ void __launch_bounds__(256) feature_mask_kernel(float* __restrict__ o
     feature_mask_quad(i, out, n, D, zero_cols, nz, seed, offset);
 }
 // the three per-iteration draws of the tabular trainer (trainer.py:248-255, generator.py:90) in one launch
+// ctr != nullptr: the Philox offsets come from a DEVICE counter — ctr[0] is the running offset (the three draws take consecutive
+// ranges from it, as DeviceRNG's host-side bookkeeping hands them out), ctr[1] a ticket; the block that takes the last ticket
+// advances ctr[0] (every block has read it by then).  A launch captured in a HIP graph then draws fresh numbers on every replay.
 __global__ void __launch_bounds__(256) house_draws_kernel(int64_t* __restrict__ target, int B, int32_t lo, int32_t hi, const int64_t* __restrict__ y,
                                                           uint64_t off_t, float* __restrict__ mask, int D, const int* __restrict__ zero_cols, int nz,
                                                           uint64_t off_m, float* __restrict__ noise, int64_t n_noise, uint64_t off_n, uint64_t seed,
-                                                          float* __restrict__ onehot_t, float* __restrict__ onehot_y) {
+                                                          float* __restrict__ onehot_t, float* __restrict__ onehot_y, unsigned long long* ctr) {
   const int64_t nm = (int64_t)B * D;
+  unsigned long long base = 0;
+  if (ctr) {                                                 // kernel-uniform
+    base = ctr[0];
+    off_t = base; off_m = off_t + (uint64_t)((B + 3) / 4); off_n = off_m + (uint64_t)((nm + 3) / 4);
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n_noise + 3) / 4; i += (int64_t)gridDim.x * 256) gumbel_quad(i, noise, n_noise, seed, off_n);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (nm + 3) / 4; i += (int64_t)gridDim.x * 256)
     feature_mask_quad(i, mask, nm, D, zero_cols, nz, seed, off_m);
@@ -177,6 +185,13 @@ __global__ void __launch_bounds__(256) house_draws_kernel(int64_t* __restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * nc; i += (int64_t)gridDim.x * 256) {
       const int64_t b = i / nc; const int q = (int)(i - b * nc);
       onehot_y[i] = y[b] - lo == q ? 1.f : 0.f;
+    }
+  }
+  if (ctr) {
+    __syncthreads();                                         // every thread of this block has read the counter
+    if (threadIdx.x == 0 && atomicAdd(reinterpret_cast<int*>(ctr + 1), 1) == (int)gridDim.x - 1) {
+      ctr[0] = off_n + (uint64_t)((n_noise + 3) / 4);
+      *reinterpret_cast<int*>(ctr + 1) = 0;
     }
   }
 }
@@ -255,15 +270,34 @@ extern "C" int pcg_feature_mask(float* out, int32_t B, int32_t D, const int32_t*
   return launch_status("feature_mask_kernel");
 }
 
+namespace {
+int house_draws_launch(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
+                       const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
+                       uint64_t seed, float* onehot_target, float* onehot_y, unsigned long long* counter, pcg_stream_t stream) {
+  PCG_REQUIRE(target_y && y && mask && noise && B > 0 && num_classes > 1 && D > 0 && T > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0),
+              "pcg_house_draws: bad arguments");
+  int64_t quads = std::max(((int64_t)B * T + 3) / 4, ((int64_t)B * D + 3) / 4);
+  unsigned blocks = grid_for(quads);
+  if (counter && blocks > 256u) blocks = 256u;               // one same-address ticket per block (see adam_launch)
+  hipLaunchKernelGGL(house_draws_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, target_y, B, 0, num_classes, y, offset_target, mask, D,
+                     zero_cols, n_zero_cols, offset_mask, noise, (int64_t)B * T, offset_noise, seed, onehot_target, onehot_y, counter);
+  return launch_status("house_draws_kernel");
+}
+}  // namespace
+
 extern "C" int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, uint64_t offset_target, float* mask, int32_t D,
                                const int32_t* zero_cols, int32_t n_zero_cols, uint64_t offset_mask, float* noise, int32_t T, uint64_t offset_noise,
                                uint64_t seed, float* onehot_target, float* onehot_y, pcg_stream_t stream) {
-  PCG_REQUIRE(target_y && y && mask && noise && B > 0 && num_classes > 1 && D > 0 && T > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0),
-              "pcg_house_draws: bad arguments");
-  const int64_t quads = std::max(((int64_t)B * T + 3) / 4, ((int64_t)B * D + 3) / 4);
-  hipLaunchKernelGGL(house_draws_kernel, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, target_y, B, 0, num_classes, y, offset_target, mask, D,
-                     zero_cols, n_zero_cols, offset_mask, noise, (int64_t)B * T, offset_noise, seed, onehot_target, onehot_y);
-  return launch_status("house_draws_kernel");
+  return house_draws_launch(target_y, B, num_classes, y, offset_target, mask, D, zero_cols, n_zero_cols, offset_mask, noise, T, offset_noise, seed,
+                            onehot_target, onehot_y, nullptr, stream);
+}
+
+extern "C" int pcg_house_draws_counter(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, float* mask, int32_t D,
+                                       const int32_t* zero_cols, int32_t n_zero_cols, float* noise, int32_t T, uint64_t seed, float* onehot_target,
+                                       float* onehot_y, uint64_t* counter, pcg_stream_t stream) {
+  PCG_REQUIRE(counter, "pcg_house_draws_counter: null counter");
+  return house_draws_launch(target_y, B, num_classes, y, 0, mask, D, zero_cols, n_zero_cols, 0, noise, T, 0, seed, onehot_target, onehot_y,
+                            reinterpret_cast<unsigned long long*>(counter), stream);
 }
 
 extern "C" int pcg_rand_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, pcg_stream_t stream) {

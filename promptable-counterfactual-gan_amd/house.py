@@ -1179,7 +1179,12 @@ class GraphedTrainStep:
     Capture needs warm-up executions of real steps; the parameters, buffers and optimizer state are snapshotted before and
     restored after, so constructing this object does not advance training."""
 
-    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap="inline"):
+    def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap="inline",
+                 rng=None):
+        """rng (an ops.DeviceRNG): the per-iteration draws (draw_batch_randoms: target class, feature mask, Gumbel noise, one-hot rows) are
+        the first launch of the captured step, their Philox offsets read from a device counter that the launch advances itself — write x
+        and y into the static buffers (`load_batch`) and replay(); the numbers are those draw_batch_randoms(rng, ...) would have drawn
+        before each eager step, and rng.offset is kept in step on the host."""
         dev = norm_vals.device
         # train_step's parallel branch: the classifier term and the logged sums; overlap="critic" adds a third stream for the
         # critic's real pass (bit-identical, no gain measured: see _train_step_branch)
@@ -1207,7 +1212,15 @@ class GraphedTrainStep:
         self.onehots = (torch.zeros((batch, nc), dtype=torch.float32, device=dev), torch.zeros((batch, nc), dtype=torch.float32, device=dev))
         ops.onehot(self.target_y, nc, out=self.onehots[0]); ops.onehot(self.y, nc, out=self.onehots[1])
 
+        self._rng = rng
+        self._span = ops.DeviceRNG.house_draws_span(batch, D_in, T)
+        self._ctr = rng.device_counter(dev) if rng is not None else None
+        ctr0 = self._ctr.clone() if rng is not None else None
+
         def step():
+            if rng is not None:
+                draw_batch_randoms(rng, generator, self.y, config, dev, out=(self.target_y, self.mask, self.noise),
+                                   onehots=self.onehots if self.branch is not None else None, counter=self._ctr)
             return train_step(generator, discriminator, classifier, opt_g, opt_d, self.x, self.y, self.target_y, self.mask, norm_vals,
                               config, gumbel=self.noise, branch=self.branch, onehots=self.onehots if self.branch is not None else None)
         self._nc = nc
@@ -1234,6 +1247,12 @@ class GraphedTrainStep:
                 b.copy_(b0)
         for o, sn in zip((opt_g, opt_d), osnap):
             o.restore(sn)
+        if rng is not None:
+            self._ctr.copy_(ctr0)        # the warm-up steps drew from the counter: back to the stream's position
+
+    def load_batch(self, x, y):
+        """With rng: the data half of a batch (the draws are made by the replay)."""
+        self.x.copy_(x); self.y.copy_(y)
 
     def load(self, x, y, target_y, mask, noise):
         self.x.copy_(x); self.y.copy_(y); self.target_y.copy_(target_y); self.mask.copy_(mask); self.noise.copy_(noise)
@@ -1241,6 +1260,8 @@ class GraphedTrainStep:
 
     def replay(self):
         self.graph.replay()
+        if self._rng is not None:
+            self._rng.offset += self._span       # the host-side mirror of the device counter
         return self.out
 
 
@@ -1340,9 +1361,10 @@ def train_classifier(X_train_all, X_test, y_train_all, y_test, scaler, config, d
     return model
 
 
-def draw_batch_randoms(rng, generator, y, config, device, out=None, onehots=None):
+def draw_batch_randoms(rng, generator, y, config, device, out=None, onehots=None, counter=None):
     """The per-iteration draws of trainer.py:248-255 + generator.py:90 on the device: (target_y != y, feature mask, Gumbel noise).
-    out = (target_y, mask, noise): draw straight into these buffers (the static inputs of a GraphedTrainStep)."""
+    out = (target_y, mask, noise): draw straight into these buffers (the static inputs of a GraphedTrainStep).  counter: the device
+    counter form of the launch (ops.DeviceRNG.house_draws)."""
     B = y.shape[0]
     imm = getattr(generator, "_imm_dev", None)
     if imm is None or imm.device != device:
@@ -1353,7 +1375,7 @@ def draw_batch_randoms(rng, generator, y, config, device, out=None, onehots=None
                torch.empty((B, generator.total_cat), dtype=torch.float32, device=device))
     # one launch; the values of randint(exclude=y), feature_mask, gumbel called in this order
     return rng.house_draws(y.contiguous(), config["num_classes"], config["input_dim"], generator.total_cat, imm if imm.numel() else None, out,
-                           onehots=onehots)
+                           onehots=onehots, counter=counter)
 
 
 def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):

@@ -1008,7 +1008,8 @@ class DeviceRNG:
 
     def _advance(self, n):
         # the Philox offset is a kernel ARGUMENT held on the host: a draw captured into a HIP graph would replay the same numbers
-        # on every launch.  Draw outside the captured step and feed the result in as a static input (GraphedStep.load).
+        # on every launch.  Draw outside the captured step and feed the result in as a static input (GraphedStep.load), or use the
+        # device-counter form of the launch where there is one (house_draws(counter=...): the launch reads and advances the offset itself).
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise _lib.PcgError("DeviceRNG draw during HIP-graph capture: the captured kernel would replay identical random numbers; "
                                 "draw before the step and pass the tensors in (GraphedStep inputs)")
@@ -1042,20 +1043,35 @@ class DeviceRNG:
         check(_lib.load().pcg_rand_gumbel(_p(out), n, self.seed, self._advance((n + 3) // 4), _stream()), "pcg_rand_gumbel")
         return out
 
-    def house_draws(self, y, num_classes, D, T, zero_cols, out, onehots=None):
+    def house_draws(self, y, num_classes, D, T, zero_cols, out, onehots=None, counter=None):
         """target class != y, feature mask, Gumbel noise [B, T] in ONE launch, drawn into out = (target_y, mask, noise): the values
         randint(exclude=y), feature_mask, gumbel give when called in this order (same counter offsets).  onehots = (onehot(target_y),
-        onehot(y)) float [B, num_classes] buffers: filled by the same launch."""
+        onehot(y)) float [B, num_classes] buffers: filled by the same launch.  counter: a device counter (device_counter()) that
+        supplies the offsets and is advanced by the launch itself — the form a HIP graph can capture (every replay draws the next
+        numbers of the stream); the host-side offset is not touched (see house.GraphedTrainStep(rng=...))."""
         o_t, o_m, o_n = out
         B = y.shape[0]
+        nz = 0 if zero_cols is None else zero_cols.numel()
+        oh_t, oh_y = onehots if onehots is not None else (None, None)
+        if counter is not None:
+            check(_lib.load().pcg_house_draws_counter(_p(o_t), B, num_classes, _p(y), _p(o_m), D, _p(zero_cols), nz, _p(o_n), T, self.seed,
+                                                      _p(oh_t), _p(oh_y), _p(counter), _stream()), "pcg_house_draws_counter")
+            return o_t, o_m, o_n
         off_t = self._advance((B + 3) // 4)
         off_m = self._advance((B * D + 3) // 4)
         off_n = self._advance((B * T + 3) // 4)
-        nz = 0 if zero_cols is None else zero_cols.numel()
-        oh_t, oh_y = onehots if onehots is not None else (None, None)
         check(_lib.load().pcg_house_draws(_p(o_t), B, num_classes, _p(y), off_t, _p(o_m), D, _p(zero_cols), nz, off_m, _p(o_n), T, off_n, self.seed,
                                           _p(oh_t), _p(oh_y), _stream()), "pcg_house_draws")
         return o_t, o_m, o_n
+
+    @staticmethod
+    def house_draws_span(B, D, T):
+        """Counter values one house_draws call consumes."""
+        return (B + 3) // 4 + (B * D + 3) // 4 + (B * T + 3) // 4
+
+    def device_counter(self, device):
+        """int64[2] on the device: [this stream's current offset, ticket] — the counter argument of house_draws."""
+        return torch.tensor([self.offset, 0], dtype=torch.int64, device=device)
 
     def feature_mask(self, B, D, device, zero_cols=None, out=None):
         """Bernoulli(1/2) modifiable-feature mask with immutable columns zeroed (house_sales_kc_usa/trainer.py:253-255);

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="A/B: the reference-order autograd step as a single-stream graph")
     ap.add_argument("--overlap", action="store_true", help="A/B: the frozen classifier's term on a parallel graph branch (two streams)")
     ap.add_argument("--inline", action="store_true", help="(default) the scheduled step's kernels on ONE stream")
+    ap.add_argument("--eager-draws", action="store_true", help="A/B: the per-step draws as an eager launch in front of each replay (host-side Philox offsets)")
     BL.add_common_args(ap, steps=200, warmup=20)
     args = ap.parse_args()
     if args.gpus != 1:
@@ -50,14 +51,16 @@ def main():
 
     gs = None
     if not args.eager:
-        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap=False if args.no_overlap else (True if args.overlap else "inline"))
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, overlap=False if args.no_overlap else (True if args.overlap else "inline"),
+                                rng=None if args.eager_draws else rng)
         gs.x.copy_(x); gs.y.copy_(y)
         t, mask, noise = gs.target_y, gs.mask, gs.noise
         y = gs.y                       # the graph's own label buffer: the draws kernel reads it for the one-hot rows
         onehots = gs.onehots if gs.branch is not None else None
 
     def run(i):
-        draws()
+        if gs is None or args.eager_draws:      # (default: the draws are the first launch of the replayed graph, offsets from a device counter)
+            draws()
         return gs.replay() if gs is not None else H.train_step(G, D, C, opt_g, opt_d, x, y, t, mask, norm, gumbel=noise)
 
     for i in range(args.warmup):
@@ -112,7 +115,8 @@ def main():
         "launch": "eager" if gs is None else ("hip-graph replay (1 graph"
                                             + (", scheduled step on one stream" if gs.branch == "inline" else
                                                ", classifier term on a parallel branch" if gs.branch is not None else ", reference-order step")
-                                            + ") + 1 RNG launch per step drawing into its input buffers"),
+                                            + (") + 1 RNG launch per step drawing into its input buffers" if args.eager_draws else
+                                               "; the per-step draws are its first launch, Philox offsets from a device counter)")),
     })
     R.finish()
 

@@ -759,3 +759,41 @@ def test_train_classifier_loop_learns(pcg):
         acc = pcg.ops.cf_metrics(model(_dev(torch.tensor(X[1000:], dtype=torch.float32))).contiguous(), _dev(torch.tensor(y[1000:])),
                                  other=_dev(torch.tensor(y[1000:])))[0].item()
     assert acc > 0.9
+
+
+def test_graphed_step_with_the_draws_inside_equals_eager_draws_and_steps(pcg, hgold):
+    """GraphedTrainStep(rng=...): the per-iteration draws (target class, feature mask, Gumbel noise, one-hot rows) are the first launch
+    of the replayed graph, their Philox offsets read from a device counter the launch advances itself.  Four replays against four
+    eager iterations that draw with the host-side offsets (draw_batch_randoms) and then step: same draws, same losses, same parameters,
+    and the host mirror of the counter in step."""
+    H, ops = pcg.house, pcg.ops
+    dev = torch.device(DEV)
+    B = 192
+    data = [HR.synthetic_batch(B, seed=s)[:2] for s in (11, 12, 13, 14)]
+    states = []
+    for graphed in (False, True):
+        G, D, C = _load_golden_nets(pcg, hgold)
+        opt_g, opt_d = H.make_optimizers(G, D)
+        norm = H.cat_norm_maps(G, H.CONFIG, dev)
+        rng = ops.DeviceRNG(21)
+        rng.rand((7,), dev)                                   # the stream does not start at offset 0
+        gs = H.GraphedTrainStep(G, D, C, opt_g, opt_d, norm, B, rng=rng) if graphed else None
+        logs = []
+        for x, y in data:
+            if graphed:
+                gs.load_batch(_dev(x), _dev(y))
+                out = gs.replay()
+                t, m, noise = gs.target_y, gs.mask, gs.noise
+            else:
+                t, m, noise = H.draw_batch_randoms(rng, G, _dev(y), H.CONFIG, dev)
+                out = H.train_step(G, D, C, opt_g, opt_d, _dev(x), _dev(y), t, m, norm, gumbel=noise)
+            logs.append((out["D_loss"].item(), out["G_loss"].item(), out["g_cls"].item(), t.clone(), m.clone(), noise.clone()))
+        states.append(({**{f"G.{k}": v.clone() for k, v in G.state_dict().items()}, **{f"D.{k}": v.clone() for k, v in D.state_dict().items()}},
+                       logs, rng.offset))
+    assert states[0][2] == states[1][2]
+    for a, b in zip(states[0][1], states[1][1]):
+        assert a[:3] == b[:3], (a[:3], b[:3])
+        for u, v in zip(a[3:], b[3:]):
+            assert torch.equal(u, v)
+    for k in states[0][0]:
+        assert torch.equal(states[0][0][k], states[1][0][k]), k
