@@ -93,7 +93,7 @@ def main():
                "sample": f"median of 3 critic updates + 3 generator updates at batch {cb}, width {args.width} (GPU run: {B} per GPU), "
                          f"1 warm-up each, combined with the 1/n_critic weight; PyTorch-CPU fp32 restatement of mnist_wgan_conditional.py:133-168"}
     if R.rank == 0:
-        roof = BL.conv_family_roofline(records, it, 1, flops_it)
+        roof = BL.conv_family_roofline(records, it, 1, flops_it, traffic=BL.pmc_traffic("wgan"))
         if roof:
             roof["gemm_time_share"] = None     # events sample one critic and one generator update, not one weighted iteration
         BL.emit({

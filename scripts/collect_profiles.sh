@@ -14,6 +14,10 @@ echo "[collect] DCGAN pmc fetch";    rocprofv3 --pmc FETCH_SIZE --output-format 
 echo "[collect] DCGAN pmc write";    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1 || exit 1
 echo "[collect] countergan";         rocprofv3 --kernel-trace --stats --output-format csv -d $O/countergan -o p -- python3 $R/scripts/bench_countergan.py --steps 5 --warmup 2 --no-cpu-baseline > $O/countergan.log 2>&1 || exit 1
 echo "[collect] wgan";               rocprofv3 --kernel-trace --stats --output-format csv -d $O/wgan -o p -- python3 $R/scripts/bench_wgan.py --steps 10 --warmup 2 --no-cpu-baseline > $O/wgan.log 2>&1 || exit 1
+echo "[collect] countergan pmc";     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_countergan -o p -- python3 $R/scripts/bench_countergan.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_countergan.log 2>&1 || exit 1
+                                     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_countergan -o p -- python3 $R/scripts/bench_countergan.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_countergan.log 2>&1 || exit 1
+echo "[collect] wgan pmc";           rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_wgan -o p -- python3 $R/scripts/bench_wgan.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_wgan.log 2>&1 || exit 1
+                                     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_wgan -o p -- python3 $R/scripts/bench_wgan.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_wgan.log 2>&1 || exit 1
 echo "[collect] house";              rocprofv3 --kernel-trace --stats --output-format csv -d $O/house -o p -- python3 $R/scripts/bench_house.py --steps 50 --warmup 10 --no-cpu-baseline > $O/house.log 2>&1 || exit 1
 cd $R
 echo "[collect] JSON lines"

@@ -81,9 +81,12 @@ if trace:
                   open(os.path.join(out, f"{tag}_house_launches.json"), "w"), indent=1)
     stats_md("house", f"{tag}_house_kernel_stats.md", "python3 scripts/bench_house.py --steps 50 --warmup 10 (batch 4096, single-stream HIP-graph replay of the scheduled step)", 63)
 
-# PMC traffic
-fe_p, wr_p = find("pmc_fetch", "*counter_collection.csv"), find("pmc_write", "*counter_collection.csv")
-if fe_p and wr_p:
+# PMC traffic (the DCGAN bench; the counteRGAN and WGAN benches the same way when their passes were collected)
+def pmc_summary(fetch_sub, write_sub, dest, cmd):
+    fe_p, wr_p = find(fetch_sub, "*counter_collection.csv"), find(write_sub, "*counter_collection.csv")
+    if not (fe_p and wr_p):
+        return
+
     def agg(path, counter):
         d = collections.defaultdict(lambda: [0, 0.0])
         for r_ in csv.DictReader(open(path)):
@@ -103,8 +106,13 @@ if fe_p and wr_p:
     res["_igemm_family"] = {
         "launches": n,
         "hbm_bytes_per_launch": sum(res[k]["launches"] * (res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]) for k in fam) / n,
-        "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes for FETCH_SIZE and WRITE_SIZE; bench.py --steps 2 --warmup 1"}
-    json.dump(res, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+        "note": f"FETCH_SIZE doubled (gfx950 correction), separate --pmc passes for FETCH_SIZE and WRITE_SIZE; {cmd}"}
+    json.dump(res, open(os.path.join(out, dest), "w"), indent=1, sort_keys=True)
+
+
+pmc_summary("pmc_fetch", "pmc_write", f"{tag}_pmc_traffic.json", "bench.py --steps 2 --warmup 1")
+pmc_summary("pmc_fetch_countergan", "pmc_write_countergan", f"{tag}_pmc_traffic_countergan.json", "scripts/bench_countergan.py --steps 2 --warmup 1")
+pmc_summary("pmc_fetch_wgan", "pmc_write_wgan", f"{tag}_pmc_traffic_wgan.json", "scripts/bench_wgan.py --steps 2 --warmup 1")
 
 for name in ("bench_line", "bench_line_dp1", "countergan_line", "wgan_line", "house_line"):
     p = os.path.join(src, name + ".json")
