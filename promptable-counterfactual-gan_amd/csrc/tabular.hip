@@ -747,12 +747,13 @@ __global__ void __launch_bounds__(256) spectral_norm_fwd_batched_kernel(SnFwdBat
   spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n, lds);
 }
 // Rider: the critic step's power iterations only need the critic's weights, so they ride with the residual block's forward —
-// blocks 0 .. 255 the residual block (its ticket counts those 256), blocks 256 .. one matrix each.  Same bodies, same bits.
+// the first n blocks one matrix each (they are the long pole of the launch: in front, they start with the launch), the 256 blocks
+// behind them the residual block (its ticket counts those 256).  Same bodies, same bits.
 constexpr int RES_BLOCKS = 256;
 __global__ void __launch_bounds__(256) house_residual_fwd_sn_kernel(ResFwdArgs a, SnFwdBatch b, float eps, int power_iter, int n, int reps) {
-  if (blockIdx.x < RES_BLOCKS) { house_residual_fwd_body<false>(a, blockIdx.x, RES_BLOCKS); return; }
+  if ((int)blockIdx.x >= n) { house_residual_fwd_body<false>(a, blockIdx.x - n, RES_BLOCKS); return; }
   __shared__ SnFwdLds lds;
-  const int l = blockIdx.x - RES_BLOCKS;
+  const int l = blockIdx.x;
   spectral_norm_fwd_body(b.W[l], b.O[l], b.I[l], b.u[l], b.v[l], eps, power_iter, b.Wbar + l, b.sigma + l, b.uu + l, b.vu + l, reps, n, lds);
 }
 __global__ void __launch_bounds__(256) spectral_norm_bwd_batched_kernel(SnBwdBatch b, SnBwdExtra x, int n, int passes) {
