@@ -41,13 +41,117 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the implicit-GEMM family from the committed rocprofv3 --pmc summary (FETCH_SIZE doubled
-    + WRITE_SIZE, collected in separate passes: profiles/r02_pmc_traffic.json), or None."""
+    """(HBM bytes per launch of the implicit-GEMM family, file) from the newest committed rocprofv3 --pmc summary (FETCH_SIZE
+    doubled + WRITE_SIZE, collected in separate passes: profiles/rNN_pmc_traffic.json), or (None, None)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def count_gpus_sysfs():
+    """GPUs of this node WITHOUT touching HIP: KFD topology nodes with simd_count > 0 (CPU nodes have 0).  None if the topology
+    is not readable (then the caller has to ask the runtime)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"])
-    except Exception:
+        nodes = os.listdir(base)
+    except OSError:
         return None
+    n = 0
+    seen = False
+    for d in nodes:
+        try:
+            with open(os.path.join(base, d, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        seen = True
+                        n += int(line.split()[1]) > 0
+                        break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n if seen else None
+
+
+class ClockSampler:
+    """Samples the GPU's shader clock (and socket power) from sysfs in a host thread while the timed steps run: hwmon freq1_input
+    (Hz) / power1_average|power1_input (uW) of the card that backs this rank's HIP device, else the starred line of pp_dpm_sclk.
+    No HIP call, no effect on the stream; every field is None when sysfs exposes nothing."""
+
+    def __init__(self, local_rank=0, period=0.01):
+        import glob
+        self.period, self.freq, self.power, self._stop, self._th = period, [], [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(p.split("card")[1].split("/")[0]))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+        self.dev = cards[local_rank] if local_rank < len(cards) else (cards[0] if cards else None)
+        self.f_freq = self.f_power = self.f_dpm = None
+        if self.dev:
+            for h in glob.glob(os.path.join(self.dev, "hwmon/hwmon*")):
+                if os.path.exists(os.path.join(h, "freq1_input")):
+                    self.f_freq = os.path.join(h, "freq1_input")
+                for nm in ("power1_average", "power1_input"):
+                    if self.f_power is None and os.path.exists(os.path.join(h, nm)):
+                        self.f_power = os.path.join(h, nm)
+            if os.path.exists(os.path.join(self.dev, "pp_dpm_sclk")):
+                self.f_dpm = os.path.join(self.dev, "pp_dpm_sclk")
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def sample(self):
+        mhz = None
+        if self.f_freq:
+            t = self._read(self.f_freq)
+            try:
+                mhz = float(t) / 1e6 if t else None
+            except ValueError:
+                mhz = None
+        if mhz is None and self.f_dpm:
+            for line in (self._read(self.f_dpm) or "").splitlines():
+                if line.rstrip().endswith("*"):
+                    try:
+                        mhz = float(line.split(":")[1].strip().lower().split("mhz")[0])
+                    except (IndexError, ValueError):
+                        pass
+        if mhz:
+            self.freq.append(mhz)
+        if self.f_power:
+            t = self._read(self.f_power)
+            try:
+                if t:
+                    self.power.append(float(t) / 1e6)
+            except ValueError:
+                pass
+
+    def _loop(self):
+        while not self._stop:
+            self.sample()
+            time.sleep(self.period)
+
+    def start(self):
+        if self.f_freq or self.f_dpm or self.f_power:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join()
+        def stats(v):
+            if not v:
+                return None
+            v = sorted(v)
+            return {"min": round(v[0], 1), "p50": round(v[len(v) // 2], 1), "max": round(v[-1], 1), "samples": len(v)}
+        return {"sclk_mhz": stats(self.freq), "power_w": stats(self.power),
+                "source": self.f_freq or self.f_dpm or None}
 
 
 def cpu_model():
@@ -111,23 +215,44 @@ def emit_json(line):
 def launch_ranks(n, argv, script=None):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as CHILD processes — one per GPU, the
     environment torch.distributed.run would give them — before anything in this process touches the GPU, relay rank 0's stdout
-    (the JSON line) and fail if any rank fails.  The parent only counts devices (no HIP initialisation) and waits."""
+    (the JSON line) and fail if any rank fails.  The parent counts GPUs from the KFD topology in sysfs (no HIP initialisation),
+    prefixes every rank's stderr with its rank, and gives up (non-zero) if the ranks have not all exited `PCG_BENCH_TIMEOUT`
+    seconds (default 900) after the start — a rank stuck in the rendezvous cannot hang the run."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = count_gpus_sysfs()                 # KFD topology: no HIP initialisation in the parent
+    if have is None:
+        have = torch.cuda.device_count()      # topology unreadable: ask the runtime (the children are fresh processes either way)
     if have < n:
         sys.exit(f"bench.py --gpus {n}: this node exposes {have} GPU(s); one rank per GPU is required (no oversubscription)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import threading
+    limit = float(os.environ.get("PCG_BENCH_TIMEOUT", "900"))
+
+    def relay(r, pipe):
+        # a rank's stderr (and, for ranks > 0, stdout) line by line with the rank in front: interleaved tracebacks stay readable
+        for raw in iter(pipe.readline, b""):
+            sys.stderr.write(f"[rank {r}] " + raw.decode("utf-8", "replace"))
+            sys.stderr.flush()
+        pipe.close()
+
+    procs, relays = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        # rank 0 inherits stdout (its JSON line is the bench output); the other ranks print nothing there, their stdout goes to stderr
-        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+        # rank 0 inherits stdout (its JSON line is the bench output); the other ranks print nothing there, their stdout joins their stderr
+        if r == 0:
+            p = subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env, stderr=subprocess.PIPE)
+        else:
+            p = subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        t = threading.Thread(target=relay, args=(r, p.stderr if r == 0 else p.stdout), daemon=True)
+        t.start()
+        procs.append(p); relays.append(t)
     rc = 0
+    t_start = time.monotonic()
     pending = dict(enumerate(procs))
     while pending:
         for r, p in list(pending.items()):
@@ -140,7 +265,22 @@ def launch_ranks(n, argv, script=None):
                 print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
                 for q in pending.values():      # exactly the processes started above
                     q.terminate()
+        if pending and time.monotonic() - t_start > limit:
+            print(f"[bench] ranks {sorted(pending)} still running after {limit:.0f} s (PCG_BENCH_TIMEOUT): a rank that never reached "
+                  f"the rendezvous, or a hung collective; stopping them", file=sys.stderr, flush=True)
+            for q in pending.values():
+                q.terminate()
+            deadline = time.monotonic() + 10
+            for q in pending.values():
+                try:
+                    q.wait(max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            pending.clear()
+            rc = rc or 124
         time.sleep(0.05)
+    for t in relays:
+        t.join(5)
     sys.exit(rc)
 
 
@@ -164,6 +304,7 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="exact global-batch BatchNorm across the ranks (SURVEY.md 8e option ii); implies --eager")
     ap.add_argument("--wgrad-stream", action="store_true", help="A/B: weight gradients on a second HIP stream beside the grad-input kernels")
     ap.add_argument("--torch-collectives", action="store_true", help="A/B: gradient exchange on torch.distributed's RCCL communicator instead of the library's (pcg_dp_*)")
+    ap.add_argument("--no-calib", action="store_true", help="skip the bare-MFMA / HBM-copy calibration around the timed region")
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: min(16, visible cores))")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -251,6 +392,14 @@ def main():
         if dp is not None:
             torch.distributed.barrier()
 
+    # Calibration, OUTSIDE the timed bracket (before the warm-up steps and after the timed ones): a ~20 ms bare fp32-MFMA loop
+    # on every CU and a 512 MiB device copy — what this box's matrix pipe and HBM sustain now, so that a slower box can be told
+    # from a slower kernel (roofline.achieved / calib.mfma_tflops does not depend on the box's clock).
+    calib = None
+    if not args.no_calib:
+        calib = {"before": ops.calibrate(dev)}
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
         out = step(i)
     if dp is not None:
@@ -262,9 +411,14 @@ def main():
     records = []
     hook = (lambda label, flops, t0, t1: records.append((label, flops, t0, t1))) if not args.no_kernel_events else None
 
+    sampler = ClockSampler(local_rank) if rank == 0 else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one record per step boundary: the spread
     barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
+    marks[0].record()
     # steps that run eagerly with events: one per --event-every timed steps, at most 3, evenly spread (>= 1: short runs still carry a
     # live roofline measurement); 2 of the default 20
     nsamp = 0 if hook is None or args.steps <= 0 else max(1, min(3, args.steps // max(1, args.event_every)))
@@ -273,6 +427,7 @@ def main():
         timed = i in sampled
         ops.set_conv_hook(hook if timed else None)
         out = step(args.warmup + i, eager=timed)
+        marks[i + 1].record()
     host_enqueue = time.perf_counter() - t0      # the host is done issuing; the GPU is still working if this < elapsed
     if dp is not None:
         dp.wait_all()
@@ -280,6 +435,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_conv_hook(None)
+    clocks = sampler.stop() if sampler is not None else None
+    if calib is not None:
+        calib["after"] = ops.calibrate(dev)
+        torch.cuda.synchronize()
+    # per-step spread from the boundary events (replayed and event-sampled eager steps told apart: the eager ones carry ~35 event
+    # pairs and the host's launch latency); `value` stays the mean over the whole bracket, as the contract defines it
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
     if dp is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -317,8 +479,8 @@ def main():
         achieved = tot_f / tot_t / 1e12
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic()[0],
+            "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, {pmc_traffic()[1]})",
             "kernel": "fp32-MFMA implicit-GEMM conv family (igemm_mainloop: conv_fwd/dgrad/wgrad_kernel); wgrad spans include slab_reduce",
             "step_frac": round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "gemm_time_share": round(tot_t / (elapsed * len(sampled) / args.steps), 4),
@@ -330,6 +492,28 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batch=args.batch, threads=args.cpu_threads)
 
+    spread = None
+    if step_ms:
+        def _stats(v):
+            v = sorted(v)
+            return {"min": round(v[0], 3), "p50": round(v[len(v) // 2], 3), "max": round(v[-1], 3), "n": len(v)}
+        replayed = [t for i, t in enumerate(step_ms) if i not in sampled]
+        spread = {"all": _stats(step_ms), "replayed": _stats(replayed) if replayed else None,
+                  "event_sampled_eager": _stats([step_ms[i] for i in sampled]) if sampled else None}
+    if calib is not None:
+        b, a = calib["before"], calib["after"]
+        calib["mfma_tflops_before"], calib["mfma_tflops_after"] = b["mfma_tflops"], a["mfma_tflops"]
+        calib["mfma_tflops"] = round(0.5 * (b["mfma_tflops"] + a["mfma_tflops"]), 2)
+        calib["hbm_gbs"] = round(0.5 * (b["hbm_gbs"] + a["hbm_gbs"]), 1)
+        calib["mfma_clock_mhz"] = round(0.5 * (b["mfma_clock_mhz"] + a["mfma_clock_mhz"]))
+        calib["what"] = ("pcg_calib_mfma: bare v_mfma_f32_32x32x2_f32 loop on every CU (~20 ms), clock from in-kernel s_memtime / "
+                         "s_memrealtime; pcg_calib_copy: 512 MiB device copy (read + write bytes); run before the warm-up and "
+                         "after the timed steps, outside the timed bracket")
+        if roofline is not None:
+            roofline["achieved_over_calib_mfma"] = round(roofline["achieved"] / calib["mfma_tflops"], 4)
+            roofline["step_over_calib_mfma"] = round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12
+                                                     / calib["mfma_tflops"], 4)
+
     if rank == 0:
         line = {
             "metric": "images/sec (G+D step) MNIST-28 cDCGAN bs512 @1/2/4/8 MI355X; % MFMA roofline",
@@ -339,7 +523,8 @@ def main():
             "config": {"workload": "dconv_gan/mnist DCGAN 64x64 (MNIST 28->64), z=100, g_hidden=d_hidden=64, "
                                    f"batch {args.batch} per GPU, full G+D step incl. BatchNorm, BCE, Adam x2",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "final_losses": losses,
+            "roofline": roofline, "cpu_baseline": cpu, "calib": calib, "step_ms": spread, "clocks_during_timed_region": clocks,
+            "final_losses": losses,
             "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
             "batchnorm": None if dp is None else ("global batch (statistic sums all-reduced)" if dp.sync_bn else "per replica"),
             "collectives": None if dp is None else ("libpcgan_hip pcg_dp_* (RCCL behind the C ABI)" if dp.native else "torch.distributed nccl"),

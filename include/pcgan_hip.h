@@ -694,6 +694,21 @@ int pcg_dp_broadcast(void* buf, int64_t nbytes, int32_t root, pcg_stream_t strea
 int pcg_dp_sync_batchnorm(int32_t enable);
 int pcg_dp_shutdown(void);
 
+/* ---- calibration (diagnostics; not on the step's path) -----------------------------------------------------------------------
+ * What THIS box's fp32 matrix pipe and HBM sustain right now — bench.py prints it next to the step (`calib`) so that a run on a
+ * slower-clocked box can be told from a slower kernel (the reference has nothing comparable: it publishes no performance numbers,
+ * BASELINE.md §2 "re-derive from the box").
+ *   pcg_calib_mfma   `rounds` blocks per CU of 4 waves, each issuing iters*16 back-to-back v_mfma_f32_32x32x2_f32 on four
+ *                    independent accumulators.  workspace: [2048 floats of operands — caller-initialised, any finite values]
+ *                    [blocks*256 floats sink][blocks*2 uint64: shader-clock ticks, 100 MHz reference ticks of the block's loop].
+ *                    *flop_out = FLOP of the launch; *stamps_out = device address of the stamps.  Time it with events on `stream`.
+ *   pcg_calib_copy   dst <- src (16 bytes per lane, grid-stride): 2*nbytes of HBM traffic.                                       */
+int32_t pcg_calib_mfma_blocks(int32_t rounds);
+size_t pcg_calib_mfma_workspace_bytes(int32_t rounds);
+int pcg_calib_mfma(int32_t iters, int32_t rounds, void* workspace, size_t workspace_bytes, double* flop_out /*nullable*/,
+                   uint64_t** stamps_out /*nullable*/, pcg_stream_t stream);
+int pcg_calib_copy(const void* src, void* dst, int64_t nbytes, pcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

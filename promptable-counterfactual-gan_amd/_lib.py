@@ -80,6 +80,10 @@ PROTOTYPES = {
     "pcg_abi_version": (_i, []),
     "pcg_last_error": (_c.c_char_p, []),
     "pcg_target_arch": (_c.c_char_p, []),
+    "pcg_calib_mfma_blocks": (_i32, [_i32]),
+    "pcg_calib_mfma_workspace_bytes": (_sz, [_i32]),
+    "pcg_calib_mfma": (_i, [_i32, _i32, _vp, _sz, _c.POINTER(_d), _c.POINTER(_c.c_uint64), _vp]),
+    "pcg_calib_copy": (_i, [_vp, _vp, _i64, _vp]),
     "pcg_conv2d_fwd_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_dgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -83,6 +83,21 @@ int dp_allreduce_f64(double* buf, int64_t n, hipStream_t s) {
 namespace {
 #define DP_READY(who) PCG_REQUIRE(g.comm != nullptr, "%s: pcg_dp_init has not been called", who)
 
+// pcg_dp_init failed after ncclCommInitRank: destroy what exists (null handles are skipped), leave the state "not initialised".
+// The error text of the failure that brought us here is kept (the destroy calls do not touch it).
+void release_partial() {
+  for (int i = 0; i < kSlots; ++i) {
+    if (g.ready[i]) (void)hipEventDestroy(g.ready[i]);
+    if (g.done[i]) (void)hipEventDestroy(g.done[i]);
+    g.ready[i] = nullptr; g.done[i] = nullptr; g.pending[i] = false;
+  }
+  if (g.side) (void)hipStreamDestroy(g.side);
+  g.side = nullptr;
+  if (g.comm) (void)g.destroy(g.comm);
+  g.comm = nullptr;
+  g.rank = -1; g.world = 0;
+}
+
 }  // namespace
 }  // namespace pcg
 
@@ -105,11 +120,18 @@ extern "C" int pcg_dp_init(const void* id_in, int32_t rank, int32_t world) {
   UniqueId id;
   memcpy(&id, id_in, sizeof(id));
   if (int e = nccl_ok(g.init(&g.comm, world, id, rank), "ncclCommInitRank")) { g.comm = nullptr; return e; }
-  if (int e = hip_ok(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking), "hipStreamCreate")) return e;
-  for (int i = 0; i < kSlots; ++i) {
-    if (int e = hip_ok(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming), "hipEventCreate")) return e;
-    if (int e = hip_ok(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming), "hipEventCreate")) return e;
-    g.pending[i] = false;
+  // From here on a failure must give everything back (communicator, stream, the events made so far): the caller sees "not
+  // initialised" and may call pcg_dp_init again; pcg_last_error() keeps the text of the FIRST failure.
+  g.side = nullptr;
+  for (int i = 0; i < kSlots; ++i) { g.ready[i] = nullptr; g.done[i] = nullptr; g.pending[i] = false; }
+  int err = hip_ok(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking), "hipStreamCreate");
+  for (int i = 0; i < kSlots && err == PCG_OK; ++i) {
+    err = hip_ok(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming), "hipEventCreate");
+    if (err == PCG_OK) err = hip_ok(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  if (err != PCG_OK) {
+    release_partial();
+    return err;
   }
   g.rank = rank; g.world = world;
   return PCG_OK;

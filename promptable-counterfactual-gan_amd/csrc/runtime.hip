@@ -23,6 +23,6 @@ int launch_status(const char* what) {
 }
 }  // namespace pcg
 
-extern "C" int pcg_abi_version(void) { return 3; }   // v2 (r02): + pcg_conv2d_*_xf, pcg_bn_train_stats_coef, pcg_dp_*; pcg_bn_bwd_partial takes fp64 partial rows.  v3 (r02): pcg_adam_step_capturable scratch is 48 bytes; pcg_linear_wgrad_grouped takes whole layers; + the pcg_house_* / spectral-norm reps / seq entry points
+extern "C" int pcg_abi_version(void) { return 4; }   // v4 (r03): + pcg_calib_*.   v2 (r02): + pcg_conv2d_*_xf, pcg_bn_train_stats_coef, pcg_dp_*; pcg_bn_bwd_partial takes fp64 partial rows.  v3 (r02): pcg_adam_step_capturable scratch is 48 bytes; pcg_linear_wgrad_grouped takes whole layers; + the pcg_house_* / spectral-norm reps / seq entry points
 extern "C" const char* pcg_last_error(void) { return pcg::g_err; }
 extern "C" const char* pcg_target_arch(void) { return "gfx950"; }

@@ -629,19 +629,27 @@ class _HipGraphCapture:
         gc.collect()
         self._gc_was_on = gc.isenabled()
         gc.disable()
-        self._g = torch.cuda.CUDAGraph()
-        # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
-        self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
-        self._ctx.__enter__()
+        try:
+            self._g = torch.cuda.CUDAGraph()
+            # thread_local: calls made by other threads (the RCCL watchdog polling events) must not invalidate the capture
+            self._ctx = torch.cuda.graph(self._g, pool=self._pool, capture_error_mode="thread_local")
+            self._ctx.__enter__()
+        except BaseException:
+            self._gc_restore()         # the capture never began: end() will not run, the collector must not stay off
+            raise
         self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
+
+    def _gc_restore(self):
+        if getattr(self, "_gc_was_on", False):
+            import gc
+            gc.enable()
+        self._gc_was_on = False
 
     def end(self):
         try:
             self._ctx.__exit__(None, None, None)
         finally:
-            if getattr(self, "_gc_was_on", False):
-                import gc
-                gc.enable()
+            self._gc_restore()
         if self._pool is None:
             self._pool = self._g.pool()
         return self._g             # .replay()

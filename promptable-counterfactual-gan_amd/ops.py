@@ -1096,3 +1096,54 @@ class DeviceRNG:
         check(_lib.load().pcg_rand_bernoulli(_p(out), n, float(keep_prob), self.seed, self._advance((n + 3) // 4), _stream()),
               "pcg_rand_bernoulli")
         return out
+
+
+# ---- calibration (bench lines; not on the step's path) -------------------------------------------------------------------
+def calibrate(device, mfma_ms=20.0, copy_mb=512, rounds=2):
+    """What this box's fp32 matrix pipe and HBM sustain NOW: {"mfma_tflops", "mfma_clock_mhz", "hbm_gbs", ...}.
+
+    A bare v_mfma_f32_32x32x2_f32 loop on every CU for ~mfma_ms (pcg_calib_mfma; the in-kernel shader clock comes from its
+    s_memtime / s_memrealtime stamps) and a copy_mb-MiB device copy (pcg_calib_copy), each timed with events on the current
+    stream.  bench.py runs it before and after the timed steps, outside the timed bracket, so that a step measured on a box
+    with a slower clock can be told from a slower kernel (roofline.achieved / calib.mfma_tflops is box-independent)."""
+    lib = _lib.load()
+    nbytes = lib.pcg_calib_mfma_workspace_bytes(rounds)
+    blocks = lib.pcg_calib_mfma_blocks(rounds)
+    if blocks <= 0:
+        raise _lib.PcgError("calibrate: no GPU visible to libpcgan_hip")
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    ws[:8192].view(torch.float32).copy_(torch.linspace(-1.0, 1.0, 2048))
+    flop = ctypes.c_double(0.0)
+    stamps = ctypes.c_uint64(0)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def run(iters):
+        e[0].record()
+        check(lib.pcg_calib_mfma(int(iters), rounds, _p(ws), nbytes, ctypes.byref(flop), ctypes.byref(stamps), _stream()), "pcg_calib_mfma")
+        e[1].record()
+        e[1].synchronize()
+        return e[0].elapsed_time(e[1])
+
+    probe_iters = 2048
+    run(probe_iters)                                   # code object load, clocks up
+    ms = run(probe_iters)
+    iters = max(probe_iters, int(probe_iters * mfma_ms / max(ms, 1e-3)))
+    ms = run(iters)
+    st = ws[8192 + blocks * 1024:].view(torch.int64).view(blocks, 2).cpu().double()
+    mhz = (st[:, 0] / st[:, 1].clamp_min(1.0) * 100.0)
+    out = {"mfma_tflops": round(flop.value / (ms * 1e-3) / 1e12, 2), "mfma_ms": round(ms, 3),
+           "mfma_clock_mhz": round(float(mhz.median()), 0), "mfma_clock_mhz_min": round(float(mhz.min()), 0),
+           "mfma_cycles_per_inst": round(float((st[:, 0] / (iters * 16.0)).median()), 2)}
+    n = int(copy_mb) << 20
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    fill(src.view(torch.float32), 1.0)
+    times = []
+    for _ in range(4):
+        e[0].record()
+        check(lib.pcg_calib_copy(_p(src), _p(dst), n, _stream()), "pcg_calib_copy")
+        e[1].record()
+        e[1].synchronize()
+        times.append(e[0].elapsed_time(e[1]))
+    out["hbm_gbs"] = round(2.0 * n / (min(times[1:]) * 1e-3) / 1e9, 1)
+    return out

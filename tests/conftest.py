@@ -16,3 +16,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _class_switches_restored():
+    """The A/B class switches of SequentialConvNet are process-wide: whatever a test sets, the next test starts from the product
+    defaults (r02 leak: one test left fold_bn_apply = True and every later file ran the opt-in folded path)."""
+    try:
+        from pcgan_amd.nn import SequentialConvNet
+    except Exception:
+        yield
+        return
+    want = {"fold_bn_apply": False, "fuse_backward_epilogue": True, "wgrad_stream": None}
+    for k, v in want.items():
+        assert getattr(SequentialConvNet, k) == v or getattr(SequentialConvNet, k) is v, f"SequentialConvNet.{k} leaked from an earlier test"
+    yield
+    for k, v in want.items():
+        setattr(SequentialConvNet, k, v)

@@ -406,7 +406,7 @@ def test_folded_bn_apply_equals_separate_pass(pcg):
             res[fold] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], _state(netG, netD),
                          netG.flat_grads.clone(), netD.flat_grads.clone(), viz)
     finally:
-        SequentialConvNet.fold_bn_apply = True
+        SequentialConvNet.fold_bn_apply = False            # the product default (nn.py): later test files must run the benched path
     assert res[True][0] == res[False][0]
     for k in res[False][1]:
         assert torch.equal(res[True][1][k], res[False][1][k]), k

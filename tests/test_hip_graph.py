@@ -88,6 +88,69 @@ def test_rng_draw_inside_capture_raises(pcg):
             rng.randn((16,), torch.device(DEV))
 
 
+def test_cyclic_garbage_before_capture_does_not_abort(pcg):
+    """The r02 process abort (gpurun_out/h17): Python's cyclic collector ran a finalizer that frees device memory while a stream
+    was capturing.  Reference cycles holding device tensors, events and a finished graph are left uncollected right before the
+    capture (collector thresholds lowered so that it WOULD run inside the capture if it were allowed to); GraphedStep must collect
+    them first, keep the collector off while capturing and hand it back enabled."""
+    import gc
+    from pcgan_amd.nn import GraphedStep
+    D = pcg.dcgan
+    cfg = {"g_hidden": 16, "d_hidden": 16, "z_dim": 32}
+    netG, netD, crit, optD, optG = _fresh(D, cfg)
+    real = (torch.rand(8, 1, 64, 64) * 2 - 1).to(DEV)
+    noise = torch.randn(8, 32, 1, 1).to(DEV)
+
+    class Node:
+        pass
+    old = gc.get_threshold()
+    gc.collect()
+    try:
+        gc.set_threshold(5, 1, 1)
+        gc.disable()
+        for _ in range(64):                         # cycles that own device memory, events and a captured graph
+            a, b = Node(), Node()
+            a.peer, b.peer = b, a
+            a.t = torch.empty(1 << 16, device=DEV)
+            b.e = torch.cuda.Event(enable_timing=True)
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0):
+            torch.zeros(4, device=DEV).add_(1.0)
+        c = Node(); c.me = c; c.g = g0
+        del a, b, c, g0
+        gc.enable()
+        assert gc.isenabled()
+        gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, real, noise, cfg), {"real": real, "noise": noise},
+                         [netG, netD], [optD, optG])
+        assert gc.isenabled()                       # handed back
+        o = gs.replay()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o[k]).item() for k in ("errD_real", "errD_fake", "errG"))
+    finally:
+        gc.set_threshold(*old)
+        gc.enable()
+
+
+def test_collector_is_handed_back_when_capture_cannot_begin(pcg, monkeypatch):
+    """_HipGraphCapture.begin disables the collector; if torch.cuda.graph(...).__enter__ raises, end() never runs — begin itself
+    must re-enable it (r02 residual)."""
+    import gc
+    from pcgan_amd import nn as N
+    cap = N._HipGraphCapture(torch.device(DEV))
+
+    class Boom:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("capture refused")
+    monkeypatch.setattr(torch.cuda, "graph", Boom)
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError, match="capture refused"):
+        cap.begin()
+    assert gc.isenabled()
+
+
 def test_native_rccl_exports_one_rank(pcg):
     """pcg_dp_* (RCCL behind the C ABI) on a one-rank communicator: in-stream average, side-stream begin / record / wait with
     follow-up work queued behind the reduction, float64 sum, broadcast — and the ordering against the producer stream."""

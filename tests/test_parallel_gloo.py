@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the data-parallel gradient exchange (one flat bucket per net, averaged across ranks,
 replicas stay identical).  The GPU path uses the same GradSync object with backend nccl (= RCCL)."""
 import os
+import time
 import socket
 
 import torch
@@ -277,16 +278,54 @@ def test_bench_launcher_starts_ranks_and_propagates_failure(tmp_path, monkeypatc
                       "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
                       "print('{\"rank\": %d, \"world\": %d, \"argv\": \"%s\"}' % (r, w, ' '.join(sys.argv[1:])))\n"
                       "sys.exit(7 if (len(sys.argv) > 1 and sys.argv[1] == 'fail' and r == 1) else 0)\n")
-    drv = ("import sys, torch; sys.path.insert(0, %r); import bench; torch.cuda.device_count = lambda: %%d; "
+    # the parent counts GPUs from the KFD topology (no HIP call); a runtime query there fails the test
+    drv = ("import sys, torch; sys.path.insert(0, %r); import bench; bench.count_gpus_sysfs = lambda: %%d; "
+           "torch.cuda.device_count = lambda: (_ for _ in ()).throw(AssertionError('the parent must not ask the HIP runtime')); "
            "bench.launch_ranks(3, sys.argv[1:], script=%r)" % (root, str(script)))
     ok = subprocess.run([sys.executable, "-c", drv % 8, "--steps", "2"], capture_output=True, text=True, timeout=120)
     assert ok.returncode == 0, ok.stderr
     assert ok.stdout.strip() == '{"rank": 0, "world": 3, "argv": "--steps 2"}'          # only rank 0 reaches stdout
-    assert '"rank": 1' in ok.stderr and '"rank": 2' in ok.stderr
+    assert '[rank 1] {"rank": 1' in ok.stderr and '[rank 2] {"rank": 2' in ok.stderr      # every rank's output carries its rank
     bad = subprocess.run([sys.executable, "-c", drv % 8, "fail"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 7 and "rank 1 exited with 7" in bad.stderr
     few = subprocess.run([sys.executable, "-c", drv % 1], capture_output=True, text=True, timeout=120)
     assert few.returncode != 0 and "exposes 1 GPU" in few.stderr
+    assert "rank" not in few.stdout and '{"rank"' not in few.stderr                        # failed before any child started
+
+
+def test_bench_launcher_rendezvous_timeout(tmp_path):
+    """A rank that never arrives (stuck in the rendezvous, a hung collective) must not hang the run: after PCG_BENCH_TIMEOUT
+    seconds the launcher stops the ranks it started and exits non-zero."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    sys.stderr.write('waiting for a peer that never comes\\n'); sys.stderr.flush(); time.sleep(600)\n")
+    drv = ("import sys, torch; sys.path.insert(0, %r); import bench; bench.count_gpus_sysfs = lambda: 2; "
+           "bench.launch_ranks(2, [], script=%r)" % (root, str(script)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PCG_BENCH_TIMEOUT="3"))
+    assert r.returncode == 124 and "still running after 3 s" in r.stderr and "[rank 1] waiting for a peer" in r.stderr
+    assert time.time() - t0 < 60
+
+
+def test_gpu_count_from_kfd_topology(tmp_path, monkeypatch):
+    """count_gpus_sysfs reads /sys/class/kfd/kfd/topology/nodes/*/properties: nodes with simd_count > 0 are GPUs."""
+    import bench
+    n = bench.count_gpus_sysfs()
+    assert n is None or n >= 0
+    base = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        (base / str(i)).mkdir(parents=True)
+        (base / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_listdir, real_open = os.listdir, open
+    monkeypatch.setattr(os, "listdir", lambda p: real_listdir(str(base)) if p == "/sys/class/kfd/kfd/topology/nodes" else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(base)), *a, **k))
+    assert bench.count_gpus_sysfs() == 3
 
 
 def _syncbn_worker(rank, world, port, q):
