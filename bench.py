@@ -80,12 +80,22 @@ class ClockSampler:
     (Hz) / power1_average|power1_input (uW) of the card that backs this rank's HIP device, else the starred line of pp_dpm_sclk.
     No HIP call, no effect on the stream; every field is None when sysfs exposes nothing."""
 
-    def __init__(self, local_rank=0, period=0.01):
+    def __init__(self, pci=None, period=0.01):
+        """pci = (domain, bus, device) of the HIP device (torch.cuda.get_device_properties: pci_domain_id, pci_bus_id,
+        pci_device_id): the DRM card whose sysfs device link ends in that address is sampled; without a match nothing is (a box
+        exposes the cards of every GPU of the host, also those this job cannot use)."""
         import glob
         self.period, self.freq, self.power, self._stop, self._th = period, [], [], False, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(p.split("card")[1].split("/")[0]))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
-        self.dev = cards[local_rank] if local_rank < len(cards) else (cards[0] if cards else None)
+        self.dev = None
+        if pci is not None:
+            want = "%04x:%02x:%02x." % tuple(int(v) for v in pci)
+            for c in glob.glob("/sys/class/drm/card[0-9]*/device"):
+                try:
+                    if os.path.basename(os.path.realpath(c)).lower().startswith(want) and "-" not in os.path.basename(os.path.dirname(c)):
+                        self.dev = c
+                        break
+                except OSError:
+                    continue
         self.f_freq = self.f_power = self.f_dpm = None
         if self.dev:
             for h in glob.glob(os.path.join(self.dev, "hwmon/hwmon*")):
@@ -151,7 +161,7 @@ class ClockSampler:
             v = sorted(v)
             return {"min": round(v[0], 1), "p50": round(v[len(v) // 2], 1), "max": round(v[-1], 1), "samples": len(v)}
         return {"sclk_mhz": stats(self.freq), "power_w": stats(self.power),
-                "source": self.f_freq or self.f_dpm or None}
+                "source": self.f_freq or self.f_dpm or None, "period_s": self.period}
 
 
 def cpu_model():
@@ -411,7 +421,10 @@ def main():
     records = []
     hook = (lambda label, flops, t0, t1: records.append((label, flops, t0, t1))) if not args.no_kernel_events else None
 
-    sampler = ClockSampler(local_rank) if rank == 0 else None
+    sampler = None
+    if rank == 0:
+        pr = torch.cuda.get_device_properties(local_rank)
+        sampler = ClockSampler((getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0)))
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # one record per step boundary: the spread
     barrier()
     torch.cuda.synchronize()

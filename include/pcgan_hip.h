@@ -341,6 +341,10 @@ int pcg_fill(float* p, int64_t n, float value, pcg_stream_t stream);
 int pcg_add_bias_rows(float* x, int64_t rows, int32_t C, const float* bias, pcg_stream_t stream);
 /* out[0] (+)= sum p[i]^2   (grad_norm diagnostic: mnist/trainer.py:41-42) */
 int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, pcg_stream_t stream);
+/* out[0] = sum over segments s of || flat[seg[2s] .. seg[2s] + seg[2s+1]) ||_2 — the grad_norm diagnostic of
+ * house_sales_kc_usa/trainer.py:182-183 (a SUM of per-parameter norms) in one launch over the net's flat gradient buffer;
+ * seg_dev: int64 [nseg][2] = (offset, numel) of every parameter, on the device. */
+int pcg_norm_sum(const float* flat, const int64_t* seg_dev, int32_t nseg, float* out, pcg_stream_t stream);
 
 /* ---- tabular CounteRGAN (conditional_counteRGAN/house_sales_kc_usa), SURVEY.md section 8a row a15 -------------------
  * All operands are dense row-major fp32 [rows][features]; the layer widths (38, 32, 21, 17, 10, 9, 30, 6, 2, 5, 13, 1)
@@ -657,6 +661,35 @@ int pcg_house_draws(int64_t* target_y, int32_t B, int32_t num_classes, const int
 int pcg_house_draws_counter(int64_t* target_y, int32_t B, int32_t num_classes, const int64_t* y, float* mask, int32_t D,
                             const int32_t* zero_cols, int32_t n_zero_cols, float* noise, int32_t T, uint64_t seed, float* onehot_target,
                             float* onehot_y, uint64_t* counter, pcg_stream_t stream);
+/* pcg_house_draws_counter + the BATCH: the training set X [n_rows][D] / Y [n_rows] and the epoch's permutation perm [n_perm] are
+ * resident in HBM; the launch copies rows perm[cursor .. cursor+B) into x_out / y_out (the static inputs of the captured step),
+ * writes the source rows to src_out (nullable) and draws target / mask / noise / one-hot rows for them.  counter: uint64[4] =
+ * [Philox offset, ticket, row cursor, unused]; the launch advances offset and cursor (+= B) itself, so a replayed graph walks
+ * through the epoch with no host-side copy — DataLoader(shuffle=True, drop_last=True) of house_sales_kc_usa/trainer.py:198. */
+int pcg_house_batch_draws_counter(int64_t* target_y, int32_t B, int32_t num_classes, const float* X, const int64_t* Y,
+                                  const int64_t* perm, int64_t n_perm, int64_t n_rows, float* x_out, int64_t* y_out,
+                                  int64_t* src_out /*nullable*/, float* mask, int32_t D, const int32_t* zero_cols, int32_t n_zero_cols,
+                                  float* noise, int32_t T, uint64_t seed, float* onehot_target /*nullable*/, float* onehot_y /*nullable*/,
+                                  uint64_t* counter, pcg_stream_t stream);
+/* The four per-iteration diagnostics of house_sales_kc_usa/trainer.py:318-343 in one single-block launch:
+ *   out4 = { pred_gain, sparsity (|masked residual| > eps), reg_loss_l2, class_flip_rate }
+ * logits_orig: the frozen classifier's logits of the ORIGINAL rows (it does not change during GAN training: evaluated once for the
+ * training set), gathered through src_rows (nullable: row b).  acc (nullable, double[8]): epoch accumulators —
+ * acc[2..5] += out4 (pcg_house_residual_bwd_losses_diag also adds D_loss, G_loss and the iteration count to acc[0], acc[1], acc[6]),
+ * read once per epoch instead of six .item() calls per iteration (trainer.py:327-353).                                          */
+int pcg_house_diag(const float* logits_cf, const float* logits_orig, const int64_t* src_rows /*nullable*/, const int64_t* target_y,
+                   const float* masked, int32_t B, int32_t nc, int32_t D, float eps, float* out4, double* acc /*nullable*/,
+                   pcg_stream_t stream);
+/* pcg_house_residual_bwd_losses with the diagnostics riding in the same launch (one more block) and the epoch accumulators. */
+int pcg_house_residual_bwd_losses_diag(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b,
+                                       float w_pen, float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev,
+                                       int32_t S, int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B,
+                                       float* dcont, float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g,
+                                       int32_t n, const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg,
+                                       float lambda_mask, float w_reg_log, const float* ce_row_loss, int32_t n_ce, float* out6,
+                                       const float* logits_cf, const float* logits_orig, const int64_t* src_rows /*nullable*/,
+                                       const int64_t* target_y, int32_t nc, float eps, float* diag_out4, double* acc /*nullable*/,
+                                       pcg_stream_t stream);
 
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per

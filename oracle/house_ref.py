@@ -4,11 +4,13 @@
     models/generator.py        FiLM :6-16, ResidualBlock :19-35, ResidualGenerator :38-92
     models/discriminator.py    :5-20    (four spectral-norm Linears + LeakyReLU(0.2))
     models/nn_classifier.py    :4-32    (frozen MLP classifier, eval mode)
-    trainer.py                 loop body of train_countergan :241-316, cat_norm_maps fallback :218-223
+    trainer.py                 loop body of train_countergan :241-316, cat_norm_maps :205-223, the per-iteration diagnostics
+                               :318-343, epoch means + grad_norm :349-366 (train_countergan below)
 on the same PyTorch operators.  The reference modules are importable: tests/golden/make_golden.py runs ONE batch through
 the reference's own train_countergan and records the random draws it made (targets, feature mask, Gumbel noise), so this
 restatement is pinned on the identical draws.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -156,6 +158,75 @@ def house_step(G, D, clf, opt_G, opt_D, x, y, target_y, mask, gumbel, norm_maps,
     return {"D_loss": D_loss.item(), "G_loss": G_loss.item(), "g_adv": G_adv.item(), "g_cls": G_cls.item(),
             "reg": G_reg.item(), "mask_pen": mask_penalty_pre.item(),
             "d_real_p": torch.sigmoid(D_real).mean().item(), "d_fake_p": torch.sigmoid(D_fake_forG).mean().item()}
+
+
+def cat_norm_maps_scaler(data_min, data_max, raw_values):
+    """trainer.py:205-216: normalised category values from the fitted MinMaxScaler's data_min_ / data_max_."""
+    out = {}
+    for f, raw in raw_values.items():
+        rng_ = float(data_max[f]) - float(data_min[f])
+        out[f] = torch.tensor((np.asarray(raw, dtype=float) - float(data_min[f])) / (rng_ + 1e-12), dtype=torch.float32)
+    return out
+
+
+def grad_norm(params):
+    """trainer.py:182-183: the SUM of the parameters' gradient norms."""
+    return sum(p.grad.norm().item() for p in params if p.grad is not None)
+
+
+def train_countergan(G, D, clf, X, y, rows, target_y, mask, gumbel, norm_maps, config=CONFIG):
+    """trainer.py:237-366 with everything random supplied: rows[e][i] (the DataLoader's batch), target_y / mask / gumbel[e][i]
+    (packed [B, T] in head order).  Per iteration the step (:241-316, house_step) and the diagnostics (:318-343); per epoch the
+    means (:349-355) and grad_norm of G and D (:362).  Returns the per-iteration lists and the per-epoch grad norms."""
+    opt_G, opt_D = make_optimizers(G, D, config)
+    heads = list(config["categorical_info"].items())
+    names = ("d_loss", "g_loss", "pred_gain", "sparsity", "l2_reg", "class_flip_rate")
+    it = {k: [] for k in names}
+    gG, gD = [], []
+    nc = config["num_classes"]
+    for e in range(len(rows)):
+        for k in names:
+            it[k].append([])
+        for i in range(len(rows[e])):
+            x, yb = X[rows[e][i]], y[rows[e][i]]
+            t, m = target_y[e][i], mask[e][i]
+            gd, off = {}, 0
+            for f, n in heads:
+                gd[f] = gumbel[e][i][:, off:off + n]
+                off += n
+            # --- the step, keeping what the diagnostics read (house_step restated with its intermediates exposed)
+            bs, d_dim = x.shape
+            target_onehot = F.one_hot(t, nc).to(x.dtype)
+            cont_residual, _, cat_samples = G(x, target_onehot, m, gd, temperature=config["gumbel_tau"])
+            residual_full = torch.zeros((bs, d_dim), dtype=cont_residual.dtype)
+            for j, f in enumerate(config["continuous_idx"]):
+                residual_full[:, f] = cont_residual[:, j]
+            for f, sample in cat_samples.items():
+                residual_full[:, f] = sample.matmul(norm_maps[f].to(x.dtype)) - x[:, f]
+            masked_residual = residual_full * m
+            x_cf = x + masked_residual
+            mask_penalty_pre = torch.mean(torch.abs(residual_full * (1.0 - m)))
+            D_real = D(x, F.one_hot(yb, nc).to(x.dtype))
+            D_fake = D(x_cf.detach(), target_onehot)
+            D_loss = -D_real.mean() + D_fake.mean()
+            opt_D.zero_grad(); D_loss.backward(); opt_D.step()
+            D_fake_forG = D(x_cf, target_onehot)
+            G_adv = -D_fake_forG.mean()
+            clf_preds = clf(x_cf)
+            G_cls = F.cross_entropy(clf_preds, t)
+            G_reg = torch.mean(torch.norm(masked_residual, p=1, dim=1))
+            G_loss = G_adv + config["lambda_cls"] * G_cls + config["lambda_reg"] * G_reg + config["lambda_mask"] * mask_penalty_pre
+            opt_G.zero_grad(); G_loss.backward(); opt_G.step()
+            with torch.no_grad():                                                               # :318-343
+                probs_orig, probs_cf = F.softmax(clf(x), dim=1), F.softmax(clf_preds, dim=1)
+                ar = torch.arange(bs)
+                it["pred_gain"][-1].append((probs_cf[ar, t] - probs_orig[ar, t]).mean().item())
+                it["sparsity"][-1].append(1.0 - (torch.abs(masked_residual) > 1e-3).float().mean().item())
+                it["l2_reg"][-1].append(torch.mean(torch.norm(masked_residual, p=2, dim=1)).item())
+                it["class_flip_rate"][-1].append((torch.argmax(clf_preds, dim=1) == t).float().mean().item())
+            it["d_loss"][-1].append(D_loss.item()); it["g_loss"][-1].append(G_loss.item())
+        gG.append(grad_norm(G.parameters())); gD.append(grad_norm(D.parameters()))              # :362
+    return it, gG, gD
 
 
 def build_counterfactuals(G, x, target_onehot, gumbel, norm_maps, config=CONFIG):

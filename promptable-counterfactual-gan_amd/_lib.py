@@ -165,6 +165,7 @@ PROTOTYPES = {
     "pcg_fill": (_i, [_vp, _i64, _f, _vp]),
     "pcg_add_bias_rows": (_i, [_vp, _i64, _i32, _vp, _vp]),
     "pcg_sumsq": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "pcg_norm_sum": (_i, [_vp, _vp, _i32, _vp, _vp]),
     "pcg_instnorm_fwd": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "pcg_instnorm_bwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_instnorm_bwd_bwd": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -194,6 +195,12 @@ PROTOTYPES = {
                                            _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _i32, _vp, _vp]),
     "pcg_house_draws": (_i, [_vp, _i32, _i32, _vp, _c.c_uint64, _vp, _i32, _vp, _i32, _c.c_uint64, _vp, _i32, _c.c_uint64, _c.c_uint64, _vp, _vp, _vp]),
     "pcg_house_draws_counter": (_i, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _c.c_uint64, _vp, _vp, _vp, _vp]),
+    "pcg_house_batch_draws_counter": (_i, [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _c.c_uint64,
+                                           _vp, _vp, _vp, _vp]),
+    "pcg_house_diag": (_i, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp, _vp]),
+    "pcg_house_residual_bwd_losses_diag": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp,
+                                                _vp, _vp, _vp, _i32, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _i32, _vp,
+                                                _vp, _vp, _vp, _vp, _i32, _f, _vp, _vp, _vp]),
     "pcg_house_critic_fwd_n": (_i, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_house_critic_bwd_n": (_i, [_i32, _vp, _i32, _i32, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_spectral_norm_fwd_batched_reps": (_i, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),

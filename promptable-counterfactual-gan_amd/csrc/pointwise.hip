@@ -201,6 +201,29 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ p,
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s;
 }
 
+// sum over segments of ||segment||_2 in ONE launch (house_sales_kc_usa/trainer.py:182-183: this trainer's grad_norm is the SUM of
+// the parameters' gradient norms).  One block of 16 waves; wave w owns segments w, w+16, ...: lanes stride the segment, fp64
+// butterfly over the wave, sqrt, running sum per wave; the 16 wave sums are added in wave order.  Fixed order: reproducible.
+__global__ void __launch_bounds__(1024) norm_sum_kernel(const float* __restrict__ flat, const int64_t* __restrict__ seg, int nseg, float* out) {
+  __shared__ double wsum[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double tot = 0.0;
+  for (int sgm = wave; sgm < nseg; sgm += 16) {
+    const int64_t off = seg[2 * sgm], n = seg[2 * sgm + 1];
+    double acc = 0.0;
+    for (int64_t i = lane; i < n; i += 64) { const double v = (double)flat[off + i]; acc = fma(v, v, acc); }
+    for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
+    tot += sqrt(acc);
+  }
+  if (lane == 0) wsum[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    out[0] = (float)t;
+  }
+}
+
 int adam_launch(float* param, const float* grad, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                 double wd, int decoupled, AdamHyper hy, int64_t* step_dev, AdamCache* cache_dev, hipStream_t s) {
   const bool al = al16(param) && al16(grad) && al16(m) && al16(v);
@@ -318,4 +341,10 @@ extern "C" int pcg_sumsq(const float* p, int64_t n, float* out, int accumulate, 
   PCG_REQUIRE(p && out && n > 0, "pcg_sumsq: bad arguments");
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, out, accumulate);
   return launch_status("sumsq_kernel");
+}
+
+extern "C" int pcg_norm_sum(const float* flat, const int64_t* seg_dev, int32_t nseg, float* out, pcg_stream_t stream) {
+  PCG_REQUIRE(flat && seg_dev && out && nseg > 0, "pcg_norm_sum: bad arguments");
+  hipLaunchKernelGGL(norm_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flat, seg_dev, nseg, out);
+  return launch_status("norm_sum_kernel");
 }

@@ -196,6 +196,57 @@ __global__ void __launch_bounds__(256) house_draws_kernel(int64_t* __restrict__ 
   }
 }
 
+// house_draws_kernel (counter form) + the BATCH itself: the training set is resident in HBM, the epoch's permutation too; the launch
+// takes rows perm[cur .. cur+B) (cur = ctr[2], advanced by B by the block that takes the last ticket) into the static x / y buffers
+// of the captured step, so a replay needs no host-side copy at all (DataLoader(shuffle=True, drop_last=True), trainer.py:198,
+// without per-batch collation and PCIe traffic).  y is gathered by the thread that draws that row's target class (the target rule
+// reads it), its one-hot row written there too; src_out[b] = the source row (the diagnostics gather the frozen classifier's logits
+// of the original rows with it).
+__global__ void __launch_bounds__(256) house_batch_draws_kernel(int64_t* __restrict__ target, int B, int32_t lo, int32_t hi,
+                                                                const float* __restrict__ X, const int64_t* __restrict__ Y,
+                                                                const int64_t* __restrict__ perm, int64_t n_perm, int64_t n_rows,
+                                                                float* __restrict__ x_out, int64_t* __restrict__ y_out, int64_t* __restrict__ src_out,
+                                                                float* __restrict__ mask, int D, const int* __restrict__ zero_cols, int nz,
+                                                                float* __restrict__ noise, int64_t n_noise, uint64_t seed,
+                                                                float* __restrict__ onehot_t, float* __restrict__ onehot_y, unsigned long long* ctr) {
+  const int64_t nm = (int64_t)B * D;
+  const unsigned long long base = ctr[0];
+  const int64_t cur = (int64_t)ctr[2];
+  const uint64_t off_t = base, off_m = off_t + (uint64_t)((B + 3) / 4), off_n = off_m + (uint64_t)((nm + 3) / 4);
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthr = (int64_t)gridDim.x * 256;
+  auto src_row = [&](int64_t b) -> int64_t {
+    int64_t p = cur + b;
+    p = p < n_perm ? p : n_perm - 1;                         // host guarantees cur + B <= n_perm; never read past the buffers
+    int64_t r = perm[p];
+    return r < 0 ? 0 : (r < n_rows ? r : n_rows - 1);
+  };
+  for (int64_t i = tid; i < (n_noise + 3) / 4; i += nthr) gumbel_quad(i, noise, n_noise, seed, off_n);
+  for (int64_t i = tid; i < (nm + 3) / 4; i += nthr) feature_mask_quad(i, mask, nm, D, zero_cols, nz, seed, off_m);
+  const int nc = hi - lo;
+  for (int64_t i = tid; i < ((int64_t)B + 3) / 4; i += nthr) {
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j >= B) break;
+      const int64_t r = src_row(j);
+      const int64_t yv = Y[r];
+      y_out[j] = yv;
+      if (src_out) src_out[j] = r;
+      if (onehot_y) for (int q = 0; q < nc; ++q) onehot_y[j * nc + q] = yv - lo == q ? 1.f : 0.f;
+    }
+    randint_quad(i, target, B, lo, hi, y_out, seed, off_t, onehot_t);      // reads the y values this thread has just written
+  }
+  for (int64_t i = tid; i < nm; i += nthr) {
+    const int64_t b = i / D; const int c = (int)(i - b * D);
+    x_out[i] = X[src_row(b) * D + c];
+  }
+  __syncthreads();                                           // every thread of this block has read the counters
+  if (threadIdx.x == 0 && atomicAdd(reinterpret_cast<int*>(ctr + 1), 1) == (int)gridDim.x - 1) {
+    ctr[0] = off_n + (uint64_t)((n_noise + 3) / 4);
+    ctr[2] = (unsigned long long)(cur + B);
+    *reinterpret_cast<int*>(ctr + 1) = 0;
+  }
+}
+
 __global__ void __launch_bounds__(256) uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
     const U4 r = draw(seed, offset, (uint64_t)i);
@@ -310,4 +361,23 @@ extern "C" int pcg_rand_bernoulli(float* out, int64_t n, float keep_prob, uint64
   PCG_REQUIRE(out && n > 0 && keep_prob >= 0.f && keep_prob <= 1.f, "pcg_rand_bernoulli: bad arguments");
   hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, keep_prob, seed, offset);
   return launch_status("bernoulli_kernel");
+}
+
+// pcg_house_draws_counter + the batch gather (see house_batch_draws_kernel).  counter: uint64[4] on the device =
+// [Philox offset, ticket, row cursor into perm, unused]; the launch advances offset and cursor itself.
+extern "C" int pcg_house_batch_draws_counter(int64_t* target_y, int32_t B, int32_t num_classes, const float* X, const int64_t* Y,
+                                             const int64_t* perm, int64_t n_perm, int64_t n_rows, float* x_out, int64_t* y_out,
+                                             int64_t* src_out, float* mask, int32_t D, const int32_t* zero_cols, int32_t n_zero_cols,
+                                             float* noise, int32_t T, uint64_t seed, float* onehot_target, float* onehot_y, uint64_t* counter,
+                                             pcg_stream_t stream) {
+  PCG_REQUIRE(target_y && X && Y && perm && x_out && y_out && mask && noise && counter && B > 0 && num_classes > 1 && D > 0 && T > 0 &&
+                  n_perm >= B && n_rows > 0 && n_zero_cols >= 0 && (zero_cols || n_zero_cols == 0),
+              "pcg_house_batch_draws_counter: bad arguments (B %d, permutation of %lld entries over %lld rows)", B, (long long)n_perm, (long long)n_rows);
+  int64_t quads = std::max(((int64_t)B * T + 3) / 4, ((int64_t)B * D + 3) / 4);
+  unsigned blocks = grid_for(quads);
+  if (blocks > 256u) blocks = 256u;                           // one same-address ticket per block
+  hipLaunchKernelGGL(house_batch_draws_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, target_y, B, 0, num_classes, X, Y, perm, n_perm, n_rows,
+                     x_out, y_out, src_out, mask, D, zero_cols, n_zero_cols, noise, (int64_t)B * T, seed, onehot_target, onehot_y,
+                     reinterpret_cast<unsigned long long*>(counter));
+  return launch_status("house_batch_draws_kernel");
 }

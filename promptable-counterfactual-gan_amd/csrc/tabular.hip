@@ -665,6 +665,7 @@ struct LossArgs {
   const float* d_real; const float* d_fake; const float* d_fake_g; size_t n; double inv_n; const float* g_cls; const float* am; const float* pen;
   float l_cls, l_reg, l_mask, w_reg_log; float* out;
   const float* rowloss; int n_ce;       // rowloss != nullptr: g_cls = the mean of these cross-entropy row terms, summed as cross_entropy_kernel does (out[5])
+  double* acc;                          // nullable: epoch accumulators (see DiagArgs): acc[0] += D_loss, acc[1] += G_loss, acc[6] += 1
 };
 __device__ __forceinline__ void house_losses_body(const LossArgs& a) {       // one block of 1024 threads
   const float* __restrict__ d_real = a.d_real; const float* __restrict__ d_fake = a.d_fake; const float* __restrict__ d_fake_g = a.d_fake_g;
@@ -710,8 +711,68 @@ __device__ __forceinline__ void house_losses_body(const LossArgs& a) {       // 
     out[2] = fmaf(-1.f, m_g, 0.f);
     out[3] = fmaf(w_reg_log, am[0], 0.f);
     out[4] = m_g;
+    if (a.acc) {                        // the trainer's per-epoch means (trainer.py:349-355) without a host read per iteration
+      a.acc[0] += (double)out[0];
+      a.acc[1] += (double)out[1];
+      a.acc[6] += 1.0;
+    }
   }
 }
+
+// The four per-iteration diagnostics of the tabular trainer (house_sales_kc_usa/trainer.py:318-343) as ONE block-wide reduction:
+//   out[0] pred_gain       = mean_b softmax(logits_cf)[b, t_b] - softmax(logits_orig)[src_b, t_b]          (:320-327)
+//   out[1] sparsity        = 1 - mean_{b,f} [ |masked_residual| > eps ]                                    (:330-333)
+//   out[2] reg_loss_l2     = mean_b ||masked_residual_b||_2                                                (:335)
+//   out[3] class_flip_rate = mean_b [ argmax logits_cf[b] == t_b ]                                         (:337-338)
+// logits_orig: the frozen classifier on the ORIGINAL rows — it never changes during GAN training, so the trainer evaluates it once
+// for the whole training set and every iteration gathers its batch's rows through src (nullptr: row b).  Fixed partition (thread t
+// owns rows t, t+1024, ...) and a fixed fp64 tree: bit-reproducible.  acc (nullable): acc[2..5] += out[0..3].
+struct DiagArgs {
+  const float* logits_cf; const float* logits_orig; const int64_t* src; const int64_t* target; const float* masked;
+  int B, nc, D; float eps; float* out; double* acc;
+};
+__device__ __forceinline__ void house_diag_body(const DiagArgs& a) {          // one block of 1024 threads
+  __shared__ double dred[4][1024];
+  double s_gain = 0.0, s_chg = 0.0, s_l2 = 0.0, s_flip = 0.0;
+  for (int b = threadIdx.x; b < a.B; b += 1024) {
+    const int t = (int)a.target[b];
+    const float* lc = a.logits_cf + (size_t)b * a.nc;
+    const float* lo = a.logits_orig + (size_t)(a.src ? a.src[b] : (int64_t)b) * a.nc;
+    float mc = lc[0], mo = lo[0];
+    int arg = 0;
+    for (int q = 1; q < a.nc; ++q) {
+      if (lc[q] > mc) { mc = lc[q]; arg = q; }      // first maximum, as torch.argmax on the CPU
+      mo = fmaxf(mo, lo[q]);
+    }
+    float zc = 0.f, zo = 0.f;
+    for (int q = 0; q < a.nc; ++q) { zc += expf(lc[q] - mc); zo += expf(lo[q] - mo); }
+    s_gain += (double)(expf(lc[t] - mc) / zc - expf(lo[t] - mo) / zo);
+    s_flip += arg == t ? 1.0 : 0.0;
+    const float* m = a.masked + (size_t)b * a.D;
+    float sq = 0.f;
+    int chg = 0;
+    for (int f = 0; f < a.D; ++f) { sq = fmaf(m[f], m[f], sq); chg += fabsf(m[f]) > a.eps; }
+    s_l2 += (double)sqrtf(sq);
+    s_chg += (double)chg;
+  }
+  dred[0][threadIdx.x] = s_gain; dred[1][threadIdx.x] = s_chg; dred[2][threadIdx.x] = s_l2; dred[3][threadIdx.x] = s_flip;
+  __syncthreads();
+  for (int k = 512; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k)
+      for (int v = 0; v < 4; ++v) dred[v][threadIdx.x] += dred[v][threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double inv_b = 1.0 / (double)a.B;
+    a.out[0] = (float)(dred[0][0] * inv_b);
+    a.out[1] = (float)(1.0 - dred[1][0] * inv_b / (double)a.D);
+    a.out[2] = (float)(dred[2][0] * inv_b);
+    a.out[3] = (float)(dred[3][0] * inv_b);
+    if (a.acc)
+      for (int v = 0; v < 4; ++v) a.acc[2 + v] += (double)a.out[v];
+  }
+}
+__global__ void __launch_bounds__(1024) house_diag_kernel(DiagArgs a) { house_diag_body(a); }
 
 __global__ void __launch_bounds__(1024) house_losses_kernel(LossArgs a) { house_losses_body(a); }
 // Riders: two launches of the tabular step that do not depend on each other as ONE launch whose blocks split between the two bodies
@@ -720,6 +781,13 @@ __global__ void __launch_bounds__(1024) house_losses_kernel(LossArgs a) { house_
 __global__ void __launch_bounds__(1024) house_residual_bwd_losses_kernel(ResBwdArgs r, LossArgs l) {
   if (blockIdx.x == 0) house_losses_body(l);
   else house_residual_bwd_body(r, blockIdx.x - 1, gridDim.x - 1, 1024);
+}
+// the same with a second rider block: the trainer's per-iteration diagnostics (they read the classifier's logits, the masked
+// residual and the targets — nothing this launch writes)
+__global__ void __launch_bounds__(1024) house_residual_bwd_losses_diag_kernel(ResBwdArgs r, LossArgs l, DiagArgs d) {
+  if (blockIdx.x == 0) house_losses_body(l);
+  else if (blockIdx.x == 1) house_diag_body(d);
+  else house_residual_bwd_body(r, blockIdx.x - 2, gridDim.x - 2, 1024);
 }
 __global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ gout, float scale, size_t n, float* __restrict__ dx) {
   const float g = (gout ? gout[0] : 1.f) * scale / (float)n;
@@ -1067,7 +1135,7 @@ extern "C" int pcg_house_losses(const float* d_real, const float* d_fake, const 
                                 float* out5, pcg_stream_t stream) {
   PCG_REQUIRE(d_real && d_fake && d_fake_g && g_cls && am && pen && out5 && n > 0 && n <= 16 * 1024,
               "pcg_house_losses: bad arguments (critic outputs of at most 16384 rows)");
-  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5, nullptr, 0};
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out5, nullptr, 0, nullptr};
   hipLaunchKernelGGL(house_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, la);
   return launch_status("house_losses_kernel");
 }
@@ -1176,9 +1244,52 @@ extern "C" int pcg_house_residual_bwd_losses(const float* res, const float* mask
   if (int e = fill_res_bwd_args(a, res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples)) return e;
   PCG_REQUIRE(d_real && d_fake && d_fake_g && (g_cls || ce_row_loss) && am && pen && out6 && n > 0 && n <= 16 * 1024 && (!ce_row_loss || n_ce > 0),
               "pcg_house_residual_bwd_losses: bad arguments (critic outputs of at most 16384 rows)");
-  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out6, ce_row_loss, n_ce};
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out6, ce_row_loss, n_ce, nullptr};
   const size_t work = (size_t)B * (ncont + S);
   hipLaunchKernelGGL(house_residual_bwd_losses_kernel, dim3(1 + (unsigned)std::min<size_t>((work + 1023) / 1024, 4096)), dim3(1024), 0,
                      (hipStream_t)stream, a, la);
   return launch_status("house_residual_bwd_losses_kernel");
+}
+
+namespace {
+int fill_diag_args(pcg::DiagArgs& d, const float* logits_cf, const float* logits_orig, const int64_t* src_rows, const int64_t* target_y,
+                   const float* masked, int32_t B, int32_t nc, int32_t D, float eps, float* out4, double* acc) {
+  PCG_REQUIRE(logits_cf && logits_orig && target_y && masked && out4 && B > 0 && nc > 1 && nc <= 64 && D > 0,
+              "pcg_house_diag: bad arguments (B %d, classes %d, features %d)", B, nc, D);
+  d = pcg::DiagArgs{logits_cf, logits_orig, src_rows, target_y, masked, B, nc, D, eps, out4, acc};
+  return PCG_OK;
+}
+}  // namespace
+
+extern "C" int pcg_house_diag(const float* logits_cf, const float* logits_orig, const int64_t* src_rows, const int64_t* target_y,
+                              const float* masked, int32_t B, int32_t nc, int32_t D, float eps, float* out4, double* acc,
+                              pcg_stream_t stream) {
+  DiagArgs d{};
+  if (int e = fill_diag_args(d, logits_cf, logits_orig, src_rows, target_y, masked, B, nc, D, eps, out4, acc)) return e;
+  hipLaunchKernelGGL(house_diag_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d);
+  return launch_status("house_diag_kernel");
+}
+
+// pcg_house_residual_bwd_losses with the diagnostics block riding along and the epoch accumulators (acc[8] doubles:
+// sum D_loss, sum G_loss, sum pred_gain, sum sparsity, sum l2, sum class_flip_rate, iterations, unused)
+extern "C" int pcg_house_residual_bwd_losses_diag(const float* res, const float* masked, const float* mask, const float* gx_a, const float* gx_b,
+                                                  float w_pen, float w_am, int32_t ncont, const int32_t* cont_idx_dev, const int32_t* seg_dev,
+                                                  int32_t S, int32_t T, const int32_t* cat_idx_dev, const float* norm, int32_t D, int32_t B,
+                                                  float* dcont, float* dsamples, const float* d_real, const float* d_fake, const float* d_fake_g,
+                                                  int32_t n, const float* g_cls, const float* am, const float* pen, float lambda_cls, float w_reg,
+                                                  float lambda_mask, float w_reg_log, const float* ce_row_loss, int32_t n_ce, float* out6,
+                                                  const float* logits_cf, const float* logits_orig, const int64_t* src_rows,
+                                                  const int64_t* target_y, int32_t nc, float eps, float* diag_out4, double* acc,
+                                                  pcg_stream_t stream) {
+  ResBwdArgs a{};
+  if (int e = fill_res_bwd_args(a, res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx_dev, seg_dev, S, T, cat_idx_dev, norm, D, B, dcont, dsamples)) return e;
+  PCG_REQUIRE(d_real && d_fake && d_fake_g && (g_cls || ce_row_loss) && am && pen && out6 && n > 0 && n <= 16 * 1024 && (!ce_row_loss || n_ce > 0),
+              "pcg_house_residual_bwd_losses_diag: bad arguments (critic outputs of at most 16384 rows)");
+  const LossArgs la{d_real, d_fake, d_fake_g, (size_t)n, 1.0 / (double)n, g_cls, am, pen, lambda_cls, w_reg, lambda_mask, w_reg_log, out6, ce_row_loss, n_ce, acc};
+  DiagArgs d{};
+  if (int e = fill_diag_args(d, logits_cf, logits_orig, src_rows, target_y, masked, B, nc, D, eps, diag_out4, acc)) return e;
+  const size_t work = (size_t)B * (ncont + S);
+  hipLaunchKernelGGL(house_residual_bwd_losses_diag_kernel, dim3(2 + (unsigned)std::min<size_t>((work + 1023) / 1024, 4096)), dim3(1024), 0,
+                     (hipStream_t)stream, a, la, d);
+  return launch_status("house_residual_bwd_losses_diag_kernel");
 }

@@ -8,7 +8,8 @@
     models/discriminator.py Discriminator :5-20             Discriminator (spectral-norm keys weight_orig / weight_u / weight_v)
     models/nn_classifier.py NNClassifier :4-32              NNClassifier (frozen / eval use: forward + grad-input)
     trainer.py  cat_norm_maps :205-223                      cat_norm_maps
-    trainer.py  train_countergan loop body :241-316         make_optimizers + train_step (+ train_countergan loop)
+    trainer.py  train_countergan loop body :241-316         make_optimizers + train_step
+    trainer.py  train_countergan :186-378                   train_countergan(generator, config, X_train, y_train, clf_model)
 
 Every network is one autograd node that sequences C-ABI calls (csrc/tabular.hip + the BatchNorm / activation / loss kernels)
 and accumulates parameter gradients straight into the FlatModule's flat gradient buffer.  The categorical heads are packed
@@ -858,7 +859,7 @@ def make_optimizers(generator, discriminator, config=CONFIG):
 
 
 def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config=CONFIG, gumbel=None,
-               ce=None, skip_dead_d_wgrad=True, branch=None, onehots=None):
+               ce=None, skip_dead_d_wgrad=True, branch=None, onehots=None, diag=None):
     """One iteration of train_countergan's loop body (trainer.py:241-316) for a batch already on the GPU.  The draws —
     `target_y` (:248-249), `mask` (:253-255) and the Gumbel noise inside G (gumbel=None: generator.rng) — are inputs.
     Returns device tensors; the reference's `.item()` calls are the caller's.
@@ -868,10 +869,15 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     the gradient with respect to x_cf; ~25 % of the chain) depends only on x_cf, so it is forked onto `branch` as soon as x_cf
     exists and runs beside the whole critic update; it joins where g_loss is formed.  autograd runs a node's backward on the
     stream its forward ran on, so the classifier's backward overlaps the critic's in the G step too.  Same kernels, same inputs:
-    results are bit-identical to the single-stream order; captured in a HIP graph the two streams become parallel branches."""
+    results are bit-identical to the single-stream order; captured in a HIP graph the two streams become parallel branches.
+
+    diag: {"logits_orig": the frozen classifier's logits of the original rows ([B, nc], or [N, nc] of the whole training set with
+    "src_rows" [B]), "acc": float64[8] epoch accumulators or None, "eps": 1e-3} — the trainer's per-iteration diagnostics
+    (trainer.py:318-343: pred_gain, sparsity, reg_loss_l2, class_flip_rate) as one fused device reduction, returned as out["diag"]
+    ([4] device tensor) and summed into `acc` together with D_loss / G_loss (read once per epoch, no .item() per iteration)."""
     if branch is not None:
         return _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel,
-                                  branch, skip_dead_d_wgrad, onehots)
+                                  branch, skip_dead_d_wgrad, onehots, diag)
     nc = config["num_classes"]
     ce = ce if ce is not None else CrossEntropyLoss()
     target_onehot = ops.onehot(target_y, nc)                                                  # :250
@@ -894,7 +900,8 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
     try:
         d_fake_for_g = discriminator(x_cf, target_onehot)                                     # :298
         m_fake = mean(d_fake_for_g)
-        g_cls = ce(classifier(x_cf), target_y)                                                # :301-302
+        clf_preds = classifier(x_cf)                                                          # :301
+        g_cls = ce(clf_preds, target_y)                                                       # :302
         am = abs_mean(masked_residual)                                                        # :305  mean_b ||.||_1 = D * mean|.|
         d_feat = float(x.shape[1])
         g_loss = weighted_sum([m_fake, g_cls, am, mask_penalty_pre],
@@ -909,8 +916,23 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_
             for p in discriminator.parameters():
                 p.requires_grad_(True)
     opt_g.step()                                                                              # :316
-    return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
-            "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+    out = {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
+           "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+    if diag is not None:                                                                      # :318-343
+        with torch.no_grad():
+            out["diag"] = ops.house_diag(clf_preds.detach().contiguous(), diag["logits_orig"], target_y, masked_residual.detach().contiguous(),
+                                         eps=diag.get("eps", 1e-3), src_rows=diag.get("src_rows"), acc=diag.get("acc"))
+            _acc_losses(diag.get("acc"), d_loss, g_loss)
+    return out
+
+
+def _acc_losses(acc, d_loss, g_loss):
+    """acc[0] += D_loss, acc[1] += G_loss, acc[6] += 1 (the schedule of train_step(branch=...) does this inside its scalars launch;
+    the reference-order step with three tiny device adds — setup / test path, not the benched one)."""
+    if acc is not None:
+        acc[0] += d_loss.detach().double()
+        acc[1] += g_loss.detach().double()
+        acc[6] += 1.0
 
 
 _cot_cache = {}
@@ -945,7 +967,7 @@ def _mean_cotangents(B, device):
 
 
 def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel, branch,
-                       skip_dead_d_wgrad, onehots=None):
+                       skip_dead_d_wgrad, onehots=None, diag=None):
     """train_step scheduled for the length of its dependency chain (the step is a chain of small kernels, 36 launches on one stream): what the
     reference's loop body computes, bit for bit (tests/test_hip_house.py: graph vs eager vs the reference-order autograd step), with
 
@@ -1091,7 +1113,9 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
                                     config["lambda_mask"], config["lambda_reg"] * d_feat, len(generator.continuous_idx), cont_idx,
                                     seg, generator.total_cat, cat_idx, norm_vals,
                                     losses=(d_real, d_fake, d_fake_for_g, g_cls, am, mask_penalty_pre, float(config["lambda_cls"]),
-                                            float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat) if ride else None)
+                                            float(config["lambda_reg"] * d_feat), float(config["lambda_mask"]), d_feat) if ride else None,
+                                    diag=(logits_c.contiguous(), diag["logits_orig"], diag.get("src_rows"), target_y, diag.get("eps", 1e-3),
+                                          diag.get("acc")) if (ride and diag is not None) else None)
         d_cont, d_samples = rb[:2]
         if ride:
             d_loss, g_loss, g_adv, g_reg = rb[2][0], rb[2][1], rb[2][2], rb[2][3]             # :292, :307-312
@@ -1102,8 +1126,17 @@ def _train_step_branch(generator, discriminator, classifier, opt_g, opt_d, x, y,
     main.wait_stream(branch)                                                                  # final join
     for t in (d_loss, g_loss, g_adv, g_reg, g_cls):
         t.record_stream(main)
-    return {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
-            "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+    out = {"D_loss": d_loss, "G_loss": g_loss, "g_adv": g_adv, "g_cls": g_cls, "reg": g_reg, "mask_pen": mask_penalty_pre,
+           "D_real": d_real, "D_fake_forG": d_fake_for_g, "x_cf": x_cf, "masked_residual": masked_residual}
+    if diag is not None:                                                                      # :318-343
+        if ride:
+            out["diag"] = rb[3]                      # rode in the residual block's backward launch, with the accumulators
+        else:
+            with torch.no_grad():
+                out["diag"] = ops.house_diag(logits_c.contiguous(), diag["logits_orig"], target_y, masked_residual, eps=diag.get("eps", 1e-3),
+                                             src_rows=diag.get("src_rows"), acc=diag.get("acc"))
+                _acc_losses(diag.get("acc"), d_loss, g_loss)
+    return out
 
 
 # ---- evaluation ------------------------------------------------------------------------------
@@ -1180,8 +1213,16 @@ class GraphedTrainStep:
     restored after, so constructing this object does not advance training."""
 
     def __init__(self, generator, discriminator, classifier, opt_g, opt_d, norm_vals, batch, config=CONFIG, warmup=3, overlap="inline",
-                 rng=None):
-        """rng (an ops.DeviceRNG): the per-iteration draws (draw_batch_randoms: target class, feature mask, Gumbel noise, one-hot rows) are
+                 rng=None, dataset=None, diag=None, with_critic_wgrad_variant=False):
+        """with_critic_wgrad_variant: also capture the step WITH the critic weight gradients of the generator step
+        (skip_dead_d_wgrad=False: what the reference's autograd computes, :314) as a second graph over the same static buffers —
+        `replay(full=True)`; the trainer runs it as the last iteration of an epoch, whose D.grad the epoch summary prints (:362).
+        dataset = (X [N, D] float32, Y [N] int64) resident on the device (needs rng): the draws launch also TAKES the batch — rows
+        perm[cursor .. cursor + batch) of the epoch's permutation (`new_epoch(perm)` uploads it and rewinds the cursor) — so a replay
+        needs no host-side copy (trainer.py:198's DataLoader(shuffle=True, drop_last=True) without collation / PCIe / copy launches).
+        diag = {"logits_orig": [N, nc] (dataset mode: gathered through the batch's source rows) or [batch, nc], "acc": float64[8] or
+        None, "eps": 1e-3}: the trainer's per-iteration diagnostics + epoch accumulators ride in the step (train_step(diag=...)).
+        rng (an ops.DeviceRNG): the per-iteration draws (draw_batch_randoms: target class, feature mask, Gumbel noise, one-hot rows) are
         the first launch of the captured step, their Philox offsets read from a device counter that the launch advances itself — write x
         and y into the static buffers (`load_batch`) and replay(); the numbers are those draw_batch_randoms(rng, ...) would have drawn
         before each eager step, and rng.offset is kept in step on the host."""
@@ -1214,21 +1255,45 @@ class GraphedTrainStep:
 
         self._rng = rng
         self._span = ops.DeviceRNG.house_draws_span(batch, D_in, T)
-        self._ctr = rng.device_counter(dev) if rng is not None else None
+        self._dataset = dataset
+        if dataset is not None and rng is None:
+            raise PcgError("GraphedTrainStep(dataset=...) needs rng: the batch is taken by the draws launch")
+        self._ctr = rng.device_counter(dev, cursor=dataset is not None) if rng is not None else None
+        self.src = self.perm = None
+        if dataset is not None:
+            X, Y = dataset
+            if X.dtype != torch.float32 or Y.dtype != torch.int64 or X.shape[1] != D_in or X.shape[0] != Y.shape[0] or X.shape[0] < batch:
+                raise PcgError(f"GraphedTrainStep(dataset=...): need X [N >= {batch}, {D_in}] float32 and Y [N] int64 on the device")
+            self.src = torch.zeros((batch,), dtype=torch.int64, device=dev)
+            self.perm = torch.arange((X.shape[0] // batch) * batch, dtype=torch.int64, device=dev)      # identity until new_epoch()
+            self._imm = torch.tensor(list(config.get("immutable_idx", [])), dtype=torch.int32, device=dev)
         ctr0 = self._ctr.clone() if rng is not None else None
+        sdiag = None
+        if diag is not None:
+            sdiag = dict(diag)
+            if dataset is not None and diag["logits_orig"].shape[0] != batch:
+                sdiag["src_rows"] = self.src
+        self._diag = sdiag
+        acc0 = sdiag["acc"].clone() if sdiag is not None and sdiag.get("acc") is not None else None
 
-        def step():
-            if rng is not None:
+        def step(skip_dead=True):
+            if dataset is not None:
+                rng.house_batch_draws(dataset[0], dataset[1], self.perm, nc, T, self._imm if self._imm.numel() else None,
+                                      (self.x, self.y, self.target_y, self.mask, self.noise), self.onehots, self._ctr, src_out=self.src)
+            elif rng is not None:
                 draw_batch_randoms(rng, generator, self.y, config, dev, out=(self.target_y, self.mask, self.noise),
                                    onehots=self.onehots if self.branch is not None else None, counter=self._ctr)
             return train_step(generator, discriminator, classifier, opt_g, opt_d, self.x, self.y, self.target_y, self.mask, norm_vals,
-                              config, gumbel=self.noise, branch=self.branch, onehots=self.onehots if self.branch is not None else None)
+                              config, gumbel=self.noise, branch=self.branch, onehots=self.onehots if self.branch is not None else None,
+                              diag=sdiag, skip_dead_d_wgrad=skip_dead)
         self._nc = nc
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
                 step()
+            if with_critic_wgrad_variant:
+                step(False)
         torch.cuda.current_stream().wait_stream(side)
         import gc
         gc.collect()                 # no finalizer may run while the stream captures (see nn._HipGraphCapture.begin)
@@ -1238,6 +1303,11 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = step()
+            self.graph_full = self.out_full = None
+            if with_critic_wgrad_variant:
+                self.graph_full = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_full):
+                    self.out_full = step(False)
         finally:
             if gc_on:
                 gc.enable()
@@ -1248,7 +1318,24 @@ class GraphedTrainStep:
         for o, sn in zip((opt_g, opt_d), osnap):
             o.restore(sn)
         if rng is not None:
-            self._ctr.copy_(ctr0)        # the warm-up steps drew from the counter: back to the stream's position
+            self._ctr.copy_(ctr0)        # the warm-up steps drew from the counter (and walked the cursor): back to the stream's position
+        if acc0 is not None:
+            sdiag["acc"].copy_(acc0)     # ... and added to the epoch accumulators
+
+    def new_epoch(self, perm):
+        """dataset mode: upload this epoch's row order (int64, at least steps * batch entries; only whole batches are used —
+        drop_last) and rewind the cursor.  Two small copies per EPOCH; the replays in between touch no host memory."""
+        if self._dataset is None:
+            raise PcgError("new_epoch: this GraphedTrainStep was not built with dataset=...")
+        n = self.perm.numel()
+        if perm.numel() < n:
+            raise PcgError(f"new_epoch: permutation of {perm.numel()} entries, {n} needed")
+        self.perm.copy_(perm[:n].to(torch.int64), non_blocking=False)
+        self._ctr[2:3].zero_()
+
+    @property
+    def steps_per_epoch(self):
+        return self.perm.numel() // self.x.shape[0] if self.perm is not None else None
 
     def load_batch(self, x, y):
         """With rng: the data half of a batch (the draws are made by the replay)."""
@@ -1258,11 +1345,17 @@ class GraphedTrainStep:
         self.x.copy_(x); self.y.copy_(y); self.target_y.copy_(target_y); self.mask.copy_(mask); self.noise.copy_(noise)
         ops.onehot(self.target_y, self._nc, out=self.onehots[0]); ops.onehot(self.y, self._nc, out=self.onehots[1])
 
-    def replay(self):
-        self.graph.replay()
+    def replay(self, full=False):
+        """full=True: the variant that also computes the generator step's critic weight gradients (with_critic_wgrad_variant)."""
+        if full:
+            if self.graph_full is None:
+                raise PcgError("replay(full=True): build the GraphedTrainStep with with_critic_wgrad_variant=True")
+            self.graph_full.replay()
+        else:
+            self.graph.replay()
         if self._rng is not None:
             self._rng.offset += self._span       # the host-side mirror of the device counter
-        return self.out
+        return self.out_full if full else self.out
 
 
 class WeightedCrossEntropyLoss(nn.Module):
@@ -1378,27 +1471,180 @@ def draw_batch_randoms(rng, generator, y, config, device, out=None, onehots=None
                            onehots=onehots, counter=counter)
 
 
-def train_countergan(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):
-    """trainer.py:181-366 without the plotting / checkpoint tail: same loop, per-epoch means of D and G loss."""
+def grad_norm_sum(net, out=None):
+    """trainer.py:182-183 — this trainer's `grad_norm`: the SUM over parameters of ||p.grad||_2 (not the root of the summed squares
+    of mnist/trainer.py:41-42).  One launch over the flat gradient buffer (pcg_norm_sum); `out` (a [1] device tensor): leave the
+    value there and return it unread (the trainer reads a whole history at once), else one host read."""
+    net._ensure_flat()
+    seg = getattr(net, "_norm_seg", None)
+    if seg is None or seg[0] != net.flat_grads.data_ptr():
+        table = torch.tensor([[off, n] for p, off, n in net._seg if p.requires_grad], dtype=torch.int64, device=net.flat_grads.device)
+        seg = net._norm_seg = (net.flat_grads.data_ptr(), table)
+    if any(p.grad is None for p, _, _ in net._seg if p.requires_grad):
+        raise PcgError("grad_norm_sum: a parameter has no gradient yet (call after a training step)")
+    res = ops.norm_sum(net.flat_grads, seg[1], out=out)
+    return res if out is not None else float(res.item())
+
+
+def epoch_permutation(n):
+    """The row order DataLoader(TensorDataset, shuffle=True) walks in one epoch, with its exact consumption of torch's global CPU
+    generator (trainer.py:198): the loader iterator draws its base seed, the RandomSampler a seed for a private generator, and
+    that generator the permutation (tests/test_host_logic.py pins this to torch.utils.data.DataLoader itself)."""
+    torch.empty((), dtype=torch.int64).random_()                                   # _BaseDataLoaderIter: base seed (unused here)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())                # RandomSampler.__iter__
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
+def train_countergan(generator, config, X_train, y_train, clf_model, *, rng=None, draws=None, graph=None, log_every=100, verbose=True,
+                     save=True, discriminator=None):
+    """house_sales_kc_usa/trainer.py:186-378 `train_countergan(generator, config, X_train, y_train, clf_model)` on the HIP kernels —
+    same signature, same body:
+
+      :187-189  device = config['cuda'] (default "cuda"); torch.manual_seed / np.random.seed(config.get('seed', 42))
+      :191-198  num_classes from y_train, batch size, DataLoader(shuffle=True, drop_last=True) — here the training set is uploaded
+                ONCE and stays in HBM; the epoch's row order is DataLoader's (epoch_permutation), batches are taken on the device
+      :200-223  cat_norm_maps from config['scaler'] (or the n-1 fallback)
+      :226-231  the Discriminator is built HERE, after the seeding (same torch draws as the reference's), Adam x2
+      :233-234  classifier to the device, eval()
+      :241-316  the iteration = train_step (draws: target class, feature mask, Gumbel noise from `rng`, an ops.DeviceRNG seeded with
+                the config seed by default; `draws(epoch, batch_idx, y) -> (target_y, mask, gumbel)` supplies them instead — parity runs)
+      :318-343  pred_gain, sparsity, L2 reg, class-flip rate: one fused device reduction riding in the step (pcg_house_diag); the
+                classifier's logits of the ORIGINAL rows are evaluated once for the whole training set (the classifier is frozen)
+      :345-355  the log line every 100 batches; D_loss / G_loss and the four diagnostics are summed on the device and read ONCE per
+                epoch (the reference: eight .item() calls per iteration)
+      :357-366  epoch summary with G_grad / D_grad (grad_norm_sum).  D's .grad there = the D step's gradients + the G step's critic
+                weight gradients (no zero_grad in between, :293 -> :314): the last iteration of an epoch therefore runs with
+                skip_dead_d_wgrad=False, all others skip that dead work
+      :369-378  torch.save(generator.state_dict(), config['generator_path']) (the loss-curve PNG is plotting: left out)
+
+    graph (default: when the batch size divides into full batches and no `draws` hook is given): every full-size iteration is ONE
+    HIP-graph replay (GraphedTrainStep(dataset=..., diag=...)) — the benched rate through the reference-shaped API.
+    Returns {"d_losses", "g_losses", "pred_gain", "sparsity", "l2_reg", "class_flip_rate", "G_grad", "D_grad", "discriminator"}
+    (per-epoch lists; the reference returns None)."""
+    device = torch.device(config.get("cuda", "cuda"))
+    if device.type != "cuda":
+        raise PcgError(f"train_countergan: config['cuda'] = {device}; libpcgan_hip has no CPU path")
+    seed = config.get("seed", 42)
+    torch.manual_seed(seed)                                                                    # :188
+    np.random.seed(seed)                                                                       # :189
+    y_np = np.asarray(y_train)
+    num_classes = int(np.unique(y_np).size)                                                    # :191
+    bs = int(config.get("batch_size", 128))                                                    # :192
+    X_t = torch.tensor(np.asarray(X_train), dtype=torch.float32)                               # :195
+    y_t = torch.tensor(y_np, dtype=torch.long)                                                 # :196
+    N = X_t.shape[0]
+    steps = N // bs                                                                            # drop_last (:198)
+    if steps < 1:
+        raise PcgError(f"train_countergan: {N} rows do not fill one batch of {bs} (drop_last=True leaves no iteration)")
+    X_dev, y_dev = X_t.to(device), y_t.to(device)                                              # the whole training set: resident
+    cfg = dict(config, num_classes=num_classes)
+    norm_vals = cat_norm_maps(generator, cfg, device)                                          # :200-223
+    G = generator.to(device)
+    D = discriminator if discriminator is not None else Discriminator(config["input_dim"], config["hidden_dim"], num_classes)   # :227
+    D = D.to(device)
+    opt_g, opt_d = make_optimizers(G, D, cfg)                                                  # :230-231
+    clf_model = clf_model.to(device)                                                           # :233
+    clf_model.eval()                                                                           # :234
+    frozen = not any(p.requires_grad for p in clf_model.parameters())
+    rng = rng if rng is not None else ops.DeviceRNG(seed=seed)
+    # the classifier on the original rows (:320): frozen, so ONE evaluation for the whole training set serves every iteration
+    with torch.no_grad():
+        logits_orig = torch.cat([clf_model(X_dev[i:i + 65536]).detach() for i in range(0, N, 65536)]).contiguous()
+    acc = torch.zeros(8, dtype=torch.float64, device=device)
+    diag = {"logits_orig": logits_orig, "acc": acc, "eps": 1e-3}
+    if graph is None:
+        graph = draws is None and frozen
+    gs = None
+    if graph:
+        if draws is not None:
+            raise PcgError("train_countergan(graph=True): supplied draws cannot be replayed from a captured step; use graph=False")
+        gs = GraphedTrainStep(G, D, clf_model, opt_g, opt_d, norm_vals, bs, cfg, rng=rng, dataset=(X_dev, y_dev), diag=diag,
+                              with_critic_wgrad_variant=True)
+    epochs = int(config["epochs"])
+    # per-epoch results stay on the device until someone needs them: verbose prints (and reads) every epoch like the reference,
+    # otherwise ONE read after the last epoch — the host never waits for the GPU inside the loop
+    acc_hist = torch.zeros((epochs, 8), dtype=torch.float64, device=device)
+    gn_hist = torch.zeros((epochs, 2), dtype=torch.float32, device=device)
+    names = ("d_losses", "g_losses", "pred_gain", "sparsity", "l2_reg", "class_flip_rate")
+    hist = {k: [] for k in names + ("G_grad", "D_grad")}
+
+    def read_epochs(lo, hi):
+        a, gn = acc_hist[lo:hi].cpu().numpy(), gn_hist[lo:hi].cpu().numpy()
+        for e in range(hi - lo):
+            n_it = max(float(a[e, 6]), 1.0)
+            for k, v in zip(names, a[e, :6] / n_it):
+                hist[k].append(float(v))
+            hist["G_grad"].append(float(gn[e, 0])); hist["D_grad"].append(float(gn[e, 1]))
+
+    sched = "inline" if (frozen and not clf_model.training) else None
+    for epoch in range(epochs):                                                                # :237
+        perm = epoch_permutation(N)[:steps * bs]                                               # :241 (the loader's order)
+        perm_dev = perm.to(device)
+        ops.fill(acc.view(torch.float32), 0.0)
+        if gs is not None:
+            gs.new_epoch(perm_dev)
+        for batch_idx in range(steps):
+            last = batch_idx == steps - 1          # keeps the G step's critic weight gradients: D_grad of the epoch summary (:362)
+            if gs is not None:
+                out = gs.replay(full=last)
+            else:
+                idx = perm_dev[batch_idx * bs:(batch_idx + 1) * bs]
+                x, y = X_dev.index_select(0, idx), y_dev.index_select(0, idx)                  # :242-243
+                if draws is not None:
+                    target_y, mask, noise = draws(epoch, batch_idx, y)                          # :248-255, generator.py:90
+                    target_y, mask = target_y.to(device), mask.to(device)
+                    noise = G.pack_noise(noise) if isinstance(noise, dict) else noise.to(device)
+                else:
+                    target_y, mask, noise = draw_batch_randoms(rng, G, y, cfg, device)
+                out = train_step(G, D, clf_model, opt_g, opt_d, x, y, target_y, mask, norm_vals, cfg, gumbel=noise, branch=sched,
+                                 diag=dict(diag, src_rows=idx), skip_dead_d_wgrad=not last)
+            if verbose and batch_idx % log_every == 0:                                         # :345-348
+                print(f"[Epoch {epoch + 1}/{epochs}] batch {batch_idx} :: "
+                      f"D(real)={torch.sigmoid(out['D_real']).mean().item():.3f}, D(fake)={torch.sigmoid(out['D_fake_forG']).mean().item():.3f}, "
+                      f"g_adv={out['g_adv'].item():.4f}, g_cls={out['g_cls'].item():.4f}, reg={out['reg'].item():.6f}, "
+                      f"mask_pen={out['mask_pen'].item():.5f}")
+        acc_hist[epoch].copy_(acc)                                                             # :349-355 (device to device, no sync)
+        grad_norm_sum(G, out=gn_hist[epoch, 0:1]); grad_norm_sum(D, out=gn_hist[epoch, 1:2])   # :362
+        if verbose:
+            read_epochs(epoch, epoch + 1)
+            print(f"[{epoch + 1}/{epochs}] D: {hist['d_losses'][-1]:.4f}, G: {hist['g_losses'][-1]:.4f}, "
+                  f"pred_gain={hist['pred_gain'][-1]:.4f}, sparsity={hist['sparsity'][-1]:.4f}, l2_reg={hist['l2_reg'][-1]:.4f}, "
+                  f"class_flip_rate={hist['class_flip_rate'][-1]:.4f} | G_grad: {hist['G_grad'][-1]:.4f}, D_grad: {hist['D_grad'][-1]:.4f}")
+    if not verbose:
+        read_epochs(0, epochs)
+    if save and config.get("generator_path"):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(config["generator_path"])) or ".", exist_ok=True)
+        torch.save({k: v.detach().cpu().contiguous() for k, v in generator.state_dict().items()}, config["generator_path"])   # :377
+        if verbose:
+            print(f"Saved generator model to {config['generator_path']}")
+    hist["discriminator"] = D
+    return hist
+
+
+def train_countergan_loop(generator, discriminator, classifier, loader, config, device, rng=None, log_every=50):
+    """The bare loop over a user-supplied iterable of (x, y) batches (r01 form; the reference-shaped entry point is train_countergan):
+    per-epoch means of D and G loss."""
     opt_g, opt_d = make_optimizers(generator, discriminator, config)
     norm_vals = cat_norm_maps(generator, config, device)
     rng = rng if rng is not None else ops.DeviceRNG(seed=0)
     classifier.eval()
     history = []
     for epoch in range(config["epochs"]):
-        d_sum = g_sum = 0.0
-        n = 0
+        pending = []
         for batch_idx, (x, y) in enumerate(loader):
             x, y = x.to(device), y.to(device)
             target_y, mask, noise = draw_batch_randoms(rng, generator, y, config, device)
             out = train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel=noise)
-            d_sum += out["D_loss"].item(); g_sum += out["G_loss"].item()
-            n += 1
+            pending.append((out["D_loss"], out["G_loss"]))
             if batch_idx % log_every == 0:
                 print(f"[Epoch {epoch + 1}/{config['epochs']}] batch {batch_idx}: D_loss={out['D_loss'].item():.4f}, "
                       f"G_loss={out['G_loss'].item():.4f}, g_adv={out['g_adv'].item():.4f}, g_cls={out['g_cls'].item():.4f}, "
                       f"reg={out['reg'].item():.4f}, mask_pen={out['mask_pen'].item():.6f}")
-        history.append((d_sum / max(n, 1), g_sum / max(n, 1)))
+        n = max(len(pending), 1)
+        history.append((sum(d.item() for d, _ in pending) / n, sum(g.item() for _, g in pending) / n))
     return history
 
 

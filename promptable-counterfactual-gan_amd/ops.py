@@ -501,6 +501,14 @@ def sumsq(t, out, accumulate=False):
 
 
 # ---- CounteRGAN pieces ---------------------------------------------------------------------------------------
+def norm_sum(flat, seg, out=None):
+    """out[0] = sum_s ||flat[seg[s,0] : seg[s,0] + seg[s,1]]||_2 (seg: int64 [n, 2] on the device) in one launch."""
+    _chk(flat, "flat"); _chk(seg, "seg", torch.int64)
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=flat.device)
+    check(_lib.load().pcg_norm_sum(_p(flat), _p(seg), seg.shape[0], _p(out), _stream()), "pcg_norm_sum")
+    return out
+
+
 def _chk_idx(idx, K, name="idx"):
     if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
         raise _lib.PcgError(f"{name}: expected a contiguous int64 tensor on the GPU")
@@ -739,12 +747,14 @@ def house_residual_fwd(cont, samples, seg_offsets, norm_vals, x, mask, col_src, 
     return res, masked, x_cf, scal[0], scal[1], outs
 
 
-def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals, losses=None):
+def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals, losses=None, diag=None):
     """(d_cont, d_samples): the tabular step's backward from dLoss/dx_cf = gx_a + gx_b and the two penalty weights down to the
     generator's outputs, in one launch (see pcg_house_residual_bwd).  losses = (d_real, d_fake, d_fake_g, g_cls, am, pen, lambda_cls,
     w_reg, lambda_mask, w_reg_log): pcg_house_losses rides in the same launch; its scalars (six floats: the five of pcg_house_losses
     and g_cls) are appended to the returned tuple.  g_cls: the cross-entropy value (a device scalar), or the [B] row terms the fused
-    classifier forward left (then their mean is formed here, in the cross-entropy kernel's order)."""
+    classifier forward left (then their mean is formed here, in the cross-entropy kernel's order).
+    diag (with losses) = (logits_cf, logits_orig, src_rows or None, target_y, eps, acc or None): the trainer's four per-iteration
+    diagnostics ride in the launch too (house_diag); their [4] tensor is appended after the scalars."""
     for t, nme in ((res, "res"), (masked, "masked"), (mask, "mask"), (gx_a, "gx_a"), (gx_b, "gx_b")):
         _chk(t, nme)
     B, D = res.shape
@@ -758,11 +768,48 @@ def house_residual_bwd(res, masked, mask, gx_a, gx_b, w_pen, w_am, ncont, cont_i
     d_real, d_fake, d_fake_g, g_cls, am, pen, l_cls, w_reg, l_mask, w_reg_log = losses
     out6 = torch.empty(6, dtype=torch.float32, device=res.device)
     rows = g_cls.numel() > 1
+    if diag is not None:
+        logits_cf, logits_orig, src_rows, target_y, eps, acc = diag
+        _chk(logits_cf, "logits_cf"); _chk(logits_orig, "logits_orig"); _chk(target_y, "target_y", torch.int64)
+        if src_rows is not None:
+            _chk(src_rows, "src_rows", torch.int64)
+        elif logits_orig.shape[0] < B:
+            raise _lib.PcgError("house_residual_bwd(diag=...): logits_orig has fewer rows than the batch and no src_rows were given")
+        if acc is not None:
+            _chk(acc, "acc", torch.float64)
+            assert acc.numel() >= 8
+        nc = logits_cf.shape[1]
+        assert logits_cf.shape[0] == B and logits_orig.shape[1] == nc and target_y.numel() == B
+        out4 = torch.empty(4, dtype=torch.float32, device=res.device)
+        check(_lib.load().pcg_house_residual_bwd_losses_diag(
+            *args, _p(d_real), _p(d_fake), _p(d_fake_g), d_real.numel(), None if rows else _p(g_cls), _p(am), _p(pen), float(l_cls),
+            float(w_reg), float(l_mask), float(w_reg_log), _p(g_cls) if rows else None, g_cls.numel() if rows else 0, _p(out6),
+            _p(logits_cf), _p(logits_orig), _p(src_rows), _p(target_y), nc, float(eps), _p(out4), _p(acc), _stream()),
+            "pcg_house_residual_bwd_losses_diag")
+        return dcont, dsamples, out6, out4
     check(_lib.load().pcg_house_residual_bwd_losses(*args, _p(d_real), _p(d_fake), _p(d_fake_g), d_real.numel(), None if rows else _p(g_cls),
                                                     _p(am), _p(pen), float(l_cls), float(w_reg), float(l_mask), float(w_reg_log),
                                                     _p(g_cls) if rows else None, g_cls.numel() if rows else 0, _p(out6), _stream()),
           "pcg_house_residual_bwd_losses")
     return dcont, dsamples, out6
+
+
+def house_diag(logits_cf, logits_orig, target_y, masked, eps=1e-3, src_rows=None, acc=None):
+    """[pred_gain, sparsity, reg_loss_l2, class_flip_rate] of house_sales_kc_usa/trainer.py:318-343 in one launch (pcg_house_diag).
+    logits_orig: the frozen classifier on the original rows ([B, nc], or [N, nc] for the whole training set with src_rows [B]);
+    acc: float64[8] epoch accumulators (acc[2..5] += the four values)."""
+    _chk(logits_cf, "logits_cf"); _chk(logits_orig, "logits_orig"); _chk(masked, "masked"); _chk(target_y, "target_y", torch.int64)
+    B, nc = logits_cf.shape
+    if src_rows is not None:
+        _chk(src_rows, "src_rows", torch.int64)
+    elif logits_orig.shape[0] < B:
+        raise _lib.PcgError("house_diag: logits_orig has fewer rows than the batch and no src_rows were given")
+    if acc is not None:
+        _chk(acc, "acc", torch.float64)
+    out = torch.empty(4, dtype=torch.float32, device=logits_cf.device)
+    check(_lib.load().pcg_house_diag(_p(logits_cf), _p(logits_orig), _p(src_rows), _p(target_y), _p(masked), B, nc, masked.shape[1], float(eps),
+                                     _p(out), _p(acc), _stream()), "pcg_house_diag")
+    return out
 
 
 def assemble_residual_bwd(dres, ncont, cont_idx, seg_offsets, T, cat_idx, norm_vals):
@@ -1064,14 +1111,31 @@ class DeviceRNG:
                                           _p(oh_t), _p(oh_y), _stream()), "pcg_house_draws")
         return o_t, o_m, o_n
 
+    def house_batch_draws(self, X, Y, perm, num_classes, T, zero_cols, out, onehots, counter, src_out=None):
+        """house_draws(counter=...) that also takes the batch: rows perm[cursor .. cursor+B) of the resident training set (X [N, D]
+        float32, Y [N] int64) are copied into out = (x, y, target_y, mask, noise), their source rows into src_out; the device counter
+        (device_counter(device, cursor=True): int64[4] = [Philox offset, ticket, row cursor, 0]) is advanced by the launch."""
+        o_x, o_y, o_t, o_m, o_n = out
+        B, D = o_x.shape
+        nz = 0 if zero_cols is None else zero_cols.numel()
+        oh_t, oh_y = onehots if onehots is not None else (None, None)
+        _chk(X, "X"); _chk(Y, "Y", torch.int64); _chk(perm, "perm", torch.int64)
+        if counter.numel() < 4 or X.shape[1] != D or Y.numel() != X.shape[0] or perm.numel() < B:
+            raise _lib.PcgError("house_batch_draws: counter must be int64[4] (device_counter(cursor=True)), X [N, D], Y [N], perm >= B entries")
+        check(_lib.load().pcg_house_batch_draws_counter(_p(o_t), B, num_classes, _p(X), _p(Y), _p(perm), perm.numel(), X.shape[0], _p(o_x), _p(o_y),
+                                                        _p(src_out), _p(o_m), D, _p(zero_cols), nz, _p(o_n), T, self.seed, _p(oh_t), _p(oh_y),
+                                                        _p(counter), _stream()), "pcg_house_batch_draws_counter")
+        return out
+
     @staticmethod
     def house_draws_span(B, D, T):
         """Counter values one house_draws call consumes."""
         return (B + 3) // 4 + (B * D + 3) // 4 + (B * T + 3) // 4
 
-    def device_counter(self, device):
-        """int64[2] on the device: [this stream's current offset, ticket] — the counter argument of house_draws."""
-        return torch.tensor([self.offset, 0], dtype=torch.int64, device=device)
+    def device_counter(self, device, cursor=False):
+        """int64[2] on the device: [this stream's current offset, ticket] — the counter argument of house_draws; cursor=True:
+        int64[4] = [offset, ticket, row cursor, 0] for house_batch_draws."""
+        return torch.tensor([self.offset, 0, 0, 0] if cursor else [self.offset, 0], dtype=torch.int64, device=device)
 
     def feature_mask(self, B, D, device, zero_cols=None, out=None):
         """Bernoulli(1/2) modifiable-feature mask with immutable columns zeroed (house_sales_kc_usa/trainer.py:253-255);

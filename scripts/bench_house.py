@@ -21,12 +21,56 @@ import _benchlib as BL  # noqa: E402
 import torch  # noqa: E402
 
 
+def through_trainer(args, R, H, ops, dev):
+    import time
+    import numpy as np
+    B, N = args.batch, 17290                                # the reference's training split (80 % of 21,613 rows)
+    rs = np.random.RandomState(0)
+    X, y = rs.random_sample((N, H.CONFIG["input_dim"])).astype(np.float32), rs.randint(0, H.CONFIG["num_classes"], N)
+    per_epoch = N // B
+    e_short = 8
+    e_long = e_short + max(1, -(-args.steps // per_epoch))
+
+    def run(epochs):
+        G, _, C = H.build(dev, seed=0)
+        cfg = dict(H.CONFIG, epochs=epochs, batch_size=B, cuda=str(dev), seed=42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hist = H.train_countergan(G, cfg, X, y, C, verbose=False, save=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, hist
+
+    run(2)                                                   # code objects, allocator
+    t_s, _ = run(e_short)
+    t_l, hist = run(e_long)
+    its = (e_long - e_short) * per_epoch
+    sec = (t_l - t_s) / its
+    if not all(np.isfinite(v) for k in ("d_losses", "g_losses", "pred_gain", "D_grad") for v in hist[k]):
+        sys.exit("non-finite history")
+    BL.emit({
+        "metric": "rows/sec (G+D step) tabular CounteRGAN house_sales_kc_usa; through house.train_countergan", "value": round(B / sec, 1),
+        "unit": "rows/sec", "n_gpus": 1, "steps": its, "warmup": e_short * per_epoch, "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"house.train_countergan(generator, config, X_train, y_train, clf_model): {N} rows, batch {B} ({per_epoch} iterations "
+                               f"per epoch, drop_last), diagnostics + epoch summaries + D_grad variant; marginal time per iteration "
+                               f"between {e_short} and {e_long} epochs", "global_batch": B, "parallelism": "dp1"},
+        "roofline": None, "cpu_baseline": None,
+        "epoch_tail": {k: hist[k][-1] for k in ("d_losses", "g_losses", "pred_gain", "sparsity", "l2_reg", "class_flip_rate", "G_grad", "D_grad")},
+        "seconds": {"short": round(t_s, 4), "long": round(t_l, 4)},
+    })
+    R.finish()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-overlap", action="store_true", help="A/B: the reference-order autograd step as a single-stream graph")
     ap.add_argument("--overlap", action="store_true", help="A/B: the frozen classifier's term on a parallel graph branch (two streams)")
     ap.add_argument("--inline", action="store_true", help="(default) the scheduled step's kernels on ONE stream")
+    ap.add_argument("--through-trainer", action="store_true",
+                    help="time the iterations THROUGH house.train_countergan(generator, config, X_train, y_train, clf_model) — the reference-shaped "
+                         "entry point (17,290 synthetic rows = the reference's training split, 4 iterations per epoch at batch 4096, diagnostics, "
+                         "epoch summaries, D_grad variant): marginal seconds per iteration between a short and a long run (setup cancels)")
     ap.add_argument("--eager-draws", action="store_true", help="A/B: the per-step draws as an eager launch in front of each replay (host-side Philox offsets)")
     BL.add_common_args(ap, steps=200, warmup=20)
     args = ap.parse_args()
@@ -35,6 +79,8 @@ def main():
     R = BL.Ranks(args, os.path.abspath(__file__))
     from pcgan_amd import house as H, ops
     dev = R.dev
+    if args.through_trainer:
+        return through_trainer(args, R, H, ops, dev)
     G, D, C = H.build(dev, seed=0)
     opt_g, opt_d = H.make_optimizers(G, D)
     norm = H.cat_norm_maps(G, H.CONFIG, dev)

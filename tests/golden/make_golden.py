@@ -371,6 +371,126 @@ def make_house(path, bs=64):
         os.chdir(cwd)
 
 
+def make_house_loop(path, bs=64, nbatches=3, epochs=2, extra_rows=17):
+    """conditional_counteRGAN/house_sales_kc_usa: the WHOLE of the reference's train_countergan (trainer.py:186-378) — seeding,
+    DataLoader(shuffle=True, drop_last=True) over nbatches*bs + extra_rows rows (the remainder is dropped every epoch), the
+    Discriminator built inside, cat_norm_maps from config['scaler'], `epochs` x `nbatches` iterations, the four per-iteration
+    diagnostics (:318-343), the epoch summaries with grad_norm (:357-366), torch.save of the generator (:377).  Recorded: per
+    iteration what the generator was called with (shuffled rows, target one-hots, feature mask) and the RNG state from which the
+    Gumbel noise is replayed; the lists the trainer averages at each epoch end (np.mean is wrapped for the run: full precision
+    instead of the printed four digits); grad_norm's return values; the log; the saved generator."""
+    import contextlib, importlib, io
+    mdir = os.path.join(REF, "conditional_counteRGAN/house_sales_kc_usa")
+    scratch = "/tmp/pcg_golden_house_loop"
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    try:
+        sys.path.insert(0, mdir)
+        for name in list(sys.modules):
+            if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+                sys.modules.pop(name)
+        cfg = importlib.import_module("config").config
+        gen_mod = importlib.import_module("models.generator")
+        dis_mod = importlib.import_module("models.discriminator")
+        clf_mod = importlib.import_module("models.nn_classifier")
+        trainer = importlib.import_module("trainer")
+
+        class Scaler:                      # the two attributes train_countergan reads of the fitted MinMaxScaler (:207-209)
+            pass
+        rs = np.random.RandomState(23)
+        n_rows = nbatches * bs + extra_rows
+        sc = Scaler()
+        sc.data_min_ = np.zeros(cfg["input_dim"])
+        sc.data_max_ = np.ones(cfg["input_dim"])
+        for f, info in cfg["categorical_info"].items():       # categorical columns span their raw values, like the real data
+            sc.data_min_[f], sc.data_max_[f] = float(min(info["raw_values"])), float(max(info["raw_values"]))
+        gpath = os.path.join(scratch, "gen_loop.pt")
+        cfg.update({"cuda": "cpu", "epochs": epochs, "batch_size": bs, "scaler": sc, "out_dir": scratch, "generator_path": gpath})
+        torch.manual_seed(0)
+        clf = clf_mod.NNClassifier(cfg["input_dim"], output_dim=cfg["num_classes"])
+        G = gen_mod.ResidualGenerator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"], continuous_idx=cfg["continuous_idx"],
+                                      categorical_info={k: {"n": v["n"], "raw_values": v["raw_values"]} for k, v in cfg["categorical_info"].items()},
+                                      tau=cfg["gumbel_tau"])
+        clf.eval()
+        for p_ in clf.parameters():
+            p_.requires_grad = False
+        out = {"meta.bs": np.int64(bs), "meta.epochs": np.int64(epochs), "meta.nbatches": np.int64(nbatches), "meta.seed": np.int64(cfg["seed"]),
+               "scaler.data_min": sc.data_min_.copy(), "scaler.data_max": sc.data_max_.copy()}
+        for f, info in cfg["categorical_info"].items():
+            out[f"raw_values.{f}"] = np.asarray(info["raw_values"], dtype=np.float64)
+        for k, v in G.state_dict().items():
+            out[f"init.G.{k}"] = v.numpy().copy()
+        for k, v in clf.state_dict().items():
+            out[f"init.C.{k}"] = tensor_digest(v.float())
+        X = rs.random_sample((n_rows, cfg["input_dim"])).astype(np.float32)
+        for f, info in cfg["categorical_info"].items():       # categorical columns hold scaled category values
+            raw = np.asarray(info["raw_values"], dtype=float)
+            X[:, f] = ((rs.choice(raw, n_rows) - sc.data_min_[f]) / (sc.data_max_[f] - sc.data_min_[f])).astype(np.float32)
+        y = np.arange(n_rows) % cfg["num_classes"]
+        rs.shuffle(y)
+        out["data.X"], out["data.y"] = X.copy(), y.astype(np.int64)
+        calls, means, norms = [], [], []
+
+        def pre_hook(mod, args, kwargs):
+            calls.append({"x": args[0].clone(), "t": args[1].clone(), "mask": kwargs["mask"].clone(), "rng": torch.get_rng_state()})
+            assert kwargs["hard"] is False and abs(kwargs["temperature"] - 0.5) < 1e-12
+        h = G.register_forward_pre_hook(pre_hook, with_kwargs=True)
+        real_mean, real_gn = np.mean, trainer.grad_norm
+
+        def rec_mean(a, *args, **kw):
+            if isinstance(a, list) and not args and not kw:
+                means.append(np.array(a, dtype=np.float64))
+            return real_mean(a, *args, **kw)
+
+        def rec_gn(params):
+            v = real_gn(params)
+            norms.append(v)
+            return v
+        buf = io.StringIO()
+        np.mean, trainer.grad_norm = rec_mean, rec_gn
+        try:
+            with contextlib.redirect_stdout(buf):
+                trainer.train_countergan(G, cfg, X, y, clf)
+        finally:
+            np.mean, trainer.grad_norm = real_mean, real_gn
+        h.remove()
+        assert len(calls) == epochs * nbatches and len(means) == 6 * epochs and len(norms) == 2 * epochs
+        torch.manual_seed(cfg["seed"])                        # :188 then :227
+        D0 = dis_mod.Discriminator(cfg["input_dim"], cfg["hidden_dim"], cfg["num_classes"])
+        for k, v in D0.state_dict().items():
+            out[f"init.D.{k}"] = v.numpy().copy()
+        T = sum(hd.out_features for hd in G.fc_cat_logits.values())
+        xs, ts, ms, gs, perms = [], [], [], [], []
+        for c in calls:
+            torch.set_rng_state(c["rng"])
+            gs.append(torch.cat([-torch.empty(bs, hd.out_features).exponential_().log() for hd in G.fc_cat_logits.values()], 1).numpy())
+            xb = c["x"].numpy()
+            rows = np.array([int(np.argmin(np.abs(X - r).sum(1))) for r in xb])
+            assert np.array_equal(X[rows], xb)
+            perms.append(rows); ts.append(c["t"].argmax(1).numpy()); ms.append(c["mask"].numpy())
+        assert gs[0].shape == (bs, T)
+        out["it.rows"] = np.stack(perms).reshape(epochs, nbatches, bs).astype(np.int64)
+        out["it.target_y"] = np.stack(ts).reshape(epochs, nbatches, bs).astype(np.int64)
+        out["it.mask"] = np.stack(ms).reshape(epochs, nbatches, bs, -1).astype(np.float32)
+        out["it.gumbel"] = np.stack(gs).reshape(epochs, nbatches, bs, T).astype(np.float32)
+        out["head_order"] = np.array([int(k) for k in G.fc_cat_logits.keys()], dtype=np.int64)
+        names = ("d_loss", "g_loss", "pred_gain", "sparsity", "l2_reg", "class_flip_rate")        # the order of the np.mean calls (:350-355)
+        for i, nme in enumerate(names):
+            out[f"it.{nme}"] = np.stack([means[6 * e + i] for e in range(epochs)])
+        out["epoch.G_grad"] = np.array(norms[0::2]); out["epoch.D_grad"] = np.array(norms[1::2])
+        out["log"] = np.array(buf.getvalue())
+        saved = torch.load(gpath, map_location="cpu", weights_only=True)
+        for k, v in saved.items():
+            out[f"saved.G.{k}"] = v.numpy().copy()
+            assert torch.equal(v, G.state_dict()[k])
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+        print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith("[1/") or l.startswith("[2/")))
+    finally:
+        os.chdir(cwd)
+
+
 def make_house_trained(path_npz, path_g, path_c, bs=32):
     """Real-weight anchor for the tabular path: the generator and classifier checkpoints the reference ships
     (house_sales_kc_usa/generator_model.pt, clf_model.pt) loaded into the reference's own modules, eval mode, with
@@ -802,6 +922,9 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
     only = sys.argv[1:]
+    if only == ["house_loop"]:
+        make_house_loop(os.path.join(HERE, "house_loop.npz"))
+        sys.exit(0)
     if only == ["dcgan_loop"]:          # regenerate one fixture without touching the others
         make_dcgan_loop(os.path.join(HERE, "dcgan_loop_small.npz"))
         sys.exit(0)
@@ -815,6 +938,7 @@ if __name__ == "__main__":
                        os.path.join(HERE, "house_classifier_trained.pt"))
     make_wgan_small(os.path.join(HERE, "wgan_ref_small.npz"))
     make_house_eval(os.path.join(HERE, "house_eval.npz"))
+    make_house_loop(os.path.join(HERE, "house_loop.npz"))
     make_countergan_eval(os.path.join(HERE, "countergan_eval.npz"))
     make_classifier_pretrain(os.path.join(HERE, "classifier_pretrain_mnist.npz"), os.path.join(HERE, "classifier_pretrain_house.npz"))
     make_mnist_resize(os.path.join(HERE, "mnist_resize.npz"))

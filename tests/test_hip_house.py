@@ -629,14 +629,177 @@ def test_device_draws(pcg):
     xs = torch.rand(4 * 128, 17)
     ys = torch.randint(0, 4, (4 * 128,))
     loader = [(xs[i * 128:(i + 1) * 128], ys[i * 128:(i + 1) * 128]) for i in range(4)]
-    hist = H.train_countergan(G, D, C, loader, cfg, torch.device(DEV), rng=ops.DeviceRNG(1), log_every=10 ** 9)
+    hist = H.train_countergan_loop(G, D, C, loader, cfg, torch.device(DEV), rng=ops.DeviceRNG(1), log_every=10 ** 9)
     assert len(hist) == 2 and all(np.isfinite(v) for e in hist for v in e)
 
 
-# ---- evaluation path ------------------------------------------------------------------------------
+# ---- the reference-shaped trainer: train_countergan(generator, config, X_train, y_train, clf_model) -------------------------------
 class _Scaler:
     def __init__(self, lo, hi):
         self.data_min_, self.data_max_ = lo, hi
+
+
+def _loop_setup(pcg, golden_dir, tmp_path, **over):
+    H = pcg.house
+    g = dict(np.load(os.path.join(golden_dir, "house_loop.npz")))
+    cfg = dict(H.CONFIG)
+    cfg["categorical_info"] = {f: {"n": len(g[f"raw_values.{f}"]), "raw_values": g[f"raw_values.{f}"].tolist()} for f in H.CONFIG["categorical_info"]}
+    cfg.update({"scaler": _Scaler(g["scaler.data_min"], g["scaler.data_max"]), "epochs": int(g["meta.epochs"]), "batch_size": int(g["meta.bs"]),
+                "seed": int(g["meta.seed"]), "cuda": DEV, "generator_path": str(tmp_path / "sub" / "generator_model.pt")})
+    cfg.update(over)
+    torch.manual_seed(0)                                     # make_golden.py: classifier, then generator, seed 0
+    C = H.NNClassifier(17, 4)
+    G = H.ResidualGenerator(17, 32, 4, cfg["continuous_idx"], cfg["categorical_info"], tau=0.5)
+    for k, v in C.state_dict().items():
+        np.testing.assert_array_equal(_digest(v.float()), g[f"init.C.{k}"], err_msg=f"C.{k}")
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("init.G.")})
+    C.eval()
+    for p in C.parameters():
+        p.requires_grad = False
+    return H, g, cfg, G, C
+
+
+def _digest(t, nsamples=64):
+    f = t.detach().reshape(-1).double()
+    idx = torch.linspace(0, f.numel() - 1, min(nsamples, f.numel())).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), (f * f).sum().item()], f[idx].numpy()])
+
+
+def test_train_countergan_is_the_reference_trainer(pcg, golden_dir, tmp_path, monkeypatch, capsys):
+    """house.train_countergan(generator, config, X_train, y_train, clf_model) against a run of the reference's own function
+    (tests/golden/house_loop.npz: 2 epochs x 3 batches of 64 out of 209 rows): seeding -> the critic built inside has the
+    reference's initial state and the first epoch's row order is the DataLoader's; cat_norm_maps from config['scaler']; per iteration
+    D_loss / G_loss and the four diagnostics (read from the device accumulators); epoch means; G_grad / D_grad (D's includes the
+    generator step's critic weight gradients); the saved generator; the log lines' format.  The draws the reference made are supplied."""
+    H, g, cfg, G, C = _loop_setup(pcg, golden_dir, tmp_path)
+    E, S, bs = int(g["meta.epochs"]), int(g["meta.nbatches"]), int(g["meta.bs"])
+    torch.manual_seed(cfg["seed"])
+    D0 = H.Discriminator(17, 32, 4)
+    for k, v in D0.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(g[f"init.D.{k}"])), f"critic init {k}"
+    real_perm = H.epoch_permutation
+    epoch_no = [0]
+
+    def perm_hook(n):
+        e = epoch_no[0]
+        epoch_no[0] += 1
+        want = torch.from_numpy(g["it.rows"][e].reshape(-1))
+        if e == 0:               # same seed, same draws before the loop: the first epoch's order must BE the DataLoader's
+            got = real_perm(n)[:S * bs]
+            assert torch.equal(got, want)
+        return want              # later epochs: the reference drew its CPU-device targets / masks from the same generator in between
+    monkeypatch.setattr(H, "epoch_permutation", perm_hook)
+    per_it = []
+
+    def draws(epoch, batch_idx, y):
+        assert torch.equal(y.cpu(), torch.from_numpy(g["data.y"][g["it.rows"][epoch, batch_idx]]))
+        return (torch.from_numpy(g["it.target_y"][epoch, batch_idx]), torch.from_numpy(g["it.mask"][epoch, batch_idx]),
+                torch.from_numpy(g["it.gumbel"][epoch, batch_idx]))
+    # per-iteration values: wrap train_step to read the device scalars (test only; the trainer itself reads once per epoch)
+    real_step = H.train_step
+
+    def step_hook(*a, **k):
+        out = real_step(*a, **k)
+        per_it.append([out["D_loss"].item(), out["G_loss"].item()] + out["diag"].cpu().tolist())
+        return out
+    monkeypatch.setattr(H, "train_step", step_hook)
+    hist = H.train_countergan(G, cfg, g["data.X"], g["data.y"], C, draws=draws)
+    per_it = np.array(per_it).reshape(E, S, 6)
+    names = ("d_loss", "g_loss", "pred_gain", "sparsity", "l2_reg", "class_flip_rate")
+    # fp32, six Adam steps deep: the oracle restatement meets the same bounds on the CPU (tests/test_oracle_golden.py)
+    tol = {"d_loss": 5e-5, "g_loss": 5e-4, "pred_gain": 2e-6, "sparsity": 4e-3, "l2_reg": 5e-4, "class_flip_rate": 0.035}
+    for i, k in enumerate(names):
+        np.testing.assert_allclose(per_it[:, :, i], g[f"it.{k}"], rtol=0, atol=tol[k], err_msg=k)
+    for k_h, k_g in (("d_losses", "d_loss"), ("g_losses", "g_loss"), ("pred_gain", "pred_gain"), ("sparsity", "sparsity"),
+                     ("l2_reg", "l2_reg"), ("class_flip_rate", "class_flip_rate")):
+        np.testing.assert_allclose(hist[k_h], g[f"it.{k_g}"].mean(1), rtol=0, atol=tol[k_g], err_msg=f"epoch mean {k_h}")
+        np.testing.assert_allclose(hist[k_h], per_it[:, :, names.index(k_g)].mean(1), rtol=1e-6, atol=1e-9)     # device accumulators
+    np.testing.assert_allclose(hist["G_grad"], g["epoch.G_grad"], rtol=5e-3)
+    np.testing.assert_allclose(hist["D_grad"], g["epoch.D_grad"], rtol=5e-3)
+    saved = torch.load(cfg["generator_path"], map_location="cpu", weights_only=True)
+    assert list(saved) == [k[8:] for k in g if k.startswith("saved.G.")]
+    for k, v in saved.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(g[f"saved.G.{k}"]) == E * S
+            continue
+        assert np.abs(v.numpy() - g[f"saved.G.{k}"]).max() <= 6 * 2.2 * cfg["lr_G"], k
+        assert torch.equal(v, G.state_dict()[k].cpu())
+    # the log: same lines, same fields, numbers to the printed precision
+    skel = lambda s: re.sub(r"-?[0-9]+\.[0-9]+", "#", s)
+    ours = [l for l in capsys.readouterr().out.splitlines() if l.startswith("[")]
+    ref = [l for l in str(g["log"]).splitlines() if l.startswith("[")]
+    assert [skel(l) for l in ours] == [skel(l) for l in ref]
+    for lo, lr_ in zip(ours, ref):
+        a, b = [float(v) for v in re.findall(r"-?[0-9]+\.[0-9]+", lo)], [float(v) for v in re.findall(r"-?[0-9]+\.[0-9]+", lr_)]
+        np.testing.assert_allclose(a, b, rtol=6e-3, atol=2e-3, err_msg=lo)
+
+
+def test_train_countergan_graph_replays_equal_eager_iterations(pcg, golden_dir, tmp_path):
+    """The same trainer with its own device draws, (a) every iteration one HIP-graph replay — batch taken, targets / mask / noise
+    drawn, step, diagnostics, accumulators, all inside the captured launches — and (b) eager iterations on index_select batches
+    with draw_batch_randoms: same Philox counters, same rows, same kernels => the histories and the trained generator are
+    BIT-identical, and so is a second graph run (determinism)."""
+    res = []
+    for graph in (True, False, True):
+        H, g, cfg, G, C = _loop_setup(pcg, golden_dir, tmp_path, epochs=3, batch_size=32)
+        hist = H.train_countergan(G, cfg, g["data.X"], g["data.y"], C, graph=graph, verbose=False, save=False)
+        D = hist.pop("discriminator")
+        res.append((hist, G.flat_params.clone(), D.flat_params.clone()))
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        assert torch.equal(other[1], res[0][1]) and torch.equal(other[2], res[0][2])
+    assert len(res[0][0]["d_losses"]) == 3 and all(np.isfinite(v) for k in res[0][0] for v in res[0][0][k])
+
+
+def test_house_batch_draws_take_the_batch(pcg):
+    """pcg_house_batch_draws_counter: rows perm[cursor : cursor + B) of the resident training set land in the static buffers
+    (bit-exact copies), the draws are those of pcg_house_draws_counter on the same y, the cursor and the Philox offset advance."""
+    H, ops = pcg.house, pcg.ops
+    dev = torch.device(DEV)
+    G = H.ResidualGenerator(17, 32, 4, H.CONFIG["continuous_idx"], H.CONFIG["categorical_info"]).to(DEV)
+    N, B, T = 1000, 96, G.total_cat
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.rand(N, 17, generator=g).to(DEV), torch.randint(0, 4, (N,), generator=g).to(DEV)
+    perm = torch.randperm(N, generator=g).to(DEV)
+    imm = torch.tensor(H.CONFIG["immutable_idx"], dtype=torch.int32, device=DEV)
+    rng_a, rng_b = ops.DeviceRNG(9), ops.DeviceRNG(9)
+    ctr = rng_a.device_counter(dev, cursor=True)
+    bufs = (torch.empty(B, 17, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV),
+            torch.empty(B, 17, device=DEV), torch.empty(B, T, device=DEV))
+    oh = (torch.empty(B, 4, device=DEV), torch.empty(B, 4, device=DEV))
+    src = torch.empty(B, dtype=torch.int64, device=DEV)
+    for it in range(3):
+        rng_a.house_batch_draws(X, Y, perm, 4, T, imm, bufs, oh, ctr, src_out=src)
+        rows = perm[it * B:(it + 1) * B]
+        assert torch.equal(src, rows) and torch.equal(bufs[0], X[rows]) and torch.equal(bufs[1], Y[rows])
+        t, m, nz = H.draw_batch_randoms(rng_b, G, Y[rows].contiguous(), H.CONFIG, dev)
+        assert torch.equal(bufs[2], t) and torch.equal(bufs[3], m) and torch.equal(bufs[4], nz)
+        assert torch.equal(oh[0], F.one_hot(t, 4).float()) and torch.equal(oh[1], F.one_hot(Y[rows], 4).float())
+        assert ctr.tolist() == [rng_b.offset, 0, (it + 1) * B, 0]
+
+
+def test_house_diag_against_torch(pcg):
+    """pcg_house_diag against the reference's expressions (trainer.py:318-343) in float64."""
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(4)
+    B, N = 777, 2000
+    lc, lo_all = torch.randn(B, 4, generator=g) * 3, torch.randn(N, 4, generator=g) * 3
+    src = torch.randint(0, N, (B,), generator=g)
+    t = torch.randint(0, 4, (B,), generator=g)
+    m = torch.randn(B, 17, generator=g) * (torch.rand(B, 17, generator=g) < 0.4) * 0.01
+    acc = torch.zeros(8, dtype=torch.float64, device=DEV)
+    out = ops.house_diag(_dev(lc), _dev(lo_all), _dev(t), _dev(m), src_rows=_dev(src), acc=acc)
+    out2 = ops.house_diag(_dev(lc), _dev(lo_all[src]), _dev(t), _dev(m), acc=acc)
+    assert torch.equal(out, out2)
+    ar = torch.arange(B)
+    pc, po = F.softmax(lc.double(), 1), F.softmax(lo_all[src].double(), 1)
+    want = [(pc[ar, t] - po[ar, t]).mean().item(), 1.0 - (m.abs() > 1e-3).double().mean().item(),
+            m.double().norm(dim=1).mean().item(), (lc.argmax(1) == t).double().mean().item()]
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(acc.cpu().numpy()[2:6], 2 * out.cpu().double().numpy(), rtol=1e-12)
+
+
+# ---- evaluation path (SURVEY.md section 8f item 2) ------------------------------------------------------------------------------
 
 
 def _eval_setup(pcg, golden_dir):

@@ -96,3 +96,21 @@ def test_adam_dense_span_detection():
     assert Adam._dense_span(w) == (flat.data_ptr(), 32)
     assert Adam._dense_span(flat[::2]) is None
     assert Adam._dense_span(flat[32:40]) == (flat.data_ptr() + 128, 8)
+
+
+def test_epoch_permutation_is_dataloaders_order():
+    """house.epoch_permutation must walk the rows exactly as DataLoader(TensorDataset, shuffle=True, drop_last=True) does after the
+    same torch.manual_seed (house_sales_kc_usa/trainer.py:188,198), epoch after epoch: the trainer keeps the data set on the device
+    and takes its batches there, so the row order is the one thing it has to reproduce of the loader."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from pcgan_amd import house as H
+    n, bs = 1000, 128
+    torch.manual_seed(42)
+    nn.Linear(4, 4)                                            # whatever consumes the generator before the loop (the critic's init)
+    dl = DataLoader(TensorDataset(torch.arange(n)), batch_size=bs, shuffle=True, drop_last=True)
+    want = [torch.cat([b[0] for b in dl]) for _ in range(3)]
+    torch.manual_seed(42)
+    nn.Linear(4, 4)
+    got = [H.epoch_permutation(n)[:(n // bs) * bs] for _ in range(3)]
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    assert all(len(set(p.tolist())) == (n // bs) * bs for p in got)

@@ -232,6 +232,39 @@ def test_house_step_matches_reference_train_loop(hgold):
         np.testing.assert_allclose(v.numpy(), hgold[f"final.G.{k}"], rtol=1e-4, atol=2e-5, err_msg=f"final {k}")
 
 
+def test_house_train_loop_matches_reference_trainer(golden_dir):
+    """The WHOLE of the reference's train_countergan (2 epochs x 3 batches of 64 out of 209 rows, scaler-derived category values,
+    the four diagnostics, epoch means, grad norms, the saved generator) against the oracle's restatement on the recorded draws."""
+    g = dict(np.load(os.path.join(golden_dir, "house_loop.npz")))
+    G, D, clf = HR.build(seed=0)
+    for k, v in clf.state_dict().items():
+        np.testing.assert_array_equal(_digest(v.float()), g[f"init.C.{k}"], err_msg=f"C.{k}")
+    G.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("init.G.")})
+    D.load_state_dict({k[7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("init.D.")})
+    assert [int(f) for f in g["head_order"]] == list(HR.CONFIG["categorical_info"])
+    norm = HR.cat_norm_maps_scaler(g["scaler.data_min"], g["scaler.data_max"], {f: g[f"raw_values.{f}"] for f in HR.CONFIG["categorical_info"]})
+    X, y = torch.from_numpy(g["data.X"]), torch.from_numpy(g["data.y"])
+    E, S = int(g["meta.epochs"]), int(g["meta.nbatches"])
+    rows = [[torch.from_numpy(g["it.rows"][e, i]) for i in range(S)] for e in range(E)]
+    # drop_last: every epoch uses 3 x 64 distinct rows of the 209
+    assert all(len(set(np.concatenate([r.numpy() for r in rows[e]]).tolist())) == S * 64 for e in range(E))
+    t = [[torch.from_numpy(g["it.target_y"][e, i]) for i in range(S)] for e in range(E)]
+    m = [[torch.from_numpy(g["it.mask"][e, i]) for i in range(S)] for e in range(E)]
+    gm = [[torch.from_numpy(g["it.gumbel"][e, i]) for i in range(S)] for e in range(E)]
+    it, gG, gD = HR.train_countergan(G, D, clf, X, y, rows, t, m, gm, norm)
+    tol = {"d_loss": 2e-5, "g_loss": 2e-4, "pred_gain": 1e-6, "sparsity": 2e-3, "l2_reg": 2e-4, "class_flip_rate": 0.02}
+    for k, a in tol.items():
+        np.testing.assert_allclose(np.array(it[k]), g[f"it.{k}"], rtol=0, atol=a, err_msg=k)
+    np.testing.assert_allclose(gG, g["epoch.G_grad"], rtol=2e-3)
+    np.testing.assert_allclose(gD, g["epoch.D_grad"], rtol=2e-3)
+    for k, v in G.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(g[f"saved.G.{k}"])
+            continue
+        # six Adam steps; biases in front of a BatchNorm carry sign noise (+-lr per step)
+        assert np.abs(v.numpy() - g[f"saved.G.{k}"]).max() <= 6 * 2.2 * HR.CONFIG["lr_G"], k
+
+
 def test_house_trained_checkpoints_eval_forward(golden_dir):
     """The generator / classifier checkpoints the reference ships, through the oracle restatement in eval mode with
     hard Gumbel-softmax, against the reference modules' own outputs (tests/golden/make_golden.py: make_house_trained)."""
