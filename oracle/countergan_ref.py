@@ -181,6 +181,30 @@ def countergan_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce,
             "d_real_p": torch.sigmoid(d_real_logits).mean().item(), "d_fake_p": torch.sigmoid(d_fake_logits).mean().item()}
 
 
+def grad_norm(parameters):
+    """trainer.py:41-42."""
+    return torch.sqrt(sum((p.grad.data.norm() ** 2) for p in parameters if p.grad is not None)).item()
+
+
+def train_countergan(generator, discriminator, classifier, batches, target_y, mask, epochs, cfg=Config):
+    """trainer.py:76-147 with the draws supplied (target_y[e][i], mask[e][i]): per-epoch means of g_loss / d_loss / g_cls
+    (:139-141) and grad_norm of both nets at the epoch's end (:142-143).  Returns (history, G_grad list, D_grad list, per-epoch
+    first-batch log scalars)."""
+    opt_g, opt_d, bce, ce = make_optimizers(generator, discriminator, cfg)
+    hist, gG, gD, first = [], [], [], []
+    for e in range(epochs):
+        g_epoch = d_epoch = cls_epoch = 0.0
+        for i, (x, y) in enumerate(batches):
+            out = countergan_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y[e][i], mask[e][i], cfg)
+            g_epoch += out["g_loss"]; d_epoch += out["d_loss"]; cls_epoch += out["g_cls"]
+            if i == 0:
+                first.append(out)
+        n = len(batches)
+        hist.append((g_epoch / n, d_epoch / n, cls_epoch / n))
+        gG.append(grad_norm(generator.parameters())); gD.append(grad_norm(discriminator.parameters()))
+    return hist, gG, gD, first
+
+
 def synthetic_batch(batch, seed, cfg=Config, dtype=torch.float32):
     """x ~ U[-1,1) [B,1,28,28]; y, target_y ~ U{0..9}; mask = 10 of 16 7x7 patches per sample."""
     g = torch.Generator().manual_seed(seed)

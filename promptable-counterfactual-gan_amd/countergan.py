@@ -781,30 +781,72 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
             "d_real_logits": d_real_logits, "d_fake_logits": d_fake_logits, "x_cf": x_cf}
 
 
-def train_countergan(generator, discriminator, classifier, train_loader, cfg, device, log_every=100, device_rng=None):
-    """trainer.py:76-147 without the plotting / checkpoint tail: same loop, same per-epoch means.
-    device_rng: an ops.DeviceRNG — draw targets and masks on the GPU instead of torch's RNG."""
-    opt_g, opt_d, bce, ce = make_optimizers(generator, discriminator, cfg)
-    history = []
-    for epoch in range(cfg.num_epochs_gan):
-        g_epoch = d_epoch = cls_epoch = 0.0
-        n = 0
-        for batch_idx, (x, y) in enumerate(train_loader):
-            x, y = x.to(device), y.to(device)
+def _lookahead(it):
+    """(item, is_last) over any iterable — the loader is `any iterable of (x, y)`, it need not have a length."""
+    it = iter(it)
+    try:
+        prev = next(it)
+    except StopIteration:
+        return
+    for cur in it:
+        yield prev, False
+        prev = cur
+    yield prev, True
+
+
+def train_countergan(generator, discriminator, classifier, train_loader, cfg, device, log_every=100, device_rng=None, draws=None,
+                     save=True, verbose=True):
+    """conditional_counteRGAN/mnist/trainer.py:76-163 `train_countergan(generator, discriminator, classifier, train_loader, cfg,
+    device)`: the same loop, the same per-epoch means (:139-141), the per-epoch `G_grad` / `D_grad` line (:142-147 — the one place
+    grad_norm :41-42 is used), `residual_mean` in the batch log line (:137) and the generator checkpoint (:162); the loss-curve PNG
+    (:149-160) is plotting and is left out.
+
+    D's .grad at the epoch summary = the D step's gradients + the generator step's critic weight gradients (no zeroing between :111
+    and :122): the LAST iteration of an epoch runs with skip_dead_d_wgrad=False, every other one skips that dead work.
+    Host reads: the reference calls .item() five times per iteration; here the per-iteration scalars stay on the device and are
+    read once per epoch (and at the log lines), summed in the same order.
+    device_rng: an ops.DeviceRNG — draw targets and masks on the GPU (SURVEY.md §8f item 1) instead of torch's RNG;
+    draws(epoch, batch_idx, x) -> (target_y, mask): supplied draws (parity runs).  Returns the per-epoch history:
+    {"g_losses", "d_losses", "g_cls_losses", "G_grad", "D_grad"}."""
+    opt_g, opt_d, bce, ce = make_optimizers(generator, discriminator, cfg)                     # :77-80
+    hist = {k: [] for k in ("g_losses", "d_losses", "g_cls_losses", "G_grad", "D_grad")}
+    for epoch in range(cfg.num_epochs_gan):                                                    # :84
+        pending = []
+        for batch_idx, ((x, y), last) in enumerate(_lookahead(train_loader)):                  # :89
+            x, y = x.to(device), y.to(device)                                                  # :90
             bs = x.size(0)
-            if device_rng is not None:
+            if draws is not None:
+                target_y, mask = (t.to(device) for t in draws(epoch, batch_idx, x))
+            elif device_rng is not None:
                 target_y = device_rng.randint(0, cfg.num_classes, bs, x.device)                # :94
                 mask = build_mask_device(device_rng, x, cfg.patch_size, cfg.num_modifiable_patches)   # :95
             else:
                 target_y = torch.randint(0, cfg.num_classes, (bs,), device=device)             # :94
                 mask = build_mask(x, cfg.patch_size, device, cfg.num_modifiable_patches)       # :95
-            out = train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg)
-            g_epoch += out["g_loss"].item(); d_epoch += out["d_loss"].item(); cls_epoch += out["g_cls"].item()
-            n += 1
-            if batch_idx % log_every == 0:
+            out = train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg,
+                             skip_dead_d_wgrad=not last)                                        # :96-123
+            pending.append((out["g_loss"], out["d_loss"], out["g_cls"]))                        # :130-132, read at the epoch's end
+            if verbose and batch_idx % log_every == 0:                                         # :134-137
+                reg = out["reg_l1"].item()
                 print(f"[Epoch {epoch + 1}/{cfg.num_epochs_gan}] batch {batch_idx} :: "
                       f"D(real)={torch.sigmoid(out['d_real_logits']).mean().item():.3f}, "
                       f"D(fake)={torch.sigmoid(out['d_fake_logits']).mean().item():.3f}, g_adv={out['g_adv'].item():.4f}, "
-                      f"g_cls={out['g_cls'].item():.4f}, reg={out['reg_l1'].item():.6f}")
-        history.append((g_epoch / n, d_epoch / n, cls_epoch / n))
-    return history
+                      f"g_cls={out['g_cls'].item():.4f}, reg={reg:.6f}, residual_mean={reg:.4f}")   # masked_residual.abs().mean() IS reg_l1 (:119)
+        n = len(pending)
+        if n == 0:
+            raise PcgError("train_countergan: the loader yielded no batch")
+        g_epoch = d_epoch = cls_epoch = 0.0                                                    # same order of additions as :130-132
+        for g_l, d_l, c_l in pending:
+            g_epoch += g_l.item(); d_epoch += d_l.item(); cls_epoch += c_l.item()
+        hist["g_losses"].append(g_epoch / n); hist["d_losses"].append(d_epoch / n); hist["g_cls_losses"].append(cls_epoch / n)   # :139-141
+        hist["G_grad"].append(grad_norm(generator)); hist["D_grad"].append(grad_norm(discriminator))                           # :142-143
+        if verbose:
+            print(f"[GAN] Epoch {epoch + 1}/{cfg.num_epochs_gan} | G: {hist['g_losses'][-1]:.4f}, D: {hist['d_losses'][-1]:.4f}, "
+                  f"G_cls: {hist['g_cls_losses'][-1]:.4f}, G_grad: {hist['G_grad'][-1]:.4f}, D_grad: {hist['D_grad'][-1]:.4f}")   # :145-147
+    if save and getattr(cfg, "generator_path", None):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(cfg.generator_path)) or ".", exist_ok=True)
+        torch.save({k: v.detach().cpu().contiguous() for k, v in generator.state_dict().items()}, cfg.generator_path)         # :162
+        if verbose:
+            print(f"Generator saved to {cfg.generator_path}")
+    return hist

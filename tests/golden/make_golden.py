@@ -223,6 +223,76 @@ def make_countergan(path, batch=4, seed=0):
     print(buf.getvalue().strip().splitlines()[0])
 
 
+def make_countergan_loop(path, batch=4, nbatches=3, epochs=2, seed=0):
+    """CounteRGAN/mnist: the reference's whole train_countergan (trainer.py:76-163) over `epochs` x `nbatches` batches — per-epoch
+    means, the per-epoch G_grad / D_grad print (:142-147, the one place grad_norm :41-42 is used; D's .grad there = its D-step
+    gradients + the generator step's critic weight gradients, no zeroing between :111 and :122), residual_mean in the batch log
+    line (:137), the generator checkpoint (:162).  Nets seeded as in make_countergan; recorded: the batches, the draws each
+    iteration made (captured at the generator's input), grad_norm's return values, the log, digests of the saved generator."""
+    mdir = os.path.join(REF, "conditional_counteRGAN/mnist")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, mdir)
+    import contextlib, importlib, io
+    for name in list(sys.modules):
+        if name in ("config", "trainer", "data_utils") or name == "models" or name.startswith("models."):
+            sys.modules.pop(name)
+    cfgmod = importlib.import_module("config")
+    gen_mod = importlib.import_module("models.generator")
+    dis_mod = importlib.import_module("models.discriminator")
+    cls_mod = importlib.import_module("models.classifier")
+    trainer = importlib.import_module("trainer")
+    cfg = cfgmod.Config()
+    torch.manual_seed(seed)
+    classifier = cls_mod.CNNClassifier(num_classes=cfg.num_classes)
+    generator = gen_mod.ResidualGenerator(img_shape=cfg.img_shape, num_classes=cfg.num_classes)
+    discriminator = dis_mod.Discriminator(img_shape=cfg.img_shape, num_classes=cfg.num_classes)
+    classifier.eval()
+    for p_ in classifier.parameters():
+        p_.requires_grad = False
+    out = {"meta.batch": np.int64(batch), "meta.seed": np.int64(seed), "meta.epochs": np.int64(epochs), "meta.nbatches": np.int64(nbatches)}
+    for tag, net in (("G", generator), ("D", discriminator), ("C", classifier)):
+        for k, v in net.state_dict().items():
+            out[f"init.{tag}.{k}"] = tensor_digest(v.float())
+    g = torch.Generator().manual_seed(321)
+    loader = [(torch.rand(batch, 1, 28, 28, generator=g) * 2 - 1, torch.randint(0, 10, (batch,), generator=g)) for _ in range(nbatches)]
+    out["data.x"] = torch.stack([b[0] for b in loader]).numpy()
+    out["data.y"] = torch.stack([b[1] for b in loader]).numpy()
+    cfg.num_epochs_gan = epochs
+    cfg.save_dir = "/tmp/pcg_golden_out_loop"
+    cfg.generator_path = os.path.join(cfg.save_dir, "generator.pt")
+    os.makedirs(cfg.save_dir, exist_ok=True)
+    calls, norms = [], []
+    h = generator.register_forward_pre_hook(lambda mod, args: calls.append((args[1].clone(), args[2].clone())))
+    real_gn = trainer.grad_norm
+
+    def rec_gn(params):
+        v = real_gn(params)
+        norms.append(v)
+        return v
+    trainer.grad_norm = rec_gn
+    torch.manual_seed(555)
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            trainer.train_countergan(generator, discriminator, classifier, loader, cfg, "cpu")
+    finally:
+        trainer.grad_norm = real_gn
+        h.remove()
+    assert len(calls) == epochs * nbatches and len(norms) == 2 * epochs
+    out["it.target_y"] = torch.stack([c[0] for c in calls]).reshape(epochs, nbatches, batch).numpy()
+    out["it.mask"] = torch.stack([c[1] for c in calls]).reshape(epochs, nbatches, batch, 1, 28, 28).numpy()
+    out["epoch.G_grad"], out["epoch.D_grad"] = np.array(norms[0::2]), np.array(norms[1::2])
+    out["log"] = np.array(buf.getvalue())
+    saved = torch.load(cfg.generator_path, map_location="cpu", weights_only=True)
+    out["saved.keys"] = np.array(list(saved.keys()))
+    for k, v in saved.items():
+        out[f"saved.G.{k}"] = tensor_digest(v.float())
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+    print("\n".join(l for l in buf.getvalue().splitlines() if l.startswith("[GAN]")))
+
+
 def make_moons(path, n=100, seed=5):
     """simple_gan/moons/make_moons_gan.py: build_generator / build_discriminator / train_gan lifted from the syntax tree
     (the module trains and plots at import).  One epoch over `n` seeded 2-D points (2 batches of 50); train_gan draws its
@@ -922,6 +992,9 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit(f"{REF} not found — golden vectors can only be regenerated where the reference is mounted")
     only = sys.argv[1:]
+    if only == ["countergan_loop"]:
+        make_countergan_loop(os.path.join(HERE, "countergan_loop_b4.npz"))
+        sys.exit(0)
     if only == ["house_loop"]:
         make_house_loop(os.path.join(HERE, "house_loop.npz"))
         sys.exit(0)
@@ -931,6 +1004,7 @@ if __name__ == "__main__":
     make_dcgan_small(os.path.join(HERE, "dcgan_ref_small.npz"))
     make_dcgan_loop(os.path.join(HERE, "dcgan_loop_small.npz"))
     make_countergan(os.path.join(HERE, "countergan_ref_b4.npz"))
+    make_countergan_loop(os.path.join(HERE, "countergan_loop_b4.npz"))
     make_moons(os.path.join(HERE, "moons_ref.npz"))
     make_countergan_trained(os.path.join(HERE, "countergan_trained_eval.npz"), os.path.join(HERE, "countergan_generator_trained.pt"))
     make_house(os.path.join(HERE, "house_ref_b64.npz"))

@@ -48,6 +48,17 @@ LAYERS = [
     ("dcgan G1 as 1x1 GEMM", 512, 8192, 100, 1, 1, 1, 0),
     ("countergan resblock 3x3", 1024, 64, 64, 28, 3, 1, 1),
     ("countergan D 14->7", 1024, 64, 128, 14, 3, 2, 1),
+    # BASELINE config 3 (conditional WGAN-GP, width 1024, 256 images per GPU; mnist_wgan_conditional.py): the critic's three passes
+    # run as ONE batch of 3B = 768 rows (:87-95 Conv k3 s2 p0; :99 Linear 8192 -> 1024), the generator at B = 256 (:61-70 ConvT).
+    # Code paths only these shapes select: GEMM + col2im grad-input (kernel size not a multiple of the stride, Cout >= 512),
+    # split-K FORWARD (M = 3B*4 rows), the K-slice cost model, a ConvT on a 1x1 input as one plain GEMM, the thin Cin = 1 layer.
+    ("wgan critic conv1 1->256 @28 (thin)", 768, 1, 256, 28, 3, 2, 0),
+    ("wgan critic conv2 256->512 @13", 768, 256, 512, 13, 3, 2, 0),
+    ("wgan critic conv3 512->1024 @6", 768, 512, 1024, 6, 3, 2, 0),
+    ("wgan critic Linear 8192->1024", 768, 8192, 1024, 1, 1, 1, 0),
+    ("wgan G ConvT 1024->1024 k4 on 1x1 as GEMM", 256, 16 * 1024, 1024, 1, 1, 1, 0),
+    ("wgan G ConvT 1024->512 k3 s2 p1 4->7 (adjoint)", 256, 512, 1024, 7, 3, 2, 1),
+    ("wgan G ConvT 512->256 k4 s2 p1 7->14 (adjoint)", 256, 256, 512, 14, 4, 2, 1),
 ]
 
 

@@ -206,6 +206,50 @@ def test_grad_norm_diagnostic(pcg):
     np.testing.assert_allclose(K.grad_norm(G), ref, rtol=1e-5)
 
 
+def test_train_countergan_tail_matches_reference_trainer(pcg, golden_dir, tmp_path, capsys):
+    """countergan.train_countergan(generator, discriminator, classifier, train_loader, cfg, device) against a run of the reference's
+    own function (tests/golden/countergan_loop_b4.npz: 2 epochs x 3 batches): per-epoch means, G_grad / D_grad (D's = its D-step
+    gradients + the generator step's critic weight gradients: the epoch's last iteration keeps them), residual_mean in the batch
+    log line, every log line's format, the saved generator checkpoint."""
+    import re
+    K = pcg.countergan
+    g = dict(np.load(os.path.join(golden_dir, "countergan_loop_b4.npz")))
+    (G, D, C), _ = _build(pcg, seed=int(g["meta.seed"]))
+    for tag, net in (("G", G), ("D", D), ("C", C)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_array_equal(_digest(v.float()), g[f"init.{tag}.{k}"], err_msg=f"{tag}.{k}")
+    E, S = int(g["meta.epochs"]), int(g["meta.nbatches"])
+
+    class Cfg(K.Config):
+        num_epochs_gan = E
+        generator_path = str(tmp_path / "ckpt" / "generator.pt")
+    loader = ((torch.from_numpy(g["data.x"][i]), torch.from_numpy(g["data.y"][i])) for i in range(S))      # a bare generator: no len()
+
+    class Loader:                      # "any iterable of (x, y)": re-iterable, no __len__
+        def __iter__(self):
+            return iter([(torch.from_numpy(g["data.x"][i]), torch.from_numpy(g["data.y"][i])) for i in range(S)])
+    del loader
+    hist = K.train_countergan(G, D, C, Loader(), Cfg, DEV,
+                              draws=lambda e, i, x: (torch.from_numpy(g["it.target_y"][e, i]), torch.from_numpy(g["it.mask"][e, i])))
+    np.testing.assert_allclose(hist["G_grad"], g["epoch.G_grad"], rtol=2e-3)
+    np.testing.assert_allclose(hist["D_grad"], g["epoch.D_grad"], rtol=2e-3)
+    ours = [l for l in capsys.readouterr().out.splitlines() if l.startswith("[")]
+    ref = [l for l in str(g["log"]).splitlines() if l.startswith("[")]
+    skel = lambda s: re.sub(r"-?[0-9]+\.[0-9]+", "#", s)
+    assert [skel(l) for l in ours] == [skel(l) for l in ref]
+    for lo, lr_ in zip(ours, ref):
+        a, b = [float(v) for v in re.findall(r"-?[0-9]+\.[0-9]+", lo)], [float(v) for v in re.findall(r"-?[0-9]+\.[0-9]+", lr_)]
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=6e-4, err_msg=lo)
+    saved = torch.load(Cfg.generator_path, map_location="cpu", weights_only=True)
+    assert list(saved) == [str(k) for k in g["saved.keys"]]
+    for k, v in saved.items():
+        if re.fullmatch(r"resblocks\.\d+\.conv[12]\.bias", k):      # zero-gradient biases: Adam sign noise, bound the move
+            assert np.abs(_digest(v.float())[3:] - g[f"saved.G.{k}"][3:]).max() <= E * S * 2.2 * Cfg.g_lr, k
+            continue
+        np.testing.assert_allclose(_digest(v.float())[3:], g[f"saved.G.{k}"][3:], rtol=2e-4, atol=E * S * 2.2 * Cfg.g_lr * 0.2, err_msg=k)
+        assert torch.equal(v, G.state_dict()[k].cpu())
+
+
 def test_trained_checkpoint_eval_forward(pcg, golden_dir):
     """The generator checkpoint the reference ships (results/generator.pt) loads into the drop-in class unchanged and, in
     eval mode (BatchNorm running statistics, the inference path of eval_utils.py / the Gradio app), reproduces the

@@ -659,10 +659,10 @@ def _loop_setup(pcg, golden_dir, tmp_path, **over):
     return H, g, cfg, G, C
 
 
-def _digest(t, nsamples=64):
-    f = t.detach().reshape(-1).double()
-    idx = torch.linspace(0, f.numel() - 1, min(nsamples, f.numel())).long()
-    return np.concatenate([[f.sum().item(), f.abs().sum().item(), (f * f).sum().item()], f[idx].numpy()])
+def _digest(t, nsamples=64):          # make_golden.py: tensor_digest
+    a = np.asarray(t.detach().cpu().numpy(), dtype=np.float64).ravel()
+    idx = np.linspace(0, a.size - 1, num=min(nsamples, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.abs(a).sum(), (a * a).sum()], a[idx]])
 
 
 def test_train_countergan_is_the_reference_trainer(pcg, golden_dir, tmp_path, monkeypatch, capsys):

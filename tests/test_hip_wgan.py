@@ -36,7 +36,8 @@ def _close(a, b, rtol, atol, msg=""):
     np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
 
 
-@pytest.mark.parametrize("B,C,H,W", [(3, 4, 13, 13), (2, 8, 6, 6), (5, 16, 2, 2), (2, 256, 13, 13), (3, 1024, 2, 2), (2, 100, 3, 5)])
+@pytest.mark.parametrize("B,C,H,W", [(3, 4, 13, 13), (2, 8, 6, 6), (5, 16, 2, 2), (2, 256, 13, 13), (3, 1024, 2, 2), (2, 100, 3, 5),
+                                     (256, 1024, 2, 2), (256, 512, 6, 6), (64, 256, 13, 13)])     # the last three: config 3's bench shapes
 def test_instance_norm_forward_backward_and_backward_of_backward(pcg, B, C, H, W):
     """pcg_instnorm_{fwd,bwd,bwd_bwd} against torch autograd in float64: y; dx, dgamma, dbeta for a cotangent dy; and, with a
     second cotangent r on dx (create_graph=True), the three cotangents reaching dy, x and gamma."""
