@@ -727,6 +727,17 @@ int pcg_dp_broadcast(void* buf, int64_t nbytes, int32_t root, pcg_stream_t strea
 int pcg_dp_sync_batchnorm(int32_t enable);
 int pcg_dp_shutdown(void);
 
+/* ---- tuning switches (diagnostics): A/B of launch-planning choices inside ONE process, e.g. scripts/conv_microbench.py --ab.
+ *   "korder"            order of the k-tiles of the forward / grad-input kernels: 0 (tap, channel chunk), 1 L2-friendly (default)
+ *   "wgrad_order"       weight-gradient block order: 0 tile-major, 1 slice-major, -1 built-in rule
+ *   "dgrad_interleave"  sub-pixel phases of a grad-input tile neighbours in launch order: 0 / 1, -1 built-in rule
+ * value -1 restores the built-in choice.  Results stay correct under every setting (the order of a sum changes, not its terms). */
+int pcg_tune_set(const char* name, int32_t value);
+/* Diagnostic builds only (`make -C csrc stamp`, -DPCG_CLOCK_STAMP): every conv kernel block leaves {shader-clock ticks, 100 MHz
+ * ticks} of its main loop at buf[2*block], buf[2*block+1] (uint64) — the clock the chip holds inside the kernel.  Returns 1 when
+ * this build stamps, 0 for the shipped library (which compiles no stamp code).  buf = NULL turns it off.                        */
+int pcg_debug_stamp_buffer(void* buf, int64_t bytes);
+
 /* ---- calibration (diagnostics; not on the step's path) -----------------------------------------------------------------------
  * What THIS box's fp32 matrix pipe and HBM sustain right now — bench.py prints it next to the step (`calib`) so that a run on a
  * slower-clocked box can be told from a slower kernel (the reference has nothing comparable: it publishes no performance numbers,

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "pcg_abi_version": (_i, []),
     "pcg_last_error": (_c.c_char_p, []),
     "pcg_target_arch": (_c.c_char_p, []),
+    "pcg_tune_set": (_i, [_c.c_char_p, _i32]),
+    "pcg_debug_stamp_buffer": (_i, [_vp, _i64]),
     "pcg_calib_mfma_blocks": (_i32, [_i32]),
     "pcg_calib_mfma_workspace_bytes": (_sz, [_i32]),
     "pcg_calib_mfma": (_i, [_i32, _i32, _vp, _sz, _c.POINTER(_d), _c.POINTER(_c.c_uint64), _vp]),

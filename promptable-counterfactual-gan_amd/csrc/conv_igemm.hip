@@ -10,6 +10,7 @@
 //
 // Replaces ATen conv forward/backward behind nn.Conv2d / nn.ConvTranspose2d at
 // dconv_gan/mnist/mnist_dcgan.py:76-88,100-111 and conditional_counteRGAN/mnist/models/*.py.
+#include <string.h>
 #include "conv_loaders.h"
 #include "thin_conv.h"
 
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, true, true>(ktiles, acc, smem);
+  igemm_consume<Cfg, true, true>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
   float* out = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
 #ifdef PCG_ABL_NO_EPILOGUE   // timing-only ablation: keep one store so the accumulators stay live
   if (acc[0][0][0] == 12345.678f) out[0] = acc[0][0][1];
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, true, false>(ktiles, acc, smem);
+  igemm_consume<Cfg, true, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, false, false>(ktiles, acc, smem);
+  igemm_consume<Cfg, false, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
   float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
     const int m = m_block + row;
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad192_kernel(ConvP p, i
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, false, false>(ktiles, acc, smem);
+  igemm_consume<Cfg, false, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
   float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
     const int m = m_block + row;
@@ -232,8 +233,15 @@ int check_geom(const pcg_conv_geom* g) {
   return PCG_OK;
 }
 
+// Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+Tune g_tune;
+
 ConvP make_params(const pcg_conv_geom* g) {
   ConvP p{};
+  static const int korder_env = getenv("PCG_KORDER") ? atoi(getenv("PCG_KORDER")) : 1;
+  p.korder = g_tune.korder >= 0 ? g_tune.korder : korder_env;
+  p.stamps = g_tune.stamps; p.stamp_slots = g_tune.stamp_slots;
   p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.Cin = g->Cin; p.OH = g->OH; p.OW = g->OW; p.Cout = g->Cout;
   p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
   p.dOW = FastDiv((uint32_t)g->OW);
@@ -323,7 +331,8 @@ int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipSt
   constexpr size_t smem = smem_bytes<Cfg, true, false>();
   static int once = set_smem(conv_dgrad_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
-  static const int il_env = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
+  static const int il_env0 = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
+  const int il_env = g_tune.dgrad_interleave >= 0 ? g_tune.dgrad_interleave : il_env0;
   DgradPhases phl = ph;
   // only for small weight tensors: interleaved phases keep ALL phases' weight slices live in an XCD's 4 MB L2 at once (measured:
   // WGAN-GP's 8 MB ConvT weights ran 20 % slower interleaved, DCGAN's 0.5 MB D2 / G4 layers 1-3 % faster)
@@ -797,7 +806,8 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   p.tilesN = ceil_div(p.N, 128);
   if (int e = hx ? set_xform("pcg_conv2d_wgrad_xf", xf_x, g->Cin, &p) : set_xform("pcg_conv2d_wgrad_xf", xf_dy, g->Cout, &p)) return e;
   hipStream_t s = (hipStream_t)stream;
-  static const int order_env = getenv("PCG_WGRAD_ORDER") ? atoi(getenv("PCG_WGRAD_ORDER")) : -1;   // A/B switch: 0 tile-major, 1 slice-major
+  static const int order_env0 = getenv("PCG_WGRAD_ORDER") ? atoi(getenv("PCG_WGRAD_ORDER")) : -1;   // A/B switch: 0 tile-major, 1 slice-major
+  const int order_env = g_tune.wgrad_order >= 0 ? g_tune.wgrad_order : order_env0;
   const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
   const int side = hx ? 1 : hy ? 2 : 0;
   int rc;
@@ -825,4 +835,25 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
 extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   return pcg_conv2d_wgrad_xf(g, x, nullptr, dy, nullptr, dw, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcg_tune_set(const char* name, int32_t value) {
+  PCG_REQUIRE(name != nullptr, "pcg_tune_set: null name");
+  if (!strcmp(name, "korder")) g_tune.korder = value;
+  else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
+  else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
+  else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave)", name); return PCG_ERR_INVALID; }
+  return PCG_OK;
+}
+
+// Diagnostic builds (make stamp: -DPCG_CLOCK_STAMP): where the conv kernels leave their per-block clock stamps; the shipped library
+// carries the pointer but compiles no stamp code.  Returns 1 if this build stamps, 0 if not.
+extern "C" int pcg_debug_stamp_buffer(void* buf, int64_t bytes) {
+  g_tune.stamps = static_cast<unsigned long long*>(buf);
+  g_tune.stamp_slots = buf ? (int)(bytes / 16) : 0;
+#ifdef PCG_CLOCK_STAMP
+  return 1;
+#else
+  return 0;
+#endif
 }

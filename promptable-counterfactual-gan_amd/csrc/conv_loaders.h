@@ -56,7 +56,56 @@ struct ConvP {
   int tilesN;
   int ktiles;        // fwd: KH*KW*ceil(Cin/32)
   int ktiles_per_split;  // fwd split-K (gridDim.y slabs of M*N floats at `out`); == ktiles when not split
+  int korder;        // order of the k-tiles of fwd / dgrad (see FwdKIter): 0 = (tap, channel chunk), 1 = L2-friendly (default)
+  unsigned long long* stamps;  // diagnostic builds only (-DPCG_CLOCK_STAMP, pcg_debug_stamp_buffer): per block {shader-clock ticks,
+  int stamp_slots;             // 100 MHz ticks} of consumer wave 0's main loop; the shipped library compiles no stamp code
   FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition
+};
+
+// Order of the forward k-tiles.  A k-tile is (tap, 32-channel chunk); which order the sum over them runs in is free (A and B
+// loaders share this iterator), but it decides what the XCD's 4 MB L2 sees: an input line [pixel][32 channels] is wanted by
+// KH*KW/stride^2 taps of the tile (4 for k4 s2, 9 for 3x3 s1).
+//   korder 0: taps in raster order, chunks inside a tap.  The re-reads of a line are 2..4 k-tiles (kw + stride) and 8..16 k-tiles
+//             (kh + stride) apart — with 64 workgroups per XCD streaming 32 KB per k-tile the far ones miss L2: measured r02,
+//             the forward kernels fetched 2.6x their input bytes.
+//   korder 1: taps grouped by their stride-parity class (kh % s, kw % s) — the taps of a class read the SAME input pixels shifted
+//             by whole output steps — then channel chunk, then the taps of the class: all re-reads of a line are 1..3 k-tiles apart.
+struct FwdKIter {
+  int KH, KW, Cin, S, mode;
+  int ch, cw, jh, jw, ci0;
+  __device__ __forceinline__ void init(const ConvP& p) {
+    KH = p.KH; KW = p.KW; Cin = p.Cin; mode = p.korder; S = mode ? p.stride : 1;
+    ch = cw = jh = jw = ci0 = 0;
+  }
+  __device__ __forceinline__ int kh() const { return ch + S * jh; }
+  __device__ __forceinline__ int kw() const { return cw + S * jw; }
+  __device__ __forceinline__ bool next_tap_in_class() {
+    if (cw + S * (++jw) < KW) return true;
+    jw = 0;
+    if (ch + S * (++jh) < KH) return true;
+    jh = 0;
+    return false;
+  }
+  __device__ __forceinline__ void next_class() {
+    if (++cw >= S || cw >= KW) { cw = 0; ++ch; }
+  }
+  __device__ __forceinline__ void advance() {
+    if (mode == 0) {                       // (tap, chunk)
+      ci0 += IG_BK;
+      if (ci0 < Cin) return;
+      ci0 = 0;
+      next_tap_in_class();                 // S == 1: one class holding every tap, raster order
+    } else {                               // (class, chunk, tap of the class)
+      if (next_tap_in_class()) return;
+      ci0 += IG_BK;
+      if (ci0 < Cin) return;
+      ci0 = 0;
+      next_class();
+    }
+  }
+  __device__ __forceinline__ void seek(int kt) {      // split-K: start at k-tile kt (wave-uniform scalar loop)
+    for (int i = 0; i < kt; ++i) advance();
+  }
 };
 
 struct PhaseInfo {
@@ -100,13 +149,15 @@ struct FwdALoader {
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV], mask[NV];
-  int IW, Cin, KW, kh, kw, ci0, kq4;
+  int IW, Cin, KW, kq4;
+  FwdKIter it;
   XfK xf;
 
   __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block, int tid) {
     if constexpr (XF) xf.init(p);
     rs = make_rsrc(p.x, p.x_bytes);
     IW = p.IW; Cin = p.Cin; KW = p.KW;
+    it.init(p);
     kq4 = (tid & 7) * 4;
     const int r0 = tid >> 3;
 #pragma unroll
@@ -123,16 +174,11 @@ struct FwdALoader {
       }
       base[i] = bs; mask[i] = mk;
     }
-    kh = 0; kw = 0; ci0 = 0;
   }
-  // start at k-tile kt (split-K): kt = tap * ceil(Cin/32) + channel tile
-  __device__ __forceinline__ void seek(int kt) {
-    const int cpt = (Cin + IG_BK - 1) / IG_BK;
-    const int tap = kt / cpt;
-    ci0 = (kt - tap * cpt) * IG_BK;
-    kh = tap / KW; kw = tap - kh * KW;
-  }
+  // start at k-tile kt (split-K)
+  __device__ __forceinline__ void seek(int kt) { it.seek(kt); }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    const int kh = it.kh(), kw = it.kw(), ci0 = it.ci0;
     const int tap = kh * KW + kw;
     const uint32_t delta = (uint32_t)(((kh * IW + kw) * Cin + ci0) * 4);
     const bool kok = kq4 < Cin - ci0;
@@ -144,8 +190,7 @@ struct FwdALoader {
       if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
     }
     if constexpr (XF) { xf.ok = okbits; xf.fetch((uint32_t)((ci0 + kq4) * 4), kok); }
-    ci0 += IG_BK;
-    if (ci0 >= Cin) { ci0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+    it.advance();
   }
   // applied to the registers of the tile fetched by the LAST load_next, right before they are written to LDS
   __device__ __forceinline__ void transform(float4 (&v)[NV]) {
@@ -162,11 +207,13 @@ struct FwdBLoader {
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   rsrc_t rs;
   uint32_t base[NV];
-  int Cin, tapoff, ci0, kq4;
+  int Cin, KW, kq4;
+  FwdKIter it;
 
   __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block, int tid) {
     rs = make_rsrc(p.w, p.w_bytes);
-    Cin = p.Cin; kq4 = (tid & 7) * 4;
+    Cin = p.Cin; KW = p.KW; kq4 = (tid & 7) * 4;
+    it.init(p);
     const int r0 = tid >> 3;
     const int Ktot = p.KH * p.KW * p.Cin;
 #pragma unroll
@@ -174,32 +221,39 @@ struct FwdBLoader {
       const int n = n_block + r0 + 32 * i;
       base[i] = n < p.N ? (uint32_t)((n * Ktot + kq4) * 4) : OOB_OFF;  // OOB_OFF + delta stays out of range
     }
-    tapoff = 0; ci0 = 0;
   }
-  __device__ __forceinline__ void seek(int kt) {
-    const int cpt = (Cin + IG_BK - 1) / IG_BK;
-    const int tap = kt / cpt;
-    ci0 = (kt - tap * cpt) * IG_BK;
-    tapoff = tap * Cin;
-  }
+  __device__ __forceinline__ void seek(int kt) { it.seek(kt); }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
-    const uint32_t delta = (uint32_t)((tapoff + ci0) * 4);
+    const int ci0 = it.ci0;
+    const uint32_t delta = (uint32_t)(((it.kh() * KW + it.kw()) * Cin + ci0) * 4);
     const bool kok = kq4 < Cin - ci0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, kok ? base[i] + delta : OOB_OFF);
-    ci0 += IG_BK;
-    if (ci0 >= Cin) { ci0 = 0; tapoff += Cin; }
+    it.advance();
   }
   __device__ __forceinline__ void transform(float4 (&)[NV]) {}
 };
 
 // ---- dgrad: per sub-pixel phase; A = dy rows gathered (K-major, k = co), B = w[co][tap][ci] slices (MN-major) ----
-struct DgradTapIter {  // k-tiles run over (jh, jw, co-chunk)
-  int Cout, ntw, jw, co0, jh;
-  __device__ __forceinline__ void init(int Cout_, int ntw_) { Cout = Cout_; ntw = ntw_; jh = 0; jw = 0; co0 = 0; }
+// k-tiles of a grad-input phase: (jh, jw, co-chunk) with the chunk innermost (mode 0), or (co-chunk, jh, jw) with the taps innermost
+// (mode 1, default): the taps of a phase read the same dy pixels shifted by one — with the taps innermost a dy line [pixel][32 co]
+// is re-read in the NEXT k-tiles instead of Cout/32 k-tiles later (see FwdKIter).
+struct DgradTapIter {
+  int Cout, nth, ntw, jw, co0, jh, mode;
+  __device__ __forceinline__ void init(int Cout_, int nth_, int ntw_, int mode_) {
+    Cout = Cout_; nth = nth_; ntw = ntw_; mode = mode_; jh = 0; jw = 0; co0 = 0;
+  }
   __device__ __forceinline__ void advance() {
-    co0 += IG_BK;
-    if (co0 >= Cout) { co0 = 0; if (++jw == ntw) { jw = 0; ++jh; } }
+    if (mode == 0) {
+      co0 += IG_BK;
+      if (co0 >= Cout) { co0 = 0; if (++jw == ntw) { jw = 0; ++jh; } }
+    } else {
+      if (++jw < ntw) return;
+      jw = 0;
+      if (++jh < nth) return;
+      jh = 0;
+      co0 += IG_BK;
+    }
   }
 };
 
@@ -234,7 +288,7 @@ struct DgradALoader {
       }
       base[i] = bs; mask[i] = mk;
     }
-    it.init(Cout, f.ntw);
+    it.init(Cout, f.nth, f.ntw, p.korder);
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const int tap = it.jh * it.ntw + it.jw;
@@ -277,7 +331,7 @@ struct DgradBLoader {
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       base[i] = n < p.N ? (uint32_t)((((kr0 + KR * i) * KHKW) * Cin + n) * 4) : OOB_OFF;
-    it.init(p.Cout, f.ntw);
+    it.init(p.Cout, f.nth, f.ntw, p.korder);
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const int tap = (kh0 + stride * it.jh) * KW + kw0 + stride * it.jw;

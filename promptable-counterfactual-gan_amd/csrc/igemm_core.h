@@ -213,8 +213,26 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
 // 16 MFMAs of k-group g; the hand-over barrier of the k-tile sits BEFORE its last k-group (whose operands are already
 // in registers), and the first fragments of the next tile are fetched right behind it — no LDS latency is exposed at
 // the tile boundary.  s_setprio keeps MFMA issue ahead of the co-resident producers' vector instructions.
+// Diagnostic build (-DPCG_CLOCK_STAMP): the clock the chip holds INSIDE the main loop = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6), one pair per block, written to a buffer nothing else reads.
+struct ClockStamp {
+  unsigned long long* out; int slots;
+#ifdef PCG_CLOCK_STAMP
+  unsigned long long t0, r0;
+  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  __device__ __forceinline__ void end() {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (out && threadIdx.x == 0 && b < slots) { out[2 * b] = t1 - t0; out[2 * b + 1] = r1 - r0; }
+  }
+#else
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void end() {}
+#endif
+};
+
 template <class Cfg, bool AK, bool BK_>
-__device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* smem) {
+__device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* smem, ClockStamp cs = ClockStamp{nullptr, 0}) {
   using IA = LdsImage<Cfg::BM, AK, Cfg::SWZ>;
   using IB = LdsImage<Cfg::BN, BK_, Cfg::SWZ>;
   constexpr int KG = IG_BK / 8;  // k-groups per tile
@@ -251,6 +269,7 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
   lds_barrier();  // barrier 0: stage 0 is ready
   if (ktiles <= 0) return;
   __builtin_amdgcn_s_setprio(2);
+  cs.begin();
   fetch(As, Bs, 0, 0);
   int cur = 0;
   for (int kt = 0; kt < ktiles; ++kt) {
@@ -266,6 +285,7 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
     if (kt + 1 < ktiles) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
     mma((KG - 1) & 1);
   }
+  cs.end();
   __builtin_amdgcn_s_setprio(0);
 }
 

@@ -1162,6 +1162,11 @@ class DeviceRNG:
         return out
 
 
+def tune(name, value):
+    """A/B switch of a launch-planning choice (pcg_tune_set): 'korder', 'wgrad_order', 'dgrad_interleave'; -1 = built-in."""
+    check(_lib.load().pcg_tune_set(name.encode(), int(value)), "pcg_tune_set")
+
+
 # ---- calibration (bench lines; not on the step's path) -------------------------------------------------------------------
 def calibrate(device, mfma_ms=20.0, copy_mb=512, rounds=2):
     """What this box's fp32 matrix pipe and HBM sustain NOW: {"mfma_tflops", "mfma_clock_mhz", "hbm_gbs", ...}.

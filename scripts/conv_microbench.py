@@ -38,9 +38,29 @@ def main():
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="D2,D3,D4,G2,G3,G4")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: not a performance number)")
+    ap.add_argument("--ab", default=None, help="A/B a tuning switch in THIS process, interleaved rounds: e.g. korder=0,1 or wgrad_order=0,1 "
+                                               "(ops.tune / pcg_tune_set); prints the median and min ms per variant")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--clock", action="store_true", help="report the in-kernel clock (needs the stamp build: make -C csrc stamp; "
+                                                         "PCG_LIB=.../csrc/build_stamp/libpcgan_hip.so)")
     args = ap.parse_args()
-    pcgan_amd.load()
+    lib = pcgan_amd.load()
     dev = torch.device("cuda:0")
+    stamps = None
+    if args.clock:
+        stamps = torch.zeros(2 * 65536, dtype=torch.int64, device=dev)
+        if lib.pcg_debug_stamp_buffer(stamps.data_ptr(), stamps.numel() * 8) != 1:
+            sys.exit("--clock: this libpcgan_hip.so has no stamp code; make -C promptable-counterfactual-gan_amd/csrc stamp and set PCG_LIB")
+
+    def clock_mhz():
+        st = stamps.view(-1, 2).cpu().double()
+        st = st[st[:, 1] > 0]
+        stamps.zero_()
+        if st.numel() == 0:
+            return float("nan")
+        loop_us = st[:, 1] / 100.0                     # 100 MHz ticks -> us: consumer wave 0's main loop, per block
+        clock_mhz.loop = (float(loop_us.median()), float(loop_us.min()), float(loop_us.max()), int(st.shape[0]))
+        return float((st[:, 0] / st[:, 1] * 100.0).median())
     B = args.batch
     tot_f = tot_t = 0.0
     for name in args.layers.split(","):
@@ -59,6 +79,40 @@ def main():
                "wgrad": lambda: ops.conv2d_wgrad(g, x, dy, dw, False)}
         for op in args.only.split(","):
             fn = fns[op]
+            if args.ab:
+                key, vals = args.ab.split("=")
+                vals = [int(v) for v in vals.split(",")]
+                res = {v: [] for v in vals}
+                clk = {}
+                for v in vals:
+                    ops.tune(key, v)
+                    for _ in range(2):
+                        fn()
+                for _ in range(args.rounds):
+                    for v in vals:
+                        ops.tune(key, v)
+                        fn()
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(args.iters):
+                            fn()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        res[v].append(e0.elapsed_time(e1) / args.iters)
+                        if stamps is not None:
+                            clk.setdefault(v, []).append(clock_mhz())
+                ops.tune(key, -1)
+                line = f"{name:4s} {op:6s} B={B} {Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p} "
+                for v in vals:
+                    r = sorted(res[v])
+                    med = r[len(r) // 2]
+                    line += f" | {key}={v}: med {med:7.4f} ms ({flops / med / 1e9:6.1f} TF) min {r[0]:7.4f}"
+                    if stamps is not None:
+                        c = sorted(clk[v])
+                        line += f" clk {c[len(c) // 2]:5.0f} MHz"
+                print(line, flush=True)
+                continue
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -70,8 +124,14 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
             tot_f += flops; tot_t += ms * 1e-3
-            print(f"{name:4s} {op:6s} M/N/K-ish B={B} {Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p}  {ms:8.4f} ms  {flops / ms / 1e9:7.2f} TFLOP/s", flush=True)
-    print(f"TOTAL {tot_f / tot_t / 1e12:.2f} TFLOP/s over {tot_t * 1e3:.3f} ms")
+            extra = ""
+            if stamps is not None:
+                c = clock_mhz()
+                lo = clock_mhz.loop
+                extra = f"  in-kernel clock {c:5.0f} MHz; main loop per block med/min/max {lo[0]:.1f}/{lo[1]:.1f}/{lo[2]:.1f} us over {lo[3]} blocks"
+            print(f"{name:4s} {op:6s} M/N/K-ish B={B} {Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p}  {ms:8.4f} ms  {flops / ms / 1e9:7.2f} TFLOP/s{extra}", flush=True)
+    if tot_t > 0:
+        print(f"TOTAL {tot_f / tot_t / 1e12:.2f} TFLOP/s over {tot_t * 1e3:.3f} ms")
 
 
 if __name__ == "__main__":
