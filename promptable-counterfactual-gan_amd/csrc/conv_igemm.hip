@@ -138,6 +138,158 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   });
 }
 
+
+#ifdef PCG_PERSISTENT_KERNELS   // experiment kept out of the shipped library (measured slower: igemm_core.h); `make lean`
+// ---- persistent, tile-pipelined forms (igemm_core.h: igemm_produce_stream / igemm_consume_stream / igemm_store_regs) -------------
+// Work item of the forward launch: (output tile, K-slice); item = slice * tiles + tile.
+template <class Cfg, bool XF>
+struct FwdSrc {
+  using LA = FwdALoader<Cfg::BM, XF>;
+  using LB = FwdBLoader<Cfg::BN>;
+  const ConvP& p; TileWalk walk; uint32_t i, tiles; int tid;
+  LA la; LB lb; int n;
+  __device__ __forceinline__ void decode(uint32_t item, int& m_block, int& n_block, int& kt_begin, int& kt) const {
+    const uint32_t split = item / tiles, tile = item - split * tiles;
+    m_block = (int)(tile / (uint32_t)p.tilesN) * Cfg::BM; n_block = (int)(tile % (uint32_t)p.tilesN) * Cfg::BN;
+    kt_begin = (int)split * p.ktiles_per_split;
+    kt = p.ktiles - kt_begin;
+    if (kt > p.ktiles_per_split) kt = p.ktiles_per_split;
+  }
+  __device__ __forceinline__ FwdSrc(const ConvP& p_, const TileWalk& w, uint32_t tiles_, int tid_, int m0, int n0, int kb0, int kt0)
+      : p(p_), walk(w), i(0), tiles(tiles_), tid(tid_), la(p_, m0, tid_), lb(p_, n0, tid_), n(kt0) {
+    if (kb0) { la.seek(kb0); lb.seek(kb0); }
+  }
+  __device__ __forceinline__ void next_tile() {
+    int m_block, n_block, kb;
+    decode(walk.item(++i), m_block, n_block, kb, n);
+    la = LA(p, m_block, tid); lb = LB(p, n_block, tid);
+    if (kb) { la.seek(kb); lb.seek(kb); }
+  }
+};
+
+template <class Cfg, bool XF>
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_pkernel(ConvP p, int splits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t tiles = (uint32_t)((p.M + Cfg::BM - 1) / Cfg::BM) * (uint32_t)p.tilesN;
+  const TileWalk walk(tiles * (uint32_t)splits);
+  const int nt = (int)walk.ntiles();
+  if (nt == 0) return;                           // workgroup-uniform
+  auto item_ktiles = [&](uint32_t item) {
+    const int kb = (int)(item / tiles) * p.ktiles_per_split;
+    const int kt = p.ktiles - kb;
+    return kt > p.ktiles_per_split ? p.ktiles_per_split : kt;
+  };
+  int S = 0;
+  for (int t = 0; t < nt; ++t) S += item_ktiles(walk.item(t));
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    const uint32_t it0 = walk.item(0), sp0 = it0 / tiles, tl0 = it0 - sp0 * tiles;
+    FwdSrc<Cfg, XF> src(p, walk, tiles, tid, (int)(tl0 / (uint32_t)p.tilesN) * Cfg::BM, (int)(tl0 % (uint32_t)p.tilesN) * Cfg::BN,
+                        (int)sp0 * p.ktiles_per_split, item_ktiles(it0));
+    igemm_produce_stream<Cfg>(src, S, smem, tid);
+    return;
+  }
+  const uint32_t slab_bytes = (uint32_t)((size_t)p.M * p.N * 4);
+  igemm_consume_stream<Cfg, true, true>(nt, [&](int t) { return item_ktiles(walk.item(t)); },
+    [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+      const uint32_t item = walk.item(t), split = item / tiles, tile = item - split * tiles;
+      const int mt = (int)(tile / (uint32_t)p.tilesN), m_block = mt * Cfg::BM, n_block = (int)(tile % (uint32_t)p.tilesN) * Cfg::BN;
+      float* out = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
+      const EpiBufs eb = make_epi_bufs(out, slab_bytes, p.epi);
+      RowsAffine rows{p.M, m_block, (uint32_t)p.N * 4u, (uint32_t)n_block * 4u, 0u, 0};
+      igemm_store_regs<Cfg>(acc, n_block, p.N, split == 0 ? p.bias : nullptr, rows, eb,
+                            p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+    }, smem, ClockStamp{p.stamps, p.stamp_slots});
+}
+
+// Work item of the grad-input launch: (sub-pixel phase, tile of the phase's pixel grid).  Phases of equal size are interleaved (the
+// phases of one pixel tile are neighbours: they gather the same dy rows); otherwise the phases' tile ranges follow each other.
+struct DgradItems {
+  int nph, interleave, cnt[4];       // cnt[p] = tiles of phase p (tilesM_p * tilesN)
+  uint32_t total;
+  __device__ __forceinline__ void decode(uint32_t item, int& py, uint32_t& tile) const {
+    if (interleave) { py = (int)(item % (uint32_t)nph); tile = item / (uint32_t)nph; return; }
+    py = 0;
+    while (py + 1 < nph && item >= (uint32_t)cnt[py]) { item -= (uint32_t)cnt[py]; ++py; }
+    tile = item;
+  }
+};
+
+template <class Cfg, bool XF>
+struct DgradSrc {
+  using LA = DgradALoader<Cfg::BM, XF>;
+  using LB = DgradBLoader<Cfg::BN>;
+  const ConvP& p; const DgradPhases& ph; const DgradItems& items; TileWalk walk; uint32_t i; int tid; uint32_t (*rowpix)[Cfg::BM];
+  LA la; LB lb; int n;
+  __device__ __forceinline__ static int ktiles_of(const ConvP& p, const PhaseInfo& f) { return f.nth * f.ntw * ((p.Cout + IG_BK - 1) / IG_BK); }
+  __device__ __forceinline__ void publish_rows(const PhaseInfo& f, int m_block, uint32_t seq) {   // byte offset of every tile row's output pixel
+    for (int r = tid; r < Cfg::BM; r += IG_LOADERS) {
+      const int m = m_block + r;
+      uint32_t off = OOB_OFF;
+      if (m < f.Mp) {
+        uint32_t t, cc, b, aa;
+        f.dPHw.divmod((uint32_t)m, t, cc);
+        f.dPHh.divmod(t, b, aa);
+        const int pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
+        off = (uint32_t)pix * (uint32_t)p.Cin * 4u;
+      }
+      rowpix[seq & 3u][r] = off;
+    }
+  }
+  __device__ __forceinline__ DgradSrc(const ConvP& p_, const DgradPhases& ph_, const DgradItems& it_, const TileWalk& w, int tid_,
+                                      uint32_t (*rowpix_)[Cfg::BM], const PhaseInfo& f0, int m0, int n0)
+      : p(p_), ph(ph_), items(it_), walk(w), i(0), tid(tid_), rowpix(rowpix_), la(p_, f0, m0, tid_), lb(p_, f0, n0, tid_), n(ktiles_of(p_, f0)) {
+    publish_rows(f0, m0, 0);
+  }
+  __device__ __forceinline__ void next_tile() {
+    int py; uint32_t tile;
+    items.decode(walk.item(++i), py, tile);
+    const PhaseInfo& f = ph.p[py];
+    const int m_block = (int)(tile / (uint32_t)p.tilesN) * Cfg::BM, n_block = (int)(tile % (uint32_t)p.tilesN) * Cfg::BN;
+    la = LA(p, f, m_block, tid); lb = LB(p, f, n_block, tid);
+    n = ktiles_of(p, f);
+    publish_rows(f, m_block, i);     // slot i & 3: the consumers are at most three tiles behind (the producers lead by <= 3 k-tiles)
+  }
+};
+
+template <class Cfg, bool XF>
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_pkernel(ConvP p, DgradPhases phases, DgradItems items) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ uint32_t rowpix[4][Cfg::BM];
+  const TileWalk walk(items.total);
+  const int nt = (int)walk.ntiles();
+  if (nt == 0) return;
+  auto item_ktiles = [&](uint32_t item) {
+    int py; uint32_t tile;
+    items.decode(item, py, tile);
+    return DgradSrc<Cfg, XF>::ktiles_of(p, phases.p[py]);
+  };
+  int S = 0;
+  for (int t = 0; t < nt; ++t) S += item_ktiles(walk.item(t));
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    int py; uint32_t tile;
+    items.decode(walk.item(0), py, tile);
+    DgradSrc<Cfg, XF> src(p, phases, items, walk, tid, rowpix, phases.p[py], (int)(tile / (uint32_t)p.tilesN) * Cfg::BM,
+                          (int)(tile % (uint32_t)p.tilesN) * Cfg::BN);
+    igemm_produce_stream<Cfg>(src, S, smem, tid);
+    return;
+  }
+  const EpiBufs eb = make_epi_bufs(p.out, p.x_bytes, p.epi);
+  igemm_consume_stream<Cfg, true, false>(nt, [&](int t) { return item_ktiles(walk.item(t)); },
+    [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+      int py; uint32_t tile;
+      items.decode(walk.item(t), py, tile);
+      const PhaseInfo& f = phases.p[py];
+      const int mt = (int)(tile / (uint32_t)p.tilesN), n_block = (int)(tile % (uint32_t)p.tilesN) * Cfg::BN;
+      RowsTable rows{rowpix[(uint32_t)t & 3u], (uint32_t)n_block * 4u, nullptr, 0u};
+      igemm_store_regs<Cfg>(acc, n_block, p.N, p.bias, rows, eb,
+                            p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+    }, smem, ClockStamp{p.stamps, p.stamp_slots});
+}
+
+#endif  // PCG_PERSISTENT_KERNELS
+
 // 64x192 tile of the weight gradient (Cout <= 64, N = KH*KW*Cin a multiple of 192): the same pipeline with the 192-column B loader
 using Cfg64x192 = TileCfg<64, 192, 2, 2>;
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad192_kernel(ConvP p, int ktiles_total, int ktiles_per_split, int tiles,
@@ -234,7 +386,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -278,10 +430,48 @@ int set_smem(K kernel, size_t bytes) {
   return PCG_OK;
 }
 
+// persistent launches: workgroups resident per CU (what the LDS and register budgets of the tile configuration admit) x CUs
+int cu_count() {
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return cus;
+}
+template <class Cfg>
+unsigned persistent_grid(uint64_t items) {
+  const unsigned slots = (unsigned)cu_count() * (Cfg::MINW >= 6 ? 3u : 2u);
+  unsigned g = items < slots ? (unsigned)items : slots;
+  if (g >= 8) g &= ~7u;                          // TileWalk: a multiple of 8 keeps the per-XCD runs
+  return g ? g : 1u;
+}
+bool use_persistent() {
+#ifdef PCG_PERSISTENT_KERNELS
+  static const int env = getenv("PCG_PERSISTENT") ? atoi(getenv("PCG_PERSISTENT")) : 0;
+  return (g_tune.persistent >= 0 ? g_tune.persistent : env) != 0;
+#else
+  return false;
+#endif
+}
+template <class Cfg, bool AK, bool BK_>
+constexpr size_t stage_smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, AK, BK_>(); }
+
 template <class Cfg, bool XF>
 int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(p.M, Cfg::BM);
+#ifdef PCG_PERSISTENT_KERNELS
+  if (use_persistent()) {
+    constexpr size_t smem = stage_smem_bytes<Cfg, true, true>();
+    static int once = set_smem(conv_fwd_pkernel<Cfg, XF>, smem);
+    if (once != PCG_OK) return once;
+    const uint64_t items = (uint64_t)tilesM * p.tilesN * splits;
+    hipLaunchKernelGGL((conv_fwd_pkernel<Cfg, XF>), dim3(persistent_grid<Cfg>(items)), dim3(IG_THREADS), smem, s, p, splits);
+    return launch_status("conv_fwd_pkernel");
+  }
+#endif
   constexpr size_t smem = smem_bytes<Cfg, true, true>();
   static int once = set_smem(conv_fwd_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
@@ -328,6 +518,27 @@ template <class Cfg, bool XF>
 int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
   const int tilesM = ceil_div(maxMp, Cfg::BM);
+#ifdef PCG_PERSISTENT_KERNELS
+  bool all_have_taps = true;
+  for (int i = 0; i < nphases; ++i) all_have_taps = all_have_taps && ph.p[i].nth > 0;
+  if (use_persistent() && all_have_taps) {
+    constexpr size_t smem = stage_smem_bytes<Cfg, true, false>();
+    static int once = set_smem(conv_dgrad_pkernel<Cfg, XF>, smem);
+    if (once != PCG_OK) return once;
+    static const int il_env0 = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;
+    const int il_env = g_tune.dgrad_interleave >= 0 ? g_tune.dgrad_interleave : il_env0;
+    DgradItems it{};
+    it.nph = nphases;
+    bool same = nphases > 1 && il_env && p.w_bytes <= (1u << 20);
+    for (int i = 1; i < nphases; ++i) same = same && ph.p[i].Mp == ph.p[0].Mp;
+    it.interleave = same ? 1 : 0;
+    uint64_t total = 0;
+    for (int i = 0; i < nphases; ++i) { it.cnt[i] = ceil_div(ph.p[i].Mp, Cfg::BM) * p.tilesN; total += (uint64_t)it.cnt[i]; }
+    it.total = (uint32_t)total;
+    hipLaunchKernelGGL((conv_dgrad_pkernel<Cfg, XF>), dim3(persistent_grid<Cfg>(total)), dim3(IG_THREADS), smem, s, p, ph, it);
+    return launch_status("conv_dgrad_pkernel");
+  }
+#endif
   constexpr size_t smem = smem_bytes<Cfg, true, false>();
   static int once = set_smem(conv_dgrad_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
@@ -842,7 +1053,8 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   if (!strcmp(name, "korder")) g_tune.korder = value;
   else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
   else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
-  else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave)", name); return PCG_ERR_INVALID; }
+  else if (!strcmp(name, "persistent")) g_tune.persistent = value;
+  else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;
 }
 

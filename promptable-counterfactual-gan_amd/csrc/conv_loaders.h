@@ -13,18 +13,6 @@
 
 namespace pcg {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr uint32_t OOB_OFF = 0x80000000u;  // >= num_records of any accepted tensor
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
 // bit (a*nw + c) set for lo_h <= a < hi_h (clipped to [0,nh)) and lo_w <= c < hi_w (clipped to [0,nw)); nh*nw <= 32
 __device__ __forceinline__ uint32_t tap_mask(int lo_h, int hi_h, int nh, int lo_w, int hi_w, int nw) {
   lo_h = lo_h < 0 ? 0 : lo_h; hi_h = hi_h > nh ? nh : hi_h;

@@ -34,6 +34,22 @@ namespace pcg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Raw buffer resources: num_records = the tensor's size in bytes, so an out-of-range byte offset reads as zeros and a store to it
+// is dropped — padding, ragged edges and K tails without branches (conv_loaders.h), and the register epilogue's edge handling.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t OOB_OFF = 0x80000000u;  // >= num_records of any accepted tensor
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(rsrc_t r, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ void buf_store1(rsrc_t r, uint32_t off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0); }
+
 constexpr int IG_LOADERS = 256;            // threads that gather one k-tile (4 waves)
 constexpr int IG_THREADS = 512;            // 4 consumer + 4 producer waves
 constexpr int IG_BK = 32;
@@ -225,9 +241,20 @@ struct ClockStamp {
     const int b = blockIdx.x + gridDim.x * blockIdx.y;
     if (out && threadIdx.x == 0 && b < slots) { out[2 * b] = t1 - t0; out[2 * b + 1] = r1 - r0; }
   }
+  // per-tile timeline of the persistent kernels (second half of the buffer: 2 + 32 words per block): mark(k) = 100 MHz ticks since begin();
+  // word 0 = begin() on the chip-wide 100 MHz clock (start skew between blocks), word 1 = hardware id
+  __device__ __forceinline__ void mark(int k) {
+    const int b = blockIdx.x;
+    if (out && threadIdx.x == 0 && b < slots / 36 && k < 32) {
+      unsigned long long* tl = out + 2 * (size_t)slots / 2 + (size_t)b * 34;     // second half of the buffer
+      tl[2 + k] = __builtin_amdgcn_s_memrealtime() - r0;
+      if (k == 0) { tl[0] = r0; tl[1] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }   // HW_REG_HW_ID, 32 bits
+    }
+  }
 #else
   __device__ __forceinline__ void begin() {}
   __device__ __forceinline__ void end() {}
+  __device__ __forceinline__ void mark(int) {}
 #endif
 };
 
@@ -381,25 +408,32 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       mu = *reinterpret_cast<const float4*>(epi->mean + n);
       is = *reinterpret_cast<const float4*>(epi->invstd + n);
     }
-    // all aux loads of the wave tile first (independent of the LDS reads), then the arithmetic
-    float4 u[Cfg::WTM / RPI];
+    // The aux reads of a CHUNK of row groups first (independent of the LDS reads), then the arithmetic; a scheduling fence between
+    // chunks.  Reading all 16 row groups of the 128x128 tile at once (r02) took 64 registers: 7 VGPRs spilled in its grad-input
+    // kernel; two chunks of 8: none (scripts/kernel_resources.py).  The three-per-CU 128x64 configuration (80 registers, 8 row
+    // groups) keeps ONE chunk — halving it made the allocator spill more, not less (57 / 65 against 11 / 17 now, all outside the
+    // main loop; r02: 37 / 18).
+    constexpr int NK = Cfg::WTM / RPI, CH = (NK >= 8 && Cfg::MINW < 6) ? NK / 2 : NK;
 #pragma unroll
-    for (int k = 0; k < Cfg::WTM / RPI; ++k) {
-      float* dst = row_base(wm * Cfg::WTM + r0 + RPI * k);
-      u[k] = (dst && nok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < NK; k0 += CH) {
+    float4 u[CH];
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      float* dst = row_base(wm * Cfg::WTM + r0 + RPI * (k0 + kk));
+      u[kk] = (dst && nok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (emode == EPI_ADDSUM) {   // wave-uniform: its own loop (the second aux tensor is read next to each row's arithmetic)
       const int64_t delta2 = epi->delta2_bytes;
       const double sc2 = (double)neg;
 #pragma unroll
-      for (int k = 0; k < Cfg::WTM / RPI; ++k) {
-        const int row = r0 + RPI * k;
+      for (int kk = 0; kk < CH; ++kk) {
+        const int row = r0 + RPI * (k0 + kk);
         float* dst = row_base(wm * Cfg::WTM + row);
         if (dst && nok) {
           float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
           const float4 z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta2);
-          v.x += u[k].x; v.y += u[k].y; v.z += u[k].z; v.w += u[k].w;
+          v.x += u[kk].x; v.y += u[kk].y; v.z += u[kk].z; v.w += u[kk].w;
           *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
           if (want_sums) {
             const double d0 = sc2 * (double)v.x, d1 = sc2 * (double)v.y, d2 = sc2 * (double)v.z, d3 = sc2 * (double)v.w;
@@ -411,27 +445,29 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
       }
     } else {
 #pragma unroll
-    for (int k = 0; k < Cfg::WTM / RPI; ++k) {
-      const int row = r0 + RPI * k;
+    for (int kk = 0; kk < CH; ++kk) {
+      const int row = r0 + RPI * (k0 + kk);
       float* dst = row_base(wm * Cfg::WTM + row);
       if (dst && nok) {
         float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
         // same expression as bn_bwd_apply / FnBnBwd use for the recomputed BatchNorm output (sc = 1, sh = 0 for EPI_MASK)
         if (emode == EPI_ADD) {   // wave-uniform
-          v.x += u[k].x; v.y += u[k].y; v.z += u[k].z; v.w += u[k].w;
+          v.x += u[kk].x; v.y += u[kk].y; v.z += u[kk].z; v.w += u[kk].w;
         } else {
-          const float4 pre = make_float4(fmaf(u[k].x, sc.x, sh.x), fmaf(u[k].y, sc.y, sh.y), fmaf(u[k].z, sc.z, sh.z), fmaf(u[k].w, sc.w, sh.w));
+          const float4 pre = make_float4(fmaf(u[kk].x, sc.x, sh.x), fmaf(u[kk].y, sc.y, sh.y), fmaf(u[kk].z, sc.z, sh.z), fmaf(u[kk].w, sc.w, sh.w));
           v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
         }
         *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
         if (want_sums) {
           s1[0] += (double)v.x; s1[1] += (double)v.y; s1[2] += (double)v.z; s1[3] += (double)v.w;
-          s2[0] = fma((double)v.x, (double)((u[k].x - mu.x) * is.x), s2[0]); s2[1] = fma((double)v.y, (double)((u[k].y - mu.y) * is.y), s2[1]);
-          s2[2] = fma((double)v.z, (double)((u[k].z - mu.z) * is.z), s2[2]); s2[3] = fma((double)v.w, (double)((u[k].w - mu.w) * is.w), s2[3]);
+          s2[0] = fma((double)v.x, (double)((u[kk].x - mu.x) * is.x), s2[0]); s2[1] = fma((double)v.y, (double)((u[kk].y - mu.y) * is.y), s2[1]);
+          s2[2] = fma((double)v.z, (double)((u[kk].z - mu.z) * is.z), s2[2]); s2[3] = fma((double)v.w, (double)((u[kk].w - mu.w) * is.w), s2[3]);
         }
       }
     }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    }   // chunk
   }
   // fused BatchNorm statistics: per-column sum / sum of squares over this wave's rows -> one fp64 partial row per
   // (tile row, wave row); a finalize kernel adds the partial rows in a fixed order (bitwise reproducible)
@@ -448,6 +484,376 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
     }
   }
 }
+
+// ======================================================================================================================
+// Persistent, tile-pipelined form (r03).  In-kernel stamps (scripts/conv_microbench.py --clock) showed where the time of the
+// one-tile-per-workgroup kernels goes: the chip holds 2.37-2.40 GHz inside them and the main loops run at 93-96 % of the MFMA rate,
+// but every tile pays 16-19 us OUTSIDE its main loop — workgroup dispatch, loader set-up, the first gathers' round trip, the LDS-
+// staged epilogue, the final write burst — which is 7 % of a 128x128 tile with K = 2048 and as long as the main loop itself for a
+// 128x64 tile with K = 512.  Here a workgroup is resident for the whole launch and walks a strided list of tiles; the k-tiles of
+// all its tiles form ONE stream through the same two LDS stages and the same barrier protocol:
+//   producers  run ahead across tile boundaries (the next tile's first k-tiles are gathered and staged while the consumers finish
+//              the current one), re-creating their loader state when the stream crosses into the next tile;
+//   consumers  store a finished tile STRAIGHT from the accumulator registers (column on the lane, rows in the registers: one
+//              128-byte row segment per half-wave per store) — no LDS staging, so the stages stay with the producers — zero the
+//              accumulators and continue with the fragments that are already waiting.
+// MEASURED (MI355X, scripts/conv_microbench.py --ab persistent=0,1 and --clock --timeline): NOT faster.  With the
+// plain epilogue it ties the one-tile-per-workgroup kernels on the forward shapes (D2 260.6 vs 261.1 us, D4 +4.6 %) and loses 3-8 %
+// on the grad-input shapes; with the full epilogue compiled in, the whole DCGAN step is 11.20 vs 10.96 ms.  Why: resident
+// workgroups that all walk equal tiles stay in LOCKSTEP — every tile boundary is chip-wide, all consumers leave the matrix pipe
+// together and all write their tiles together (a 32 MB burst: 8-9 us per 128x128 tile boundary), whereas the dispatcher's own
+// round-robin of short-lived workgroups desynchronises after the first round and hides one workgroup's prologue / epilogue
+// behind its CU neighbour's main loop; and a static tile walk ends with its slowest workgroup (main-loop spread 200-252 us).
+// Kept as an opt-in experiment (-DPCG_PERSISTENT_KERNELS: `make -C csrc lean`, pcg_tune_set("persistent", 1)); the shipped
+// library does not compile it.
+// ======================================================================================================================
+#ifdef PCG_PERSISTENT_KERNELS
+
+// Walk of one workgroup over the launch's work items (tiles, or (tile, K-slice) pairs): the `total` items are cut into 8 contiguous
+// runs, one per XCD (blocks b and b + 8 share an XCD and its L2), and the G/8 workgroups of an XCD take the items of their run
+// round-robin — at any time the workgroups of one XCD work on neighbouring tiles (shared halo rows / weight panels in that L2).
+struct TileWalk {
+  uint32_t base, count, q, step;   // this workgroup visits base + q, base + q + step, ... < base + count
+  __device__ __forceinline__ TileWalk(uint32_t total) {
+    const uint32_t w = blockIdx.x, G = gridDim.x;
+    if (G & 7u) {                              // not a multiple of 8 (tiny launches): plain striding
+      base = 0; count = total; q = w; step = G;
+    } else {
+      const uint32_t x = w & 7u, qq = total >> 3, r = total & 7u;
+      base = x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq;
+      count = qq + (x < r ? 1u : 0u);
+      q = w >> 3; step = G >> 3;
+    }
+  }
+  __device__ __forceinline__ uint32_t ntiles() const { return q < count ? (count - q + step - 1) / step : 0u; }
+  __device__ __forceinline__ uint32_t item(uint32_t i) const { return base + q + i * step; }
+};
+
+// Producer side.  Src concept: `la`, `lb` (loaders of the CURRENT tile), `int n` (its k-tiles, >= 1), `bool next_tile()` (advance to
+// this workgroup's next tile and rebuild la / lb / n; false when there is none).  S = k-tiles of the whole stream.
+template <class Cfg, class Src>
+__device__ __forceinline__ void igemm_produce_stream(Src& src, int S, float* smem, int tid) {
+  using LA = decltype(src.la);
+  using LB = decltype(src.lb);
+  using IA = LdsImage<Cfg::BM, LA::KMAJOR, Cfg::SWZ>;
+  using IB = LdsImage<Cfg::BN, LB::KMAJOR, Cfg::SWZ>;
+  static_assert(LA::ROWS == Cfg::BM && LB::ROWS == Cfg::BN, "loader/tile mismatch");
+  float* As = smem;
+  float* Bs = smem + 2 * IA::FLOATS;
+  int left = src.n;                            // k-tiles of the current tile not yet gathered
+  auto issue = [&](float4 (&ra)[IA::NV], float4 (&rb)[IB::NV]) {
+    if (left == 0) { src.next_tile(); left = src.n; }        // only called while the stream has elements left
+    src.la.load_next(ra); src.lb.load_next(rb);
+    --left;
+  };
+  if constexpr (Cfg::PF == 2 && !LA::XFORM && !LB::XFORM) {
+    float4 ra[2][IA::NV], rb[2][IB::NV];
+    if (S > 0) {
+      issue(ra[0], rb[0]);
+      if (S > 1) issue(ra[1], rb[1]);
+      IA::store(As, ra[0], tid);
+      IB::store(Bs, rb[0], tid);
+      if (S > 2) issue(ra[0], rb[0]);
+    }
+    lds_barrier();
+    int g = 0;
+    for (; g + 1 < S; g += 2) {
+      IA::store(As + IA::FLOATS, ra[1], tid);
+      IB::store(Bs + IB::FLOATS, rb[1], tid);
+      if (g + 3 < S) issue(ra[1], rb[1]);
+      lds_barrier();
+      if (g + 2 < S) {
+        IA::store(As, ra[0], tid);
+        IB::store(Bs, rb[0], tid);
+      }
+      if (g + 4 < S) issue(ra[0], rb[0]);
+      lds_barrier();
+    }
+    if (g < S) lds_barrier();
+  } else {
+    float4 ra[IA::NV], rb[IB::NV];
+    if (S > 0) {
+      issue(ra, rb);
+      src.la.transform(ra); src.lb.transform(rb);
+      IA::store(As, ra, tid);
+      IB::store(Bs, rb, tid);
+      if (S > 1) issue(ra, rb);
+    }
+    lds_barrier();
+    int nxt = 1;
+    for (int g = 0; g < S; ++g) {
+      if (g + 1 < S) {
+        src.la.transform(ra); src.lb.transform(rb);      // the state of the loader that issued this k-tile: transform precedes the next issue
+        IA::store(As + nxt * IA::FLOATS, ra, tid);
+        IB::store(Bs + nxt * IB::FLOATS, rb, tid);
+      }
+      if (g + 2 < S) issue(ra, rb);
+      lds_barrier();
+      nxt ^= 1;
+    }
+  }
+}
+
+// Consumer side.  ktiles_of(i) = k-tiles of this workgroup's i-th tile (>= 1); epilogue(i, acc) stores it (registers -> global).
+template <class Cfg, bool AK, bool BK_, class KtOf, class Epi>
+__device__ __forceinline__ void igemm_consume_stream(int ntiles, KtOf ktiles_of, Epi epilogue, const float* smem, ClockStamp cs = ClockStamp{nullptr, 0}) {
+  using IA = LdsImage<Cfg::BM, AK, Cfg::SWZ>;
+  using IB = LdsImage<Cfg::BN, BK_, Cfg::SWZ>;
+  constexpr int KG = IG_BK / 8;
+  const float* As = smem;
+  const float* Bs = smem + 2 * IA::FLOATS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+  const int arow = wm * Cfg::WTM, brow = wn * Cfg::WTN;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  float a[2][Cfg::TM][4], b[2][Cfg::TN][4];
+  auto fetch = [&](const float* as, const float* bs, int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) IA::frag(as, arow + 32 * i, ks, li, lh, a[buf][i]);
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) IB::frag(bs, brow + 32 * j, ks, li, lh, b[buf][j]);
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][i][t], b[buf][j][t], acc[i][j], 0, 0, 0);
+  };
+  lds_barrier();                                 // barrier 0: the stream's first k-tile is staged
+  if (ntiles <= 0) return;
+  __builtin_amdgcn_s_setprio(2);
+  cs.begin();
+  fetch(As, Bs, 0, 0);
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int n = ktiles_of(t);
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < n; ++kt) {
+      const float* as = As + cur * IA::FLOATS;
+      const float* bs = Bs + cur * IB::FLOATS;
+#pragma unroll
+      for (int ks = 0; ks < KG - 1; ++ks) {
+        fetch(as, bs, ks + 1, (ks + 1) & 1);
+        mma(ks & 1);
+      }
+      lds_barrier();                             // all reads of stage cur retired; stage cur^1 (the stream's next k-tile) is ready
+      cur ^= 1;
+      if (kt + 1 < n) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
+      mma((KG - 1) & 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    cs.mark(2 * t);
+    epilogue(t, acc);                            // registers -> global; the LDS stages stay with the producers
+    cs.mark(2 * t + 1);
+    __builtin_amdgcn_s_setprio(2);
+    // the next tile's first fragments only now: they would be 16 more live registers across the epilogue (one exposed LDS read per tile)
+    if (t + 1 < ntiles) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
+  }
+  cs.end();
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// Epilogue straight from the accumulator registers: element (i, j, r) of lane (li, lh) is row 32i + acc_row(r, lh), column 32j + li
+// of the wave tile, so a store instruction writes two 128-byte row segments (one per half-wave) and every per-column constant
+// (bias, BatchNorm mean / invstd / scale / shift) is ONE value per lane and j.  Same arithmetic per element as igemm_store_tile;
+// the column sums (fused statistics / BatchNorm-backward sums) are taken per lane over its rows in fp64 and the two half-waves
+// added by one shuffle.  Addressing is by 32-bit byte offsets into raw buffer resources of the output (and of the aux tensors of
+// the backward epilogues, which have the output's shape): row_off(row) = offset of the tile row's column n_block, or OOB_OFF for a
+// row outside the problem — such stores are dropped and such loads return zero, no branches.
+struct EpiBufs { rsrc_t out, aux, aux2; };
+__device__ __forceinline__ EpiBufs make_epi_bufs(float* out, uint32_t out_bytes, const EpiAux& e) {
+  EpiBufs b;
+  b.out = make_rsrc(out, out_bytes);
+  b.aux = make_rsrc(reinterpret_cast<const char*>(out) + e.delta_bytes, e.mode != EPI_NONE ? out_bytes : 0u);
+  b.aux2 = make_rsrc(reinterpret_cast<const char*>(out) + e.delta2_bytes, e.mode == EPI_ADDSUM ? out_bytes : 0u);
+  return b;
+}
+
+// Row addressing policies of the register epilogue.  An element's address is (per-lane VGPR offset) + (wave-uniform SGPR offset):
+// gfx950 range-checks their SUM against num_records (scripts/probes/soffset_probe.hip), so for a row-major [M][N] output the rows
+// beyond M fall out of range by themselves and the sixteen row steps of an accumulator are sixteen SGPR constants — one VGPR of
+// addressing per accumulator instead of sixteen.  begin(lane_row, colb) is called once per accumulator with this lane's first row
+// (wm*WTM + 32*i + 4*lh) and column byte offset inside the tile row; c = (r & 3) + 8 * (r >> 2) is a compile-time constant.
+struct RowsAffine {            // consecutive rows of a row-major [M][N] matrix (forward, split-K slabs)
+  int M, m_block; uint32_t n4, nb4;      // n4 = 4*N, nb4 = 4*n_block
+  uint32_t vbase; int left;
+  __device__ __forceinline__ void begin(int lane_row, uint32_t colb) {
+    const int m = m_block + lane_row;
+    vbase = (uint32_t)m * n4 + nb4 + colb;
+    left = M - m;
+  }
+  __device__ __forceinline__ uint32_t voff(int) const { return vbase; }
+  __device__ __forceinline__ uint32_t soff(int c) const { return (uint32_t)c * n4; }
+  __device__ __forceinline__ bool valid(int c) const { return c < left; }
+};
+struct RowsTable {             // rows map to arbitrary pixels: a table in LDS of byte offsets (or OOB_OFF), one per tile row (grad-input)
+  const uint32_t* table; uint32_t nb4;
+  const uint32_t* p; uint32_t colb;
+  __device__ __forceinline__ void begin(int lane_row, uint32_t colb_) { p = table + lane_row; colb = nb4 + colb_; }
+  __device__ __forceinline__ uint32_t voff(int c) const { return p[c] + colb; }      // OOB_OFF + (< 2^31) stays out of range
+  __device__ __forceinline__ uint32_t soff(int) const { return 0u; }
+  __device__ __forceinline__ bool valid(int c) const { return p[c] < OOB_OFF; }
+};
+__device__ __forceinline__ float buf_load1s(rsrc_t r, uint32_t voff, uint32_t soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void buf_store1s(rsrc_t r, uint32_t voff, uint32_t soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0); }
+// fence between the accumulators of the epilogue: nothing is scheduled or kept alive across it (the compiler otherwise hoists the
+// address arithmetic and the aux reads of all accumulators to the front — seen: 250+ spilled VGPRs)
+__device__ __forceinline__ void epi_fence() { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+// What makes this epilogue fast or slow is the in-order vmcnt: waiting for ANY load means waiting for every store issued before
+// it, and a tile's stores complete only after a trip through a memory system that every workgroup is writing into.  So: all
+// per-column constants are loaded before the first store, and the aux reads of accumulator k+1 are issued BEFORE the stores of
+// accumulator k (the counted wait then leaves exactly those stores in flight).  The fp64 column sums sit behind a wave-uniform
+// branch; a lane whose column lies outside N is masked off for the whole accumulator.
+template <class Cfg, class Rows>
+__device__ __forceinline__ void igemm_store_regs(f32x16 (&acc)[Cfg::TM][Cfg::TN], int n_block, int N, const float* bias, Rows rows,
+                                                 const EpiBufs& eb, double* stat_row, int act, float slope, const EpiAux* epi) {
+  // Opaque copy of the thread index: everything below that depends only on it is loop-invariant over the workgroup's tiles, and the
+  // compiler would hoist it out of the tile loop and keep it alive — i.e. spill it — across the main loop.
+  int tix = threadIdx.x;
+  asm volatile("" : "+v"(tix));
+  const int lane = tix & 63, wave = tix >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N, li = lane & 31, lh = lane >> 5;
+  const int emode = epi ? epi->mode : EPI_NONE;       // wave-uniform
+  const bool want_sums = stat_row != nullptr;         // wave-uniform
+  const float neg = epi ? epi->neg : 1.f;
+  constexpr int NA = Cfg::TM * Cfg::TN;               // accumulators of the wave tile, visited j-major: k = j * TM + i
+  int ncol[Cfg::TN];
+  float bv[Cfg::TN], mu[Cfg::TN], is[Cfg::TN], sc[Cfg::TN], sh[Cfg::TN];
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {                 // every per-column load before the first store
+    const int n = n_block + wn * Cfg::WTN + 32 * j + li;
+    const bool ok = n < N;
+    ncol[j] = ok ? n : -1;
+    bv[j] = (bias && ok) ? bias[n] : 0.f;
+    mu[j] = 0.f; is[j] = 1.f; sc[j] = 1.f; sh[j] = 0.f;
+    if ((emode == EPI_BNBWD || emode == EPI_ADDSUM) && ok) { mu[j] = epi->mean[n]; is[j] = epi->invstd[n]; }
+    if (emode == EPI_BNBWD && ok) bn_fold(epi->gamma[n], epi->beta[n], mu[j], is[j], sc[j], sh[j]);
+  }
+  auto rows_of = [&](int k) {
+    Rows rw = rows;
+    rw.begin(wm * Cfg::WTM + 32 * (k % Cfg::TM) + 4 * lh, (uint32_t)(4 * (wn * Cfg::WTN + 32 * (k / Cfg::TM) + li)));
+    return rw;
+  };
+#ifdef PCG_EPI_LEAN   // measurement-only build: the plain epilogue without statistics, nothing else compiled in
+  {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int j = k / Cfg::TM, i = k % Cfg::TM;
+      if (ncol[j] >= 0) {
+        const Rows rw = rows_of(k);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bv[j];
+          if (act != PCG_ACT_NONE) v = act_neg_scale(v, slope);
+          buf_store1s(eb.out, rw.voff(c), rw.soff(c), v);
+        }
+      }
+      epi_fence();
+    }
+    return;
+  }
+#endif
+  double s1 = 0.0, s2 = 0.0;
+  auto flush_sums = [&](int j) {
+    double* pr = stat_row + (size_t)wm * 2 * N;       // [wm][2][N] inside this tile row's slot
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (lh == 0 && ncol[j] >= 0) { pr[ncol[j]] = s1; pr[N + ncol[j]] = s2; }
+    s1 = 0.0; s2 = 0.0;
+  };
+  if (emode == EPI_NONE) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const int j = k / Cfg::TM, i = k % Cfg::TM;
+      if (ncol[j] >= 0) {
+        const Rows rw = rows_of(k);
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          v[r] = acc[i][j][r] + bv[j];
+          if (act != PCG_ACT_NONE) v[r] = act_neg_scale(v[r], slope);
+          buf_store1s(eb.out, rw.voff(c), rw.soff(c), v[r]);
+        }
+        if (want_sums) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const double d = rw.valid((r & 3) + 8 * (r >> 2)) ? (double)v[r] : 0.0; s1 += d; s2 = fma(d, d, s2); }
+        }
+      }
+      if (want_sums && i == Cfg::TM - 1) flush_sums(j);
+      epi_fence();
+    }
+    return;
+  }
+  // backward-pass epilogues: aux reads software-pipelined one accumulator ahead of the stores
+  float u[2][16];
+  auto load_aux = [&](int k, float (&dst)[16], rsrc_t rs) {
+    if (ncol[k / Cfg::TM] >= 0) {
+      const Rows rw = rows_of(k);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int c = (r & 3) + 8 * (r >> 2); dst[r] = buf_load1s(rs, rw.voff(c), rw.soff(c)); }
+    }
+  };
+  load_aux(0, u[0], eb.aux);
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const int j = k / Cfg::TM, i = k % Cfg::TM;
+    if (k + 1 < NA) load_aux(k + 1, u[(k + 1) & 1], eb.aux);
+    float (&uu)[16] = u[k & 1];
+    if (ncol[j] >= 0) {
+      const Rows rw = rows_of(k);
+      if (emode == EPI_ADD || emode == EPI_ADDSUM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float v = acc[i][j][r] + uu[r];
+          buf_store1s(eb.out, rw.voff(c), rw.soff(c), v);
+          acc[i][j][r] = v;                          // EPI_ADDSUM needs the sum once more
+        }
+        if (emode == EPI_ADDSUM && want_sums) {       // the second aux tensor (the next BatchNorm's pre-normalisation output)
+          float z[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const int c = (r & 3) + 8 * (r >> 2); z[r] = buf_load1s(eb.aux2, rw.voff(c), rw.soff(c)); }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const double d = rw.valid((r & 3) + 8 * (r >> 2)) ? (double)neg * (double)acc[i][j][r] : 0.0;
+            s1 += d; s2 = fma(d, (double)((z[r] - mu[j]) * is[j]), s2);
+          }
+        }
+      } else {                                        // EPI_MASK (sc = 1, sh = 0) / EPI_BNBWD: the forward's own expression for the sign
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float pre = fmaf(uu[r], sc[j], sh[j]);
+          v[r] = acc[i][j][r] * (pre > 0.f ? 1.f : neg);
+          buf_store1s(eb.out, rw.voff(c), rw.soff(c), v[r]);
+        }
+        if (want_sums) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const double d = rw.valid((r & 3) + 8 * (r >> 2)) ? (double)v[r] : 0.0;
+            s1 += d; s2 = fma(d, (double)((uu[r] - mu[j]) * is[j]), s2);
+          }
+        }
+      }
+    }
+    if (want_sums && i == Cfg::TM - 1) flush_sums(j);
+    epi_fence();
+  }
+}
+
+#endif  // PCG_PERSISTENT_KERNELS
 
 // Accumulator element (tile i,j ; register r) of lane (li,lh) sits at
 //   row = 32*i + (r&3) + 8*(r>>2) + 4*lh   col = 32*j + li      (within the wave tile)

@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--ab", default=None, help="A/B a tuning switch in THIS process, interleaved rounds: e.g. korder=0,1 or wgrad_order=0,1 "
                                                "(ops.tune / pcg_tune_set); prints the median and min ms per variant")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--timeline", type=int, default=0, help="with --clock: print the per-tile timeline (loop end / epilogue end, us since the "
+                                                            "stream began) of this many workgroups of the persistent kernels")
     ap.add_argument("--clock", action="store_true", help="report the in-kernel clock (needs the stamp build: make -C csrc stamp; "
                                                          "PCG_LIB=.../csrc/build_stamp/libpcgan_hip.so)")
     args = ap.parse_args()
@@ -48,12 +50,29 @@ def main():
     dev = torch.device("cuda:0")
     stamps = None
     if args.clock:
-        stamps = torch.zeros(2 * 65536, dtype=torch.int64, device=dev)
+        stamps = torch.zeros(4 * 65536, dtype=torch.int64, device=dev)
         if lib.pcg_debug_stamp_buffer(stamps.data_ptr(), stamps.numel() * 8) != 1:
             sys.exit("--clock: this libpcgan_hip.so has no stamp code; make -C promptable-counterfactual-gan_amd/csrc stamp and set PCG_LIB")
 
     def clock_mhz():
-        st = stamps.view(-1, 2).cpu().double()
+        half = stamps.numel() // 2
+        if args.timeline:
+            tl = stamps[half:].cpu().view(-1)
+            nb = 0
+            t00 = None
+            rows = []
+            for b in range(min(1024, (half // 2) // 36 if False else 1024)):
+                rec = tl[b * 34:(b + 1) * 34]
+                if int(rec[0]) == 0:
+                    continue
+                rows.append((b, int(rec[0]), int(rec[1]), [int(v) / 100.0 for v in rec[2:] if int(v) > 0]))
+            if rows:
+                t00 = min(r[1] for r in rows)
+                for b, r0, hw, ev in rows[:args.timeline]:
+                    cu = (hw >> 8) & 15; se = (hw >> 13) & 7; tg = (hw >> 16) & 15; simd = (hw >> 4) & 3
+                    print(f"    wg {b:4d} start +{(r0 - t00) / 100.0:6.1f} us hw_id 0x{hw:08x} (se {se} cu {cu} tg {tg}) | " +
+                          " ".join(f"{v:.1f}" for v in ev))
+        st = stamps[:half].view(-1, 2).cpu().double()
         st = st[st[:, 1] > 0]
         stamps.zero_()
         if st.numel() == 0:
