@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, PcgError
-from .nn import FlatModule
+from .nn import weighted_sum, FlatModule
 from .optim import Adam
 
 
@@ -752,7 +752,7 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
     if d_real_logits is None:
         d_real_logits = discriminator(x, y)                                            # :103
     d_fake_logits = discriminator(x_cf.detach(), target_y)                             # :104
-    d_loss = bce(d_real_logits, 1.0) + bce(d_fake_logits, 0.0)                         # :106-107
+    d_loss = weighted_sum([bce(d_real_logits, 1.0), bce(d_fake_logits, 0.0)], [1.0, 1.0])   # :106-107 (one launch each way, no ATen add)
     d_loss.backward()                                                                  # :111
     if dp is not None:
         dp.sync_now(discriminator)
@@ -767,7 +767,8 @@ def train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y
         g_adv = bce(g_fake_logits, 1.0)                                                # :117
         g_cls = ce(classifier(x_cf), target_y)                                         # :118
         reg_l1 = abs_mean(masked_residual)                                             # :119
-        g_loss = cfg.lambda_adv * g_adv + cfg.lambda_cls * g_cls + cfg.lambda_reg * reg_l1 + cfg.lambda_mask * mask_penalty_pre  # :121
+        g_loss = weighted_sum([g_adv, g_cls, reg_l1, mask_penalty_pre],
+                              [cfg.lambda_adv, cfg.lambda_cls, cfg.lambda_reg, cfg.lambda_mask])   # :121 (was seven ATen mul / add launches)
         g_loss.backward()                                                              # :122
     finally:
         if skip_dead_d_wgrad:

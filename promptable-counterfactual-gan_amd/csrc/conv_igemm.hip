@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, true, true>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
+  ClockStamp cs{p.stamps, p.stamp_slots};
+  cs.phase(0);
+  igemm_consume<Cfg, true, true>(ktiles, acc, smem, cs);
   float* out = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
 #ifdef PCG_ABL_NO_EPILOGUE   // timing-only ablation: keep one store so the accumulators stay live
   if (acc[0][0][0] == 12345.678f) out[0] = acc[0][0][1];
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
     const int m = m_block + row;
     return m < p.M ? out + (size_t)m * p.N + n_block : nullptr;
   }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+  cs.phase(3);
 }
 
 template <class Cfg, bool XF>

@@ -241,6 +241,12 @@ struct ClockStamp {
     const int b = blockIdx.x + gridDim.x * blockIdx.y;
     if (out && threadIdx.x == 0 && b < slots) { out[2 * b] = t1 - t0; out[2 * b + 1] = r1 - r0; }
   }
+  // phase stamps of the one-tile-per-workgroup kernels (third quarter of the buffer, 4 words per block): absolute 100 MHz ticks at
+  // kernel entry, main-loop begin, main-loop end, epilogue end — where a launch's time outside its main loops goes
+  __device__ __forceinline__ void phase(int k) {
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (out && threadIdx.x == 0 && b < slots / 8) out[(size_t)slots + (size_t)b * 4 + k] = __builtin_amdgcn_s_memrealtime();
+  }
   // per-tile timeline of the persistent kernels (second half of the buffer: 2 + 32 words per block): mark(k) = 100 MHz ticks since begin();
   // word 0 = begin() on the chip-wide 100 MHz clock (start skew between blocks), word 1 = hardware id
   __device__ __forceinline__ void mark(int k) {
@@ -255,6 +261,7 @@ struct ClockStamp {
   __device__ __forceinline__ void begin() {}
   __device__ __forceinline__ void end() {}
   __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void phase(int) {}
 #endif
 };
 
@@ -296,7 +303,7 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
   lds_barrier();  // barrier 0: stage 0 is ready
   if (ktiles <= 0) return;
   __builtin_amdgcn_s_setprio(2);
-  cs.begin();
+  cs.begin(); cs.phase(1);
   fetch(As, Bs, 0, 0);
   int cur = 0;
   for (int kt = 0; kt < ktiles; ++kt) {
@@ -312,7 +319,7 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
     if (kt + 1 < ktiles) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
     mma((KG - 1) & 1);
   }
-  cs.end();
+  cs.end(); cs.phase(2);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -344,6 +351,10 @@ struct EpiAux {
   int64_t delta2_bytes;     // EPI_ADDSUM: (char*)z_next - (char*)out
   const float* mean; const float* invstd; const float* gamma; const float* beta;   // EPI_BNBWD, per output column
 };
+
+// the tile's output store: plain write-back stores.  Measured r03 (whole DCGAN step, two rounds each): non-temporal stores 11.13 vs
+// 11.11 ms, write-through (sc1) 11.15 — the dirty lines the kernel boundary has to write back are not what a launch's tail costs.
+__device__ __forceinline__ void epi_store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
@@ -385,7 +396,7 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
         if (act != PCG_ACT_NONE) {   // wave-uniform; ReLU / LeakyReLU only (slope = 0 / negative slope), others are applied by the host wrapper
           v.x = act_neg_scale(v.x, slope); v.y = act_neg_scale(v.y, slope); v.z = act_neg_scale(v.z, slope); v.w = act_neg_scale(v.w, slope);
         }
-        *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+        epi_store4(dst + wn * Cfg::WTN + 4 * cq, v);
         if (want_sums) {
           const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
           s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
@@ -434,7 +445,7 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
           float4 v = *reinterpret_cast<const float4*>(reg + row * LDW + 4 * cq);
           const float4 z = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta2);
           v.x += u[kk].x; v.y += u[kk].y; v.z += u[kk].z; v.w += u[kk].w;
-          *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+          epi_store4(dst + wn * Cfg::WTN + 4 * cq, v);
           if (want_sums) {
             const double d0 = sc2 * (double)v.x, d1 = sc2 * (double)v.y, d2 = sc2 * (double)v.z, d3 = sc2 * (double)v.w;
             s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
@@ -457,7 +468,7 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
           const float4 pre = make_float4(fmaf(u[kk].x, sc.x, sh.x), fmaf(u[kk].y, sc.y, sh.y), fmaf(u[kk].z, sc.z, sh.z), fmaf(u[kk].w, sc.w, sh.w));
           v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;
         }
-        *reinterpret_cast<float4*>(dst + wn * Cfg::WTN + 4 * cq) = v;
+        epi_store4(dst + wn * Cfg::WTN + 4 * cq, v);
         if (want_sums) {
           s1[0] += (double)v.x; s1[1] += (double)v.y; s1[2] += (double)v.z; s1[3] += (double)v.w;
           s2[0] = fma((double)v.x, (double)((u[kk].x - mu.x) * is.x), s2[0]); s2[1] = fma((double)v.y, (double)((u[kk].y - mu.y) * is.y), s2[1]);

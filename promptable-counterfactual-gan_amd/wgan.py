@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import ACT_LRELU, PcgError
-from .nn import FlatModule, GraphedStep, SequentialConvNet, _compile, linear_dgrad, linear_fwd, linear_wgrad, mean
+from .nn import FlatModule, GraphedStep, SequentialConvNet, _compile, linear_dgrad, linear_fwd, linear_wgrad, mean, weighted_sum
 from .optim import AdamW
 
 
@@ -406,7 +406,7 @@ def critic_step(critic, generator, critic_optimizer, hp, real_images, real_class
     gradients = torch.autograd.grad(d_interpolates, interpolates, _ones_like_out(critic, B, real_images.device),
                                     create_graph=True, only_inputs=True)[0]              # :149
     gp = gradient_penalty(gradients, hp.gp_lambda)                                       # :150
-    critic_loss = -critic_loss_real + critic_loss_fake + gp                              # :152
+    critic_loss = weighted_sum([critic_loss_real, critic_loss_fake, gp], [-1.0, 1.0, 1.0])   # :152
     critic_loss.backward()                                                               # :154
     if dp is not None:
         dp.sync_now(critic)
@@ -424,7 +424,7 @@ def generator_step(critic, generator, generator_optimizer, fake_class_labels, no
             p.requires_grad_(False)
     try:
         fake_image = generator(noise, fake_class_labels)                                 # :163
-        generator_loss = -mean(critic(fake_image, fake_class_labels))                    # :164-165
+        generator_loss = weighted_sum([mean(critic(fake_image, fake_class_labels))], [-1.0])   # :164-165 (no ATen neg launch)
         generator_loss.backward()                                                        # :167
     finally:
         if skip_dead_critic_wgrad:

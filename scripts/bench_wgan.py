@@ -80,18 +80,19 @@ def main():
     cpu = None
     if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline:
         from oracle import wgan_ref as WR                 # the checker's restatement: CPU-baseline leg only
-        cb = 32                                           # full width on the CPU: ~2 s per critic update at 32 images
+        cb = B                                            # AT THE GPU BATCH (r02 timed 32 images against the GPU's 256), full width
         ohp = WR.Hyperparameter()
         ohp.critic_size = ohp.generator_size = ohp.critic_hidden_size = args.width
         ocr, og_ = WR.build(ohp, seed=1)
         oc_opt, og_opt = WR.make_optimizers(ocr, og_)
         xb, yb, zb, ab, y2, z2 = WR.synthetic_batch(ohp, cb, seed=0)
-        mc, thr, avail = BL.cpu_median(lambda: WR.critic_step(ocr, og_, oc_opt, ohp, xb, yb, zb, ab), steps=3, threads=args.cpu_threads)
-        mg, _, _ = BL.cpu_median(lambda: WR.generator_step(ocr, og_, og_opt, y2, z2), steps=3, threads=args.cpu_threads)
+        ns, nw = (1, 0) if cb > 64 else (3, 1)            # a bounded sample: one update of each kind at the full batch
+        mc, thr, avail = BL.cpu_median(lambda: WR.critic_step(ocr, og_, oc_opt, ohp, xb, yb, zb, ab), steps=ns, warmup=nw, threads=args.cpu_threads)
+        mg, _, _ = BL.cpu_median(lambda: WR.generator_step(ocr, og_, og_opt, y2, z2), steps=ns, warmup=nw, threads=args.cpu_threads)
         cpu = {"value": round(cb / (mc + mg / hp.n_critic), 2), "unit": "images/sec", "cores": thr, "kind": "port", "cpu_model": BL.cpu_model(),
                "host_cpus_visible": avail,
-               "sample": f"median of 3 critic updates + 3 generator updates at batch {cb}, width {args.width} (GPU run: {B} per GPU), "
-                         f"1 warm-up each, combined with the 1/n_critic weight; PyTorch-CPU fp32 restatement of mnist_wgan_conditional.py:133-168"}
+               "sample": f"{ns} critic update(s) + {ns} generator update(s) at batch {cb} (= the GPU run's batch per GPU), width {args.width}, "
+                         f"{nw} warm-up each, combined with the 1/n_critic weight; PyTorch-CPU fp32 restatement of mnist_wgan_conditional.py:133-168"}
     if R.rank == 0:
         roof = BL.conv_family_roofline(records, it, 1, flops_it, traffic=BL.pmc_traffic("wgan"))
         if roof:

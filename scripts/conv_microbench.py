@@ -72,6 +72,14 @@ def main():
                     cu = (hw >> 8) & 15; se = (hw >> 13) & 7; tg = (hw >> 16) & 15; simd = (hw >> 4) & 3
                     print(f"    wg {b:4d} start +{(r0 - t00) / 100.0:6.1f} us hw_id 0x{hw:08x} (se {se} cu {cu} tg {tg}) | " +
                           " ".join(f"{v:.1f}" for v in ev))
+        ph = stamps[half:half + half // 2].cpu().view(-1, 4).double()
+        ph = ph[(ph[:, 0] > 0) & (ph[:, 3] > 0)]
+        clock_mhz.phases = None
+        if ph.shape[0] > 0:
+            t0 = ph[:, 0].min()
+            med = lambda v: float(v.median()) / 100.0
+            clock_mhz.phases = (med(ph[:, 0] - t0), med(ph[:, 1] - ph[:, 0]), med(ph[:, 2] - ph[:, 1]), med(ph[:, 3] - ph[:, 2]),
+                                float(ph[:, 3].max() - t0) / 100.0, float((ph[:, 3] - t0).median()) / 100.0)
         st = stamps[:half].view(-1, 2).cpu().double()
         st = st[st[:, 1] > 0]
         stamps.zero_()
@@ -148,6 +156,10 @@ def main():
                 c = clock_mhz()
                 lo = clock_mhz.loop
                 extra = f"  in-kernel clock {c:5.0f} MHz; main loop per block med/min/max {lo[0]:.1f}/{lo[1]:.1f}/{lo[2]:.1f} us over {lo[3]} blocks"
+                if clock_mhz.phases:
+                    q = clock_mhz.phases
+                    extra += (f"\n        phases (us, medians over blocks of the LAST launch): entry skew {q[0]:.1f}, entry->loop {q[1]:.1f}, loop {q[2]:.1f}, "
+                              f"epilogue {q[3]:.1f}; last block done at {q[4]:.1f} (median block at {q[5]:.1f}) after the first entry")
             print(f"{name:4s} {op:6s} M/N/K-ish B={B} {Cin:4d}->{Cout:4d} {H:3d}x{H:<3d} k{k}s{s}p{p}  {ms:8.4f} ms  {flops / ms / 1e9:7.2f} TFLOP/s{extra}", flush=True)
     if tot_t > 0:
         print(f"TOTAL {tot_f / tot_t / 1e12:.2f} TFLOP/s over {tot_t * 1e3:.3f} ms")
