@@ -389,7 +389,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -447,6 +447,9 @@ template <class Cfg>
 unsigned persistent_grid(uint64_t items) {
   const unsigned slots = (unsigned)cu_count() * (Cfg::MINW >= 6 ? 3u : 2u);
   unsigned g = items < slots ? (unsigned)items : slots;
+  // persist_tiles = T > 0: T tiles per workgroup instead of all-resident workgroups — more workgroups than slots, dispatched in
+  // rounds, so they desynchronise like the one-tile kernels while a workgroup's second .. T-th prologue is pipelined away
+  if (g_tune.persist_tiles > 0) g = (unsigned)((items + g_tune.persist_tiles - 1) / g_tune.persist_tiles);
   if (g >= 8) g &= ~7u;                          // TileWalk: a multiple of 8 keeps the per-XCD runs
   return g ? g : 1u;
 }
@@ -495,13 +498,20 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
   const int tiles = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64);
   const int ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
   FwdPlan f{1, ktiles};
+  if (g_tune.fwd_splits > 0) {               // A/B override (pcg_tune_set("fwd_splits", s)): s K-slices whatever the shape
+    f.ktiles_per_split = ceil_div(ktiles, g_tune.fwd_splits);
+    f.splits = ceil_div(ktiles, f.ktiles_per_split);
+    return f;
+  }
   if (tiles > 256 && tiles < 448 && ktiles >= 32) {
     // a little over one block per CU (288 tiles: 32 CUs get two full-K blocks, the others one — the critic's conv2 at batch 256
-    // ran at 73 TFLOP/s): 3-4 K-slices bring the blocks per CU to ceil(tiles*s/256)/s ~ 1.25 instead of 2
+    // ran at 73 TFLOP/s): a few K-slices bring the blocks per CU to ceil(tiles*s/256)/s.  Each slice also costs a slab of M*N
+    // floats written and read: measured r03 (scripts/probes/fwd_splits_scan.py, 288 tiles x 72 k-tiles) 1: 283, 2: 241, 3: 221,
+    // 4: 256 us — the slab term is worth ~0.1 of a block per slice.
     int best = 1;
     double bc = 2.0;
     for (int s = 2; s <= 4; ++s) {
-      const double c = (double)ceil_div(tiles * s, 256) / s;
+      const double c = (double)ceil_div(tiles * s, 256) / s + 0.1 * s;
       if (c < bc - 1e-9) { bc = c; best = s; }
     }
     f.ktiles_per_split = ceil_div(ktiles, best);
@@ -509,7 +519,7 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
     return f;
   }
   if (tiles > 96 || ktiles < 32) return f;
-  int splits = ceil_div(384, tiles);
+  int splits = ceil_div(tiles >= 48 ? 512 : 384, tiles);     // (64 tiles x 144 k-tiles, r03 scan: 6 slices 115 us, 8 slices 101)
   if (splits > ktiles / 8) splits = ktiles / 8;
   if (splits < 2) return f;
   f.ktiles_per_split = ceil_div(ktiles, splits);
@@ -1057,6 +1067,8 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
   else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
+  else if (!strcmp(name, "persist_tiles")) g_tune.persist_tiles = value;
+  else if (!strcmp(name, "fwd_splits")) g_tune.fwd_splits = value;
   else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;
 }
