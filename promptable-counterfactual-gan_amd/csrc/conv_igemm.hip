@@ -38,10 +38,12 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
 
   if (wave_id() >= 4) {  // producers
     const int tid = threadIdx.x - IG_LOADERS;
-    FwdALoader<Cfg::BM, XF> la(p, m_block, tid);
-    FwdBLoader<Cfg::BN> lb(p, n_block, tid);
+    constexpr bool DMA = Cfg::DMA && !XF;
+    FwdALoader<Cfg::BM, XF> la(p, m_block, tid, DMA);
+    FwdBLoader<Cfg::BN> lb(p, n_block, tid, DMA);
     if (kt_begin) { la.seek(kt_begin); lb.seek(kt_begin); }
-    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    if constexpr (DMA) igemm_produce_dma<Cfg>(la, lb, ktiles, smem, tid, ClockStamp{p.stamps, p.stamp_slots});
+    else igemm_produce<Cfg>(la, lb, ktiles, smem, tid, ClockStamp{p.stamps, p.stamp_slots});
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -364,6 +366,7 @@ __global__ void __launch_bounds__(256) col2im_kernel(const float4* __restrict__ 
 // host side
 // ------------------------------------------------------------------------------------------------
 using Cfg128x128 = TileCfg<128, 128, 2, 2>;
+using Cfg128x128D = TileCfg<128, 128, 2, 2, true, 4, PCG_PREFETCH_DEPTH, true>;   // operands by LDS-DMA into unpadded swizzled images
 #ifndef PCG_TILE64_SWZ
 #define PCG_TILE64_SWZ 1     // 128x64 tiles: swizzled unpadded LDS images, three workgroups per CU (0: the r01 layout, two per CU)
 #endif
@@ -389,7 +392,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -695,7 +698,10 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   const bool fuse = act_is_cheap(act) && f.splits == 1;   // the epilogue fuses ReLU / LeakyReLU; tanh / sigmoid run as a second pass
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   if (f.splits > 1) { p.out = (float*)workspace; p.ktiles_per_split = f.ktiles_per_split; }
-  if (int e = p.N > 64 ? launch_fwd<Cfg128x128>(p, f.splits, s) : launch_fwd<Cfg128x64>(p, f.splits, s)) return e;
+  static const int dma_env = getenv("PCG_DMA") ? atoi(getenv("PCG_DMA")) : 0;
+  const bool dma = (g_tune.dma >= 0 ? g_tune.dma : dma_env) != 0 && !p.in_sc;
+  if (int e = p.N > 64 ? (dma ? launch_fwd<Cfg128x128D>(p, f.splits, s) : launch_fwd<Cfg128x128>(p, f.splits, s))
+                       : launch_fwd<Cfg128x64>(p, f.splits, s)) return e;
   if (f.splits > 1) {
     const size_t n = (size_t)p.M * p.N;
     if (int e = launch_slab_reduce((const float*)workspace, y, n, n, f.splits, 0, s)) return e;
@@ -1069,6 +1075,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
   else if (!strcmp(name, "persist_tiles")) g_tune.persist_tiles = value;
   else if (!strcmp(name, "fwd_splits")) g_tune.fwd_splits = value;
+  else if (!strcmp(name, "dma")) g_tune.dma = value;
   else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;
 }

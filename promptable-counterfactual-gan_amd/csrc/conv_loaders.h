@@ -141,12 +141,15 @@ struct FwdALoader {
   FwdKIter it;
   XfK xf;
 
-  __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block, int tid) {
+  // src_swz: LDS-DMA staging (igemm_produce_dma) — the destination of a lane is fixed (base + lane * 16), so the XOR swizzle of the
+  // unpadded K-major image is applied on the SOURCE side: the lane at chunk position tid & 7 of row r fetches the logical chunk
+  // (tid & 7) ^ ((r >> 1) & 7), the same involution LdsImage<.., SWZ>::frag applies on the read side
+  __device__ __forceinline__ FwdALoader(const ConvP& p, int m_block, int tid, bool src_swz = false) {
     if constexpr (XF) xf.init(p);
     rs = make_rsrc(p.x, p.x_bytes);
     IW = p.IW; Cin = p.Cin; KW = p.KW;
     it.init(p);
-    kq4 = (tid & 7) * 4;
+    kq4 = (src_swz ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7)) * 4;
     const int r0 = tid >> 3;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -165,6 +168,16 @@ struct FwdALoader {
   }
   // start at k-tile kt (split-K)
   __device__ __forceinline__ void seek(int kt) { it.seek(kt); }
+  // byte offsets of the next k-tile's NV gathers (OOB_OFF where the hardware is to deliver zeros); advances to the following k-tile
+  __device__ __forceinline__ void next_offsets(uint32_t (&off)[NV]) {
+    const int kh = it.kh(), kw = it.kw(), ci0 = it.ci0;
+    const int tap = kh * KW + kw;
+    const uint32_t delta = (uint32_t)(((kh * IW + kw) * Cin + ci0) * 4);
+    const bool kok = kq4 < Cin - ci0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) off[i] = (kok && ((mask[i] >> tap) & 1u)) ? base[i] + delta : OOB_OFF;
+    it.advance();
+  }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const int kh = it.kh(), kw = it.kw(), ci0 = it.ci0;
     const int tap = kh * KW + kw;
@@ -198,9 +211,9 @@ struct FwdBLoader {
   int Cin, KW, kq4;
   FwdKIter it;
 
-  __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block, int tid) {
+  __device__ __forceinline__ FwdBLoader(const ConvP& p, int n_block, int tid, bool src_swz = false) {
     rs = make_rsrc(p.w, p.w_bytes);
-    Cin = p.Cin; KW = p.KW; kq4 = (tid & 7) * 4;
+    Cin = p.Cin; KW = p.KW; kq4 = (src_swz ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7)) * 4;
     it.init(p);
     const int r0 = tid >> 3;
     const int Ktot = p.KH * p.KW * p.Cin;
@@ -211,6 +224,14 @@ struct FwdBLoader {
     }
   }
   __device__ __forceinline__ void seek(int kt) { it.seek(kt); }
+  __device__ __forceinline__ void next_offsets(uint32_t (&off)[NV]) {
+    const int ci0 = it.ci0;
+    const uint32_t delta = (uint32_t)(((it.kh() * KW + it.kw()) * Cin + ci0) * 4);
+    const bool kok = kq4 < Cin - ci0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) off[i] = kok ? base[i] + delta : OOB_OFF;
+    it.advance();
+  }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     const int ci0 = it.ci0;
     const uint32_t delta = (uint32_t)(((it.kh() * KW + it.kw()) * Cin + ci0) * 4);

@@ -56,16 +56,27 @@ constexpr int IG_BK = 32;
 #ifndef PCG_PREFETCH_DEPTH
 #define PCG_PREFETCH_DEPTH 2               // k-tiles of operand gathers in flight per producer thread (1: the r01 pipeline)
 #endif
+#ifndef PCG_CONSUMER_PRIO
+#define PCG_CONSUMER_PRIO 2                // s_setprio of the consumer waves inside their main loop (A/B builds: 0, 1, 2)
+#endif
+#ifndef PCG_CONSUMER_ALTERNATE
+#define PCG_CONSUMER_ALTERNATE 256
+#endif
+#ifndef PCG_PRODUCER_PRIO
+#define PCG_PRODUCER_PRIO 3                // s_setprio of the producer waves: ABOVE the consumers (r03, see igemm_produce)
+#endif
 constexpr int IG_LDK = IG_BK + 4;          // K-major row stride: 144 B = 9*16 (aligned for b128, conflict-free)
 
 // SWZ_: K-major LDS images without row padding, 16-byte chunks XOR-swizzled by the row (LdsImage): 128x64 tiles then need 49 KB
 //       instead of 55 KB and THREE workgroups fit a CU's 160 KB — while one of them is in its prologue / epilogue the SIMD still
 //       hosts two consumer waves (one wave alone does not keep the MFMA pipe full).  MINW_: waves per SIMD the register budget
 //       must allow (launch bounds); PF_: k-tiles of gathers in flight per producer thread (register sets).
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool SWZ_ = false, int MINW_ = 4, int PF_ = PCG_PREFETCH_DEPTH>
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool SWZ_ = false, int MINW_ = 4, int PF_ = PCG_PREFETCH_DEPTH, bool DMA_ = false>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
   static constexpr bool SWZ = SWZ_;
+  static constexpr bool DMA = DMA_;          // operand tiles go global -> LDS directly (buffer_load ... lds), see igemm_produce_dma
+  static_assert(!DMA_ || SWZ_, "LDS-DMA needs the lane-linear (unpadded, swizzled) K-major images");
   static constexpr int MINW = MINW_, PF = PF_;
   static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   static constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -145,17 +156,86 @@ constexpr int igemm_smem_floats() {
   return 2 * (LdsImage<Cfg::BM, AK, Cfg::SWZ>::FLOATS + LdsImage<Cfg::BN, BK_, Cfg::SWZ>::FLOATS);
 }
 
+// Diagnostic build (-DPCG_CLOCK_STAMP): the clock the chip holds INSIDE the main loop = delta s_memtime / delta s_memrealtime x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6), one pair per block, written to a buffer nothing else reads.
+struct ClockStamp {
+  unsigned long long* out; int slots;
+#ifdef PCG_CLOCK_STAMP
+  unsigned long long t0, r0;
+  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  __device__ __forceinline__ void end() {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (out && threadIdx.x == 0 && b < slots) { out[2 * b] = t1 - t0; out[2 * b + 1] = r1 - r0; }
+  }
+  // phase stamps of the one-tile-per-workgroup kernels (third quarter of the buffer, 4 words per block): absolute 100 MHz ticks at
+  // kernel entry, main-loop begin, main-loop end, epilogue end — where a launch's time outside its main loops goes
+  __device__ __forceinline__ void phase(int k) {
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (out && threadIdx.x == 0 && b < slots / 8) out[(size_t)slots + (size_t)b * 4 + k] = __builtin_amdgcn_s_memrealtime();
+  }
+  // barrier-wait accounting (fourth quarter of the buffer, 4 words per block): shader cycles consumer wave 0 / producer wave 4
+  // spent inside the per-k-tile hand-over barrier (lgkmcnt wait + s_barrier), and their loop cycles — who waits for whom
+  unsigned long long bar_acc, bar_t, sec_acc[3], sec_t;
+  __device__ __forceinline__ void sec_begin() { sec_t = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void sec_end(int k) { const unsigned long long t = __builtin_amdgcn_s_memtime(); sec_acc[k] += t - sec_t; sec_t = t; }
+  __device__ __forceinline__ void bar_begin() { bar_t = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void bar_end() { bar_acc += __builtin_amdgcn_s_memtime() - bar_t; }
+  __device__ __forceinline__ void bar_init() { bar_acc = 0; sec_acc[0] = sec_acc[1] = sec_acc[2] = 0; }
+  __device__ __forceinline__ void bar_flush(int who, unsigned long long loop_cycles) {    // who: 0 consumer, 1 producer
+    const int b = blockIdx.x + gridDim.x * blockIdx.y;
+    if (out && (threadIdx.x & 63) == 0 && b < slots / 8) {
+      out[(size_t)slots + (size_t)slots / 2 + (size_t)b * 4 + 2 * who] = bar_acc;
+      out[(size_t)slots + (size_t)slots / 2 + (size_t)b * 4 + 2 * who + 1] = loop_cycles;
+      if (who == 1 && b < slots / 16) {       // producer sections: [0] waiting for gathers + ds_write issue, [1] gather issue
+        out[(size_t)slots + (size_t)slots / 2 + (size_t)slots / 4 + (size_t)b * 2] = sec_acc[0] | (sec_acc[2] << 32);   // [2]: pure wait for the gathers
+        out[(size_t)slots + (size_t)slots / 2 + (size_t)slots / 4 + (size_t)b * 2 + 1] = sec_acc[1];
+      }
+    }
+  }
+  // per-tile timeline of the persistent kernels (second half of the buffer: 2 + 32 words per block): mark(k) = 100 MHz ticks since begin();
+  // word 0 = begin() on the chip-wide 100 MHz clock (start skew between blocks), word 1 = hardware id
+  __device__ __forceinline__ void mark(int k) {
+    const int b = blockIdx.x;
+    if (out && threadIdx.x == 0 && b < slots / 36 && k < 32) {
+      unsigned long long* tl = out + 2 * (size_t)slots / 2 + (size_t)b * 34;     // second half of the buffer
+      tl[2 + k] = __builtin_amdgcn_s_memrealtime() - r0;
+      if (k == 0) { tl[0] = r0; tl[1] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }   // HW_REG_HW_ID, 32 bits
+    }
+  }
+#else
+  __device__ __forceinline__ void begin() {}
+  __device__ __forceinline__ void end() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void phase(int) {}
+  __device__ __forceinline__ void bar_begin() {}
+  __device__ __forceinline__ void bar_end() {}
+  __device__ __forceinline__ void bar_init() {}
+  __device__ __forceinline__ void bar_flush(int, unsigned long long) {}
+  __device__ __forceinline__ void sec_begin() {}
+  __device__ __forceinline__ void sec_end(int) {}
+#endif
+};
+
 // Loader concept (per-thread state of a producer thread, constructed with its loader-thread id 0..255):
 //   static constexpr bool KMAJOR; static constexpr int ROWS;
 //   __device__ void load_next(float4 (&v)[ROWS/32]);   // gathers the next k-tile (sequential) into registers
 //   __device__ void transform(float4 (&v)[ROWS/32]);   // applied to the registers of the last load_next before the ds_write
 template <class Cfg, class LA, class LB>
-__device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float* smem, int tid) {
+__device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float* smem, int tid, ClockStamp cs = ClockStamp{nullptr, 0}) {
   using IA = LdsImage<Cfg::BM, LA::KMAJOR, Cfg::SWZ>;
   using IB = LdsImage<Cfg::BN, LB::KMAJOR, Cfg::SWZ>;
   static_assert(LA::ROWS == Cfg::BM && LB::ROWS == Cfg::BN, "loader/tile mismatch");
   float* As = smem;
   float* Bs = smem + 2 * IA::FLOATS;
+  // The producers outrank the consumers in the SIMD's issue arbitration (r03).  They issue ~100 vector instructions per k-tile
+  // (addresses, selects, eight gathers, eight ds_writes); at priority 0 under priority-2 consumers, whose next MFMA is pending
+  // almost every cycle, each of those got about one issue slot per MFMA interval: stamps showed a producer wave 72-81 % of its
+  // k-tile inside its eight ds_writes (0.1 % waiting for its gathers) and the consumers 16-30 % of theirs in the hand-over barrier,
+  // waiting for it.  With the producers on top their instructions go out at once and cost the consumers next to nothing: D3
+  // forward 130.8 -> 140.2 TFLOP/s, D4 grad-input 133.5 -> 139.5, weight gradients +2 %; consumers at 0 / 1 / 2 make no
+  // difference, equal priorities lose the gain (scripts/conv_microbench.py on builds with -DPCG_CONSUMER_PRIO / -DPCG_PRODUCER_PRIO).
+  if (PCG_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(PCG_PRODUCER_PRIO);
   // loaders that carry an input transform keep ONE pending tile of transform state: they run the depth-1 pipeline
   if constexpr (Cfg::PF == 2 && !LA::XFORM && !LB::XFORM) {
   // Two k-tiles of gathers in flight.  One k-tile of MFMAs is 2048 (128x64 tile) .. 4096 cycles (128x128) = 1 .. 2 us, which is no
@@ -173,15 +253,50 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
     if (ktiles > 2) { la.load_next(ra[0]); lb.load_next(rb[0]); }   // tile 2
   }
   lds_barrier();  // barrier 0: stage 0 is ready
+  cs.bar_init();
+#ifdef PCG_CLOCK_STAMP
+  const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // invariant at the top of iteration kt: set (kt+1)&1 holds tile kt+1 (in flight or landed), set kt&1 holds tile kt+2
   int kt = 0;
-  for (; kt + 1 < ktiles; kt += 2) {
+  // Steady state WITHOUT conditionals (r03).  With the refills behind `if (kt + 3 < ktiles)` the compiler's wait-count pass lost
+  // track of what is in flight at the control-flow joins and put `s_waitcnt vmcnt(7) ... vmcnt(0)` in front of the eight ds_writes
+  // of a tile: the write of tile t+1 then waited for the gathers of tile t+2 as well — one k-tile of prefetch distance, not
+  // two, and in-kernel stamps showed the consumers 26-28 % of their loop in the hand-over barrier while the producers waited
+  // there 3-9 %.  Straight-line code gives the pass exact counts: vmcnt(8+..) leaves the younger tile's eight gathers in flight.
+#ifndef PCG_OLD_PRODUCER_LOOP   // (A/B builds)
+  for (; kt + 4 < ktiles; kt += 2) {
+    cs.sec_begin();
+#ifdef PCG_CLOCK_STAMP
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // (stamp build only) the older tile has landed: separates waiting from storing
+    cs.sec_end(2);
+#endif
+    IA::store(As + IA::FLOATS, ra[1], tid);
+    IB::store(Bs + IB::FLOATS, rb[1], tid);
+    cs.sec_end(0);
+    la.load_next(ra[1]); lb.load_next(rb[1]);
+    cs.sec_end(1);
+    cs.bar_begin(); lds_barrier(); cs.bar_end();
+    cs.sec_begin();
+#ifdef PCG_CLOCK_STAMP
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    cs.sec_end(2);
+#endif
+    IA::store(As, ra[0], tid);
+    IB::store(Bs, rb[0], tid);
+    cs.sec_end(0);
+    la.load_next(ra[0]); lb.load_next(rb[0]);
+    cs.sec_end(1);
+    cs.bar_begin(); lds_barrier(); cs.bar_end();
+  }
+#endif
+  for (; kt + 1 < ktiles; kt += 2) {          // the last (up to four) k-tiles: the same steps, each behind its bound
     // kt even: tile kt+1 is in set 1 -> stage 1; refill set 1 with tile kt+3
     la.transform(ra[1]); lb.transform(rb[1]);
     IA::store(As + IA::FLOATS, ra[1], tid);
     IB::store(Bs + IB::FLOATS, rb[1], tid);
     if (kt + 3 < ktiles) { la.load_next(ra[1]); lb.load_next(rb[1]); }
-    lds_barrier();
+    cs.bar_begin(); lds_barrier(); cs.bar_end();
     // kt+1 odd: tile kt+2 is in set 0 -> stage 0; refill set 0 with tile kt+4
     if (kt + 2 < ktiles) {
       la.transform(ra[0]); lb.transform(rb[0]);
@@ -189,9 +304,12 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
       IB::store(Bs, rb[0], tid);
     }
     if (kt + 4 < ktiles) { la.load_next(ra[0]); lb.load_next(rb[0]); }
-    lds_barrier();
+    cs.bar_begin(); lds_barrier(); cs.bar_end();
   }
   if (kt < ktiles) lds_barrier();   // odd ktiles: the last iteration has nothing left to stage
+#ifdef PCG_CLOCK_STAMP
+  cs.bar_flush(1, __builtin_amdgcn_s_memtime() - loop_t0);
+#endif
   } else {
   float4 ra[IA::NV], rb[IB::NV];
   if (ktiles > 0) {
@@ -225,46 +343,63 @@ __device__ __forceinline__ void igemm_produce(LA& la, LB& lb, int ktiles, float*
   }
 }
 
+// Producer by LDS-DMA (r03).  In-kernel stamps of the register-staged producers (scripts/conv_microbench.py --clock) showed what they
+// spend their k-tile on: 0.1 % waiting for their gathers, 11-14 % issuing the next ones — and 72-81 % inside their eight
+// ds_write_b128, behind consumers whose fp32 MFMAs own the register file's read ports almost every cycle; the consumers in turn
+// sat 16-30 % of their loop in the hand-over barrier waiting for those writes.  `buffer_load_dwordx4 ... lds` moves a gathered
+// 16-byte chunk from memory straight into LDS (lane l of the wave lands at M0 + 16*l; a lane whose offset is out of range lands
+// as zeros — scripts/probes/ldsdma_probe.hip): no VGPR staging, no ds_write, no producer-side register traffic at all.
+//   * the image must be lane-linear: the unpadded K-major image (32 floats per row); one wave-instruction fills eight rows.  Its
+//     XOR swizzle (conflict-free ds_read_b128 fragments) moves to the SOURCE side: the loaders are built with src_swz, the lane at
+//     chunk position c of row r fetches logical chunk c ^ ((r >> 1) & 7) — the involution LdsImage::frag applies when reading.
+//   * two stages; tile t+1 is issued into stage (t+1)&1 right after barrier t (its last readers retired their ds_reads before
+//     that barrier) and must have landed — the issuing wave's vmcnt(0) — before barrier t+1, after which the consumers read it.
+//     One k-tile (1.7-3.5 us of MFMAs) is several loaded L2 round trips.
+// Loaders need next_offsets() (conv_loaders.h); K-major operands only (forward: both; grad-input: the dy operand).
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void igemm_produce_dma(LA& la, LB& lb, int ktiles, float* smem, int tid, ClockStamp cs = ClockStamp{nullptr, 0}) {
+  using IA = LdsImage<Cfg::BM, true, true>;
+  using IB = LdsImage<Cfg::BN, true, true>;
+  static_assert(LA::KMAJOR && LB::KMAJOR && !LA::XFORM && !LB::XFORM, "LDS-DMA staging: plain K-major operands");
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* As = smem;
+  float* Bs = smem + 2 * IA::FLOATS;
+  if (PCG_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(PCG_PRODUCER_PRIO);
+  auto issue = [&](int stage) {          // rows 8*wave + 32*p .. +7 of each image: one 1 KB wave-instruction per p
+    uint32_t oa[IA::NV], ob[IB::NV];
+    la.next_offsets(oa); lb.next_offsets(ob);
+#pragma unroll
+    for (int p = 0; p < IA::NV; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(la.rs, (lds_ptr_t)(As + stage * IA::FLOATS + (8 * wave + 32 * p) * IG_BK), 16, oa[p], 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < IB::NV; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lb.rs, (lds_ptr_t)(Bs + stage * IB::FLOATS + (8 * wave + 32 * p) * IG_BK), 16, ob[p], 0, 0, 0);
+  };
+  if (ktiles > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();                           // barrier 0: stage 0 is ready
+  cs.bar_init();
+#ifdef PCG_CLOCK_STAMP
+  const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int kt = 0; kt < ktiles; ++kt) {
+    cs.sec_begin();
+    if (kt + 1 < ktiles) issue((kt + 1) & 1);
+    cs.sec_end(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed in LDS
+    cs.sec_end(2);
+    cs.bar_begin(); lds_barrier(); cs.bar_end();          // barrier kt+1: stage (kt+1)&1 handed to the consumers, stage kt&1 handed back
+  }
+#ifdef PCG_CLOCK_STAMP
+  cs.bar_flush(1, __builtin_amdgcn_s_memtime() - loop_t0);
+#endif
+}
+
 // Consumer: fragments are double-buffered in registers so that the LDS read of k-group g+1 is in flight under the
 // 16 MFMAs of k-group g; the hand-over barrier of the k-tile sits BEFORE its last k-group (whose operands are already
 // in registers), and the first fragments of the next tile are fetched right behind it — no LDS latency is exposed at
-// the tile boundary.  s_setprio keeps MFMA issue ahead of the co-resident producers' vector instructions.
-// Diagnostic build (-DPCG_CLOCK_STAMP): the clock the chip holds INSIDE the main loop = delta s_memtime / delta s_memrealtime x 100 MHz
-// (MI355X_MICROARCH.md, DVFS give-back item 6), one pair per block, written to a buffer nothing else reads.
-struct ClockStamp {
-  unsigned long long* out; int slots;
-#ifdef PCG_CLOCK_STAMP
-  unsigned long long t0, r0;
-  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-  __device__ __forceinline__ void end() {
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    const int b = blockIdx.x + gridDim.x * blockIdx.y;
-    if (out && threadIdx.x == 0 && b < slots) { out[2 * b] = t1 - t0; out[2 * b + 1] = r1 - r0; }
-  }
-  // phase stamps of the one-tile-per-workgroup kernels (third quarter of the buffer, 4 words per block): absolute 100 MHz ticks at
-  // kernel entry, main-loop begin, main-loop end, epilogue end — where a launch's time outside its main loops goes
-  __device__ __forceinline__ void phase(int k) {
-    const int b = blockIdx.x + gridDim.x * blockIdx.y;
-    if (out && threadIdx.x == 0 && b < slots / 8) out[(size_t)slots + (size_t)b * 4 + k] = __builtin_amdgcn_s_memrealtime();
-  }
-  // per-tile timeline of the persistent kernels (second half of the buffer: 2 + 32 words per block): mark(k) = 100 MHz ticks since begin();
-  // word 0 = begin() on the chip-wide 100 MHz clock (start skew between blocks), word 1 = hardware id
-  __device__ __forceinline__ void mark(int k) {
-    const int b = blockIdx.x;
-    if (out && threadIdx.x == 0 && b < slots / 36 && k < 32) {
-      unsigned long long* tl = out + 2 * (size_t)slots / 2 + (size_t)b * 34;     // second half of the buffer
-      tl[2 + k] = __builtin_amdgcn_s_memrealtime() - r0;
-      if (k == 0) { tl[0] = r0; tl[1] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }   // HW_REG_HW_ID, 32 bits
-    }
-  }
-#else
-  __device__ __forceinline__ void begin() {}
-  __device__ __forceinline__ void end() {}
-  __device__ __forceinline__ void mark(int) {}
-  __device__ __forceinline__ void phase(int) {}
-#endif
-};
-
+// the tile boundary.  (s_setprio 2 here dates from r01; what matters is that the PRODUCERS rank above it — igemm_produce.)
 template <class Cfg, bool AK, bool BK_>
 __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* smem, ClockStamp cs = ClockStamp{nullptr, 0}) {
   using IA = LdsImage<Cfg::BM, AK, Cfg::SWZ>;
@@ -302,11 +437,25 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
 
   lds_barrier();  // barrier 0: stage 0 is ready
   if (ktiles <= 0) return;
-  __builtin_amdgcn_s_setprio(2);
-  cs.begin(); cs.phase(1);
+  __builtin_amdgcn_s_setprio(PCG_CONSUMER_PRIO);
+  cs.begin(); cs.phase(1); cs.bar_init();
+#ifdef PCG_CLOCK_STAMP
+  const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime();
+#endif
   fetch(As, Bs, 0, 0);
   int cur = 0;
+#if PCG_CONSUMER_ALTERNATE
+  // fairness between the two workgroups of a CU: the arbiter breaks priority ties by age, so the older workgroup's
+  // consumers win every contested MFMA slot and finish early, and the younger one finishes alone at a fraction of the pipe.
+  // Alternate the priority k-tile by k-tile, in opposite phase for the two workgroups (block b and b + #CUs usually share a CU).
+  // Measured (r03): median block of D3 fwd finishes at 212 us instead of 200 us, the last one at 234 instead of 237; whole DCGAN step
+  // -0.4 % (10.86 -> 10.80 ms).  PCG_CONSUMER_ALTERNATE=0 builds the fixed-priority loop.
+  const int alt_phase = (int)((blockIdx.x / PCG_CONSUMER_ALTERNATE) & 1u);
+#endif
   for (int kt = 0; kt < ktiles; ++kt) {
+#if PCG_CONSUMER_ALTERNATE
+    if ((kt + alt_phase) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
     const float* as = As + cur * IA::FLOATS;
     const float* bs = Bs + cur * IB::FLOATS;
 #pragma unroll
@@ -314,12 +463,17 @@ __device__ __forceinline__ void igemm_consume(int ktiles, f32x16 (&acc)[Cfg::TM]
       fetch(as, bs, ks + 1, (ks + 1) & 1);
       mma(ks & 1);
     }
+    cs.bar_begin();
     lds_barrier();  // barrier kt+1: all reads of stage cur have retired (lgkmcnt(0)); stage cur^1 is ready
+    cs.bar_end();
     cur ^= 1;
     if (kt + 1 < ktiles) fetch(As + cur * IA::FLOATS, Bs + cur * IB::FLOATS, 0, KG & 1);
     mma((KG - 1) & 1);
   }
   cs.end(); cs.phase(2);
+#ifdef PCG_CLOCK_STAMP
+  cs.bar_flush(0, __builtin_amdgcn_s_memtime() - loop_t0);
+#endif
   __builtin_amdgcn_s_setprio(0);
 }
 

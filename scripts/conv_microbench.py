@@ -80,6 +80,20 @@ def main():
             med = lambda v: float(v.median()) / 100.0
             clock_mhz.phases = (med(ph[:, 0] - t0), med(ph[:, 1] - ph[:, 0]), med(ph[:, 2] - ph[:, 1]), med(ph[:, 3] - ph[:, 2]),
                                 float(ph[:, 3].max() - t0) / 100.0, float((ph[:, 3] - t0).median()) / 100.0)
+        bw = stamps[half + half // 2:].cpu().view(-1, 4).double()
+        bw = bw[(bw[:, 1] > 0) & (bw[:, 3] > 0)]
+        clock_mhz.barwait = None
+        if bw.shape[0] > 0:
+            q3 = half + half // 2
+            secraw = stamps[q3 + half // 4:].cpu().view(-1, 2)[:bw.shape[0]]
+            wait_only = (secraw[:, 0] >> 32).double()
+            sec = torch.stack([(secraw[:, 0] & 0xFFFFFFFF).double(), secraw[:, 1].double()], 1)
+            loopc = stamps[q3:q3 + half // 4].cpu().view(-1, 4).double()
+            loopc = loopc[(loopc[:, 1] > 0) & (loopc[:, 3] > 0)][:sec.shape[0], 3]
+            n = min(sec.shape[0], loopc.shape[0])
+            clock_mhz.barwait = (float((bw[:, 0] / bw[:, 1]).median()), float((bw[:, 2] / bw[:, 3]).median()),
+                                 float((sec[:n, 0] / loopc[:n]).median()) if n else float("nan"), float((sec[:n, 1] / loopc[:n]).median()) if n else float("nan"),
+                                 float((wait_only[:n] / loopc[:n]).median()) if n else float("nan"))
         st = stamps[:half].view(-1, 2).cpu().double()
         st = st[st[:, 1] > 0]
         stamps.zero_()
@@ -156,6 +170,10 @@ def main():
                 c = clock_mhz()
                 lo = clock_mhz.loop
                 extra = f"  in-kernel clock {c:5.0f} MHz; main loop per block med/min/max {lo[0]:.1f}/{lo[1]:.1f}/{lo[2]:.1f} us over {lo[3]} blocks"
+                if clock_mhz.barwait:
+                    extra += (f"\n        share of the main loop spent in the hand-over barrier: consumer wave 0 {100 * clock_mhz.barwait[0]:.1f} %, "
+                              f"producer wave 4 {100 * clock_mhz.barwait[1]:.1f} % (waiting for the gathers {100 * clock_mhz.barwait[4]:.1f} %, its ds_writes {100 * clock_mhz.barwait[2]:.1f} %, "
+                              f"issuing the next gathers {100 * clock_mhz.barwait[3]:.1f} %)")
                 if clock_mhz.phases:
                     q = clock_mhz.phases
                     extra += (f"\n        phases (us, medians over blocks of the LAST launch): entry skew {q[0]:.1f}, entry->loop {q[1]:.1f}, loop {q[2]:.1f}, "
