@@ -731,8 +731,22 @@ int pcg_dp_shutdown(void);
  *   "korder"            order of the k-tiles of the forward / grad-input kernels: 0 (tap, channel chunk), 1 L2-friendly (default)
  *   "wgrad_order"       weight-gradient block order: 0 tile-major, 1 slice-major, -1 built-in rule
  *   "dgrad_interleave"  sub-pixel phases of a grad-input tile neighbours in launch order: 0 / 1, -1 built-in rule
+ *   "stream_k"          hybrid stream-K launches: 0 off, 1 where the launch plan's model gains > 10 % (default), 2 wherever valid
+ *   "sk_blocks"         number of stream-K workgroups (512 / 256 / 128 / 64), -1 built-in choice
  * value -1 restores the built-in choice.  Results stay correct under every setting (the order of a sum changes, not its terms). */
 int pcg_tune_set(const char* name, int32_t value);
+
+/* ---- scratch of the hybrid stream-K launches (conv_igemm.hip: conv_fwd_sk_kernel / conv_dgrad_sk_kernel) --------------------------
+ * A forward / grad-input launch whose tile count is not a multiple of the chip's 512 workgroup slots gives its remainder tiles to
+ * workgroups that each take an equal share of those tiles' K loop; they exchange partial accumulator tiles through `parts` and
+ * count arrivals per tile in `arrivals`.  Both buffers are the caller's, registered for ONE stream (launches on that stream use
+ * them in stream order; two graphs that bake the same scratch must not replay concurrently).  `arrivals` must be zero when it is
+ * registered; the kernels leave it zero.  A stream without scratch runs the plain launches (same results up to the order of the
+ * K sum).  parts == NULL forgets the stream.  The reference has no counterpart: ATen picks its conv algorithm inside
+ * torch.nn.functional.conv2d (mnist_wgan_conditional.py:61-70,87-95).                                                          */
+size_t pcg_conv_scratch_parts_bytes(void);
+size_t pcg_conv_scratch_arrivals_bytes(void);
+int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t parts_bytes, void* arrivals, size_t arrivals_bytes);
 /* Diagnostic builds only (`make -C csrc stamp`, -DPCG_CLOCK_STAMP): every conv kernel block leaves {shader-clock ticks, 100 MHz
  * ticks} of its main loop at buf[2*block], buf[2*block+1] (uint64) — the clock the chip holds inside the kernel.  Returns 1 when
  * this build stamps, 0 for the shipped library (which compiles no stamp code).  buf = NULL turns it off.                        */

@@ -82,6 +82,9 @@ PROTOTYPES = {
     "pcg_target_arch": (_c.c_char_p, []),
     "pcg_tune_set": (_i, [_c.c_char_p, _i32]),
     "pcg_debug_stamp_buffer": (_i, [_vp, _i64]),
+    "pcg_conv_scratch_parts_bytes": (_sz, []),
+    "pcg_conv_scratch_arrivals_bytes": (_sz, []),
+    "pcg_conv_set_scratch": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "pcg_calib_mfma_blocks": (_i32, [_i32]),
     "pcg_calib_mfma_workspace_bytes": (_sz, [_i32]),
     "pcg_calib_mfma": (_i, [_i32, _i32, _vp, _sz, _c.POINTER(_d), _c.POINTER(_c.c_uint64), _vp]),

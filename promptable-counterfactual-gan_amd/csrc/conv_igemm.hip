@@ -11,6 +11,7 @@
 // Replaces ATen conv forward/backward behind nn.Conv2d / nn.ConvTranspose2d at
 // dconv_gan/mnist/mnist_dcgan.py:76-88,100-111 and conditional_counteRGAN/mnist/models/*.py.
 #include <string.h>
+#include <mutex>
 #include "conv_loaders.h"
 #include "thin_conv.h"
 
@@ -106,6 +107,192 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
   }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+}
+
+// ======================================================================================================================
+// Hybrid stream-K launches (r03).  The one-tile-per-workgroup kernels above run in rounds of 512 workgroups (2 per CU); a launch
+// whose tile count is not a multiple of that pays a whole extra round for the remainder — the in-kernel stamps of WGAN-GP's
+// 288-tile grad-input GEMM (1024 x 4608, K = 1024) show 224 CUs finishing their single tile at 69 us and 32 CUs running two tiles
+// side by side until 124 us: 66 TFLOP/s.  Here the first `dp_tiles` tiles (whole rounds) keep one workgroup each, and the k-tiles
+// of the remaining `sk_tiles` tiles form ONE iteration space that is cut into `sk_blocks` equal contiguous ranges, one per
+// workgroup; a range covers the tail of one tile and the head of the next (at most two segments: sk_blocks >= sk_tiles).
+// A segment that is not a whole tile leaves its accumulators as a partial tile in the scratch buffer (register layout, coalesced
+// 16-byte stores) and bumps the arrival counter of (tile, consumer wave); the wave that arrives LAST adds the partial tiles of its
+// quadrant in K order — its own included, from memory: the order of the sum never depends on who arrives when, results are
+// bit-reproducible — and runs the ordinary epilogue (bias, activation, statistics, backward riders: nothing is lost to the
+// split, unlike the slab form of plan_fwd).  Counters return to zero behind the last arrival; visibility across the XCDs' L2s
+// comes from the agent-scope release / acquire fences around the counter update.
+// ======================================================================================================================
+struct SkPlan {
+  int dp_tiles, sk_tiles, sk_blocks, ktiles;   // ktiles: per tile
+  float* parts;                                // [2 * sk_blocks][BM * BN]
+  int* arrivals;                               // [sk_tiles][4], zero between launches
+};
+struct SkSeg { int tile, kt_begin, nkt, nparts, first_block; };   // tile: index among ALL tiles of the launch
+
+// (wave-uniform values; the divisions run on the vector unit, readfirstlane puts the results back into scalar registers.
+//  32-bit: the host keeps sk_tiles * ktiles * sk_blocks below 2^31)
+__device__ __forceinline__ int sk_start(int g, const SkPlan& sk) {
+  return __builtin_amdgcn_readfirstlane((int)((uint32_t)g * (uint32_t)(sk.sk_tiles * sk.ktiles) / (uint32_t)sk.sk_blocks));
+}
+__device__ __forceinline__ int sk_owner(int x, const SkPlan& sk) {     // the block whose range holds iteration x
+  return __builtin_amdgcn_readfirstlane((int)((((uint32_t)x + 1u) * (uint32_t)sk.sk_blocks - 1u) / (uint32_t)(sk.sk_tiles * sk.ktiles)));
+}
+__device__ __forceinline__ int sk_segments(const SkPlan& sk, SkSeg& s0, SkSeg& s1) {
+  const int b = blockIdx.x;
+  if (b < sk.dp_tiles) { s0 = SkSeg{(int)xcd_remap((uint32_t)b, (uint32_t)sk.dp_tiles), 0, sk.ktiles, 1, 0}; return 1; }
+  const int g = b - sk.dp_tiles, KT = sk.ktiles;
+  const int it0 = sk_start(g, sk), it1 = sk_start(g + 1, sk);
+  const int j0 = __builtin_amdgcn_readfirstlane(it0 / KT), e0 = it1 < (j0 + 1) * KT ? it1 : (j0 + 1) * KT;
+  auto fill = [&](SkSeg& sg, int j, int from, int to) {
+    const int f = sk_owner(j * KT, sk), l = sk_owner((j + 1) * KT - 1, sk);
+    sg = SkSeg{sk.dp_tiles + j, from - j * KT, to - from, l - f + 1, f};
+  };
+  fill(s0, j0, it0, e0);
+  if (it1 <= e0) return 1;
+  fill(s1, j0 + 1, e0, it1);
+  return 2;
+}
+// Partial tiles cross XCDs (each has its own L2).  Their stores and loads carry sc1 (agent scope: written through / read past
+// the non-coherent lines; raw-buffer builtins with aux 16, so the compiler counts them) instead of an agent-scope release /
+// acquire fence pair around the counter, which writes back and invalidates whole caches once per wave and arrival (measured r03:
+// with the fences the 288-tile GEMM went from 137 to 203 us).  Each storing wave drains its stores (vmcnt(0)) before ITS add to
+// the (tile, wave) counter; the wave whose add returns nparts - 1 loads only behind that return.
+__device__ __forceinline__ void sk_store4(rsrc_t r, uint32_t off, float a, float b, float c, float d) {
+  const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+}
+__device__ __forceinline__ float4 sk_load4(rsrc_t r, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// consumer waves, after the main loop of a segment: true when this wave holds the finished sum of its quadrant in `acc`
+template <class Cfg>
+__device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  if (sg.nparts == 1) return true;
+  constexpr uint32_t TILE_BYTES = Cfg::BM * Cfg::BN * 4;
+  const int g = (int)blockIdx.x - sk.dp_tiles, j = sg.tile - sk.dp_tiles, KT = sk.ktiles;
+  auto slot_of = [&](int blk) { return (uint32_t)(2 * blk + (sk_start(blk, sk) >= j * KT ? 0 : 1)); };   // the tile is the block's first one?
+  const rsrc_t rs = make_rsrc(sk.parts, (uint32_t)(2 * sk.sk_blocks) * TILE_BYTES);
+  const uint32_t toff = threadIdx.x * 16u;                 // consumer threads 0..255: one 16-byte column of each 4 KB row of the partial tile
+  const uint32_t mine = slot_of(g) * TILE_BYTES + toff;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        sk_store4(rs, mine + (uint32_t)(((i * Cfg::TN + jj) * 4 + q) * IG_LOADERS * 16),
+                  acc[i][jj][4 * q], acc[i][jj][4 * q + 1], acc[i][jj][4 * q + 2], acc[i][jj][4 * q + 3]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's partial quadrant has left for memory
+  int* cnt = sk.arrivals + j * 4 + (int)(threadIdx.x >> 6);
+  int old = 0;
+  if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != sg.nparts - 1) return false;
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+  for (int k = 0; k < sg.nparts; ++k) {
+    const uint32_t src = slot_of(sg.first_block + k) * TILE_BYTES + toff;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < Cfg::TN; ++jj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = sk_load4(rs, src + (uint32_t)(((i * Cfg::TN + jj) * 4 + q) * IG_LOADERS * 16));
+          acc[i][jj][4 * q] += v.x; acc[i][jj][4 * q + 1] += v.y; acc[i][jj][4 * q + 2] += v.z; acc[i][jj][4 * q + 3] += v.w;
+        }
+  }
+  return true;
+}
+
+// One segment = the base kernel's body over k-tiles [kt_begin, kt_begin + nkt) of one tile.  A workgroup runs it once or twice;
+// the two runs are two inlined copies, not a loop (as a loop the compiler kept both segments' state live across the body: 60-80
+// spilled VGPRs and a scratch access inside the k-tile loop; the all-data-parallel cost of that kernel was +13..21 % on grad-input
+// launches, scripts/probes/streamk_dp_cost.py).
+template <class Cfg, bool XF>
+__device__ __forceinline__ void fwd_sk_segment(const ConvP& p, const SkPlan& sk, const SkSeg& sg, float* smem) {
+  const int mt = __builtin_amdgcn_readfirstlane(sg.tile / p.tilesN), nt = sg.tile - mt * p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  if (wave_id() >= 4) {  // producers
+    const int tid = threadIdx.x - IG_LOADERS;
+    FwdALoader<Cfg::BM, XF> la(p, m_block, tid);
+    FwdBLoader<Cfg::BN> lb(p, n_block, tid);
+    if (sg.kt_begin) { la.seek(sg.kt_begin); lb.seek(sg.kt_begin); }
+    igemm_produce<Cfg>(la, lb, sg.nkt, smem, tid, ClockStamp{nullptr, 0});
+    return;
+  }
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_consume<Cfg, true, true>(sg.nkt, acc, smem);
+  if (sk_combine<Cfg>(sk, sg, acc))
+    igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+      const int m = m_block + row;
+      return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
+    }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+}
+template <class Cfg, bool XF>
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_sk_kernel(ConvP p, SkPlan sk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  SkSeg s0, s1{};
+  const int nseg = sk_segments(sk, s0, s1);
+  fwd_sk_segment<Cfg, XF>(p, sk, s0, smem);
+  if (nseg == 1) return;
+  lds_barrier();   // the epilogue staged through the LDS stages: the second segment's producers wait for it
+  fwd_sk_segment<Cfg, XF>(p, sk, s1, smem);
+}
+
+// grad-input: the tiles of all sub-pixel phases are numbered phase-major (phase = tile / tiles_per_phase); the host only takes
+// this form when every phase has the same number of rows and taps (one iteration space)
+template <class Cfg, bool XF>
+__device__ __forceinline__ void dgrad_sk_segment(const ConvP& p, const DgradPhases& phases, const SkPlan& sk, const SkSeg& sg, int tiles_per_phase,
+                                                 float* smem, int* rowpix) {
+  const int py = __builtin_amdgcn_readfirstlane(sg.tile / tiles_per_phase), tile = sg.tile - py * tiles_per_phase;
+  const PhaseInfo& f = phases.p[py];
+  const int mt = __builtin_amdgcn_readfirstlane(tile / p.tilesN), nt = tile - mt * p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    for (int r = tid; r < Cfg::BM; r += IG_LOADERS) {
+      const int m = m_block + r;
+      int pix = -1;
+      if (m < f.Mp) {
+        uint32_t t, cc, b, aa;
+        f.dPHw.divmod((uint32_t)m, t, cc);
+        f.dPHh.divmod(t, b, aa);
+        pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
+      }
+      rowpix[r] = pix;
+    }
+    DgradALoader<Cfg::BM, XF> la(p, f, m_block, tid);
+    DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
+    if (sg.kt_begin) { la.seek(sg.kt_begin); lb.seek(sg.kt_begin); }
+    igemm_produce<Cfg>(la, lb, sg.nkt, smem, tid, ClockStamp{nullptr, 0});
+    return;
+  }
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_consume<Cfg, true, false>(sg.nkt, acc, smem);
+  if (sk_combine<Cfg>(sk, sg, acc))
+    igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+      const int pix = rowpix[row];
+      return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
+    }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+}
+template <class Cfg, bool XF>
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_sk_kernel(ConvP p, DgradPhases phases, SkPlan sk, int tiles_per_phase) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int rowpix[Cfg::BM];
+  SkSeg s0, s1{};
+  const int nseg = sk_segments(sk, s0, s1);
+  dgrad_sk_segment<Cfg, XF>(p, phases, sk, s0, tiles_per_phase, smem, rowpix);
+  if (nseg == 1) return;
+  lds_barrier();
+  dgrad_sk_segment<Cfg, XF>(p, phases, sk, s1, tiles_per_phase, smem, rowpix);
 }
 
 template <class Cfg, bool XFA, bool XFB>   // XFA: the dy operand is a transformed activation (ConvTranspose2d layers); XFB: x is
@@ -392,7 +579,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -467,6 +654,58 @@ bool use_persistent() {
 template <class Cfg, bool AK, bool BK_>
 constexpr size_t stage_smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, AK, BK_>(); }
 
+// ---- stream-K scratch: caller-owned, registered per stream (pcg_conv_set_scratch) --------------------------------------
+constexpr int SK_MAX_BLOCKS = 512, SK_MAX_TILES = 1024;
+constexpr size_t SK_PARTS_BYTES = (size_t)2 * SK_MAX_BLOCKS * 128 * 128 * sizeof(float);
+constexpr size_t SK_ARRIVALS_BYTES = (size_t)SK_MAX_TILES * 4 * sizeof(int);
+struct SkScratch { hipStream_t stream; float* parts; int* arrivals; };
+SkScratch g_sk_scratch[64];
+int g_sk_scratch_n = 0;
+std::mutex g_sk_mutex;
+bool sk_scratch_of(hipStream_t s, SkPlan* sk) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  for (int i = 0; i < g_sk_scratch_n; ++i)
+    if (g_sk_scratch[i].stream == s) { sk->parts = g_sk_scratch[i].parts; sk->arrivals = g_sk_scratch[i].arrivals; return true; }
+  return false;
+}
+int sk_mode() {      // 0 off, 1 where the model sees > 10 % to gain (default), 2 wherever the form is valid (tests, scans)
+  static const int env = getenv("PCG_STREAM_K") ? atoi(getenv("PCG_STREAM_K")) : 1;
+  return g_tune.stream_k >= 0 ? g_tune.stream_k : env;
+}
+// Decide between whole rounds + stream-K remainder and the plain launch.  Times in us from the r03 stamps of the 128x128 kernels:
+// a k-tile takes a workgroup 3.5 us when two share a CU (the matrix pipe's rate) and 2.2 us when it has the CU alone; a whole
+// tile costs ~6 us outside its main loop, a stream-K segment ~12 (partial tile out, counter, the next segment's cold start); the
+// last arrival reads ~1.5 us per partial tile.  Checked against scripts/probes/streamk_scan.py: the model takes the launches
+// that gained 7-24 % there and leaves the K = 512 grad-input GEMMs (16 k-tiles per tile: no gain) data-parallel.
+bool plan_sk(int tiles, int ktiles, hipStream_t s, SkPlan* sk) {
+  const int mode = sk_mode();
+  if (mode == 3) {                       // diagnostic: every tile data-parallel, but through the stream-K kernels (their cost as such)
+    if (!sk_scratch_of(s, sk)) return false;
+    sk->dp_tiles = tiles; sk->sk_tiles = 0; sk->sk_blocks = 0; sk->ktiles = ktiles;
+    return true;
+  }
+  if (mode == 0 || ktiles < 8) return false;
+  const int dp = tiles / 512 * 512, r = tiles - dp;
+  if (r == 0 || r > SK_MAX_TILES || (int64_t)r * ktiles * 512 >= (1ll << 31)) return false;
+  const double t_dp = (r <= 256 ? 2.2 : 3.5) * ktiles + 6.0;
+  double best = 1e30;
+  int bg = 0;
+  for (int G = 512; G >= 64; G >>= 1) {
+    if (g_tune.sk_blocks > 0 && G != g_tune.sk_blocks) continue;
+    if (G < r) break;
+    const int it = ceil_div(r * ktiles, G);
+    if (it < 4) continue;
+    const int parts = ceil_div(ktiles, it) + 1;
+    if (parts > 8) continue;
+    const double t = it * (G == 512 ? 3.5 : 2.2) + 2 * 12.0 + 3.0 + 1.5 * parts;
+    if (t < best) { best = t; bg = G; }
+  }
+  if (!bg || (mode == 1 && best > 0.9 * t_dp)) return false;
+  if (!sk_scratch_of(s, sk)) return false;
+  sk->dp_tiles = dp; sk->sk_tiles = r; sk->sk_blocks = bg; sk->ktiles = ktiles;
+  return true;
+}
+
 template <class Cfg, bool XF>
 int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
   p.tilesN = ceil_div(p.N, Cfg::BN);
@@ -482,6 +721,15 @@ int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
   }
 #endif
   constexpr size_t smem = smem_bytes<Cfg, true, true>();
+  if constexpr (Cfg::BM == 128 && Cfg::BN == 128 && !Cfg::DMA) {
+    SkPlan sk{};
+    if (splits == 1 && plan_sk(tilesM * p.tilesN, p.ktiles, s, &sk)) {
+      static int once_sk = set_smem(conv_fwd_sk_kernel<Cfg, XF>, smem);
+      if (once_sk != PCG_OK) return once_sk;
+      hipLaunchKernelGGL((conv_fwd_sk_kernel<Cfg, XF>), dim3((unsigned)(sk.dp_tiles + sk.sk_blocks)), dim3(IG_THREADS), smem, s, p, sk);
+      return launch_status("conv_fwd_sk_kernel");
+    }
+  }
   static int once = set_smem(conv_fwd_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
   hipLaunchKernelGGL((conv_fwd_kernel<Cfg, XF>), dim3((unsigned)tilesM * p.tilesN, splits), dim3(IG_THREADS), smem, s, p);
@@ -506,7 +754,7 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
     f.splits = ceil_div(ktiles, f.ktiles_per_split);
     return f;
   }
-  if (tiles > 256 && tiles < 448 && ktiles >= 32) {
+  if (tiles > 256 && tiles < 448 && ktiles >= 32 && !(sk_mode() != 0 && g_sk_scratch_n > 0)) {     // (stream-K takes these when it has scratch)
     // a little over one block per CU (288 tiles: 32 CUs get two full-K blocks, the others one — the critic's conv2 at batch 256
     // ran at 73 TFLOP/s): a few K-slices bring the blocks per CU to ceil(tiles*s/256)/s.  Each slice also costs a slab of M*N
     // floats written and read: measured r03 (scripts/probes/fwd_splits_scan.py, 288 tiles x 72 k-tiles) 1: 283, 2: 241, 3: 221,
@@ -556,6 +804,21 @@ int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipSt
   }
 #endif
   constexpr size_t smem = smem_bytes<Cfg, true, false>();
+  if constexpr (Cfg::BM == 128 && Cfg::BN == 128) {
+    bool uniform = true;
+    for (int i = 0; i < nphases; ++i)
+      uniform = uniform && ph.p[i].Mp == ph.p[0].Mp && ph.p[i].nth * ph.p[i].ntw == ph.p[0].nth * ph.p[0].ntw && ph.p[i].nth > 0 && ph.p[i].ntw > 0;
+    SkPlan sk{};
+    const int tpp = tilesM * p.tilesN;
+    if (uniform && plan_sk(tpp * nphases, ph.p[0].nth * ph.p[0].ntw * ceil_div(p.Cout, IG_BK), s, &sk)) {
+      static int once_sk = set_smem(conv_dgrad_sk_kernel<Cfg, XF>, smem);
+      if (once_sk != PCG_OK) return once_sk;
+      DgradPhases phs = ph;
+      phs.interleave = 0;
+      hipLaunchKernelGGL((conv_dgrad_sk_kernel<Cfg, XF>), dim3((unsigned)(sk.dp_tiles + sk.sk_blocks)), dim3(IG_THREADS), smem, s, p, phs, sk, tpp);
+      return launch_status("conv_dgrad_sk_kernel");
+    }
+  }
   static int once = set_smem(conv_dgrad_kernel<Cfg, XF>, smem);
   if (once != PCG_OK) return once;
   static const int il_env0 = getenv("PCG_DGRAD_INTERLEAVE") ? atoi(getenv("PCG_DGRAD_INTERLEAVE")) : 1;   // A/B switch
@@ -644,6 +907,32 @@ static bool dgrad_as_gemm(const pcg_conv_geom* g) {
   return bytes < (1ll << 31);
 }
 static size_t dgrad_gemm_bytes(const pcg_conv_geom* g) { return (size_t)g->B * g->OH * g->OW * g->KH * g->KW * g->Cin * sizeof(float); }
+
+// Scratch of the hybrid stream-K launches (partial accumulator tiles + arrival counters), owned by the caller and registered for
+// ONE stream: launches on that stream use it in stream order.  `arrivals` must be zero-filled when it is registered; the kernels
+// leave it zero.  A stream without scratch runs the plain launches.  parts == nullptr forgets the stream.
+extern "C" size_t pcg_conv_scratch_parts_bytes(void) { return pcg::SK_PARTS_BYTES; }
+extern "C" size_t pcg_conv_scratch_arrivals_bytes(void) { return pcg::SK_ARRIVALS_BYTES; }
+extern "C" int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t parts_bytes, void* arrivals, size_t arrivals_bytes) {
+  using namespace pcg;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  int at = -1;
+  for (int i = 0; i < g_sk_scratch_n; ++i) if (g_sk_scratch[i].stream == s) at = i;
+  if (!parts) {
+    if (at >= 0) g_sk_scratch[at] = g_sk_scratch[--g_sk_scratch_n];
+    return PCG_OK;
+  }
+  PCG_REQUIRE(arrivals != nullptr && parts_bytes >= SK_PARTS_BYTES && arrivals_bytes >= SK_ARRIVALS_BYTES,
+              "pcg_conv_set_scratch: parts %zu B (need %zu), arrivals %zu B (need %zu)", parts_bytes, SK_PARTS_BYTES, arrivals_bytes, SK_ARRIVALS_BYTES);
+  PCG_REQUIRE((((uintptr_t)parts) & 15) == 0 && (((uintptr_t)arrivals) & 3) == 0, "pcg_conv_set_scratch: misaligned scratch");
+  if (at < 0) {
+    PCG_REQUIRE(g_sk_scratch_n < 64, "pcg_conv_set_scratch: more than 64 streams with scratch");
+    at = g_sk_scratch_n++;
+  }
+  g_sk_scratch[at] = SkScratch{s, (float*)parts, (int*)arrivals};
+  return PCG_OK;
+}
 
 extern "C" size_t pcg_conv2d_dgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;
@@ -1075,6 +1364,8 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
   else if (!strcmp(name, "persist_tiles")) g_tune.persist_tiles = value;
   else if (!strcmp(name, "fwd_splits")) g_tune.fwd_splits = value;
+  else if (!strcmp(name, "stream_k")) g_tune.stream_k = value;
+  else if (!strcmp(name, "sk_blocks")) g_tune.sk_blocks = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
   else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;

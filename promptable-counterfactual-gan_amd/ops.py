@@ -65,8 +65,31 @@ class _Timed:
         return False
 
 
+_sk_streams = {}      # (device index, stream handle) -> (parts, arrivals): scratch of the stream-K conv launches, alive for the process
+_sk_arrival_pool = {}
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = torch.cuda.current_stream()
+    if (s.device_index, s.cuda_stream) not in _sk_streams:
+        _register_conv_scratch(s)
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _register_conv_scratch(s):
+    """First library call on a stream: give the hybrid stream-K conv launches their scratch for it (include/pcgan_hip.h,
+    pcg_conv_set_scratch).  The arrival counters must be zero and stay out of a capture's fill nodes: they come from a pool
+    zeroed outside any capture, like the linear weight-gradient tickets."""
+    lib = _lib.load()
+    dev = torch.device("cuda", s.device_index)
+    nparts, narr = lib.pcg_conv_scratch_parts_bytes(), lib.pcg_conv_scratch_arrivals_bytes()
+    pool = _sk_arrival_pool.setdefault(s.device_index, [])
+    if not pool and not torch.cuda.is_current_stream_capturing():
+        pool.extend(torch.zeros((8, narr), dtype=torch.uint8, device=dev).unbind(0))
+    arrivals = pool.pop() if pool else torch.zeros(narr, dtype=torch.uint8, device=dev)
+    parts = torch.empty(nparts, dtype=torch.uint8, device=dev)
+    _sk_streams[(s.device_index, s.cuda_stream)] = (parts, arrivals)
+    check(lib.pcg_conv_set_scratch(ctypes.c_void_p(s.cuda_stream), _p(parts), nparts, _p(arrivals), narr), "pcg_conv_set_scratch")
 
 
 def _p(t):

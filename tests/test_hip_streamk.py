@@ -1,0 +1,82 @@
+"""Hybrid stream-K launches of the forward / grad-input conv kernels (csrc/conv_igemm.hip: conv_fwd_sk_kernel, conv_dgrad_sk_kernel)
+against the one-tile-per-workgroup launches of the same library and against fp64 samples: same terms, another order of the K sum.
+The layers are the WGAN-GP shapes the form was built for (mnist_wgan_conditional.py:61-70,87-95 at width 1024) plus ragged ones."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+
+@pytest.fixture()
+def pcg():
+    import pcgan_amd
+    pcgan_amd.load()
+    yield pcgan_amd
+    pcgan_amd.ops.tune("stream_k", -1)
+    pcgan_amd.ops.tune("sk_blocks", -1)
+
+
+# (B, Cin, Cout, H, k, s, p)
+FWD = [(1024, 1024, 4608, 1, 1, 1, 0),      # the 288-tile GEMM of the critic's conv3 grad-input (as a 1x1 forward)
+       (256, 256, 512, 13, 3, 2, 0),        # critic conv2: 288 tiles x 72 k-tiles
+       (96, 96, 640, 9, 3, 1, 1),           # ragged M and K (Cin % 32 != 0), 61 x 5 tiles
+       (512, 128, 256, 16, 4, 2, 1)]        # DCGAN D3 (512 tiles: stays data-parallel unless forced; forced it has no remainder)
+DGRAD = [(256, 8192, 1024, 1, 1, 1, 0),     # Linear 8192 -> 1024 grad-input: 128 tiles x 32 k-tiles
+         (256, 256, 512, 14, 4, 2, 1),      # G ConvT3: four uniform sub-pixel phases, 784 tiles
+         (64, 96, 160, 10, 4, 2, 1)]        # ragged phases' tiles
+
+
+def _geom(ops, B, Cin, Cout, H, k, s, p):
+    return ops.conv_geom(B, H, H, Cin, Cout, k, k, s, p)
+
+
+@pytest.mark.parametrize("shape", FWD)
+@pytest.mark.parametrize("blocks", [-1, 256])
+def test_forward_streamk_matches_plain(pcg, shape, blocks):
+    ops = pcg.ops
+    B, Cin, Cout, H, k, s, p = shape
+    g = _geom(ops, *shape)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn((B, H, H, Cin), generator=gen).to(DEV)
+    w = (torch.randn((Cout, k, k, Cin), generator=gen) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=gen).to(DEV)
+    ops.tune("stream_k", 0)
+    ref = ops.conv2d_fwd(g, x, w, b, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+    ops.tune("stream_k", 2); ops.tune("sk_blocks", blocks)
+    y1 = ops.conv2d_fwd(g, x, w, b, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+    y2 = ops.conv2d_fwd(g, x, w, b, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+    assert torch.equal(y1, y2)                                   # the sum's order does not depend on who arrives last
+    K = k * k * Cin
+    tol = 16 * 2.0 ** -24 * K * float(x.abs().mean() * w.abs().mean()) * 4 + 1e-6     # same bound family as test_hip_benchshape
+    assert float((y1 - ref).abs().max()) <= tol
+    parts, arrivals = ops._sk_streams[(0, torch.cuda.current_stream().cuda_stream)]
+    assert int(arrivals.view(torch.int32).abs().sum()) == 0      # counters are back to zero
+    # fp64 samples
+    xs = x[:4].double().permute(0, 3, 1, 2).cpu(); ws = w.double().permute(0, 3, 1, 2).cpu()
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xs, ws, b.double().cpu(), stride=s, padding=p), 0.2).permute(0, 2, 3, 1)
+    assert float((y1[:4].double().cpu() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("shape", DGRAD)
+def test_grad_input_streamk_matches_plain(pcg, shape):
+    ops = pcg.ops
+    B, Cin, Cout, H, k, s, p = shape
+    g = _geom(ops, *shape)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    dy = torch.randn((B, g.OH, g.OW, Cout), generator=gen).to(DEV)
+    w = (torch.randn((Cout, k, k, Cin), generator=gen) * 0.05).to(DEV)
+    ops.tune("stream_k", 0)
+    ref = ops.conv2d_dgrad(g, dy, w).clone()
+    ops.tune("stream_k", 2)
+    d1 = ops.conv2d_dgrad(g, dy, w).clone()
+    d2 = ops.conv2d_dgrad(g, dy, w).clone()
+    assert torch.equal(d1, d2)
+    K = k * k * Cout
+    tol = 16 * 2.0 ** -24 * K * float(dy.abs().mean() * w.abs().mean()) * 4 + 1e-6
+    assert float((d1 - ref).abs().max()) <= tol
+    want = torch.nn.functional.conv_transpose2d(dy[:2].double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), stride=s, padding=p,
+                                                output_padding=H - ((g.OH - 1) * s - 2 * p + k)).permute(0, 2, 3, 1)
+    assert float((d1[:2].double().cpu() - want).abs().max()) <= tol
