@@ -449,10 +449,24 @@ int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C, const flo
 /* backward: dx (nullable); per-sample partial sums dgamma_partial / dbeta_partial [B][C] (nullable; reduce over B with pcg_colsum) */
 int pcg_instnorm_bwd(const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean, const float* invstd,
                      const float* gamma, float* dx, float* dgamma_partial, float* dbeta_partial, pcg_stream_t stream);
+/* the same with the stage's neighbours folded in (one launch for what autograd runs as LeakyReLU backward, InstanceNorm backward, an
+ * add and the conv bias gradient's reduction, :88-95): act_y (nullable) = the LeakyReLU OUTPUT, dy is multiplied by lrelu'(.) first
+ * (dn_out, nullable, keeps that masked gradient for the double backward); addend (nullable) is added to the stored dx;
+ * dxsum_partial (nullable) [B][C] = sum over HW of the stored dx (the conv bias gradient's per-sample partial).                  */
+int pcg_instnorm_bwd_fused(const float* dy, const float* act_y, float neg_slope, const float* x, int32_t B, int32_t HW, int32_t C,
+                           const float* mean, const float* invstd, const float* gamma, float* dn_out, const float* addend, float* dx,
+                           float* dgamma_partial, float* dbeta_partial, float* dxsum_partial, pcg_stream_t stream);
+/* sums over the rows of up to three [rows][C] partial arrays (the three above) in one launch; acc_k: dst_k += instead of =        */
+int pcg_rowsum3(int32_t n, const float* src0, float* dst0, int acc0, const float* src1, float* dst1, int acc1, const float* src2,
+                float* dst2, int acc2, int32_t rows, int32_t C, pcg_stream_t stream);
 /* backward of pcg_instnorm_bwd — what autograd.grad(..., create_graph=True) + critic_loss.backward() (:149,154) need: with r
  * the cotangent on dx, returns the cotangents reaching dy (ddy), x (ez) and gamma (per-sample partials); any may be NULL. */
 int pcg_instnorm_bwd_bwd(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,
                          const float* invstd, const float* gamma, float* ddy, float* ez, float* dgamma_partial, pcg_stream_t stream);
+/* ... with the cotangent ddy continuing through the stage's LeakyReLU (act_y = its output; nullable) in the same launch          */
+int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,
+                             const float* invstd, const float* gamma, const float* act_y, float neg_slope, float* ddy, float* ez,
+                             float* dgamma_partial, pcg_stream_t stream);
 /* nn.Flatten of an NCHW tensor (:96) from the NHWC activation, flat[b][c*HW + p] = act[b][p][c]; inverse != 0: the other way */
 int pcg_nhwc_to_nchw_flat(const float* src, float* dst, int32_t B, int32_t HW, int32_t C, int inverse, pcg_stream_t stream);
 /* interpolates = alpha*real + (1-alpha)*fake, alpha per sample (:147) */

@@ -174,6 +174,9 @@ PROTOTYPES = {
     "pcg_instnorm_fwd": (_i, [_vp, _i32, _i32, _i32, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "pcg_instnorm_bwd": (_i, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_instnorm_bwd_bwd": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_instnorm_bwd_fused": (_i, [_vp, _vp, _f, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcg_instnorm_bwd_bwd_act": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "pcg_rowsum3": (_i, [_i32, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i32, _i32, _vp]),
     "pcg_nhwc_to_nchw_flat": (_i, [_vp, _vp, _i32, _i32, _i32, _i, _vp]),
     "pcg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pcg_gradient_penalty_fwd": (_i, [_vp, _i32, _i32, _f, _vp, _vp, _vp]),

@@ -141,7 +141,8 @@ __device__ __forceinline__ int sk_owner(int x, const SkPlan& sk) {     // the bl
 __device__ __forceinline__ int sk_segments(const SkPlan& sk, SkSeg& s0, SkSeg& s1) {
   const int b = blockIdx.x;
   if (b < sk.dp_tiles) { s0 = SkSeg{(int)xcd_remap((uint32_t)b, (uint32_t)sk.dp_tiles), 0, sk.ktiles, 1, 0}; return 1; }
-  const int g = b - sk.dp_tiles, KT = sk.ktiles;
+  // neighbouring ranges (neighbouring tiles: shared operand rows) on ONE XCD, like the tiles of the data-parallel part
+  const int g = (int)xcd_remap((uint32_t)(b - sk.dp_tiles), (uint32_t)sk.sk_blocks), KT = sk.ktiles;
   const int it0 = sk_start(g, sk), it1 = sk_start(g + 1, sk);
   const int j0 = __builtin_amdgcn_readfirstlane(it0 / KT), e0 = it1 < (j0 + 1) * KT ? it1 : (j0 + 1) * KT;
   auto fill = [&](SkSeg& sg, int j, int from, int to) {
@@ -171,7 +172,7 @@ template <class Cfg>
 __device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
   if (sg.nparts == 1) return true;
   constexpr uint32_t TILE_BYTES = Cfg::BM * Cfg::BN * 4;
-  const int g = (int)blockIdx.x - sk.dp_tiles, j = sg.tile - sk.dp_tiles, KT = sk.ktiles;
+  const int g = (int)xcd_remap((uint32_t)((int)blockIdx.x - sk.dp_tiles), (uint32_t)sk.sk_blocks), j = sg.tile - sk.dp_tiles, KT = sk.ktiles;
   auto slot_of = [&](int blk) { return (uint32_t)(2 * blk + (sk_start(blk, sk) >= j * KT ? 0 : 1)); };   // the tile is the block's first one?
   const rsrc_t rs = make_rsrc(sk.parts, (uint32_t)(2 * sk.sk_blocks) * TILE_BYTES);
   const uint32_t toff = threadIdx.x * 16u;                 // consumer threads 0..255: one 16-byte column of each 4 KB row of the partial tile
@@ -328,6 +329,41 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
     const int m = m_block + row;
     return m < p.M ? slab + (size_t)m * p.N + n_block : nullptr;
   });
+}
+
+
+// weight gradient as a stream-K launch: the K = B*OH*OW loops of ALL tiles form the iteration space (a gradient has at most a few
+// hundred tiles), the last arrival of a (tile, wave) writes dw itself — with the .grad accumulation as an EPI_ADD on dw — so
+// neither slabs nor the slab_reduce pass exist (288-tile gradients of the WGAN-GP critic: one workgroup per tile left 224 CUs
+// with one tile and 32 with two).
+template <class Cfg, bool XFA, bool XFB>
+__device__ __forceinline__ void wgrad_sk_segment(const ConvP& p, const SkPlan& sk, const SkSeg& sg, float* smem) {
+  const int mt = __builtin_amdgcn_readfirstlane(sg.tile / p.tilesN), nt = sg.tile - mt * p.tilesN;
+  const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
+    WgradALoader<Cfg::BM, XFA> la(p, m_block, sg.kt_begin, tid);
+    WgradBLoader<Cfg::BN, XFB> lb(p, n_block, sg.kt_begin, tid);
+    igemm_produce<Cfg>(la, lb, sg.nkt, smem, tid, ClockStamp{nullptr, 0});
+    return;
+  }
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  igemm_consume<Cfg, false, false>(sg.nkt, acc, smem);
+  if (sk_combine<Cfg>(sk, sg, acc))
+    igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
+      const int m = m_block + row;
+      return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
+    }, nullptr, PCG_ACT_NONE, 0.f, &p.epi);
+}
+template <class Cfg, bool XFA, bool XFB>
+__global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_sk_kernel(ConvP p, SkPlan sk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  SkSeg s0, s1{};
+  const int nseg = sk_segments(sk, s0, s1);
+  wgrad_sk_segment<Cfg, XFA, XFB>(p, sk, s0, smem);
+  if (nseg == 1) return;
+  lds_barrier();
+  wgrad_sk_segment<Cfg, XFA, XFB>(p, sk, s1, smem);
 }
 
 
@@ -1293,6 +1329,14 @@ static int launch_wgrad_x(const ConvP& p, const WgradPlan& wp, int slice_major, 
                      dim3(IG_THREADS), smem, s, p, wp.ktiles_total, wp.ktiles_per_split, wp.tiles, slice_major);
   return launch_status("conv_wgrad_kernel");
 }
+template <class Cfg, bool XFA, bool XFB>
+static int launch_wgrad_sk_x(const ConvP& p, const SkPlan& sk, hipStream_t s) {
+  constexpr size_t smem = smem_bytes<Cfg, false, false>();
+  static int once = set_smem(conv_wgrad_sk_kernel<Cfg, XFA, XFB>, smem);
+  if (once != PCG_OK) return once;
+  hipLaunchKernelGGL((conv_wgrad_sk_kernel<Cfg, XFA, XFB>), dim3((unsigned)(sk.dp_tiles + sk.sk_blocks)), dim3(IG_THREADS), smem, s, p, sk);
+  return launch_status("conv_wgrad_sk_kernel");
+}
 template <class Cfg>
 static int launch_wgrad(const ConvP& p, const WgradPlan& wp, int slice_major, int xf_side, hipStream_t s) {
   if (xf_side == 1) return launch_wgrad_x<Cfg, false, true>(p, wp, slice_major, s);    // x is a transformed activation
@@ -1329,6 +1373,16 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   const int order_env = g_tune.wgrad_order >= 0 ? g_tune.wgrad_order : order_env0;
   const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
   const int side = hx ? 1 : hy ? 2 : 0;
+  // one full-K block per tile and a tile count that leaves the chip unevenly loaded: stream-K, straight into dw
+  if (!wp.narrow && !wp.wide192 && wp.tiles > 96) {
+    SkPlan sk{};
+    if (plan_sk(wp.tiles, wp.ktiles_total, s, &sk)) {
+      p.out = dw;
+      if (accumulate) { p.epi.mode = EPI_ADD; p.epi.neg = 1.f; p.epi.delta_bytes = 0; }
+      return side == 1 ? launch_wgrad_sk_x<Cfg128x128, false, true>(p, sk, s)
+           : side == 2 ? launch_wgrad_sk_x<Cfg128x128, true, false>(p, sk, s) : launch_wgrad_sk_x<Cfg128x128, false, false>(p, sk, s);
+    }
+  }
   int rc;
   if (wp.wide192 && side == 0) {
     p.tilesN = p.N / 192;

@@ -11,6 +11,7 @@
 //                     ez  = -gamma*invstd^2 * (q*a + m*rt + (p - 3*m*q)*xh)              (cotangent reaching x)
 //                     dgamma += invstd * HW * (p - m*q)
 // (derivation checked against torch autograd in float64: tests/test_hip_wgan.py)
+#include <initializer_list>
 #include "pcg_common.h"
 
 namespace pcg {
@@ -18,13 +19,30 @@ namespace {
 
 constexpr int IN_THREADS = 256;
 
-struct Lanes { int tc, th, ch, lane, c; bool on; };
+// A block owns one sample and `tc` channels; a thread owns V consecutive channels (V = 4: 16-byte loads, a row of 64 channels is
+// 16 threads and the block's 16 position-lanes cover 16 rows per step; V = 1 for channel counts that are not multiples of 4).
+// r03: the scalar form (4 bytes per lane, 4 position-lanes) moved 2.2 TB/s on the B = 768 first stage; these passes carry the
+// LeakyReLU' / add / bias-partial work of their neighbours now, so their rate is what the critic's element-wise time is made of.
+template <int V> struct Vec { float v[V]; };
+template <int V> __device__ __forceinline__ Vec<V> ldv(const float* p) {
+  Vec<V> r;
+  if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+  else r.v[0] = *p;
+  return r;
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const Vec<V>& a) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  else *p = a.v[0];
+}
 
+struct Lanes { int tr, th, ch, lane, c; bool on; };   // tr: threads per row, th: position-lanes, c: first channel of this thread
+
+template <int V>
 __device__ __forceinline__ Lanes lanes_of(int C, int tc) {
   Lanes l;
-  l.tc = tc; l.th = IN_THREADS / tc;
-  l.ch = threadIdx.x % tc; l.lane = threadIdx.x / tc;
-  l.c = blockIdx.y * tc + l.ch;
+  l.tr = tc / V; l.th = IN_THREADS / l.tr;
+  l.ch = threadIdx.x % l.tr; l.lane = threadIdx.x / l.tr;
+  l.c = blockIdx.y * tc + l.ch * V;
   l.on = l.c < C;
   return l;
 }
@@ -39,7 +57,7 @@ __device__ __forceinline__ void lane_sum(float (&v)[K], const Lanes& l, float* s
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float s = 0.f;
-      for (int j = 0; j < l.th; ++j) s += smem[k * IN_THREADS + j * l.tc + l.ch];
+      for (int j = 0; j < l.th; ++j) s += smem[k * IN_THREADS + j * l.tr + l.ch];
       smem[k * IN_THREADS + l.ch] = s;
     }
   }
@@ -49,99 +67,214 @@ __device__ __forceinline__ void lane_sum(float (&v)[K], const Lanes& l, float* s
   __syncthreads();
 }
 
+template <int V>
 __global__ void __launch_bounds__(IN_THREADS) instnorm_fwd_kernel(const float* __restrict__ x, int HW, int C, int tc,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, int act, float slope, float* __restrict__ y,
                                                                  float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  __shared__ float smem[IN_THREADS];
-  const Lanes l = lanes_of(C, tc);
+  __shared__ float smem[V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
   const size_t base = (size_t)blockIdx.x * HW * C;
-  float s[1] = {0.f};
-  if (l.on) for (int p = l.lane; p < HW; p += l.th) s[0] += x[base + (size_t)p * C + l.c];
-  lane_sum<1>(s, l, smem);
-  const float mean = s[0] / (float)HW;
-  float q[1] = {0.f};
-  if (l.on) for (int p = l.lane; p < HW; p += l.th) { const float d = x[base + (size_t)p * C + l.c] - mean; q[0] = fmaf(d, d, q[0]); }
-  lane_sum<1>(q, l, smem);
-  const float invstd = rsqrtf(q[0] / (float)HW + eps);
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
+  if (l.on)
+    for (int p = l.lane; p < HW; p += l.th) {
+      const Vec<V> xv = ldv<V>(x + base + (size_t)p * C + l.c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += xv.v[e];
+    }
+  lane_sum<V>(s, l, smem);
+  float mean[V], q[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean[e] = s[e] / (float)HW; q[e] = 0.f; }
+  if (l.on)
+    for (int p = l.lane; p < HW; p += l.th) {
+      const Vec<V> xv = ldv<V>(x + base + (size_t)p * C + l.c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = xv.v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
+    }
+  lane_sum<V>(q, l, smem);
   if (!l.on) return;
-  if (l.lane == 0) { mean_out[(size_t)blockIdx.x * C + l.c] = mean; invstd_out[(size_t)blockIdx.x * C + l.c] = invstd; }
-  const float g = gamma[l.c] * invstd, b = beta[l.c];
+  float g[V], b[V];
+  const Vec<V> gv = ldv<V>(gamma + l.c), bv = ldv<V>(beta + l.c);
+  Vec<V> mo, io;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float invstd = rsqrtf(q[e] / (float)HW + eps);
+    mo.v[e] = mean[e]; io.v[e] = invstd;
+    g[e] = gv.v[e] * invstd; b[e] = bv.v[e];
+  }
+  if (l.lane == 0) { stv<V>(mean_out + (size_t)blockIdx.x * C + l.c, mo); stv<V>(invstd_out + (size_t)blockIdx.x * C + l.c, io); }
   for (int p = l.lane; p < HW; p += l.th) {
     const size_t i = base + (size_t)p * C + l.c;
-    y[i] = act_apply(fmaf(x[i] - mean, g, b), act, slope);
+    const Vec<V> xv = ldv<V>(x + i);
+    Vec<V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.v[e] = act_apply(fmaf(xv.v[e] - mean[e], g[e], b[e]), act, slope);
+    stv<V>(y + i, o);
   }
 }
 
-__global__ void __launch_bounds__(IN_THREADS) instnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int HW, int C,
+// One launch for the chain LeakyReLU' -> InstanceNorm' of a critic stage (mnist_wgan_conditional.py:88-95 backward):
+//   act_y  (nullable) the activation's OUTPUT: dy is first multiplied by lrelu'(.) (sign of the output = sign of the input), the
+//          separate act_bwd pass over the tensor disappears; dn_out (nullable) keeps that masked gradient for the double backward
+//   addend (nullable) added to the stored dx (the cotangent ez that the gradient penalty's second pass adds at this tensor)
+//   dxsum_part (nullable) [B][C]: sum over HW of the stored dx — the conv bias gradient's per-sample partial, so the bias
+//          gradient needs no pass of its own over dx (pcg_rowsum3 reduces the three partial arrays over B in one launch)
+template <int V>
+__global__ void __launch_bounds__(IN_THREADS) instnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act_y, float neg,
+                                                                 const float* __restrict__ x, int HW, int C,
                                                                  int tc, const float* __restrict__ mean_in,
                                                                  const float* __restrict__ invstd_in, const float* __restrict__ gamma,
+                                                                 float* __restrict__ dn_out, const float* __restrict__ addend,
                                                                  float* __restrict__ dx, float* __restrict__ dgamma_part,
-                                                                 float* __restrict__ dbeta_part) {
-  __shared__ float smem[2 * IN_THREADS];
-  const Lanes l = lanes_of(C, tc);
+                                                                 float* __restrict__ dbeta_part, float* __restrict__ dxsum_part) {
+  __shared__ float smem[2 * V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
   const size_t base = (size_t)blockIdx.x * HW * C;
-  const float mean = l.on ? mean_in[(size_t)blockIdx.x * C + l.c] : 0.f, invstd = l.on ? invstd_in[(size_t)blockIdx.x * C + l.c] : 0.f;
-  float s[2] = {0.f, 0.f};
+  Vec<V> mean, invstd;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean.v[e] = 0.f; invstd.v[e] = 0.f; }
+  if (l.on) { mean = ldv<V>(mean_in + (size_t)blockIdx.x * C + l.c); invstd = ldv<V>(invstd_in + (size_t)blockIdx.x * C + l.c); }
+  float s[2 * V];                          // [0..V): sum d, [V..2V): sum d*xh
+#pragma unroll
+  for (int e = 0; e < 2 * V; ++e) s[e] = 0.f;
   if (l.on)
     for (int p = l.lane; p < HW; p += l.th) {
       const size_t i = base + (size_t)p * C + l.c;
-      const float d = dy[i];
-      s[0] += d;
-      s[1] = fmaf(d, (x[i] - mean) * invstd, s[1]);
+      Vec<V> d = ldv<V>(dy + i);
+      const Vec<V> xv = ldv<V>(x + i);
+      if (act_y) {
+        const Vec<V> yv = ldv<V>(act_y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d.v[e] *= yv.v[e] > 0.f ? 1.f : neg;
+        if (dn_out) stv<V>(dn_out + i, d);
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) { s[e] += d.v[e]; s[V + e] = fmaf(d.v[e], (xv.v[e] - mean.v[e]) * invstd.v[e], s[V + e]); }
     }
-  lane_sum<2>(s, l, smem);
-  if (!l.on) return;
-  if (l.lane == 0) {
-    if (dgamma_part) dgamma_part[(size_t)blockIdx.x * C + l.c] = s[1];
-    if (dbeta_part) dbeta_part[(size_t)blockIdx.x * C + l.c] = s[0];
+  lane_sum<2 * V>(s, l, smem);
+  if (l.on && l.lane == 0) {
+    Vec<V> a, b;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { a.v[e] = s[V + e]; b.v[e] = s[e]; }
+    if (dgamma_part) stv<V>(dgamma_part + (size_t)blockIdx.x * C + l.c, a);
+    if (dbeta_part) stv<V>(dbeta_part + (size_t)blockIdx.x * C + l.c, b);
   }
-  if (!dx) return;
+  if (!dx) return;                         // (uniform)
   const float inv_n = 1.f / (float)HW;
-  const float m1 = s[0] * inv_n, m2 = s[1] * inv_n, g = gamma[l.c] * invstd;
-  for (int p = l.lane; p < HW; p += l.th) {
-    const size_t i = base + (size_t)p * C + l.c;
-    const float xh = (x[i] - mean) * invstd;
-    dx[i] = g * (dy[i] - m1 - xh * m2);
+  float m1[V], m2[V], g[V], t[V];
+  Vec<V> gv;
+#pragma unroll
+  for (int e = 0; e < V; ++e) gv.v[e] = 0.f;
+  if (l.on) gv = ldv<V>(gamma + l.c);
+#pragma unroll
+  for (int e = 0; e < V; ++e) { m1[e] = s[e] * inv_n; m2[e] = s[V + e] * inv_n; g[e] = gv.v[e] * invstd.v[e]; t[e] = 0.f; }
+  if (l.on)
+    for (int p = l.lane; p < HW; p += l.th) {
+      const size_t i = base + (size_t)p * C + l.c;
+      // (dn_out, when kept, already holds the masked gradient of this thread's own elements)
+      Vec<V> d = ldv<V>((act_y && dn_out) ? dn_out + i : dy + i);
+      const Vec<V> xv = ldv<V>(x + i);
+      if (act_y && !dn_out) {
+        const Vec<V> yv = ldv<V>(act_y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d.v[e] *= yv.v[e] > 0.f ? 1.f : neg;
+      }
+      Vec<V> o;
+#pragma unroll
+      for (int e = 0; e < V; ++e) o.v[e] = g[e] * (d.v[e] - m1[e] - (xv.v[e] - mean.v[e]) * invstd.v[e] * m2[e]);
+      if (addend) {
+        const Vec<V> av = ldv<V>(addend + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] += av.v[e];
+      }
+      stv<V>(dx + i, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) t[e] += o.v[e];
+    }
+  if (!dxsum_part) return;                 // (uniform)
+  lane_sum<V>(t, l, smem);
+  if (l.on && l.lane == 0) {
+    Vec<V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.v[e] = t[e];
+    stv<V>(dxsum_part + (size_t)blockIdx.x * C + l.c, o);
   }
 }
 
+template <int V>
 __global__ void __launch_bounds__(IN_THREADS) instnorm_bwd_bwd_kernel(const float* __restrict__ r, const float* __restrict__ dy,
                                                                      const float* __restrict__ x, int HW, int C, int tc,
                                                                      const float* __restrict__ mean_in, const float* __restrict__ invstd_in,
                                                                      const float* __restrict__ gamma, float* __restrict__ ddy,
-                                                                     float* __restrict__ ez, float* __restrict__ dgamma_part) {
-  __shared__ float smem[4 * IN_THREADS];
-  const Lanes l = lanes_of(C, tc);
+                                                                     float* __restrict__ ez, float* __restrict__ dgamma_part,
+                                                                     const float* __restrict__ act_y, float neg) {
+  __shared__ float smem[4 * V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
   const size_t base = (size_t)blockIdx.x * HW * C;
-  const float mean = l.on ? mean_in[(size_t)blockIdx.x * C + l.c] : 0.f, invstd = l.on ? invstd_in[(size_t)blockIdx.x * C + l.c] : 0.f;
-  float s[4] = {0.f, 0.f, 0.f, 0.f};   // sum r, sum r*xh, sum dy, sum dy*xh
+  Vec<V> mean, invstd;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean.v[e] = 0.f; invstd.v[e] = 0.f; }
+  if (l.on) { mean = ldv<V>(mean_in + (size_t)blockIdx.x * C + l.c); invstd = ldv<V>(invstd_in + (size_t)blockIdx.x * C + l.c); }
+  float s[4 * V];   // per channel e: [e] sum r, [V+e] sum r*xh, [2V+e] sum dy, [3V+e] sum dy*xh
+#pragma unroll
+  for (int e = 0; e < 4 * V; ++e) s[e] = 0.f;
   if (l.on)
     for (int p = l.lane; p < HW; p += l.th) {
       const size_t i = base + (size_t)p * C + l.c;
-      const float rv = r[i], dv = dy[i], xh = (x[i] - mean) * invstd;
-      s[0] += rv; s[1] = fmaf(rv, xh, s[1]); s[2] += dv; s[3] = fmaf(dv, xh, s[3]);
+      const Vec<V> rv = ldv<V>(r + i), dv = ldv<V>(dy + i), xv = ldv<V>(x + i);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (xv.v[e] - mean.v[e]) * invstd.v[e];
+        s[e] += rv.v[e]; s[V + e] = fmaf(rv.v[e], xh, s[V + e]); s[2 * V + e] += dv.v[e]; s[3 * V + e] = fmaf(dv.v[e], xh, s[3 * V + e]);
+      }
     }
-  lane_sum<4>(s, l, smem);
+  lane_sum<4 * V>(s, l, smem);
   const float inv_n = 1.f / (float)HW;
-  const float mr = s[0] * inv_n, q = s[1] * inv_n, md = s[2] * inv_n, m = s[3] * inv_n;
-  float c[1] = {0.f};                    // sum (r - mean r)*(dy - mean dy): centred second pass, no cancellation
+  float mr[V], q[V], md[V], m[V], c[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mr[e] = s[e] * inv_n; q[e] = s[V + e] * inv_n; md[e] = s[2 * V + e] * inv_n; m[e] = s[3 * V + e] * inv_n; c[e] = 0.f; }
+  // sum (r - mean r)*(dy - mean dy): centred second pass, no cancellation
   if (l.on)
     for (int p = l.lane; p < HW; p += l.th) {
       const size_t i = base + (size_t)p * C + l.c;
-      c[0] = fmaf(r[i] - mr, dy[i] - md, c[0]);
+      const Vec<V> rv = ldv<V>(r + i), dv = ldv<V>(dy + i);
+#pragma unroll
+      for (int e = 0; e < V; ++e) c[e] = fmaf(rv.v[e] - mr[e], dv.v[e] - md[e], c[e]);
     }
-  lane_sum<1>(c, l, smem);
+  lane_sum<V>(c, l, smem);
   if (!l.on) return;
-  const float pp = c[0] * inv_n;                                               // mean(r * a)
-  const float gam = gamma[l.c];
-  if (l.lane == 0 && dgamma_part) dgamma_part[(size_t)blockIdx.x * C + l.c] = invstd * (float)HW * (pp - m * q);
-  const float g1 = gam * invstd, g2 = -gam * invstd * invstd, k3 = pp - 3.f * m * q;
+  const Vec<V> gam = ldv<V>(gamma + l.c);
+  float g1[V], g2[V], k3[V];
+  Vec<V> dg;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float pp = c[e] * inv_n;                                             // mean(r * a)
+    dg.v[e] = invstd.v[e] * (float)HW * (pp - m[e] * q[e]);
+    g1[e] = gam.v[e] * invstd.v[e]; g2[e] = -gam.v[e] * invstd.v[e] * invstd.v[e]; k3[e] = pp - 3.f * m[e] * q[e];
+  }
+  if (l.lane == 0 && dgamma_part) stv<V>(dgamma_part + (size_t)blockIdx.x * C + l.c, dg);
   for (int p = l.lane; p < HW; p += l.th) {
     const size_t i = base + (size_t)p * C + l.c;
-    const float xh = (x[i] - mean) * invstd, a = dy[i] - md, rt = r[i] - mr;
-    if (ddy) ddy[i] = g1 * (rt - xh * q);
-    if (ez) ez[i] = g2 * (q * a + m * rt + k3 * xh);
+    const Vec<V> rv = ldv<V>(r + i), dv = ldv<V>(dy + i), xv = ldv<V>(x + i);
+    Vec<V> o1, o2;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float xh = (xv.v[e] - mean.v[e]) * invstd.v[e], a = dv.v[e] - md[e], rt = rv.v[e] - mr[e];
+      o1.v[e] = g1[e] * (rt - xh * q[e]);
+      o2.v[e] = g2[e] * (q[e] * a + m[e] * rt + k3[e] * xh);
+    }
+    if (ddy) {      // act_y: the cotangent continues through the stage's LeakyReLU (its mask is the forward's), no act_bwd pass
+      if (act_y) {
+        const Vec<V> yv = ldv<V>(act_y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o1.v[e] *= yv.v[e] > 0.f ? 1.f : neg;
+      }
+      stv<V>(ddy + i, o1);
+    }
+    if (ez) stv<V>(ez + i, o2);
   }
 }
 
@@ -199,10 +332,43 @@ __global__ void __launch_bounds__(256) gp_bwd_kernel(const float* __restrict__ g
   }
 }
 
-int pick_tc(int C) {
-  int tc = 1;
+// Sums of up to three [rows][C] partial arrays over their rows, one launch: block = 32 columns x 8 row groups of one array, fp64
+// accumulation in row order (deterministic), accumulate[k] adds into dst[k] (.grad accumulation).
+struct RowSum3 { const float* src[3]; float* dst[3]; int acc[3]; };
+__global__ void __launch_bounds__(256) rowsum3_kernel(RowSum3 a, int rows, int C) {
+  __shared__ double sm[256];
+  const int k = blockIdx.y;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;    // 32 columns x 8 row groups
+  const float* src = a.src[k];
+  double s = 0.0;
+  if (c < C) {
+    int r = rg;
+    for (; r + 24 < rows; r += 32) {     // four independent loads in flight per thread; the adds stay in row order
+      const float v0 = src[(size_t)r * C + c], v1 = src[(size_t)(r + 8) * C + c], v2 = src[(size_t)(r + 16) * C + c], v3 = src[(size_t)(r + 24) * C + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; r < rows; r += 8) s += (double)src[(size_t)r * C + c];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double t = sm[threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += sm[threadIdx.x + 32 * j];
+    float* dst = a.dst[k];
+    dst[c] = a.acc[k] ? dst[c] + (float)t : (float)t;
+  }
+}
+
+int pick_tc(int C) {                      // channels per block: 64, or the next power of two >= C below that (>= 4 when vectorised)
+  int tc = C % 4 == 0 ? 4 : 1;
   while (tc < C && tc < 64) tc <<= 1;
   return tc;
+}
+bool vec4(int C, std::initializer_list<const void*> ptrs) {
+  if (C % 4) return false;
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15)) return false;
+  return true;
 }
 unsigned ew_blocks(size_t n) {
   size_t b = (n + 255) / 256;
@@ -219,30 +385,70 @@ using namespace pcg;
 extern "C" int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C, const float* gamma, const float* beta, float eps, int act,
                                 float slope, float* y, float* mean, float* invstd, pcg_stream_t stream) {
   PCG_REQUIRE(x && gamma && beta && y && mean && invstd && B > 0 && HW > 0 && C > 0, "pcg_instnorm_fwd: bad arguments");
-  const int tc = pick_tc(C);
-  hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps,
-                     act, slope, y, mean, invstd);
+  if (vec4(C, {x, gamma, beta, y, mean, invstd})) {
+    const int tc = pick_tc(C);
+    hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps,
+                       act, slope, y, mean, invstd);
+  } else {
+    int tc = 1;
+    while (tc < C && tc < 64) tc <<= 1;
+    hipLaunchKernelGGL(instnorm_fwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps,
+                       act, slope, y, mean, invstd);
+  }
   return launch_status("instnorm_fwd_kernel");
 }
 
-extern "C" int pcg_instnorm_bwd(const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean, const float* invstd,
-                                const float* gamma, float* dx, float* dgamma_partial, float* dbeta_partial, pcg_stream_t stream) {
+extern "C" int pcg_instnorm_bwd_fused(const float* dy, const float* act_y, float neg_slope, const float* x, int32_t B, int32_t HW, int32_t C,
+                                      const float* mean, const float* invstd, const float* gamma, float* dn_out, const float* addend, float* dx,
+                                      float* dgamma_partial, float* dbeta_partial, float* dxsum_partial, pcg_stream_t stream) {
   PCG_REQUIRE(dy && x && mean && invstd && gamma && (dx || dgamma_partial) && B > 0 && HW > 0 && C > 0, "pcg_instnorm_bwd: bad arguments");
-  const int tc = pick_tc(C);
-  hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, x, HW, C, tc, mean, invstd,
-                     gamma, dx, dgamma_partial, dbeta_partial);
+  PCG_REQUIRE((!dn_out || act_y) && (!addend || dx) && (!dxsum_partial || dx), "pcg_instnorm_bwd_fused: dn_out needs act_y; addend / dxsum_partial need dx");
+  if (vec4(C, {dy, act_y, x, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial})) {
+    const int tc = pick_tc(C);
+    hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc,
+                       mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+  } else {
+    int tc = 1;
+    while (tc < C && tc < 64) tc <<= 1;
+    hipLaunchKernelGGL(instnorm_bwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc,
+                       mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+  }
   return launch_status("instnorm_bwd_kernel");
 }
+extern "C" int pcg_instnorm_bwd(const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean, const float* invstd,
+                                const float* gamma, float* dx, float* dgamma_partial, float* dbeta_partial, pcg_stream_t stream) {
+  return pcg_instnorm_bwd_fused(dy, nullptr, 0.f, x, B, HW, C, mean, invstd, gamma, nullptr, nullptr, dx, dgamma_partial, dbeta_partial, nullptr, stream);
+}
 
+extern "C" int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,
+                                        const float* invstd, const float* gamma, const float* act_y, float neg_slope, float* ddy, float* ez,
+                                        float* dgamma_partial, pcg_stream_t stream) {
+  PCG_REQUIRE(r && dy && x && mean && invstd && gamma && (ddy || ez || dgamma_partial) && B > 0 && HW > 0 && C > 0,
+              "pcg_instnorm_bwd_bwd: bad arguments");
+  if (vec4(C, {r, dy, x, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y})) {
+    const int tc = pick_tc(C);
+    hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean,
+                       invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+  } else {
+    int tc = 1;
+    while (tc < C && tc < 64) tc <<= 1;
+    hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean,
+                       invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+  }
+  return launch_status("instnorm_bwd_bwd_kernel");
+}
 extern "C" int pcg_instnorm_bwd_bwd(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,
                                     const float* invstd, const float* gamma, float* ddy, float* ez, float* dgamma_partial,
                                     pcg_stream_t stream) {
-  PCG_REQUIRE(r && dy && x && mean && invstd && gamma && (ddy || ez || dgamma_partial) && B > 0 && HW > 0 && C > 0,
-              "pcg_instnorm_bwd_bwd: bad arguments");
-  const int tc = pick_tc(C);
-  hipLaunchKernelGGL(instnorm_bwd_bwd_kernel, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean,
-                     invstd, gamma, ddy, ez, dgamma_partial);
-  return launch_status("instnorm_bwd_bwd_kernel");
+  return pcg_instnorm_bwd_bwd_act(r, dy, x, B, HW, C, mean, invstd, gamma, nullptr, 0.f, ddy, ez, dgamma_partial, stream);
+}
+
+extern "C" int pcg_rowsum3(int32_t n, const float* src0, float* dst0, int acc0, const float* src1, float* dst1, int acc1, const float* src2,
+                           float* dst2, int acc2, int32_t rows, int32_t C, pcg_stream_t stream) {
+  PCG_REQUIRE(n >= 1 && n <= 3 && rows > 0 && C > 0 && src0 && dst0 && (n < 2 || (src1 && dst1)) && (n < 3 || (src2 && dst2)), "pcg_rowsum3: bad arguments");
+  RowSum3 a{{src0, src1, src2}, {dst0, dst1, dst2}, {acc0, acc1, acc2}};
+  hipLaunchKernelGGL(rowsum3_kernel, dim3((C + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, a, rows, C);
+  return launch_status("rowsum3_kernel");
 }
 
 extern "C" int pcg_nhwc_to_nchw_flat(const float* src, float* dst, int32_t B, int32_t HW, int32_t C, int inverse, pcg_stream_t stream) {

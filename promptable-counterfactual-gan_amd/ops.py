@@ -1026,14 +1026,38 @@ def instnorm_bwd(dy, x, B, HW, C, mean, invstd, gamma, need_dx=True, need_params
     return dx, dgp, dbp
 
 
-def instnorm_bwd_bwd(r, dy, x, B, HW, C, mean, invstd, gamma, need_ddy=True, need_ez=True, need_gamma=True):
-    """(ddy, ez, dgamma_partial [B,C])"""
+def instnorm_bwd_fused(dy, x, B, HW, C, mean, invstd, gamma, act_y=None, slope=0.0, keep_dn=False, addend=None, need_params=True,
+                       need_dxsum=False):
+    """LeakyReLU' -> InstanceNorm' (-> + addend) of a critic stage in one launch: (dx, dn or None, dgamma_partial, dbeta_partial,
+    dxsum_partial), partials [B, C] (rowsum3 reduces them over B); see pcg_instnorm_bwd_fused in include/pcgan_hip.h."""
+    _chk(dy, "dy"); _chk(x, "x")
+    dx = torch.empty_like(x)
+    dn = torch.empty_like(x) if (keep_dn and act_y is not None) else None
+    mk = lambda on: torch.empty((B, C), dtype=torch.float32, device=x.device) if on else None
+    dgp, dbp, dsp = mk(need_params), mk(need_params), mk(need_dxsum)
+    check(_lib.load().pcg_instnorm_bwd_fused(_p(dy), _p(act_y), float(slope), _p(x), B, HW, C, _p(mean), _p(invstd), _p(gamma), _p(dn), _p(addend),
+                                             _p(dx), _p(dgp), _p(dbp), _p(dsp), _stream()), "pcg_instnorm_bwd_fused")
+    return dx, dn, dgp, dbp, dsp
+
+
+def rowsum3(items, rows, C):
+    """items: up to three (src [rows, C], dst [C], accumulate) — dst (+)= column sums of src, all in one launch."""
+    assert 1 <= len(items) <= 3
+    a = []
+    for k in range(3):
+        src, dst, acc = items[k] if k < len(items) else (None, None, False)
+        a += [_p(src), _p(dst), int(bool(acc))]
+    check(_lib.load().pcg_rowsum3(len(items), *a, int(rows), int(C), _stream()), "pcg_rowsum3")
+
+
+def instnorm_bwd_bwd(r, dy, x, B, HW, C, mean, invstd, gamma, need_ddy=True, need_ez=True, need_gamma=True, act_y=None, slope=0.0):
+    """(ddy, ez, dgamma_partial [B,C]); act_y: ddy continues through the stage's LeakyReLU (its output) in the same launch"""
     _chk(r, "r"); _chk(dy, "dy"); _chk(x, "x")
     ddy = torch.empty_like(x) if need_ddy else None
     ez = torch.empty_like(x) if need_ez else None
     dgp = torch.empty((B, C), dtype=torch.float32, device=x.device) if need_gamma else None
-    check(_lib.load().pcg_instnorm_bwd_bwd(_p(r), _p(dy), _p(x), B, HW, C, _p(mean), _p(invstd), _p(gamma), _p(ddy), _p(ez), _p(dgp),
-                                           _stream()), "pcg_instnorm_bwd_bwd")
+    check(_lib.load().pcg_instnorm_bwd_bwd_act(_p(r), _p(dy), _p(x), B, HW, C, _p(mean), _p(invstd), _p(gamma), _p(act_y), float(slope), _p(ddy),
+                                               _p(ez), _p(dgp), _stream()), "pcg_instnorm_bwd_bwd_act")
     return ddy, ez, dgp
 
 

@@ -227,11 +227,12 @@ class Critic(FlatModule):
         for i in range(len(stages) - 1, -1, -1):
             g, a, z, mean_, invstd, y = stages[i]
             conv, inorm = stage_mods[i]
-            dn = ops.act_bwd(d, y, ACT_LRELU, 0.2, out=None if keep else d)
-            dz, dgp, dbp = ops.instnorm_bwd(dn, z, B, g.OH * g.OW, g.Cout, mean_, invstd, inorm.weight.data, need_params=need_p)
+            # LeakyReLU' -> InstanceNorm' in one launch, with the per-sample partials of dgamma, dbeta and the conv bias gradient
+            dz, dn, dgp, dbp, dsp = ops.instnorm_bwd_fused(d, z, B, g.OH * g.OW, g.Cout, mean_, invstd, inorm.weight.data, act_y=y, slope=0.2,
+                                                           keep_dn=keep, need_params=need_p, need_dxsum=need_p)
             if need_p:
-                self._in_param_grads(inorm, dgp, dbp, B)
-                self._conv_param_grads(conv, g, a, dz)
+                self._stage_vector_grads(inorm, conv, dgp, dbp, dsp, B)
+                self._conv_param_grads(conv, g, a, dz, bias=False)
             if keep:
                 first.append((dn, dz))
             if i == 0 and not need_x:
@@ -241,19 +242,20 @@ class Critic(FlatModule):
         dx = d.view(B, 1, d.shape[1], d.shape[2]) if d is not None else None
         return dx, ((first[::-1], dp, dout) if keep else None)
 
-    def _in_param_grads(self, inorm, dgp, dbp, B):
-        C = inorm.num_features
-        if dgp is not None:
-            gg, acc = self._grad_view(inorm.weight)
-            ops.colsum(B, C, dgp, gg, acc)
-        if dbp is not None:
-            gb, acc = self._grad_view(inorm.bias)
-            ops.colsum(B, C, dbp, gb, acc)
+    def _stage_vector_grads(self, inorm, conv, dgp, dbp, dsp, B):
+        """dgamma, dbeta (InstanceNorm affine) and the conv bias gradient from their [B, C] per-sample partials: one launch."""
+        items = []
+        for prm, part in ((inorm.weight, dgp), (inorm.bias, dbp), (conv.bias, dsp)):
+            if part is not None:
+                gv, acc = self._grad_view(prm)
+                items.append((part, gv, acc))
+        if items:
+            ops.rowsum3(items, B, inorm.num_features)
 
-    def _conv_param_grads(self, conv, g, a, dz, x_side=None):
+    def _conv_param_grads(self, conv, g, a, dz, x_side=None, bias=True):
         gw, acc = self._grad_view(conv.weight)
         ops.conv2d_wgrad(g, a if x_side is None else x_side, dz, ops.ohwi(gw), acc)
-        if x_side is None:
+        if x_side is None and bias:
             gb, accb = self._grad_view(conv.bias)
             ops.colsum(dz.numel() // g.Cout, g.Cout, dz, gb, accb)
 
@@ -272,10 +274,9 @@ class Critic(FlatModule):
             dn, dz = firsts[i]
             ddz = ops.conv2d_fwd(g, rl, ops.ohwi(conv.weight.data), None)              # adjoint of dgrad in dz
             self._conv_param_grads(conv, g, a, dz, x_side=rl)                          # d/dW of <r, dgrad(dz; W)>
-            ddn, ez, dgp = ops.instnorm_bwd_bwd(ddz, dn, z, B, g.OH * g.OW, g.Cout, mean_, invstd, inorm.weight.data)
-            self._in_param_grads(inorm, dgp, None, B)
+            rl, ez, dgp = ops.instnorm_bwd_bwd(ddz, dn, z, B, g.OH * g.OW, g.Cout, mean_, invstd, inorm.weight.data, act_y=y, slope=0.2)
+            self._stage_vector_grads(inorm, conv, dgp, None, None, B)                  # (rl: the cotangent on da_l, LeakyReLU' applied)
             ezs.append(ez)
-            rl = ops.act_bwd(ddn, y, ACT_LRELU, 0.2, out=ddn)                          # cotangent on da_l
         # head: da_3 = unflatten(du[:, :nf]); du = dp W1; dp = dh * lrelu'(p); dh = dout W2
         l1, l2 = self.Critic_net[0], self.Critic_net[2]
         nf = HW * C
@@ -289,19 +290,21 @@ class Critic(FlatModule):
         linear_wgrad(self, l2, ddh, dout, use_bias=False)                                # dW2 += dout^T ddh
         # down: the cotangents ez_l sit on forward activations z_l — ordinary backward through the forward graph
         e = ezs[-1]
+        bias_done = False                          # the last stage's e comes from instnorm_bwd_bwd: its bias gradient is a colsum of its own
         for i in range(len(stages) - 1, -1, -1):
             g, a, z, mean_, invstd, y = stages[i]
             conv, inorm = stage_mods[i]
-            self._conv_param_grads(conv, g, a, e)
+            self._conv_param_grads(conv, g, a, e, bias=not bias_done)
             if i == 0:
                 break
             gp_, ap, zp, meanp, invstdp, yp = stages[i - 1]
             convp, inormp = stage_mods[i - 1]
             da = ops.conv2d_dgrad(g, e, ops.ohwi(conv.weight.data))
-            dn = ops.act_bwd(da, yp, ACT_LRELU, 0.2, out=da)
-            dz, dgp, dbp = ops.instnorm_bwd(dn, zp, B, gp_.OH * gp_.OW, gp_.Cout, meanp, invstdp, inormp.weight.data)
-            self._in_param_grads(inormp, dgp, dbp, B)
-            e = ops.axpby(1.0, dz, 1.0, ezs[i - 1], out=dz)
+            # e_{l-1} = IN'(lrelu'(da)) + ez_{l-1}, and the per-sample partial of its bias gradient, in one launch
+            e, _, dgp, dbp, esp = ops.instnorm_bwd_fused(da, zp, B, gp_.OH * gp_.OW, gp_.Cout, meanp, invstdp, inormp.weight.data, act_y=yp, slope=0.2,
+                                                         addend=ezs[i - 1], need_params=True, need_dxsum=True)
+            self._stage_vector_grads(inormp, convp, dgp, dbp, esp, B)
+            bias_done = True
 
 
 # ---- gradient penalty -------------------------------------------------------------------------------------------------------

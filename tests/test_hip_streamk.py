@@ -80,3 +80,33 @@ def test_grad_input_streamk_matches_plain(pcg, shape):
     want = torch.nn.functional.conv_transpose2d(dy[:2].double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), stride=s, padding=p,
                                                 output_padding=H - ((g.OH - 1) * s - 2 * p + k)).permute(0, 2, 3, 1)
     assert float((d1[:2].double().cpu() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("shape", [(512, 512, 1024, 6, 3, 2, 0),     # critic conv3 at B = 512: 288 tiles x 64 k-tiles
+                                   (256, 512, 1024, 7, 3, 2, 1),     # generator ConvT2's gradient: 288 tiles x 128 k-tiles
+                                   (40, 96, 160, 9, 3, 1, 1)])       # ragged
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_grad_weight_streamk_matches_slabs(pcg, shape, accumulate):
+    ops = pcg.ops
+    B, Cin, Cout, H, k, s, p = shape
+    g = _geom(ops, *shape)
+    gen = torch.Generator(device="cpu").manual_seed(13)
+    x = torch.randn((B, H, H, Cin), generator=gen).to(DEV)
+    dy = (torch.randn((B, g.OH, g.OW, Cout), generator=gen) * 0.1).to(DEV)
+    base = torch.randn((Cout, k, k, Cin), generator=gen).to(DEV)
+    outs = []
+    for mode in (0, 2, 2):
+        ops.tune("stream_k", mode)
+        dw = base.clone()
+        ops.conv2d_wgrad(g, x, dy, dw, accumulate)
+        outs.append(dw)
+    assert torch.equal(outs[1], outs[2])
+    K = B * g.OH * g.OW
+    tol = 16 * 2.0 ** -24 * K * float(x.abs().mean() * dy.abs().mean()) * 4 + 1e-6
+    assert float((outs[1] - outs[0]).abs().max()) <= tol
+    # fp64 sample: four output channels
+    xs = x.double().permute(0, 3, 1, 2).cpu(); dys = dy.double().permute(0, 3, 1, 2).cpu()
+    w0 = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xs, w0, None, stride=s, padding=p).backward(dys)
+    want = w0.grad.permute(0, 2, 3, 1)[:4] + (base[:4].double().cpu() if accumulate else 0.0)
+    assert float((outs[1][:4].double().cpu() - want).abs().max()) <= tol
