@@ -106,17 +106,21 @@ class Ranks:
 
 
 def pmc_traffic(name):
-    """HBM bytes per launch of the implicit-GEMM family from the committed rocprofv3 --pmc summary of this bench (FETCH_SIZE doubled +
-    WRITE_SIZE, separate passes: profiles/r02_pmc_traffic_<name>.json), or None."""
+    """(HBM bytes per launch of the implicit-GEMM family, file) from the newest committed rocprofv3 --pmc summary of this bench
+    (FETCH_SIZE doubled + WRITE_SIZE, separate passes: profiles/r0N_pmc_traffic_<name>.json), or (None, None)."""
     import json
-    try:
-        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r02_pmc_traffic_{name}.json")) as f:
-            return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    for tag in ("r03", "r02"):
+        try:
+            fn = f"{tag}_pmc_traffic_{name}.json"
+            with open(os.path.join(root, fn)) as f:
+                return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"]), fn
+        except Exception:
+            continue
+    return None, None
 
 
-def conv_family_roofline(records, step_seconds, sampled_steps, algo_flops_per_step, traffic=None):
+def conv_family_roofline(records, step_seconds, sampled_steps, algo_flops_per_step, traffic=None, traffic_file=None):
     """`records`: (label, flops, start_event, end_event) of every MFMA conv launch in the event-sampled eager steps (ops.set_conv_hook)."""
     agg = {}
     for label, flops, e0, e1 in records:
@@ -129,7 +133,7 @@ def conv_family_roofline(records, step_seconds, sampled_steps, algo_flops_per_st
         return None
     ach = tot_f / tot_t / 1e12
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_traffic_*.json)",
+            "traffic": traffic, "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, profiles/{traffic_file})" if traffic_file else None,
             "kernel": "fp32-MFMA implicit-GEMM conv family (conv_fwd / dgrad / wgrad kernels; HIP events around every launch)",
             "step_frac": round(algo_flops_per_step / step_seconds / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "gemm_time_share": round(tot_t / (step_seconds * sampled_steps), 4),

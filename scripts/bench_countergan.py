@@ -108,7 +108,7 @@ def main():
             "config": {"workload": f"conditional_counteRGAN/mnist CounteRGAN (ResidualGenerator 6 blocks, Discriminator, frozen CNNClassifier), "
                                    f"28x28, batch {args.batch} per GPU, full step incl. BatchNorm, BCE/CE/L1 losses, Adam x2",
                        "global_batch": R.world * args.batch, "parallelism": f"dp{R.world}"},
-            "roofline": BL.conv_family_roofline(records, sec, len(sampled), ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch, traffic=BL.pmc_traffic("countergan")),
+            "roofline": BL.conv_family_roofline(records, sec, len(sampled), ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch, **dict(zip(("traffic", "traffic_file"), BL.pmc_traffic("countergan")))),
             "cpu_baseline": cpu, "final_losses": losses,
             "rccl_ranks": None if dp is None else dp.rccl_ranks(), "replicas_identical": same,
             "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",

@@ -126,11 +126,13 @@ def main():
                   + 28 * (nG + nD)                        # Adam: p, g read; m, v read+write; p write
                   + B * per_row_saved)
     launches = None
-    try:
-        with open(os.path.join(BL.ROOT, "profiles", "r02_house_launches.json")) as f:
-            launches = json.load(f)["launches_per_step"]
-    except Exception:
-        pass
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(BL.ROOT, "profiles", f"{tag}_house_launches.json")) as f:
+                launches = json.load(f)["launches_per_step"]
+            break
+        except Exception:
+            pass
     ach = algo_bytes / sec / 1e9
     roofline = {"bound": "launch/hbm", "achieved": round(ach, 2), "peak": BL.PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / BL.PEAK_HBM_GBS, 5),
                 "traffic": None, "algorithmic_bytes_per_step": int(algo_bytes), "launches_per_step": launches,

@@ -94,7 +94,7 @@ def main():
                "sample": f"{ns} critic update(s) + {ns} generator update(s) at batch {cb} (= the GPU run's batch per GPU), width {args.width}, "
                          f"{nw} warm-up each, combined with the 1/n_critic weight; PyTorch-CPU fp32 restatement of mnist_wgan_conditional.py:133-168"}
     if R.rank == 0:
-        roof = BL.conv_family_roofline(records, it, 1, flops_it, traffic=BL.pmc_traffic("wgan"))
+        roof = BL.conv_family_roofline(records, it, 1, flops_it, **dict(zip(("traffic", "traffic_file"), BL.pmc_traffic("wgan"))))
         if roof:
             roof["gemm_time_share"] = None     # events sample one critic and one generator update, not one weighted iteration
         BL.emit({

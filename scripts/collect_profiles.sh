@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r02
+#   bash scripts/collect_profiles.sh r03
 # kernel statistics of the four benches, the PMC traffic passes (FETCH_SIZE and WRITE_SIZE separately) and the JSON lines.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/prof_$TAG

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -25,7 +25,7 @@ def short(name):
     import re
     name = name.replace("pcg::(anonymous namespace)::", "").replace("void ", "")
     # TileCfg<BM, BN, WM, WN[, swizzled, min waves/SIMD, prefetch depth]> -> BMxBN (+ "/swz3" for the unpadded three-per-CU config)
-    name = re.sub(r"pcg::TileCfg<(\d+), (\d+), \d+, \d+(?:, (true|false), \d+, \d+)?>",
+    name = re.sub(r"pcg::TileCfg<(\d+), (\d+), \d+, \d+(?:, (true|false), \d+, \d+(?:, (?:true|false))?)?>",
                   lambda m: f"{m.group(1)}x{m.group(2)}" + ("/swz3" if m.group(3) == "true" else ""), name)
     return name.split("(")[0]
 
@@ -74,8 +74,11 @@ if trace:
         busy = sum(int(r_["End_Timestamp"]) - int(r_["Start_Timestamp"]) for r_ in rows[a:b]) / 10.0 / 1e3
         nat = sum(1 for r_ in rows[a:b] if "at::native" in r_["Kernel_Name"]) / 10.0
         queues = sorted({r_["Queue_Id"] for r_ in rows[a:b]})
+        per_name = collections.Counter(short(r_["Kernel_Name"]) for r_ in rows[a:b])
         json.dump({"launches_per_step": lps, "step_period_us_under_profiler": period, "sum_of_kernel_durations_us": busy,
                    "aten_kernels_per_step": nat, "hw_queues_used": len(queues),
+                   "copy_kernels_per_step": sum(v for k, v in per_name.items() if "copyBuffer" in k or "fillBuffer" in k) / 10.0,
+                   "dispatches_per_step_by_kernel": {k: v / 10.0 for k, v in sorted(per_name.items())},
                    "how": "dispatches between consecutive house_draws_kernel launches (one per step), mean of the last 10 steps of "
                           "rocprofv3 --kernel-trace -- python3 scripts/bench_house.py --steps 50 --warmup 10"},
                   open(os.path.join(out, f"{tag}_house_launches.json"), "w"), indent=1)

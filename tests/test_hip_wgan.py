@@ -71,6 +71,49 @@ def test_instance_norm_forward_backward_and_backward_of_backward(pcg, B, C, H, W
     assert only_ez[0] is None and only_ez[2] is None and torch.equal(only_ez[1], ezd)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 8, 13, 13), (5, 64, 6, 6), (256, 1024, 2, 2), (64, 256, 13, 13), (2, 6, 3, 5)])
+def test_fused_stage_backward_equals_the_chain_it_replaces(pcg, B, C, H, W):
+    """pcg_instnorm_bwd_fused (LeakyReLU' -> InstanceNorm' -> + addend, per-sample partials of dgamma / dbeta / the conv bias gradient),
+    pcg_rowsum3 and the masked ddy of pcg_instnorm_bwd_bwd_act against float64 autograd of the chain
+    z -> InstanceNorm -> LeakyReLU (mnist_wgan_conditional.py:88-95) — what the critic's backward sweeps launch per stage."""
+    ops = pcg.ops
+    g = torch.Generator().manual_seed(B * 77 + C)
+    z = (torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 1.3 + 0.2).requires_grad_(True)
+    gamma = (torch.randn(C, generator=g, dtype=torch.float64) * 0.5 + 1).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    d = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)          # cotangent on the activation's output
+    add = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    r = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    y = F.leaky_relu(F.instance_norm(z, weight=gamma, bias=beta, eps=1e-5), 0.2)
+    dz, dgam, dbet = torch.autograd.grad(y, [z, gamma, beta], d)
+    want_dx = dz + add
+    HW = H * W
+    zd, dd, addd, rd = (_dev(_nhwc(t.detach()).float()) for t in (z, d, add, r))
+    gd, bd = _dev(gamma.detach().float()), _dev(beta.detach().float())
+    yd, mean, invstd = ops.instnorm_fwd(zd, B, HW, C, gd, bd, 1e-5, pcg._lib.ACT_LRELU, 0.2)
+    dx, dn, dgp, dbp, dsp = ops.instnorm_bwd_fused(dd, zd, B, HW, C, mean, invstd, gd, act_y=yd, slope=0.2, keep_dn=True, addend=addd,
+                                                   need_params=True, need_dxsum=True)
+    sc = float(want_dx.abs().max())
+    _close(dx, _nhwc(want_dx), 1e-4, 2e-5 * sc, "dx + addend")
+    mask = torch.where(_nhwc(y.detach()) > 0, 1.0, 0.2)
+    _close(dn, _nhwc(d) * mask, 1e-6, 1e-6, "dn")
+    # the same launch without dn / addend / partials gives the same dz
+    dx2, dn2, _, _, _ = ops.instnorm_bwd_fused(dd, zd, B, HW, C, mean, invstd, gd, act_y=yd, slope=0.2, need_params=False)
+    assert dn2 is None
+    _close(dx2, _nhwc(dz), 1e-4, 2e-5 * float(dz.abs().max()), "dz")
+    # one launch for the three vector gradients, with and without accumulation
+    out = [torch.full((C,), 0.5, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)]
+    ops.rowsum3([(dgp, out[0], True), (dbp, out[1], False), (dsp, out[2], False)], B, C)
+    _close(out[0], dgam + 0.5, 1e-4, 2e-5 * float(dgam.abs().max()) + 1e-5, "dgamma (+=)")
+    _close(out[1], dbet, 1e-4, 2e-5 * float(dbet.abs().max()) + 1e-5, "dbeta")
+    _close(out[2], want_dx.sum((0, 2, 3)), 1e-4, 3e-5 * float(want_dx.abs().sum((0, 2, 3)).max()) + 1e-5, "sum of the stored dx (conv bias gradient)")
+    # masked ddy
+    ddy_plain, ez, dg2 = ops.instnorm_bwd_bwd(rd, dn, zd, B, HW, C, mean, invstd, gd)
+    ddy_masked, ez2, _ = ops.instnorm_bwd_bwd(rd, dn, zd, B, HW, C, mean, invstd, gd, act_y=yd, slope=0.2)
+    assert torch.equal(ez, ez2)
+    assert torch.equal(ddy_masked, ops.act_bwd(ddy_plain, yd, pcg._lib.ACT_LRELU, 0.2))
+
+
 def test_flatten_interpolate_gradient_penalty(pcg):
     ops, W = pcg.ops, pcg.wgan
     g = torch.Generator().manual_seed(5)
