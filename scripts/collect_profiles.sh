@@ -9,9 +9,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-echo "[collect] DCGAN kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcgan -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/dcgan.log 2>&1 || exit 1
-echo "[collect] DCGAN pmc fetch";    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 || exit 1
-echo "[collect] DCGAN pmc write";    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1 || exit 1
+echo "[collect] DCGAN kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcgan -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-calib > $O/dcgan.log 2>&1 || exit 1
+echo "[collect] DCGAN pmc fetch";    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calib > $O/pmc_fetch.log 2>&1 || exit 1
+echo "[collect] DCGAN pmc write";    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calib > $O/pmc_write.log 2>&1 || exit 1
 echo "[collect] countergan";         rocprofv3 --kernel-trace --stats --output-format csv -d $O/countergan -o p -- python3 $R/scripts/bench_countergan.py --steps 5 --warmup 2 --no-cpu-baseline > $O/countergan.log 2>&1 || exit 1
 echo "[collect] wgan";               rocprofv3 --kernel-trace --stats --output-format csv -d $O/wgan -o p -- python3 $R/scripts/bench_wgan.py --steps 10 --warmup 2 --no-cpu-baseline > $O/wgan.log 2>&1 || exit 1
 echo "[collect] countergan pmc";     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_countergan -o p -- python3 $R/scripts/bench_countergan.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_countergan.log 2>&1 || exit 1

@@ -56,7 +56,7 @@ def stats_md(sub, dest, title, steps):
     return path, tot, calls
 
 
-r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline (DCGAN 64x64, batch 512)", 16)
+r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-calib (DCGAN 64x64, batch 512)", 16)
 if r:
     shutil.copy(r[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
 stats_md("countergan", f"{tag}_countergan_kernel_stats.md", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 (batch 1024)", 10)
