@@ -1373,10 +1373,14 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   const int order_env = g_tune.wgrad_order >= 0 ? g_tune.wgrad_order : order_env0;
   const int slice_major = order_env >= 0 ? order_env : (wp.tiles <= 8 ? 1 : 0);
   const int side = hx ? 1 : hy ? 2 : 0;
-  // one full-K block per tile and a tile count that leaves the chip unevenly loaded: stream-K, straight into dw
-  if (!wp.narrow && !wp.wide192 && wp.tiles > 96) {
+  // a tile count that leaves the chip unevenly loaded: stream-K, straight into dw.  One full-K block per tile anyway (splits == 1:
+  // the Linear 8192 -> 1024 gradients, 512 tiles x 8-16 k-tiles): the same kernel with every tile data-parallel — dw written (or
+  // accumulated) by the epilogue, no slab and no slab_reduce pass (30 us behind an 84 us kernel in the r03 critic trace)
+  if (!wp.narrow && !wp.wide192 && wp.tiles > 96 && sk_mode() != 0) {
     SkPlan sk{};
-    if (plan_sk(wp.tiles, wp.ktiles_total, s, &sk)) {
+    bool take = plan_sk(wp.tiles, wp.ktiles_total, s, &sk);
+    if (!take && wp.splits == 1) { sk = SkPlan{wp.tiles, 0, 0, wp.ktiles_total, nullptr, nullptr}; take = true; }
+    if (take) {
       p.out = dw;
       if (accumulate) { p.epi.mode = EPI_ADD; p.epi.neg = 1.f; p.epi.delta_bytes = 0; }
       return side == 1 ? launch_wgrad_sk_x<Cfg128x128, false, true>(p, sk, s)
