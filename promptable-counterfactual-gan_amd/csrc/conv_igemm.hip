@@ -167,14 +167,16 @@ __device__ __forceinline__ float4 sk_load4(rsrc_t r, uint32_t off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-// consumer waves, after the main loop of a segment: true when this wave holds the finished sum of its quadrant in `acc`
-template <class Cfg>
-__device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
-  if (sg.nparts == 1) return true;
+// consumer waves, after the main loop of a segment: true when this wave holds the finished sum of its quadrant in `acc`.
+//   g: this workgroup's range index, j: arrival-counter index of the tile, nparts / first_block: the ranges that touch the tile,
+//   first_of(blk): does range blk START inside this tile (its partial is then in the range's slot 0, else in slot 1)
+template <class Cfg, class FirstOf>
+__device__ __forceinline__ bool sk_combine_core(float* parts, int* arrivals, int nblocks, int g, int j, int nparts, int first_block,
+                                                FirstOf first_of, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  if (nparts == 1) return true;
   constexpr uint32_t TILE_BYTES = Cfg::BM * Cfg::BN * 4;
-  const int g = (int)xcd_remap((uint32_t)((int)blockIdx.x - sk.dp_tiles), (uint32_t)sk.sk_blocks), j = sg.tile - sk.dp_tiles, KT = sk.ktiles;
-  auto slot_of = [&](int blk) { return (uint32_t)(2 * blk + (sk_start(blk, sk) >= j * KT ? 0 : 1)); };   // the tile is the block's first one?
-  const rsrc_t rs = make_rsrc(sk.parts, (uint32_t)(2 * sk.sk_blocks) * TILE_BYTES);
+  auto slot_of = [&](int blk) { return (uint32_t)(2 * blk + (first_of(blk) ? 0 : 1)); };
+  const rsrc_t rs = make_rsrc(parts, (uint32_t)(2 * nblocks) * TILE_BYTES);
   const uint32_t toff = threadIdx.x * 16u;                 // consumer threads 0..255: one 16-byte column of each 4 KB row of the partial tile
   const uint32_t mine = slot_of(g) * TILE_BYTES + toff;
 #pragma unroll
@@ -186,11 +188,11 @@ __device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f3
         sk_store4(rs, mine + (uint32_t)(((i * Cfg::TN + jj) * 4 + q) * IG_LOADERS * 16),
                   acc[i][jj][4 * q], acc[i][jj][4 * q + 1], acc[i][jj][4 * q + 2], acc[i][jj][4 * q + 3]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's partial quadrant has left for memory
-  int* cnt = sk.arrivals + j * 4 + (int)(threadIdx.x >> 6);
+  int* cnt = arrivals + j * 4 + (int)(threadIdx.x >> 6);
   int old = 0;
   if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __builtin_amdgcn_readfirstlane(old);
-  if (old != sg.nparts - 1) return false;
+  if (old != nparts - 1) return false;
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
@@ -198,8 +200,8 @@ __device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f3
     for (int jj = 0; jj < Cfg::TN; ++jj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-  for (int k = 0; k < sg.nparts; ++k) {
-    const uint32_t src = slot_of(sg.first_block + k) * TILE_BYTES + toff;
+  for (int k = 0; k < nparts; ++k) {
+    const uint32_t src = slot_of(first_block + k) * TILE_BYTES + toff;
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -211,6 +213,12 @@ __device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f3
         }
   }
   return true;
+}
+template <class Cfg>
+__device__ __forceinline__ bool sk_combine(const SkPlan& sk, const SkSeg& sg, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+  const int g = (int)xcd_remap((uint32_t)((int)blockIdx.x - sk.dp_tiles), (uint32_t)sk.sk_blocks), j = sg.tile - sk.dp_tiles, KT = sk.ktiles;
+  return sk_combine_core<Cfg>(sk.parts, sk.arrivals, sk.sk_blocks, g, j, sg.nparts, sg.first_block,
+                              [&](int blk) { return sk_start(blk, sk) >= j * KT; }, acc);
 }
 
 // One segment = the base kernel's body over k-tiles [kt_begin, kt_begin + nkt) of one tile.  A workgroup runs it once or twice;
@@ -331,6 +339,76 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   });
 }
 
+
+// Grad-input whose sub-pixel phases differ in rows AND taps (k3 s2: 4 : 2 : 2 : 1 taps; the longest phase's tiles alone are as
+// long as the whole launch should be): ALL tiles are stream-K.  The k-tiles of every tile of every phase, phase-major, form one
+// iteration space cut into `blocks` equal ranges; a range covers any number of tiles — a loop over segments, whose descriptors are
+// derived from the iteration index inside the loop (nothing but the index is carried: the loop form costs ~40 spilled registers in
+// the segments' prologue / epilogue and none in the k-tile loops).  Only a range's first and last segment can be partial tiles:
+// two partial slots per range as before.  Replaces the GEMM + col2im detour where it was only there for balance.
+struct SkNPlan {
+  int nph, blocks, total;        // sub-pixel phases, workgroups, k-tile iterations of the launch
+  int tile0[5], it0[5], kt[4];   // per phase: first tile (arrival-counter index), first iteration, k-tiles per tile; [nph]: totals
+  float* parts; int* arrivals;
+};
+__device__ __forceinline__ int skn_start(int g, const SkNPlan& sk) {
+  return __builtin_amdgcn_readfirstlane((int)((uint32_t)g * (uint32_t)sk.total / (uint32_t)sk.blocks));
+}
+__device__ __forceinline__ int skn_owner(int x, const SkNPlan& sk) {
+  return __builtin_amdgcn_readfirstlane((int)((((uint32_t)x + 1u) * (uint32_t)sk.blocks - 1u) / (uint32_t)sk.total));
+}
+template <class Cfg, bool XF>
+__global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_skn_kernel(ConvP p, DgradPhases phases, SkNPlan sk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int rowpix[Cfg::BM];
+  const int g = (int)xcd_remap(blockIdx.x, (uint32_t)sk.blocks);
+  const int it1 = skn_start(g + 1, sk);
+#pragma unroll 1
+  for (int it = skn_start(g, sk); it < it1;) {
+    int py = 0;
+    if (sk.nph > 1 && it >= sk.it0[1]) py = 1;
+    if (sk.nph > 2 && it >= sk.it0[2]) py = 2;
+    if (sk.nph > 3 && it >= sk.it0[3]) py = 3;
+    const int KT = sk.kt[py], local = it - sk.it0[py];
+    const int tin = __builtin_amdgcn_readfirstlane(local / KT);          // tile inside the phase
+    const int t_begin = sk.it0[py] + tin * KT, t_end = t_begin + KT;     // the tile's iterations
+    const int e = it1 < t_end ? it1 : t_end;
+    const int kt_begin = it - t_begin, nkt = e - it;
+    const int fb = skn_owner(t_begin, sk), nparts = skn_owner(t_end - 1, sk) - fb + 1;
+    const PhaseInfo& f = phases.p[py];
+    const int mt = __builtin_amdgcn_readfirstlane(tin / p.tilesN), nt = tin - mt * p.tilesN;
+    const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
+    if (wave_id() >= 4) {
+      const int tid = threadIdx.x - IG_LOADERS;
+      for (int r = tid; r < Cfg::BM; r += IG_LOADERS) {
+        const int m = m_block + r;
+        int pix = -1;
+        if (m < f.Mp) {
+          uint32_t t, cc, b, aa;
+          f.dPHw.divmod((uint32_t)m, t, cc);
+          f.dPHh.divmod(t, b, aa);
+          pix = ((int)b * p.IH + (int)aa * p.stride + f.ph) * p.IW + (int)cc * p.stride + f.pw;
+        }
+        rowpix[r] = pix;
+      }
+      DgradALoader<Cfg::BM, XF> la(p, f, m_block, tid);
+      DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
+      if (kt_begin) { la.seek(kt_begin); lb.seek(kt_begin); }
+      igemm_produce<Cfg>(la, lb, nkt, smem, tid, ClockStamp{nullptr, 0});
+    } else {
+      f32x16 acc[Cfg::TM][Cfg::TN];
+      igemm_consume<Cfg, true, false>(nkt, acc, smem);
+      if (sk_combine_core<Cfg>(sk.parts, sk.arrivals, sk.blocks, g, sk.tile0[py] + tin, nparts, fb,
+                               [&](int blk) { return skn_start(blk, sk) >= t_begin; }, acc))
+        igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
+          const int pix = rowpix[row];
+          return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
+        }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+    }
+    it = e;
+    if (it < it1) lds_barrier();   // the epilogue staged through the LDS stages / read rowpix: the next segment's producers wait
+  }
+}
 
 // weight gradient as a stream-K launch: the K = B*OH*OW loops of ALL tiles form the iteration space (a gradient has at most a few
 // hundred tiles), the last arrival of a (tile, wave) writes dw itself — with the .grad accumulation as an EPI_ADD on dw — so
@@ -615,7 +693,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -691,7 +769,7 @@ template <class Cfg, bool AK, bool BK_>
 constexpr size_t stage_smem_bytes() { return sizeof(float) * (size_t)igemm_smem_floats<Cfg, AK, BK_>(); }
 
 // ---- stream-K scratch: caller-owned, registered per stream (pcg_conv_set_scratch) --------------------------------------
-constexpr int SK_MAX_BLOCKS = 512, SK_MAX_TILES = 1024;
+constexpr int SK_MAX_BLOCKS = 512, SK_MAX_TILES = 4096;
 constexpr size_t SK_PARTS_BYTES = (size_t)2 * SK_MAX_BLOCKS * 128 * 128 * sizeof(float);
 constexpr size_t SK_ARRIVALS_BYTES = (size_t)SK_MAX_TILES * 4 * sizeof(int);
 struct SkScratch { hipStream_t stream; float* parts; int* arrivals; };
@@ -844,6 +922,38 @@ int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipSt
     bool uniform = true;
     for (int i = 0; i < nphases; ++i)
       uniform = uniform && ph.p[i].Mp == ph.p[0].Mp && ph.p[i].nth * ph.p[i].ntw == ph.p[0].nth * ph.p[0].ntw && ph.p[i].nth > 0 && ph.p[i].ntw > 0;
+    if (!uniform && nphases > 1 && sk_mode() != 0) {
+      // phases of different length: every tile stream-K (conv_dgrad_skn_kernel).  512 ranges, or 256 for small launches (>= 16
+      // k-tiles per range, at most 8 ranges per tile)
+      SkNPlan sn{};
+      SkPlan scratch{};
+      sn.nph = nphases;
+      bool ok = sk_scratch_of(s, &scratch);
+      int tiles = 0, total = 0, ktmax = 0;
+      for (int i = 0; i < nphases && ok; ++i) {
+        const int kt = ph.p[i].nth * ph.p[i].ntw * ceil_div(p.Cout, IG_BK), t = ceil_div(ph.p[i].Mp, Cfg::BM) * p.tilesN;
+        ok = ph.p[i].nth > 0 && ph.p[i].ntw > 0 && ph.p[i].Mp > 0 && kt > 0;
+        sn.tile0[i] = tiles; sn.it0[i] = total; sn.kt[i] = kt;
+        tiles += t; total += t * kt;
+        if (kt > ktmax) ktmax = kt;
+      }
+      sn.tile0[nphases] = tiles; sn.it0[nphases] = total;
+      int blocks = total / 512 >= 16 ? 512 : 256;
+      if (g_tune.sk_blocks > 0) blocks = g_tune.sk_blocks;
+      // (measured: pays where the tiles are long — 72-79 k-tiles on average: 309 -> 201 and 363 -> 237 us — and loses where they
+      //  are short — 38 on average, 13x13 -> 6x6 at 512 channels: 236 -> 261 us: ~2.7 segments per range, each with its fixed cost)
+      ok = ok && tiles <= SK_MAX_TILES && blocks <= SK_MAX_BLOCKS && total / blocks >= 8 && (int64_t)total * blocks < (1ll << 31) &&
+           ktmax <= 8 * (total / blocks) && (sk_mode() == 2 || g_tune.sk_blocks > 0 || total >= 48 * tiles);
+      if (ok) {
+        sn.blocks = blocks; sn.total = total; sn.parts = scratch.parts; sn.arrivals = scratch.arrivals;
+        static int once_sn = set_smem(conv_dgrad_skn_kernel<Cfg, XF>, smem);
+        if (once_sn != PCG_OK) return once_sn;
+        DgradPhases phs = ph;
+        phs.interleave = 0;
+        hipLaunchKernelGGL((conv_dgrad_skn_kernel<Cfg, XF>), dim3((unsigned)blocks), dim3(IG_THREADS), smem, s, p, phs, sn);
+        return launch_status("conv_dgrad_skn_kernel");
+      }
+    }
     SkPlan sk{};
     const int tpp = tilesM * p.tilesN;
     if (uniform && plan_sk(tpp * nphases, ph.p[0].nth * ph.p[0].ntw * ceil_div(p.Cout, IG_BK), s, &sk)) {
@@ -937,6 +1047,23 @@ extern "C" size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g) {
 // form, every block the same K = Cout — followed by a col2im pass over dcol (HBM-bound, 2 x |dcol| extra traffic).
 static bool dgrad_as_gemm(const pcg_conv_geom* g) {
   if (thin_is_cin(g) || thin_is_cout(g)) return false;
+  if (g_tune.dgrad_gemm == 0) return false;       // A/B: the phase kernel instead
+  if (g_tune.dgrad_gemm < 0 && sk_mode() != 0 && g_sk_scratch_n > 0 && g->stride == 2) {
+    // The phase form multiplies every pixel of a phase by every tap of the phase, the GEMM form every dy pixel by every tap:
+    // which one wastes fewer MACs on taps that fall outside depends on the geometry (7 -> 4 with padding 1: 121 against 144 per
+    // image and channel pair; 13 -> 6 without padding: 400 against 324; 6 -> 2: 81 against 36).  With its load balance repaired
+    // by conv_dgrad_skn_kernel the phase form is taken where it has clearly fewer (measured r03, B = 256 ConvT 1024 -> 512:
+    // 328 -> 237 us).
+    int64_t phase_macs = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        const int PHh = a < g->IH ? (g->IH - a + 1) / 2 : 0, PHw = b < g->IW ? (g->IW - b + 1) / 2 : 0;
+        const int kh0 = (a + g->pad) % 2, kw0 = (b + g->pad) % 2;
+        const int nth = kh0 < g->KH ? (g->KH - kh0 + 1) / 2 : 0, ntw = kw0 < g->KW ? (g->KW - kw0 + 1) / 2 : 0;
+        phase_macs += (int64_t)PHh * PHw * nth * ntw;
+      }
+    if (phase_macs * 20 <= (int64_t)g->OH * g->OW * g->KH * g->KW * 19) return false;
+  }
   if (g->stride < 2 || (g->KH % g->stride == 0 && g->KW % g->stride == 0)) return false;
   if (g->Cout < 512 || g->Cin % 4 || g->Cout % 4) return false;          // K = Cout: >= 16 k-tiles per block
   const int64_t bytes = (int64_t)g->B * g->OH * g->OW * g->KH * g->KW * g->Cin * 4;
@@ -1424,6 +1551,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "fwd_splits")) g_tune.fwd_splits = value;
   else if (!strcmp(name, "stream_k")) g_tune.stream_k = value;
   else if (!strcmp(name, "sk_blocks")) g_tune.sk_blocks = value;
+  else if (!strcmp(name, "dgrad_gemm")) g_tune.dgrad_gemm = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
   else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;

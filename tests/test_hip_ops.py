@@ -272,9 +272,13 @@ def test_dgrad_gemm_col2im_path_equals_phase_kernel(pcg, B, Cin, Cout, H, W, k, 
     dy = torch.randn(B, g.OH, g.OW, Cout, generator=gen)
     b_in = torch.randn(Cin, generator=gen)
     lib = _lib.load()
-    assert lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g)) == B * g.OH * g.OW * k * k * Cin * 4
     wd, dyd, bd = w.to(dev()), dy.to(dev()), b_in.to(dev())
-    got_gemm = ops.conv2d_dgrad(g, dyd, wd, bd, act=O.ACT_RELU)                       # workspace given -> GEMM + col2im
+    ops.tune("dgrad_gemm", 1)            # (r03: geometries where the phase form has clearly fewer MACs otherwise keep the phase form)
+    try:
+        assert lib.pcg_conv2d_dgrad_workspace_bytes(ctypes.byref(g)) == B * g.OH * g.OW * k * k * Cin * 4
+        got_gemm = ops.conv2d_dgrad(g, dyd, wd, bd, act=O.ACT_RELU)                   # workspace given -> GEMM + col2im
+    finally:
+        ops.tune("dgrad_gemm", -1)
     got_phase = torch.empty_like(got_gemm)
     _lib.check(lib.pcg_conv2d_dgrad_act(ctypes.byref(g), ops._p(dyd), ops._p(wd), ops._p(bd), O.ACT_RELU, 0.0, ops._p(got_phase), None, 0,
                                         ops._stream()), "pcg_conv2d_dgrad_act")          # no workspace -> phase kernel

@@ -110,3 +110,38 @@ def test_grad_weight_streamk_matches_slabs(pcg, shape, accumulate):
     torch.nn.functional.conv2d(xs, w0, None, stride=s, padding=p).backward(dys)
     want = w0.grad.permute(0, 2, 3, 1)[:4] + (base[:4].double().cpu() if accumulate else 0.0)
     assert float((outs[1][:4].double().cpu() - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 512, 13, 3, 2, 0),     # critic conv2: phases of 49 / 42 / 42 / 36 pixels and 4 / 2 / 2 / 1 taps
+                                   (256, 512, 1024, 6, 3, 2, 0),     # critic conv3
+                                   (256, 512, 1024, 7, 3, 2, 1),     # generator ConvT2 (4 -> 7)
+                                   (24, 96, 160, 9, 3, 2, 1)])       # ragged tiles
+@pytest.mark.parametrize("blocks", [-1, 256])
+def test_grad_input_with_unequal_phases_streamk(pcg, shape, blocks):
+    """conv_dgrad_skn_kernel (every tile stream-K, any number of segments per workgroup) against the plain phase kernel and fp64."""
+    ops = pcg.ops
+    B, Cin, Cout, H, k, s, p = shape
+    g = _geom(ops, *shape)
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    dy = torch.randn((B, g.OH, g.OW, Cout), generator=gen).to(DEV)
+    w = (torch.randn((Cout, k, k, Cin), generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(Cin, generator=gen).to(DEV)
+    ops.tune("dgrad_gemm", 0)                                    # the phase form, not GEMM + col2im
+    try:
+        ops.tune("stream_k", 0)
+        ref = ops.conv2d_dgrad(g, dy, w, bias, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+        ops.tune("stream_k", 1); ops.tune("sk_blocks", blocks)
+        d1 = ops.conv2d_dgrad(g, dy, w, bias, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+        d2 = ops.conv2d_dgrad(g, dy, w, bias, act=pcg.ops.ACT_LRELU, slope=0.2).clone()
+    finally:
+        ops.tune("dgrad_gemm", -1)
+    assert torch.equal(d1, d2)
+    K = k * k * Cout
+    tol = 16 * 2.0 ** -24 * K * float(dy.abs().mean() * w.abs().mean()) * 4 + 1e-6
+    assert float((d1 - ref).abs().max()) <= tol
+    parts, arrivals = ops._sk_streams[(0, torch.cuda.current_stream().cuda_stream)]
+    assert int(arrivals.view(torch.int32).abs().sum()) == 0
+    want = torch.nn.functional.conv_transpose2d(dy[:2].double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), bias.double().cpu(),
+                                                stride=s, padding=p, output_padding=H - ((g.OH - 1) * s - 2 * p + k))
+    want = torch.nn.functional.leaky_relu(want, 0.2).permute(0, 2, 3, 1)
+    assert float((d1[:2].double().cpu() - want).abs().max()) <= tol
