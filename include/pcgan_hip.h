@@ -747,6 +747,9 @@ int pcg_dp_shutdown(void);
  *   "dgrad_interleave"  sub-pixel phases of a grad-input tile neighbours in launch order: 0 / 1, -1 built-in rule
  *   "stream_k"          hybrid stream-K launches: 0 off, 1 where the launch plan's model gains > 10 % (default), 2 wherever valid
  *   "sk_blocks"         number of stream-K workgroups (512 / 256 / 128 / 64), -1 built-in choice
+ *   "dgrad_gemm"        grad-input of a kernel size that is not a multiple of the stride: 0 sub-pixel-phase kernel, 1 one GEMM +
+ *                       col2im, -1 whichever has fewer multiply-adds for the geometry (built-in)
+ *   "fwd_splits", "persistent", "persist_tiles", "dma"   forward K-slices; experiments that are compiled out of / off in the shipped library
  * value -1 restores the built-in choice.  Results stay correct under every setting (the order of a sum changes, not its terms). */
 int pcg_tune_set(const char* name, int32_t value);
 
