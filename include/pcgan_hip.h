@@ -749,6 +749,7 @@ int pcg_dp_shutdown(void);
  *   "sk_blocks"         number of stream-K workgroups (512 / 256 / 128 / 64), -1 built-in choice
  *   "dgrad_gemm"        grad-input of a kernel size that is not a multiple of the stride: 0 sub-pixel-phase kernel, 1 one GEMM +
  *                       col2im, -1 whichever has fewer multiply-adds for the geometry (built-in)
+ *   "t64"               forward launches with at most 256 tiles of 128x128: 64x128 tiles instead (default 1), 0 keeps 128x128
  *   "fwd_splits", "persistent", "persist_tiles", "dma"   forward K-slices; experiments that are compiled out of / off in the shipped library
  * value -1 restores the built-in choice.  Results stay correct under every setting (the order of a sum changes, not its terms). */
 int pcg_tune_set(const char* name, int32_t value);

@@ -693,7 +693,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -1152,7 +1152,15 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   if (f.splits > 1) { p.out = (float*)workspace; p.ktiles_per_split = f.ktiles_per_split; }
   static const int dma_env = getenv("PCG_DMA") ? atoi(getenv("PCG_DMA")) : 0;
   const bool dma = (g_tune.dma >= 0 ? g_tune.dma : dma_env) != 0 && !p.in_sc;
-  if (int e = p.N > 64 ? (dma ? launch_fwd<Cfg128x128D>(p, f.splits, s) : launch_fwd<Cfg128x128>(p, f.splits, s))
+  // At most one 128x128 tile per CU (DCGAN D4: 8192 x 512 = 256 tiles): a workgroup alone on a CU runs at ~80 % of the matrix rate
+  // (one consumer wave per SIMD exposes its own latencies).  64x128 tiles double the workgroups — two per CU again — at the price
+  // of 64x32 wave tiles: measured r03, D4 forward 262 -> 249 us (131 -> 138 TFLOP/s), G2's 260 -> 249; stream-K on the 256 big
+  // tiles had measured neutral.  (pcg_tune_set("t64", 0) keeps the 128x128 tiles.)
+  // Only where the doubled count fills the 512 slots (225..256 big tiles); fewer tiles take stream-K / K-slices as before.
+  const int tiles128 = ceil_div(p.M, 128) * ceil_div(p.N, 128);
+  const bool t64 = g_tune.t64 != 0 && p.N > 64 && f.splits == 1 && tiles128 > 224 && tiles128 <= 256 && p.M % 128 == 0;
+  if (int e = t64 ? launch_fwd<TileCfg<64, 128, 1, 4>>(p, f.splits, s)
+                  : p.N > 64 ? (dma ? launch_fwd<Cfg128x128D>(p, f.splits, s) : launch_fwd<Cfg128x128>(p, f.splits, s))
                        : launch_fwd<Cfg128x64>(p, f.splits, s)) return e;
   if (f.splits > 1) {
     const size_t n = (size_t)p.M * p.N;
@@ -1552,6 +1560,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "stream_k")) g_tune.stream_k = value;
   else if (!strcmp(name, "sk_blocks")) g_tune.sk_blocks = value;
   else if (!strcmp(name, "dgrad_gemm")) g_tune.dgrad_gemm = value;
+  else if (!strcmp(name, "t64")) g_tune.t64 = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
   else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
   return PCG_OK;
