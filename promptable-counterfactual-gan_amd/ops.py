@@ -47,6 +47,7 @@ def _conv_flops(g):
 
 class _Timed:
     def __init__(self, g, op):
+        _conv_scratch()                      # every conv entry point passes here: the stream-K launches get their scratch
         self.on = _conv_hook is not None
         if self.on:
             self.g, self.op = g, op
@@ -70,16 +71,18 @@ _sk_arrival_pool = {}
 
 
 def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv_scratch():
+    """First conv call on a stream: give the hybrid stream-K launches their scratch for it (include/pcgan_hip.h,
+    pcg_conv_set_scratch; 64 MiB of partial tiles + the arrival counters).  The counters must be zero and stay out of a capture's
+    fill nodes: they come from a pool zeroed outside any capture, like the linear weight-gradient tickets.  A stream the library has
+    no slot left for (it keeps 64) simply runs the plain launches — same results up to the order of the K sum."""
     s = torch.cuda.current_stream()
-    if (s.device_index, s.cuda_stream) not in _sk_streams:
-        _register_conv_scratch(s)
-    return ctypes.c_void_p(s.cuda_stream)
-
-
-def _register_conv_scratch(s):
-    """First library call on a stream: give the hybrid stream-K conv launches their scratch for it (include/pcgan_hip.h,
-    pcg_conv_set_scratch).  The arrival counters must be zero and stay out of a capture's fill nodes: they come from a pool
-    zeroed outside any capture, like the linear weight-gradient tickets."""
+    key = (s.device_index, s.cuda_stream)
+    if key in _sk_streams:
+        return
     lib = _lib.load()
     dev = torch.device("cuda", s.device_index)
     nparts, narr = lib.pcg_conv_scratch_parts_bytes(), lib.pcg_conv_scratch_arrivals_bytes()
@@ -88,8 +91,11 @@ def _register_conv_scratch(s):
         pool.extend(torch.zeros((8, narr), dtype=torch.uint8, device=dev).unbind(0))
     arrivals = pool.pop() if pool else torch.zeros(narr, dtype=torch.uint8, device=dev)
     parts = torch.empty(nparts, dtype=torch.uint8, device=dev)
-    _sk_streams[(s.device_index, s.cuda_stream)] = (parts, arrivals)
-    check(lib.pcg_conv_set_scratch(ctypes.c_void_p(s.cuda_stream), _p(parts), nparts, _p(arrivals), narr), "pcg_conv_set_scratch")
+    if lib.pcg_conv_set_scratch(ctypes.c_void_p(s.cuda_stream), _p(parts), nparts, _p(arrivals), narr) == 0:
+        _sk_streams[key] = (parts, arrivals)
+    else:
+        pool.append(arrivals)
+        _sk_streams[key] = None
 
 
 def _p(t):
