@@ -375,7 +375,7 @@ struct DgradBLoader {
     const int n = n_block + 4 * c4;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      base[i] = n < p.N ? (uint32_t)((((kr0 + KR * i) * KHKW) * Cin + n) * 4) : OOB_OFF;
+      base[i] = n < p.N ? (uint32_t)(((mn_krow<NV>(kr0, i) * KHKW) * Cin + n) * 4) : OOB_OFF;
     it.init(p.Cout, f.nth, f.ntw, p.korder);
   }
   __device__ __forceinline__ void seek(int kt) { it.seek(kt); }
@@ -384,7 +384,7 @@ struct DgradBLoader {
     const uint32_t delta = (uint32_t)(((it.co0 * KHKW + tap) * Cin) * 4);
     const int krem = it.Cout - it.co0;  // rows kr < krem are real output channels
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, (kr0 + KR * i) < krem ? base[i] + delta : OOB_OFF);
+    for (int i = 0; i < NV; ++i) v[i] = buf_load4(rs, mn_krow<NV>(kr0, i) < krem ? base[i] + delta : OOB_OFF);
     it.advance();
   }
   __device__ __forceinline__ void transform(float4 (&)[NV]) {}
@@ -411,7 +411,7 @@ struct WgradALoader {
     const int m = m_block + 4 * c4;
     mok = m < p.M;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) base[i] = mok ? (uint32_t)(((kr0 + KR * i) * Cout + m) * 4) : OOB_OFF;
+    for (int i = 0; i < NV; ++i) base[i] = mok ? (uint32_t)((mn_krow<NV>(kr0, i) * Cout + m) * 4) : OOB_OFF;
     q0 = kt_begin * IG_BK;
     if constexpr (XF) {
       neg = p.in_neg; okb = 0;
@@ -425,7 +425,7 @@ struct WgradALoader {
     uint32_t okbits = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const bool ok = (kr0 + KR * i) < krem;
+      const bool ok = mn_krow<NV>(kr0, i) < krem;
       v[i] = buf_load4(rs, ok ? base[i] + delta : OOB_OFF);
       if constexpr (XF) okbits |= ((ok && mok) ? 1u : 0u) << i;
     }
@@ -446,7 +446,7 @@ struct WgradBLoader {
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
   rsrc_t rs;
-  int IH, IW, Cin, stride, K, q0, dh, dw, ci;  // dh = kh - pad
+  int IH, IW, Cin, stride, K, q0, kr0, OH, OW, dh, dw, ci;  // dh = kh - pad
   bool nok;
   FastDiv dOW, dOH;
   float4 sc, sh; float neg; uint32_t okb;
@@ -462,7 +462,7 @@ struct WgradBLoader {
     ci = nok ? n - tap * Cin : 0;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     dh = kh - p.pad; dw = kw - p.pad;
-    q0 = kt_begin * IG_BK + tid / C4;
+    q0 = kt_begin * IG_BK; kr0 = tid / C4; OH = p.OH; OW = p.OW;
     if constexpr (XF) {
       neg = p.in_neg; okb = 0;
       sc = nok ? *reinterpret_cast<const float4*>(p.in_sc + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -471,12 +471,23 @@ struct WgradBLoader {
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     uint32_t okbits = 0;
+    uint32_t t, ow, b, oh;
+    if constexpr (PCG_MN_CONSEC) {           // this thread's NV pixels are consecutive: decompose the first, carry for the others
+      dOW.divmod((uint32_t)(q0 + mn_krow<NV>(kr0, 0)), t, ow);
+      dOH.divmod(t, b, oh);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int q = q0 + KR * i;
-      uint32_t t, ow, b, oh;
-      dOW.divmod((uint32_t)q, t, ow);
-      dOH.divmod(t, b, oh);
+      const int q = q0 + mn_krow<NV>(kr0, i);
+      if constexpr (PCG_MN_CONSEC) {
+        if (i > 0) {
+          ++ow;
+          if (ow == (uint32_t)OW) { ow = 0; ++oh; if (oh == (uint32_t)OH) { oh = 0; ++b; } }
+        }
+      } else {
+        dOW.divmod((uint32_t)q, t, ow);
+        dOH.divmod(t, b, oh);
+      }
       const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
       const bool ok = nok && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
       const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci) * 4);
@@ -501,7 +512,7 @@ struct WgradBLoader192 {
   static constexpr bool KMAJOR = false, XFORM = false;
   static constexpr int ROWS = 192, NV = 6;
   rsrc_t rs;
-  int IH, IW, Cin, stride, K, q0, dh[3], dw[3], ci[3];
+  int IH, IW, Cin, stride, K, q0, kr0, OH, OW, dh[3], dw[3], ci[3];
   bool nok[3];
   FastDiv dOW, dOH;
 
@@ -519,15 +530,26 @@ struct WgradBLoader192 {
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
       dh[s] = kh - p.pad; dw[s] = kw - p.pad;
     }
-    q0 = kt_begin * IG_BK + (tid >> 4);
+    q0 = kt_begin * IG_BK; kr0 = tid >> 4; OH = p.OH; OW = p.OW;
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
+    uint32_t t, ow, b, oh;
+    if constexpr (PCG_MN_CONSEC) {
+      dOW.divmod((uint32_t)(q0 + mn_krow<2>(kr0, 0)), t, ow);
+      dOH.divmod(t, b, oh);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int q = q0 + 16 * h;
-      uint32_t t, ow, b, oh;
-      dOW.divmod((uint32_t)q, t, ow);
-      dOH.divmod(t, b, oh);
+      const int q = q0 + mn_krow<2>(kr0, h);
+      if constexpr (PCG_MN_CONSEC) {
+        if (h > 0) {
+          ++ow;
+          if (ow == (uint32_t)OW) { ow = 0; ++oh; if (oh == (uint32_t)OH) { oh = 0; ++b; } }
+        }
+      } else {
+        dOW.divmod((uint32_t)q, t, ow);
+        dOH.divmod(t, b, oh);
+      }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int ih = (int)oh * stride + dh[s], iw = (int)ow * stride + dw[s];

@@ -71,6 +71,16 @@ constexpr int IG_LDK = IG_BK + 4;          // K-major row stride: 144 B = 9*16 (
 //       instead of 55 KB and THREE workgroups fit a CU's 160 KB — while one of them is in its prologue / epilogue the SIMD still
 //       hosts two consumer waves (one wave alone does not keep the MFMA pipe full).  MINW_: waves per SIMD the register budget
 //       must allow (launch bounds); PF_: k-tiles of gathers in flight per producer thread (register sets).
+// MN-major operands (both operands of the weight gradient, the weight operand of the grad-input): k-row (0..31) of a k-tile that a
+// loader thread of row group kr0 fetches as its i-th of NV loads.  Consecutive rows (r03; r01/r02: kr0 + (32 / NV) * i): the weight
+// gradient's x operand is gathered per output PIXEL = k-row, and consecutive pixels share their (image, row) decomposition up to
+// a carry — one FastDiv pair per k-tile and thread instead of NV (WgradBLoader).  PCG_MN_CONSEC=0 builds the strided mapping.
+#ifndef PCG_MN_CONSEC
+#define PCG_MN_CONSEC 1
+#endif
+template <int NV>
+__device__ __forceinline__ constexpr int mn_krow(int kr0, int i) { return PCG_MN_CONSEC ? NV * kr0 + i : kr0 + (32 / NV) * i; }
+
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool SWZ_ = false, int MINW_ = 4, int PF_ = PCG_PREFETCH_DEPTH, bool DMA_ = false>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
@@ -110,9 +120,10 @@ struct LdsImage {
       constexpr int C4 = ROWS / 4;          // float4 per k-row
       constexpr int KR = IG_LOADERS / C4;   // k-rows per pass
       const int c4 = tid % C4, kr0 = tid / C4;
+      static_assert(KR * NV == IG_BK, "MN-major image: loader threads x loads must cover the k-tile");
 #pragma unroll
       for (int p = 0; p < NV; ++p)
-        *reinterpret_cast<float4*>(lds + (kr0 + KR * p) * LDM + 4 * c4) = v[p];
+        *reinterpret_cast<float4*>(lds + mn_krow<NV>(kr0, p) * LDM + 4 * c4) = v[p];
     } else {
       // ROWS = 192 (48 float4 per k-row do not divide the 256 loader threads): three 64-column sub-images side by side, each
       // loaded like a 64-row image (16 float4 per k-row, 16 k-rows per pass, 2 passes); v[2*s + h] = sub-image s, k-rows 16h..16h+15
@@ -122,7 +133,7 @@ struct LdsImage {
       for (int s = 0; s < ROWS / 64; ++s)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          *reinterpret_cast<float4*>(lds + (kr0 + 16 * h) * LDM + 64 * s + 4 * c4) = v[2 * s + h];
+          *reinterpret_cast<float4*>(lds + mn_krow<2>(kr0, h) * LDM + 64 * s + 4 * c4) = v[2 * s + h];
     }
   }
   // fragment for MFMA tile rows [row0, row0+32), k-group ks (8 k's): f[t] = T[row0+i][8ks+4h+t]
