@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP
     }
     DgradALoader<Cfg::BM, XF> la(p, f, m_block, tid);
     DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
-    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid, ClockStamp{p.stamps, p.stamp_slots});
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
     const int tid = threadIdx.x - IG_LOADERS;
     WgradALoader<Cfg::BM, XFA> la(p, m_block, kt_begin, tid);
     WgradBLoader<Cfg::BN, XFB> lb(p, n_block, kt_begin, tid);
-    igemm_produce<Cfg>(la, lb, ktiles, smem, tid);
+    igemm_produce<Cfg>(la, lb, ktiles, smem, tid, ClockStamp{p.stamps, p.stamp_slots});
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];

@@ -445,8 +445,14 @@ struct WgradBLoader {
   static constexpr bool KMAJOR = false, XFORM = XF;
   static constexpr int ROWS = ROWS_, NV = ROWS_ / 32;
   static constexpr int C4 = ROWS_ / 4, KR = IG_LOADERS / C4;
+  // 128-column tiles: the 64 lanes of a wave own 32 column quads x TWO row groups (lanes 0..31 / 32..63), i.e. only two different
+  // pixels per load instruction.  Their (image, oh, ow) decomposition and base offset are computed ONCE per wave on the scalar unit
+  // and selected per half; a lane adds its own (tap, channel) part.  r03 stamps of the weight gradient: its producers spent 75 % of
+  // the loop issuing gathers (address arithmetic) and the consumers waited 18 % of theirs at the barrier.
+  static constexpr bool SCALAR_PIX = PCG_MN_CONSEC && C4 == 32;
   rsrc_t rs;
   int IH, IW, Cin, stride, K, q0, kr0, OH, OW, dh, dw, ci;  // dh = kh - pad
+  int lane_off;      // SCALAR_PIX: ((dh * IW + dw) * Cin + ci) * 4, this lane's part of every offset
   bool nok;
   FastDiv dOW, dOH;
   float4 sc, sh; float neg; uint32_t okb;
@@ -462,6 +468,7 @@ struct WgradBLoader {
     ci = nok ? n - tap * Cin : 0;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     dh = kh - p.pad; dw = kw - p.pad;
+    lane_off = ((dh * IW + dw) * Cin + ci) * 4;
     q0 = kt_begin * IG_BK; kr0 = tid / C4; OH = p.OH; OW = p.OW;
     if constexpr (XF) {
       neg = p.in_neg; okb = 0;
@@ -471,28 +478,58 @@ struct WgradBLoader {
   }
   __device__ __forceinline__ void load_next(float4 (&v)[NV]) {
     uint32_t okbits = 0;
-    uint32_t t, ow, b, oh;
-    if constexpr (PCG_MN_CONSEC) {           // this thread's NV pixels are consecutive: decompose the first, carry for the others
-      dOW.divmod((uint32_t)(q0 + mn_krow<NV>(kr0, 0)), t, ow);
-      dOH.divmod(t, b, oh);
-    }
+    if constexpr (SCALAR_PIX) {
+      const bool hi = (threadIdx.x & 32) != 0;                                   // second row group of the wave
+      const int qw = __builtin_amdgcn_readfirstlane(q0 + NV * (kr0 & ~1));      // first pixel of the wave's first row group
+      uint32_t t, ow[2], b[2], oh[2];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int q = q0 + mn_krow<NV>(kr0, i);
-      if constexpr (PCG_MN_CONSEC) {
-        if (i > 0) {
-          ++ow;
-          if (ow == (uint32_t)OW) { ow = 0; ++oh; if (oh == (uint32_t)OH) { oh = 0; ++b; } }
+      for (int h = 0; h < 2; ++h) {                                              // (wave-uniform: scalar multiplies and shifts)
+        dOW.divmod((uint32_t)(qw + NV * h), t, ow[h]);
+        dOH.divmod(t, b[h], oh[h]);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int pix[2], ihs[2], iws[2];
+        bool in[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (i > 0) {
+            ++ow[h];
+            if (ow[h] == (uint32_t)OW) { ow[h] = 0; ++oh[h]; if (oh[h] == (uint32_t)OH) { oh[h] = 0; ++b[h]; } }
+          }
+          ihs[h] = (int)oh[h] * stride; iws[h] = (int)ow[h] * stride;
+          pix[h] = (((int)b[h] * IH + ihs[h]) * IW + iws[h]) * Cin * 4;
+          in[h] = qw + NV * h + i < K;
         }
-      } else {
-        dOW.divmod((uint32_t)q, t, ow);
+        const int ih = (hi ? ihs[1] : ihs[0]) + dh, iw = (hi ? iws[1] : iws[0]) + dw;
+        const bool ok = nok && (hi ? in[1] : in[0]) && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+        v[i] = buf_load4(rs, ok ? (uint32_t)((hi ? pix[1] : pix[0]) + lane_off) : OOB_OFF);
+        if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
+      }
+    } else {
+      uint32_t t, ow, b, oh;
+      if constexpr (PCG_MN_CONSEC) {           // this thread's NV pixels are consecutive: decompose the first, carry for the others
+        dOW.divmod((uint32_t)(q0 + mn_krow<NV>(kr0, 0)), t, ow);
         dOH.divmod(t, b, oh);
       }
-      const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
-      const bool ok = nok && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
-      const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci) * 4);
-      v[i] = buf_load4(rs, ok ? off : OOB_OFF);
-      if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int q = q0 + mn_krow<NV>(kr0, i);
+        if constexpr (PCG_MN_CONSEC) {
+          if (i > 0) {
+            ++ow;
+            if (ow == (uint32_t)OW) { ow = 0; ++oh; if (oh == (uint32_t)OH) { oh = 0; ++b; } }
+          }
+        } else {
+          dOW.divmod((uint32_t)q, t, ow);
+          dOH.divmod(t, b, oh);
+        }
+        const int ih = (int)oh * stride + dh, iw = (int)ow * stride + dw;
+        const bool ok = nok && q < K && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+        const uint32_t off = (uint32_t)(((((int)b * IH + ih) * IW + iw) * Cin + ci) * 4);
+        v[i] = buf_load4(rs, ok ? off : OOB_OFF);
+        if constexpr (XF) okbits |= (ok ? 1u : 0u) << i;
+      }
     }
     if constexpr (XF) okb = okbits;
     q0 += IG_BK;
