@@ -762,6 +762,10 @@ int pcg_tune_set(const char* name, int32_t value);
  * registered; the kernels leave it zero.  A stream without scratch runs the plain launches (same results up to the order of the
  * K sum).  parts == NULL forgets the stream.  The reference has no counterpart: ATen picks its conv algorithm inside
  * torch.nn.functional.conv2d (mnist_wgan_conditional.py:61-70,87-95).                                                          */
+/* Which launch form a convolution takes, as text ("128x128 tiles: 512", "64x128 tiles: 512", "stream-K: 512 whole tiles + 352 tiles x
+ * 72 k-tiles over 512 ranges", "GEMM + col2im: ...", "4 phases: stream-K over unequal phases: ..."): the host-side launch planning,
+ * no device needed.  op: 0 forward, 1 grad-input, 2 grad-weight; assume_scratch != 0: plan as if the stream had stream-K scratch. */
+int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_t assume_scratch, char* out, size_t out_bytes);
 size_t pcg_conv_scratch_parts_bytes(void);
 size_t pcg_conv_scratch_arrivals_bytes(void);
 int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t parts_bytes, void* arrivals, size_t arrivals_bytes);

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "pcg_target_arch": (_c.c_char_p, []),
     "pcg_tune_set": (_i, [_c.c_char_p, _i32]),
     "pcg_debug_stamp_buffer": (_i, [_vp, _i64]),
+    "pcg_conv_plan_describe": (_i, [_c.POINTER(ConvGeom), _i32, _i32, _c.c_char_p, _sz]),
     "pcg_conv_scratch_parts_bytes": (_sz, []),
     "pcg_conv_scratch_arrivals_bytes": (_sz, []),
     "pcg_conv_set_scratch": (_i, [_vp, _vp, _sz, _vp, _sz]),

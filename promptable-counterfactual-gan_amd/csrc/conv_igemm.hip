@@ -791,10 +791,9 @@ int sk_mode() {      // 0 off, 1 where the model sees > 10 % to gain (default), 
 // tile costs ~6 us outside its main loop, a stream-K segment ~12 (partial tile out, counter, the next segment's cold start); the
 // last arrival reads ~1.5 us per partial tile.  Checked against scripts/probes/streamk_scan.py: the model takes the launches
 // that gained 7-24 % there and leaves the K = 512 grad-input GEMMs (16 k-tiles per tile: no gain) data-parallel.
-bool plan_sk(int tiles, int ktiles, hipStream_t s, SkPlan* sk) {
+bool plan_sk_shape(int tiles, int ktiles, SkPlan* sk) {       // the decision alone (no scratch, no stream): host logic, CPU-testable
   const int mode = sk_mode();
   if (mode == 3) {                       // diagnostic: every tile data-parallel, but through the stream-K kernels (their cost as such)
-    if (!sk_scratch_of(s, sk)) return false;
     sk->dp_tiles = tiles; sk->sk_tiles = 0; sk->sk_blocks = 0; sk->ktiles = ktiles;
     return true;
   }
@@ -815,10 +814,11 @@ bool plan_sk(int tiles, int ktiles, hipStream_t s, SkPlan* sk) {
     if (t < best) { best = t; bg = G; }
   }
   if (!bg || (mode == 1 && best > 0.9 * t_dp)) return false;
-  if (!sk_scratch_of(s, sk)) return false;
   sk->dp_tiles = dp; sk->sk_tiles = r; sk->sk_blocks = bg; sk->ktiles = ktiles;
   return true;
 }
+bool plan_sk(int tiles, int ktiles, hipStream_t s, SkPlan* sk) { return plan_sk_shape(tiles, ktiles, sk) && sk_scratch_of(s, sk); }
+bool have_sk_scratch() { return sk_mode() != 0 && g_sk_scratch_n > 0; }
 
 template <class Cfg, bool XF>
 int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
@@ -858,7 +858,8 @@ int launch_fwd(const ConvP& p, int splits, hipStream_t s) {
 // the WGAN-GP critic's conv3 / 8192->1024 Linear, the generator's 1x1 -> 4x4 ConvT backward), K is cut into slabs that are
 // summed in slab order by slab_reduce — the same deterministic scheme as the weight gradient.
 struct FwdPlan { int splits, ktiles_per_split; };
-FwdPlan plan_fwd(const pcg_conv_geom* g) {
+FwdPlan plan_fwd(const pcg_conv_geom* g, int have_sk = -1) {
+  if (have_sk < 0) have_sk = have_sk_scratch() ? 1 : 0;
   const int M = g->B * g->OH * g->OW, N = g->Cout;
   const int tiles = ceil_div(M, 128) * ceil_div(N, N > 64 ? 128 : 64);
   const int ktiles = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
@@ -868,7 +869,7 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
     f.splits = ceil_div(ktiles, f.ktiles_per_split);
     return f;
   }
-  if (tiles > 256 && tiles < 448 && ktiles >= 32 && !(sk_mode() != 0 && g_sk_scratch_n > 0)) {     // (stream-K takes these when it has scratch)
+  if (tiles > 256 && tiles < 448 && ktiles >= 32 && !have_sk) {     // (stream-K takes these when it has scratch)
     // a little over one block per CU (288 tiles: 32 CUs get two full-K blocks, the others one — the critic's conv2 at batch 256
     // ran at 73 TFLOP/s): a few K-slices bring the blocks per CU to ceil(tiles*s/256)/s.  Each slice also costs a slab of M*N
     // floats written and read: measured r03 (scripts/probes/fwd_splits_scan.py, 288 tiles x 72 k-tiles) 1: 283, 2: 241, 3: 221,
@@ -890,6 +891,30 @@ FwdPlan plan_fwd(const pcg_conv_geom* g) {
   f.ktiles_per_split = ceil_div(ktiles, splits);
   f.splits = ceil_div(ktiles, f.ktiles_per_split);
   return f;
+}
+
+// every tile stream-K over phases of different length (conv_dgrad_skn_kernel): the decision alone
+bool plan_skn_shape(const DgradPhases& ph, int nphases, int BM, int tilesN, int Cout, SkNPlan* sn) {
+  if (sk_mode() == 0 || nphases < 2) return false;
+  sn->nph = nphases;
+  bool ok = true;
+  int tiles = 0, total = 0, ktmax = 0;
+  for (int i = 0; i < nphases && ok; ++i) {
+    const int kt = ph.p[i].nth * ph.p[i].ntw * ceil_div(Cout, IG_BK), t = ceil_div(ph.p[i].Mp, BM) * tilesN;
+    ok = ph.p[i].nth > 0 && ph.p[i].ntw > 0 && ph.p[i].Mp > 0 && kt > 0;
+    sn->tile0[i] = tiles; sn->it0[i] = total; sn->kt[i] = kt;
+    tiles += t; total += t * kt;
+    if (kt > ktmax) ktmax = kt;
+  }
+  sn->tile0[nphases] = tiles; sn->it0[nphases] = total;
+  int blocks = total / 512 >= 16 ? 512 : 256;
+  if (g_tune.sk_blocks > 0) blocks = g_tune.sk_blocks;
+  // (measured: pays where the tiles are long — 72-79 k-tiles on average: 309 -> 201 and 363 -> 237 us — and loses where they
+  //  are short — 38 on average, 13x13 -> 6x6 at 512 channels: 236 -> 261 us: ~2.7 segments per range, each with its fixed cost)
+  ok = ok && tiles <= SK_MAX_TILES && blocks <= SK_MAX_BLOCKS && total / blocks >= 8 && (int64_t)total * blocks < (1ll << 31) &&
+       ktmax <= 8 * (total / blocks) && (sk_mode() == 2 || g_tune.sk_blocks > 0 || total >= 48 * tiles);
+  sn->blocks = blocks; sn->total = total;
+  return ok;
 }
 
 template <class Cfg, bool XF>
@@ -927,30 +952,13 @@ int launch_dgrad_x(ConvP p, const DgradPhases& ph, int nphases, int maxMp, hipSt
       // k-tiles per range, at most 8 ranges per tile)
       SkNPlan sn{};
       SkPlan scratch{};
-      sn.nph = nphases;
-      bool ok = sk_scratch_of(s, &scratch);
-      int tiles = 0, total = 0, ktmax = 0;
-      for (int i = 0; i < nphases && ok; ++i) {
-        const int kt = ph.p[i].nth * ph.p[i].ntw * ceil_div(p.Cout, IG_BK), t = ceil_div(ph.p[i].Mp, Cfg::BM) * p.tilesN;
-        ok = ph.p[i].nth > 0 && ph.p[i].ntw > 0 && ph.p[i].Mp > 0 && kt > 0;
-        sn.tile0[i] = tiles; sn.it0[i] = total; sn.kt[i] = kt;
-        tiles += t; total += t * kt;
-        if (kt > ktmax) ktmax = kt;
-      }
-      sn.tile0[nphases] = tiles; sn.it0[nphases] = total;
-      int blocks = total / 512 >= 16 ? 512 : 256;
-      if (g_tune.sk_blocks > 0) blocks = g_tune.sk_blocks;
-      // (measured: pays where the tiles are long — 72-79 k-tiles on average: 309 -> 201 and 363 -> 237 us — and loses where they
-      //  are short — 38 on average, 13x13 -> 6x6 at 512 channels: 236 -> 261 us: ~2.7 segments per range, each with its fixed cost)
-      ok = ok && tiles <= SK_MAX_TILES && blocks <= SK_MAX_BLOCKS && total / blocks >= 8 && (int64_t)total * blocks < (1ll << 31) &&
-           ktmax <= 8 * (total / blocks) && (sk_mode() == 2 || g_tune.sk_blocks > 0 || total >= 48 * tiles);
-      if (ok) {
-        sn.blocks = blocks; sn.total = total; sn.parts = scratch.parts; sn.arrivals = scratch.arrivals;
+      if (plan_skn_shape(ph, nphases, Cfg::BM, p.tilesN, p.Cout, &sn) && sk_scratch_of(s, &scratch)) {
+        sn.parts = scratch.parts; sn.arrivals = scratch.arrivals;
         static int once_sn = set_smem(conv_dgrad_skn_kernel<Cfg, XF>, smem);
         if (once_sn != PCG_OK) return once_sn;
         DgradPhases phs = ph;
         phs.interleave = 0;
-        hipLaunchKernelGGL((conv_dgrad_skn_kernel<Cfg, XF>), dim3((unsigned)blocks), dim3(IG_THREADS), smem, s, p, phs, sn);
+        hipLaunchKernelGGL((conv_dgrad_skn_kernel<Cfg, XF>), dim3((unsigned)sn.blocks), dim3(IG_THREADS), smem, s, p, phs, sn);
         return launch_status("conv_dgrad_skn_kernel");
       }
     }
@@ -1045,10 +1053,11 @@ extern "C" size_t pcg_conv2d_fwd_workspace_bytes(const pcg_conv_geom* g) {
 // critical path (measured 30-60 TFLOP/s on the critic's conv2 / conv3).  dcol[B*OH*OW][KH*KW*Cin] = dy * W is the grad-input of
 // the 1x1 convolution with Cin' = KH*KW*Cin on the SAME weight bytes (OHWI rows are [Cout][KH*KW*Cin]) — same MACs as the phase
 // form, every block the same K = Cout — followed by a col2im pass over dcol (HBM-bound, 2 x |dcol| extra traffic).
-static bool dgrad_as_gemm(const pcg_conv_geom* g) {
+static bool dgrad_as_gemm(const pcg_conv_geom* g, int have_sk = -1) {
+  if (have_sk < 0) have_sk = have_sk_scratch() ? 1 : 0;
   if (thin_is_cin(g) || thin_is_cout(g)) return false;
   if (g_tune.dgrad_gemm == 0) return false;       // A/B: the phase kernel instead
-  if (g_tune.dgrad_gemm < 0 && sk_mode() != 0 && g_sk_scratch_n > 0 && g->stride == 2) {
+  if (g_tune.dgrad_gemm < 0 && have_sk && g->stride == 2) {
     // The phase form multiplies every pixel of a phase by every tap of the phase, the GEMM form every dy pixel by every tap:
     // which one wastes fewer MACs on taps that fall outside depends on the geometry (7 -> 4 with padding 1: 121 against 144 per
     // image and channel pair; 13 -> 6 without padding: 400 against 324; 6 -> 2: 81 against 36).  With its load balance repaired
@@ -1123,6 +1132,10 @@ static int dgrad_stat_rows(const pcg_conv_geom* g) {
   return rows;
 }
 
+static bool fwd_use_t64(int M, int N, int splits) {
+  const int tiles128 = ceil_div(M, 128) * ceil_div(N, 128);
+  return g_tune.t64 != 0 && N > 64 && splits == 1 && tiles128 > 224 && tiles128 <= 256 && M % 128 == 0;
+}
 static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
                            double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
                            float slope = 0.f, const EpiAux* epi = nullptr, const pcg_in_xform* xf = nullptr) {
@@ -1157,8 +1170,7 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   // of 64x32 wave tiles: measured r03, D4 forward 262 -> 249 us (131 -> 138 TFLOP/s), G2's 260 -> 249; stream-K on the 256 big
   // tiles had measured neutral.  (pcg_tune_set("t64", 0) keeps the 128x128 tiles.)
   // Only where the doubled count fills the 512 slots (225..256 big tiles); fewer tiles take stream-K / K-slices as before.
-  const int tiles128 = ceil_div(p.M, 128) * ceil_div(p.N, 128);
-  const bool t64 = g_tune.t64 != 0 && p.N > 64 && f.splits == 1 && tiles128 > 224 && tiles128 <= 256 && p.M % 128 == 0;
+  const bool t64 = fwd_use_t64(p.M, p.N, f.splits);
   if (int e = t64 ? launch_fwd<TileCfg<64, 128, 1, 4>>(p, f.splits, s)
                   : p.N > 64 ? (dma ? launch_fwd<Cfg128x128D>(p, f.splits, s) : launch_fwd<Cfg128x128>(p, f.splits, s))
                        : launch_fwd<Cfg128x64>(p, f.splits, s)) return e;
@@ -1212,6 +1224,33 @@ extern "C" int pcg_conv2d_fwd_xf(const pcg_conv_geom* g, const float* x, const p
   return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream, act, slope, nullptr, xf);
 }
 
+// the sub-pixel phases (ih % s, iw % s) of a grad-input: rows, first taps, taps per axis, partial-statistics rows
+static int build_phases(const pcg_conv_geom* g, DgradPhases* php, int* maxMp_out) {
+  DgradPhases& ph = *php;
+  int nph = 0, maxMp = 0, prow = 0;
+  const int s = g->stride;
+  for (int a = 0; a < s; ++a)
+    for (int b = 0; b < s; ++b) {
+      PhaseInfo& f = ph.p[nph];
+      f.ph = a; f.pw = b;
+      f.PHh = a < g->IH ? (g->IH - a + s - 1) / s : 0;
+      f.PHw = b < g->IW ? (g->IW - b + s - 1) / s : 0;
+      f.Mp = g->B * f.PHh * f.PHw;
+      if (f.Mp == 0) continue;
+      f.kh0 = (a + g->pad) % s; f.kw0 = (b + g->pad) % s;
+      f.nth = f.kh0 < g->KH ? (g->KH - f.kh0 + s - 1) / s : 0;
+      f.ntw = f.kw0 < g->KW ? (g->KW - f.kw0 + s - 1) / s : 0;
+      if (f.nth == 0 || f.ntw == 0) { f.nth = 0; f.ntw = 1; }
+      f.dh0 = (a + g->pad - f.kh0) / s; f.dw0 = (b + g->pad - f.kw0) / s;
+      f.dPHw = FastDiv((uint32_t)f.PHw); f.dPHh = FastDiv((uint32_t)f.PHh);
+      if (f.Mp > maxMp) maxMp = f.Mp;
+      f.prow0 = prow; prow += ceil_div(f.Mp, 128) * 2;
+      ++nph;
+    }
+  *maxMp_out = maxMp;
+  return nph;
+}
+
 static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx,
                              double* stat_partial, void* workspace, size_t workspace_bytes, pcg_stream_t stream, int act = PCG_ACT_NONE,
                              float slope = 0.f, const EpiAux* epi = nullptr, const pcg_in_xform* xf = nullptr) {
@@ -1250,26 +1289,8 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   p.N = g->Cin;
   DgradPhases ph{};
-  int nph = 0, maxMp = 0, prow = 0;
-  const int s = g->stride;
-  for (int a = 0; a < s; ++a)
-    for (int b = 0; b < s; ++b) {
-      PhaseInfo& f = ph.p[nph];
-      f.ph = a; f.pw = b;
-      f.PHh = a < g->IH ? (g->IH - a + s - 1) / s : 0;
-      f.PHw = b < g->IW ? (g->IW - b + s - 1) / s : 0;
-      f.Mp = g->B * f.PHh * f.PHw;
-      if (f.Mp == 0) continue;
-      f.kh0 = (a + g->pad) % s; f.kw0 = (b + g->pad) % s;
-      f.nth = f.kh0 < g->KH ? (g->KH - f.kh0 + s - 1) / s : 0;
-      f.ntw = f.kw0 < g->KW ? (g->KW - f.kw0 + s - 1) / s : 0;
-      if (f.nth == 0 || f.ntw == 0) { f.nth = 0; f.ntw = 1; }
-      f.dh0 = (a + g->pad - f.kh0) / s; f.dw0 = (b + g->pad - f.kw0) / s;
-      f.dPHw = FastDiv((uint32_t)f.PHw); f.dPHh = FastDiv((uint32_t)f.PHh);
-      if (f.Mp > maxMp) maxMp = f.Mp;
-      f.prow0 = prow; prow += ceil_div(f.Mp, 128) * 2;
-      ++nph;
-    }
+  int maxMp = 0;
+  const int nph = build_phases(g, &ph, &maxMp);
   PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
   hipStream_t st = (hipStream_t)stream;
   if (int e = p.N > 64 ? launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st)
@@ -1547,6 +1568,65 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
 extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,
                                 void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   return pcg_conv2d_wgrad_xf(g, x, nullptr, dy, nullptr, dw, accumulate, workspace, workspace_bytes, stream);
+}
+
+// Which launch form a layer takes (the host-side planning above, no device needed): "thin", "128x128 x tiles [x K-slices]",
+// "64x128 tiles", "stream-K: ...", "GEMM + col2im", ... — the decisions DESIGN.md section 3.1.1 tabulates, as text.
+// op: 0 forward, 1 grad-input, 2 grad-weight.  assume_scratch: plan as if the stream had stream-K scratch registered.
+extern "C" int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_t assume_scratch, char* out, size_t out_bytes) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(out && out_bytes > 0 && op >= 0 && op <= 2, "pcg_conv_plan_describe: bad arguments");
+  const int have = assume_scratch ? (sk_mode() != 0 ? 1 : 0) : (have_sk_scratch() ? 1 : 0);
+  char buf[512];
+  buf[0] = 0;
+  auto say = [&](const char* fmt, auto... a) { snprintf(buf + strlen(buf), sizeof(buf) - strlen(buf), fmt, a...); };
+  if (thin_is_cin(g) || thin_is_cout(g)) {
+    say("thin (Cin or Cout <= 3): no matrix-core launch");
+  } else if (op == 0) {
+    const int M = g->B * g->OH * g->OW, N = g->Cout, kt = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
+    const FwdPlan f = plan_fwd(g, have);
+    SkPlan sk{};
+    if (N <= 64) say("128x64 tiles: %d", ceil_div(M, 128));
+    else if (fwd_use_t64(M, N, f.splits)) say("64x128 tiles: %d", ceil_div(M, 64) * ceil_div(N, 128));
+    else if (f.splits == 1 && have && plan_sk_shape(ceil_div(M, 128) * ceil_div(N, 128), kt, &sk))
+      say("stream-K: %d whole tiles + %d tiles x %d k-tiles over %d ranges", sk.dp_tiles, sk.sk_tiles, kt, sk.sk_blocks);
+    else if (f.splits > 1) say("128x128 tiles: %d x %d K-slices of %d k-tiles (slabs)", ceil_div(M, 128) * ceil_div(N, 128), f.splits, f.ktiles_per_split);
+    else say("128x128 tiles: %d", ceil_div(M, 128) * ceil_div(N, 128));
+  } else if (op == 1) {
+    if (dgrad_as_gemm(g, have)) {
+      const int M = g->B * g->OH * g->OW, N = g->KH * g->KW * g->Cin, kt = ceil_div(g->Cout, IG_BK), tiles = ceil_div(M, 128) * ceil_div(N, 128);
+      SkPlan sk{};
+      say("GEMM + col2im: ");
+      if (have && plan_sk_shape(tiles, kt, &sk)) say("stream-K: %d whole tiles + %d tiles x %d k-tiles over %d ranges", sk.dp_tiles, sk.sk_tiles, kt, sk.sk_blocks);
+      else say("128x128 tiles: %d", tiles);
+    } else {
+      DgradPhases ph{};
+      int maxMp = 0;
+      const int nph = build_phases(g, &ph, &maxMp);
+      const int N = g->Cin, tilesN = ceil_div(N, N > 64 ? 128 : 64);
+      bool uniform = true;
+      for (int i = 0; i < nph; ++i)
+        uniform = uniform && ph.p[i].Mp == ph.p[0].Mp && ph.p[i].nth * ph.p[i].ntw == ph.p[0].nth * ph.p[0].ntw && ph.p[i].nth > 0 && ph.p[i].ntw > 0;
+      SkNPlan sn{};
+      SkPlan sk{};
+      say("%d phase%s: ", nph, nph == 1 ? "" : "s");
+      if (N > 64 && have && !uniform && plan_skn_shape(ph, nph, 128, tilesN, g->Cout, &sn))
+        say("stream-K over unequal phases: %d tiles, %d k-tile iterations over %d ranges", sn.tile0[nph], sn.total, sn.blocks);
+      else if (N > 64 && have && uniform && nph > 0 &&
+               plan_sk_shape(ceil_div(maxMp, 128) * tilesN * nph, ph.p[0].nth * ph.p[0].ntw * ceil_div(g->Cout, IG_BK), &sk))
+        say("stream-K: %d whole tiles + %d tiles over %d ranges", sk.dp_tiles, sk.sk_tiles, sk.sk_blocks);
+      else say("%s tiles: %d per phase", N > 64 ? "128x128" : "128x64", ceil_div(maxMp, 128) * tilesN);
+    }
+  } else {
+    const WgradPlan w = plan_wgrad(g);
+    SkPlan sk{};
+    if (!w.narrow && !w.wide192 && w.tiles > 96 && have && plan_sk_shape(w.tiles, w.ktiles_total, &sk))
+      say("stream-K: %d whole tiles + %d tiles x %d k-tiles over %d ranges, dw written by the epilogue", sk.dp_tiles, sk.sk_tiles, w.ktiles_total, sk.sk_blocks);
+    else if (!w.narrow && !w.wide192 && w.tiles > 96 && w.splits == 1 && sk_mode() != 0) say("128x128 tiles: %d, dw written by the epilogue", w.tiles);
+    else say("%s tiles: %d x %d K-slices of %d k-tiles (slabs + slab_reduce)", w.wide192 ? "64x192" : w.narrow ? "64x128" : "128x128", w.tiles, w.splits, w.ktiles_per_split);
+  }
+  snprintf(out, out_bytes, "%s", buf);
+  return PCG_OK;
 }
 
 extern "C" int pcg_tune_set(const char* name, int32_t value) {

@@ -145,3 +145,30 @@ def test_grad_input_with_unequal_phases_streamk(pcg, shape, blocks):
                                                 stride=s, padding=p, output_padding=H - ((g.OH - 1) * s - 2 * p + k))
     want = torch.nn.functional.leaky_relu(want, 0.2).permute(0, 2, 3, 1)
     assert float((d1[:2].double().cpu() - want).abs().max()) <= tol
+
+
+def test_convtranspose_with_fused_statistics_takes_the_unequal_phase_form(pcg):
+    """The generator's ConvTranspose2d(1024 -> 512, k3 s2 p1, 4x4 -> 7x7) + BatchNorm statistics at the bench batch
+    (mnist_wgan_conditional.py:64-66): grad-input kernel with the statistics in its epilogue, phases of 16 / 12 / 12 / 9 pixels and
+    4 / 2 / 2 / 1 taps -> conv_dgrad_skn_kernel.  Output, batch statistics and running statistics against the plain launch."""
+    ops = pcg.ops
+    B, Cin, Cout, H, k, s, p = 256, 512, 1024, 7, 3, 2, 1          # adjoint geometry: the ConvT's output is this conv's input
+    g = _geom(ops, B, Cin, Cout, H, k, s, p)
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    a = torch.randn((B, g.OH, g.OW, Cout), generator=gen).to(DEV)
+    w = (torch.randn((Cout, k, k, Cin), generator=gen) * 0.03).to(DEV)
+    res = []
+    for mode in (0, 1, 1):
+        ops.tune("stream_k", mode)
+        rm, rv, nbt = torch.zeros(Cin, device=DEV), torch.ones(Cin, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        z, mean, invstd = ops.conv_bn_train(g, a, w, None, True, 1e-5, 0.1, rm, rv, nbt)
+        res.append((z.clone(), mean.clone(), invstd.clone(), rm.clone(), rv.clone()))
+    for x, y in zip(res[1], res[2]):
+        assert torch.equal(x, y)                                    # run-to-run identical
+    K = k * k * Cout
+    tol = 16 * 2.0 ** -24 * K * float(a.abs().mean() * w.abs().mean()) * 4 + 1e-6
+    assert float((res[1][0] - res[0][0]).abs().max()) <= tol
+    for i in (1, 2, 3, 4):
+        np.testing.assert_allclose(res[1][i].cpu().numpy(), res[0][i].cpu().numpy(), rtol=2e-4, atol=2e-5)
+    zd = res[1][0].double()
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), zd.mean((0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-5)

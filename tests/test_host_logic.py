@@ -114,3 +114,49 @@ def test_epoch_permutation_is_dataloaders_order():
     got = [H.epoch_permutation(n)[:(n // bs) * bs] for _ in range(3)]
     assert all(torch.equal(a, b) for a, b in zip(want, got))
     assert all(len(set(p.tolist())) == (n // bs) * bs for p in got)
+
+
+def test_conv_launch_planning_at_the_bench_shapes():
+    """The launch form each bench-shape convolution takes (csrc/conv_igemm.hip: plan_fwd, fwd_use_t64, plan_sk_shape, plan_skn_shape,
+    dgrad_as_gemm, plan_wgrad) through pcg_conv_plan_describe — host logic, no device.  Pins the decisions DESIGN.md 3.1.1 tabulates:
+    DCGAN's tile counts stay data-parallel (D4's 256 big tiles become 512 tiles of 64x128), the WGAN-GP layers whose tile counts do
+    not fill the chip's 512 workgroup slots take stream-K when the stream has scratch and the r02 forms when it has none."""
+    import ctypes
+    from pcgan_amd import _lib
+    lib = _lib.load()
+
+    def plan(B, Cin, Cout, H, k, s, p, op, scratch):
+        OH = (H + 2 * p - k) // s + 1
+        g = _lib.ConvGeom(B, H, H, Cin, OH, OH, Cout, k, k, s, p)
+        buf = ctypes.create_string_buffer(512)
+        assert lib.pcg_conv_plan_describe(ctypes.byref(g), op, scratch, buf, 512) == 0
+        return buf.value.decode()
+
+    FWD, DGRAD, WGRAD = 0, 1, 2
+    d2, d3, d4 = (512, 64, 128, 32, 4, 2, 1), (512, 128, 256, 16, 4, 2, 1), (512, 256, 512, 8, 4, 2, 1)
+    for scratch in (0, 1):                                           # DCGAN: the same forms with or without scratch
+        assert plan(*d2, FWD, scratch) == "128x128 tiles: 1024"
+        assert plan(*d3, FWD, scratch) == "128x128 tiles: 512"
+        assert plan(*d4, FWD, scratch) == "64x128 tiles: 512"
+        assert plan(*d2, DGRAD, scratch) == "4 phases: 128x64 tiles: 1024 per phase"
+        assert plan(*d3, DGRAD, scratch) == "4 phases: 128x128 tiles: 256 per phase"
+        assert plan(*d3, WGRAD, scratch).startswith("128x128 tiles: 32 x 16 K-slices")
+        assert plan(512, 1, 64, 64, 4, 2, 1, FWD, scratch).startswith("thin")
+    # WGAN-GP, width 1024
+    c2_768, c3_256 = (768, 256, 512, 13, 3, 2, 0), (256, 512, 1024, 6, 3, 2, 0)
+    assert plan(*c2_768, FWD, 1) == "stream-K: 512 whole tiles + 352 tiles x 72 k-tiles over 512 ranges"
+    assert plan(*c2_768, FWD, 0) == "128x128 tiles: 864"
+    assert plan(256, 256, 512, 13, 3, 2, 0, FWD, 0).startswith("128x128 tiles: 288 x 3 K-slices")     # r02's answer to 288 tiles
+    assert plan(256, 256, 512, 13, 3, 2, 0, FWD, 1).startswith("stream-K: 0 whole tiles + 288 tiles")
+    assert plan(*c3_256, FWD, 1).startswith("128x128 tiles: 64 x 8 K-slices")                           # deep K split stays slabs
+    assert plan(*c3_256, DGRAD, 1) == "GEMM + col2im: stream-K: 0 whole tiles + 288 tiles x 32 k-tiles over 512 ranges"
+    assert plan(*c3_256, DGRAD, 0) == "GEMM + col2im: 128x128 tiles: 288"
+    assert plan(*c3_256, WGRAD, 1).startswith("stream-K: 0 whole tiles + 288 tiles x 32 k-tiles over 512 ranges")
+    t2 = (256, 512, 1024, 7, 3, 2, 1)                               # generator ConvT 1024 -> 512, 4x4 -> 7x7 (adjoint geometry)
+    assert plan(*t2, DGRAD, 1).startswith("4 phases: stream-K over unequal phases: 392 tiles, 25600 k-tile iterations over 512 ranges")
+    assert plan(*t2, DGRAD, 0) == "GEMM + col2im: 128x128 tiles: 1152"
+    assert plan(256, 256, 512, 13, 3, 2, 0, DGRAD, 1).startswith("GEMM + col2im")                      # 13 -> 6: the phase form has MORE MACs
+    assert plan(256, 8192, 1024, 1, 1, 1, 0, WGRAD, 1) == "128x128 tiles: 512, dw written by the epilogue"
+    # counteRGAN 3x3 64 -> 64
+    assert plan(1024, 64, 64, 28, 3, 1, 1, FWD, 1) == "128x64 tiles: 6272"
+    assert plan(1024, 64, 64, 28, 3, 1, 1, WGRAD, 1).startswith("64x192 tiles: 3 x")
