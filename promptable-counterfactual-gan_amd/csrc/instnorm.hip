@@ -332,6 +332,239 @@ __global__ void __launch_bounds__(256) gp_bwd_kernel(const float* __restrict__ g
   }
 }
 
+// ---- register-resident forms (r03): HW <= 16 * NP positions per (sample, 64-channel group) -------------------------------------
+// A block's slice of one sample is HW x 64 channels x 4 B <= 48 KB (HW = 169): each thread keeps its <= NP float4 of every tensor it
+// needs twice in registers, so x / dy / r are read from HBM ONCE instead of two or three times.  Same lanes, same order of every sum
+// as the streaming kernels above: bit-identical results.  (r03 critic trace: the three InstanceNorm kernels are 0.6 ms of a 6 ms
+// update, all of it memory passes.)
+template <int NP>
+__global__ void __launch_bounds__(IN_THREADS) instnorm_fwd_reg_kernel(const float* __restrict__ x, int HW, int C, int tc,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, int act, float slope, float* __restrict__ y,
+                                                                     float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  constexpr int V = 4;
+  __shared__ float smem[V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
+  const size_t base = (size_t)blockIdx.x * HW * C;
+  Vec<V> xr[NP];
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+      xr[k] = ldv<V>(x + base + (size_t)p * C + l.c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += xr[k].v[e];
+    }
+  }
+  lane_sum<V>(s, l, smem);
+  float mean[V], q[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean[e] = s[e] / (float)HW; q[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = xr[k].v[e] - mean[e]; q[e] = fmaf(d, d, q[e]); }
+    }
+  }
+  lane_sum<V>(q, l, smem);
+  if (!l.on) return;
+  float g[V], b[V];
+  const Vec<V> gv = ldv<V>(gamma + l.c), bv = ldv<V>(beta + l.c);
+  Vec<V> mo, io;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float invstd = rsqrtf(q[e] / (float)HW + eps);
+    mo.v[e] = mean[e]; io.v[e] = invstd;
+    g[e] = gv.v[e] * invstd; b[e] = bv.v[e];
+  }
+  if (l.lane == 0) { stv<V>(mean_out + (size_t)blockIdx.x * C + l.c, mo); stv<V>(invstd_out + (size_t)blockIdx.x * C + l.c, io); }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (p < HW) {
+      Vec<V> o;
+#pragma unroll
+      for (int e = 0; e < V; ++e) o.v[e] = act_apply(fmaf(xr[k].v[e] - mean[e], g[e], b[e]), act, slope);
+      stv<V>(y + base + (size_t)p * C + l.c, o);
+    }
+  }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(IN_THREADS) instnorm_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ act_y, float neg,
+                                                                     const float* __restrict__ x, int HW, int C,
+                                                                     int tc, const float* __restrict__ mean_in,
+                                                                     const float* __restrict__ invstd_in, const float* __restrict__ gamma,
+                                                                     float* __restrict__ dn_out, const float* __restrict__ addend,
+                                                                     float* __restrict__ dx, float* __restrict__ dgamma_part,
+                                                                     float* __restrict__ dbeta_part, float* __restrict__ dxsum_part) {
+  constexpr int V = 4;
+  __shared__ float smem[2 * V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
+  const size_t base = (size_t)blockIdx.x * HW * C;
+  Vec<V> mean, invstd;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean.v[e] = 0.f; invstd.v[e] = 0.f; }
+  if (l.on) { mean = ldv<V>(mean_in + (size_t)blockIdx.x * C + l.c); invstd = ldv<V>(invstd_in + (size_t)blockIdx.x * C + l.c); }
+  Vec<V> dr[NP], xh[NP];                   // the masked gradient and the normalised activation of this thread's elements
+  float s[2 * V];
+#pragma unroll
+  for (int e = 0; e < 2 * V; ++e) s[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+      const size_t i = base + (size_t)p * C + l.c;
+      Vec<V> d = ldv<V>(dy + i);
+      const Vec<V> xv = ldv<V>(x + i);
+      if (act_y) {
+        const Vec<V> yv = ldv<V>(act_y + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d.v[e] *= yv.v[e] > 0.f ? 1.f : neg;
+        if (dn_out) stv<V>(dn_out + i, d);
+      }
+      dr[k] = d;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        xh[k].v[e] = (xv.v[e] - mean.v[e]) * invstd.v[e];
+        s[e] += d.v[e]; s[V + e] = fmaf(d.v[e], xh[k].v[e], s[V + e]);
+      }
+    }
+  }
+  lane_sum<2 * V>(s, l, smem);
+  if (l.on && l.lane == 0) {
+    Vec<V> a, b;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { a.v[e] = s[V + e]; b.v[e] = s[e]; }
+    if (dgamma_part) stv<V>(dgamma_part + (size_t)blockIdx.x * C + l.c, a);
+    if (dbeta_part) stv<V>(dbeta_part + (size_t)blockIdx.x * C + l.c, b);
+  }
+  if (!dx) return;                         // (uniform)
+  const float inv_n = 1.f / (float)HW;
+  float m1[V], m2[V], g[V], t[V];
+  Vec<V> gv;
+#pragma unroll
+  for (int e = 0; e < V; ++e) gv.v[e] = 0.f;
+  if (l.on) gv = ldv<V>(gamma + l.c);
+#pragma unroll
+  for (int e = 0; e < V; ++e) { m1[e] = s[e] * inv_n; m2[e] = s[V + e] * inv_n; g[e] = gv.v[e] * invstd.v[e]; t[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+      const size_t i = base + (size_t)p * C + l.c;
+      Vec<V> o;
+#pragma unroll
+      for (int e = 0; e < V; ++e) o.v[e] = g[e] * (dr[k].v[e] - m1[e] - xh[k].v[e] * m2[e]);
+      if (addend) {
+        const Vec<V> av = ldv<V>(addend + i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o.v[e] += av.v[e];
+      }
+      stv<V>(dx + i, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) t[e] += o.v[e];
+    }
+  }
+  if (!dxsum_part) return;                 // (uniform)
+  lane_sum<V>(t, l, smem);
+  if (l.on && l.lane == 0) {
+    Vec<V> o;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o.v[e] = t[e];
+    stv<V>(dxsum_part + (size_t)blockIdx.x * C + l.c, o);
+  }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(IN_THREADS) instnorm_bwd_bwd_reg_kernel(const float* __restrict__ r, const float* __restrict__ dy,
+                                                                         const float* __restrict__ x, int HW, int C, int tc,
+                                                                         const float* __restrict__ mean_in, const float* __restrict__ invstd_in,
+                                                                         const float* __restrict__ gamma, float* __restrict__ ddy,
+                                                                         float* __restrict__ ez, float* __restrict__ dgamma_part,
+                                                                         const float* __restrict__ act_y, float neg) {
+  constexpr int V = 4;
+  __shared__ float smem[4 * V * IN_THREADS];
+  const Lanes l = lanes_of<V>(C, tc);
+  const size_t base = (size_t)blockIdx.x * HW * C;
+  Vec<V> mean, invstd;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean.v[e] = 0.f; invstd.v[e] = 0.f; }
+  if (l.on) { mean = ldv<V>(mean_in + (size_t)blockIdx.x * C + l.c); invstd = ldv<V>(invstd_in + (size_t)blockIdx.x * C + l.c); }
+  Vec<V> rr[NP], dd[NP], xh[NP];
+  float s[4 * V];
+#pragma unroll
+  for (int e = 0; e < 4 * V; ++e) s[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+      const size_t i = base + (size_t)p * C + l.c;
+      rr[k] = ldv<V>(r + i); dd[k] = ldv<V>(dy + i);
+      const Vec<V> xv = ldv<V>(x + i);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        xh[k].v[e] = (xv.v[e] - mean.v[e]) * invstd.v[e];
+        s[e] += rr[k].v[e]; s[V + e] = fmaf(rr[k].v[e], xh[k].v[e], s[V + e]);
+        s[2 * V + e] += dd[k].v[e]; s[3 * V + e] = fmaf(dd[k].v[e], xh[k].v[e], s[3 * V + e]);
+      }
+    }
+  }
+  lane_sum<4 * V>(s, l, smem);
+  const float inv_n = 1.f / (float)HW;
+  float mr[V], q[V], md[V], m[V], c[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mr[e] = s[e] * inv_n; q[e] = s[V + e] * inv_n; md[e] = s[2 * V + e] * inv_n; m[e] = s[3 * V + e] * inv_n; c[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (l.on && p < HW) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) c[e] = fmaf(rr[k].v[e] - mr[e], dd[k].v[e] - md[e], c[e]);
+    }
+  }
+  lane_sum<V>(c, l, smem);
+  if (!l.on) return;
+  const Vec<V> gam = ldv<V>(gamma + l.c);
+  float g1[V], g2[V], k3[V];
+  Vec<V> dg;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float pp = c[e] * inv_n;
+    dg.v[e] = invstd.v[e] * (float)HW * (pp - m[e] * q[e]);
+    g1[e] = gam.v[e] * invstd.v[e]; g2[e] = -gam.v[e] * invstd.v[e] * invstd.v[e]; k3[e] = pp - 3.f * m[e] * q[e];
+  }
+  if (l.lane == 0 && dgamma_part) stv<V>(dgamma_part + (size_t)blockIdx.x * C + l.c, dg);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = l.lane + k * l.th;
+    if (p < HW) {
+      const size_t i = base + (size_t)p * C + l.c;
+      Vec<V> o1, o2;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float a = dd[k].v[e] - md[e], rt = rr[k].v[e] - mr[e];
+        o1.v[e] = g1[e] * (rt - xh[k].v[e] * q[e]);
+        o2.v[e] = g2[e] * (q[e] * a + m[e] * rt + k3[e] * xh[k].v[e]);
+      }
+      if (ddy) {
+        if (act_y) {
+          const Vec<V> yv = ldv<V>(act_y + i);
+#pragma unroll
+          for (int e = 0; e < V; ++e) o1.v[e] *= yv.v[e] > 0.f ? 1.f : neg;
+        }
+        stv<V>(ddy + i, o1);
+      }
+      if (ez) stv<V>(ez + i, o2);
+    }
+  }
+}
+
 // Sums of up to three [rows][C] partial arrays over their rows, one launch: block = 32 columns x 8 row groups of one array, fp64
 // accumulation in row order (deterministic), accumulate[k] adds into dst[k] (.grad accumulation).
 struct RowSum3 { const float* src[3]; float* dst[3]; int acc[3]; };
@@ -387,8 +620,11 @@ extern "C" int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C
   PCG_REQUIRE(x && gamma && beta && y && mean && invstd && B > 0 && HW > 0 && C > 0, "pcg_instnorm_fwd: bad arguments");
   if (vec4(C, {x, gamma, beta, y, mean, invstd})) {
     const int tc = pick_tc(C);
-    hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps,
-                       act, slope, y, mean, invstd);
+    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
+    else hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
   } else {
     int tc = 1;
     while (tc < C && tc < 64) tc <<= 1;
@@ -405,8 +641,11 @@ extern "C" int pcg_instnorm_bwd_fused(const float* dy, const float* act_y, float
   PCG_REQUIRE((!dn_out || act_y) && (!addend || dx) && (!dxsum_partial || dx), "pcg_instnorm_bwd_fused: dn_out needs act_y; addend / dxsum_partial need dx");
   if (vec4(C, {dy, act_y, x, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial})) {
     const int tc = pick_tc(C);
-    hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc,
-                       mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
   } else {
     int tc = 1;
     while (tc < C && tc < 64) tc <<= 1;
@@ -427,8 +666,11 @@ extern "C" int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const f
               "pcg_instnorm_bwd_bwd: bad arguments");
   if (vec4(C, {r, dy, x, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y})) {
     const int tc = pick_tc(C);
-    hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean,
-                       invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
   } else {
     int tc = 1;
     while (tc < C && tc < 64) tc <<= 1;
