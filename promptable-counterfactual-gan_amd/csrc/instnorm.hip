@@ -620,10 +620,18 @@ extern "C" int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C
   PCG_REQUIRE(x && gamma && beta && y && mean && invstd && B > 0 && HW > 0 && C > 0, "pcg_instnorm_fwd: bad arguments");
   if (vec4(C, {x, gamma, beta, y, mean, invstd})) {
     const int tc = pick_tc(C);
-    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
+    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
+    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
+    int tcr = tc;
+    if (HW <= 4 && C % 256 == 0) tcr = 256;
+    else if (HW <= 8 && C % 128 == 0) tcr = 128;
+    else if (HW > 48 && C % 32 == 0 && tc >= 32) tcr = 32;
+    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 2) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 6) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
     else hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
   } else {
     int tc = 1;
@@ -641,10 +649,18 @@ extern "C" int pcg_instnorm_bwd_fused(const float* dy, const float* act_y, float
   PCG_REQUIRE((!dn_out || act_y) && (!addend || dx) && (!dxsum_partial || dx), "pcg_instnorm_bwd_fused: dn_out needs act_y; addend / dxsum_partial need dx");
   if (vec4(C, {dy, act_y, x, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial})) {
     const int tc = pick_tc(C);
-    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
+    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
+    int tcr = tc;
+    if (HW <= 4 && C % 256 == 0) tcr = 256;
+    else if (HW <= 8 && C % 128 == 0) tcr = 128;
+    else if (HW > 48 && C % 32 == 0 && tc >= 32) tcr = 32;
+    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 2) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 6) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
     else hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
   } else {
     int tc = 1;
@@ -666,10 +682,18 @@ extern "C" int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const f
               "pcg_instnorm_bwd_bwd: bad arguments");
   if (vec4(C, {r, dy, x, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y})) {
     const int tc = pick_tc(C);
-    const int th = IN_THREADS / (tc / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<3>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<12>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
+    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
+    int tcr = tc;
+    if (HW <= 4 && C % 256 == 0) tcr = 256;
+    else if (HW <= 8 && C % 128 == 0) tcr = 128;
+    // (13x13 maps keep 16 lanes x 64 channels here: with three tensors in registers the 32-lane form measured 80 against 61 us)
+    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
+    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 2) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 6) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
+    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
     else hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
   } else {
     int tc = 1;
