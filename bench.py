@@ -43,7 +43,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 def pmc_traffic():
     """(HBM bytes per launch of the implicit-GEMM family, file) from the newest committed rocprofv3 --pmc summary (FETCH_SIZE
     doubled + WRITE_SIZE, collected in separate passes: profiles/rNN_pmc_traffic.json), or (None, None)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return round(json.load(f)["_igemm_family"]["hbm_bytes_per_launch"]), "profiles/" + name
@@ -201,6 +201,61 @@ def cpu_baseline(batch=BATCH_PER_GPU, steps=3, threads=None):
                       f"restatement of mnist_dcgan.py:147-175 (oracle/dcgan_ref.py), {torch.get_num_threads()} threads"}
 
 
+def secondary_benches(dev, no_calib=False):
+    """BASELINE configs 3 / 4 / 5 on the same box, in this process, AFTER the headline's timed region and calibration: a short
+    replay of scripts/bench_wgan.py, bench_countergan.py and bench_house.py (their own main(), lines captured instead of printed;
+    no CPU baseline).  Each entry carries a bare-MFMA calibration taken right behind it, so `step_over_calib_mfma` does not depend
+    on the box's clock.  The headline `value` is not touched by any of this."""
+    import importlib
+    sdir = os.path.join(ROOT, "scripts")
+    if sdir not in sys.path:
+        sys.path.insert(0, sdir)
+    BL = importlib.import_module("_benchlib")
+    from pcgan_amd import ops
+    out = {}
+    for name, mod, argv in (("wgan", "bench_wgan", ["--steps", "10", "--warmup", "2"]),
+                            ("countergan", "bench_countergan", ["--steps", "8", "--warmup", "2"]),
+                            ("house", "bench_house", ["--steps", "200", "--warmup", "20"])):
+        t0 = time.perf_counter()
+        lines = BL.capture(True)
+        try:
+            importlib.import_module(mod).main(argv + ["--no-cpu-baseline"])
+            line = lines[-1] if lines else None
+        except SystemExit as e:      # a bench that refuses (non-finite losses, ...) must not take the headline line down with it
+            line, err = None, str(e)
+        except Exception as e:
+            line, err = None, f"{type(e).__name__}: {e}"
+        finally:
+            BL.capture(False)
+            ops.set_conv_hook(None)
+        if line is None:
+            out[name] = {"error": err if "err" in dir() else "no line"}
+            continue
+        roof = line.get("roofline") or {}
+        ent = {"ms_per_step": line["ms_per_step"], "value": line["value"], "unit": line["unit"], "steps": line["steps"],
+               "workload": line["config"]["workload"], "step_frac": roof.get("step_frac"),
+               "family_tflops": roof.get("achieved") if roof.get("bound") == "mfma" else None,
+               "launches_per_step": roof.get("launches_per_step"), "launch": line.get("launch"),
+               "final_losses": line.get("final_losses")}
+        for k in ("critic_update_ms", "generator_update_ms"):
+            if k in line:
+                ent[k] = line[k]
+        if not no_calib:
+            torch.cuda.synchronize()
+            c = ops.calibrate(dev, copy_mb=64)
+            ent["calib_mfma_tflops"] = c["mfma_tflops"]
+            if ent["step_frac"] is not None:
+                ent["step_over_calib_mfma"] = round(ent["step_frac"] * PEAK_F32_MFMA_TFLOPS / c["mfma_tflops"], 4)
+            if ent["family_tflops"] is not None:
+                ent["family_over_calib_mfma"] = round(ent["family_tflops"] / c["mfma_tflops"], 4)
+        ent["seconds_spent"] = round(time.perf_counter() - t0, 1)
+        out[name] = ent
+    out["what"] = ("BASELINE configs 3 (conditional WGAN-GP, width 1024, batch 256), 4 (CounteRGAN/mnist, batch 1024) and 5 (house-sales "
+                   "tabular CounteRGAN, batch 4096) timed on this box after the headline: scripts/bench_{wgan,countergan,house}.py run "
+                   "in-process with the step counts above; same contract (inputs resident, graph replay, barrier + synchronize brackets)")
+    return out
+
+
 _json_fd = None
 
 
@@ -294,6 +349,17 @@ def launch_ranks(n, argv, script=None):
     sys.exit(rc)
 
 
+def _read_tail(path, limit=2000):
+    """What RCCL wrote for this rank under NCCL_DEBUG=WARN (empty = no warning), or None when the log was redirected elsewhere."""
+    if not path:
+        return None
+    try:
+        with open(path, errors="replace") as f:
+            return f.read()[-limit:]
+    except OSError:
+        return ""
+
+
 def params_digest(nets):
     """One int64 per net: the wrap-around sum of the parameter bits — equal on two replicas iff (up to a 2^-64 collision) their
     flat parameter buffers are bit-identical.  Runs after the timed region (ATen reduction: diagnostics, not the step)."""
@@ -315,6 +381,7 @@ def main():
     ap.add_argument("--wgrad-stream", action="store_true", help="A/B: weight gradients on a second HIP stream beside the grad-input kernels")
     ap.add_argument("--torch-collectives", action="store_true", help="A/B: gradient exchange on torch.distributed's RCCL communicator instead of the library's (pcg_dp_*)")
     ap.add_argument("--no-calib", action="store_true", help="skip the bare-MFMA / HBM-copy calibration around the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short replays of BASELINE configs 3 / 4 / 5 behind the headline (the `secondary` block)")
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: min(16, visible cores))")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -340,7 +407,13 @@ def main():
 
     dp = None
     rccl_ranks = None
+    rccl_log = None
     if world > 1 or args.force_dp:
+        import tempfile
+        os.environ.setdefault("NCCL_DEBUG", "WARN")                     # RCCL's warnings of every rank (first contact with N > 1)
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            rccl_log = os.path.join(tempfile.gettempdir(), f"pcg_bench_rccl_{os.getpid()}_rank{rank}.log")
+            os.environ["NCCL_DEBUG_FILE"] = rccl_log
         import torch.distributed as dist
         from pcgan_amd.parallel import GradSync, broadcast_parameters
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -398,9 +471,9 @@ def main():
         gs.load(real=reals[i % nbatches], noise=noises[i % nbatches])
         return gs.replay()
 
-    def barrier():
+    def barrier():          # on the communicator that carries the exchange (pcg_dp_barrier): the timed region uses ONE communicator
         if dp is not None:
-            torch.distributed.barrier()
+            dp.barrier()
 
     # Calibration, OUTSIDE the timed bracket (before the warm-up steps and after the timed ones): a ~20 ms bare fp32-MFMA loop
     # on every CU and a 512 MiB device copy — what this box's matrix pipe and HBM sustain now, so that a slower box can be told
@@ -505,6 +578,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batch=args.batch, threads=args.cpu_threads)
 
+    second = None
+    if rank == 0 and world == 1 and dp is None and not args.no_secondary:
+        second = secondary_benches(dev, no_calib=args.no_calib)
+
     spread = None
     if step_ms:
         def _stats(v):
@@ -520,8 +597,8 @@ def main():
         calib["hbm_gbs"] = round(0.5 * (b["hbm_gbs"] + a["hbm_gbs"]), 1)
         calib["mfma_clock_mhz"] = round(0.5 * (b["mfma_clock_mhz"] + a["mfma_clock_mhz"]))
         calib["what"] = ("pcg_calib_mfma: bare v_mfma_f32_32x32x2_f32 loop on every CU (~20 ms), clock from in-kernel s_memtime / "
-                         "s_memrealtime; pcg_calib_copy: 512 MiB device copy (read + write bytes); run before the warm-up and "
-                         "after the timed steps, outside the timed bracket")
+                         "s_memrealtime, behind ~30 ms of the same loop untimed (no cold-clock reading); pcg_calib_copy: 512 MiB device "
+                         "copy (read + write bytes); run before the warm-up and after the timed steps, outside the timed bracket")
         if roofline is not None:
             roofline["achieved_over_calib_mfma"] = round(roofline["achieved"] / calib["mfma_tflops"], 4)
             roofline["step_over_calib_mfma"] = round(ALGO_GFLOP_PER_IMAGE * 1e9 * args.batch / (elapsed / args.steps) / 1e12
@@ -537,10 +614,13 @@ def main():
                                    f"batch {args.batch} per GPU, full G+D step incl. BatchNorm, BCE, Adam x2",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "calib": calib, "step_ms": spread, "clocks_during_timed_region": clocks,
-            "final_losses": losses,
+            "final_losses": losses, "secondary": second,
             "rccl_ranks": rccl_ranks, "replicas_identical": replicas_identical,
             "batchnorm": None if dp is None else ("global batch (statistic sums all-reduced)" if dp.sync_bn else "per replica"),
-            "collectives": None if dp is None else ("libpcgan_hip pcg_dp_* (RCCL behind the C ABI)" if dp.native else "torch.distributed nccl"),
+            "collectives": None if dp is None else {
+                "backend": "libpcgan_hip pcg_dp_* (RCCL behind the C ABI)" if dp.native else "torch.distributed nccl",
+                "rccl_version": dp.rccl_version(), "timed_region_barrier": "pcg_dp_barrier (same communicator)" if dp.native else "torch.distributed.barrier",
+                "nccl_debug": os.environ.get("NCCL_DEBUG"), "rank0_rccl_log": _read_tail(rccl_log)},
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "launch": "eager" if gs is None else f"hip-graph replay ({len(gs.program)} segment(s)); {len(sampled)} of {args.steps} timed steps eager with HIP events",
         }

@@ -251,6 +251,43 @@ int pcg_bn_bwd_partial_db(const float* dm, const float* x, int64_t rows, int32_t
                           float* dbeta, int accumulate, float* dcol /*nullable*/, int accumulate_col, void* workspace,
                           size_t workspace_bytes, pcg_stream_t stream);
 
+/* ---- grouped batches (r04): the discriminator's real and fake passes as ONE pass --------------------------------------------
+ * mnist_dcgan.py:151-161 runs netD twice per D step — on the real batch and on fake.detach() — and adds the two backward passes
+ * into .grad before optimizerD.step() (:164).  Neither pass depends on the other, so both run as one tensor of `groups` (= 2)
+ * batches side by side along the batch axis: one convolution launch per layer and direction over 2B images, one weight-gradient
+ * launch whose sum over pixels covers both batches (the .grad accumulation of :153,161).  BatchNorm keeps the reference's
+ * semantics: every group has its OWN batch statistics (save_mean / save_invstd / the backward's two means are [groups][C], taken
+ * from the group's own 64-row partial sums in the fixed order of the ungrouped finalize), the running statistics are updated
+ * once per group in group order, num_batches_tracked advances by `groups`; dgamma / dbeta are the groups' sums added in group
+ * order.  Against two separate passes the results differ only where a sum's ORDER differs: the weight gradients (one K-loop over
+ * 2B images instead of two added results) — a few ulp, stated in tests/test_hip_groups.py.  Constraints: C / 4 a power of two
+ * <= 256, (B / groups) * OH * OW a multiple of 128, equal sub-pixel phases; not available in the exact-BatchNorm data-parallel
+ * mode.  Callers fall back to separate passes otherwise (pcgan_amd.nn.SequentialConvNet.supports_groups).                      */
+int pcg_conv2d_fwd_bn_g(const pcg_conv_geom* g, const float* x, const float* w, const float* bias /*nullable*/, float* y, float eps,
+                        float momentum, float* save_mean /*[groups][Cout]*/, float* save_invstd /*[groups][Cout]*/,
+                        float* running_mean /*nullable*/, float* running_var /*nullable*/, int64_t* num_batches_tracked /*nullable*/,
+                        int32_t groups, void* workspace /*pcg_conv2d_fwd_bn_workspace_bytes*/, size_t workspace_bytes, pcg_stream_t stream);
+/* y = act(bn_g(x)) with group g's statistics on group g's rows (training mode only: mean / invstd are save_mean / save_invstd) */
+int pcg_bn_apply_act_g(const float* x, int64_t rows, int32_t C, const float* mean /*[groups][C]*/, const float* invstd /*[groups][C]*/,
+                       const float* gamma, const float* beta, int act, float slope, float* y, int32_t groups, pcg_stream_t stream);
+/* pcg_conv2d_dgrad_bnbwd on `groups` side-by-side batches: mean / invstd of the layer below are [groups][Cin]; the partial rows keep
+ * the ungrouped layout ([phase][tile row], pcg_conv2d_dgrad_bn_partial_rows of them in pcg_conv2d_dgrad_bn_phases phases).       */
+int32_t pcg_conv2d_dgrad_bn_phases(const pcg_conv_geom* g);
+int pcg_conv2d_dgrad_bnbwd_g(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dx,
+                             void* partial, size_t partial_bytes, int32_t groups, pcg_stream_t stream);
+/* pcg_bn_bwd_partial on `groups` side-by-side batches (partial rows from pcg_conv2d_dgrad_bnbwd_g; nphases = the phases of that launch) */
+size_t pcg_bn_bwd_partial_g_workspace_bytes(int32_t C, int32_t groups);
+int pcg_bn_bwd_partial_g(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                         const float* gamma, const void* partial, int32_t nparts, int32_t nphases, float* dx, float* dgamma,
+                         float* dbeta, int accumulate, int32_t groups, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+/* pcg_bn_act_bwd_premask on `groups` side-by-side batches (BatchNorm + ReLU / LeakyReLU backward behind a thin layer: one column
+ * reduction per group, one grouped finalize, one grouped apply)                                                               */
+size_t pcg_bn_act_bwd_g_workspace_bytes(int64_t rows, int32_t C, int32_t groups);
+int pcg_bn_act_bwd_premask_g(const float* dy, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, float slope, float* dx, float* dgamma, float* dbeta,
+                             int accumulate, int32_t groups, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */
 int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream);
@@ -263,6 +300,13 @@ int pcg_act_bwd(const float* dy, const float* y, int64_t n, int act, float slope
 int pcg_bce_fwd_bwd(const float* p, const float* target /*nullable → target_const*/, float target_const,
                     int64_t n, float grad_scale, const float* grad_out_dev /*nullable: one float, multiplies dp*/,
                     float* loss /*nullable*/, float* dp /*nullable*/, pcg_stream_t stream);
+/* Two nn.BCELoss (mean) over the two halves of p in ONE launch: the discriminator's real and fake outputs side by side
+ * (mnist_dcgan.py:152,160) and errD = errD_real + errD_fake (:163).  loss3 = {BCE(p[:n], target0), BCE(p[n:], target1), their fp32
+ * sum}; the first two carry the bits pcg_bce_fwd_bwd gives on each half.  Backward: g0 / g1 / g2 = one-element device cotangents of
+ * the three outputs (nullable: 0; all null: 1); dp[h*n + i] = (g_h + g2) / n * dBCE/dp.                                          */
+int pcg_bce_pair(const float* p, int64_t n_half, float target0, float target1, const float* g0_dev /*nullable*/,
+                 const float* g1_dev /*nullable*/, const float* g2_dev /*nullable*/, float* loss3 /*nullable*/, float* dp /*nullable*/,
+                 pcg_stream_t stream);
 /* nn.BCEWithLogitsLoss (mean): conditional_counteRGAN/mnist/trainer.py:79,106-107,117              */
 int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale,
                            const float* grad_out_dev /*nullable*/, float* loss /*nullable*/, float* dz /*nullable*/,
@@ -705,6 +749,12 @@ int pcg_house_residual_bwd_losses_diag(const float* res, const float* masked, co
                                        const int64_t* target_y, int32_t nc, float eps, float* diag_out4, double* acc /*nullable*/,
                                        pcg_stream_t stream);
 
+/* A barrier of the ranks on the library's own communicator (a 4-byte all-reduce in stream order; synchronise `stream` afterwards):
+ * bench.py brackets its timed region with it, so that region uses ONE communicator — the one that carries the gradient exchange.
+ * pcg_dp_rccl_version: ncclGetVersion of the RCCL the library bound (22105 = 2.21.5; 0 = unknown).                              */
+int pcg_dp_barrier(pcg_stream_t stream);
+int32_t pcg_dp_rccl_version(void);
+
 /* ---- data-parallel exchange (RCCL over xGMI) --------------------------------------------------------------------------------
  * The reference is single-process (mnist_dcgan.py:140-175, mnist/trainer.py:89-123); data-parallel replicas add ONE exchange per
  * optimizer step: the average of the net's flat fp32 gradient bucket.  The library owns the RCCL communicator (bound at run time,
@@ -769,6 +819,10 @@ int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_t assume_sc
 size_t pcg_conv_scratch_parts_bytes(void);
 size_t pcg_conv_scratch_arrivals_bytes(void);
 int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t parts_bytes, void* arrivals, size_t arrivals_bytes);
+/* Zero-fill the arrival counters of `stream`'s scratch in stream order — after a launch on that stream failed or was aborted (the
+ * kernels leave the counters zero only when every range of a launch ran).  The registry is keyed by (current device, stream): the
+ * default stream has the same handle on every device.  No-op for a stream without scratch.                                      */
+int pcg_conv_reset_scratch(pcg_stream_t stream);
 /* Diagnostic builds only (`make -C csrc stamp`, -DPCG_CLOCK_STAMP): every conv kernel block leaves {shader-clock ticks, 100 MHz
  * ticks} of its main loop at buf[2*block], buf[2*block+1] (uint64) — the clock the chip holds inside the kernel.  Returns 1 when
  * this build stamps, 0 for the shipped library (which compiles no stamp code).  buf = NULL turns it off.                        */

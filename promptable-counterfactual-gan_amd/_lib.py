@@ -86,6 +86,16 @@ PROTOTYPES = {
     "pcg_conv_scratch_parts_bytes": (_sz, []),
     "pcg_conv_scratch_arrivals_bytes": (_sz, []),
     "pcg_conv_set_scratch": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "pcg_conv_reset_scratch": (_i, [_vp]),
+    "pcg_conv2d_fwd_bn_g": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "pcg_bn_apply_act_g": (_i, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i, _f, _vp, _i32, _vp]),
+    "pcg_conv2d_dgrad_bn_phases": (_i32, [_gp]),
+    "pcg_conv2d_dgrad_bnbwd_g": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _i32, _vp]),
+    "pcg_bn_bwd_partial_g_workspace_bytes": (_sz, [_i32, _i32]),
+    "pcg_bn_bwd_partial_g": (_i, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i, _i32, _vp, _sz, _vp]),
+    "pcg_bn_act_bwd_g_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "pcg_bn_act_bwd_premask_g": (_i, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i32, _vp, _sz, _vp]),
+    "pcg_bce_pair": (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcg_calib_mfma_blocks": (_i32, [_i32]),
     "pcg_calib_mfma_workspace_bytes": (_sz, [_i32]),
     "pcg_calib_mfma": (_i, [_i32, _i32, _vp, _sz, _c.POINTER(_d), _c.POINTER(_c.c_uint64), _vp]),
@@ -136,6 +146,8 @@ PROTOTYPES = {
     "pcg_dp_allreduce_sum_f64": (_i, [_vp, _i64, _vp]),
     "pcg_dp_broadcast": (_i, [_vp, _i64, _i32, _vp]),
     "pcg_dp_sync_batchnorm": (_i, [_i32]),
+    "pcg_dp_barrier": (_i, [_vp]),
+    "pcg_dp_rccl_version": (_i32, []),
     "pcg_dp_shutdown": (_i, []),
     "pcg_conv2d_wgrad_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_wgrad": (_i, [_gp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
@@ -268,7 +280,16 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get("PCG_TRACE_OPS")     # diagnostic: a file; every library call is followed by a device synchronise and logged there
+
+
 def check(rc, what=""):
     if rc != PCG_OK:
         msg = load().pcg_last_error().decode("utf-8", "replace")
         raise PcgError(f"{what or 'libpcgan_hip'} failed (status {rc}): {msg}")
+    if _TRACE:      # (a faulting kernel is then the call AFTER the last line of the file)
+        with open(_TRACE, "a") as f:
+            f.write(f"{what} issued\n")
+        torch.cuda.synchronize()
+        with open(_TRACE, "a") as f:
+            f.write(f"{what} done\n")

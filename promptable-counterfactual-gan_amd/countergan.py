@@ -826,7 +826,10 @@ def train_countergan(generator, discriminator, classifier, train_loader, cfg, de
                 mask = build_mask(x, cfg.patch_size, device, cfg.num_modifiable_patches)       # :95
             out = train_step(generator, discriminator, classifier, opt_g, opt_d, bce, ce, x, y, target_y, mask, cfg,
                              skip_dead_d_wgrad=not last)                                        # :96-123
-            pending.append((out["g_loss"], out["d_loss"], out["g_cls"]))                        # :130-132, read at the epoch's end
+            # :130-132, read at the epoch's end.  Detached: a scalar with its grad_fn would keep every custom node's saved
+            # activations (ctx.saved is a plain attribute, not released by backward) alive until the epoch ends — 0.67 GB per
+            # iteration at the reference batch
+            pending.append((out["g_loss"].detach(), out["d_loss"].detach(), out["g_cls"].detach()))
             if verbose and batch_idx % log_every == 0:                                         # :134-137
                 reg = out["reg_l1"].item()
                 print(f"[Epoch {epoch + 1}/{cfg.num_epochs_gan}] batch {batch_idx} :: "

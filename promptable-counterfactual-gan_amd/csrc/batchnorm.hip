@@ -152,9 +152,17 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(Fn fn, int64_t ro
 
 // Sum NVAL per-channel partial rows in fp64: thread (c, slice) adds partial blocks slice, slice+FIN_SL, ... and the FIN_SL
 // slices are combined in a fixed order through LDS (bitwise reproducible; ~nblocks/(8 FIN_SL) dependent load batches per thread).
-template <int NVAL, class SrcT>
+// Which physical partial row the i-th row of a sum is.  Identity for the plain finalizes; RowMapSeg for the GROUPED ones (several
+// independent batches side by side along the rows of one launch, r04): group g's rows are `seg_len` consecutive rows out of every
+// `seg_stride` (one segment per sub-pixel phase of a grad-input launch, a single segment for a forward launch), starting at `off`.
+struct RowMapId { __device__ __forceinline__ int operator()(int i) const { return i; } };
+struct RowMapSeg {
+  int seg_len, seg_stride, off;
+  __device__ __forceinline__ int operator()(int i) const { const int q = i / seg_len; return q * seg_stride + off + (i - q * seg_len); }
+};
+template <int NVAL, class SrcT, class Map = RowMapId>
 __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, int nblocks, int C, int& c_out,
-                                              double (&sum)[NVAL]) {
+                                              double (&sum)[NVAL], const Map map = Map()) {
   __shared__ double red[NVAL][FIN_SL][FIN_CH];
   const int SL = blockDim.x / FIN_CH;          // 32 or 128 slices (fin_threads)
   const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
@@ -169,7 +177,7 @@ __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, 
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int k = 0; k < NVAL; ++k) v[j][k] = partial[((size_t)(b + j * SL) * NVAL + k) * C + c];
+        for (int k = 0; k < NVAL; ++k) v[j][k] = partial[((size_t)map(b + j * SL) * NVAL + k) * C + c];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -177,7 +185,7 @@ __device__ __forceinline__ bool finalize_sums(const SrcT* __restrict__ partial, 
     }
     for (; b < nblocks; b += SL)
 #pragma unroll
-      for (int k = 0; k < NVAL; ++k) acc[k] += (double)partial[((size_t)b * NVAL + k) * C + c];
+      for (int k = 0; k < NVAL; ++k) acc[k] += (double)partial[((size_t)map(b) * NVAL + k) * C + c];
   }
 #pragma unroll
   for (int k = 0; k < NVAL; ++k) red[k][sl][cl] = acc[k];
@@ -248,6 +256,50 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_kernel(
   coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
   coef[C + c] = (float)(sm[0] * inv_rows);
   coef[2 * C + c] = (float)(sm[1] * inv_rows);
+}
+
+// ---- grouped forms (r04): G independent batches side by side along the rows of ONE launch (the discriminator's real and fake
+// passes of mnist_dcgan.py:151-161 as one 2B-row pass).  Each group has its own batch statistics — save_mean / save_invstd /
+// coef are [G][..] — taken from its own partial rows in the same fixed order the one-batch finalize uses; the running statistics
+// are updated group after group, which is what G successive training-mode forwards do ([torch] momentum update per call).
+template <class SrcT>
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_stats_finalize_g_kernel(
+    const SrcT* __restrict__ partial, int rows_per_group, int groups, int seg_len, int seg_stride, int C, double inv_rows, double unbias,
+    float eps, float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += groups;
+  for (int g = 0; g < groups; ++g) {
+    __syncthreads();                       // the previous group's reads of the LDS slices are done
+    int c;
+    double sm[2];
+    if (!finalize_sums<2, SrcT, RowMapSeg>(partial, rows_per_group, C, c, sm, RowMapSeg{seg_len, seg_stride, g * seg_len})) continue;
+    const double mean = sm[0] * inv_rows;
+    double var = sm[1] * inv_rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[(size_t)g * C + c] = (float)mean;
+    save_invstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  }
+}
+// coef[g][0][c] = gamma*invstd_g ; coef[g][1][c] = mean_g(dz) ; coef[g][2][c] = mean_g(dz*xhat); dgamma / dbeta: the groups' sums added
+// in group order (what G successive backward passes accumulate into .grad)
+template <class SrcT>
+__global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_g_kernel(
+    const SrcT* __restrict__ partial, int rows_per_group, int groups, int seg_len, int seg_stride, int C, double inv_rows,
+    const float* gamma, const float* invstd, float* coef, float* dgamma, float* dbeta, int accumulate) {
+  for (int g = 0; g < groups; ++g) {
+    __syncthreads();
+    int c;
+    double sm[2];
+    if (!finalize_sums<2, SrcT, RowMapSeg>(partial, rows_per_group, C, c, sm, RowMapSeg{seg_len, seg_stride, g * seg_len})) continue;
+    const bool acc = accumulate || g > 0;
+    if (dbeta) dbeta[c] = (acc ? dbeta[c] : 0.f) + (float)sm[0];
+    if (dgamma) dgamma[c] = (acc ? dgamma[c] : 0.f) + (float)sm[1];
+    float* cg = coef + (size_t)g * 3 * C;
+    cg[c] = (gamma ? gamma[c] : 1.f) * invstd[(size_t)g * C + c];
+    cg[C + c] = (float)(sm[0] * inv_rows);
+    cg[2 * C + c] = (float)(sm[1] * inv_rows);
+  }
 }
 
 // Many partial rows (the conv epilogues leave one per 64 output rows: 12544 for a 1024x28x28 activation) make the finalize a
@@ -378,7 +430,12 @@ __global__ void __launch_bounds__(256) bn_apply_act_fast_kernel(const float4* __
                                                                 float var_eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int act, float slope,
                                                                 const float4* __restrict__ residual, float alpha,
-                                                                float4* __restrict__ y) {
+                                                                float4* __restrict__ y, size_t group_n4 = 0) {
+  if (group_n4) {      // grouped form: blockIdx.y = group; its rows are contiguous, its statistics the y-th [C] row of mean / invstd
+    const size_t g = blockIdx.y;
+    x += g * group_n4; y += g * group_n4; if (residual) residual += g * group_n4;
+    mean += g * C; invstd += g * C; n4 = group_n4;
+  }
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
   float sc[4], sh[4];
@@ -411,7 +468,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, int act, float slope,
                                                                 float dy_scale, float4* __restrict__ dx, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, double* __restrict__ colpart) {
+                                                                const float* __restrict__ beta, double* __restrict__ colpart,
+                                                                size_t group_n4 = 0) {
+  if (group_n4) {      // grouped form (no fused column sums): blockIdx.y = group, coef is [G][3][C]
+    const size_t g = blockIdx.y;
+    dy += g * group_n4; x += g * group_n4; dx += g * group_n4; if (y) y += g * group_n4;
+    mean += g * C; invstd += g * C; coef += g * 3 * C; n4 = group_n4;
+  }
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
   const int c0 = (int)(gtid % (size_t)(C >> 2)) * 4;
   float mu[4], is[4], k0[4], k1[4], k2[4], msc[4], msh[4];
@@ -778,6 +841,116 @@ extern "C" int pcg_bn_act_bwd_db(const float* dy, const float* x, const float* y
   PCG_REQUIRE(dcol != nullptr, "pcg_bn_act_bwd_db: null column-sum output");
   return bn_act_bwd_impl(dy, x, y, rows, C, mean, invstd, gamma, beta, act, slope, dy_scale, dx, dgamma, dbeta, accumulate, workspace,
                          workspace_bytes, stream, dcol, accumulate_col);
+}
+
+// ---- grouped BatchNorm (G independent batches along the rows of one tensor; see bn_stats_finalize_g_kernel) --------------------
+namespace pcg {
+// partial rows of a grouped conv launch -> per-group statistics.  nphases: sub-pixel phases of a grad-input launch (1 for a forward
+// launch); every phase holds nparts / nphases rows, the g-th G-th of them belong to group g.
+int launch_bn_stats_finalize_g(const double* partial, int nparts, int nphases, int groups, int64_t rows_per_group, int C, float eps,
+                               float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                               int64_t* nbt, hipStream_t s) {
+  PCG_REQUIRE(!dp_sync_bn(), "grouped BatchNorm: not available in the exact global-batch mode (pcg_dp_sync_batchnorm)");
+  PCG_REQUIRE(groups >= 1 && nphases >= 1 && nparts % (nphases * groups) == 0, "grouped BatchNorm: %d partial rows do not split into %d phases x %d groups", nparts, nphases, groups);
+  const int per_phase = nparts / nphases, seg = per_phase / groups, rpg = seg * nphases;
+  const double unbias = rows_per_group > 1 ? (double)rows_per_group / (double)(rows_per_group - 1) : 1.0;
+  hipLaunchKernelGGL(bn_stats_finalize_g_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(rpg)), 0, s, partial, rpg, groups,
+                     seg, per_phase, C, 1.0 / (double)rows_per_group, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
+  return launch_status("bn_stats_finalize_g_kernel");
+}
+}  // namespace pcg
+
+static bool grouped_shape_ok(int64_t rows, int32_t C, int32_t groups) {
+  return groups >= 1 && groups <= 8 && rows > 0 && rows % groups == 0 && fast_channels(C);
+}
+static unsigned grouped_apply_blocks(size_t n4_group) {
+  unsigned blocks = (unsigned)((n4_group + 511) / 512);
+  if (blocks > 4096) blocks = 4096;
+  return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int pcg_bn_apply_act_g(const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int act, float slope, float* y, int32_t groups, pcg_stream_t stream) {
+  PCG_REQUIRE(x && y && mean && invstd, "pcg_bn_apply_act_g: null pointer");
+  PCG_REQUIRE(grouped_shape_ok(rows, C, groups) && al16(x) && al16(y),
+              "pcg_bn_apply_act_g: needs rows %% groups == 0, C / 4 a power of two <= 256 and 16-byte aligned tensors (rows %lld, C %d, groups %d)",
+              (long long)rows, C, groups);
+  const size_t n4g = (size_t)(rows / groups) * C / 4;
+  hipLaunchKernelGGL(bn_apply_act_fast_kernel, dim3(grouped_apply_blocks(n4g), groups), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), n4g, C, mean, invstd, -1.f, gamma, beta, act, slope, (const float4*)nullptr, 1.f,
+                     reinterpret_cast<float4*>(y), n4g);
+  return launch_status("bn_apply_act_fast_kernel");
+}
+
+extern "C" size_t pcg_bn_bwd_partial_g_workspace_bytes(int32_t C, int32_t groups) { return (size_t)3 * C * groups * sizeof(float); }
+
+static int launch_bwd_finalize_apply_g(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int act, float slope, const double* partial, int rpg, int seg,
+                                       int seg_stride, float* dx, float* dgamma, float* dbeta, int accumulate, int32_t groups, float* coef,
+                                       hipStream_t s) {
+  const int64_t rows_g = rows / groups;
+  hipLaunchKernelGGL(bn_bwd_finalize_g_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(rpg)), 0, s, partial, rpg, groups, seg,
+                     seg_stride, C, 1.0 / (double)rows_g, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  if (int e = launch_status("bn_bwd_finalize_g_kernel")) return e;
+  const size_t n4g = (size_t)rows_g * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(grouped_apply_blocks(n4g), groups), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
+                     reinterpret_cast<const float4*>(x), (const float4*)nullptr, n4g, C, mean, invstd, (const float*)coef, act, slope, 1.f,
+                     reinterpret_cast<float4*>(dx), gamma, beta, (double*)nullptr, n4g);
+  return launch_status("bn_bwd_apply_fast_kernel");
+}
+
+// BatchNorm backward of G side-by-side batches from the column sums a grouped fused grad-input epilogue left in `partial`
+// (pcg_conv2d_dgrad_bnbwd_g; dm is already masked).  mean / invstd: [G][C]; nphases: sub-pixel phases of the launch that wrote the
+// partial rows (pcg_conv2d_dgrad_bn_phases), 1 for a forward-kernel launch.
+extern "C" int pcg_bn_bwd_partial_g(const float* dm, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                    const float* gamma, const void* partial_, int32_t nparts, int32_t nphases, float* dx, float* dgamma,
+                                    float* dbeta, int accumulate, int32_t groups, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  const double* partial = static_cast<const double*>(partial_);
+  PCG_REQUIRE(dm && x && mean && invstd && partial && dx && nparts > 0 && nphases > 0, "pcg_bn_bwd_partial_g: bad arguments");
+  PCG_REQUIRE(grouped_shape_ok(rows, C, groups) && al16(dm) && al16(x) && al16(dx) && ((uintptr_t)partial & 7) == 0,
+              "pcg_bn_bwd_partial_g: needs rows %% groups == 0, C / 4 a power of two <= 256 and aligned tensors (rows %lld, C %d, groups %d)",
+              (long long)rows, C, groups);
+  PCG_REQUIRE(nparts % (nphases * groups) == 0, "pcg_bn_bwd_partial_g: %d partial rows do not split into %d phases x %d groups", nparts, nphases, groups);
+  PCG_REQUIRE(!dp_sync_bn(), "pcg_bn_bwd_partial_g: not available in the exact global-batch mode");
+  if (!workspace || workspace_bytes < pcg_bn_bwd_partial_g_workspace_bytes(C, groups)) {
+    set_error("pcg_bn_bwd_partial_g: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_bwd_partial_g_workspace_bytes(C, groups));
+    return PCG_ERR_WORKSPACE;
+  }
+  const int per_phase = nparts / nphases, seg = per_phase / groups;
+  return launch_bwd_finalize_apply_g(dm, x, rows, C, mean, invstd, gamma, nullptr, PCG_ACT_NONE, 0.f, partial, seg * nphases, seg, per_phase, dx,
+                                     dgamma, dbeta, accumulate, groups, (float*)workspace, (hipStream_t)stream);
+}
+
+// BatchNorm(train) + ReLU / LeakyReLU backward of G side-by-side batches without a fused producer (the layer above is a thin
+// layer): one column reduction per group, then the grouped finalize and apply.  The mask is recomputed from x (premask form).
+extern "C" size_t pcg_bn_act_bwd_g_workspace_bytes(int64_t rows, int32_t C, int32_t groups) {
+  if (rows <= 0 || C <= 0 || groups <= 0 || rows % groups) return 0;
+  const ColPlan a = plan_cols(rows / groups, C, true);
+  return ((size_t)groups * a.nblocks * 2 * C) * sizeof(double) + (size_t)3 * C * groups * sizeof(float);
+}
+extern "C" int pcg_bn_act_bwd_premask_g(const float* dy, const float* x, int64_t rows, int32_t C, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, int act, float slope, float* dx, float* dgamma, float* dbeta,
+                                        int accumulate, int32_t groups, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  PCG_REQUIRE(dy && x && mean && invstd && gamma && beta && dx, "pcg_bn_act_bwd_premask_g: null pointer");
+  PCG_REQUIRE(act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU, "pcg_bn_act_bwd_premask_g: activation %d is not none / ReLU / LeakyReLU", act);
+  PCG_REQUIRE(grouped_shape_ok(rows, C, groups) && al16(dy) && al16(x) && al16(dx) && ((rows / groups) * C) % 4 == 0,
+              "pcg_bn_act_bwd_premask_g: needs rows %% groups == 0, C / 4 a power of two <= 256 and aligned tensors (rows %lld, C %d, groups %d)",
+              (long long)rows, C, groups);
+  PCG_REQUIRE(!dp_sync_bn(), "pcg_bn_act_bwd_premask_g: not available in the exact global-batch mode");
+  const size_t need = pcg_bn_act_bwd_g_workspace_bytes(rows, C, groups);
+  if (!workspace || workspace_bytes < need) { set_error("pcg_bn_act_bwd_premask_g: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows_g = rows / groups;
+  const ColPlan cp = plan_cols(rows_g, C, true);
+  double* partial = (double*)workspace;
+  float* coef = reinterpret_cast<float*>(partial + (size_t)groups * cp.nblocks * 2 * C);
+  for (int g = 0; g < groups; ++g) {
+    const size_t off = (size_t)g * rows_g * C;
+    FnBnBwd fn{dy + off, x + off, nullptr, mean + (size_t)g * C, invstd + (size_t)g * C, act, slope, 1.f, gamma, beta};
+    if (int e = launch_colreduce(fn, rows_g, C, cp, partial + (size_t)g * cp.nblocks * 2 * C, s)) return e;
+  }
+  return launch_bwd_finalize_apply_g(dy, x, rows, C, mean, invstd, gamma, beta, act, slope, partial, cp.nblocks, cp.nblocks, cp.nblocks * groups,
+                                     dx, dgamma, dbeta, accumulate, groups, coef, s);
 }
 
 extern "C" int pcg_colsum(const float* dy, int64_t rows, int32_t C, float* db, int accumulate, void* workspace,

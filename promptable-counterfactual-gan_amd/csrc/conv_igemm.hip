@@ -24,11 +24,25 @@ namespace {
 // role of this wave, provably wave-uniform for the compiler (scalar branch, no exec masking)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Issue priority at the edges of a workgroup's life (ConvP::edge_prio).  The main loops run producers at 3 and consumers at 1-2
+// (igemm_core.h); everything outside them — loader set-up with its divisions, the first gathers, the LDS-staged epilogue — used to
+// run at priority 0 and was handed an issue slot only when no wave of the CU's other workgroups wanted one: in-kernel stamps
+// (r04, 3x3 64->64 forward, three workgroups per CU) read 4.0 us from entry to the first k-tile and 7.1 us for a ~150-instruction
+// epilogue, 17 % of the workgroup's life.
+__device__ __forceinline__ void prio_entry(const ConvP& p) { if (p.edge_prio & 1) __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void prio_epilogue(const ConvP& p) { if (p.edge_prio & 2) __builtin_amdgcn_s_setprio(3); }
+
+// grouped launches (EpiAux::group_rows): float offset of the tile's group inside the [G][N] BatchNorm statistics
+__device__ __forceinline__ int epi_group_off(const ConvP& p, int m_block) {
+  return p.epi.group_rows > 0 ? __builtin_amdgcn_readfirstlane(m_block / p.epi.group_rows) * p.N : 0;
+}
+
 // XF (here and below): the activation operand carries an input transform (ConvP::in_sc) — a separate instantiation, so the
 // plain kernels pay nothing for it.
 template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  prio_entry(p);
   const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / p.tilesN, nt = tile % p.tilesN;
   const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
@@ -51,6 +65,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
   ClockStamp cs{p.stamps, p.stamp_slots};
   cs.phase(0);
   igemm_consume<Cfg, true, true>(ktiles, acc, smem, cs);
+  prio_epilogue(p);
   float* out = p.out + (size_t)blockIdx.y * (size_t)p.M * (size_t)p.N;
 #ifdef PCG_ABL_NO_EPILOGUE   // timing-only ablation: keep one store so the accumulators stay live
   if (acc[0][0][0] == 12345.678f) out[0] = acc[0][0][1];
@@ -59,7 +74,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_kernel(ConvP p
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, blockIdx.y == 0 ? p.bias : nullptr, [&](int row) -> float* {
     const int m = m_block + row;
     return m < p.M ? out + (size_t)m * p.N + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+  }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
   cs.phase(3);
 }
 
@@ -67,6 +82,7 @@ template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP p, DgradPhases phases) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
+  prio_entry(p);
   // phases.interleave (all phases the same size, 1-D grid): the sub-pixel phases of one tile are neighbours in launch order and
   // on one XCD — they gather the same dy rows, which then come from HBM once and from that XCD's L2 for the other phases
   uint32_t bx = blockIdx.x, py = blockIdx.y;
@@ -102,11 +118,15 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_kernel(ConvP
     return;
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
-  igemm_consume<Cfg, true, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
+  ClockStamp cs{p.stamps, p.stamp_slots};
+  cs.phase(0);
+  igemm_consume<Cfg, true, false>(ktiles, acc, smem, cs);
+  prio_epilogue(p);
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
     const int pix = rowpix[row];
     return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+  }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
+  cs.phase(3);
 }
 
 // ======================================================================================================================
@@ -159,6 +179,11 @@ __device__ __forceinline__ int sk_segments(const SkPlan& sk, SkSeg& s0, SkSeg& s
 // acquire fence pair around the counter, which writes back and invalidates whole caches once per wave and arrival (measured r03:
 // with the fences the 288-tile GEMM went from 137 to 203 us).  Each storing wave drains its stores (vmcnt(0)) before ITS add to
 // the (tile, wave) counter; the wave whose add returns nparts - 1 loads only behind that return.
+// PER-ARCHITECTURE REQUIREMENT: this protocol (sc1 stores drained by vmcnt(0), then a relaxed agent-scope atomic, no fences) is
+// what gfx950's memory model guarantees for agent-scope visibility; another target has to re-derive it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "stream-K partial-tile exchange (sc1 stores + relaxed agent-scope counters) is written for gfx950 only"
+#endif
 __device__ __forceinline__ void sk_store4(rsrc_t r, uint32_t off, float a, float b, float c, float d) {
   const u32x4 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
   __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
@@ -243,7 +268,7 @@ __device__ __forceinline__ void fwd_sk_segment(const ConvP& p, const SkPlan& sk,
     igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
       const int m = m_block + row;
       return m < p.M ? p.out + (size_t)m * p.N + n_block : nullptr;
-    }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+    }, p.stat_partial ? p.stat_partial + (size_t)mt * Cfg::WAVES_M * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
 }
 template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_fwd_sk_kernel(ConvP p, SkPlan sk) {
@@ -290,7 +315,7 @@ __device__ __forceinline__ void dgrad_sk_segment(const ConvP& p, const DgradPhas
     igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
       const int pix = rowpix[row];
       return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-    }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+    }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
 }
 template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_sk_kernel(ConvP p, DgradPhases phases, SkPlan sk, int tiles_per_phase) {
@@ -308,6 +333,7 @@ template <class Cfg, bool XFA, bool XFB>   // XFA: the dy operand is a transform
 __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int ktiles_total, int ktiles_per_split, int tiles,
                                                                    int slice_major) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  prio_entry(p);
   // slice_major: 1-D grid, the output tiles of one K-slice are consecutive on ONE XCD, so the slice of dy / x they all read
   // comes from HBM once and from that XCD's L2 afterwards (layers with few output tiles re-read their operands per tile)
   uint32_t tile, split;
@@ -332,6 +358,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad_kernel(ConvP p, int 
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, false, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
+  prio_epilogue(p);
   float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
     const int m = m_block + row;
@@ -403,7 +430,7 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_skn_kernel(C
         igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
           const int pix = rowpix[row];
           return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-        }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi);
+        }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
     }
     it = e;
     if (it < it1) lds_barrier();   // the epilogue staged through the LDS stages / read rowpix: the next segment's producers wait
@@ -602,6 +629,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad192_kernel(ConvP p, i
                                                                       int slice_major) {
   using Cfg = Cfg64x192;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  prio_entry(p);
   uint32_t tile, split;
   if (slice_major) {
     const uint32_t l = xcd_remap(blockIdx.x, gridDim.x);
@@ -623,6 +651,7 @@ __global__ void __launch_bounds__(IG_THREADS, 4) conv_wgrad192_kernel(ConvP p, i
   }
   f32x16 acc[Cfg::TM][Cfg::TN];
   igemm_consume<Cfg, false, false>(ktiles, acc, smem, ClockStamp{p.stamps, p.stamp_slots});
+  prio_epilogue(p);
   float* slab = p.out + (size_t)split * (size_t)p.M * (size_t)p.N;
   igemm_store_tile<Cfg>(acc, smem, n_block, p.N, nullptr, [&](int row) -> float* {
     const int m = m_block + row;
@@ -693,13 +722,15 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int edge_prio = -1, korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
   ConvP p{};
   static const int korder_env = getenv("PCG_KORDER") ? atoi(getenv("PCG_KORDER")) : 1;
   p.korder = g_tune.korder >= 0 ? g_tune.korder : korder_env;
+  static const int edge_env = getenv("PCG_EDGE_PRIO") ? atoi(getenv("PCG_EDGE_PRIO")) : 0;
+  p.edge_prio = g_tune.edge_prio >= 0 ? g_tune.edge_prio : edge_env;
   p.stamps = g_tune.stamps; p.stamp_slots = g_tune.stamp_slots;
   p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.Cin = g->Cin; p.OH = g->OH; p.OW = g->OW; p.Cout = g->Cout;
   p.KH = g->KH; p.KW = g->KW; p.stride = g->stride; p.pad = g->pad;
@@ -772,14 +803,21 @@ constexpr size_t stage_smem_bytes() { return sizeof(float) * (size_t)igemm_smem_
 constexpr int SK_MAX_BLOCKS = 512, SK_MAX_TILES = 4096;
 constexpr size_t SK_PARTS_BYTES = (size_t)2 * SK_MAX_BLOCKS * 128 * 128 * sizeof(float);
 constexpr size_t SK_ARRIVALS_BYTES = (size_t)SK_MAX_TILES * 4 * sizeof(int);
-struct SkScratch { hipStream_t stream; float* parts; int* arrivals; };
+// keyed by (device, stream): the default stream has handle 0 on EVERY device, so the handle alone would let a second GPU's
+// registration overwrite the first one's
+struct SkScratch { int device; hipStream_t stream; float* parts; int* arrivals; };
 SkScratch g_sk_scratch[64];
 int g_sk_scratch_n = 0;
 std::mutex g_sk_mutex;
+int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : 0; }
 bool sk_scratch_of(hipStream_t s, SkPlan* sk) {
+  const int dev = current_device();
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   for (int i = 0; i < g_sk_scratch_n; ++i)
-    if (g_sk_scratch[i].stream == s) { sk->parts = g_sk_scratch[i].parts; sk->arrivals = g_sk_scratch[i].arrivals; return true; }
+    if (g_sk_scratch[i].stream == s && g_sk_scratch[i].device == dev) {
+      if (sk) { sk->parts = g_sk_scratch[i].parts; sk->arrivals = g_sk_scratch[i].arrivals; }
+      return true;
+    }
   return false;
 }
 int sk_mode() {      // 0 off, 1 where the model sees > 10 % to gain (default), 2 wherever the form is valid (tests, scans)
@@ -818,7 +856,16 @@ bool plan_sk_shape(int tiles, int ktiles, SkPlan* sk) {       // the decision al
   return true;
 }
 bool plan_sk(int tiles, int ktiles, hipStream_t s, SkPlan* sk) { return plan_sk_shape(tiles, ktiles, sk) && sk_scratch_of(s, sk); }
-bool have_sk_scratch() { return sk_mode() != 0 && g_sk_scratch_n > 0; }
+// workspace queries carry no stream: they assume scratch when ANY stream of this device has it (an upper bound on what a launch
+// may need; a launch on a stream without scratch plans with stream_has_sk and falls back to the plain forms)
+bool have_sk_scratch() {
+  if (sk_mode() == 0) return false;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  for (int i = 0; i < g_sk_scratch_n; ++i) if (g_sk_scratch[i].device == dev) return true;
+  return false;
+}
+int stream_has_sk(hipStream_t s) { return sk_mode() != 0 && sk_scratch_of(s, nullptr) ? 1 : 0; }
 
 template <class Cfg, bool XF>
 int launch_fwd_x(ConvP p, int splits, hipStream_t s) {
@@ -1088,9 +1135,10 @@ extern "C" size_t pcg_conv_scratch_arrivals_bytes(void) { return pcg::SK_ARRIVAL
 extern "C" int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t parts_bytes, void* arrivals, size_t arrivals_bytes) {
   using namespace pcg;
   hipStream_t s = (hipStream_t)stream;
+  const int dev = current_device();
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   int at = -1;
-  for (int i = 0; i < g_sk_scratch_n; ++i) if (g_sk_scratch[i].stream == s) at = i;
+  for (int i = 0; i < g_sk_scratch_n; ++i) if (g_sk_scratch[i].stream == s && g_sk_scratch[i].device == dev) at = i;
   if (!parts) {
     if (at >= 0) g_sk_scratch[at] = g_sk_scratch[--g_sk_scratch_n];
     return PCG_OK;
@@ -1102,7 +1150,18 @@ extern "C" int pcg_conv_set_scratch(pcg_stream_t stream, void* parts, size_t par
     PCG_REQUIRE(g_sk_scratch_n < 64, "pcg_conv_set_scratch: more than 64 streams with scratch");
     at = g_sk_scratch_n++;
   }
-  g_sk_scratch[at] = SkScratch{s, (float*)parts, (int*)arrivals};
+  g_sk_scratch[at] = SkScratch{dev, s, (float*)parts, (int*)arrivals};
+  return PCG_OK;
+}
+// The stream-K kernels rely on the arrival counters being zero between launches (the last arrival of a tile resets its counters).
+// After a launch on `stream` failed or was aborted they may not be: this zero-fills them in stream order.  No-op for a stream
+// without scratch.
+extern "C" int pcg_conv_reset_scratch(pcg_stream_t stream) {
+  using namespace pcg;
+  SkPlan sk{};
+  if (!sk_scratch_of((hipStream_t)stream, &sk)) return PCG_OK;
+  hipError_t e = hipMemsetAsync(sk.arrivals, 0, SK_ARRIVALS_BYTES, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("pcg_conv_reset_scratch: %s", hipGetErrorString(e)); return PCG_ERR_LAUNCH; }
   return PCG_OK;
 }
 
@@ -1117,6 +1176,9 @@ int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, in
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
                              bool has_presum_tail, const float* gamma = nullptr, const float* beta = nullptr, float* coef = nullptr);
 size_t bn_partial_buffer_bytes(int nparts, int C);
+int launch_bn_stats_finalize_g(const double* partial, int nparts, int nphases, int groups, int64_t rows_per_group, int C, float eps,
+                               float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                               int64_t* nbt, hipStream_t s);
 }
 
 static bool mfma_layer(const pcg_conv_geom* g) { return !(thin_is_cin(g) || thin_is_cout(g)); }
@@ -1156,7 +1218,7 @@ static int conv2d_fwd_impl(const pcg_conv_geom* g, const float* x, const float* 
   p.ktiles_per_split = p.ktiles;
   hipStream_t s = (hipStream_t)stream;
   // split-K needs the slab workspace and cannot fuse statistics or the activation (both need the complete sum)
-  FwdPlan f = plan_fwd(g);
+  FwdPlan f = plan_fwd(g, stream_has_sk(s));        // this stream's scratch decides, not "some stream has scratch"
   const size_t need = (size_t)f.splits * p.M * p.N * sizeof(float);
   if (f.splits > 1 && (stat_partial || epi || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 15) || ((uintptr_t)y & 15) || (p.M * (size_t)p.N) % 4))
     f = FwdPlan{1, p.ktiles};
@@ -1219,6 +1281,25 @@ extern "C" int pcg_conv2d_fwd_bn(const pcg_conv_geom* g, const float* x, const f
   return pcg_conv2d_fwd_bn_xf(g, x, nullptr, w, bias, y, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                               num_batches_tracked, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
+// Grouped form (r04): `groups` independent batches of g->B / groups images side by side in ONE launch — the discriminator's real and
+// fake passes (mnist_dcgan.py:151-161) as one 2B-row convolution per layer.  The convolution itself does not care; BatchNorm does:
+// each group gets its own batch statistics (save_mean / save_invstd are [groups][Cout]) from its own partial rows, the running
+// statistics move once per group in group order and num_batches_tracked advances by `groups`, exactly what `groups` successive
+// training-mode forwards do.  Needs (B / groups) * OH * OW % 128 == 0 (whole tiles per group).
+extern "C" int pcg_conv2d_fwd_bn_g(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float eps,
+                                   float momentum, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, int32_t groups, void* workspace, size_t workspace_bytes,
+                                   pcg_stream_t stream) {
+  const size_t need = pcg_conv2d_fwd_bn_workspace_bytes(g);
+  PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_bn_g: only MFMA layers (Cin > 3, Cout > 3, Cout %% 4 == 0)");
+  PCG_REQUIRE(save_mean && save_invstd, "pcg_conv2d_fwd_bn_g: null statistics output");
+  PCG_REQUIRE(groups >= 1 && groups <= 8 && g->B % groups == 0 && ((int64_t)(g->B / groups) * g->OH * g->OW) % 128 == 0,
+              "pcg_conv2d_fwd_bn_g: %d images do not split into %d groups of whole 128-row tiles (%d x %d output)", g->B, groups, g->OH, g->OW);
+  if (!workspace || workspace_bytes < need) { set_error("pcg_conv2d_fwd_bn_g: workspace %zu B < required %zu B", workspace_bytes, need); return PCG_ERR_WORKSPACE; }
+  if (int e = conv2d_fwd_impl(g, x, w, bias, y, (double*)workspace, nullptr, 0, stream)) return e;
+  return launch_bn_stats_finalize_g((const double*)workspace, fwd_stat_rows(g), 1, groups, (int64_t)(g->B / groups) * g->OH * g->OW, g->Cout,
+                                    eps, momentum, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, (hipStream_t)stream);
+}
 extern "C" int pcg_conv2d_fwd_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xform* xf, const float* w, const float* bias,
                                  int act, float slope, float* y, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   return conv2d_fwd_impl(g, x, w, bias, y, nullptr, workspace, workspace_bytes, stream, act, slope, nullptr, xf);
@@ -1264,7 +1345,7 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   }
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
-  if (!epi && !stat_partial && !has_xf && dgrad_as_gemm(g) && workspace && workspace_bytes >= dgrad_gemm_bytes(g) &&
+  if (!epi && !stat_partial && !has_xf && dgrad_as_gemm(g, stream_has_sk((hipStream_t)stream)) && workspace && workspace_bytes >= dgrad_gemm_bytes(g) &&
       (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0) {
     pcg_conv_geom g1 = {g->B, g->OH, g->OW, g->KH * g->KW * g->Cin, g->OH, g->OW, g->Cout, 1, 1, 1, 0};
     float* dcol = (float*)workspace;
@@ -1466,6 +1547,32 @@ extern "C" int pcg_conv2d_fwd_bnbwd(const pcg_conv_geom* g, const float* x, cons
                          pcg_conv2d_fwd_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
   return conv2d_fwd_impl(g, x, w, nullptr, y, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
 }
+// Grouped form of pcg_conv2d_dgrad_bnbwd: dy holds `groups` batches side by side; mean / invstd of the layer below are [groups][Cin].
+// The partial rows keep the layout of the ungrouped launch ([phase][tile row]); pcg_bn_bwd_partial_g reads each group's share of
+// every phase (pcg_conv2d_dgrad_bn_phases of them).  Needs equal sub-pixel phases with whole 128-row tiles per group.
+extern "C" int32_t pcg_conv2d_dgrad_bn_phases(const pcg_conv_geom* g) {
+  if (check_geom(g) != PCG_OK) return 0;
+  DgradPhases ph{};
+  int maxMp = 0;
+  return build_phases(g, &ph, &maxMp);
+}
+extern "C" int pcg_conv2d_dgrad_bnbwd_g(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dx,
+                                        void* partial, size_t partial_bytes, int32_t groups, pcg_stream_t stream) {
+  EpiAux e{};
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = bnbwd_epi("pcg_conv2d_dgrad_bnbwd_g", g, dx, z_below, mean, invstd, gamma, beta, act, slope,
+                         pcg_conv2d_dgrad_bn_workspace_bytes(g), partial, partial_bytes, &e)) return rc;
+  DgradPhases ph{};
+  int maxMp = 0;
+  const int nph = build_phases(g, &ph, &maxMp);
+  bool ok = groups >= 1 && groups <= 8 && g->B % groups == 0 && nph > 0;
+  for (int i = 0; i < nph && ok; ++i) ok = ph.p[i].Mp == maxMp;
+  ok = ok && (maxMp / groups) % 128 == 0 && maxMp % groups == 0;
+  PCG_REQUIRE(ok, "pcg_conv2d_dgrad_bnbwd_g: needs equal sub-pixel phases whose rows split into %d groups of whole 128-row tiles", groups);
+  e.group_rows = groups > 1 ? maxMp / groups : 0;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 
@@ -1632,6 +1739,7 @@ extern "C" int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_
 extern "C" int pcg_tune_set(const char* name, int32_t value) {
   PCG_REQUIRE(name != nullptr, "pcg_tune_set: null name");
   if (!strcmp(name, "korder")) g_tune.korder = value;
+  else if (!strcmp(name, "edge_prio")) g_tune.edge_prio = value;
   else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
   else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
@@ -1642,7 +1750,11 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "dgrad_gemm")) g_tune.dgrad_gemm = value;
   else if (!strcmp(name, "t64")) g_tune.t64 = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
-  else { set_error("pcg_tune_set: unknown switch '%s' (korder, wgrad_order, dgrad_interleave, persistent)", name); return PCG_ERR_INVALID; }
+  else {
+    set_error("pcg_tune_set: unknown switch '%s' (korder, edge_prio, wgrad_order, dgrad_interleave, persistent, persist_tiles, fwd_splits, "
+              "stream_k, sk_blocks, dgrad_gemm, t64, dma)", name);
+    return PCG_ERR_INVALID;
+  }
   return PCG_OK;
 }
 

@@ -45,6 +45,8 @@ struct ConvP {
   int ktiles;        // fwd: KH*KW*ceil(Cin/32)
   int ktiles_per_split;  // fwd split-K (gridDim.y slabs of M*N floats at `out`); == ktiles when not split
   int korder;        // order of the k-tiles of fwd / dgrad (see FwdKIter): 0 = (tap, channel chunk), 1 = L2-friendly (default)
+  int edge_prio;     // issue priority outside the main loops (r04): bit 0 — every wave enters at priority 3 (loader set-up, first
+                     // gathers), bit 1 — the consumers run the epilogue at priority 3 (was 0: starved by the other workgroups' loops)
   unsigned long long* stamps;  // diagnostic builds only (-DPCG_CLOCK_STAMP, pcg_debug_stamp_buffer): per block {shader-clock ticks,
   int stamp_slots;             // 100 MHz ticks} of consumer wave 0's main loop; the shipped library compiles no stamp code
   FastDiv dOW, dOH;  // fwd/wgrad pixel decomposition

@@ -27,12 +27,14 @@ using fn_destroy = int (*)(ncclComm_t);
 using fn_allreduce = int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
 using fn_bcast = int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
 using fn_errstr = const char* (*)(int);
+using fn_version = int (*)(int*);
 
 constexpr int kSlots = 8;
 struct Dp {
   void* lib = nullptr;
   fn_get_id get_id = nullptr; fn_init init = nullptr; fn_destroy destroy = nullptr; fn_allreduce allreduce = nullptr;
-  fn_bcast bcast = nullptr; fn_errstr errstr = nullptr;
+  fn_bcast bcast = nullptr; fn_errstr errstr = nullptr; fn_version version = nullptr;
+  float* token = nullptr;        // 64 bytes of device memory: the operand of pcg_dp_barrier's 4-byte all-reduce
   ncclComm_t comm = nullptr;
   int rank = -1, world = 0, device = -1;
   hipStream_t side = nullptr;
@@ -53,6 +55,7 @@ int bind() {
   g.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
   g.bcast = (fn_bcast)dlsym(h, "ncclBroadcast");
   g.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+  g.version = (fn_version)dlsym(h, "ncclGetVersion");      // optional
   if (!g.get_id || !g.init || !g.destroy || !g.allreduce || !g.bcast || !g.errstr) {
     set_error("pcg_dp: librccl lacks an expected symbol");
     return PCG_ERR_INVALID;
@@ -93,6 +96,8 @@ void release_partial() {
   }
   if (g.side) (void)hipStreamDestroy(g.side);
   g.side = nullptr;
+  if (g.token) (void)hipFree(g.token);
+  g.token = nullptr;
   if (g.comm) (void)g.destroy(g.comm);
   g.comm = nullptr;
   g.rank = -1; g.world = 0;
@@ -125,6 +130,8 @@ extern "C" int pcg_dp_init(const void* id_in, int32_t rank, int32_t world) {
   g.side = nullptr;
   for (int i = 0; i < kSlots; ++i) { g.ready[i] = nullptr; g.done[i] = nullptr; g.pending[i] = false; }
   int err = hip_ok(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking), "hipStreamCreate");
+  if (err == PCG_OK) err = hip_ok(hipMalloc((void**)&g.token, 64), "hipMalloc(barrier token)");
+  if (err == PCG_OK) err = hip_ok(hipMemset(g.token, 0, 64), "hipMemset(barrier token)");
   for (int i = 0; i < kSlots && err == PCG_OK; ++i) {
     err = hip_ok(hipEventCreateWithFlags(&g.ready[i], hipEventDisableTiming), "hipEventCreate");
     if (err == PCG_OK) err = hip_ok(hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming), "hipEventCreate");
@@ -183,6 +190,19 @@ extern "C" int pcg_dp_broadcast(void* buf, int64_t nbytes, int32_t root, pcg_str
   return nccl_ok(g.bcast(buf, buf, (size_t)nbytes, /*ncclInt8*/ 0, root, g.comm, (hipStream_t)stream), "ncclBroadcast");
 }
 
+// A barrier of the ranks ON THE LIBRARY'S COMMUNICATOR: a 4-byte all-reduce in stream order (the caller synchronises the stream).
+// bench.py brackets its timed region with it, so the region runs on ONE communicator — the one that carries the exchange.
+extern "C" int pcg_dp_barrier(pcg_stream_t stream) {
+  DP_READY("pcg_dp_barrier");
+  return nccl_ok(g.allreduce(g.token, g.token, 1, kFloat, kSum, g.comm, (hipStream_t)stream), "ncclAllReduce(barrier)");
+}
+// ncclGetVersion of the RCCL this library bound (e.g. 22105 = 2.21.5), 0 if RCCL is not loaded or too old to say
+extern "C" int32_t pcg_dp_rccl_version(void) {
+  if (bind() != PCG_OK || !g.version) return 0;
+  int v = 0;
+  return g.version(&v) == 0 ? v : 0;
+}
+
 extern "C" int pcg_dp_sync_batchnorm(int32_t enable) {
   PCG_REQUIRE(!enable || g.comm != nullptr, "pcg_dp_sync_batchnorm: pcg_dp_init has not been called");
   g.sync_bn = enable != 0;
@@ -197,6 +217,8 @@ extern "C" int pcg_dp_shutdown(void) {
   g.comm = nullptr;
   for (int i = 0; i < kSlots; ++i) { (void)hipEventDestroy(g.ready[i]); (void)hipEventDestroy(g.done[i]); g.pending[i] = false; }
   (void)hipStreamDestroy(g.side);
+  if (g.token) (void)hipFree(g.token);
+  g.token = nullptr;
   g.side = nullptr; g.rank = -1; g.world = 0;
   return nccl_ok(rc, "ncclCommDestroy");
 }

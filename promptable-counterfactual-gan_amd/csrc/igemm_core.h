@@ -515,6 +515,9 @@ struct EpiAux {
   int64_t delta_bytes;      // (char*)aux - (char*)out
   int64_t delta2_bytes;     // EPI_ADDSUM: (char*)z_next - (char*)out
   const float* mean; const float* invstd; const float* gamma; const float* beta;   // EPI_BNBWD, per output column
+  int group_rows;           // > 0: grouped launch (r04) — G independent batches side by side along M, `group_rows` rows each (per sub-pixel
+                            // phase for a grad-input launch; a multiple of the tile height): mean / invstd are [G][N], the tile's group
+                            // picks the row (the caller passes the offset to igemm_store_tile)
 };
 
 // the tile's output store: plain write-back stores.  Measured r03 (whole DCGAN step, two rounds each): non-temporal stores 11.13 vs
@@ -524,7 +527,7 @@ __device__ __forceinline__ void epi_store4(float* p, float4 v) { *reinterpret_ca
 template <class Cfg, class RowBase>
 __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, int n_block, int N,
                                                  const float* bias, RowBase row_base, double* stat_row = nullptr, int act = PCG_ACT_NONE,
-                                                 float slope = 0.f, const EpiAux* epi = nullptr) {
+                                                 float slope = 0.f, const EpiAux* epi = nullptr, int stat_goff = 0) {
   constexpr int LDW = Cfg::WTN + 4;
   constexpr int Q = Cfg::WTN / 4;          // float4 per row of the wave tile
   constexpr int RPI = 64 / Q;              // rows per store instruction (Q = 24, the 64x192 tile: 2 rows, lanes 48..63 idle)
@@ -573,9 +576,9 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
     const float neg = epi->neg;
     const int64_t delta = epi->delta_bytes;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sc;
-    if (emode == EPI_BNBWD && nok) {
-      mu = *reinterpret_cast<const float4*>(epi->mean + n);
-      is = *reinterpret_cast<const float4*>(epi->invstd + n);
+    if (emode == EPI_BNBWD && nok) {     // stat_goff: this tile's group's row of the [G][N] statistics (0 for ordinary launches)
+      mu = *reinterpret_cast<const float4*>(epi->mean + stat_goff + n);
+      is = *reinterpret_cast<const float4*>(epi->invstd + stat_goff + n);
       const float4 ga = *reinterpret_cast<const float4*>(epi->gamma + n), be = *reinterpret_cast<const float4*>(epi->beta + n);
       bn_fold(ga.x, be.x, mu.x, is.x, sc.x, sh.x); bn_fold(ga.y, be.y, mu.y, is.y, sc.y, sh.y);
       bn_fold(ga.z, be.z, mu.z, is.z, sc.z, sh.z); bn_fold(ga.w, be.w, mu.w, is.w, sc.w, sh.w);

@@ -78,6 +78,35 @@ __global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ p, c
   if (threadIdx.x == 0 && loss) loss[0] = s * inv_n;
 }
 
+// Two BCE(mean) losses over the two halves of p in one launch — the discriminator's real and fake outputs side by side
+// (mnist_dcgan.py:152,160; errD = errD_real + errD_fake :163).  Each half is summed exactly as bce_kernel sums it (same strided
+// per-thread order, same block sum), so loss[0] / loss[1] carry the bits of two separate launches; loss[2] = loss[0] + loss[1] in
+// fp32.  Backward: g0, g1, g2 are the (nullable, one-element, device) cotangents of the three outputs; dp of half h =
+// (g_h + g2) / n * dBCE/dp, a missing cotangent counts as 0 (all three missing: 1).
+__global__ void __launch_bounds__(256) bce_pair_kernel(const float* __restrict__ p, int64_t n, float t0, float t1, const float* g0,
+                                                       const float* g1, const float* g2, float* loss, float* __restrict__ dp) {
+  __shared__ float red[4];
+  const float inv_n = 1.f / (float)n;
+  const bool any = g0 || g1 || g2;
+  float l[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float t = h ? t1 : t0;
+    const float* gh = h ? g1 : g0;
+    const float gs = any ? (gh ? gh[0] : 0.f) + (g2 ? g2[0] : 0.f) : 1.f;
+    const float* ph = p + (size_t)h * n;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      const float pi = ph[i];
+      const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+      acc += (t - 1.f) * lq - t * lp;
+      if (dp) dp[(size_t)h * n + i] = gs * inv_n * (pi - t) / fmaxf((1.f - pi) * pi, 1e-12f);
+    }
+    l[h] = block_sum_256(acc, red) * inv_n;
+  }
+  if (threadIdx.x == 0 && loss) { loss[0] = l[0]; loss[1] = l[1]; loss[2] = l[0] + l[1]; }
+}
+
 __global__ void __launch_bounds__(256) bce_logits_kernel(const float* __restrict__ z, float t, int64_t n, float grad_scale,
                                                          const float* grad_out, float* loss, float* __restrict__ dz) {
   __shared__ float red[4];
@@ -281,6 +310,13 @@ extern "C" int pcg_bce_fwd_bwd(const float* p, const float* target, float target
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, target, target_const, n, grad_scale, grad_out_dev,
                      loss, dp);
   return launch_status("bce_kernel");
+}
+
+extern "C" int pcg_bce_pair(const float* p, int64_t n_half, float target0, float target1, const float* g0_dev, const float* g1_dev,
+                            const float* g2_dev, float* loss3, float* dp, pcg_stream_t stream) {
+  PCG_REQUIRE(p && n_half > 0 && (loss3 || dp), "pcg_bce_pair: bad arguments");
+  hipLaunchKernelGGL(bce_pair_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n_half, target0, target1, g0_dev, g1_dev, g2_dev, loss3, dp);
+  return launch_status("bce_pair_kernel");
 }
 
 extern "C" int pcg_bce_logits_fwd_bwd(const float* z, float target_const, int64_t n, float grad_scale,

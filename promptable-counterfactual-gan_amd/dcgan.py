@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import nn as _nn
 from .nn import BCELoss, SequentialConvNet
 from .optim import Adam
 
@@ -81,6 +82,10 @@ class Discriminator(SequentialConvNet):
     def forward(self, input):
         return super().forward(input).view(-1, 1).squeeze(1)  # :116
 
+    def forward_groups(self, inputs):
+        """netD on several independent batches in one pass (nn.SequentialConvNet.forward_groups): [G*B] probabilities."""
+        return super().forward_groups(inputs).view(-1, 1).squeeze(1)
+
 
 def make_optimizers(netG, netD, cfg=None):
     """mnist_dcgan.py:125-127."""
@@ -110,7 +115,7 @@ class _Labels:
 _labels = _Labels()
 
 
-def train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, cfg=None, dp=None, skip_dead_d_wgrad=True):
+def train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, cfg=None, dp=None, skip_dead_d_wgrad=True, pair=True):
     """One iteration of the reference loop body (mnist_dcgan.py:147-175) for a batch `real` already on the GPU and a
     noise tensor `noise` ([B, z_dim, 1, 1]; the reference draws it at :156).
 
@@ -121,28 +126,49 @@ def train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, cfg=N
     `netD.zero_grad()` (:147) throws away at the next iteration.  With True they are not computed (D's parameters are
     marked requires_grad=False around that pass); parameters, losses and G gradients are unchanged.
     dp: optional `parallel.GradSync` — averages D's / G's flat gradient bucket across ranks before each Adam step.
+    pair: run the D step's two discriminator passes (:151 on `real`, :159 on `fake.detach()`) as ONE pass over 2B images
+    (`netD.forward_groups`, include/pcgan_hip.h "grouped batches") when the net and the batch allow it: the generator's forward
+    (:157, independent of D) moves in front, `errD_real.backward(); errD_fake.backward()` (:153,161 — two accumulations into
+    .grad) becomes the backward of errD = errD_real + errD_fake (:163), BatchNorm keeps per-pass statistics and two running-
+    statistics updates.  Same numbers except for the order of the sum inside D's weight gradients (tests/test_hip_groups.py).
+    pair=False is the statement-by-statement order.
     """
     c = _cfg(cfg)
     b_size = real.size(0)
     dev = real.device
+    pair = (pair and isinstance(criterion, BCELoss) and not (dp is not None and getattr(dp, "sync_bn", False))
+            and hasattr(netD, "supports_groups") and netD.supports_groups(real.shape, 2))
     # (1) Update D network
-    netD.zero_grad()                                              # :147
-    label = _labels.get(b_size, c["real_label"], dev)            # :150
-    out_real = netD(real)                                         # :151
-    errD_real = criterion(out_real, label)                        # :152
-    errD_real.backward()                                          # :153
-    if dp is not None:
-        dp.wait(netG)                                             # previous iteration's G all-reduce + Adam(G) done
-    fake = netG(noise)                                            # :157
-    label = _labels.get(b_size, c["fake_label"], dev)            # :158
-    out_fake = netD(fake.detach())                                # :159
-    errD_fake = criterion(out_fake, label)                        # :160
-    errD_fake.backward()                                          # :161
+    if pair:
+        netD.drop_grads()                                         # :147 — every D parameter gets a gradient below: the first writer overwrites
+        if dp is not None:
+            dp.wait(netG)                                         # previous iteration's G all-reduce + Adam(G) done
+        fake = netG(noise)                                        # :157
+        out_pair = netD.forward_groups([real, fake.detach()])    # :151 + :159
+        errD_real, errD_fake, errD = _nn.bce_pair(out_pair, c["real_label"], c["fake_label"])   # :152, :160, :163
+        _nn.backward(errD)                                        # :153 + :161
+        out_real, out_fake = out_pair[:b_size], out_pair[b_size:]
+    else:
+        netD.zero_grad()                                          # :147
+        label = _labels.get(b_size, c["real_label"], dev)        # :150
+        out_real = netD(real)                                     # :151
+        errD_real = criterion(out_real, label)                    # :152
+        _nn.backward(errD_real)                                   # :153
+        if dp is not None:
+            dp.wait(netG)                                         # previous iteration's G all-reduce + Adam(G) done
+        fake = netG(noise)                                        # :157
+        label = _labels.get(b_size, c["fake_label"], dev)        # :158
+        out_fake = netD(fake.detach())                            # :159
+        errD_fake = criterion(out_fake, label)                    # :160
+        _nn.backward(errD_fake)                                   # :161
     if dp is not None:
         dp.sync_now(netD)
     optimizerD.step()                                             # :164
     # (2) Update G network
-    netG.zero_grad()                                              # :169
+    if pair:
+        netG.drop_grads()                                         # :169 — every G parameter gets a gradient in this backward
+    else:
+        netG.zero_grad()                                          # :169
     label = _labels.get(b_size, c["real_label"], dev)            # :170
     if skip_dead_d_wgrad:
         for p in netD.parameters():
@@ -150,7 +176,7 @@ def train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, cfg=N
     try:
         out_g = netD(fake)                                        # :171
         errG = criterion(out_g, label)                            # :172
-        errG.backward()                                           # :173
+        _nn.backward(errG)                                        # :173
     finally:
         if skip_dead_d_wgrad:
             for p in netD.parameters():
@@ -210,7 +236,7 @@ def train(dataloader, cfg=None, netG=None, netD=None, device="cuda", log=print, 
             real = data[0].to(dev)                                            # :148
             noise = randn(real.size(0))                                       # :156
             out = train_step(netG, netD, criterion, optimizerD, optimizerG, real, noise, c, dp=dp)   # :147-175
-            pending.append((out["errD_real"], out["errD_fake"], out["errG"]))
+            pending.append((out["errD_real"].detach(), out["errD_fake"].detach(), out["errG"].detach()))   # no grad_fn kept: see countergan.train_countergan
             if i % 200 == 0:                                                  # :178-181
                 errD = float(np.float32(out["errD_real"].item()) + np.float32(out["errD_fake"].item()))   # :163
                 log(f"[{epoch}/{c['epochs']}][{i}/{nbatches}] Loss_D: {errD:.4f} Loss_G: {out['errG'].item():.4f} "

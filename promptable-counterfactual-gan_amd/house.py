@@ -1638,7 +1638,7 @@ def train_countergan_loop(generator, discriminator, classifier, loader, config, 
             x, y = x.to(device), y.to(device)
             target_y, mask, noise = draw_batch_randoms(rng, generator, y, config, device)
             out = train_step(generator, discriminator, classifier, opt_g, opt_d, x, y, target_y, mask, norm_vals, config, gumbel=noise)
-            pending.append((out["D_loss"], out["G_loss"]))
+            pending.append((out["D_loss"].detach(), out["G_loss"].detach()))   # no grad_fn kept alive over the epoch
             if batch_idx % log_every == 0:
                 print(f"[Epoch {epoch + 1}/{config['epochs']}] batch {batch_idx}: D_loss={out['D_loss'].item():.4f}, "
                       f"G_loss={out['G_loss'].item():.4f}, g_adv={out['g_adv'].item():.4f}, g_cls={out['g_cls'].item():.4f}, "

@@ -249,6 +249,25 @@ class _SeqFn(torch.autograd.Function):
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _SeqGroupFn(torch.autograd.Function):
+    """The stack on G independent batches side by side (SequentialConvNet.forward_groups): one node, parameter gradients only."""
+
+    @staticmethod
+    def forward(ctx, net, ngroups, *rest):
+        xs = rest[:ngroups]
+        y, saved = net._run_forward_groups(xs)
+        ctx.net, ctx.saved, ctx.ngroups = net, saved, ngroups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if any(ctx.needs_input_grad[2:2 + ctx.ngroups]):
+            raise PcgError("forward_groups: gradients w.r.t. the inputs are not implemented (detach them: the D step of mnist_dcgan.py:159)")
+        if any(ctx.needs_input_grad[2 + ctx.ngroups:]):
+            ctx.net._run_backward_groups(ctx.saved, dy)
+        return (None,) * len(ctx.needs_input_grad)
+
+
 class SequentialConvNet(FlatModule):
     """Runs `self.main` (an nn.Sequential of torch conv / BN / activation layers) on the HIP kernels.
 
@@ -375,6 +394,158 @@ class SequentialConvNet(FlatModule):
                 saved.append((g, a, z, mean, invstd, y, b.bn is not None and not b.bn.training, xf_in))
             a, H, W = (y if xf is None else z), OH, OW
         return a, saved
+
+    # -- G independent batches side by side (r04) ------------------------------------------------------------------------------
+    def supports_groups(self, shape, groups=2):
+        """Can `forward_groups` run `groups` inputs of NCHW shape `shape`?  (Conv2d / Linear stacks whose first block has no
+        BatchNorm; training-mode BatchNorm layers behind MFMA convolutions with whole 128-row tiles per group; see
+        include/pcgan_hip.h "grouped batches".)  Cached per (shape, groups, training)."""
+        self._ensure_flat()
+        if self._blocks is None:
+            self._blocks = _compile(self.main)
+        key = (tuple(shape), int(groups), self.training)
+        cache = self.__dict__.setdefault("_group_ok", {})
+        if key in cache:
+            return cache[key]
+        ok = self._group_check(tuple(shape), int(groups))
+        cache[key] = ok
+        return ok
+
+    def _group_check(self, shape, G):
+        if len(shape) != 4 or G < 2 or G > 8:
+            return False
+        B, C, H, W = shape
+        for idx, b in enumerate(self._blocks):
+            c = b.conv
+            if b.transposed or C != c.in_channels:
+                return False
+            g = ops.conv_geom(B if idx == 0 else G * B, H, W, c.in_channels, c.out_channels, b.kh, b.kw, b.stride, b.pad)
+            if idx == 0 and b.bn is not None:
+                return False
+            if b.bn is not None:
+                if not b.bn.training or b.act not in (ACT_NONE, ACT_RELU, ACT_LRELU) or not ops.group_fwd_ok(g, G):
+                    return False
+            C, H, W = c.out_channels, g.OH, g.OW
+        return True
+
+    def forward_groups(self, inputs):
+        """The stack applied to G independent batches in ONE pass: `inputs` = G tensors of the same [B, C, H, W] shape (the real
+        batch and fake.detach() of mnist_dcgan.py:151,159); returns the [G*B, ...] output, group after group.  Per layer one
+        convolution launch over G*B images; BatchNorm statistics, running-statistics updates and the backward's means stay per
+        group (see include/pcgan_hip.h).  Inputs get no gradient."""
+        inputs = list(inputs)
+        if not self.supports_groups(inputs[0].shape, len(inputs)):
+            raise PcgError(f"forward_groups: this stack / shape {tuple(inputs[0].shape)} x {len(inputs)} is not eligible (supports_groups)")
+        xs = []
+        for t in inputs:
+            if t.shape != inputs[0].shape or t.dtype != torch.float32:
+                raise PcgError("forward_groups: the inputs must be float32 tensors of one shape")
+            x = t.permute(0, 2, 3, 1)
+            xs.append(x if x.is_contiguous() else x.contiguous())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            y = _SeqGroupFn.apply(self, len(xs), *xs, *self.parameters())
+        else:
+            y, _ = self._run_forward_groups(xs, keep=False)
+        return y.permute(0, 3, 1, 2)
+
+    def _run_forward_groups(self, xs, keep=True):
+        G = len(xs)
+        B, H, W, C = xs[0].shape
+        saved = []
+        a = None
+        for idx, b in enumerate(self._blocks):
+            c = b.conv
+            w = _w_ohwi(c.weight.data)
+            bias = c.bias.data if c.bias is not None else None
+            mean = invstd = z = None
+            if idx == 0:
+                # the groups' inputs are separate tensors: the first layer runs once per group into its slice of ONE output
+                g = ops.conv_geom(B, H, W, c.in_channels, c.out_channels, b.kh, b.kw, b.stride, b.pad)
+                y = torch.empty((G * B, g.OH, g.OW, c.out_channels), dtype=torch.float32, device=xs[0].device)
+                for k, x in enumerate(xs):
+                    ops.conv2d_fwd(g, x, w, bias, out=y[k * B:(k + 1) * B], act=b.act, slope=b.slope)
+                a_in = tuple(xs)
+            else:
+                g = ops.conv_geom(G * B, H, W, c.in_channels, c.out_channels, b.kh, b.kw, b.stride, b.pad)
+                a_in = a
+                if b.bn is not None and b.bn.training:
+                    bn = b.bn
+                    z, mean, invstd = ops.conv_bn_train_g(g, a, w, bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                          bn.num_batches_tracked, G)
+                    y = ops.bn_apply_act_g(z, c.out_channels, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, G)
+                elif b.bn is not None:
+                    bn = b.bn
+                    z = ops.conv2d_fwd(g, a, w, bias)
+                    y = ops.bn_apply_act(z, c.out_channels, bn.running_mean, bn.running_var, bn.weight.data, bn.bias.data, b.act, b.slope,
+                                         var_eps=bn.eps, out=z)
+                    z = None
+                else:
+                    y = ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope)
+            if keep:
+                saved.append((g, a_in, z, mean, invstd, y, b.bn is not None and not b.bn.training))
+            a, H, W = y, g.OH, g.OW
+        return a, (saved, G, B)
+
+    def _run_backward_groups(self, saved_all, dy):
+        saved, G, B = saved_all
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        d, own = dy, False
+        fused = None           # ("bn", partial, nparts, nphases) | ("mask",) | None — see _run_backward_impl
+        for idx in range(len(self._blocks) - 1, -1, -1):
+            b = self._blocks[idx]
+            g, a, z, mean, invstd, y, bn_eval = saved[idx]
+            c = b.conv
+            C = c.out_channels
+            if b.bn is not None:
+                if bn_eval:
+                    raise PcgError("backward through an eval-mode BatchNorm2d is not implemented")
+                bn = b.bn
+                dg = db = None
+                acc = False
+                if bn.weight.requires_grad:
+                    dg, acc = self._grad_view(bn.weight)
+                    db, _ = self._grad_view(bn.bias)
+                if fused is not None:
+                    dz = ops.bn_bwd_partial_g(d, z, C, mean, invstd, bn.weight.data, fused[1], fused[2], fused[3], dg, db, acc, G, out=d)
+                else:
+                    dz = ops.bn_act_bwd_g(d, z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, dg, db, acc, G,
+                                          out=d if own else None)
+            elif fused is not None or b.act == ACT_NONE:
+                dz = d
+            else:
+                dz = ops.act_bwd(d, y, b.act, b.slope, out=d if own else None)
+            own = True
+            if c.weight.requires_grad:
+                gw, acc = self._grad_view(c.weight)
+                gw = _w_ohwi(gw)
+                if idx == 0:
+                    for k, x in enumerate(a):       # per group: the inputs are separate tensors (.grad accumulation of :153,161)
+                        ops.conv2d_wgrad(g, x, dz[k * B:(k + 1) * B], gw, acc or k > 0)
+                else:
+                    ops.conv2d_wgrad(g, a, dz, gw, acc)      # ONE sum over the pixels of all groups
+                if c.bias is not None and c.bias.requires_grad:
+                    gb, accb = self._grad_view(c.bias)
+                    ops.colsum(dz.numel() // C, C, dz, gb, accb)
+            if idx == 0:
+                return None
+            lo = self._blocks[idx - 1]
+            _, _, zl, ml, il, yl, lo_eval = saved[idx - 1]
+            w = _w_ohwi(c.weight.data)
+            fused = None
+            mfma = g.Cin > 3 and g.Cout > 3 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and g.stride <= 2
+            if self.fuse_backward_epilogue and mfma and lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU):
+                if lo.bn is not None and not lo_eval and zl is not None and ops.group_dgrad_ok(g, G):
+                    d, partial, nparts, nphases = ops.conv_bwd_data_fused_g(g, dz, w, lo.act, lo.slope, zl,
+                                                                            (ml, il, lo.bn.weight.data, lo.bn.bias.data), G)
+                    fused = ("bn", partial, nparts, nphases)
+                    continue
+                if lo.bn is None and lo.act != ACT_NONE:
+                    res = ops.conv_bwd_data_fused(g, dz, w, False, lo.act, lo.slope, a_below=yl)
+                    if res is not None:
+                        d, fused = res[0], ("mask",)
+                        continue
+            d = ops.conv2d_dgrad(g, dz, w)
 
     wgrad_stream = None      # opt-in A/B: a second HIP stream for the weight gradients (they and the grad-input of a layer both need only dz)
 
@@ -677,6 +848,10 @@ class GraphedStep:
 
     def __init__(self, step_fn, inputs, modules, optimizers, warmup=3, dp=None, capture=None):
         self.inputs = dict(inputs)
+        # the captured launches carry raw pointers into the modules' flat buffers, the optimizers' state and whatever the step
+        # closes over: keep all of it alive as long as the graph can be replayed (a caller that drops its own references — a
+        # builder function returning only the GraphedStep — must not leave the graph writing into freed memory)
+        self._keepalive = (step_fn, list(modules), list(optimizers), dp)
         if dp is not None and getattr(dp, "sync_bn", False):
             raise PcgError("exact-BatchNorm mode (GradSync(sync_bn=True)) issues RCCL collectives inside the BatchNorm calls, which "
                            "cannot be captured in a HIP graph: run the step eagerly")
@@ -748,3 +923,47 @@ class _BCEFn(torch.autograd.Function):
         p, target = ctx.saved_tensors
         _, dp = ops.bce_fwd_bwd(p, target, 0.0, need_loss=False, grad_out=grad_out.contiguous().view(1))
         return dp, None
+
+
+class _BCEPairFn(torch.autograd.Function):
+    """(BCE(p[:n], t0), BCE(p[n:], t1), their sum) in one launch forward and one backward (ops.bce_pair)."""
+
+    @staticmethod
+    def forward(ctx, p, t0, t1):
+        p = p.contiguous()
+        n = p.numel() // 2
+        loss, _ = ops.bce_pair(p, n, t0, t1, need_loss=True)
+        ctx.save_for_backward(p)
+        ctx.t = (float(t0), float(t1), n)
+        ctx.set_materialize_grads(False)
+        return loss[0], loss[1], loss[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        (p,) = ctx.saved_tensors
+        t0, t1, n = ctx.t
+        cot = tuple(None if g is None else g.contiguous().view(1) for g in (g0, g1, g2))
+        _, dp = ops.bce_pair(p, n, t0, t1, need_loss=False, need_grad=True, cotangents=cot)
+        return dp, None, None
+
+
+def bce_pair(p, target0, target1):
+    """nn.BCELoss()(p[:n], full(target0)), nn.BCELoss()(p[n:], full(target1)) and their sum (errD_real, errD_fake, errD of
+    mnist_dcgan.py:152,160,163) for the output of a two-group discriminator pass."""
+    if p.numel() % 2:
+        raise PcgError("bce_pair: expected an even number of outputs (two groups)")
+    return _BCEPairFn.apply(p, float(target0), float(target1))
+
+
+_ones = {}
+
+
+def backward(loss):
+    """loss.backward() with the seed gradient taken from a cached one-element tensor: autograd's own `ones_like(loss)` is an ATen
+    fill launch per call (three per DCGAN step)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ones.get(key)
+    if one is None:
+        one = ops.fill(torch.empty(loss.shape, dtype=loss.dtype, device=loss.device), 1.0) if loss.numel() else torch.ones_like(loss)
+        _ones[key] = one
+    torch.autograd.backward(loss, grad_tensors=one)

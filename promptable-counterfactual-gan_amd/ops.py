@@ -67,35 +67,63 @@ class _Timed:
 
 
 _sk_streams = {}      # (device index, stream handle) -> (parts, arrivals): scratch of the stream-K conv launches, alive for the process
-_sk_arrival_pool = {}
+_sk_pool = {}         # device index -> [(parts, arrivals), ...] spare scratch sets, allocated and zeroed OUTSIDE any capture
+_sk_arrival_pool = _sk_pool      # (name kept for the tests)
+_SK_SPARES = 2
+_sk_last = None       # the stream key seen by the previous conv call (eager launches: skips the dictionary work)
 
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _conv_scratch():
-    """First conv call on a stream: give the hybrid stream-K launches their scratch for it (include/pcgan_hip.h,
-    pcg_conv_set_scratch; 64 MiB of partial tiles + the arrival counters).  The counters must be zero and stay out of a capture's
-    fill nodes: they come from a pool zeroed outside any capture, like the linear weight-gradient tickets.  A stream the library has
-    no slot left for (it keeps 64) simply runs the plain launches — same results up to the order of the K sum."""
-    s = torch.cuda.current_stream()
-    key = (s.device_index, s.cuda_stream)
-    if key in _sk_streams:
+def prepare_conv_scratch(device_index=None):
+    """Keep `_SK_SPARES` spare stream-K scratch sets (64 MiB of partial tiles + zeroed arrival counters each) for the device:
+    the library holds these pointers for the life of the process, so they must never come out of a graph's private pool, and
+    the counters' zero-fill must never become a captured fill node.  Called when the library loads (current device) and by every
+    conv call outside a capture; a conv call INSIDE a capture on a stream that has no scratch yet is served from the spares."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
         return
     lib = _lib.load()
-    dev = torch.device("cuda", s.device_index)
+    dev = torch.device("cuda", device_index)
     nparts, narr = lib.pcg_conv_scratch_parts_bytes(), lib.pcg_conv_scratch_arrivals_bytes()
-    pool = _sk_arrival_pool.setdefault(s.device_index, [])
-    if not pool and not torch.cuda.is_current_stream_capturing():
-        pool.extend(torch.zeros((8, narr), dtype=torch.uint8, device=dev).unbind(0))
-    arrivals = pool.pop() if pool else torch.zeros(narr, dtype=torch.uint8, device=dev)
-    parts = torch.empty(nparts, dtype=torch.uint8, device=dev)
-    if lib.pcg_conv_set_scratch(ctypes.c_void_p(s.cuda_stream), _p(parts), nparts, _p(arrivals), narr) == 0:
-        _sk_streams[key] = (parts, arrivals)
-    else:
-        pool.append(arrivals)
-        _sk_streams[key] = None
+    pool = _sk_pool.setdefault(device_index, [])
+    while len(pool) < _SK_SPARES:
+        pool.append((torch.empty(nparts, dtype=torch.uint8, device=dev), torch.zeros(narr, dtype=torch.uint8, device=dev)))
+
+
+def _conv_scratch():
+    """First conv call on a stream: give the hybrid stream-K launches their scratch for it (include/pcgan_hip.h,
+    pcg_conv_set_scratch).  The scratch comes from the spares of prepare_conv_scratch — never from an allocation made while a stream
+    captures (r03 allocated the counters inside the capture when the pool was empty: memory of the graph's private pool handed to
+    the library for the life of the process).  An empty pool under capture raises.  A stream the library has no slot left for (it
+    keeps 64) simply runs the plain launches — same results up to the order of the K sum."""
+    global _sk_last
+    s = torch.cuda.current_stream()
+    key = (s.device_index, s.cuda_stream)
+    if key == _sk_last:
+        return
+    if key not in _sk_streams:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            prepare_conv_scratch(s.device_index)
+        pool = _sk_pool.setdefault(s.device_index, [])
+        if not pool:
+            raise _lib.PcgError("conv call on a new stream inside a HIP-graph capture with no spare stream-K scratch left: call "
+                                "pcgan_amd.ops.prepare_conv_scratch() on this device before capturing (the scratch must not come "
+                                "from the graph's private memory pool)")
+        parts, arrivals = pool.pop()
+        lib = _lib.load()
+        if lib.pcg_conv_set_scratch(ctypes.c_void_p(s.cuda_stream), _p(parts), parts.numel(), _p(arrivals), arrivals.numel()) == 0:
+            _sk_streams[key] = (parts, arrivals)
+        else:
+            pool.append((parts, arrivals))
+            _sk_streams[key] = None
+        if not capturing:
+            prepare_conv_scratch(s.device_index)      # refill: the next capture stream finds a spare
+    _sk_last = key
 
 
 def _p(t):
@@ -493,6 +521,110 @@ def bce_logits_fwd_bwd(z, target_const, grad_scale=1.0, need_loss=True, need_gra
     check(_lib.load().pcg_bce_logits_fwd_bwd(_p(z), float(target_const), z.numel(), grad_scale, _p(grad_out), _p(loss), _p(dz),
                                              _stream()), "pcg_bce_logits_fwd_bwd")
     return loss, dz
+
+
+def bce_pair(p, n_half, target0, target1, need_loss=True, need_grad=False, cotangents=(None, None, None)):
+    """Two nn.BCELoss(mean) over p[:n_half] / p[n_half:] in one launch (pcg_bce_pair).  Returns (loss3 or None, dp or None);
+    loss3 = [BCE(first half, target0), BCE(second half, target1), their sum].  cotangents: one-element device tensors or None."""
+    _chk(p, "p")
+    assert p.numel() == 2 * n_half
+    loss = torch.empty(3, dtype=torch.float32, device=p.device) if need_loss else None
+    dp = torch.empty_like(p) if need_grad else None
+    g0, g1, g2 = cotangents
+    check(_lib.load().pcg_bce_pair(_p(p), int(n_half), float(target0), float(target1), _p(g0), _p(g1), _p(g2), _p(loss), _p(dp), _stream()),
+          "pcg_bce_pair")
+    return loss, dp
+
+
+# ---- grouped batches: G independent batches side by side along the batch axis (include/pcgan_hip.h, "grouped batches") -------------
+def _fast_channels(C):
+    q = C // 4
+    return C % 4 == 0 and 0 < q <= 256 and (q & (q - 1)) == 0
+
+
+def group_fwd_ok(g, groups):
+    """Can conv_bn_train_g run geometry g (B = all groups' images) with `groups` groups?"""
+    lib = _lib.load()
+    return (g.B % groups == 0 and ((g.B // groups) * g.OH * g.OW) % 128 == 0 and _fast_channels(g.Cout)
+            and lib.pcg_conv2d_fwd_bn_workspace_bytes(ctypes.byref(g)) > 0)
+
+
+def group_dgrad_ok(g, groups):
+    """Can conv_bwd_data_fused_g run the grad-input of geometry g on `groups` groups (equal phases, whole tiles per group)?"""
+    if g.B % groups or g.Cin <= 3 or g.Cout <= 3 or g.Cin % 4 or g.Cout % 4 or g.stride > 2 or not _fast_channels(g.Cin):
+        return False
+    if _lib.load().pcg_conv2d_dgrad_bn_workspace_bytes(ctypes.byref(g)) == 0:
+        return False
+    s = g.stride
+    if g.IH % s or g.IW % s:
+        return False
+    return ((g.B // groups) * (g.IH // s) * (g.IW // s)) % 128 == 0
+
+
+def conv_bn_train_g(g, a, w, bias, eps, momentum, running_mean, running_var, num_batches_tracked, groups):
+    """Conv2d forward over `groups` side-by-side batches + per-group training-mode BatchNorm statistics (pcg_conv2d_fwd_bn_g).
+    Returns (z, save_mean [groups, C], save_invstd [groups, C])."""
+    _chk(a, "a"); _chk(w, "w")
+    lib = _lib.load()
+    C = g.Cout
+    need = lib.pcg_conv2d_fwd_bn_workspace_bytes(ctypes.byref(g))
+    z = torch.empty((g.B, g.OH, g.OW, C), dtype=torch.float32, device=a.device)
+    mean = torch.empty((groups, C), dtype=torch.float32, device=a.device)
+    invstd = torch.empty((groups, C), dtype=torch.float32, device=a.device)
+    ws = workspace(need, a.device)
+    with _Timed(g, "fwd"):
+        check(lib.pcg_conv2d_fwd_bn_g(ctypes.byref(g), _p(a), _p(w), _p(bias), _p(z), eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                                      _p(running_var), _p(num_batches_tracked), int(groups), _p(ws), ws.numel(), _stream()), "pcg_conv2d_fwd_bn_g")
+    return z, mean, invstd
+
+
+def bn_apply_act_g(x, C, mean, invstd, gamma, beta, act, slope, groups, out=None):
+    _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.load().pcg_bn_apply_act_g(_p(x), x.numel() // C, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act), float(slope), _p(y),
+                                         int(groups), _stream()), "pcg_bn_apply_act_g")
+    return y
+
+
+def conv_bwd_data_fused_g(g, d, w, below_act, below_slope, z_below, bn, groups):
+    """Grouped pcg_conv2d_dgrad_bnbwd: returns (dm, partial, nparts, nphases) for bn_bwd_partial_g."""
+    lib = _lib.load()
+    _chk(d, "d"); _chk(w, "w"); _chk(z_below, "z_below")
+    out = torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=d.device)
+    assert z_below.numel() == out.numel()
+    mean, invstd, gamma, beta = bn
+    need = lib.pcg_conv2d_dgrad_bn_workspace_bytes(ctypes.byref(g))
+    nparts = lib.pcg_conv2d_dgrad_bn_partial_rows(ctypes.byref(g))
+    nphases = lib.pcg_conv2d_dgrad_bn_phases(ctypes.byref(g))
+    partial = torch.empty(need // 4, dtype=torch.float32, device=d.device)
+    with _Timed(g, "dgrad"):
+        check(lib.pcg_conv2d_dgrad_bnbwd_g(ctypes.byref(g), _p(d), _p(w), _p(z_below), _p(mean), _p(invstd), _p(gamma), _p(beta), int(below_act),
+                                           float(below_slope), _p(out), _p(partial), need, int(groups), _stream()), "pcg_conv2d_dgrad_bnbwd_g")
+    return out, partial, nparts, nphases
+
+
+def bn_bwd_partial_g(dm, x, C, mean, invstd, gamma, partial, nparts, nphases, dgamma, dbeta, accumulate, groups, out=None):
+    _chk(dm, "dm"); _chk(x, "x")
+    dx = out if out is not None else torch.empty_like(x)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_bn_bwd_partial_g_workspace_bytes(C, int(groups)), x.device)
+    check(lib.pcg_bn_bwd_partial_g(_p(dm), _p(x), x.numel() // C, C, _p(mean), _p(invstd), _p(gamma), _p(partial), int(nparts), int(nphases),
+                                   _p(dx), _p(dgamma), _p(dbeta), int(bool(accumulate)), int(groups), _p(ws), ws.numel(), _stream()),
+          "pcg_bn_bwd_partial_g")
+    return dx
+
+
+def bn_act_bwd_g(dy, x, C, mean, invstd, gamma, beta, act, slope, dgamma, dbeta, accumulate, groups, out=None):
+    """BatchNorm(train) + ReLU / LeakyReLU backward of `groups` side-by-side batches (mask recomputed from x)."""
+    _chk(dy, "dy"); _chk(x, "x")
+    dx = out if out is not None else torch.empty_like(x)
+    lib = _lib.load()
+    rows = x.numel() // C
+    ws = workspace(lib.pcg_bn_act_bwd_g_workspace_bytes(rows, C, int(groups)), x.device)
+    check(lib.pcg_bn_act_bwd_premask_g(_p(dy), _p(x), rows, C, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act), float(slope), _p(dx),
+                                       _p(dgamma), _p(dbeta), int(bool(accumulate)), int(groups), _p(ws), ws.numel(), _stream()),
+          "pcg_bn_act_bwd_premask_g")
+    return dx
 
 
 # ---- optimizer / helpers ------------------------------------------------------------------------------
@@ -1221,7 +1353,7 @@ def tune(name, value):
 
 
 # ---- calibration (bench lines; not on the step's path) -------------------------------------------------------------------
-def calibrate(device, mfma_ms=20.0, copy_mb=512, rounds=2):
+def calibrate(device, mfma_ms=20.0, copy_mb=512, rounds=2, warm_ms=30.0):
     """What this box's fp32 matrix pipe and HBM sustain NOW: {"mfma_tflops", "mfma_clock_mhz", "hbm_gbs", ...}.
 
     A bare v_mfma_f32_32x32x2_f32 loop on every CU for ~mfma_ms (pcg_calib_mfma; the in-kernel shader clock comes from its
@@ -1250,6 +1382,8 @@ def calibrate(device, mfma_ms=20.0, copy_mb=512, rounds=2):
     run(probe_iters)                                   # code object load, clocks up
     ms = run(probe_iters)
     iters = max(probe_iters, int(probe_iters * mfma_ms / max(ms, 1e-3)))
+    if warm_ms > 0:                                    # untimed: the reading that follows is not a cold-clock one (r03: "before" read
+        run(int(iters * warm_ms / mfma_ms))            # 2273 MHz against 2365 after the timed steps)
     ms = run(iters)
     st = ws[8192 + blocks * 1024:].view(torch.int64).view(blocks, 2).cpu().double()
     mhz = (st[:, 0] / st[:, 1].clamp_min(1.0) * 100.0)

@@ -83,6 +83,27 @@ class GradSync:
         """Ranks the communicator that carries the gradient exchange spans."""
         return int(self._lib.pcg_dp_world()) if self.native else self.world
 
+    def rccl_version(self):
+        """ncclGetVersion of the RCCL carrying the exchange (e.g. 22105), or None."""
+        if self.native:
+            v = int(self._lib.pcg_dp_rccl_version())
+            return v or None
+        try:
+            v = torch.cuda.nccl.version()
+            return int(v[0]) * 10000 + int(v[1]) * 100 + int(v[2]) if isinstance(v, tuple) else int(v)
+        except Exception:
+            return None
+
+    def barrier(self):
+        """All ranks have reached this point and their queued GPU work is done.  On the GPU with the library's communicator: a
+        4-byte all-reduce on THAT communicator (pcg_dp_barrier) + a stream synchronise — the timed region of the benches then uses
+        one communicator only; otherwise torch.distributed.barrier()."""
+        if self.native and torch.cuda.is_available():
+            check(self._lib.pcg_dp_barrier(_cur_stream()), "pcg_dp_barrier")
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.barrier(group=self.group)
+
     def _slot(self, net):
         s = self._slots.get(id(net))
         if s is None:

@@ -35,7 +35,8 @@ class Ranks:
     def __init__(self, args, script):
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             _contract.launch_ranks(args.gpus, sys.argv[1:], script=script)      # does not return
-        _contract.claim_stdout()
+        if _capture is None:
+            _contract.claim_stdout()
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -65,7 +66,7 @@ class Ranks:
 
     def barrier(self):
         if self.dp is not None:
-            torch.distributed.barrier()
+            self.dp.barrier()
 
     def timed(self, fn, steps):
         """barrier + sync, `steps` calls of fn(i), drain, barrier; returns (seconds: MAX over ranks, last result)."""
@@ -110,7 +111,7 @@ def pmc_traffic(name):
     (FETCH_SIZE doubled + WRITE_SIZE, separate passes: profiles/r0N_pmc_traffic_<name>.json), or (None, None)."""
     import json
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         try:
             fn = f"{tag}_pmc_traffic_{name}.json"
             with open(os.path.join(root, fn)) as f:
@@ -155,8 +156,21 @@ def cpu_median(step_fn, steps=3, warmup=1, threads=None):
     return sorted(ts)[len(ts) // 2], torch.get_num_threads(), avail
 
 
+_capture = None      # a list: emit() appends the line there instead of printing it (bench.py's `secondary` block runs the benches in-process)
+
+
+def capture(on=True):
+    """Start (returns the list the lines go to) or stop capturing emit()."""
+    global _capture
+    _capture = [] if on else None
+    return _capture
+
+
 def emit(line):
-    _contract.emit_json(line)
+    if _capture is not None:
+        _capture.append(line)
+    else:
+        _contract.emit_json(line)
 
 
 cpu_model = _contract.cpu_model

@@ -19,11 +19,11 @@ import torch  # noqa: E402
 ALGO_GFLOP_PER_IMAGE = 2.476
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
     BL.add_common_args(ap, steps=10, warmup=3)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     R = BL.Ranks(args, os.path.abspath(__file__))
     from pcgan_amd import countergan as K, ops
     dev, dp = R.dev, R.dp

@@ -61,7 +61,7 @@ def through_trainer(args, R, H, ops, dev):
     R.finish()
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-overlap", action="store_true", help="A/B: the reference-order autograd step as a single-stream graph")
@@ -73,7 +73,7 @@ def main():
                          "epoch summaries, D_grad variant): marginal seconds per iteration between a short and a long run (setup cancels)")
     ap.add_argument("--eager-draws", action="store_true", help="A/B: the per-step draws as an eager launch in front of each replay (host-side Philox offsets)")
     BL.add_common_args(ap, steps=200, warmup=20)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.gpus != 1:
         sys.exit("bench_house.py: the tabular step does not shard (BASELINE config 5 is single-GPU); run one process per replica")
     R = BL.Ranks(args, os.path.abspath(__file__))
@@ -126,7 +126,7 @@ def main():
                   + 28 * (nG + nD)                        # Adam: p, g read; m, v read+write; p write
                   + B * per_row_saved)
     launches = None
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         try:
             with open(os.path.join(BL.ROOT, "profiles", f"{tag}_house_launches.json")) as f:
                 launches = json.load(f)["launches_per_step"]

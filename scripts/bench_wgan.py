@@ -20,12 +20,12 @@ import _benchlib as BL  # noqa: E402
 import torch  # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--width", type=int, default=1024)
     BL.add_common_args(ap, steps=20, warmup=3)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     R = BL.Ranks(args, os.path.abspath(__file__))
     from pcgan_amd import wgan as W, ops
     dev, dp = R.dev, R.dp

@@ -137,8 +137,12 @@ def test_golden_reference_forward_and_step(pcg, golden_dir):
             np.testing.assert_allclose(got[3:], ref[3:], rtol=1e-4, atol=1.2e-4, err_msg=f"final {tag}.{k}")  # Adam: <= 2*lr
 
 
-@pytest.mark.parametrize("batch", [16])
+@pytest.mark.parametrize("batch", [16, 1024])
 def test_step_vs_oracle_float64(pcg, batch):
+    """One train_step (trainer.py:96-123) against the float64 and float32 oracle: every loss, every G and D gradient.  batch 1024 is
+    BASELINE config 4's per-GPU shard (r04: the whole step at the bench size against the oracle, ~25 s of CPU work — the CPU
+    baseline of scripts/bench_countergan.py shows one fp32 step takes ~7 s there): the three-per-CU 128x64 kernels, the 64x192
+    weight gradient, the skip-add epilogues and the fused column sums composed end to end."""
     K = pcg.countergan
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     (G, D, C), (refG, refD, refC) = _build(pcg, seed=3)
@@ -148,7 +152,9 @@ def test_step_vs_oracle_float64(pcg, batch):
     ref = CR.countergan_step(refG, refD, refC, *o32, x, y, t, m)
     tru = CR.countergan_step(*r64, *o64, x.double(), y, t, m.double())
     opt_g, opt_d, bce, ce = K.make_optimizers(G, D)
-    out = K.train_step(G, D, C, opt_g, opt_d, bce, ce, x.to(DEV), y.to(DEV), t.to(DEV), m.to(DEV))
+    # skip_dead_d_wgrad=False: D's .grad then holds what the oracle's autograd leaves there (D step + the G step's critic weight
+    # gradients, trainer.py:111-122)
+    out = K.train_step(G, D, C, opt_g, opt_d, bce, ce, x.to(DEV), y.to(DEV), t.to(DEV), m.to(DEV), skip_dead_d_wgrad=False)
     for name in ("d_loss", "g_adv", "g_cls", "reg_l1", "mask_pen", "g_loss"):
         tol = max(2e-5 * abs(tru[name]) + 1e-6, 3 * abs(ref[name] - tru[name]))
         assert abs(out[name].item() - tru[name]) <= tol, f"{name}: {out[name].item()} vs {tru[name]} (tol {tol:.1e})"
@@ -157,6 +163,11 @@ def test_step_vs_oracle_float64(pcg, batch):
         den = max(np.linalg.norm(t64), 1e-30)
         l2, l2r = np.linalg.norm(got - t64) / den, np.linalg.norm(r32 - t64) / den
         assert l2 <= max(1e-4, 3 * l2r), f"G grad {n}: rel-L2 {l2:.2e} (reference fp32 noise {l2r:.2e})"
+    for (n, p), (_, q), (_, w) in zip(D.named_parameters(), refD.named_parameters(), r64[1].named_parameters()):
+        got, t64, r32 = (a.detach().cpu().double().numpy() for a in (p.grad, w.grad, q.grad))
+        den = max(np.linalg.norm(t64), 1e-30)
+        l2, l2r = np.linalg.norm(got - t64) / den, np.linalg.norm(r32 - t64) / den
+        assert l2 <= max(1e-4, 3 * l2r), f"D grad {n}: rel-L2 {l2:.2e} (reference fp32 noise {l2r:.2e})"
 
 
 def test_device_batch_synthesis(pcg):

@@ -1,6 +1,9 @@
-"""GPU, BASELINE.json sizes of the secondary configurations: there is no oracle run at these sizes (the CPU path needs minutes), so
-the checks are size-independent properties — two runs from identical state and inputs are bit-identical (fixed summation orders:
-what data-parallel replicas and checkpoint/resume rely on), every loss is finite, parameters move."""
+"""GPU, BASELINE.json sizes of the secondary configurations: size-independent properties — two runs from identical state and inputs
+are bit-identical (fixed summation orders: what data-parallel replicas and checkpoint/resume rely on), every loss is finite,
+parameters move.  The ORACLE comparisons at these sizes live next to the small-size ones (r04; they cost seconds, not minutes):
+test_hip_countergan.py::test_step_vs_oracle_float64[1024], test_hip_house.py::test_step_vs_oracle_float64[4096],
+test_hip_wgan.py::test_critic_and_generator_steps_vs_oracle_float64[1024-32-True] (full width; the batch-256 iteration below is
+the bench shape), test_hip_groups.py::test_paired_d_step_equals_two_passes[None-512-True] and test_hip_benchshape.py."""
 import numpy as np
 import pytest
 import torch

@@ -217,7 +217,8 @@ def test_exact_batchnorm_mode_one_rank_equals_per_replica(pcg):
             dp = parallel.GradSync(always_exchange=True, sync_bn=sync)
             netG, netD, crit, optD, optG = _fresh(D, cfg)
             for _ in range(2):
-                o = D.train_step(netG, netD, crit, optD, optG, real, noise, cfg, dp=dp, skip_dead_d_wgrad=False)
+                # pair=False: the exact mode has no grouped form (the step falls back to two passes), so the comparison runs both that way
+                o = D.train_step(netG, netD, crit, optD, optG, real, noise, cfg, dp=dp, skip_dead_d_wgrad=False, pair=False)
             dp.wait_all()
             res[sync] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params.clone(), netD.flat_params.clone(),
                          [b.clone() for b in netD.buffers()] + [b.clone() for b in netG.buffers()])

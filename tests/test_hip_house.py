@@ -316,10 +316,11 @@ def test_golden_reference_train_loop_batch(pcg, hgold):
             assert float(d.max()) <= 2.2 * H.CONFIG["lr_D"] and int((d > 2e-5).sum()) <= max(2, 0.03 * d.numel()), (k, float(d.max()), int((d > 2e-5).sum()))
 
 
-@pytest.mark.parametrize("batch", [256])
+@pytest.mark.parametrize("batch", [256, 4096])
 def test_step_vs_oracle_float64(pcg, hgold, batch):
     """Synthetic batch: every loss, every G gradient and every D gradient of one step against the
-    float64 oracle; tolerance = max(1e-4 relative to the tensor's max, 3x the float32 oracle's own distance from float64)."""
+    float64 oracle; tolerance = max(1e-4 relative to the tensor's max, 3x the float32 oracle's own distance from float64).
+    batch 4096 = BASELINE config 5 (r04: the whole step at the bench size against the oracle; ~0.1 s of CPU work)."""
     H = pcg.house
     G, D, C = _load_golden_nets(pcg, hgold)
     x, y, t, m, gumbel = HR.synthetic_batch(batch, seed=9, dtype=torch.float64)

@@ -206,13 +206,16 @@ def test_golden_reference_loop_iterations(pcg, golden_dir, batched):
             assert bad.sum() <= max(2, 0.01 * d.size) and d.max() <= 2.2 * 1e-4 * steps, (f"final.{tag}.{k_}", int(bad.sum()), float(d.max()))
 
 
-@pytest.mark.parametrize("batched", [False, True])
-@pytest.mark.parametrize("width,batch", [(64, 8)])
+@pytest.mark.parametrize("width,batch,batched", [(64, 8, False), (64, 8, True), (1024, 32, True)])
 def test_critic_and_generator_steps_vs_oracle_float64(pcg, width, batch, batched):
     """Wider nets (every channel count a multiple of 16, MFMA kernels engaged), one critic step + one generator step: losses,
     image gradients and every parameter gradient against the float64 oracle; tolerance = max(1e-4 of the tensor's scale,
-    3x the float32 oracle's own distance from float64, 2e-6 of the net's largest gradient)."""
+    3x the float32 oracle's own distance from float64, 2e-6 of the net's largest gradient).
+    (1024, 32) is the reference's FULL width (mnist_wgan_conditional.py:20-31) — r04: the composition of the stream-K launches, the
+    unequal-phase grad-input, the register-resident InstanceNorm at C = 1024 and the backward of the backward, checked end to end
+    against the oracle (losses, every gradient incl. rel-L2, the weights after AdamW); ~2 s of CPU work per precision."""
     W = pcg.wgan
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     kw = dict(critic_size=width, generator_size=width, critic_hidden_size=width, batchsize=batch)
     hp, ohp, critic, generator, oc, og = _build_pair(pcg, kw)
     x, y, z, alpha, y2, z2 = WR.synthetic_batch(ohp, batch, seed=4, dtype=torch.float64)
@@ -226,13 +229,14 @@ def test_critic_and_generator_steps_vs_oracle_float64(pcg, width, batch, batched
         cg = {n: p.grad.double().clone() for n, p in c.named_parameters()}
         o2 = WR.generator_step(c, g, g_opt, y2.to(dt), z2.to(dt))
         gg = {n: p.grad.double().clone() for n, p in g.named_parameters()}
-        res[dt] = (o1, o2, cg, gg)
+        res[dt] = (o1, o2, cg, gg, {k_: v.detach().clone() for k_, v in c.state_dict().items()},
+                   {k_: v.detach().clone() for k_, v in g.state_dict().items()})
     c_opt, g_opt = W.make_optimizers(critic, generator)
     out = W.critic_step(critic, generator, c_opt, hp, _dev(x.float()), _dev(y.float()), _dev(z.float()), _dev(alpha.float()), batched=batched)
     mine_cg = {n: p.grad.detach().cpu().double().clone() for n, p in critic.named_parameters()}
     out2 = W.generator_step(critic, generator, g_opt, _dev(y2.float()), _dev(z2.float()))
     mine_gg = {n: p.grad.detach().cpu().double().clone() for n, p in generator.named_parameters()}
-    (o1_64, o2_64, cg64, gg64), (o1_32, o2_32, cg32, gg32) = res[torch.float64], res[torch.float32]
+    (o1_64, o2_64, cg64, gg64), (o1_32, o2_32, cg32, gg32) = res[torch.float64][:4], res[torch.float32][:4]
     for k in ("critic_loss", "loss_real", "loss_fake", "gradient_penalty"):
         tol = max(2e-5 + 2e-5 * abs(o1_64[k]), 3 * abs(o1_32[k] - o1_64[k]))
         assert abs(out[k].item() - o1_64[k]) <= tol, (k, out[k].item(), o1_64[k], tol)
@@ -246,10 +250,35 @@ def test_critic_and_generator_steps_vs_oracle_float64(pcg, width, batch, batched
         assert err <= tol, (label, err, tol, scale)
     check(out["gradients"].detach().cpu().double(), o1_64["gradients"], o1_32["gradients"].double(), "image gradients", 0.0)
     cs, gs = max(float(v.abs().max()) for v in cg64.values()), max(float(v.abs().max()) for v in gg64.values())
+
+    def check_l2(mine, truth, noise32, label, net_scale):     # rel-L2 of the whole tensor (a tile in the wrong place shows here)
+        den = float(truth.norm())
+        if den < 1e-3 * net_scale * truth.numel() ** 0.5:   # zero-gradient parameters (biases in front of a normalisation): noise
+            return
+        l2, l2r = float((mine - truth).norm()) / den, float((noise32 - truth).norm()) / den
+        assert l2 <= max(1e-4, 3 * l2r), (label, l2, l2r)
     for n in cg64:
         check(mine_cg[n], cg64[n], cg32[n], f"critic grad {n}", cs)
+        check_l2(mine_cg[n], cg64[n], cg32[n], f"critic grad {n} (rel-L2)", cs)
     for n in gg64:
         check(mine_gg[n], gg64[n], gg32[n], f"generator grad {n}", gs)
+        check_l2(mine_gg[n], gg64[n], gg32[n], f"generator grad {n} (rel-L2)", gs)
+    # the weights after the AdamW steps (:118-119: lr 1e-4, beta1 = 0 — every entry moves by ~lr * sign(g)): against the fp32
+    # oracle's weights; an entry whose gradient is at noise level may take the other sign, bounded by the possible move
+    lr = 1e-4
+    for net, onet, tag, g64_, sc_ in ((critic, res[torch.float32][4], "critic", cg64, cs), (generator, res[torch.float32][5], "generator", gg64, gs)):
+        for k_, v in net.state_dict().items():
+            ref = onet[k_]
+            if k_ in g64_ and float(g64_[k_].abs().max()) < 1e-5 * sc_:     # zero-gradient bias: the noise's sign decides a +-lr move
+                assert float((v.detach().cpu().double() - ref.double()).abs().max()) <= 2.2 * lr, (tag, k_)
+                continue
+            if not ref.dtype.is_floating_point:
+                assert int(v) == int(ref), k_
+                continue
+            d = (v.detach().cpu().double() - ref.double()).abs()
+            tol = 2e-6 + 2e-5 * ref.double().abs()
+            nbad = int((d > tol).sum())
+            assert float(d.max()) <= 2.2 * lr + 1e-4 * float(ref.abs().max()) and nbad <= max(4, 0.02 * d.numel()), (tag, k_, float(d.max()), nbad, d.numel())
 
 
 def test_reference_style_penalty_expression_is_a_drop_in(pcg):
