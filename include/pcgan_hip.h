@@ -288,6 +288,18 @@ int pcg_bn_act_bwd_premask_g(const float* dy, const float* x, int64_t rows, int3
                              const float* gamma, const float* beta, int act, float slope, float* dx, float* dgamma, float* dbeta,
                              int accumulate, int32_t groups, void* workspace, size_t workspace_bytes, pcg_stream_t stream);
 
+/* Thin forward fused with the BatchNorm backward of the layer below (r04).  A ConvTranspose2d with ONE output channel (DCGAN's G5,
+ * mnist_dcgan.py:88) hands its grad-input — a forward convolution of the image gradient with Cin = 1 — to BatchNorm2d + ReLU
+ * (:86-87).  The chain wrote that gradient (134 MB at batch 512), reduced it against z, and read both again; it costs 16 FMAs per
+ * element to recompute, so here it never reaches memory: pass 1 leaves the two column sums, the usual finalize follows, pass 2
+ * writes dz.  dgamma / dbeta as in pcg_bn_act_bwd.  Only k4, Cin = 1 geometries the row-block form covers (..._ok).               */
+int32_t pcg_conv2d_fwd_bnbwd_thin_ok(const pcg_conv_geom* g);
+size_t pcg_conv2d_fwd_bnbwd_thin_workspace_bytes(const pcg_conv_geom* g);
+int pcg_conv2d_fwd_bnbwd_thin(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dz,
+                              float* dgamma /*nullable*/, float* dbeta /*nullable*/, int accumulate, void* workspace,
+                              size_t workspace_bytes, pcg_stream_t stream);
+
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */
 int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream);

@@ -346,6 +346,19 @@ const double* launch_presum(const double* partial, int nparts, int cols, int* nc
   return out;
 }
 
+// grouped launches: the same level-1 sums, taken only when a chunk never straddles a group's (or phase's) segment of `*seg` rows;
+// on success *partial points at the chunk sums and *per_phase / *seg count chunks
+struct GroupPre { int rpc; };
+GroupPre launch_presum_g(const double** partial, int nparts, int cols, int* per_phase, int* seg, hipStream_t s) {
+  const PrePlan q = plan_presum(nparts);
+  if (q.nchunks == 0 || (*seg) % q.rpc != 0 || nparts % q.rpc != 0) return GroupPre{0};
+  int nchunks = 0;
+  const double* pre = launch_presum(*partial, nparts, cols, &nchunks, s);
+  if (!pre) return GroupPre{0};
+  *partial = pre; *per_phase /= q.rpc; *seg /= q.rpc;
+  return GroupPre{q.rpc};
+}
+
 // exact-BatchNorm mode: reduce `src` (partial rows or chunk sums) to this rank's sums, all-reduce them, and hand back what the
 // finalize kernel should read instead: one row of global sums.  scratch: 4*C doubles ([2][C] local | [2][C] global).
 int sync_exchange(const double* src, int nrows, int C, double* scratch, hipStream_t s) {
@@ -566,6 +579,14 @@ size_t bn_partial_buffer_bytes(int nparts, int C) {
   // partial[nparts][2][C] doubles (+ the chunk sums of the two-level finalize when there are many rows)
   const PrePlan q = plan_presum(nparts);
   return (presum_offset(nparts, 2 * C) + (size_t)q.nchunks * 2 * C + 4 * (size_t)C) * sizeof(double);   // + exact-BatchNorm scratch
+}
+// partial[nblocks][2][C] (fp64 column sums of dm and dm*xhat) -> coef[3][C], dgamma / dbeta (thin_conv.hip's fused BatchNorm backward)
+int launch_bn_bwd_finalize(const double* partial, int nblocks, int64_t rows, int C, const float* gamma, const float* invstd, float* coef,
+                           float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+  PCG_REQUIRE(!dp_sync_bn(), "fused thin BatchNorm backward: not available in the exact global-batch mode");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(nblocks)), 0, s, partial, nblocks, C,
+                     1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate, (const double*)nullptr);
+  return launch_status("bn_bwd_finalize_kernel");
 }
 int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
@@ -852,7 +873,13 @@ int launch_bn_stats_finalize_g(const double* partial, int nparts, int nphases, i
                                int64_t* nbt, hipStream_t s) {
   PCG_REQUIRE(!dp_sync_bn(), "grouped BatchNorm: not available in the exact global-batch mode (pcg_dp_sync_batchnorm)");
   PCG_REQUIRE(groups >= 1 && nphases >= 1 && nparts % (nphases * groups) == 0, "grouped BatchNorm: %d partial rows do not split into %d phases x %d groups", nparts, nphases, groups);
-  const int per_phase = nparts / nphases, seg = per_phase / groups, rpg = seg * nphases;
+  int per_phase = nparts / nphases, seg = per_phase / groups;
+  // many partial rows (the two passes of D2 at batch 512 leave 4096): the one-block-per-8-channels finalize walks them in a
+  // latency-bound loop, once per group (33 us measured r04).  Level 1 of the two-level finalize first (partial_presum_kernel: every
+  // CU adds `rpc` consecutive rows) whenever its chunks respect the group / phase boundaries; the grouped finalize then reads chunks.
+  const GroupPre gp = launch_presum_g(&partial, nparts, 2 * C, &per_phase, &seg, s);
+  (void)gp;
+  const int rpg = seg * nphases;
   const double unbias = rows_per_group > 1 ? (double)rows_per_group / (double)(rows_per_group - 1) : 1.0;
   hipLaunchKernelGGL(bn_stats_finalize_g_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(rpg)), 0, s, partial, rpg, groups,
                      seg, per_phase, C, 1.0 / (double)rows_per_group, unbias, eps, momentum, save_mean, save_invstd, running_mean, running_var, nbt);
@@ -916,7 +943,8 @@ extern "C" int pcg_bn_bwd_partial_g(const float* dm, const float* x, int64_t row
     set_error("pcg_bn_bwd_partial_g: workspace %zu B < required %zu B", workspace_bytes, pcg_bn_bwd_partial_g_workspace_bytes(C, groups));
     return PCG_ERR_WORKSPACE;
   }
-  const int per_phase = nparts / nphases, seg = per_phase / groups;
+  int per_phase = nparts / nphases, seg = per_phase / groups;
+  (void)launch_presum_g(&partial, nparts, 2 * C, &per_phase, &seg, (hipStream_t)stream);   // the buffer of pcg_conv2d_*_bn_workspace_bytes has the tail
   return launch_bwd_finalize_apply_g(dm, x, rows, C, mean, invstd, gamma, nullptr, PCG_ACT_NONE, 0.f, partial, seg * nphases, seg, per_phase, dx,
                                      dgamma, dbeta, accumulate, groups, (float*)workspace, (hipStream_t)stream);
 }

@@ -722,14 +722,16 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int edge_prio = -1, korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int edge_prio = -1, dgrad_swz3 = -1, korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
   ConvP p{};
   static const int korder_env = getenv("PCG_KORDER") ? atoi(getenv("PCG_KORDER")) : 1;
   p.korder = g_tune.korder >= 0 ? g_tune.korder : korder_env;
-  static const int edge_env = getenv("PCG_EDGE_PRIO") ? atoi(getenv("PCG_EDGE_PRIO")) : 0;
+  // default 2: the epilogue at priority 3, the entry left alone (measured r04, CounteRGAN step, one process, interleaved:
+  // 0: 27.15 ms, 2: 26.49, 3: 27.62 — raising the entry as well lets every new workgroup's set-up cut into the running loops)
+  static const int edge_env = getenv("PCG_EDGE_PRIO") ? atoi(getenv("PCG_EDGE_PRIO")) : 2;
   p.edge_prio = g_tune.edge_prio >= 0 ? g_tune.edge_prio : edge_env;
   p.stamps = g_tune.stamps; p.stamp_slots = g_tune.stamp_slots;
   p.B = g->B; p.IH = g->IH; p.IW = g->IW; p.Cin = g->Cin; p.OH = g->OH; p.OW = g->OW; p.Cout = g->Cout;
@@ -1375,7 +1377,8 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   PCG_REQUIRE(nph > 0, "pcg_conv2d_dgrad: empty problem");
   hipStream_t st = (hipStream_t)stream;
   if (int e = p.N > 64 ? launch_dgrad<Cfg128x128>(p, ph, nph, maxMp, st)
-                       : nph > 1 ? launch_dgrad<Cfg128x64P>(p, ph, nph, maxMp, st) : launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st)) return e;
+                       : (nph > 1 && g_tune.dgrad_swz3 == 0) ? launch_dgrad<Cfg128x64P>(p, ph, nph, maxMp, st)   // (r04: with the epilogue at priority 3 the three-per-CU config also wins on the four-phase k4 s2 grad-input: D2 0.2957 -> 0.2893 ms)
+                                                             : launch_dgrad<Cfg128x64>(p, ph, nph, maxMp, st)) return e;
   return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, stream);
 }
 
@@ -1573,6 +1576,25 @@ extern "C" int pcg_conv2d_dgrad_bnbwd_g(const pcg_conv_geom* g, const float* dy,
   e.group_rows = groups > 1 ? maxMp / groups : 0;
   return conv2d_dgrad_impl(g, dy, w, nullptr, dx, (double*)partial, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
 }
+// Thin forward (Cin = 1, k4) whose output is a gradient w.r.t. the activated output of  z -> BatchNorm(train) -> ReLU / LeakyReLU:
+// returns dz directly and adds dgamma / dbeta — the output tensor itself, the reduction pass over it and the re-read in the apply pass
+// disappear (thin_rows_expand_bn_kernel; DCGAN: G5's grad-input + G4's BatchNorm backward, mnist_dcgan.py:85-88 backward).
+extern "C" int32_t pcg_conv2d_fwd_bnbwd_thin_ok(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK && thin_conv_fwd_bnbwd_ok(g) && g->Cout % 4 == 0 ? 1 : 0; }
+extern "C" size_t pcg_conv2d_fwd_bnbwd_thin_workspace_bytes(const pcg_conv_geom* g) {
+  return pcg_conv2d_fwd_bnbwd_thin_ok(g) ? thin_conv_fwd_bnbwd_workspace_bytes(g) : 0;
+}
+extern "C" int pcg_conv2d_fwd_bnbwd_thin(const pcg_conv_geom* g, const float* x, const float* w, const float* z_below, const float* mean,
+                                         const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dz,
+                                         float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                                         pcg_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(x && w && z_below && mean && invstd && gamma && beta && dz, "pcg_conv2d_fwd_bnbwd_thin: null pointer");
+  PCG_REQUIRE(act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU, "pcg_conv2d_fwd_bnbwd_thin: activation %d is not none / ReLU / LeakyReLU", act);
+  PCG_REQUIRE(pcg_conv2d_fwd_bnbwd_thin_ok(g), "pcg_conv2d_fwd_bnbwd_thin: geometry not eligible (pcg_conv2d_fwd_bnbwd_thin_ok)");
+  PCG_REQUIRE((((uintptr_t)z_below | (uintptr_t)dz) & 15) == 0, "pcg_conv2d_fwd_bnbwd_thin: tensors must be 16-byte aligned");
+  return thin_conv_fwd_bnbwd(g, x, w, z_below, mean, invstd, gamma, beta, act, slope, dz, dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 
@@ -1740,6 +1762,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   PCG_REQUIRE(name != nullptr, "pcg_tune_set: null name");
   if (!strcmp(name, "korder")) g_tune.korder = value;
   else if (!strcmp(name, "edge_prio")) g_tune.edge_prio = value;
+  else if (!strcmp(name, "dgrad_swz3")) g_tune.dgrad_swz3 = value;      // A/B: multi-phase N <= 64 grad-inputs on the three-per-CU tile configuration
   else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
   else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
@@ -1751,7 +1774,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "t64")) g_tune.t64 = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
   else {
-    set_error("pcg_tune_set: unknown switch '%s' (korder, edge_prio, wgrad_order, dgrad_interleave, persistent, persist_tiles, fwd_splits, "
+    set_error("pcg_tune_set: unknown switch '%s' (korder, edge_prio, dgrad_swz3, wgrad_order, dgrad_interleave, persistent, persist_tiles, fwd_splits, "
               "stream_k, sk_blocks, dgrad_gemm, t64, dma)", name);
     return PCG_ERR_INVALID;
   }

@@ -18,6 +18,13 @@ size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g);
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
                     size_t ws_bytes, hipStream_t s);
 
+// Cin-thin forward fused with the BatchNorm + ReLU / LeakyReLU backward of the layer whose activated output it is a gradient of (r04)
+bool thin_conv_fwd_bnbwd_ok(const pcg_conv_geom* g);
+size_t thin_conv_fwd_bnbwd_workspace_bytes(const pcg_conv_geom* g);
+int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int act, float slope, float* dz, float* dgamma, float* dbeta, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t s);
+
 // shared with conv_igemm.hip: dw[i] = (acc ? dw[i] : 0) + sum_z slab[z*stride + i]
 int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s);
 

@@ -482,6 +482,49 @@ int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const 
   return launch_reduce(p, ws, ws_bytes, s);
 }
 
+// batchnorm.hip: partial[nblocks][2][C] (fp64) -> coef[3][C], dgamma / dbeta
+int launch_bn_bwd_finalize(const double* partial, int nblocks, int64_t rows, int C, const float* gamma, const float* invstd, float* coef,
+                           float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+
+// y-side gradient of a Cin-thin convolution (= the grad-input of a ConvTranspose2d with a thin output, DCGAN's G5) fused with the
+// BatchNorm + ReLU / LeakyReLU backward of the layer below: see thin_rows_expand_bn_kernel.  workspace: thin_fwd_bnbwd_bytes.
+constexpr unsigned THIN_BN_BLOCKS = 2048;
+size_t thin_conv_fwd_bnbwd_workspace_bytes(const pcg_conv_geom* g) {
+  return (size_t)THIN_BN_BLOCKS * 2 * g->Cout * sizeof(double) + (size_t)3 * g->Cout * sizeof(float);
+}
+bool thin_conv_fwd_bnbwd_ok(const pcg_conv_geom* g) {
+  if (!thin_is_cin(g) || g->Cin != 1 || !(g->KH == 4 && g->KW == 4)) return false;
+  ThinP p{};
+  if (fill_common(p, g, true, true) != PCG_OK) return false;
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  return rows_plan(p, rp, &patch_bytes) && lds_weight_bytes(p) <= 64 * 1024;
+}
+int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, const float* z, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int act, float slope, float* dz, float* dgamma, float* dbeta, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t s) {
+  PCG_REQUIRE(thin_conv_fwd_bnbwd_ok(g), "thin conv + BatchNorm backward: only the k4 one-channel row-block form");
+  PCG_REQUIRE(ws && ws_bytes >= thin_conv_fwd_bnbwd_workspace_bytes(g), "thin conv + BatchNorm backward: workspace too small");
+  ThinP p{};
+  if (int e = fill_common(p, g, true, true)) return e;
+  p.w = w; p.bias = nullptr; p.out = dz; p.thin = x; p.act = PCG_ACT_NONE; p.slope = 0.f;
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  rows_plan(p, rp, &patch_bytes);
+  const size_t smem = lds_weight_bytes(p), sm = smem > patch_bytes ? smem : patch_bytes;
+  const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
+  const unsigned blocks = (unsigned)(rp.nunits < (int)THIN_BN_BLOCKS ? rp.nunits : (int)THIN_BN_BLOCKS);
+  double* partial = (double*)ws;
+  float* coef = reinterpret_cast<float*>(partial + (size_t)THIN_BN_BLOCKS * 2 * p.C);
+  ThinBnBwd bn{z, mean, invstd, gamma, beta, coef, act_neg_of(act, slope), partial};
+  hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, false>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
+  if (int e = launch_status("thin_rows_expand_bn_kernel(sums)")) return e;
+  if (int e = launch_bn_bwd_finalize(partial, (int)blocks, (int64_t)g->B * g->OH * g->OW, p.C, gamma, invstd, coef, dgamma, dbeta, accumulate, s)) return e;
+  const unsigned ablocks = (unsigned)(rp.nunits < 4096 ? rp.nunits : 4096);
+  hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, true>), dim3(ablocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
+  return launch_status("thin_rows_expand_bn_kernel(apply)");
+}
+
 int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
                     size_t ws_bytes, hipStream_t s, int act, float slope) {
   ThinP p{};

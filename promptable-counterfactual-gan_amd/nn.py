@@ -585,7 +585,9 @@ class SequentialConvNet(FlatModule):
                     db, acc2 = self._grad_view(bn.bias)
                     if acc != acc2:
                         raise PcgError("inconsistent .grad state on BatchNorm weight/bias")
-                if fused is not None:
+                if fused is not None and fused[0] == "done":
+                    dz = d               # the thin layer above pushed its gradient through this BatchNorm already (thin_fwd_bn_bwd)
+                elif fused is not None:
                     dz = ops.bn_bwd_partial(d, z, C, mean, invstd, bn.weight.data, fused[1], fused[2], dg, db, acc, out=d)
                 else:
                     # ReLU / LeakyReLU: the mask is recomputed from z (no read of y)
@@ -636,6 +638,19 @@ class SequentialConvNet(FlatModule):
             if not b.transposed:
                 d = ops.conv2d_dgrad(g, dz, _w_ohwi(c.weight.data))
             else:
+                lo = self._blocks[idx - 1] if not last else None
+                if (lo is not None and self.fuse_backward_epilogue and lo.bn is not None and lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+                        and not saved[idx - 1][6] and saved[idx - 1][2] is not None and lo.bn.weight.requires_grad and need_p
+                        and ops.thin_fwd_bn_bwd_ok(g)):
+                    # a one-channel ConvTranspose2d above a BatchNorm layer (G5 above G4): its grad-input goes through that
+                    # BatchNorm's backward without being written
+                    _, _, zl, ml, il, _, _, _ = saved[idx - 1]
+                    dgl, accl = self._grad_view(lo.bn.weight)
+                    dbl, _ = self._grad_view(lo.bn.bias)
+                    d = ops.thin_fwd_bn_bwd(g, dz, _w_ohwi(c.weight.data), zl, ml, il, lo.bn.weight.data, lo.bn.bias.data, lo.act, lo.slope,
+                                            dgl, dbl, accl)
+                    fused = ("done",)
+                    continue
                 d = ops.conv2d_fwd(g, dz, _w_ohwi(c.weight.data))
         return d
 

@@ -627,6 +627,24 @@ def bn_act_bwd_g(dy, x, C, mean, invstd, gamma, beta, act, slope, dgamma, dbeta,
     return dx
 
 
+def thin_fwd_bn_bwd_ok(g):
+    return bool(_lib.load().pcg_conv2d_fwd_bnbwd_thin_ok(ctypes.byref(g)))
+
+
+def thin_fwd_bn_bwd(g, x, w, z_below, mean, invstd, gamma, beta, act, slope, dgamma, dbeta, accumulate):
+    """conv2d_fwd(g, x, w) with Cin = 1 taken as the gradient w.r.t. act(bn(z_below)) and pushed through that BatchNorm + activation
+    backward without being written (pcg_conv2d_fwd_bnbwd_thin).  Returns dz [B, OH, OW, Cout]."""
+    _chk(x, "x"); _chk(w, "w"); _chk(z_below, "z_below")
+    assert z_below.numel() == g.B * g.OH * g.OW * g.Cout
+    dz = torch.empty_like(z_below)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_conv2d_fwd_bnbwd_thin_workspace_bytes(ctypes.byref(g)), x.device)
+    check(lib.pcg_conv2d_fwd_bnbwd_thin(ctypes.byref(g), _p(x), _p(w), _p(z_below), _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+                                        float(slope), _p(dz), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
+          "pcg_conv2d_fwd_bnbwd_thin")
+    return dz
+
+
 # ---- optimizer / helpers ------------------------------------------------------------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, decoupled, step):
     for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):

@@ -30,7 +30,7 @@ def build_dcgan(dev, batch, variant):
     real = (torch.rand(batch, 1, 64, 64, generator=g) * 2 - 1).to(dev)
     noise = torch.randn(batch, 100, 1, 1, generator=g).to(dev)
     kw = dict(variant.get("kwargs", {}))
-    return GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, real, noise, **kw), {"real": real, "noise": noise}, [netG, netD], [optD, optG])
+    return GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, real, noise, **kw), {"real": real, "noise": noise}, [netG, netD], [optD, optG])   # (keeps the nets alive: nn.GraphedStep._keepalive)
 
 
 def build_countergan(dev, batch, variant):

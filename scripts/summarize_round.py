@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -56,11 +56,26 @@ def stats_md(sub, dest, title, steps):
     return path, tot, calls
 
 
-r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-calib (DCGAN 64x64, batch 512)", 16)
+r = stats_md("dcgan", f"{tag}_kernel_stats.md", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-calib --no-secondary (DCGAN 64x64, batch 512)", 16)
 if r:
     shutil.copy(r[0], os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
 stats_md("countergan", f"{tag}_countergan_kernel_stats.md", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 (batch 1024)", 10)
 stats_md("wgan", f"{tag}_wgan_kernel_stats.md", "python3 scripts/bench_wgan.py --steps 10 --warmup 2 (14 critic updates + 14 generator updates executed: 2 capture warm-ups, 2 warm-ups, 10 timed of each kind; a \"step\" in the table is the average update)", 28)
+
+# DCGAN / CounteRGAN: the dispatches of ONE steady-state step, in order (scripts/step_census.py: between the step-ending Adam launches) —
+# unlike the --stats table divided by the step count this leaves out set-up dispatches
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from step_census import census  # noqa: E402
+for sub, dest, how in (("dcgan", f"{tag}_dcgan_launches.json", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-calib --no-secondary"),
+                       ("countergan", f"{tag}_countergan_launches.json", "python3 scripts/bench_countergan.py --steps 5 --warmup 2 --no-cpu-baseline")):
+    tr = find(sub, "*kernel_trace.csv")
+    if tr:
+        try:
+            c = census(tr, "adam_kernel", 2, 1)
+            c["how"] = f"dispatches after the previous step's second adam_kernel launch up to and including this step's, last complete step of rocprofv3 --kernel-trace -- {how}"
+            json.dump(c, open(os.path.join(out, dest), "w"), indent=1)
+        except SystemExit as e:
+            print("census", sub, e)
 
 # house: launches per step = dispatches between two consecutive house_draws_kernel launches in the steady state
 trace = find("house", "*kernel_trace.csv")

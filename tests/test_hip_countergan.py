@@ -167,7 +167,12 @@ def test_step_vs_oracle_float64(pcg, batch):
         got, t64, r32 = (a.detach().cpu().double().numpy() for a in (p.grad, w.grad, q.grad))
         den = max(np.linalg.norm(t64), 1e-30)
         l2, l2r = np.linalg.norm(got - t64) / den, np.linalg.norm(r32 - t64) / den
-        assert l2 <= max(1e-4, 3 * l2r), f"D grad {n}: rel-L2 {l2:.2e} (reference fp32 noise {l2r:.2e})"
+        # D's LeakyReLU(0.2) kinks: at batch 1024 some of the 6.4 M pre-activations per layer lie within rounding of zero, and two fp32
+        # convolutions that sum in different orders disagree about one's sign — that element's gradient changes by 80 %, which is
+        # ~0.8 / sqrt(pixels) / sqrt(channels) ~ 1-3e-4 of the layer's weight gradient (DESIGN.md §3.2 "the ReLU-kink noise floor";
+        # measured r04: 1.2e-4 on main.4.weight with the oracle's own fp32 run at 8e-7, i.e. no flip there).  Floor: two flips.
+        flip_floor = 5e-4 if batch >= 256 else 0.0
+        assert l2 <= max(1e-4, 3 * l2r, flip_floor), f"D grad {n}: rel-L2 {l2:.2e} (reference fp32 noise {l2r:.2e})"
 
 
 def test_device_batch_synthesis(pcg):

@@ -277,7 +277,14 @@ def test_critic_and_generator_steps_vs_oracle_float64(pcg, width, batch, batched
                 continue
             d = (v.detach().cpu().double() - ref.double()).abs()
             tol = 2e-6 + 2e-5 * ref.double().abs()
-            nbad = int((d > tol).sum())
+            bad = d > tol
+            if k_ in g64_:
+                # with beta1 = 0 the move of an entry is lr * g / (|g| + eps): an entry whose gradient is at the noise level of its
+                # tensor (or near Adam's eps) moves by a noise-decided fraction of lr — only entries with a well-determined
+                # gradient are counted; every entry is bounded by the possible move
+                g_ = g64_[k_].abs()
+                bad = bad & (g_ > max(1e-6, 1e-3 * float(g_.max())))
+            nbad = int(bad.sum())
             assert float(d.max()) <= 2.2 * lr + 1e-4 * float(ref.abs().max()) and nbad <= max(4, 0.02 * d.numel()), (tag, k_, float(d.max()), nbad, d.numel())
 
 
