@@ -178,6 +178,9 @@ int pcg_conv2d_fwd_add_bnsum(const pcg_conv_geom* g, const float* x, const float
                              const float* mean, const float* invstd, float sum_scale, float* y, void* partial, size_t partial_bytes,
                              pcg_stream_t stream);
 int pcg_conv_weight_adjoint(const float* w, float* w_adj, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, pcg_stream_t stream);
+/* The same for n <= 16 layers of one shape in ONE launch (host arrays of device pointers). */
+int pcg_conv_weight_adjoint_many(const float* const* w, float* const* w_adj, int32_t n, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin,
+                                 pcg_stream_t stream);
 int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g);
 int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g);
 /* db[c] (+)= sum_rows dy[row][c]   (bias gradient of Conv2d / Linear; rows = B*OH*OW)             */

@@ -136,6 +136,7 @@ PROTOTYPES = {
     "pcg_conv2d_fwd_add": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_fwd_add_bnsum": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv_weight_adjoint": (_i, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pcg_conv_weight_adjoint_many": (_i, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pcg_house_losses": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp]),
     "pcg_dp_unique_id": (_i, [_vp]),
     "pcg_dp_init": (_i, [_vp, _i32, _i32]),

@@ -305,6 +305,19 @@ class ResidualGenerator(FlatModule):
         ops.act_bwd(d, hm, ACT_LRELU, slope, out=d)
         dh = _conv_bwd(self, self.conv_mid, g_mid, h_last, d, True, True)
         order = list(zip(reversed(self.resblocks), reversed(blocks)))
+        # adjoint weights of every stride-1 conv whose grad-input runs on the forward kernel: ONE launch for all of them (r04; was one
+        # 6 us launch in front of each of the 12 grad-inputs)
+        adjw = {}
+        if FUSE_BACKWARD_EPILOGUE and S1_DGRAD_AS_FWD:
+            convs = [c for blk, sv in order for c, g_ in ((blk.conv2, sv[6]), (blk.conv1, sv[0])) if g_.stride == 1 and ops.xform_ok(g_, "x")]
+            shapes = {tuple(c.weight.shape) for c in convs}
+            if convs and len(shapes) == 1 and len(convs) <= 16:
+                for c, wa in zip(convs, ops.conv_weight_adjoint_many([ops.ohwi(c.weight.data) for c in convs])):
+                    adjw[id(c)] = wa
+
+        def adjoint_of(conv):
+            wa = adjw.get(id(conv))
+            return wa if wa is not None else ops.conv_weight_adjoint(ops.ohwi(conv.weight.data))
         pending = None      # (partial, nparts): bn2's backward sums of the gradient `dh`, left by the previous block's skip-add epilogue
         for bi, (blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2)) in enumerate(order):
             C = blk.bn2.num_features
@@ -325,7 +338,7 @@ class ResidualGenerator(FlatModule):
             # stride-1 layers: the grad-input runs on the FORWARD kernel with the adjoint weight (both operands K-major)
             adj = FUSE_BACKWARD_EPILOGUE and S1_DGRAD_AS_FWD and g2.stride == 1 and ops.xform_ok(g2, "x")
             if adj:
-                res = ops.conv_bwd_data_fused(ops.adjoint_geom(g2), dz2, ops.conv_weight_adjoint(ops.ohwi(blk.conv2.weight.data)), True,
+                res = ops.conv_bwd_data_fused(ops.adjoint_geom(g2), dz2, adjoint_of(blk.conv2), True,
                                               ACT_LRELU, slope, z_below=z1, bn=(m1, s1, blk.bn1.weight.data, blk.bn1.bias.data))
             else:
                 res = (ops.conv_bwd_data_fused(g2, dz2, ops.ohwi(blk.conv2.weight.data), False, ACT_LRELU, slope, z_below=z1,
@@ -342,7 +355,7 @@ class ResidualGenerator(FlatModule):
             if FUSE_BACKWARD_EPILOGUE:   # skip path + block path: the add happens in conv1's grad-input epilogue, in place
                 nxt = order[bi + 1][1] if (bi + 1 < len(order) and FUSE_SKIP_BNSUM) else None
                 adj1 = S1_DGRAD_AS_FWD and g1.stride == 1 and ops.xform_ok(g1, "x")
-                ga, wa = ((ops.adjoint_geom(g1), ops.conv_weight_adjoint(ops.ohwi(blk.conv1.weight.data))) if adj1
+                ga, wa = ((ops.adjoint_geom(g1), adjoint_of(blk.conv1)) if adj1
                           else (g1, ops.ohwi(blk.conv1.weight.data)))
                 if nxt is not None:      # ... together with the BatchNorm-backward sums the NEXT block's bn2 needs from this sum
                     dh, part, nparts = ops.conv2d_dgrad_add(ga, dz1, wa, dh, out=dh, bnsum=(nxt[7], nxt[8], nxt[9], 0.1), transposed=adj1)

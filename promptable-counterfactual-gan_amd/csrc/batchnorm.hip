@@ -681,7 +681,9 @@ extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const f
   return launch_status("bn_apply_act_kernel");
 }
 
-constexpr int COL_MAX_BLOCKS = 4096;   // grid cap of the fast apply kernels = partial rows of their fused column sums
+constexpr int COL_MAX_BLOCKS = 4096;   // grid cap of the fast apply kernels
+constexpr int COL_SUM_BLOCKS = 1024;   // ... when the pass also leaves column sums (one fp64 partial row per block): the finalize behind it
+                                       // walks the rows in a latency-bound loop (12 us at 4096 rows, r04 census of the CounteRGAN step)
 static size_t colpart_bytes(int32_t C) { return (size_t)COL_MAX_BLOCKS * C * sizeof(double); }
 
 static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* mean,
@@ -723,7 +725,7 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
   const bool fused_col = dcol != nullptr;
   if (fast_channels(C) && aligned) {
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
-    if (blocks > COL_MAX_BLOCKS) blocks = COL_MAX_BLOCKS;
+    if (blocks > (fused_col ? COL_SUM_BLOCKS : COL_MAX_BLOCKS)) blocks = fused_col ? COL_SUM_BLOCKS : COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
@@ -809,7 +811,7 @@ static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, in
   double* colpart = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)3 * C * sizeof(float) + 7) & ~(size_t)7));
   if (fast_channels(C) && aligned) {
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
-    if (blocks > COL_MAX_BLOCKS) blocks = COL_MAX_BLOCKS;
+    if (blocks > (dcol ? COL_SUM_BLOCKS : COL_MAX_BLOCKS)) blocks = dcol ? COL_SUM_BLOCKS : COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
                        reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, PCG_ACT_NONE,

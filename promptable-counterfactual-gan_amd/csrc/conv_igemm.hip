@@ -707,6 +707,10 @@ using Cfg128x64 = TileCfg<128, 64, 2, 2, true, 6, 1>;      // measured r02: 3x3 
 using Cfg128x64 = Cfg128x64P;                              // 9 % (105.7 -> 96.6) and therefore keeps the padded config
 #endif
 
+// (r04: 192x64 tiles — four consumer waves of 96x32, two workgroups per CU, 1.5x the MFMAs per workgroup — were built and measured:
+//  bit-identical results, no gain: 3x3 64->64 forward 0.4867 -> 0.4943 ms, its grad-input 0.4969 -> 0.5227, D2's k4 s2 grad-input
+//  0.2875 -> 0.2877.  The epilogue is per-OUTPUT work, not per-workgroup work; only the ~4 us entry is amortised.  Removed)
+
 int check_geom(const pcg_conv_geom* g) {
   PCG_REQUIRE(g != nullptr, "conv geometry is null");
   PCG_REQUIRE(g->B > 0 && g->IH > 0 && g->IW > 0 && g->Cin > 0 && g->OH > 0 && g->OW > 0 && g->Cout > 0,
@@ -1491,6 +1495,35 @@ __global__ void __launch_bounds__(256) weight_adjoint_kernel(const float* __rest
   }
 }
 } }
+namespace pcg { namespace {
+struct AdjMany { const float* w[16]; float* wa[16]; };
+__global__ void __launch_bounds__(256) weight_adjoint_many_kernel(AdjMany a, int Cout, int KHW, int Cin) {
+  const float* __restrict__ w = a.w[blockIdx.y];
+  float* __restrict__ wa = a.wa[blockIdx.y];
+  const int total = Cout * KHW * Cin;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+    const int co = o % Cout, t = o / Cout;
+    const int tapr = t % KHW, ci = t / KHW;
+    wa[o] = w[((size_t)co * KHW + (KHW - 1 - tapr)) * Cin + ci];
+  }
+}
+} }
+// pcg_conv_weight_adjoint for up to 16 layers of ONE shape in a single launch (the 12 3x3 64->64 convolutions of the CounteRGAN
+// generator's residual blocks, models/generator.py:11-14, whose grad-inputs all run on the forward kernel: 12 launches of 6 us -> 1)
+extern "C" int pcg_conv_weight_adjoint_many(const float* const* w, float* const* w_adj, int32_t n, int32_t Cout, int32_t KH, int32_t KW,
+                                            int32_t Cin, pcg_stream_t stream) {
+  PCG_REQUIRE(w && w_adj && n >= 1 && n <= 16 && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "pcg_conv_weight_adjoint_many: bad arguments (1..16 layers)");
+  AdjMany a{};
+  for (int i = 0; i < n; ++i) {
+    PCG_REQUIRE(w[i] && w_adj[i], "pcg_conv_weight_adjoint_many: null pointer");
+    a.w[i] = w[i]; a.wa[i] = w_adj[i];
+  }
+  const int total = Cout * KH * KW * Cin;
+  hipLaunchKernelGGL(weight_adjoint_many_kernel, dim3((unsigned)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, a, Cout, KH * KW, Cin);
+  return launch_status("weight_adjoint_many_kernel");
+}
+
 // Stride-1 layers: the grad-input convolution is itself a forward convolution of dy with the 180-degree-rotated, channel-transposed
 // weight and padding K-1-pad.  Running it on the FORWARD kernel makes both operands K-major (one ds_read_b128 per fragment
 // instead of four ds_read_b32 for the transposed weight slices of the grad-input kernel): measured r02 on the 3x3 64->64 layers.

@@ -344,6 +344,20 @@ def conv_weight_adjoint(w):
     return wa
 
 
+def conv_weight_adjoint_many(ws):
+    """conv_weight_adjoint of up to 16 OHWI weights of one shape in ONE launch; returns the list of adjoint weights (views of one buffer)."""
+    n = len(ws)
+    Cout, KH, KW, Cin = ws[0].shape
+    for w in ws:
+        _chk(w, "w")
+        assert tuple(w.shape) == (Cout, KH, KW, Cin)
+    buf = torch.empty((n, Cin, KH, KW, Cout), dtype=torch.float32, device=ws[0].device)
+    src = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    dst = (ctypes.c_void_p * n)(*[buf[i].data_ptr() for i in range(n)])
+    check(_lib.load().pcg_conv_weight_adjoint_many(src, dst, n, Cout, KH, KW, Cin, _stream()), "pcg_conv_weight_adjoint_many")
+    return [buf[i] for i in range(n)]
+
+
 def adjoint_geom(g):
     """Geometry of the grad-input of a stride-1 convolution seen as a forward convolution of dy (see conv_weight_adjoint)."""
     assert g.stride == 1
