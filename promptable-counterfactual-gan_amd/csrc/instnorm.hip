@@ -610,6 +610,41 @@ unsigned ew_blocks(size_t n) {
   return (unsigned)b;
 }
 
+// One dispatcher for the three InstanceNorm passes (forward, backward, backward of the backward).  A pass has a register-resident
+// form `Reg<NP>` (a block's slice of one sample lives in registers: NP positions per lane, every tensor read from HBM once), a
+// streaming form `Stream<4>` for maps too large for that and `Stream<1>` for channel counts that are not a multiple of 4.
+// Channels per block of the register-resident form are chosen so that the position-lanes match the map: 4 lanes x 256 channels for a
+// 2x2 map, 16 x 64 for 6x6, 32 x 32 for 13x13 (`wide13`: the backward-of-backward keeps 16 x 64 there — with three tensors in
+// registers the 32-lane form measured 80 against 61 us).  `launch(kernel, grid, tc)` issues the chosen instantiation.
+template <template <int> class Reg, template <int> class Stream, class Launch>
+void instnorm_dispatch(bool vec, int B, int HW, int C, bool wide13, Launch launch) {
+  if (!vec) {
+    int tc = 1;
+    while (tc < C && tc < 64) tc <<= 1;
+    launch(Stream<1>::fn(), dim3(B, (C + tc - 1) / tc), tc);
+    return;
+  }
+  const int tc = pick_tc(C);
+  int tcr = tc;
+  if (HW <= 4 && C % 256 == 0) tcr = 256;
+  else if (HW <= 8 && C % 128 == 0) tcr = 128;
+  else if (wide13 && HW > 48 && C % 32 == 0 && tc >= 32) tcr = 32;
+  const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
+  const dim3 grid(B, (C + tcr - 1) / tcr);
+  if (np <= 1) launch(Reg<1>::fn(), grid, tcr);
+  else if (np <= 2) launch(Reg<2>::fn(), grid, tcr);
+  else if (np <= 3) launch(Reg<3>::fn(), grid, tcr);
+  else if (np <= 6) launch(Reg<6>::fn(), grid, tcr);
+  else if (np <= 12) launch(Reg<12>::fn(), grid, tcr);
+  else launch(Stream<4>::fn(), dim3(B, (C + tc - 1) / tc), tc);
+}
+template <int NP> struct FwdReg { static auto fn() { return instnorm_fwd_reg_kernel<NP>; } };
+template <int V> struct FwdStream { static auto fn() { return instnorm_fwd_kernel<V>; } };
+template <int NP> struct BwdReg { static auto fn() { return instnorm_bwd_reg_kernel<NP>; } };
+template <int V> struct BwdStream { static auto fn() { return instnorm_bwd_kernel<V>; } };
+template <int NP> struct BwdBwdReg { static auto fn() { return instnorm_bwd_bwd_reg_kernel<NP>; } };
+template <int V> struct BwdBwdStream { static auto fn() { return instnorm_bwd_bwd_kernel<V>; } };
+
 }  // namespace
 }  // namespace pcg
 
@@ -618,27 +653,9 @@ using namespace pcg;
 extern "C" int pcg_instnorm_fwd(const float* x, int32_t B, int32_t HW, int32_t C, const float* gamma, const float* beta, float eps, int act,
                                 float slope, float* y, float* mean, float* invstd, pcg_stream_t stream) {
   PCG_REQUIRE(x && gamma && beta && y && mean && invstd && B > 0 && HW > 0 && C > 0, "pcg_instnorm_fwd: bad arguments");
-  if (vec4(C, {x, gamma, beta, y, mean, invstd})) {
-    const int tc = pick_tc(C);
-    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
-    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
-    int tcr = tc;
-    if (HW <= 4 && C % 256 == 0) tcr = 256;
-    else if (HW <= 8 && C % 128 == 0) tcr = 128;
-    else if (HW > 48 && C % 32 == 0 && tc >= 32) tcr = 32;
-    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 2) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 6) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_fwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tcr, gamma, beta, eps, act, slope, y, mean, invstd);
-    else hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
-  } else {
-    int tc = 1;
-    while (tc < C && tc < 64) tc <<= 1;
-    hipLaunchKernelGGL(instnorm_fwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps,
-                       act, slope, y, mean, invstd);
-  }
+  instnorm_dispatch<FwdReg, FwdStream>(vec4(C, {x, gamma, beta, y, mean, invstd}), B, HW, C, true, [&](auto kernel, dim3 grid, int tc) {
+    hipLaunchKernelGGL(kernel, grid, dim3(IN_THREADS), 0, (hipStream_t)stream, x, HW, C, tc, gamma, beta, eps, act, slope, y, mean, invstd);
+  });
   return launch_status("instnorm_fwd_kernel");
 }
 
@@ -647,27 +664,11 @@ extern "C" int pcg_instnorm_bwd_fused(const float* dy, const float* act_y, float
                                       float* dgamma_partial, float* dbeta_partial, float* dxsum_partial, pcg_stream_t stream) {
   PCG_REQUIRE(dy && x && mean && invstd && gamma && (dx || dgamma_partial) && B > 0 && HW > 0 && C > 0, "pcg_instnorm_bwd: bad arguments");
   PCG_REQUIRE((!dn_out || act_y) && (!addend || dx) && (!dxsum_partial || dx), "pcg_instnorm_bwd_fused: dn_out needs act_y; addend / dxsum_partial need dx");
-  if (vec4(C, {dy, act_y, x, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial})) {
-    const int tc = pick_tc(C);
-    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
-    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
-    int tcr = tc;
-    if (HW <= 4 && C % 256 == 0) tcr = 256;
-    else if (HW <= 8 && C % 128 == 0) tcr = 128;
-    else if (HW > 48 && C % 32 == 0 && tc >= 32) tcr = 32;
-    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 2) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 6) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tcr, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-    else hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-  } else {
-    int tc = 1;
-    while (tc < C && tc < 64) tc <<= 1;
-    hipLaunchKernelGGL(instnorm_bwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc,
-                       mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial);
-  }
+  instnorm_dispatch<BwdReg, BwdStream>(vec4(C, {dy, act_y, x, mean, invstd, gamma, dn_out, addend, dx, dgamma_partial, dbeta_partial, dxsum_partial}),
+                                       B, HW, C, true, [&](auto kernel, dim3 grid, int tc) {
+    hipLaunchKernelGGL(kernel, grid, dim3(IN_THREADS), 0, (hipStream_t)stream, dy, act_y, neg_slope, x, HW, C, tc, mean, invstd, gamma, dn_out, addend, dx,
+                       dgamma_partial, dbeta_partial, dxsum_partial);
+  });
   return launch_status("instnorm_bwd_kernel");
 }
 extern "C" int pcg_instnorm_bwd(const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean, const float* invstd,
@@ -680,27 +681,11 @@ extern "C" int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const f
                                         float* dgamma_partial, pcg_stream_t stream) {
   PCG_REQUIRE(r && dy && x && mean && invstd && gamma && (ddy || ez || dgamma_partial) && B > 0 && HW > 0 && C > 0,
               "pcg_instnorm_bwd_bwd: bad arguments");
-  if (vec4(C, {r, dy, x, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y})) {
-    const int tc = pick_tc(C);
-    // register-resident form: channels per block chosen so that the position-lanes match HW (4 lanes x 256 channels for a 2x2
-    // map, 16 x 64 for 6x6, 32 x 32 for 13x13: full lanes, <= 6 float4 per tensor and thread)
-    int tcr = tc;
-    if (HW <= 4 && C % 256 == 0) tcr = 256;
-    else if (HW <= 8 && C % 128 == 0) tcr = 128;
-    // (13x13 maps keep 16 lanes x 64 channels here: with three tensors in registers the 32-lane form measured 80 against 61 us)
-    const int th = IN_THREADS / (tcr / 4), np = (HW + th - 1) / th;     // positions per lane
-    if (np <= 1) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<1>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 2) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<2>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 3) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<3>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 6) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<6>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else if (np <= 12) hipLaunchKernelGGL(instnorm_bwd_bwd_reg_kernel<12>, dim3(B, (C + tcr - 1) / tcr), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tcr, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-    else hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<4>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-  } else {
-    int tc = 1;
-    while (tc < C && tc < 64) tc <<= 1;
-    hipLaunchKernelGGL(instnorm_bwd_bwd_kernel<1>, dim3(B, (C + tc - 1) / tc), dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean,
-                       invstd, gamma, ddy, ez, dgamma_partial, act_y, neg_slope);
-  }
+  instnorm_dispatch<BwdBwdReg, BwdBwdStream>(vec4(C, {r, dy, x, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y}), B, HW, C, false,
+                                             [&](auto kernel, dim3 grid, int tc) {
+    hipLaunchKernelGGL(kernel, grid, dim3(IN_THREADS), 0, (hipStream_t)stream, r, dy, x, HW, C, tc, mean, invstd, gamma, ddy, ez, dgamma_partial, act_y,
+                       neg_slope);
+  });
   return launch_status("instnorm_bwd_bwd_kernel");
 }
 extern "C" int pcg_instnorm_bwd_bwd(const float* r, const float* dy, const float* x, int32_t B, int32_t HW, int32_t C, const float* mean,

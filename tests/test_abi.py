@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(pcgan_amd.LIB_PATH)
     for name in _declared():
         assert hasattr(raw, name), f"{name} declared in pcgan_hip.h but not exported by libpcgan_hip.so"
-    assert lib.pcg_abi_version() == 4
+    assert lib.pcg_abi_version() == 5
     assert lib.pcg_target_arch() == b"gfx950"
 
 
