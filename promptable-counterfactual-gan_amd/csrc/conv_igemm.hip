@@ -384,29 +384,41 @@ __device__ __forceinline__ int skn_start(int g, const SkNPlan& sk) {
 __device__ __forceinline__ int skn_owner(int x, const SkNPlan& sk) {
   return __builtin_amdgcn_readfirstlane((int)((((uint32_t)x + 1u) * (uint32_t)sk.blocks - 1u) / (uint32_t)sk.total));
 }
+// one segment of a range: which tile, which of its k-tiles, who shares the tile (all wave-uniform, derived from the iteration index)
+struct SkNSeg { int py, tin, t_begin, e, kt_begin, nkt, fb, nparts, mt, nt; };
+__device__ __forceinline__ SkNSeg skn_segment(int it, int it1, const SkNPlan& sk, int tilesN) {
+  SkNSeg s;
+  s.py = 0;
+  if (sk.nph > 1 && it >= sk.it0[1]) s.py = 1;
+  if (sk.nph > 2 && it >= sk.it0[2]) s.py = 2;
+  if (sk.nph > 3 && it >= sk.it0[3]) s.py = 3;
+  const int KT = sk.kt[s.py], local = it - sk.it0[s.py];
+  s.tin = __builtin_amdgcn_readfirstlane(local / KT);                  // tile inside the phase
+  s.t_begin = sk.it0[s.py] + s.tin * KT;                               // the tile's iterations: [t_begin, t_begin + KT)
+  const int t_end = s.t_begin + KT;
+  s.e = it1 < t_end ? it1 : t_end;
+  s.kt_begin = it - s.t_begin; s.nkt = s.e - it;
+  s.fb = skn_owner(s.t_begin, sk); s.nparts = skn_owner(t_end - 1, sk) - s.fb + 1;
+  s.mt = __builtin_amdgcn_readfirstlane(s.tin / tilesN); s.nt = s.tin - s.mt * tilesN;
+  return s;
+}
+// The segment loop exists TWICE, once per role (r04): as one loop holding both roles' bodies the register allocator had to carry the
+// union of the producers' loader state and the consumers' accumulators / epilogue temporaries across the back edge — 61 spilled
+// VGPRs and 208 bytes of scratch.  Both loops derive the same segments from the same indices and meet at the same
+// barriers.
 template <class Cfg, bool XF>
 __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_skn_kernel(ConvP p, DgradPhases phases, SkNPlan sk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int rowpix[Cfg::BM];
   const int g = (int)xcd_remap(blockIdx.x, (uint32_t)sk.blocks);
   const int it1 = skn_start(g + 1, sk);
+  if (wave_id() >= 4) {
+    const int tid = threadIdx.x - IG_LOADERS;
 #pragma unroll 1
-  for (int it = skn_start(g, sk); it < it1;) {
-    int py = 0;
-    if (sk.nph > 1 && it >= sk.it0[1]) py = 1;
-    if (sk.nph > 2 && it >= sk.it0[2]) py = 2;
-    if (sk.nph > 3 && it >= sk.it0[3]) py = 3;
-    const int KT = sk.kt[py], local = it - sk.it0[py];
-    const int tin = __builtin_amdgcn_readfirstlane(local / KT);          // tile inside the phase
-    const int t_begin = sk.it0[py] + tin * KT, t_end = t_begin + KT;     // the tile's iterations
-    const int e = it1 < t_end ? it1 : t_end;
-    const int kt_begin = it - t_begin, nkt = e - it;
-    const int fb = skn_owner(t_begin, sk), nparts = skn_owner(t_end - 1, sk) - fb + 1;
-    const PhaseInfo& f = phases.p[py];
-    const int mt = __builtin_amdgcn_readfirstlane(tin / p.tilesN), nt = tin - mt * p.tilesN;
-    const int m_block = mt * Cfg::BM, n_block = nt * Cfg::BN;
-    if (wave_id() >= 4) {
-      const int tid = threadIdx.x - IG_LOADERS;
+    for (int it = skn_start(g, sk); it < it1;) {
+      const SkNSeg sg = skn_segment(it, it1, sk, p.tilesN);
+      const PhaseInfo& f = phases.p[sg.py];
+      const int m_block = sg.mt * Cfg::BM, n_block = sg.nt * Cfg::BN;
       for (int r = tid; r < Cfg::BM; r += IG_LOADERS) {
         const int m = m_block + r;
         int pix = -1;
@@ -420,20 +432,31 @@ __global__ void __launch_bounds__(IG_THREADS, Cfg::MINW) conv_dgrad_skn_kernel(C
       }
       DgradALoader<Cfg::BM, XF> la(p, f, m_block, tid);
       DgradBLoader<Cfg::BN> lb(p, f, n_block, tid);
-      if (kt_begin) { la.seek(kt_begin); lb.seek(kt_begin); }
-      igemm_produce<Cfg>(la, lb, nkt, smem, tid, ClockStamp{nullptr, 0});
-    } else {
+      if (sg.kt_begin) { la.seek(sg.kt_begin); lb.seek(sg.kt_begin); }
+      igemm_produce<Cfg>(la, lb, sg.nkt, smem, tid, ClockStamp{nullptr, 0});
+      it = sg.e;
+      if (it < it1) lds_barrier();   // the consumers' epilogue staged through the LDS stages / read rowpix: wait for it
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int it = skn_start(g, sk); it < it1;) {
+    const SkNSeg sg = skn_segment(it, it1, sk, p.tilesN);
+    const PhaseInfo& f = phases.p[sg.py];
+    const int m_block = sg.mt * Cfg::BM, n_block = sg.nt * Cfg::BN;
+    {
       f32x16 acc[Cfg::TM][Cfg::TN];
-      igemm_consume<Cfg, true, false>(nkt, acc, smem);
-      if (sk_combine_core<Cfg>(sk.parts, sk.arrivals, sk.blocks, g, sk.tile0[py] + tin, nparts, fb,
+      igemm_consume<Cfg, true, false>(sg.nkt, acc, smem);
+      const int t_begin = sg.t_begin;
+      if (sk_combine_core<Cfg>(sk.parts, sk.arrivals, sk.blocks, g, sk.tile0[sg.py] + sg.tin, sg.nparts, sg.fb,
                                [&](int blk) { return skn_start(blk, sk) >= t_begin; }, acc))
         igemm_store_tile<Cfg>(acc, smem, n_block, p.N, p.bias, [&](int row) -> float* {
           const int pix = rowpix[row];
           return pix >= 0 ? p.out + (size_t)pix * p.Cin + n_block : nullptr;
-        }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
+        }, p.stat_partial ? p.stat_partial + (size_t)(f.prow0 + sg.mt * Cfg::WAVES_M) * 2 * p.N : nullptr, p.act, p.slope, &p.epi, epi_group_off(p, m_block));
     }
-    it = e;
-    if (it < it1) lds_barrier();   // the epilogue staged through the LDS stages / read rowpix: the next segment's producers wait
+    it = sg.e;
+    if (it < it1) lds_barrier();
   }
 }
 
@@ -726,7 +749,7 @@ int check_geom(const pcg_conv_geom* g) {
 }
 
 // Tuning switches for A/B measurements in ONE process (pcg_tune_set; scripts/conv_microbench.py --ab): -1 = the built-in choice.
-struct Tune { int edge_prio = -1, dgrad_swz3 = -1, korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
+struct Tune { int edge_prio = -1, dgrad_swz3 = -1, wgrad_rounds = -1, korder = -1, wgrad_order = -1, dgrad_interleave = -1, persistent = -1, persist_tiles = -1, fwd_splits = -1, dma = -1, stream_k = -1, sk_blocks = -1, dgrad_gemm = -1, t64 = -1; unsigned long long* stamps = nullptr; int stamp_slots = 0; };
 Tune g_tune;
 
 ConvP make_params(const pcg_conv_geom* g) {
@@ -1062,7 +1085,8 @@ WgradPlan plan_wgrad(const pcg_conv_geom* g) {
   w.ktiles_total = (int)ceil_div64(K, IG_BK);
   // fill the 512 block slots (2 per CU) in ONE round — 515 blocks would run as 512 + a second round of 3 — but keep
   // >= 8 k-tiles (256 pixels) per slice
-  int splits = w.tiles <= 512 ? 512 / w.tiles : 1;
+  const int slots = 512 * (g_tune.wgrad_rounds > 0 ? g_tune.wgrad_rounds : 1);      // (A/B: more, shorter K-slices = more than one round of workgroups)
+  int splits = w.tiles <= slots ? slots / w.tiles : 1;
   const int max_splits = w.ktiles_total / 8 > 0 ? w.ktiles_total / 8 : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -1612,7 +1636,10 @@ extern "C" int pcg_conv2d_dgrad_bnbwd_g(const pcg_conv_geom* g, const float* dy,
 // Thin forward (Cin = 1, k4) whose output is a gradient w.r.t. the activated output of  z -> BatchNorm(train) -> ReLU / LeakyReLU:
 // returns dz directly and adds dgamma / dbeta — the output tensor itself, the reduction pass over it and the re-read in the apply pass
 // disappear (thin_rows_expand_bn_kernel; DCGAN: G5's grad-input + G4's BatchNorm backward, mnist_dcgan.py:85-88 backward).
-extern "C" int32_t pcg_conv2d_fwd_bnbwd_thin_ok(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK && thin_conv_fwd_bnbwd_ok(g) && g->Cout % 4 == 0 ? 1 : 0; }
+namespace pcg { bool dp_sync_bn(); }     // dp_rccl.hip: exact global-batch BatchNorm is on (its sums are all-reduced inside the BatchNorm entry points)
+extern "C" int32_t pcg_conv2d_fwd_bnbwd_thin_ok(const pcg_conv_geom* g) {
+  return check_geom(g) == PCG_OK && !pcg::dp_sync_bn() && thin_conv_fwd_bnbwd_ok(g) && g->Cout % 4 == 0 ? 1 : 0;
+}
 extern "C" size_t pcg_conv2d_fwd_bnbwd_thin_workspace_bytes(const pcg_conv_geom* g) {
   return pcg_conv2d_fwd_bnbwd_thin_ok(g) ? thin_conv_fwd_bnbwd_workspace_bytes(g) : 0;
 }
@@ -1795,7 +1822,8 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   PCG_REQUIRE(name != nullptr, "pcg_tune_set: null name");
   if (!strcmp(name, "korder")) g_tune.korder = value;
   else if (!strcmp(name, "edge_prio")) g_tune.edge_prio = value;
-  else if (!strcmp(name, "dgrad_swz3")) g_tune.dgrad_swz3 = value;      // A/B: multi-phase N <= 64 grad-inputs on the three-per-CU tile configuration
+  else if (!strcmp(name, "dgrad_swz3")) g_tune.dgrad_swz3 = value;
+  else if (!strcmp(name, "wgrad_rounds")) g_tune.wgrad_rounds = value;  // A/B: K-slices of the weight gradient sized for this many rounds of 512 workgroups      // A/B: multi-phase N <= 64 grad-inputs on the three-per-CU tile configuration
   else if (!strcmp(name, "wgrad_order")) g_tune.wgrad_order = value;
   else if (!strcmp(name, "dgrad_interleave")) g_tune.dgrad_interleave = value;
   else if (!strcmp(name, "persistent")) g_tune.persistent = value;
@@ -1807,7 +1835,7 @@ extern "C" int pcg_tune_set(const char* name, int32_t value) {
   else if (!strcmp(name, "t64")) g_tune.t64 = value;
   else if (!strcmp(name, "dma")) g_tune.dma = value;
   else {
-    set_error("pcg_tune_set: unknown switch '%s' (korder, edge_prio, dgrad_swz3, wgrad_order, dgrad_interleave, persistent, persist_tiles, fwd_splits, "
+    set_error("pcg_tune_set: unknown switch '%s' (korder, edge_prio, dgrad_swz3, wgrad_rounds, wgrad_order, dgrad_interleave, persistent, persist_tiles, fwd_splits, "
               "stream_k, sk_blocks, dgrad_gemm, t64, dma)", name);
     return PCG_ERR_INVALID;
   }
