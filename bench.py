@@ -410,7 +410,8 @@ def main():
     rccl_log = None
     if world > 1 or args.force_dp:
         import tempfile
-        os.environ.setdefault("NCCL_DEBUG", "WARN")                     # RCCL's warnings of every rank (first contact with N > 1)
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":  # RCCL's warnings of every rank (first contact with N > 1);
+            os.environ["NCCL_DEBUG"] = "WARN"                             # an explicit INFO / TRACE from the caller is left alone
         if "NCCL_DEBUG_FILE" not in os.environ:
             rccl_log = os.path.join(tempfile.gettempdir(), f"pcg_bench_rccl_{os.getpid()}_rank{rank}.log")
             os.environ["NCCL_DEBUG_FILE"] = rccl_log

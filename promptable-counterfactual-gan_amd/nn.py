@@ -231,6 +231,44 @@ def _compile(seq):
     return blocks
 
 
+class _WgradDefer:
+    """Experiment (r04, `SequentialConvNet.wgrad_overlap = "bn"`): a layer's weight gradient is launched on a side stream AFTER the
+    layer's grad-input has been queued, so that it runs beside the next layer's BatchNorm-backward finalize + apply pass (HBM-bound,
+    no LDS, few waves) instead of before it; the next grad-input waits for it, so two MFMA grids never share the chip (that form —
+    `wgrad_stream` — measured slower in r03)."""
+
+    def __init__(self, side, main):
+        self.side, self.main, self.job, self.inflight = side, main, None, False
+
+    def submit(self, fn, tensors):
+        self.job = (fn, tensors)
+
+    def start_pending(self):
+        if self.job is None:
+            return
+        fn, tensors = self.job
+        self.job = None
+        self.side.wait_stream(self.main)          # everything queued so far (the layer's grad-input included) comes first
+        for t in tensors:
+            t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+        self.inflight = True
+
+    def join(self):
+        if self.inflight:
+            self.main.wait_stream(self.side)
+            self.inflight = False
+
+    def finish(self):
+        if self.job is not None:                  # the last layer's: nothing left to run beside it
+            fn, _ = self.job
+            self.job = None
+            self.join()
+            fn()
+        self.join()
+
+
 class _SeqFn(torch.autograd.Function):
     """One autograd node for the whole stack.  Parameters are passed only so that autograd knows the output
     depends on them; their gradients are accumulated into the flat buffer inside backward (returned as None)."""
@@ -492,11 +530,21 @@ class SequentialConvNet(FlatModule):
             dy = dy.contiguous()
         d, own = dy, False
         fused = None           # ("bn", partial, nparts, nphases) | ("mask",) | None — see _run_backward_impl
+        defer = self._defer()
+        try:
+            self._run_backward_groups_impl(saved, G, B, d, own, fused, defer)
+        finally:
+            if defer is not None:
+                defer.finish()
+
+    def _run_backward_groups_impl(self, saved, G, B, d, own, fused, defer):
         for idx in range(len(self._blocks) - 1, -1, -1):
             b = self._blocks[idx]
             g, a, z, mean, invstd, y, bn_eval = saved[idx]
             c = b.conv
             C = c.out_channels
+            if defer is not None:
+                defer.start_pending()
             if b.bn is not None:
                 if bn_eval:
                     raise PcgError("backward through an eval-mode BatchNorm2d is not implemented")
@@ -519,14 +567,24 @@ class SequentialConvNet(FlatModule):
             if c.weight.requires_grad:
                 gw, acc = self._grad_view(c.weight)
                 gw = _w_ohwi(gw)
-                if idx == 0:
-                    for k, x in enumerate(a):       # per group: the inputs are separate tensors (.grad accumulation of :153,161)
-                        ops.conv2d_wgrad(g, x, dz[k * B:(k + 1) * B], gw, acc or k > 0)
+
+                def wgrad_job(idx=idx, g=g, a=a, dz=dz, gw=gw, acc=acc, c=c, C=C):
+                    if idx == 0:
+                        for k, x in enumerate(a):       # per group: the inputs are separate tensors (.grad accumulation of :153,161)
+                            ops.conv2d_wgrad(g, x, dz[k * B:(k + 1) * B], gw, acc or k > 0)
+                    else:
+                        ops.conv2d_wgrad(g, a, dz, gw, acc)      # ONE sum over the pixels of all groups
+                    if c.bias is not None and c.bias.requires_grad:
+                        gb, accb = self._grad_view(c.bias)
+                        ops.colsum(dz.numel() // C, C, dz, gb, accb)
+                if defer is not None:
+                    defer.join()
+                if defer is not None and idx > 0 and g.Cin > 3 and g.Cout > 3:
+                    defer.submit(wgrad_job, (dz, a))
                 else:
-                    ops.conv2d_wgrad(g, a, dz, gw, acc)      # ONE sum over the pixels of all groups
-                if c.bias is not None and c.bias.requires_grad:
-                    gb, accb = self._grad_view(c.bias)
-                    ops.colsum(dz.numel() // C, C, dz, gb, accb)
+                    wgrad_job()
+            elif defer is not None:
+                defer.join()
             if idx == 0:
                 return None
             lo = self._blocks[idx - 1]
@@ -549,18 +607,31 @@ class SequentialConvNet(FlatModule):
 
     wgrad_stream = None      # opt-in A/B: a second HIP stream for the weight gradients (they and the grad-input of a layer both need only dz)
 
+    wgrad_overlap = None     # experiment: "bn" = weight gradients beside the next layer's BatchNorm-backward passes (_WgradDefer)
+
+    def _defer(self):
+        if self.wgrad_overlap != "bn":
+            return None
+        side = self.__dict__.get("_overlap_stream")
+        if side is None:
+            side = self.__dict__["_overlap_stream"] = torch.cuda.Stream()
+        return _WgradDefer(side, torch.cuda.current_stream())
+
     def _run_backward(self, saved, dy, need_x, need_p):
         if not dy.is_contiguous():
             dy = dy.contiguous()
         side = self.wgrad_stream
         main = torch.cuda.current_stream() if side is not None else None
+        defer = self._defer() if side is None else None
         try:
-            return self._run_backward_impl(saved, dy, need_x, need_p, side, main)
+            return self._run_backward_impl(saved, dy, need_x, need_p, side, main, defer)
         finally:
             if side is not None:
                 main.wait_stream(side)
+            if defer is not None:
+                defer.finish()
 
-    def _run_backward_impl(self, saved, dy, need_x, need_p, side, main):
+    def _run_backward_impl(self, saved, dy, need_x, need_p, side, main, defer=None):
         d = dy
         own = False  # never write into autograd's incoming grad tensor; deeper gradients are ours to overwrite
         nblk = len(self._blocks)
@@ -574,6 +645,8 @@ class SequentialConvNet(FlatModule):
             g, a, z, mean, invstd, y, bn_eval, xf_in = saved[idx]
             c = b.conv
             C = c.out_channels
+            if defer is not None:
+                defer.start_pending()     # the layer above's weight gradient: beside this layer's BatchNorm backward
             if b.bn is not None:
                 if bn_eval:
                     raise PcgError("backward through an eval-mode BatchNorm2d is not implemented")
@@ -604,7 +677,8 @@ class SequentialConvNet(FlatModule):
                 if side is not None:
                     side.wait_stream(main)                       # dz is complete
                     dz.record_stream(side); a.record_stream(side)
-                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+
+                def wgrad_job(b=b, g=g, a=a, dz=dz, gw=gw, acc=acc, xf_in=xf_in, c=c, C=C):
                     if not b.transposed:      # `a` may be the layer below's pre-BatchNorm output read through its transform
                         ops.conv2d_wgrad(g, a, dz, gw, acc, xf_x=xf_in)
                     else:
@@ -612,6 +686,17 @@ class SequentialConvNet(FlatModule):
                     if c.bias is not None and c.bias.requires_grad:
                         gb, accb = self._grad_view(c.bias)
                         ops.colsum(dz.numel() // C, C, dz, gb, accb)
+                mfma = g.Cin > 3 and g.Cout > 3
+                if defer is not None and mfma and idx > 0:
+                    defer.join()                                 # (an earlier deferred gradient: one MFMA grid at a time)
+                    defer.submit(wgrad_job, (dz, a))             # launched at the top of the next iteration, behind this layer's grad-input
+                else:
+                    if defer is not None:
+                        defer.join()
+                    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                        wgrad_job()
+            elif defer is not None:
+                defer.join()
             last = idx == 0
             if last and not need_x:
                 return None

@@ -67,10 +67,16 @@ def main():
         variant = {}
         if key == "pair":
             variant["kwargs"] = {"pair": bool(v)}
+        elif key == "overlap":           # nn.SequentialConvNet.wgrad_overlap (class switch: baked into the graph at capture)
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.wgrad_overlap = "bn" if v else None
         else:
             ops.tune(key, v)
         graphs[v] = (build_dcgan if a.model == "dcgan" else build_countergan)(dev, batch, variant)
-        if key != "pair":
+        if key == "overlap":
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.wgrad_overlap = None
+        elif key != "pair":
             ops.tune(key, -1)
     res = {v: [] for v in vals}
     for v in vals:

@@ -285,3 +285,34 @@ def test_thin_grad_input_through_batchnorm_backward_without_being_written(pcg, B
     n = dm.reshape(-1, C).shape[0]
     want = gamma.double().cpu() * i64 * (dm - dm.reshape(-1, C).sum(0) / n - xh * (dm * xh).reshape(-1, C).sum(0) / n)
     assert _rel_l2(dz.cpu(), want) <= 2e-4      # (batch 512: 5e-5 — the two means are differences of sums over 524288 rows)
+
+
+def test_weight_gradients_beside_the_batchnorm_backward_are_the_same_numbers(pcg):
+    """SequentialConvNet.wgrad_overlap = "bn" (experiment: a layer's weight gradient on a side stream beside the next layer's
+    BatchNorm-backward passes) changes the order of launches across two streams, not one number: eager and graph-replayed steps are
+    bit-identical to the one-stream schedule."""
+    from pcgan_amd.nn import GraphedStep, SequentialConvNet
+    D = pcg.dcgan
+    c = {"g_hidden": 16, "d_hidden": 16, "z_dim": 32}
+    batches = [R.synthetic_batch(32, seed=20 + i, config=c) for i in range(3)]
+    res = {}
+    for mode in (None, "bn", "bn-graph"):
+        SequentialConvNet.wgrad_overlap = "bn" if mode else None
+        netG, netD, _, _ = _nets(pcg, c)
+        crit, optD, optG = D.make_optimizers(netG, netD, c)
+        if mode == "bn-graph":
+            s_real, s_noise = batches[0][0].to(DEV).clone(), batches[0][1].to(DEV).clone()
+            gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, c), {"real": s_real, "noise": s_noise},
+                             [netG, netD], [optD, optG])
+        for real, noise in batches:
+            if mode == "bn-graph":
+                gs.load(real=real.to(DEV), noise=noise.to(DEV))
+                o = gs.replay()
+            else:
+                o = D.train_step(netG, netD, crit, optD, optG, real.to(DEV), noise.to(DEV), c)
+        torch.cuda.synchronize()
+        res[mode] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params.clone(), netD.flat_params.clone())
+    SequentialConvNet.wgrad_overlap = None
+    for mode in ("bn", "bn-graph"):
+        assert res[mode][0] == res[None][0], mode
+        assert torch.equal(res[mode][1], res[None][1]) and torch.equal(res[mode][2], res[None][2]), mode
