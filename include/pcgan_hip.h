@@ -149,6 +149,15 @@ int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const pcg_in_xfo
  * The `fwd` forms are the same for ConvTranspose2d layers (their grad-input is a forward convolution).  act: none / ReLU / LeakyReLU. */
 int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope,
                           float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
+/* r04: pcg_conv2d_dgrad_mask also serves one-channel layers whose grad-input takes the row-block form (..._thin_ok: k3 / k4, Cout
+ * <= 3, Cin a power-of-two multiple of 4): the mask is applied in the thin expand kernel (CounteRGAN conv_out, models/generator.py:50). */
+int32_t pcg_conv2d_dgrad_mask_thin_ok(const pcg_conv_geom* g);
+/* y = (conv(x, w) + addend) * act'(a_below) — pcg_conv2d_*_add followed by pcg_act_bwd in ONE epilogue: the last skip-add of a residual
+ * chain arriving at the entry convolution's LeakyReLU (models/generator.py:76 backward).  a_below: the activated output, output's shape. */
+int pcg_conv2d_fwd_add_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* a_below, int act,
+                            float slope, float* y, pcg_stream_t stream);
+int pcg_conv2d_dgrad_add_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* a_below, int act,
+                              float slope, float* dx, pcg_stream_t stream);
 int pcg_conv2d_fwd_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* a_below, int act, float slope,
                         float* y, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 int pcg_conv2d_dgrad_bnbwd(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,

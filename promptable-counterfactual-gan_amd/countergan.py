@@ -301,8 +301,8 @@ class ResidualGenerator(FlatModule):
         dr = d_raw.contiguous() if d_raw is not None else None
         dm = d_masked.contiguous() if d_masked is not None else None
         dc = ops.scale_mask_bwd(dr, dm, mr, self.residual_scaling, like=mr).view(g_out.B, g_out.OH, g_out.OW, 1)
-        d = _conv_bwd(self, self.conv_out, g_out, hm, dc, True, True)
-        ops.act_bwd(d, hm, ACT_LRELU, slope, out=d)
+        _conv_wgrad(self, self.conv_out, g_out, hm, dc, True)
+        d = _dgrad_act(g_out, dc, ops.ohwi(self.conv_out.weight.data), hm, ACT_LRELU, slope)     # the mask rides in the thin expand kernel
         dh = _conv_bwd(self, self.conv_mid, g_mid, h_last, d, True, True)
         order = list(zip(reversed(self.resblocks), reversed(blocks)))
         # adjoint weights of every stride-1 conv whose grad-input runs on the forward kernel: ONE launch for all of them (r04; was one
@@ -319,6 +319,7 @@ class ResidualGenerator(FlatModule):
             wa = adjw.get(id(conv))
             return wa if wa is not None else ops.conv_weight_adjoint(ops.ohwi(conv.weight.data))
         pending = None      # (partial, nparts): bn2's backward sums of the gradient `dh`, left by the previous block's skip-add epilogue
+        h0_masked = False
         for bi, (blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2)) in enumerate(order):
             C = blk.bn2.num_features
             dg2, acc = self._grad_view(blk.bn2.weight)
@@ -360,12 +361,16 @@ class ResidualGenerator(FlatModule):
                 if nxt is not None:      # ... together with the BatchNorm-backward sums the NEXT block's bn2 needs from this sum
                     dh, part, nparts = ops.conv2d_dgrad_add(ga, dz1, wa, dh, out=dh, bnsum=(nxt[7], nxt[8], nxt[9], 0.1), transposed=adj1)
                     pending = (part, nparts)
+                elif bi + 1 == len(order):   # the chain's last sum is the gradient w.r.t. h0 = LeakyReLU(conv_in(inp)): its mask in the same epilogue
+                    dh = ops.conv2d_dgrad_add_mask(ga, dz1, wa, dh, h, ACT_LRELU, slope, out=dh, transposed=adj1)
+                    h0_masked = True
                 else:
                     dh = ops.conv2d_dgrad_add(ga, dz1, wa, dh, out=dh, transposed=adj1)
             else:
                 dconv = ops.conv2d_dgrad(g1, dz1, ops.ohwi(blk.conv1.weight.data))
                 dh = ops.axpby(1.0, dh, 1.0, dconv, out=dconv)
-        ops.act_bwd(dh, blocks[0][1] if blocks else h_last, ACT_LRELU, slope, out=dh)   # h0 = LeakyReLU(conv_in(inp))
+        if not h0_masked:
+            ops.act_bwd(dh, blocks[0][1] if blocks else h_last, ACT_LRELU, slope, out=dh)   # h0 = LeakyReLU(conv_in(inp))
         dinp = _conv_bwd(self, self.conv_in, g_in, inp, dh, True, True)
         ge, acc = self._grad_view(self.embed.weight)
         ops.embed_concat_bwd(dinp, target, 3, self.embed.num_embeddings, dtable=ge, accumulate=acc)

@@ -1456,11 +1456,17 @@ static int epi_common(const char* who, const pcg_conv_geom* g, const float* out,
   return PCG_OK;
 }
 
+extern "C" int32_t pcg_conv2d_dgrad_mask_thin_ok(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK && thin_conv_dgrad_mask_ok(g) && g->Cin % 4 == 0 ? 1 : 0; }
 extern "C" int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope,
                                      float* dx, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
   EpiAux e{};
   e.mode = EPI_MASK;
   if (int rc = check_geom(g)) return rc;
+  if (pcg_conv2d_dgrad_mask_thin_ok(g)) {      // a one-channel layer's grad-input (r04): the mask in the row-block expand kernel
+    PCG_REQUIRE(dy && w && a_below && dx && (((uintptr_t)a_below | (uintptr_t)dx) & 15) == 0, "pcg_conv2d_dgrad_mask: null or misaligned tensor");
+    PCG_REQUIRE(act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU, "pcg_conv2d_dgrad_mask: activation %d is not none / ReLU / LeakyReLU", act);
+    return thin_conv_dgrad_mask(g, dy, w, a_below, act, slope, dx, (hipStream_t)stream);
+  }
   if (int rc = epi_common("pcg_conv2d_dgrad_mask", g, dx, a_below, act, slope, &e)) return rc;
   return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
 }
@@ -1489,6 +1495,29 @@ extern "C" int pcg_conv2d_fwd_add(const pcg_conv_geom* g, const float* x, const 
   if (int rc = check_geom(g)) return rc;
   if (int rc = epi_common("pcg_conv2d_fwd_add", g, y, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
   return conv2d_fwd_impl(g, x, w, nullptr, y, nullptr, workspace, workspace_bytes, stream, PCG_ACT_NONE, 0.f, &e);
+}
+// skip-add followed by the ReLU / LeakyReLU backward of the layer whose activated output a_below the sum is a gradient of:
+// y = (conv(x, w) + addend) * (a_below > 0 ? 1 : slope) in ONE epilogue (was pcg_conv2d_*_add + a pcg_act_bwd pass over the tensor)
+static int add_mask_epi(const char* who, const pcg_conv_geom* g, const float* out, const float* addend, const float* a_below, int act,
+                        float slope, EpiAux* e) {
+  e->mode = EPI_ADD;
+  if (int rc = check_geom(g)) return rc;
+  if (int rc = epi_common(who, g, out, addend, act, slope, e)) return rc;      // e->neg = the activation's negative-side factor
+  PCG_REQUIRE(a_below && a_below != out && (((uintptr_t)a_below) & 15) == 0, "%s: a_below must be a 16-byte aligned tensor other than the output", who);
+  e->delta2_bytes = (int64_t)((intptr_t)a_below - (intptr_t)out);
+  return PCG_OK;
+}
+extern "C" int pcg_conv2d_fwd_add_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* a_below,
+                                       int act, float slope, float* y, pcg_stream_t stream) {
+  EpiAux e{};
+  if (int rc = add_mask_epi("pcg_conv2d_fwd_add_mask", g, y, addend, a_below, act, slope, &e)) return rc;
+  return conv2d_fwd_impl(g, x, w, nullptr, y, nullptr, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
+}
+extern "C" int pcg_conv2d_dgrad_add_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* a_below,
+                                         int act, float slope, float* dx, pcg_stream_t stream) {
+  EpiAux e{};
+  if (int rc = add_mask_epi("pcg_conv2d_dgrad_add_mask", g, dx, addend, a_below, act, slope, &e)) return rc;
+  return conv2d_dgrad_impl(g, dy, w, nullptr, dx, nullptr, nullptr, 0, stream, PCG_ACT_NONE, 0.f, &e);
 }
 extern "C" int pcg_conv2d_fwd_add_bnsum(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* z_next,
                                         const float* mean, const float* invstd, float sum_scale, float* y, void* partial,

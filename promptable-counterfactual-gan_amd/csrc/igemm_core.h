@@ -503,7 +503,9 @@ constexpr int epilogue_smem_floats() { return 4 * Cfg::WTM * (Cfg::WTN + 4); }
 //   EPI_BNBWD  aux = z (the layer below's pre-BatchNorm conv output).  pre = z*sc + sh (sc = gamma*invstd, sh = beta - mean*sc),
 //              v *= (pre > 0 ? 1 : neg), xhat = (z - mean)*invstd; column sums of v and v*xhat go to the partial rows
 //              (-> dbeta, dgamma and the two means BatchNorm's backward needs): no separate reduction pass over (dy, z).
-//   EPI_ADD    aux = an addend of the output's shape (may BE the output: in-place accumulation).  v += aux   — skip connections
+//   EPI_ADD    aux = an addend of the output's shape (may BE the output: in-place accumulation).  v += aux   — skip connections.
+//              With delta2_bytes != 0 (r04): aux2 = the activated output a of the layer below, v = (v + aux) * (aux2 > 0 ? 1 : neg) — the
+//              last skip-add of a residual chain followed by the entry convolution's LeakyReLU backward (models/generator.py:76)
 //   EPI_ADDSUM EPI_ADD + the BatchNorm-backward column sums of the SUM for the next BatchNorm down the skip chain: aux2 = that layer's
 //              pre-BatchNorm output z (delta2_bytes), mean / invstd its statistics; no activation in between (x + 0.1*bn2(...), models/
 //              generator.py:20).  The partial rows get sum(scale*v) and sum(scale*v*xhat) (scale = neg: the 0.1 of the residual branch);
@@ -632,6 +634,10 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
         // same expression as bn_bwd_apply / FnBnBwd use for the recomputed BatchNorm output (sc = 1, sh = 0 for EPI_MASK)
         if (emode == EPI_ADD) {   // wave-uniform
           v.x += u[kk].x; v.y += u[kk].y; v.z += u[kk].z; v.w += u[kk].w;
+          if (epi->delta2_bytes != 0) {   // wave-uniform: the sum times the activation derivative of the layer below
+            const float4 a2 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + epi->delta2_bytes);
+            v.x *= a2.x > 0.f ? 1.f : neg; v.y *= a2.y > 0.f ? 1.f : neg; v.z *= a2.z > 0.f ? 1.f : neg; v.w *= a2.w > 0.f ? 1.f : neg;
+          }
         } else {
           const float4 pre = make_float4(fmaf(u[kk].x, sc.x, sh.x), fmaf(u[kk].y, sc.y, sh.y), fmaf(u[kk].z, sc.z, sh.z), fmaf(u[kk].w, sc.w, sh.w));
           v.x *= pre.x > 0.f ? 1.f : neg; v.y *= pre.y > 0.f ? 1.f : neg; v.z *= pre.z > 0.f ? 1.f : neg; v.w *= pre.w > 0.f ? 1.f : neg;

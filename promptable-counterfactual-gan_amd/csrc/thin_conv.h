@@ -25,6 +25,11 @@ int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, 
                         const float* gamma, const float* beta, int act, float slope, float* dz, float* dgamma, float* dbeta, int accumulate,
                         void* ws, size_t ws_bytes, hipStream_t s);
 
+// grad-input of a Cout-thin convolution times act'(a_below) in the same pass (row-block forms only)
+bool thin_conv_dgrad_mask_ok(const pcg_conv_geom* g);
+int thin_conv_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope, float* dx,
+                         hipStream_t s);
+
 // shared with conv_igemm.hip: dw[i] = (acc ? dw[i] : 0) + sum_z slab[z*stride + i]
 int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s);
 

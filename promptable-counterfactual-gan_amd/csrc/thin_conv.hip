@@ -22,6 +22,8 @@ struct ThinP {
   const float* bias;
   float* out;
   int act; float slope;   // activation fused into the output write (PCG_ACT_NONE: none)
+  const float* mask_src; float mask_neg;   // row-block expand only (r04): out *= (mask_src > 0 ? 1 : mask_neg), mask_src of the output's shape —
+                                           // the ReLU / LeakyReLU backward of the layer whose activated output this gradient belongs to
   int B, TH, TW, Cs, WH, WW, C;
   int KH, KW, stride, pad, transposed;
   int wsS, wsT, wsC;       // weight element (cs, tap, c) lives at cs*wsS + tap*wsT + c*wsC
@@ -538,6 +540,27 @@ int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, con
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
   if (int e = launch_expand(p, s)) return e;
   return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, (pcg_stream_t)s);
+}
+
+// grad-input of a Cout-thin convolution (dx wide) times the activation derivative of the layer below, read from its activated
+// output a_below (CounteRGAN: conv_out's grad-input arriving at conv_mid's LeakyReLU, models/generator.py:78-80 backward)
+bool thin_conv_dgrad_mask_ok(const pcg_conv_geom* g) {
+  if (!thin_is_cout(g)) return false;
+  ThinP p{};
+  if (fill_common(p, g, false, false) != PCG_OK) return false;
+  const bool k44 = p.KH == 4 && p.KW == 4, k33 = p.KH == 3 && p.KW == 3;
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  return (k44 || k33) && (k33 || p.Cs == 1) && lds_weight_bytes(p) <= 64 * 1024 && rows_plan(p, rp, &patch_bytes);
+}
+int thin_conv_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope, float* dx,
+                         hipStream_t s) {
+  PCG_REQUIRE(thin_conv_dgrad_mask_ok(g), "thin grad-input with mask: only the row-block forms (k3 / k4 with a thin output)");
+  ThinP p{};
+  if (int e = fill_common(p, g, false, /*iter_on_output=*/false)) return e;
+  p.w = w; p.bias = nullptr; p.out = dx; p.thin = dy; p.act = PCG_ACT_NONE; p.slope = 0.f;
+  p.mask_src = a_below; p.mask_neg = act_neg_of(act, slope);
+  return launch_expand(p, s);
 }
 
 size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g) {

@@ -305,6 +305,14 @@ def conv_bwd_data_fused(g, d, w, transposed, below_act, below_slope, a_below=Non
     for bn_bwd_partial.  a_below: the layer below is Conv -> act without BatchNorm; returns (dx_masked, None, 0).
     Returns None when the layer is not eligible (thin layers, split-K): the caller then takes the unfused path."""
     lib = _lib.load()
+    if (not transposed and bn is None and a_below is not None and g.Cout <= 3
+            and lib.pcg_conv2d_dgrad_mask_thin_ok(ctypes.byref(g))):       # a one-channel layer's grad-input: mask in the thin expand kernel
+        _chk(d, "d"); _chk(w, "w"); _chk(a_below, "a_below")
+        out = torch.empty((g.B, g.IH, g.IW, g.Cin), dtype=torch.float32, device=d.device)
+        assert a_below.numel() == out.numel()
+        check(lib.pcg_conv2d_dgrad_mask(ctypes.byref(g), _p(d), _p(w), _p(a_below), int(below_act), float(below_slope), _p(out), None, 0, _stream()),
+              "pcg_conv2d_dgrad_mask(thin)")
+        return out, None, 0
     if g.Cin <= 3 or g.Cout <= 3 or g.Cin % 4 or g.Cout % 4 or g.stride > 2:
         return None
     shape = (g.B, g.OH, g.OW, g.Cout) if transposed else (g.B, g.IH, g.IW, g.Cin)
@@ -362,6 +370,19 @@ def adjoint_geom(g):
     """Geometry of the grad-input of a stride-1 convolution seen as a forward convolution of dy (see conv_weight_adjoint)."""
     assert g.stride == 1
     return conv_geom(g.B, g.OH, g.OW, g.Cout, g.Cin, g.KH, g.KW, 1, g.KH - 1 - g.pad)
+
+
+def conv2d_dgrad_add_mask(g, dy, w, addend, a_below, act, slope, out=None, transposed=False):
+    """dx = (conv_dgrad(dy, w) + addend) * act'(a_below) in one epilogue (out may be `addend`); transposed: the forward-kernel form."""
+    _chk(dy, "dy"); _chk(w, "w"); _chk(addend, "addend"); _chk(a_below, "a_below")
+    shape = (g.B, g.OH, g.OW, g.Cout) if transposed else (g.B, g.IH, g.IW, g.Cin)
+    n = shape[0] * shape[1] * shape[2] * shape[3]
+    assert addend.numel() == n and a_below.numel() == n
+    dx = out if out is not None else torch.empty(shape, dtype=torch.float32, device=dy.device)
+    fn = _lib.load().pcg_conv2d_fwd_add_mask if transposed else _lib.load().pcg_conv2d_dgrad_add_mask
+    with _Timed(g, "fwd" if transposed else "dgrad"):
+        check(fn(ctypes.byref(g), _p(dy), _p(w), _p(addend), _p(a_below), int(act), float(slope), _p(dx), _stream()), "pcg_conv2d_*_add_mask")
+    return dx
 
 
 def conv2d_dgrad_add(g, dy, w, addend, out=None, bnsum=None, transposed=False):
