@@ -362,6 +362,11 @@ int pcg_embed_concat_fwd(const float* x, const int64_t* idx, const float* table,
                          float* out, int32_t B, int32_t HW, int32_t C, int32_t K, pcg_stream_t stream);
 int pcg_embed_concat_bwd(const float* dinp, const int64_t* idx, float* dtable /*nullable*/, float* dx /*nullable*/,
                          int32_t B, int32_t HW, int32_t C, int32_t K, int accumulate, pcg_stream_t stream);
+/* r04: the table gradient alone from channel `ch` of a [B][HW][C] gradient, and the [rows] column `ch` of a [rows][C] tensor — together
+ * they let conv_in's grad-input be computed for its label-map channel only (the image and mask channels' gradients are read by nobody). */
+int pcg_embed_table_grad(const float* dinp, const int64_t* idx, float* dtable, int32_t B, int32_t HW, int32_t C, int32_t ch, int32_t K,
+                         int accumulate, pcg_stream_t stream);
+int pcg_gather_channel(const float* src, float* dst, int32_t rows, int32_t C, int32_t ch, pcg_stream_t stream);
 /* out = a*x + b*y (y nullable): residual-path gradient sums */
 int pcg_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, pcg_stream_t stream);
 /* raw = scale*c ; masked = raw*mask (generator.py:80-82);  bwd: dc = scale*(d_raw + d_masked*mask) */

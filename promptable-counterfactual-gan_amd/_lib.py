@@ -167,6 +167,8 @@ PROTOTYPES = {
     "pcg_bn_act_bwd_premask": (_i, [_vp, _vp, _i64, _c.c_int32, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_embed_concat_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _vp]),
     "pcg_embed_concat_bwd": (_i, [_vp, _vp, _vp, _vp, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_int32, _i, _vp]),
+    "pcg_embed_table_grad": (_i, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i, _vp]),
+    "pcg_gather_channel": (_i, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "pcg_axpby": (_i, [_vp, _f, _vp, _f, _vp, _i64, _vp]),
     "pcg_scale_mask_fwd": (_i, [_vp, _vp, _f, _vp, _vp, _i64, _vp]),
     "pcg_scale_mask_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _i64, _vp]),

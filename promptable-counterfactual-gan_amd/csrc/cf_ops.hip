@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(256) embed_concat_fwd_kernel(const float* __re
 // ascending order, the 16 chunk sums are added in chunk order through LDS (fixed association: reproducible).  One thread per (k,p)
 // walking the whole batch alone was a 1024-step dependent chain in 31 blocks (108 us at batch 1024).
 __global__ void __launch_bounds__(256) embed_table_grad_kernel(const float* __restrict__ dinp, const int64_t* __restrict__ idx,
-                                                               float* __restrict__ dtable, int B, int HW, int C, int K, int accumulate) {
+                                                               float* __restrict__ dtable, int B, int HW, int C, int K, int accumulate,
+                                                               int ch = 1) {
   __shared__ float red[16][16];
   const int il = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + il, total = K * HW;
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(256) embed_table_grad_kernel(const float* __re
     const int k = i / HW, p = i - k * HW;
     const int chunk = (B + 15) / 16, b0 = g * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
     for (int b = b0; b < b1; ++b)
-      if (idx[b] == (int64_t)k) s += dinp[((size_t)b * HW + p) * C + 1];
+      if (idx[b] == (int64_t)k) s += dinp[((size_t)b * HW + p) * C + ch];
   }
   red[g][il] = s;
   __syncthreads();
@@ -284,6 +285,29 @@ extern "C" int pcg_embed_concat_bwd(const float* dinp, const int64_t* idx, float
   hipLaunchKernelGGL(embed_concat_bwd_kernel, dim3(ew_blocks(work)), dim3(256), 0, (hipStream_t)stream, dinp, idx, dtable, dx, B, HW,
                      C, K, accumulate);
   return launch_status("embed_concat_bwd_kernel");
+}
+
+namespace pcg { namespace {
+__global__ void __launch_bounds__(256) gather_channel_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, int ch) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) dst[i] = src[(size_t)i * C + ch];
+}
+} }
+// dst[r] = src[r][ch] for a [rows][C] tensor: the OHWI weight of ONE input channel of a convolution (conv_in's label-map channel: the
+// only one of its three input channels whose gradient anybody reads, models/generator.py:73-74)
+extern "C" int pcg_gather_channel(const float* src, float* dst, int32_t rows, int32_t C, int32_t ch, pcg_stream_t stream) {
+  PCG_REQUIRE(src && dst && rows > 0 && C > 0 && ch >= 0 && ch < C, "pcg_gather_channel: bad arguments");
+  hipLaunchKernelGGL(gather_channel_kernel, dim3((unsigned)((rows + 255) / 256 > 1024 ? 1024 : (rows + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, rows, C, ch);
+  return launch_status("gather_channel_kernel");
+}
+// The embedding-table gradient alone, from channel `ch` of a [B][HW][C] gradient (pcg_embed_concat_bwd reads channel 1 of C >= 2):
+// dtable[k][p] (+)= sum over b with idx[b] == k, ascending b, of dinp[b][p][ch]
+extern "C" int pcg_embed_table_grad(const float* dinp, const int64_t* idx, float* dtable, int32_t B, int32_t HW, int32_t C, int32_t ch,
+                                    int32_t K, int accumulate, pcg_stream_t stream) {
+  PCG_REQUIRE(dinp && idx && dtable && B > 0 && HW > 0 && K > 0 && C >= 1 && ch >= 0 && ch < C, "pcg_embed_table_grad: bad arguments");
+  hipLaunchKernelGGL(embed_table_grad_kernel, dim3((unsigned)(((size_t)K * HW + 15) / 16)), dim3(256), 0, (hipStream_t)stream, dinp, idx,
+                     dtable, B, HW, C, K, accumulate, ch);
+  return launch_status("embed_table_grad_kernel");
 }
 
 extern "C" int pcg_axpby(float* out, float a, const float* x, float b, const float* y, int64_t n, pcg_stream_t stream) {

@@ -750,6 +750,24 @@ def embed_concat_bwd(dinp, idx, C, K, dtable=None, accumulate=False, need_dx=Fal
     return dx
 
 
+def embed_table_grad(dinp, idx, C, ch, K, dtable, accumulate=False):
+    """dtable[k][p] (+)= sum over the rows b with idx[b] == k of dinp[b][p][ch] (dinp: [B, HW, C])."""
+    _chk(dinp, "dinp"); _chk(dtable, "dtable")
+    B = idx.numel()
+    HW = dinp.numel() // (B * C)
+    check(_lib.load().pcg_embed_table_grad(_p(dinp), _p(idx), _p(dtable), B, HW, C, int(ch), K, int(bool(accumulate)), _stream()),
+          "pcg_embed_table_grad")
+
+
+def gather_channel(t, ch):
+    """[..., C] -> [..., 1]: channel `ch` of the last axis as a contiguous tensor (one tiny launch)."""
+    _chk(t, "t")
+    C = t.shape[-1]
+    out = torch.empty(t.shape[:-1] + (1,), dtype=torch.float32, device=t.device)
+    check(_lib.load().pcg_gather_channel(_p(t), _p(out), t.numel() // C, C, int(ch), _stream()), "pcg_gather_channel")
+    return out
+
+
 def axpby(a, x, b=0.0, y=None, out=None):
     _chk(x, "x")
     out = out if out is not None else torch.empty_like(x)

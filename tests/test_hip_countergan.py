@@ -472,3 +472,28 @@ def test_train_countergan_memory_stays_flat_over_an_epoch(pcg):
     assert len(mem) == 20
     grown = max(mem[5:]) - mem[5]
     assert grown <= 4 << 20, f"memory grows over the epoch: {[m >> 20 for m in mem]} MiB"
+
+
+def test_label_channel_grad_input_equals_the_three_channel_form(pcg):
+    """conv_in's grad-input computed for the label-map channel only (the image and mask channels' gradients have no consumer) against
+    the three-channel grad-input + pcg_embed_concat_bwd: the embedding table's gradient to summation-order accuracy, every other
+    gradient bit-identical."""
+    K = pcg.countergan
+    x, y, t, m = (v.to(DEV) for v in CR.synthetic_batch(16, seed=9))
+    grads = {}
+    for flag in (True, False):
+        K.GRAD_INPUT_LABEL_CHANNEL_ONLY = flag
+        try:
+            (G, D, C), _ = _build(pcg, seed=6)
+            raw, masked = G(x, t, m)
+            (raw.square().mean() + masked.abs().mean()).backward()
+            grads[flag] = {n: p.grad.clone() for n, p in G.named_parameters()}
+        finally:
+            K.GRAD_INPUT_LABEL_CHANNEL_ONLY = True
+    for n in grads[True]:
+        if n == "embed.weight":
+            a, b = grads[True][n], grads[False][n]
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, n
+            assert float(b.abs().max()) > 0
+        else:
+            assert torch.equal(grads[True][n], grads[False][n]), n
