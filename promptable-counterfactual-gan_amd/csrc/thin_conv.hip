@@ -143,6 +143,93 @@ __global__ void __launch_bounds__(256) thin_reduce_kernel(ThinP p) {
 #include "thin_fast.inc"
 #include "thin_rows.inc"
 
+// ---- full-window forms (r04) ------------------------------------------------------------------------------------------------
+// A Cout = 1 convolution whose window is the whole input map (DCGAN D's last layer, mnist_dcgan.py:110: Conv2d(512, 1, 4, 1, 0) on a
+// 4x4 map) is one dot product per sample over L = KH*KW*Cin contiguous floats: the NHWC row of x[b] and the OHWI filter run in the
+// same order.  The tap-map kernels above spend 16 taps' worth of loads and FMAs per element on it, 15 of them on padding zeros.
+//   forward     y[b]  = act(bias + <x[b], w>)        one block per sample, lanes stride the row, fixed-order block sum
+//   grad-input  dx[b] = dy[b] * w                    outer product: one thread per float4 column, write-bound
+//   weight grad dw    = sum_b dy[b] * x[b]           column threads over a chunk of samples -> slab rows -> launch_slab_reduce
+constexpr int FULL_ROWS_DX = 8;    // samples per block, grad-input
+constexpr int FULL_ROWS_DW = 16;   // samples per slab row, weight gradient
+
+bool full_window(const pcg_conv_geom* g) {
+  const int64_t L = (int64_t)g->KH * g->KW * g->Cin;
+  return g->Cout == 1 && g->Cin > 3 && g->pad == 0 && g->KH == g->IH && g->KW == g->IW && g->OH == 1 && g->OW == 1 && L % 4 == 0 &&
+         (int64_t)g->B * L < (1ll << 31);
+}
+
+__global__ void __launch_bounds__(256) thin_full_dot_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int B, int L4, int act, float slope) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float4* xr = x + (size_t)b * L4;
+    float a = 0.f;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < L4; i += 8 * 256) {   // 8 independent 16-byte loads of the row in flight
+      float4 v[8], u[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = xr[i + 256 * j]; u[j] = w[i + 256 * j]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a = fmaf(v[j].x, u[j].x, a); a = fmaf(v[j].y, u[j].y, a); a = fmaf(v[j].z, u[j].z, a); a = fmaf(v[j].w, u[j].w, a);
+      }
+    }
+    for (; i < L4; i += 256) {
+      const float4 v = xr[i], u = w[i];
+      a = fmaf(v.x, u.x, a); a = fmaf(v.y, u.y, a); a = fmaf(v.z, u.z, a); a = fmaf(v.w, u.w, a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) y[b] = act_apply(((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.f), act, slope);
+    __syncthreads();
+  }
+}
+
+// grid (ceil(L4/256), ceil(B/FULL_ROWS_DX)); neg = 1: no activation, 0 / slope: ReLU / LeakyReLU on the written value
+__global__ void __launch_bounds__(256) thin_full_outer_kernel(const float* __restrict__ dy, const float4* __restrict__ w, float4* __restrict__ dx, int B,
+                                                              int L4, float neg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L4) return;
+  const float4 u = w[i];
+  const int b0 = blockIdx.y * FULL_ROWS_DX;
+#pragma unroll
+  for (int j = 0; j < FULL_ROWS_DX; ++j) {
+    const int b = b0 + j;
+    if (b >= B) break;
+    const float d = dy[b];
+    float4 o = make_float4(d * u.x, d * u.y, d * u.z, d * u.w);
+    if (neg != 1.f) { o.x = act_neg_scale(o.x, neg); o.y = act_neg_scale(o.y, neg); o.z = act_neg_scale(o.z, neg); o.w = act_neg_scale(o.w, neg); }
+    dx[(size_t)b * L4 + i] = o;
+  }
+}
+
+// grid (ceil(L4/256), ceil(B/FULL_ROWS_DW)); slab row blockIdx.y holds the chunk's sums, samples added in order
+__global__ void __launch_bounds__(256) thin_full_wgrad_kernel(const float4* __restrict__ x, const float* __restrict__ dy, float4* __restrict__ slab, int B,
+                                                              int L4) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L4) return;
+  const int b0 = blockIdx.y * FULL_ROWS_DW;
+  float4 v[FULL_ROWS_DW];
+  float d[FULL_ROWS_DW];
+#pragma unroll
+  for (int j = 0; j < FULL_ROWS_DW; ++j) {
+    const int b = b0 + j;
+    const bool ok = b < B;
+    v[j] = ok ? x[(size_t)b * L4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    d[j] = ok ? dy[b] : 0.f;
+  }
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < FULL_ROWS_DW; ++j) {
+    a.x = fmaf(d[j], v[j].x, a.x); a.y = fmaf(d[j], v[j].y, a.y); a.z = fmaf(d[j], v[j].z, a.z); a.w = fmaf(d[j], v[j].w, a.w);
+  }
+  slab[(size_t)blockIdx.y * L4 + i] = a;
+}
+
 // Each block owns `ppb` iteration pixels; thread (cq, pl) accumulates NT float4 sums over pixels pl, pl+PL, ...
 // then the PL pixel-lanes are summed through LDS in a fixed order and the block writes its slab in dw layout.
 template <int KH, int KW, int CS>
@@ -405,7 +492,11 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     unsigned blocks = (unsigned)((q.npix + 15) / 16);
     if (blocks > 8192) blocks = 8192;
     const int nt = p.KH * p.KW;
-    if (nt == 16) hipLaunchKernelGGL(thin_tapdot_kernel<16>, dim3(blocks), dim3(256), smem, s, q, T);
+    if (p.C == 64 && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0) {
+      unsigned mb = (unsigned)((q.npix + 127) / 128);
+      if (mb > 4096) mb = 4096;
+      hipLaunchKernelGGL(thin_tapdot64_mfma_kernel, dim3(mb), dim3(256), 0, s, q, T);
+    } else if (nt == 16) hipLaunchKernelGGL(thin_tapdot_kernel<16>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 9) hipLaunchKernelGGL(thin_tapdot_kernel<9>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 1) hipLaunchKernelGGL(thin_tapdot_kernel<1>, dim3(blocks), dim3(256), smem, s, q, T);
     else goto generic;
@@ -481,6 +572,12 @@ int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const 
     return fuse ? PCG_OK : pcg_act_fwd(y, (int64_t)g->B * g->OH * g->OW * g->Cout, act, slope, y, (pcg_stream_t)s);
   }
   p.wide = x;                                                 // y thin
+  if (full_window(g) && (((uintptr_t)x | (uintptr_t)w) & 15) == 0) {
+    const int L4 = g->KH * g->KW * g->Cin / 4;
+    hipLaunchKernelGGL(thin_full_dot_kernel, dim3((unsigned)(g->B < 4096 ? g->B : 4096)), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<const float4*>(w), bias, y, g->B, L4, act, slope);
+    return launch_status("thin_full_dot_kernel");
+  }
   return launch_reduce(p, ws, ws_bytes, s);
 }
 
@@ -538,6 +635,13 @@ int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, con
   p.thin = dy;                                                              // dx wide
   const bool fuse = act_is_cheap(act);
   p.act = fuse ? act : PCG_ACT_NONE; p.slope = act_neg_of(p.act, slope);
+  if (full_window(g) && bias_x == nullptr && (((uintptr_t)dx | (uintptr_t)w) & 15) == 0) {
+    const int L4 = g->KH * g->KW * g->Cin / 4;
+    hipLaunchKernelGGL(thin_full_outer_kernel, dim3((unsigned)((L4 + 255) / 256), (unsigned)((g->B + FULL_ROWS_DX - 1) / FULL_ROWS_DX)), dim3(256), 0, s, dy,
+                       reinterpret_cast<const float4*>(w), reinterpret_cast<float4*>(dx), g->B, L4, p.slope);
+    if (int e = launch_status("thin_full_outer_kernel")) return e;
+    return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, (pcg_stream_t)s);
+  }
   if (int e = launch_expand(p, s)) return e;
   return fuse ? PCG_OK : pcg_act_fwd(dx, (int64_t)g->B * g->IH * g->IW * g->Cin, act, slope, dx, (pcg_stream_t)s);
 }
@@ -588,6 +692,7 @@ size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
   size_t patch_bytes = 0;
   if (fill_common(p, g, cin_thin, cin_thin) == PCG_OK && rows_wgrad_ok(p, g, rp, &patch_bytes) && (size_t)rows_wgrad_blocks(rp) > blocks)
     blocks = (size_t)rows_wgrad_blocks(rp);
+  if (full_window(g) && (size_t)((g->B + FULL_ROWS_DW - 1) / FULL_ROWS_DW) > blocks) blocks = (size_t)((g->B + FULL_ROWS_DW - 1) / FULL_ROWS_DW);
   return blocks * (size_t)g->Cout * g->KH * g->KW * g->Cin * sizeof(float);
 }
 
@@ -595,6 +700,18 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
                     size_t ws_bytes, hipStream_t s) {
   ThinP p{};
   const bool cin_thin = thin_is_cin(g);
+  if (full_window(g) && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0) {
+    const int L = g->KH * g->KW * g->Cin, nslabs = (g->B + FULL_ROWS_DW - 1) / FULL_ROWS_DW;
+    const size_t need = (size_t)nslabs * L * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+      set_error("thin conv wgrad: workspace %zu B < required %zu B", ws_bytes, need);
+      return PCG_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(thin_full_wgrad_kernel, dim3((unsigned)((L / 4 + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, reinterpret_cast<const float4*>(x), dy,
+                       reinterpret_cast<float4*>(ws), g->B, L / 4);
+    if (int e = launch_status("thin_full_wgrad_kernel")) return e;
+    return launch_slab_reduce((const float*)ws, dw, (size_t)L, (size_t)L, nslabs, accumulate, s);
+  }
   // iterate over the wide tensor's pixels: dy (output grid) when Cin is thin, x (input grid) when Cout is thin
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/cin_thin)) return e;
   PCG_REQUIRE(p.C / 4 <= 256 && is_pow2(p.C / 4), "thin conv wgrad: wide channel count %d must be 4*2^k <= 1024", p.C);

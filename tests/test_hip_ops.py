@@ -39,7 +39,8 @@ CONV_CASES = [
     (4, 128, 256, 16, 16, 4, 2, 1),    # D3 / G3 adjoint
     (4, 256, 512, 8, 8, 4, 2, 1),      # D4 / G2 adjoint
     (8, 1, 64, 64, 64, 4, 2, 1),       # D1 (thin Cin) / G5 adjoint
-    (8, 512, 1, 4, 4, 4, 1, 0),        # D5 (thin Cout)
+    (8, 512, 1, 4, 4, 4, 1, 0),        # D5 (thin Cout; a full-window layer: dot / outer-product kernels)
+    (37, 512, 1, 4, 4, 4, 1, 0), (19, 64, 1, 4, 4, 4, 1, 0), (5, 128, 1, 5, 5, 5, 1, 0),   # ragged sample counts, a row that is no multiple of 256 float4
     (8, 8192, 100, 1, 1, 1, 1, 0),     # G1 adjoint as a 1x1 conv (K tail: Cout=100)
     # counteRGAN shapes
     (3, 64, 64, 28, 28, 3, 1, 1),      # resblock conv
@@ -124,6 +125,19 @@ def test_conv_fused_activation_equals_conv_then_activation(pcg, B, Cin, Cout, H,
     b_out, b_in = torch.randn(Cout, generator=gen).to(dev()), torch.randn(Cin, generator=gen).to(dev())
     assert torch.equal(ops.conv2d_fwd(g, x, w, b_out, act=act, slope=slope), ops.act_fwd(ops.conv2d_fwd(g, x, w, b_out), act, slope))
     assert torch.equal(ops.conv2d_dgrad(g, dy, w, b_in, act=act, slope=slope), ops.act_fwd(ops.conv2d_dgrad(g, dy, w, b_in), act, slope))
+
+
+@pytest.mark.parametrize("B", [8, 37])
+@pytest.mark.parametrize("act,slope", [(O.ACT_LRELU, 0.2), (O.ACT_RELU, 0.0), (O.ACT_TANH, 0.0)])
+def test_full_window_grad_input_with_activation(pcg, B, act, slope):
+    """The outer-product grad-input of a full-window Cout = 1 layer (no bias) with the activation in the write == plain + pcg_act_fwd."""
+    ops = pcg.ops
+    g = ops.conv_geom(B, 4, 4, 512, 1, 4, 4, 1, 0)
+    gen = torch.Generator().manual_seed(11)
+    w = (torch.randn(1, 4, 4, 512, generator=gen) * 0.1).to(dev()); dy = torch.randn(B, 1, 1, 1, generator=gen).to(dev())
+    plain = ops.conv2d_dgrad(g, dy, w)
+    assert torch.equal(plain, (dy.reshape(B, 1, 1, 1) * w).reshape(B, 4, 4, 512))          # one multiply per element: exact
+    assert torch.equal(ops.conv2d_dgrad(g, dy, w, None, act=act, slope=slope), ops.act_fwd(plain, act, slope))
 
 
 def test_conv_rejects_bad_geometry(pcg):
