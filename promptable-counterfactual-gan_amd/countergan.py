@@ -473,6 +473,14 @@ class Discriminator(FlatModule):
                 d = None
                 continue
             w = ops.ohwi(convs[i].weight.data)
+            if last and not need_x and GRAD_INPUT_LABEL_CHANNEL_ONLY and g.Cin == 2:
+                # D(real) / D(fake.detach()): of the entry conv's two input channels (image, label map: discriminator.py:35-36) only
+                # the label map has a consumer, the embedding table — 9 tap products per pixel instead of 18
+                g1 = ops.conv_geom(g.B, g.IH, g.IW, 1, g.Cout, g.KH, g.KW, g.stride, g.pad)
+                d1 = ops.conv2d_dgrad(g1, d, ops.gather_channel(w, 1))
+                ge, acc = self._grad_view(self.cond_embed.weight)
+                ops.embed_table_grad(d1, cond_idx, 1, 0, self.cond_embed.num_embeddings, ge, accumulate=acc)
+                return None
             res = ops.conv_bwd_data_fused(g, d, w, False, ACT_LRELU, 0.2, a_below=a) if (not last and FUSE_BACKWARD_EPILOGUE) else None
             if res is not None:
                 d, masked = res[0], True
