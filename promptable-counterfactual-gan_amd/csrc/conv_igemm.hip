@@ -1799,7 +1799,7 @@ extern "C" int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_
   buf[0] = 0;
   auto say = [&](const char* fmt, auto... a) { snprintf(buf + strlen(buf), sizeof(buf) - strlen(buf), fmt, a...); };
   if (thin_is_cin(g) || thin_is_cout(g)) {
-    say("thin (Cin or Cout <= 3): no matrix-core launch");
+    say("%s", "thin (Cin or Cout <= 3): no matrix-core launch");
   } else if (op == 0) {
     const int M = g->B * g->OH * g->OW, N = g->Cout, kt = g->KH * g->KW * ceil_div(g->Cin, IG_BK);
     const FwdPlan f = plan_fwd(g, have);

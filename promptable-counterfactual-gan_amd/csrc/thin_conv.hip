@@ -11,6 +11,7 @@
 //   reduce : thin[P][cs] = bias[cs] + sum_{tap} sum_c wide[map(P,tap)][c] * W[tap,cs][c]
 //   wgrad  : dW[tap,cs][c] = sum_P wide[P][c] * thin[map(P,tap)][cs]
 #include "thin_conv.h"
+#include <cstdlib>
 
 namespace pcg {
 namespace {
@@ -349,7 +350,7 @@ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // row-block plan (thin_rows.inc): direct tap map with any stride, or the transposed map with stride 1; the wide grid must be
 // a real image (>= 64 pixels) and the thin tensor addressable with 32-bit byte offsets
-bool rows_plan(const ThinP& p, RowsP& rp, size_t* patch_bytes, int px_per_thread = 16, size_t max_patch_bytes = 40 * 1024) {
+bool rows_plan(const ThinP& p, RowsP& rp, size_t* patch_bytes, int px_per_thread = 16, size_t max_patch_bytes = (size_t)ROWS_MAXP * 256 * sizeof(float)) {
   const bool direct = !p.transposed;
   if (!direct && p.stride != 1) return false;
   const int CQ = p.C / 4;
@@ -405,6 +406,12 @@ int fill_common(ThinP& p, const pcg_conv_geom* g, bool cin_thin, bool iter_on_ou
   return PCG_OK;
 }
 
+// blocks of the row-block expand kernels: every block walks units blockIdx.x, + gridDim.x, ... with the next patch in flight
+unsigned rows_expand_blocks(int nunits) {
+  static const int cap = [] { const char* e = getenv("PCG_ROWS_EXPAND_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  return (unsigned)(nunits < cap ? nunits : cap);
+}
+
 size_t lds_weight_bytes(const ThinP& p) { return (size_t)p.KH * p.KW * p.Cs * p.C * sizeof(float); }
 
 bool fast_ok(const ThinP& p) {
@@ -418,9 +425,9 @@ int launch_expand(ThinP& p, hipStream_t s) {
   RowsP rp{};
   size_t patch_bytes = 0;
   if ((k44 || k33) && (k33 || p.Cs == 1) && rows_plan(p, rp, &patch_bytes)) {
-    const size_t sm = smem > patch_bytes ? smem : patch_bytes;
+    const size_t two = 2 * ((patch_bytes + 15) & ~(size_t)15), sm = smem > two ? smem : two;
     const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
-    const unsigned blocks = (unsigned)(rp.nunits < 4096 ? rp.nunits : 4096);
+    const unsigned blocks = rows_expand_blocks(rp.nunits);
 #define PCG_ROWS_EXPAND_CASE(KH_, KW_, CS_)                                                                                  \
     if (p.KH == KH_ && p.Cs == CS_) {                                                                                         \
       hipLaunchKernelGGL((thin_rows_expand_kernel<KH_, KW_, CS_>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes);      \
@@ -620,16 +627,16 @@ int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, 
   RowsP rp{};
   size_t patch_bytes = 0;
   rows_plan(p, rp, &patch_bytes);
-  const size_t smem = lds_weight_bytes(p), sm = smem > patch_bytes ? smem : patch_bytes;
+  const size_t smem = lds_weight_bytes(p), two = 2 * ((patch_bytes + 15) & ~(size_t)15), sm = smem > two ? smem : two;
   const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
-  const unsigned blocks = (unsigned)(rp.nunits < (int)THIN_BN_BLOCKS ? rp.nunits : (int)THIN_BN_BLOCKS);
+  const unsigned blocks = rows_expand_blocks(rp.nunits) < THIN_BN_BLOCKS ? rows_expand_blocks(rp.nunits) : THIN_BN_BLOCKS;
   double* partial = (double*)ws;
   float* coef = reinterpret_cast<float*>(partial + (size_t)THIN_BN_BLOCKS * 2 * p.C);
   ThinBnBwd bn{z, mean, invstd, gamma, beta, coef, act_neg_of(act, slope), partial};
   hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, false>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
   if (int e = launch_status("thin_rows_expand_bn_kernel(sums)")) return e;
   if (int e = launch_bn_bwd_finalize(partial, (int)blocks, (int64_t)g->B * g->OH * g->OW, p.C, gamma, invstd, coef, dgamma, dbeta, accumulate, s)) return e;
-  const unsigned ablocks = (unsigned)(rp.nunits < 4096 ? rp.nunits : 4096);
+  const unsigned ablocks = rows_expand_blocks(rp.nunits);
   hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, true>), dim3(ablocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
   return launch_status("thin_rows_expand_bn_kernel(apply)");
 }
