@@ -1814,7 +1814,7 @@ extern "C" int pcg_conv_plan_describe(const pcg_conv_geom* g, int32_t op, int32_
     if (dgrad_as_gemm(g, have)) {
       const int M = g->B * g->OH * g->OW, N = g->KH * g->KW * g->Cin, kt = ceil_div(g->Cout, IG_BK), tiles = ceil_div(M, 128) * ceil_div(N, 128);
       SkPlan sk{};
-      say("GEMM + col2im: ");
+      say("%s", "GEMM + col2im: ");
       if (have && plan_sk_shape(tiles, kt, &sk)) say("stream-K: %d whole tiles + %d tiles x %d k-tiles over %d ranges", sk.dp_tiles, sk.sk_tiles, kt, sk.sk_blocks);
       else say("128x128 tiles: %d", tiles);
     } else {
