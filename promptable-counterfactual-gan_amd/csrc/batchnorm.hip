@@ -5,6 +5,7 @@
 // float atomics).  Replaces nn.BatchNorm2d + nn.ReLU/nn.LeakyReLU at mnist_dcgan.py:77-87,103-110 and
 // conditional_counteRGAN/mnist/models/generator.py:12-20; [torch] semantics cited in pcgan_hip.h.
 #include "pcg_common.h"
+#include <cstdlib>
 
 namespace pcg {
 // dp_rccl.hip: exact global-batch BatchNorm under data parallelism
@@ -438,12 +439,32 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 // ---- fast paths: (C/4) is a power of two <= 256, so a thread's channel quad is the same in every grid-stride step:
 // the per-channel coefficients live in registers and the loop body is pure streaming (two 16-byte accesses per tensor in
 // flight per thread).
+// A/B knobs of the streaming passes (environment, read once): grid cap, loads in flight per thread, non-temporal output stores.
+// PCG_BN_NT: 0 never, 1 always, unset: when the tensor is at least PCG_BN_NT_MB (default 160) MB — measured r04 (scripts/probes/bn_pass_probe.py):
+// a 205 MB CounteRGAN activation applies in 63.7 us with non-temporal stores against 82.4 without (its input and output together
+// exceed the 256 MB Infinity Cache, and ordinary stores evict the input lines ahead of their reads); 134 MB DCGAN tensors: no change.
+struct BnTune { int blocks, depth, nt; size_t nt_bytes; };
+static const BnTune& bn_tune() {
+  static const BnTune t = [] {
+    auto env = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
+    return BnTune{env("PCG_BN_BLOCKS", 4096), env("PCG_BN_DEPTH", 2), env("PCG_BN_NT", -1), (size_t)env("PCG_BN_NT_MB", 160) * 1000000u};
+  }();
+  return t;
+}
+static bool bn_use_nt(size_t n4) { const BnTune& t = bn_tune(); return t.nt < 0 ? n4 * 16 >= t.nt_bytes : t.nt != 0; }
+template <bool NT>
+__device__ __forceinline__ void bn_store4(float4* at, const float4& v) {
+  typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (NT) __builtin_nontemporal_store(nt_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f32x4*>(at)); else *at = v;
+}
+
+template <int DEPTH, bool NT>
 __global__ void __launch_bounds__(256) bn_apply_act_fast_kernel(const float4* __restrict__ x, size_t n4, int C,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 float var_eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int act, float slope,
                                                                 const float4* __restrict__ residual, float alpha,
-                                                                float4* __restrict__ y, size_t group_n4 = 0) {
+                                                                float4* __restrict__ y, size_t group_n4) {
   if (group_n4) {      // grouped form: blockIdx.y = group; its rows are contiguous, its statistics the y-th [C] row of mean / invstd
     const size_t g = blockIdx.y;
     x += g * group_n4; y += g * group_n4; if (residual) residual += g * group_n4;
@@ -466,23 +487,35 @@ __global__ void __launch_bounds__(256) bn_apply_act_fast_kernel(const float4* __
     return q;
   };
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto put = [&](size_t at, const float4& v) { bn_store4<NT>(y + at, v); };
   size_t i = gtid;
-  for (; i + stride < n4; i += 2 * stride) {
-    const float4 q0 = x[i], q1 = x[i + stride];
-    const float4 r0 = residual ? residual[i] : zero, r1 = residual ? residual[i + stride] : zero;
-    y[i] = one(q0, r0);
-    y[i + stride] = one(q1, r1);
+  for (; i + (DEPTH - 1) * stride < n4; i += DEPTH * stride) {
+    float4 q[DEPTH], r[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) { q[j] = x[i + j * stride]; r[j] = residual ? residual[i + j * stride] : zero; }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) put(i + j * stride, one(q[j], r[j]));
   }
-  if (i < n4) y[i] = one(x[i], residual ? residual[i] : zero);
+  for (; i < n4; i += stride) put(i, one(x[i], residual ? residual[i] : zero));
+}
+template <class... A>
+static void launch_bn_apply_fast(dim3 grid, hipStream_t s, size_t n4_all, A... a) {
+  const BnTune& t = bn_tune();
+  const bool nt = bn_use_nt(n4_all);
+  if (t.depth == 4 && nt) hipLaunchKernelGGL((bn_apply_act_fast_kernel<4, true>), grid, dim3(256), 0, s, a...);
+  else if (t.depth == 4) hipLaunchKernelGGL((bn_apply_act_fast_kernel<4, false>), grid, dim3(256), 0, s, a...);
+  else if (nt) hipLaunchKernelGGL((bn_apply_act_fast_kernel<2, true>), grid, dim3(256), 0, s, a...);
+  else hipLaunchKernelGGL((bn_apply_act_fast_kernel<2, false>), grid, dim3(256), 0, s, a...);
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
                                                                 const float4* __restrict__ y, size_t n4, int C,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ coef, int act, float slope,
                                                                 float dy_scale, float4* __restrict__ dx, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, double* __restrict__ colpart,
-                                                                size_t group_n4 = 0) {
+                                                                size_t group_n4) {
   if (group_n4) {      // grouped form (no fused column sums): blockIdx.y = group, coef is [G][3][C]
     const size_t g = blockIdx.y;
     dy += g * group_n4; x += g * group_n4; dx += g * group_n4; if (y) y += g * group_n4;
@@ -522,13 +555,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
     const float4 g0 = dy[i], g1 = dy[i + stride], x0 = x[i], x1 = x[i + stride];
     const float4 y0 = (has_act && !premask) ? y[i] : ones, y1 = (has_act && !premask) ? y[i + stride] : ones;
     const float4 o0 = one(g0, x0, y0), o1 = one(g1, x1, y1);
-    dx[i] = o0;
-    dx[i + stride] = o1;
+    bn_store4<NT>(dx + i, o0);
+    bn_store4<NT>(dx + i + stride, o1);
     if (colpart) { tally(o0); tally(o1); }
   }
   if (i < n4) {
     const float4 o = one(dy[i], x[i], (has_act && !premask) ? y[i] : ones);
-    dx[i] = o;
+    bn_store4<NT>(dx + i, o);
     if (colpart) tally(o);
   }
   if (colpart) {   // kernel-uniform
@@ -546,6 +579,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fast_kernel(const float4* __
       }
     }
   }
+}
+
+template <class... A>
+static void launch_bn_bwd_apply_fast(dim3 grid, hipStream_t s, size_t n4_all, A... a) {
+  if (bn_use_nt(n4_all)) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<true>), grid, dim3(256), 0, s, a...);
+  else hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<false>), grid, dim3(256), 0, s, a...);
 }
 
 bool fast_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
@@ -669,11 +708,11 @@ extern "C" int pcg_bn_apply_act(const float* x, int64_t rows, int32_t C, const f
   const size_t n = (size_t)rows * C;
   if (fast_channels(C) && al16(x) && al16(y) && al16(residual)) {
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > (unsigned)bn_tune().blocks) blocks = (unsigned)bn_tune().blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_apply_act_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(x), n / 4, C, mean,
-                       invstd, var_eps, gamma, beta, act, slope, reinterpret_cast<const float4*>(residual), alpha,
-                       reinterpret_cast<float4*>(y));
+    launch_bn_apply_fast(dim3(blocks), s, n / 4, reinterpret_cast<const float4*>(x), n / 4, C, mean,
+                         invstd, var_eps, gamma, beta, act, slope, reinterpret_cast<const float4*>(residual), alpha,
+                         reinterpret_cast<float4*>(y), (size_t)0);
   } else if (C % 4 == 0 && al16(x) && al16(y) && al16(residual))
     hipLaunchKernelGGL(bn_apply_act_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), 0, s, x, n, C, mean, invstd, var_eps, gamma, beta, act, slope, residual, alpha, y);
   else
@@ -727,9 +766,10 @@ static int bn_act_bwd_impl(const float* dy, const float* x, const float* y, int6
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
     if (blocks > (fused_col ? COL_SUM_BLOCKS : COL_MAX_BLOCKS)) blocks = fused_col ? COL_SUM_BLOCKS : COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dy),
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
-                       (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx), gamma, beta, fused_col ? colpart : nullptr);
+    launch_bn_bwd_apply_fast(dim3(blocks), s, n / 4, reinterpret_cast<const float4*>(dy),
+                             reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y), n / 4, C, mean, invstd,
+                             (const float*)coef, act, slope, dy_scale, reinterpret_cast<float4*>(dx), gamma, beta, fused_col ? colpart : (double*)nullptr,
+                             (size_t)0);
     if (fused_col) {
       if (int e = launch_status("bn_bwd_apply_kernel")) return e;
       hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads((int)blocks)), 0, s, (const double*)colpart,
@@ -813,9 +853,9 @@ static int bn_bwd_partial_impl(const float* dm, const float* x, int64_t rows, in
     unsigned blocks = (unsigned)((n / 4 + 511) / 512);
     if (blocks > (dcol ? COL_SUM_BLOCKS : COL_MAX_BLOCKS)) blocks = dcol ? COL_SUM_BLOCKS : COL_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
-                       reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, PCG_ACT_NONE,
-                       0.f, dm_scale, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr, dcol ? colpart : nullptr);
+    launch_bn_bwd_apply_fast(dim3(blocks), s, n / 4, reinterpret_cast<const float4*>(dm),
+                             reinterpret_cast<const float4*>(x), (const float4*)nullptr, n / 4, C, mean, invstd, (const float*)coef, (int)PCG_ACT_NONE,
+                             0.f, dm_scale, reinterpret_cast<float4*>(dx), gamma, (const float*)nullptr, dcol ? colpart : (double*)nullptr, (size_t)0);
     if (int e = launch_status("bn_bwd_apply_kernel")) return e;
     if (dcol) {
       hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads((int)blocks)), 0, s, (const double*)colpart,
@@ -894,7 +934,7 @@ static bool grouped_shape_ok(int64_t rows, int32_t C, int32_t groups) {
 }
 static unsigned grouped_apply_blocks(size_t n4_group) {
   unsigned blocks = (unsigned)((n4_group + 511) / 512);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (unsigned)bn_tune().blocks) blocks = (unsigned)bn_tune().blocks;
   return blocks < 1 ? 1 : blocks;
 }
 
@@ -905,9 +945,9 @@ extern "C" int pcg_bn_apply_act_g(const float* x, int64_t rows, int32_t C, const
               "pcg_bn_apply_act_g: needs rows %% groups == 0, C / 4 a power of two <= 256 and 16-byte aligned tensors (rows %lld, C %d, groups %d)",
               (long long)rows, C, groups);
   const size_t n4g = (size_t)(rows / groups) * C / 4;
-  hipLaunchKernelGGL(bn_apply_act_fast_kernel, dim3(grouped_apply_blocks(n4g), groups), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(x), n4g, C, mean, invstd, -1.f, gamma, beta, act, slope, (const float4*)nullptr, 1.f,
-                     reinterpret_cast<float4*>(y), n4g);
+  launch_bn_apply_fast(dim3(grouped_apply_blocks(n4g), groups), (hipStream_t)stream, n4g * groups,
+                       reinterpret_cast<const float4*>(x), n4g, C, mean, invstd, -1.f, gamma, beta, act, slope, (const float4*)nullptr, 1.f,
+                       reinterpret_cast<float4*>(y), n4g);
   return launch_status("bn_apply_act_fast_kernel");
 }
 
@@ -922,9 +962,9 @@ static int launch_bwd_finalize_apply_g(const float* dm, const float* x, int64_t 
                      seg_stride, C, 1.0 / (double)rows_g, gamma, invstd, coef, dgamma, dbeta, accumulate);
   if (int e = launch_status("bn_bwd_finalize_g_kernel")) return e;
   const size_t n4g = (size_t)rows_g * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_fast_kernel, dim3(grouped_apply_blocks(n4g), groups), dim3(256), 0, s, reinterpret_cast<const float4*>(dm),
-                     reinterpret_cast<const float4*>(x), (const float4*)nullptr, n4g, C, mean, invstd, (const float*)coef, act, slope, 1.f,
-                     reinterpret_cast<float4*>(dx), gamma, beta, (double*)nullptr, n4g);
+  launch_bn_bwd_apply_fast(dim3(grouped_apply_blocks(n4g), groups), s, n4g * groups, reinterpret_cast<const float4*>(dm),
+                           reinterpret_cast<const float4*>(x), (const float4*)nullptr, n4g, C, mean, invstd, (const float*)coef, act, slope, 1.f,
+                           reinterpret_cast<float4*>(dx), gamma, beta, (double*)nullptr, n4g);
   return launch_status("bn_bwd_apply_fast_kernel");
 }
 
