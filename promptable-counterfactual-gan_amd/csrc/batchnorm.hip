@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(FIN_CH * FIN_SL) bn_bwd_finalize_g_kernel(
 // Many partial rows (the conv epilogues leave one per 64 output rows: 12544 for a 1024x28x28 activation) make the finalize a
 // latency-bound loop in a handful of blocks.  Level 1 below sums groups of `rpc` consecutive rows, full rows coalesced, in fp64
 // into out[chunk][cols] (cols = NVAL*C); the finalize kernels then read <= PRE_CHUNKS rows of doubles.  Fixed orders throughout.
-constexpr int PRE_CHUNKS = 256, PRE_MIN_ROWS = 4096;   // below ~4k rows the direct finalize (128 row slices per block) is as fast
+constexpr int PRE_CHUNKS = 256, PRE_MIN_ROWS = 2048;   // a direct finalize of 2048 rows x 128 channels costs 13 us, the two levels 5 + 5 (r04: DCGAN step -0.025 ms); at 1024 rows no gain
 __global__ void __launch_bounds__(256) partial_presum_kernel(const double* __restrict__ partial, int nparts, int cols, int rpc,
                                                              double* __restrict__ out) {
   const int col = blockIdx.y * 256 + threadIdx.x;
