@@ -20,6 +20,7 @@ def main():
         w = torch.randn(Cout, k, k, Cin, device=dev) * 0.02
         dx = torch.empty_like(x); dw = torch.zeros_like(w)
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        p_hi, p_lo = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)   # r04: does a priority order the two grids (tail overlap only)?
 
         def serial():
             ops.conv2d_dgrad(g, dy, w, out=dx)
@@ -34,8 +35,18 @@ def main():
                 ops.conv2d_wgrad(g, x, dy, dw, False)
             cur.wait_stream(s1); cur.wait_stream(s2)
 
+        def prioritized():
+            cur = torch.cuda.current_stream()
+            p_hi.wait_stream(cur); p_lo.wait_stream(cur)
+            with torch.cuda.stream(p_hi):
+                ops.conv2d_dgrad(g, dy, w, out=dx)
+            with torch.cuda.stream(p_lo):
+                ops.conv2d_wgrad(g, x, dy, dw, False)
+            cur.wait_stream(p_hi); cur.wait_stream(p_lo)
+
         res = {}
-        for label, fn in (("serial", serial), ("two streams", overlapped), ("serial", serial), ("two streams", overlapped)):
+        for label, fn in (("serial", serial), ("two streams", overlapped), ("priority", prioritized), ("serial", serial), ("two streams", overlapped),
+                          ("priority", prioritized)):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -46,7 +57,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             res.setdefault(label, []).append(e0.elapsed_time(e1) / 20 * 1e3)
-        print(f"{name}: grad-input + weight gradient  serial {min(res['serial']):.1f} us | on two streams {min(res['two streams']):.1f} us", flush=True)
+        print(f"{name}: grad-input + weight gradient  serial {min(res['serial']):.1f} us | on two streams {min(res['two streams']):.1f} us | "
+              f"high- / low-priority streams {min(res['priority']):.1f} us", flush=True)
 
 
 if __name__ == "__main__":
