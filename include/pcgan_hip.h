@@ -311,6 +311,19 @@ int pcg_conv2d_fwd_bnbwd_thin(const pcg_conv_geom* g, const float* x, const floa
                               const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dz,
                               float* dgamma /*nullable*/, float* dbeta /*nullable*/, int accumulate, void* workspace,
                               size_t workspace_bytes, pcg_stream_t stream);
+/* The same idea for a FULL-WINDOW Cout = 1 convolution above a BatchNorm layer (r04): DCGAN D's last conv, Conv2d(512, 1, 4, 1, 0) on
+ * a 4x4 map (mnist_dcgan.py:110), whose grad-input dy[b] * w[hw][c] is ONE multiply per element; the layer below is Conv -> BatchNorm2d
+ * -> LeakyReLU (:107-109).  Instead of  outer product (write d) -> column sums (read d, z) -> apply (read d, z; write dz)  the sums
+ * pass reads z only and the apply pass reads z and writes dz.  `groups` side-by-side batches of B / groups samples with their own
+ * statistics (mean / invstd [G][C]; the paired D step, section "grouped batches"); dgamma / dbeta: the groups' sums in group order.
+ * Eligibility (..._ok): Cout = 1, window = input map, KH*KW a divisor of 256, (Cin/4) a multiple of 256/(KH*KW), B / groups a
+ * multiple of 16; not in the exact-BatchNorm data-parallel mode.                                                                */
+int32_t pcg_conv2d_dgrad_bnbwd_full_ok(const pcg_conv_geom* g, int32_t groups);
+size_t pcg_conv2d_dgrad_bnbwd_full_workspace_bytes(const pcg_conv_geom* g, int32_t groups);
+int pcg_conv2d_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dz,
+                                float* dgamma /*nullable*/, float* dbeta /*nullable*/, int accumulate, int32_t groups, void* workspace,
+                                size_t workspace_bytes, pcg_stream_t stream);
 
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */

@@ -627,6 +627,15 @@ int launch_bn_bwd_finalize(const double* partial, int nblocks, int64_t rows, int
                      1.0 / (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate, (const double*)nullptr);
   return launch_status("bn_bwd_finalize_kernel");
 }
+// grouped form: group g's sums are partial rows [g*rows_per_group, (g+1)*rows_per_group); coef [G][3][C], invstd [G][C]
+int launch_bn_bwd_finalize_g(const double* partial, int rows_per_group, int groups, int64_t rows_g, int C, const float* gamma, const float* invstd,
+                             float* coef, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+  PCG_REQUIRE(!dp_sync_bn(), "fused thin BatchNorm backward: not available in the exact global-batch mode");
+  hipLaunchKernelGGL(bn_bwd_finalize_g_kernel<double>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(fin_threads(rows_per_group)), 0, s, partial,
+                     rows_per_group, groups, rows_per_group, rows_per_group * groups, C, 1.0 / (double)rows_g, gamma, invstd, coef, dgamma, dbeta,
+                     accumulate);
+  return launch_status("bn_bwd_finalize_g_kernel");
+}
 int launch_bn_stats_finalize(const double* partial, int nparts, int64_t rows, int C, float eps, float momentum, float* save_mean,
                              float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, hipStream_t s,
                              bool has_presum_tail, const float* gamma, const float* beta, float* coef) {

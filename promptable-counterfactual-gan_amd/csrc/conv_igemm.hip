@@ -1684,6 +1684,26 @@ extern "C" int pcg_conv2d_fwd_bnbwd_thin(const pcg_conv_geom* g, const float* x,
   return thin_conv_fwd_bnbwd(g, x, w, z_below, mean, invstd, gamma, beta, act, slope, dz, dgamma, dbeta, accumulate, workspace, workspace_bytes,
                              (hipStream_t)stream);
 }
+// Grad-input of a full-window Cout = 1 convolution (DCGAN D's last layer, mnist_dcgan.py:110) pushed through the BatchNorm + LeakyReLU backward of
+// the layer below it without being written; groups side-by-side batches with their own statistics (mean / invstd [G][C]).
+extern "C" int32_t pcg_conv2d_dgrad_bnbwd_full_ok(const pcg_conv_geom* g, int32_t groups) {
+  return check_geom(g) == PCG_OK && !pcg::dp_sync_bn() && thin_conv_dgrad_bnbwd_full_ok(g, groups) ? 1 : 0;
+}
+extern "C" size_t pcg_conv2d_dgrad_bnbwd_full_workspace_bytes(const pcg_conv_geom* g, int32_t groups) {
+  return pcg_conv2d_dgrad_bnbwd_full_ok(g, groups) ? thin_conv_dgrad_bnbwd_full_workspace_bytes(g, groups) : 0;
+}
+extern "C" int pcg_conv2d_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const float* w, const float* z_below, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, int act, float slope, float* dz,
+                                           float* dgamma, float* dbeta, int accumulate, int32_t groups, void* workspace, size_t workspace_bytes,
+                                           pcg_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(dy && w && z_below && mean && invstd && gamma && beta && dz, "pcg_conv2d_dgrad_bnbwd_full: null pointer");
+  PCG_REQUIRE(act == PCG_ACT_NONE || act == PCG_ACT_RELU || act == PCG_ACT_LRELU, "pcg_conv2d_dgrad_bnbwd_full: activation %d is not none / ReLU / LeakyReLU", act);
+  PCG_REQUIRE(pcg_conv2d_dgrad_bnbwd_full_ok(g, groups), "pcg_conv2d_dgrad_bnbwd_full: geometry / batch not eligible (pcg_conv2d_dgrad_bnbwd_full_ok)");
+  PCG_REQUIRE((((uintptr_t)z_below | (uintptr_t)dz | (uintptr_t)w) & 15) == 0, "pcg_conv2d_dgrad_bnbwd_full: tensors must be 16-byte aligned");
+  return thin_conv_dgrad_bnbwd_full(g, dy, w, z_below, mean, invstd, gamma, beta, act, slope, dz, dgamma, dbeta, accumulate, groups, workspace,
+                                    workspace_bytes, (hipStream_t)stream);
+}
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 

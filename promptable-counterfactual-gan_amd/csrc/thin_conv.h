@@ -30,6 +30,13 @@ bool thin_conv_dgrad_mask_ok(const pcg_conv_geom* g);
 int thin_conv_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope, float* dx,
                          hipStream_t s);
 
+// grad-input of a full-window Cout = 1 convolution pushed through the BatchNorm + ReLU / LeakyReLU backward of the layer below (r04)
+bool thin_conv_dgrad_bnbwd_full_ok(const pcg_conv_geom* g, int groups);
+size_t thin_conv_dgrad_bnbwd_full_workspace_bytes(const pcg_conv_geom* g, int groups);
+int thin_conv_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const float* w, const float* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int act, float slope, float* dz, float* dgamma, float* dbeta, int accumulate,
+                               int groups, void* ws, size_t ws_bytes, hipStream_t s);
+
 // shared with conv_igemm.hip: dw[i] = (acc ? dw[i] : 0) + sum_z slab[z*stride + i]
 int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s);
 

@@ -231,6 +231,103 @@ __global__ void __launch_bounds__(256) thin_full_wgrad_kernel(const float4* __re
   slab[(size_t)blockIdx.y * L4 + i] = a;
 }
 
+// Full-window grad-input pushed through the BatchNorm(train) + ReLU / LeakyReLU BACKWARD of the layer below without being written (r04):
+// d[b][hw][c] = dy[b] * w[hw][c] is one multiply to recompute, so the chain  outer product (write d) -> column sums (read d, z) -> apply
+// (read d, z; write dz)  becomes  sums (read z) -> finalize -> apply (read z, write dz).  DCGAN: D's last conv above D4's BatchNorm
+// (mnist_dcgan.py:108-110 backward), in the D step with two groups of samples (real | fake: their own statistics, §3.5).
+// Same expressions for the mask (fma(z, sc, sh) > 0), xhat and dz as bn_bwd_apply / FnBnBwd / thin_rows_expand_bn_kernel.
+//   sums : block (cb, chunk) owns FULLBN_CHUNK samples and 256/HW channel quads at ALL HW positions: thread (hw, cq); fp64 tallies per
+//          thread, the HW positions of a channel added through LDS in position order -> one partial row [2][C] per chunk
+//   apply: thread = one float4 column of the [B][L] gradient (fixed filter quad and channel quad), FULLBN_ROWS samples per block
+constexpr int FULLBN_CHUNK = 16, FULLBN_ROWS = 8;
+struct FullBn {
+  const float* dy; const float4* w; const float4* z; const float* mean; const float* invstd; const float* gamma; const float* beta;
+  const float* coef;     // [G][3][C]
+  float neg; int C, HW, Bg;   // Bg: samples per group
+};
+__global__ void __launch_bounds__(256) thin_full_bn_sums_kernel(FullBn q, double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int CQ = q.C >> 2, CQB = 256 / q.HW;
+  const int hw = threadIdx.x / CQB, cq = blockIdx.x * CQB + threadIdx.x % CQB;
+  const int b0 = blockIdx.y * FULLBN_CHUNK, grp = b0 / q.Bg;
+  const float4 w4 = q.w[hw * CQ + cq];
+  const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+  float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = grp * q.C + 4 * cq + e;
+    mu[e] = q.mean[c]; is[e] = q.invstd[c];
+    bn_fold(q.gamma[4 * cq + e], q.beta[4 * cq + e], mu[e], is[e], sc[e], sh[e]);
+  }
+  float4 zv[FULLBN_CHUNK];
+  float dv[FULLBN_CHUNK];
+#pragma unroll
+  for (int j = 0; j < FULLBN_CHUNK; ++j) {
+    zv[j] = q.z[((size_t)(b0 + j) * q.HW + hw) * CQ + cq];
+    dv[j] = q.dy[b0 + j];
+  }
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < FULLBN_CHUNK; ++j) {
+    const float zz[4] = {zv[j].x, zv[j].y, zv[j].z, zv[j].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pre = fmaf(zz[e], sc[e], sh[e]);
+      const float dm = (dv[j] * ww[e]) * (pre > 0.f ? 1.f : q.neg);
+      const float xh = (zz[e] - mu[e]) * is[e];
+      s1[e] += (double)dm; s2[e] += (double)dm * (double)xh;
+    }
+  }
+  double* row = partial + (size_t)blockIdx.y * 2 * q.C;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __syncthreads();
+      red[threadIdx.x] = k ? s2[e] : s1[e];
+      __syncthreads();
+      if (hw == 0) {
+        double t = red[threadIdx.x];
+        for (int j = 1; j < q.HW; ++j) t += red[j * CQB + threadIdx.x];
+        row[(size_t)k * q.C + 4 * cq + e] = t;
+      }
+    }
+}
+__global__ void __launch_bounds__(256) thin_full_bn_apply_kernel(FullBn q, float4* __restrict__ dz, int B, int L4) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= L4) return;
+  const int CQ = q.C >> 2, cq = i4 % CQ;
+  const int b0 = blockIdx.y * FULLBN_ROWS, grp = b0 / q.Bg;
+  const float4 w4 = q.w[i4];
+  const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+  float sc[4], sh[4], mu[4], is[4], k0[4], k1[4], k2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * cq + e;
+    mu[e] = q.mean[grp * q.C + c]; is[e] = q.invstd[grp * q.C + c];
+    bn_fold(q.gamma[c], q.beta[c], mu[e], is[e], sc[e], sh[e]);
+    const float* cg = q.coef + (size_t)grp * 3 * q.C;
+    k0[e] = cg[c]; k1[e] = cg[q.C + c]; k2[e] = cg[2 * q.C + c];
+  }
+#pragma unroll
+  for (int j = 0; j < FULLBN_ROWS; ++j) {
+    const int b = b0 + j;
+    if (b >= B) break;
+    const float4 zv = q.z[(size_t)b * L4 + i4];
+    const float d = q.dy[b];
+    const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pre = fmaf(zz[e], sc[e], sh[e]);
+      const float dm = (d * ww[e]) * (pre > 0.f ? 1.f : q.neg);
+      const float xh = (zz[e] - mu[e]) * is[e];
+      o[e] = k0[e] * (dm - k1[e] - xh * k2[e]);
+    }
+    dz[(size_t)b * L4 + i4] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // Each block owns `ppb` iteration pixels; thread (cq, pl) accumulates NT float4 sums over pixels pl, pl+PL, ...
 // then the PL pixel-lanes are summed through LDS in a fixed order and the block writes its slab in dw layout.
 template <int KH, int KW, int CS>
@@ -682,6 +779,41 @@ int thin_conv_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w
   p.w = w; p.bias = nullptr; p.out = dx; p.thin = dy; p.act = PCG_ACT_NONE; p.slope = 0.f;
   p.mask_src = a_below; p.mask_neg = act_neg_of(act, slope);
   return launch_expand(p, s);
+}
+
+int launch_bn_bwd_finalize_g(const double* partial, int rows_per_group, int groups, int64_t rows_g, int C, const float* gamma, const float* invstd,
+                             float* coef, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+
+// full-window grad-input through the BatchNorm backward below it (thin_full_bn_*_kernel); groups side-by-side batches of B / groups samples
+bool thin_conv_dgrad_bnbwd_full_ok(const pcg_conv_geom* g, int groups) {
+  if (!full_window(g) || groups < 1 || groups > 8 || g->B % groups) return false;
+  const int HW = g->KH * g->KW, CQ = g->Cin / 4;
+  if (g->Cin % 4 || HW > 256 || 256 % HW) return false;
+  const int CQB = 256 / HW;
+  return CQ % CQB == 0 && (g->B / groups) % FULLBN_CHUNK == 0 && g->B / FULLBN_CHUNK <= 65535;
+}
+size_t thin_conv_dgrad_bnbwd_full_workspace_bytes(const pcg_conv_geom* g, int groups) {
+  return (size_t)(g->B / FULLBN_CHUNK) * 2 * g->Cin * sizeof(double) + (size_t)groups * 3 * g->Cin * sizeof(float);
+}
+int thin_conv_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const float* w, const float* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int act, float slope, float* dz, float* dgamma, float* dbeta, int accumulate,
+                               int groups, void* ws, size_t ws_bytes, hipStream_t s) {
+  PCG_REQUIRE(thin_conv_dgrad_bnbwd_full_ok(g, groups), "full-window grad-input + BatchNorm backward: geometry / batch not eligible");
+  PCG_REQUIRE(ws && ws_bytes >= thin_conv_dgrad_bnbwd_full_workspace_bytes(g, groups), "full-window grad-input + BatchNorm backward: workspace too small");
+  const int C = g->Cin, HW = g->KH * g->KW, L4 = HW * C / 4, nchunks = g->B / FULLBN_CHUNK, Bg = g->B / groups;
+  double* partial = (double*)ws;
+  float* coef = reinterpret_cast<float*>(partial + (size_t)nchunks * 2 * C);
+  FullBn q{dy, reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(z), mean, invstd, gamma, beta, coef, act_neg_of(act, slope), C, HW, Bg};
+  hipLaunchKernelGGL(thin_full_bn_sums_kernel, dim3((unsigned)((C / 4) / (256 / HW)), (unsigned)nchunks), dim3(256), 0, s, q, partial);
+  if (int e = launch_status("thin_full_bn_sums_kernel")) return e;
+  if (groups == 1) {
+    if (int e = launch_bn_bwd_finalize(partial, nchunks, (int64_t)g->B * HW, C, gamma, invstd, coef, dgamma, dbeta, accumulate, s)) return e;
+  } else {
+    if (int e = launch_bn_bwd_finalize_g(partial, nchunks / groups, groups, (int64_t)Bg * HW, C, gamma, invstd, coef, dgamma, dbeta, accumulate, s)) return e;
+  }
+  hipLaunchKernelGGL(thin_full_bn_apply_kernel, dim3((unsigned)((L4 + 255) / 256), (unsigned)((g->B + FULLBN_ROWS - 1) / FULLBN_ROWS)), dim3(256), 0, s, q,
+                     reinterpret_cast<float4*>(dz), g->B, L4);
+  return launch_status("thin_full_bn_apply_kernel");
 }
 
 size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g) {

@@ -554,7 +554,9 @@ class SequentialConvNet(FlatModule):
                 if bn.weight.requires_grad:
                     dg, acc = self._grad_view(bn.weight)
                     db, _ = self._grad_view(bn.bias)
-                if fused is not None:
+                if fused is not None and fused[0] == "done":
+                    dz = d               # the full-window layer above pushed its gradient through this BatchNorm already
+                elif fused is not None:
                     dz = ops.bn_bwd_partial_g(d, z, C, mean, invstd, bn.weight.data, fused[1], fused[2], fused[3], dg, db, acc, G, out=d)
                 else:
                     dz = ops.bn_act_bwd_g(d, z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, dg, db, acc, G,
@@ -603,7 +605,16 @@ class SequentialConvNet(FlatModule):
                     if res is not None:
                         d, fused = res[0], ("mask",)
                         continue
+            if (self.fuse_backward_epilogue and lo.bn is not None and lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU) and not lo_eval and zl is not None
+                    and lo.bn.weight.requires_grad and self.fuse_full_window_bn and ops.full_dgrad_bn_bwd_ok(g, G)):
+                dgl, accl = self._grad_view(lo.bn.weight)
+                dbl, _ = self._grad_view(lo.bn.bias)
+                d = ops.full_dgrad_bn_bwd(g, dz, w, zl, ml, il, lo.bn.weight.data, lo.bn.bias.data, lo.act, lo.slope, dgl, dbl, accl, groups=G)
+                fused = ("done",)
+                continue
             d = ops.conv2d_dgrad(g, dz, w)
+
+    fuse_full_window_bn = True   # A/B: a full-window one-channel conv's grad-input through the BatchNorm backward below it, unwritten (pcg_conv2d_dgrad_bnbwd_full)
 
     wgrad_stream = None      # opt-in A/B: a second HIP stream for the weight gradients (they and the grad-input of a layer both need only dz)
 
@@ -721,6 +732,19 @@ class SequentialConvNet(FlatModule):
                 if res is not None:
                     continue
             if not b.transposed:
+                lo = self._blocks[idx - 1] if not last else None
+                if (lo is not None and self.fuse_backward_epilogue and lo.bn is not None and lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+                        and not saved[idx - 1][6] and saved[idx - 1][2] is not None and lo.bn.weight.requires_grad and need_p
+                        and self.fuse_full_window_bn and ops.full_dgrad_bn_bwd_ok(g)):
+                    # a full-window one-channel convolution above a BatchNorm layer (D5 above D4): its grad-input — one multiply per
+                    # element — goes through that BatchNorm's backward without being written
+                    _, _, zl, ml, il, _, _, _ = saved[idx - 1]
+                    dgl, accl = self._grad_view(lo.bn.weight)
+                    dbl, _ = self._grad_view(lo.bn.bias)
+                    d = ops.full_dgrad_bn_bwd(g, dz, _w_ohwi(c.weight.data), zl, ml, il, lo.bn.weight.data, lo.bn.bias.data, lo.act, lo.slope,
+                                              dgl, dbl, accl)
+                    fused = ("done",)
+                    continue
                 d = ops.conv2d_dgrad(g, dz, _w_ohwi(c.weight.data))
             else:
                 lo = self._blocks[idx - 1] if not last else None

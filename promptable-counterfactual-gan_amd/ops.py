@@ -662,6 +662,24 @@ def bn_act_bwd_g(dy, x, C, mean, invstd, gamma, beta, act, slope, dgamma, dbeta,
     return dx
 
 
+def full_dgrad_bn_bwd_ok(g, groups=1):
+    return bool(_lib.load().pcg_conv2d_dgrad_bnbwd_full_ok(ctypes.byref(g), int(groups)))
+
+
+def full_dgrad_bn_bwd(g, dy, w, z_below, mean, invstd, gamma, beta, act, slope, dgamma, dbeta, accumulate, groups=1):
+    """conv2d_dgrad(g, dy, w) of a full-window Cout = 1 layer pushed through the BatchNorm + activation backward of the layer below
+    without being written (pcg_conv2d_dgrad_bnbwd_full).  Returns dz [B, IH, IW, Cin]; mean / invstd [groups][C]."""
+    _chk(dy, "dy"); _chk(w, "w"); _chk(z_below, "z_below")
+    assert z_below.numel() == g.B * g.IH * g.IW * g.Cin and dy.numel() == g.B
+    dz = torch.empty_like(z_below)
+    lib = _lib.load()
+    ws = workspace(lib.pcg_conv2d_dgrad_bnbwd_full_workspace_bytes(ctypes.byref(g), int(groups)), dy.device)
+    check(lib.pcg_conv2d_dgrad_bnbwd_full(ctypes.byref(g), _p(dy), _p(w), _p(z_below), _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+                                          float(slope), _p(dz), _p(dgamma), _p(dbeta), int(bool(accumulate)), int(groups), _p(ws), ws.numel(),
+                                          _stream()), "pcg_conv2d_dgrad_bnbwd_full")
+    return dz
+
+
 def thin_fwd_bn_bwd_ok(g):
     return bool(_lib.load().pcg_conv2d_fwd_bnbwd_thin_ok(ctypes.byref(g)))
 

@@ -4,6 +4,7 @@
   python scripts/step_ab.py --model dcgan --ab edge_prio=0,2 [--rounds 6 --steps 10]
   python scripts/step_ab.py --model countergan --ab edge_prio=0,2
   python scripts/step_ab.py --model dcgan --ab pair=0,1          (pair: dcgan.train_step(pair=...) — the batched real + fake D pass)
+  python scripts/step_ab.py --model dcgan --ab fullbn=0,1        (SequentialConvNet.fuse_full_window_bn)
 
 Per variant the step is captured as its own HIP graph (kernel arguments, tuning included, are baked in at capture), then the graphs
 are replayed in alternating rounds; prints min / median ms per step of every variant.  Boxes differ by up to 20 % and drift within a
@@ -70,12 +71,18 @@ def main():
         elif key == "overlap":           # nn.SequentialConvNet.wgrad_overlap (class switch: baked into the graph at capture)
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.wgrad_overlap = "bn" if v else None
+        elif key == "fullbn":            # nn.SequentialConvNet.fuse_full_window_bn: D5's grad-input through D4's BatchNorm backward unwritten
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.fuse_full_window_bn = bool(v)
         else:
             ops.tune(key, v)
         graphs[v] = (build_dcgan if a.model == "dcgan" else build_countergan)(dev, batch, variant)
         if key == "overlap":
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.wgrad_overlap = None
+        elif key == "fullbn":
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.fuse_full_window_bn = True
         elif key != "pair":
             ops.tune(key, -1)
     res = {v: [] for v in vals}

@@ -140,6 +140,40 @@ def test_full_window_grad_input_with_activation(pcg, B, act, slope):
     assert torch.equal(ops.conv2d_dgrad(g, dy, w, None, act=act, slope=slope), ops.act_fwd(plain, act, slope))
 
 
+@pytest.mark.parametrize("B,groups", [(32, 1), (64, 2), (48, 3)])
+@pytest.mark.parametrize("act,slope", [(O.ACT_LRELU, 0.2), (O.ACT_RELU, 0.0)])
+def test_full_window_grad_input_through_batchnorm_backward(pcg, B, groups, act, slope):
+    """pcg_conv2d_dgrad_bnbwd_full == conv2d_dgrad followed by the BatchNorm + activation backward, group by group (the column sums are
+    fp64 in both; only their order differs)."""
+    ops = pcg.ops
+    C, Bg = 512, B // groups
+    g = ops.conv_geom(B, 4, 4, C, 1, 4, 4, 1, 0)
+    assert ops.full_dgrad_bn_bwd_ok(g, groups) and not ops.full_dgrad_bn_bwd_ok(ops.conv_geom(B + 1, 4, 4, C, 1, 4, 4, 1, 0), 1)
+    gen = torch.Generator().manual_seed(5 + B)
+    z = (torch.randn(B, 4, 4, C, generator=gen) * 1.3 + 0.2).to(dev()); w = (torch.randn(1, 4, 4, C, generator=gen) * 0.1).to(dev())
+    dy = torch.randn(B, 1, 1, 1, generator=gen).to(dev())
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=gen)).to(dev()), (0.1 * torch.randn(C, generator=gen)).to(dev())
+    zg = z.reshape(groups, Bg * 16, C)
+    mean = zg.mean(1).contiguous(); invstd = (1.0 / torch.sqrt(zg.var(1, unbiased=False) + 1e-5)).contiguous()
+    dg_ref, db_ref = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    ref = []
+    for k in range(groups):
+        gk = ops.conv_geom(Bg, 4, 4, C, 1, 4, 4, 1, 0)
+        d = ops.conv2d_dgrad(gk, dy[k * Bg:(k + 1) * Bg].contiguous(), w)
+        ref.append(ops.bn_act_bwd(d, z[k * Bg:(k + 1) * Bg].contiguous(), None, C, mean[k].contiguous(), invstd[k].contiguous(), gamma, act, slope,
+                                  dg_ref, db_ref, k > 0, beta=beta))
+    ref = torch.cat(ref)
+    dg, db = torch.full((C,), 7.0, device=dev()), torch.full((C,), -7.0, device=dev())
+    out = ops.full_dgrad_bn_bwd(g, dy, w, z, mean, invstd, gamma, beta, act, slope, dg, db, False, groups=groups)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-6 * scale
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * dg_ref.abs().max().item())
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * db_ref.abs().max().item())
+    # accumulate: a second call adds into dgamma / dbeta
+    ops.full_dgrad_bn_bwd(g, dy, w, z, mean, invstd, gamma, beta, act, slope, dg, db, True, groups=groups)
+    np.testing.assert_allclose(dg.cpu().numpy(), 2 * dg_ref.cpu().numpy(), rtol=2e-5, atol=4e-6 * dg_ref.abs().max().item())
+
+
 def test_conv_rejects_bad_geometry(pcg):
     ops = pcg.ops
     g = ops.conv_geom(2, 8, 8, 8, 8, 4, 4, 2, 1)
