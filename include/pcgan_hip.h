@@ -87,6 +87,15 @@ int pcg_conv2d_fwd_act(const pcg_conv_geom* g, const float* x, const float* w, c
 int pcg_conv2d_dgrad_act(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x /*nullable*/, int act, float slope,
                          float* dx, void* workspace /*nullable*/, size_t workspace_bytes, pcg_stream_t stream);
 size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g);
+/* Deferred slab reductions (r04).  A split-K weight gradient ends with a small launch that sums its K-slice slabs into dw; in a backward
+ * sweep nothing reads dw before the sweep ends (optimizer.step(), mnist_dcgan.py:164,176; the gradient exchange).  Between
+ * pcg_slab_defer_begin(stream) and pcg_slab_defer_flush(stream) the pcg_conv2d_wgrad* calls of THIS thread on `stream` leave their slabs
+ * unreduced and the flush sums all of them in ONE launch — bit-identical to the per-call reductions (same order per element).  The
+ * caller must give every deferred call its own workspace and keep it until the flush; two sums into the same dw stay in call order.
+ * No nesting.  pcg_slab_defer_pending(): recorded entries, -1 when not deferring.                                                  */
+int pcg_slab_defer_begin(pcg_stream_t stream);
+int pcg_slab_defer_flush(pcg_stream_t stream);
+int32_t pcg_slab_defer_pending(void);
 /* dw[co,kh,kw,ci] (+)= sum_{b,oh,ow} dy[b,oh,ow,co] * x[b,oh*s-p+kh,ow*s-p+kw,ci];  accumulate!=0 adds into dw
  * (the reference accumulates .grad over two backward() calls: mnist_dcgan.py:153,161).             */
 int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,

@@ -1707,6 +1707,14 @@ extern "C" int pcg_conv2d_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* 
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 
+// Deferred slab reductions (thin_conv.hip): every split-K weight gradient issued on `stream` by THIS thread between begin and flush leaves its
+// slabs unreduced; the flush sums all of them in one launch, bit-identical to the per-layer reductions.  The caller keeps each call's
+// workspace alive and distinct until the flush.  Replaces the 5-6 us reduction launch behind every weight gradient of a backward sweep
+// (mnist_dcgan.py:153,161,173 — the gradients are read by optimizer.step() at :164,176, after the sweep).
+extern "C" int pcg_slab_defer_begin(pcg_stream_t stream) { return slab_defer_begin((hipStream_t)stream); }
+extern "C" int pcg_slab_defer_flush(pcg_stream_t stream) { return slab_defer_flush((hipStream_t)stream); }
+extern "C" int32_t pcg_slab_defer_pending(void) { return slab_defer_pending(); }
+
 extern "C" size_t pcg_conv2d_wgrad_workspace_bytes(const pcg_conv_geom* g) {
   if (check_geom(g) != PCG_OK) return 0;
   if (thin_is_cin(g) || thin_is_cout(g)) return thin_conv_wgrad_workspace_bytes(g);
@@ -1800,7 +1808,7 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   }
   if (rc != PCG_OK) return rc;
   const size_t n = (size_t)p.M * p.N;
-  return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s);
+  return launch_slab_reduce((const float*)workspace, dw, n, n, wp.splits, accumulate, s, true);
 }
 
 extern "C" int pcg_conv2d_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate,

@@ -38,6 +38,12 @@ int thin_conv_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const fl
                                int groups, void* ws, size_t ws_bytes, hipStream_t s);
 
 // shared with conv_igemm.hip: dw[i] = (acc ? dw[i] : 0) + sum_z slab[z*stride + i]
-int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s);
+// deferrable: a weight gradient's reduction — recorded instead of launched while slab_defer_begin .. slab_defer_flush is open on this thread
+int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s, bool deferrable = false);
+
+// deferred slab reductions: between begin and flush launch_slab_reduce records its arguments; the flush reduces all entries in one launch
+int slab_defer_begin(hipStream_t s);
+int slab_defer_flush(hipStream_t s);
+int slab_defer_pending();   // entries recorded and not yet launched; -1 when not deferring
 
 }  // namespace pcg

@@ -443,6 +443,74 @@ __global__ void __launch_bounds__(256) slab_reduce1_kernel(const float* __restri
   }
 }
 
+// Deferred slab reductions (r04).  A backward sweep ends every split-K weight gradient with a 5-6 us reduction launch (DCGAN: 9 per
+// step, CounteRGAN: 29) that nothing in the sweep reads — the gradients are consumed after it, by Adam or the gradient exchange.
+// Between pcg_slab_defer_begin and pcg_slab_defer_flush launch_slab_reduce only records (slab, dw, ...); the flush reduces all of
+// them in ONE launch, blockIdx.y = entry, each entry summed exactly as the kernel it replaces sums it (plain: one thread per float4
+// in slab order; wide: 16 threads per float4, groups added in group order) — bit-identical gradients.  The caller keeps every recorded
+// slab buffer alive and distinct until the flush (ops.conv2d_wgrad takes one scratch slot per deferred call).
+struct SlabEntry { const float4* slab; float4* dw; uint32_t n4, stride4; int nslabs, accumulate, wide; };
+constexpr int SLAB_MANY_MAX = 24;
+struct SlabMany { SlabEntry e[SLAB_MANY_MAX]; };
+__global__ void __launch_bounds__(256) slab_reduce_many_kernel(SlabMany m) {
+  __shared__ float4 red[16][16];
+  const SlabEntry e = m.e[blockIdx.y];
+  if (e.wide) {
+    if ((size_t)blockIdx.x * 16 >= e.n4) return;                 // (block-uniform)
+    const int il = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + il;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < e.n4) {
+      int z = g;
+      for (; z + 7 * 16 < e.nslabs; z += 8 * 16) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = e.slab[(size_t)(z + 16 * j) * e.stride4 + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+      }
+      for (; z < e.nslabs; z += 16) {
+        const float4 v = e.slab[(size_t)z * e.stride4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    red[g][il] = a;
+    __syncthreads();
+    if (g == 0 && i < e.n4) {
+      float4 t = e.accumulate ? e.dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const float4 v = red[j][il]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      e.dw[i] = t;
+    }
+    return;
+  }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e.n4) return;
+  float4 a = e.accumulate ? e.dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int z = 0;
+  for (; z + 8 <= e.nslabs; z += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = e.slab[(size_t)(z + j) * e.stride4 + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+  }
+  for (; z < e.nslabs; ++z) {
+    const float4 v = e.slab[(size_t)z * e.stride4 + i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  e.dw[i] = a;
+}
+struct SlabDefer { bool on = false; hipStream_t stream = nullptr; int n = 0; unsigned max_blocks = 0; SlabMany m; };
+thread_local SlabDefer g_slab_defer;
+int slab_defer_launch() {
+  SlabDefer& d = g_slab_defer;
+  if (d.n == 0) return PCG_OK;
+  hipLaunchKernelGGL(slab_reduce_many_kernel, dim3(d.max_blocks, (unsigned)d.n), dim3(256), 0, d.stream, d.m);
+  d.n = 0; d.max_blocks = 0;
+  return launch_status("slab_reduce_many_kernel");
+}
+
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // row-block plan (thin_rows.inc): direct tap map with any stride, or the transposed map with stride 1; the wide grid must be
@@ -648,8 +716,22 @@ ThinWgradPlan plan_thin_wgrad(int npix, int C) {
 
 }  // namespace
 
-int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s) {
+int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_stride, int nslabs, int accumulate, hipStream_t s, bool deferrable) {
   const bool vec = (n % 4 == 0) && (slab_stride % 4 == 0) && (((uintptr_t)slab | (uintptr_t)dw) & 15) == 0;
+  if (deferrable && vec && g_slab_defer.on && s == g_slab_defer.stream && n / 4 < (1ull << 32) && slab_stride / 4 < (1ull << 32)) {
+    SlabDefer& d = g_slab_defer;
+    const size_t n4 = n / 4;
+    bool clash = d.n == SLAB_MANY_MAX;
+    for (int k = 0; k < d.n && !clash; ++k) clash = (const void*)d.m.e[k].dw == (const void*)dw;     // a second sum into the same gradient: in order
+    if (clash)
+      if (int e = slab_defer_launch()) return e;
+    const int wide = nslabs >= 64 && n4 <= 16 * 1024;
+    d.m.e[d.n++] = SlabEntry{reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), (uint32_t)n4, (uint32_t)(slab_stride / 4), nslabs,
+                             accumulate, wide};
+    const unsigned blocks = (unsigned)(wide ? (n4 + 15) / 16 : (n4 + 255) / 256);
+    if (blocks > d.max_blocks) d.max_blocks = blocks;
+    return PCG_OK;
+  }
   if (vec) {
     const size_t n4 = n / 4;
     if (nslabs >= 64 && n4 <= 16 * 1024) {   // few outputs, many slabs: 16 threads per output
@@ -859,7 +941,7 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
     hipLaunchKernelGGL(thin_full_wgrad_kernel, dim3((unsigned)((L / 4 + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, reinterpret_cast<const float4*>(x), dy,
                        reinterpret_cast<float4*>(ws), g->B, L / 4);
     if (int e = launch_status("thin_full_wgrad_kernel")) return e;
-    return launch_slab_reduce((const float*)ws, dw, (size_t)L, (size_t)L, nslabs, accumulate, s);
+    return launch_slab_reduce((const float*)ws, dw, (size_t)L, (size_t)L, nslabs, accumulate, s, true);
   }
   // iterate over the wide tensor's pixels: dy (output grid) when Cin is thin, x (input grid) when Cout is thin
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/cin_thin)) return e;
@@ -886,7 +968,7 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
       hipLaunchKernelGGL((thin_rows_wgrad_kernel<KH_, KW_, CS_>), dim3(nb), dim3(256), 2 * ((patch_bytes + 15) & ~(size_t)15), s, p, rp, slab, wn, upb, \
                          thin_bytes);                                                                                             \
       if (int e = launch_status("thin_rows_wgrad_kernel")) return e;                                                              \
-      return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, nb, accumulate, s);                                             \
+      return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, nb, accumulate, s, true);                                             \
     }
     PCG_ROWS_WGRAD_CASE(4, 4, 1)
     PCG_ROWS_WGRAD_CASE(3, 3, 1)
@@ -911,7 +993,22 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
   }
 #undef PCG_THIN_WGRAD_CASE
   if (int e = launch_status("thin_wgrad_kernel")) return e;
-  return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, wp.nblocks, accumulate, s);
+  return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, wp.nblocks, accumulate, s, true);
 }
+
+int slab_defer_begin(hipStream_t s) {
+  SlabDefer& d = g_slab_defer;
+  PCG_REQUIRE(!d.on, "pcg_slab_defer_begin: already deferring on this thread (no nesting)");
+  d.on = true; d.stream = s; d.n = 0; d.max_blocks = 0;
+  return PCG_OK;
+}
+int slab_defer_flush(hipStream_t s) {
+  SlabDefer& d = g_slab_defer;
+  if (!d.on) return PCG_OK;
+  d.on = false;
+  PCG_REQUIRE(s == d.stream, "pcg_slab_defer_flush: called on another stream than pcg_slab_defer_begin");
+  return slab_defer_launch();
+}
+int slab_defer_pending() { return g_slab_defer.on ? g_slab_defer.n : -1; }
 
 }  // namespace pcg

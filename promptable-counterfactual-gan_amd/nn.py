@@ -532,7 +532,8 @@ class SequentialConvNet(FlatModule):
         fused = None           # ("bn", partial, nparts, nphases) | ("mask",) | None — see _run_backward_impl
         defer = self._defer()
         try:
-            self._run_backward_groups_impl(saved, G, B, d, own, fused, defer)
+            with ops.slab_reductions_deferred(self.defer_slab_reductions and defer is None):
+                self._run_backward_groups_impl(saved, G, B, d, own, fused, defer)
         finally:
             if defer is not None:
                 defer.finish()
@@ -614,6 +615,11 @@ class SequentialConvNet(FlatModule):
                 continue
             d = ops.conv2d_dgrad(g, dz, w)
 
+    # opt-in A/B: one slab-reduction launch per backward sweep instead of one per weight gradient (ops.slab_reductions_deferred): bit-identical;
+    # measured r04: DCGAN 10.174 / 10.178 ms, CounteRGAN 26.68 -> 26.64 — the one launch (16.5 us for four entries) reads slabs that have left
+    # the caches by then, the per-layer launches (5-7 us each) read them right behind the kernel that wrote them
+    defer_slab_reductions = False
+
     fuse_full_window_bn = True   # A/B: a full-window one-channel conv's grad-input through the BatchNorm backward below it, unwritten (pcg_conv2d_dgrad_bnbwd_full)
 
     wgrad_stream = None      # opt-in A/B: a second HIP stream for the weight gradients (they and the grad-input of a layer both need only dz)
@@ -635,7 +641,8 @@ class SequentialConvNet(FlatModule):
         main = torch.cuda.current_stream() if side is not None else None
         defer = self._defer() if side is None else None
         try:
-            return self._run_backward_impl(saved, dy, need_x, need_p, side, main, defer)
+            with ops.slab_reductions_deferred(self.defer_slab_reductions and side is None and defer is None):
+                return self._run_backward_impl(saved, dy, need_x, need_p, side, main, defer)
         finally:
             if side is not None:
                 main.wait_stream(side)

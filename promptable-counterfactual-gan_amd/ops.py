@@ -440,6 +440,37 @@ def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta
     return dx
 
 
+# ---- deferred slab reductions (pcg_slab_defer_*): one reduction launch per backward sweep instead of one per weight gradient -------
+import threading as _threading
+
+_slab_defer = _threading.local()      # per thread, like the library's record (autograd runs a net's backward on its own thread)
+_SLAB_SLOT0 = 16                      # scratch kinds 16, 17, ...: one slab buffer per deferred weight gradient of the sweep
+
+
+class slab_reductions_deferred:
+    """with ops.slab_reductions_deferred(): ... conv2d_wgrad calls ... — the weight gradients (dw) are complete when the block exits.
+    Inside, every split-K weight gradient keeps its slabs in its own scratch slot; the exit sums all of them in one launch,
+    bit-identical to the per-call reductions.  Nothing inside the block may read a dw written inside it.  Not re-entrant; on the
+    current stream of the entry."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and not getattr(_slab_defer, "on", False)
+
+    def __enter__(self):
+        if self.enabled:
+            check(_lib.load().pcg_slab_defer_begin(_stream()), "pcg_slab_defer_begin")
+            _slab_defer.on, _slab_defer.n = True, 0
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.enabled:
+            _slab_defer.on = False
+            rc = _lib.load().pcg_slab_defer_flush(_stream())
+            if et is None:
+                check(rc, "pcg_slab_defer_flush")
+        return False
+
+
 def conv2d_wgrad(g, x, dy, dw, accumulate, xf_x=None, xf_dy=None):
     """dw (OHWI, written in place) (+)= sum over pixels of dy (x) gathered x.  xf_x / xf_dy: input transform on the operand that
     is an activation (x for Conv2d; dy for ConvTranspose2d, whose forward input sits on the dy side of the adjoint geometry)."""
@@ -447,7 +478,11 @@ def conv2d_wgrad(g, x, dy, dw, accumulate, xf_x=None, xf_dy=None):
     assert dw.numel() == g.Cout * g.KH * g.KW * g.Cin
     lib = _lib.load()
     need = lib.pcg_conv2d_wgrad_workspace_bytes(ctypes.byref(g))
-    ws = workspace(need, x.device)
+    if getattr(_slab_defer, "on", False):
+        ws = _scratch(_SLAB_SLOT0 + _slab_defer.n, need, x.device)       # its own slot: the slabs live until the sweep's flush
+        _slab_defer.n += 1
+    else:
+        ws = workspace(need, x.device)
     with _Timed(g, "wgrad"):
         if xf_x is None and xf_dy is None:
             check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),

@@ -5,6 +5,7 @@
   python scripts/step_ab.py --model countergan --ab edge_prio=0,2
   python scripts/step_ab.py --model dcgan --ab pair=0,1          (pair: dcgan.train_step(pair=...) — the batched real + fake D pass)
   python scripts/step_ab.py --model dcgan --ab fullbn=0,1        (SequentialConvNet.fuse_full_window_bn)
+  python scripts/step_ab.py --model dcgan --ab slabdefer=0,1     (SequentialConvNet.defer_slab_reductions)
 
 Per variant the step is captured as its own HIP graph (kernel arguments, tuning included, are baked in at capture), then the graphs
 are replayed in alternating rounds; prints min / median ms per step of every variant.  Boxes differ by up to 20 % and drift within a
@@ -74,6 +75,9 @@ def main():
         elif key == "fullbn":            # nn.SequentialConvNet.fuse_full_window_bn: D5's grad-input through D4's BatchNorm backward unwritten
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.fuse_full_window_bn = bool(v)
+        elif key == "slabdefer":         # nn.SequentialConvNet.defer_slab_reductions: one slab reduction per backward sweep
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.defer_slab_reductions = bool(v)
         else:
             ops.tune(key, v)
         graphs[v] = (build_dcgan if a.model == "dcgan" else build_countergan)(dev, batch, variant)
@@ -83,6 +87,9 @@ def main():
         elif key == "fullbn":
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.fuse_full_window_bn = True
+        elif key == "slabdefer":
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.defer_slab_reductions = False
         elif key != "pair":
             ops.tune(key, -1)
     res = {v: [] for v in vals}

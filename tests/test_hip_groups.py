@@ -316,3 +316,35 @@ def test_weight_gradients_beside_the_batchnorm_backward_are_the_same_numbers(pcg
     for mode in ("bn", "bn-graph"):
         assert res[mode][0] == res[None][0], mode
         assert torch.equal(res[mode][1], res[None][1]) and torch.equal(res[mode][2], res[None][2]), mode
+
+
+def test_deferred_slab_reductions_in_the_step_are_the_same_numbers(pcg):
+    """SequentialConvNet.defer_slab_reductions (opt-in: one slab-reduction launch per backward sweep, pcg_slab_defer_*): eager and
+    graph-replayed steps are bit-identical to the per-layer reductions, paired and two-pass D step."""
+    from pcgan_amd.nn import GraphedStep, SequentialConvNet
+    D = pcg.dcgan
+    c = {"g_hidden": 16, "d_hidden": 16, "z_dim": 32}
+    batches = [R.synthetic_batch(32, seed=40 + i, config=c) for i in range(3)]
+    for pair in (True, False):
+        res = {}
+        for mode in (None, "defer", "defer-graph"):
+            SequentialConvNet.defer_slab_reductions = mode is not None
+            netG, netD, _, _ = _nets(pcg, c)
+            crit, optD, optG = D.make_optimizers(netG, netD, c)
+            if mode == "defer-graph":
+                s_real, s_noise = batches[0][0].to(DEV).clone(), batches[0][1].to(DEV).clone()
+                gs = GraphedStep(lambda: D.train_step(netG, netD, crit, optD, optG, s_real, s_noise, c, pair=pair),
+                                 {"real": s_real, "noise": s_noise}, [netG, netD], [optD, optG])
+            for real, noise in batches:
+                if mode == "defer-graph":
+                    gs.load(real=real.to(DEV), noise=noise.to(DEV))
+                    o = gs.replay()
+                else:
+                    o = D.train_step(netG, netD, crit, optD, optG, real.to(DEV), noise.to(DEV), c, pair=pair)
+            torch.cuda.synchronize()
+            res[mode] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], netG.flat_params.clone(), netD.flat_params.clone())
+        SequentialConvNet.defer_slab_reductions = False
+        assert pcg._lib.load().pcg_slab_defer_pending() == -1
+        for mode in ("defer", "defer-graph"):
+            assert res[mode][0] == res[None][0], (pair, mode)
+            assert torch.equal(res[mode][1], res[None][1]) and torch.equal(res[mode][2], res[None][2]), (pair, mode)

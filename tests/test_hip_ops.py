@@ -174,6 +174,44 @@ def test_full_window_grad_input_through_batchnorm_backward(pcg, B, groups, act, 
     np.testing.assert_allclose(dg.cpu().numpy(), 2 * dg_ref.cpu().numpy(), rtol=2e-5, atol=4e-6 * dg_ref.abs().max().item())
 
 
+def test_deferred_slab_reductions_are_bit_identical(pcg):
+    """ops.slab_reductions_deferred(): the weight gradients of a sweep reduced in one launch == reduced per call, bit for bit; two sums
+    into the same gradient stay in call order; a split-K FORWARD inside the block is not deferred."""
+    ops = pcg.ops
+    lib = pcg._lib.load()
+    gen = torch.Generator().manual_seed(21)
+    cases = [(16, 128, 256, 16, 4, 2, 1), (16, 64, 128, 32, 4, 2, 1), (16, 1, 64, 64, 4, 2, 1), (32, 512, 1, 4, 4, 1, 0), (8, 64, 64, 28, 3, 1, 1)]
+    data = []
+    for B, Cin, Cout, H, k, s, p in cases:
+        g = ops.conv_geom(B, H, H, Cin, Cout, k, k, s, p)
+        x = torch.randn(B, H, H, Cin, generator=gen).to(dev()); dy = torch.randn(B, g.OH, g.OW, Cout, generator=gen).to(dev())
+        data.append((g, x, dy, (Cout, k, k, Cin)))
+    ref = []
+    for g, x, dy, shp in data:
+        dw = torch.full(shp, 0.25, device=dev())
+        ops.conv2d_wgrad(g, x, dy, dw, False)
+        ops.conv2d_wgrad(g, x, dy, dw, True)              # accumulate on top
+        ref.append(dw)
+    assert lib.pcg_slab_defer_pending() == -1
+    out = [torch.full(shp, 0.25, device=dev()) for _, _, _, shp in data]
+    with ops.slab_reductions_deferred():
+        for (g, x, dy, _), dw in zip(data, out):
+            ops.conv2d_wgrad(g, x, dy, dw, False)
+        assert lib.pcg_slab_defer_pending() >= 3              # (stream-K weight gradients have no slabs to defer)
+        for (g, x, dy, _), dw in zip(data, out):
+            ops.conv2d_wgrad(g, x, dy, dw, True)              # same dw again: the first batch is launched before this one is recorded
+    assert lib.pcg_slab_defer_pending() == -1
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    check = pcg._lib.check
+    check(lib.pcg_slab_defer_begin(None), "begin")
+    try:
+        with pytest.raises(pcg.PcgError, match="already deferring"):
+            check(lib.pcg_slab_defer_begin(None), "begin")
+    finally:
+        check(lib.pcg_slab_defer_flush(None), "flush")
+
+
 def test_conv_rejects_bad_geometry(pcg):
     ops = pcg.ops
     g = ops.conv_geom(2, 8, 8, 8, 8, 4, 4, 2, 1)
