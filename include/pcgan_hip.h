@@ -161,6 +161,12 @@ int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* 
 /* r04: pcg_conv2d_dgrad_mask also serves one-channel layers whose grad-input takes the row-block form (..._thin_ok: k3 / k4, Cout
  * <= 3, Cin a power-of-two multiple of 4): the mask is applied in the thin expand kernel (CounteRGAN conv_out, models/generator.py:50). */
 int32_t pcg_conv2d_dgrad_mask_thin_ok(const pcg_conv_geom* g);
+/* Thin layers that take an input transform (r04): a Cin = 1 geometry with Cout = 64 and <= 16 taps — DCGAN's last ConvTranspose2d(64, 1, 4, 2, 1)
+ * (mnist_dcgan.py:88), whose input is BatchNorm2d + ReLU of the layer before (:86-87).  pcg_conv2d_dgrad_xf (its forward) and
+ * pcg_conv2d_wgrad_xf with xf_dy (its weight gradient) then read the PRE-BatchNorm tensor: the BatchNorm-apply pass and the activated
+ * copy of that activation disappear (both kernels are HBM-bound: the transform is free).  Needs the workspace of
+ * pcg_conv2d_dgrad_workspace_bytes / pcg_conv2d_wgrad_workspace_bytes.                                                              */
+int32_t pcg_conv2d_xf_thin_ok(const pcg_conv_geom* g);
 /* y = (conv(x, w) + addend) * act'(a_below) — pcg_conv2d_*_add followed by pcg_act_bwd in ONE epilogue: the last skip-add of a residual
  * chain arriving at the entry convolution's LeakyReLU (models/generator.py:76 backward).  a_below: the activated output, output's shape. */
 int pcg_conv2d_fwd_add_mask(const pcg_conv_geom* g, const float* x, const float* w, const float* addend, const float* a_below, int act,

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "pcg_conv2d_dgrad_bn": (_i, [_gp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad_mask": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),
     "pcg_conv2d_dgrad_mask_thin_ok": (_i32, [_gp]),
+    "pcg_conv2d_xf_thin_ok": (_i32, [_gp]),
     "pcg_conv2d_fwd_add_mask": (_i, [_gp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "pcg_conv2d_dgrad_add_mask": (_i, [_gp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]),
     "pcg_conv2d_fwd_mask": (_i, [_gp, _vp, _vp, _vp, _i, _f, _vp, _vp, _sz, _vp]),

@@ -1370,8 +1370,10 @@ static int conv2d_dgrad_impl(const pcg_conv_geom* g, const float* dy, const floa
   PCG_REQUIRE(act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_dgrad: unknown activation %d", act);
   const bool has_xf = xf && xf->scale;
   if (thin_is_cin(g) || thin_is_cout(g)) {
-    PCG_REQUIRE(!has_xf, "pcg_conv2d_dgrad: input transforms are only implemented on the MFMA path (Cin > 3 and Cout > 3)");
-    return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream, act, slope);
+    PCG_REQUIRE(!has_xf || thin_conv_xf_ok(g), "pcg_conv2d_dgrad: input transforms on the MFMA path (Cin > 3 and Cout > 3) and on the thin forms of pcg_conv2d_xf_thin_ok only");
+    PCG_REQUIRE(!has_xf || (xf->act == PCG_ACT_NONE || xf->act == PCG_ACT_RELU || xf->act == PCG_ACT_LRELU), "pcg_conv2d_dgrad: transform activation %d", has_xf ? xf->act : 0);
+    const ThinXf tx{has_xf ? xf->scale : nullptr, has_xf ? xf->shift : nullptr, has_xf ? act_neg_of(xf->act, xf->slope) : 1.f};
+    return thin_conv_dgrad(g, dy, w, bias_x, dx, workspace, workspace_bytes, (hipStream_t)stream, act, slope, &tx);
   }
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_dgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   PCG_REQUIRE(g->stride <= 2, "pcg_conv2d_dgrad: stride %d > 2 unsupported", g->stride);
@@ -1456,6 +1458,9 @@ static int epi_common(const char* who, const pcg_conv_geom* g, const float* out,
   return PCG_OK;
 }
 
+// a Cin = 1 layer whose dy-side operand may carry an input transform (pcg_conv2d_dgrad_xf, pcg_conv2d_wgrad_xf with xf_dy): DCGAN's last
+// ConvTranspose2d(64, 1, 4, 2, 1) behind BatchNorm + ReLU (mnist_dcgan.py:85-88) — no BatchNorm-apply pass, no activated copy
+extern "C" int32_t pcg_conv2d_xf_thin_ok(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK && thin_conv_xf_ok(g) ? 1 : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_mask_thin_ok(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK && thin_conv_dgrad_mask_ok(g) && g->Cin % 4 == 0 ? 1 : 0; }
 extern "C" int pcg_conv2d_dgrad_mask(const pcg_conv_geom* g, const float* dy, const float* w, const float* a_below, int act, float slope,
                                      float* dx, void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
@@ -1754,8 +1759,10 @@ extern "C" int pcg_conv2d_wgrad_xf(const pcg_conv_geom* g, const float* x, const
   const bool hx = xf_x && xf_x->scale, hy = xf_dy && xf_dy->scale;
   PCG_REQUIRE(!(hx && hy), "pcg_conv2d_wgrad_xf: at most one operand can carry an input transform");
   if (thin_is_cin(g) || thin_is_cout(g)) {
-    PCG_REQUIRE(!hx && !hy, "pcg_conv2d_wgrad: input transforms are only implemented on the MFMA path (Cin > 3 and Cout > 3)");
-    return thin_conv_wgrad(g, x, dy, dw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+    PCG_REQUIRE(!hx && (!hy || thin_conv_xf_ok(g)), "pcg_conv2d_wgrad: input transforms on the MFMA path (Cin > 3 and Cout > 3) and, on the dy side, on the thin forms of pcg_conv2d_xf_thin_ok only");
+    PCG_REQUIRE(!hy || (xf_dy->act == PCG_ACT_NONE || xf_dy->act == PCG_ACT_RELU || xf_dy->act == PCG_ACT_LRELU), "pcg_conv2d_wgrad: transform activation %d", hy ? xf_dy->act : 0);
+    const ThinXf tx{hy ? xf_dy->scale : nullptr, hy ? xf_dy->shift : nullptr, hy ? act_neg_of(xf_dy->act, xf_dy->slope) : 1.f};
+    return thin_conv_wgrad(g, x, dy, dw, accumulate, workspace, workspace_bytes, (hipStream_t)stream, &tx);
   }
   PCG_REQUIRE(g->Cin % 4 == 0 && g->Cout % 4 == 0, "pcg_conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 4", g->Cin, g->Cout);
   const WgradPlan wp = plan_wgrad(g);

@@ -10,13 +10,17 @@ inline bool thin_is_cout(const pcg_conv_geom* g) { return g->Cout <= 3 && !thin_
 
 int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
                   size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f);
+// input transform on the WIDE operand of a Cin-thin layer (r04): it is a pre-BatchNorm tensor read as act(z * scale[c] + shift[c]) — a
+// one-channel ConvTranspose2d behind BatchNorm + ReLU (DCGAN's G5 behind G4) then needs no BatchNorm-apply pass and no activated copy
+struct ThinXf { const float* scale; const float* shift; float neg; };
+bool thin_conv_xf_ok(const pcg_conv_geom* g);
 int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
-                    size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f);
+                    size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f, const ThinXf* xf = nullptr);
 size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g);   // optional scratch enabling the two-stage reduce path
 size_t thin_conv_dgrad_workspace_bytes(const pcg_conv_geom* g);
 size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g);
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, const ThinXf* xf = nullptr);
 
 // Cin-thin forward fused with the BatchNorm + ReLU / LeakyReLU backward of the layer whose activated output it is a gradient of (r04)
 bool thin_conv_fwd_bnbwd_ok(const pcg_conv_geom* g);

@@ -23,6 +23,8 @@ struct ThinP {
   const float* bias;
   float* out;
   int act; float slope;   // activation fused into the output write (PCG_ACT_NONE: none)
+  const float* xf_scale; const float* xf_shift; float xf_neg;   // input transform on the WIDE operand (r04, tap-dot on the matrix cores and row-block weight
+                                                               // gradient only): wide := act(wide * scale[c] + shift[c]) — the producer's BatchNorm + ReLU / LeakyReLU
   const float* mask_src; float mask_neg;   // row-block expand only (r04): out *= (mask_src > 0 ? 1 : mask_neg), mask_src of the output's shape —
                                            // the ReLU / LeakyReLU backward of the layer whose activated output this gradient belongs to
   int B, TH, TW, Cs, WH, WW, C;
@@ -643,6 +645,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
   const size_t smem = lds_weight_bytes(p);
   PCG_REQUIRE(smem <= 64 * 1024, "thin conv: weight image %zu B exceeds 64 KB of LDS", smem);
   const size_t need = reduce_scratch_bytes(p);
+  PCG_REQUIRE(!p.xf_scale || !fast32_ok(p), "thin conv: input transforms only with one thin channel");
   if (need && ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0 && fast32_ok(p)) {
     float* T = (float*)ws;
     ThinP q = p;
@@ -668,6 +671,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     unsigned blocks = (unsigned)((q.npix + 15) / 16);
     if (blocks > 8192) blocks = 8192;
     const int nt = p.KH * p.KW;
+    PCG_REQUIRE(!p.xf_scale || (p.C == 64 && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0), "thin conv: an input transform needs the matrix-core tap-dot form");
     if (p.C == 64 && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0) {
       unsigned mb = (unsigned)((q.npix + 127) / 128);
       if (mb > 4096) mb = 4096;
@@ -689,6 +693,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     return launch_status("thin_col2im_kernel");
   }
 generic:
+  PCG_REQUIRE(!p.xf_scale, "thin conv: an input transform needs the matrix-core tap-dot form (workspace of pcg_conv2d_dgrad_workspace_bytes)");
   unsigned blocks = (unsigned)((p.npix + 15) / 16);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(thin_reduce_kernel, dim3(blocks), dim3(256), smem, s, p);
@@ -820,13 +825,29 @@ int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, 
   return launch_status("thin_rows_expand_bn_kernel(apply)");
 }
 
+// a Cin-thin layer whose wide (dy-side) operand can carry an input transform: grad-input through the matrix-core tap-dot, weight
+// gradient through the row-block kernel
+bool thin_conv_xf_ok(const pcg_conv_geom* g) {
+  if (!thin_is_cin(g) || g->Cin != 1 || g->Cout != 64) return false;
+  ThinP p{};
+  if (fill_common(p, g, true, false) != PCG_OK || !fast_ok(p) || reduce_scratch_bytes(p) == 0) return false;
+  ThinP q{};
+  RowsP rp{};
+  size_t patch_bytes = 0;
+  return fill_common(q, g, true, true) == PCG_OK && rows_wgrad_ok(q, g, rp, &patch_bytes);
+}
+
 int thin_conv_dgrad(const pcg_conv_geom* g, const float* dy, const float* w, const float* bias_x, float* dx, void* ws,
-                    size_t ws_bytes, hipStream_t s, int act, float slope) {
+                    size_t ws_bytes, hipStream_t s, int act, float slope, const ThinXf* xf) {
   ThinP p{};
   p.act = act; p.slope = slope;
   const bool cin_thin = thin_is_cin(g);
   if (int e = fill_common(p, g, cin_thin, /*iter_on_output=*/false)) return e;
   p.w = w; p.bias = bias_x; p.out = dx;
+  if (xf && xf->scale) {
+    PCG_REQUIRE(thin_conv_xf_ok(g), "thin conv grad-input: this geometry takes no input transform (thin_conv_xf_ok)");
+    p.xf_scale = xf->scale; p.xf_shift = xf->shift; p.xf_neg = xf->neg;
+  }
   if (cin_thin) { p.wide = dy; return launch_reduce(p, ws, ws_bytes, s); }  // dx thin
   p.thin = dy;                                                              // dx wide
   const bool fuse = act_is_cheap(act);
@@ -928,9 +949,12 @@ size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
 }
 
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
+                    size_t ws_bytes, hipStream_t s, const ThinXf* xf) {
   ThinP p{};
   const bool cin_thin = thin_is_cin(g);
+  const bool has_xf = xf && xf->scale;
+  PCG_REQUIRE(!has_xf || thin_conv_xf_ok(g), "thin conv weight gradient: this geometry takes no input transform (thin_conv_xf_ok)");
+  if (has_xf) { p.xf_scale = xf->scale; p.xf_shift = xf->shift; p.xf_neg = xf->neg; }
   if (full_window(g) && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0) {
     const int L = g->KH * g->KW * g->Cin, nslabs = (g->B + FULL_ROWS_DW - 1) / FULL_ROWS_DW;
     const size_t need = (size_t)nslabs * L * sizeof(float);
@@ -952,6 +976,7 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
   RowsP rp{};
   size_t patch_bytes = 0;
   const bool rows = rows_wgrad_ok(p, g, rp, &patch_bytes);
+  PCG_REQUIRE(!has_xf || rows, "thin conv weight gradient: an input transform needs the row-block form");
   const int nslabs = rows ? rows_wgrad_blocks(rp) : wp.nblocks;
   const size_t need = (size_t)nslabs * wn * sizeof(float);
   if (ws == nullptr || ws_bytes < need) {

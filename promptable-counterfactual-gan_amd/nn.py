@@ -316,6 +316,7 @@ class SequentialConvNet(FlatModule):
     fuse_backward_epilogue = True   # A/B switch (tests compare both forms): activation derivative / BatchNorm-backward sums of the
                                     # layer below taken in the grad-input kernel's epilogue instead of in separate passes
     fold_bn_apply = False           # A/B switch: BatchNorm(train) + ReLU / LeakyReLU applied inside the next convolution's gathers
+    fold_bn_apply_thin = True       # ... inside a thin one-channel ConvTranspose2d's loads (G5 behind G4: no apply pass, no activated copy; bit-identical)
                                     # (forward and weight gradient) instead of as a pass that writes the activated tensor.
                                     # Bit-identical results; OFF by default because it is SLOWER on gfx950 (profiles/README.md r02:
                                     # DCGAN step 10.97 -> 11.26 ms): the ~16 VALU per gathered float4 in the producer waves are not
@@ -350,7 +351,8 @@ class SequentialConvNet(FlatModule):
         return y.reshape(y.shape[0], y.shape[1]) if flat_in else y
 
     def _can_consume_xform(self, nxt, B, H, W):
-        """Can block `nxt` read its input [B, H, W, C] through an input transform (MFMA conv kernels only)?"""
+        """Should block `nxt` read its input [B, H, W, C] through an input transform?  MFMA consumers: opt-in (fold_bn_apply: measured
+        slower, their gathers are the bottleneck); a thin one-channel ConvTranspose2d: yes (fold_bn_apply_thin: its kernels are HBM-bound)."""
         if nxt.transposed:
             OH = (H - 1) * nxt.stride - 2 * nxt.pad + nxt.kh
             OW = (W - 1) * nxt.stride - 2 * nxt.pad + nxt.kw
@@ -359,7 +361,9 @@ class SequentialConvNet(FlatModule):
             g = ops.conv_geom(B, OH, OW, nxt.conv.out_channels, nxt.conv.in_channels, nxt.kh, nxt.kw, nxt.stride, nxt.pad)
         else:
             g = ops.conv_geom(B, H, W, nxt.conv.in_channels, nxt.conv.out_channels, nxt.kh, nxt.kw, nxt.stride, nxt.pad)
-        return ops.xform_ok(g, "dy" if nxt.transposed else "x")
+        if ops.xform_ok(g, "dy" if nxt.transposed else "x"):
+            return self.fold_bn_apply
+        return self.fold_bn_apply_thin and nxt.transposed and g.Cin == 1 and ops.xform_thin_ok(g)
 
     def _run_forward(self, x, keep=True):
         B, H, W, C = x.shape
@@ -379,7 +383,7 @@ class SequentialConvNet(FlatModule):
             xf_in, xf = xf, None
             # BatchNorm(train) + ReLU / LeakyReLU of this block folded into the NEXT block's gathers: this block then never
             # writes its activated output
-            fold = (self.fold_bn_apply and idx + 1 < nblk and b.bn is not None and b.bn.training
+            fold = (idx + 1 < nblk and b.bn is not None and b.bn.training
                     and b.act in (ACT_NONE, ACT_RELU, ACT_LRELU) and self._can_consume_xform(self._blocks[idx + 1], B, OH, OW))
             if b.transposed and b.flat:
                 # plain-GEMM form: bias is shared by the KH*KW positions of a channel, statistics are per channel over B*KH*KW rows

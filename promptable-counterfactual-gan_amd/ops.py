@@ -226,6 +226,11 @@ def xform_ok(g, operand):
     return g.Cin > 3 and g.Cout > 3 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and g.stride <= 2
 
 
+def xform_thin_ok(g):
+    """A Cin = 1 layer whose dy-side operand may carry an input transform (pcg_conv2d_xf_thin_ok): conv2d_dgrad(xf=) / conv2d_wgrad(xf_dy=)."""
+    return bool(_lib.load().pcg_conv2d_xf_thin_ok(ctypes.byref(g)))
+
+
 def _xref(xf):
     return xf.ref() if xf is not None else None
 

@@ -6,6 +6,7 @@
   python scripts/step_ab.py --model dcgan --ab pair=0,1          (pair: dcgan.train_step(pair=...) — the batched real + fake D pass)
   python scripts/step_ab.py --model dcgan --ab fullbn=0,1        (SequentialConvNet.fuse_full_window_bn)
   python scripts/step_ab.py --model dcgan --ab slabdefer=0,1     (SequentialConvNet.defer_slab_reductions)
+  python scripts/step_ab.py --model dcgan --ab foldthin=0,1      (SequentialConvNet.fold_bn_apply_thin)
 
 Per variant the step is captured as its own HIP graph (kernel arguments, tuning included, are baked in at capture), then the graphs
 are replayed in alternating rounds; prints min / median ms per step of every variant.  Boxes differ by up to 20 % and drift within a
@@ -75,6 +76,9 @@ def main():
         elif key == "fullbn":            # nn.SequentialConvNet.fuse_full_window_bn: D5's grad-input through D4's BatchNorm backward unwritten
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.fuse_full_window_bn = bool(v)
+        elif key == "foldthin":          # nn.SequentialConvNet.fold_bn_apply_thin: G4's BatchNorm + ReLU inside G5's loads
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.fold_bn_apply_thin = bool(v)
         elif key == "slabdefer":         # nn.SequentialConvNet.defer_slab_reductions: one slab reduction per backward sweep
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.defer_slab_reductions = bool(v)
@@ -90,6 +94,9 @@ def main():
         elif key == "slabdefer":
             from pcgan_amd.nn import SequentialConvNet
             SequentialConvNet.defer_slab_reductions = False
+        elif key == "foldthin":
+            from pcgan_amd.nn import SequentialConvNet
+            SequentialConvNet.fold_bn_apply_thin = True
         elif key != "pair":
             ops.tune(key, -1)
     res = {v: [] for v in vals}

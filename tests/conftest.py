@@ -27,7 +27,7 @@ def _class_switches_restored():
     except Exception:
         yield
         return
-    want = {"fold_bn_apply": False, "fuse_backward_epilogue": True, "wgrad_stream": None, "wgrad_overlap": None, "fuse_full_window_bn": True, "defer_slab_reductions": False}
+    want = {"fold_bn_apply": False, "fuse_backward_epilogue": True, "wgrad_stream": None, "wgrad_overlap": None, "fuse_full_window_bn": True, "defer_slab_reductions": False, "fold_bn_apply_thin": True}
     for k, v in want.items():
         assert getattr(SequentialConvNet, k) == v or getattr(SequentialConvNet, k) is v, f"SequentialConvNet.{k} leaked from an earlier test"
     yield

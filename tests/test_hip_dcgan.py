@@ -384,6 +384,37 @@ def test_fused_backward_epilogue_equals_separate_passes(pcg):
         assert l2 <= 2e-5, f"{k}: rel-L2 {l2:.2e}"
 
 
+def test_thin_layer_reads_its_input_through_the_batchnorm_transform(pcg):
+    """SequentialConvNet.fold_bn_apply_thin (default ON): G's last ConvTranspose2d(64, 1, 4, 2, 1) reads the PRE-BatchNorm output of the
+    layer before it and applies BatchNorm + ReLU inside its own loads (forward: matrix-core tap-dot; weight gradient: row-block kernel) —
+    no apply pass, no activated copy.  Same scale / shift expression, same values into the same arithmetic: two full training steps are
+    BIT-identical with the switch on and off, paired and two-pass D step, full width (the tap-dot form needs 64 channels)."""
+    D = pcg.dcgan
+    from pcgan_amd.nn import SequentialConvNet
+    g = torch.Generator().manual_seed(34)
+    reals = [(torch.rand(32, 1, 64, 64, generator=g) * 2 - 1).to(DEV) for _ in range(2)]
+    noises = [torch.randn(32, 100, 1, 1, generator=g).to(DEV) for _ in range(2)]
+    for pair in (True, False):
+        res = {}
+        try:
+            for fold in (True, False):
+                SequentialConvNet.fold_bn_apply_thin = fold
+                netG, netD, crit, optD, optG = _fresh_dcgan(D, seed=5)
+                for i in range(2):
+                    o = D.train_step(netG, netD, crit, optD, optG, reals[i], noises[i], skip_dead_d_wgrad=False, pair=pair)
+                with torch.no_grad():
+                    viz = netG(noises[0]).clone()
+                res[fold] = ([o[k].item() for k in ("errD_real", "errD_fake", "errG")], _state(netG, netD),
+                             netG.flat_grads.clone(), netD.flat_grads.clone(), viz)
+        finally:
+            SequentialConvNet.fold_bn_apply_thin = True
+        assert res[True][0] == res[False][0], pair
+        for k in res[False][1]:
+            assert torch.equal(res[True][1][k], res[False][1][k]), (pair, k)
+        for i in (2, 3, 4):
+            assert torch.equal(res[True][i], res[False][i]), (pair, i)
+
+
 def test_folded_bn_apply_equals_separate_pass(pcg):
     """SequentialConvNet.fold_bn_apply: BatchNorm(train) + ReLU / LeakyReLU of a layer applied inside the next convolution's
     gathers (forward and weight gradient) instead of by pcg_bn_apply_act.  Same scale / shift expression, same values into the
