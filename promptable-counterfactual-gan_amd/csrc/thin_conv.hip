@@ -655,7 +655,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     if (p.C == 64 && (((uintptr_t)p.wide) & 15) == 0) {   // the matrix-core form: two 16-output column blocks
       unsigned mb = (unsigned)((q.npix + 127) / 128);
       if (mb > 4096) mb = 4096;
-      hipLaunchKernelGGL(thin_tapdot64_mfma_kernel<2>, dim3(mb), dim3(256), 0, s, q, T);
+      hipLaunchKernelGGL((thin_tapdot64_mfma_kernel<2, false>), dim3(mb), dim3(256), 0, s, q, T);
     } else if (p.Cs == 2) hipLaunchKernelGGL(thin_tapdot32_kernel<18>, dim3(blocks), dim3(256), smem, s, q, T);
     else hipLaunchKernelGGL(thin_tapdot32_kernel<27>, dim3(blocks), dim3(256), smem, s, q, T);
     if (int e = launch_status("thin_tapdot32_kernel")) return e;
@@ -671,11 +671,16 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     unsigned blocks = (unsigned)((q.npix + 15) / 16);
     if (blocks > 8192) blocks = 8192;
     const int nt = p.KH * p.KW;
-    PCG_REQUIRE(!p.xf_scale || (p.C == 64 && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0), "thin conv: an input transform needs the matrix-core tap-dot form");
-    if (p.C == 64 && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0) {
+    const bool mfma1 = p.C == 64, mfmaN = p.C % 64 == 0 && p.C > 64 && p.C <= TD64_MAX_C;
+    PCG_REQUIRE(!p.xf_scale || ((mfma1 || mfmaN) && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0), "thin conv: an input transform needs the matrix-core tap-dot form");
+    if ((mfma1 || mfmaN) && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0) {
       unsigned mb = (unsigned)((q.npix + 127) / 128);
       if (mb > 4096) mb = 4096;
-      hipLaunchKernelGGL(thin_tapdot64_mfma_kernel<1>, dim3(mb), dim3(256), 0, s, q, T);
+      if (mfma1) hipLaunchKernelGGL((thin_tapdot64_mfma_kernel<1, false>), dim3(mb), dim3(256), 0, s, q, T);
+      else {
+        if (mb > 1024) mb = 1024;     // (every block stages the filter image once)
+        hipLaunchKernelGGL((thin_tapdot64_mfma_kernel<1, true>), dim3(mb), dim3(256), (size_t)16 * (p.C + 4) * sizeof(float), s, q, T);
+      }
     } else if (nt == 16) hipLaunchKernelGGL(thin_tapdot_kernel<16>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 9) hipLaunchKernelGGL(thin_tapdot_kernel<9>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 1) hipLaunchKernelGGL(thin_tapdot_kernel<1>, dim3(blocks), dim3(256), smem, s, q, T);
@@ -828,7 +833,7 @@ int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, 
 // a Cin-thin layer whose wide (dy-side) operand can carry an input transform: grad-input through the matrix-core tap-dot, weight
 // gradient through the row-block kernel
 bool thin_conv_xf_ok(const pcg_conv_geom* g) {
-  if (!thin_is_cin(g) || g->Cin != 1 || g->Cout != 64) return false;
+  if (!thin_is_cin(g) || g->Cin != 1 || g->Cout % 64 || g->Cout > TD64_MAX_C) return false;
   ThinP p{};
   if (fill_common(p, g, true, false) != PCG_OK || !fast_ok(p) || reduce_scratch_bytes(p) == 0) return false;
   ThinP q{};

@@ -12,6 +12,7 @@ single RCCL call on the flat gradient bucket.  Backward accumulates straight int
 (`p.grad` are views of it), which is autograd's `.grad` accumulation contract without extra add kernels.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -316,7 +317,7 @@ class SequentialConvNet(FlatModule):
     fuse_backward_epilogue = True   # A/B switch (tests compare both forms): activation derivative / BatchNorm-backward sums of the
                                     # layer below taken in the grad-input kernel's epilogue instead of in separate passes
     fold_bn_apply = False           # A/B switch: BatchNorm(train) + ReLU / LeakyReLU applied inside the next convolution's gathers
-    fold_bn_apply_thin = True       # ... inside a thin one-channel ConvTranspose2d's loads (G5 behind G4: no apply pass, no activated copy; bit-identical)
+    fold_bn_apply_thin = os.environ.get("PCG_FOLD_THIN", "1") != "0"   # ... inside a thin one-channel ConvTranspose2d's loads (G5 behind G4: no apply pass, no activated copy; bit-identical)
                                     # (forward and weight gradient) instead of as a pass that writes the activated tensor.
                                     # Bit-identical results; OFF by default because it is SLOWER on gfx950 (profiles/README.md r02:
                                     # DCGAN step 10.97 -> 11.26 ms): the ~16 VALU per gathered float4 in the producer waves are not

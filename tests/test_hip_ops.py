@@ -474,23 +474,23 @@ def test_input_transform_equals_bn_apply_then_conv(pcg, B, Cin, Cout, H, W, k, s
         assert all(torch.equal(u, v) for u, v in zip(r1[:3], r2))
 
 
-@pytest.mark.parametrize("B,H", [(8, 64), (3, 28)])
+@pytest.mark.parametrize("B,H,C", [(8, 64, 64), (3, 28, 64), (4, 28, 256)])
 @pytest.mark.parametrize("act,slope", [(O.ACT_RELU, 0.0), (O.ACT_LRELU, 0.2)])
-def test_input_transform_on_the_one_channel_transposed_layer(pcg, B, H, act, slope):
-    """pcg_conv2d_dgrad_xf / pcg_conv2d_wgrad_xf(xf_dy) on a Cin = 1, Cout = 64 geometry (pcg_conv2d_xf_thin_ok) == the plain calls on
-    bn_apply_act(z): bit for bit."""
+def test_input_transform_on_the_one_channel_transposed_layer(pcg, B, H, C, act, slope):
+    """pcg_conv2d_dgrad_xf / pcg_conv2d_wgrad_xf(xf_dy) on a Cin = 1, Cout = 64 k geometry (pcg_conv2d_xf_thin_ok: DCGAN's and WGAN-GP's
+    last ConvTranspose2d) == the plain calls on bn_apply_act(z): bit for bit."""
     ops = pcg.ops
-    g = ops.conv_geom(B, H, H, 1, 64, 4, 4, 2, 1)
+    g = ops.conv_geom(B, H, H, 1, C, 4, 4, 2, 1)
     assert ops.xform_thin_ok(g) and not ops.xform_thin_ok(ops.conv_geom(B, H, H, 1, 32, 4, 4, 2, 1))
-    gen = torch.Generator().manual_seed(B + H)
-    z = (torch.randn(B, g.OH, g.OW, 64, generator=gen) * 1.5 + 0.3).to(dev()); w = (torch.randn(64, 4, 4, 1, generator=gen) * 0.1).to(dev())
+    gen = torch.Generator().manual_seed(B + H + C)
+    z = (torch.randn(B, g.OH, g.OW, C, generator=gen) * 1.5 + 0.3).to(dev()); w = (torch.randn(C, 4, 4, 1, generator=gen) * 0.1).to(dev())
     dimg = torch.randn(B, H, H, 1, generator=gen).to(dev())
-    gamma, beta = (1 + 0.1 * torch.randn(64, generator=gen)).to(dev()), (0.1 * torch.randn(64, generator=gen)).to(dev())
-    mean, invstd, coef = ops.bn_train_stats(z, 64, 1e-5, 0.1, gamma=gamma, beta=beta)
-    a = ops.bn_apply_act(z, 64, mean, invstd, gamma, beta, act, slope)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=gen)).to(dev()), (0.1 * torch.randn(C, generator=gen)).to(dev())
+    mean, invstd, coef = ops.bn_train_stats(z, C, 1e-5, 0.1, gamma=gamma, beta=beta)
+    a = ops.bn_apply_act(z, C, mean, invstd, gamma, beta, act, slope)
     xf = ops.InputXform(coef, act, slope)
     assert torch.equal(ops.conv2d_dgrad(g, z, w, None, act=O.ACT_TANH, xf=xf), ops.conv2d_dgrad(g, a, w, None, act=O.ACT_TANH))
-    dw1, dw2 = torch.zeros(64, 4, 4, 1, device=dev()), torch.zeros(64, 4, 4, 1, device=dev())
+    dw1, dw2 = torch.zeros(C, 4, 4, 1, device=dev()), torch.zeros(C, 4, 4, 1, device=dev())
     ops.conv2d_wgrad(g, dimg, z, dw1, False, xf_dy=xf)
     ops.conv2d_wgrad(g, dimg, a, dw2, False)
     assert torch.equal(dw1, dw2)
