@@ -7,6 +7,7 @@ on the CPU and nothing falls back to ATen kernels: every function launches kerne
 torch's current HIP stream.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -446,9 +447,7 @@ def bn_bwd_partial(dm, x, C, mean, invstd, gamma, partial, nparts, dgamma, dbeta
 
 
 # ---- deferred slab reductions (pcg_slab_defer_*): one reduction launch per backward sweep instead of one per weight gradient -------
-import threading as _threading
-
-_slab_defer = _threading.local()      # per thread, like the library's record (autograd runs a net's backward on its own thread)
+_slab_defer = threading.local()      # per thread, like the library's record (autograd runs a net's backward on its own thread)
 _SLAB_SLOT0 = 16                      # scratch kinds 16, 17, ...: one slab buffer per deferred weight gradient of the sweep
 
 
