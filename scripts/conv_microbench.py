@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="D2,D3,D4,G2,G3,G4")
+    ap.add_argument("--xf", action="store_true", help="fwd / wgrad with an input transform on x (the fold_bn_apply form)")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: not a performance number)")
     ap.add_argument("--ab", default=None, help="A/B a tuning switch in THIS process, interleaved rounds: e.g. korder=0,1 or wgrad_order=0,1 "
                                                "(ops.tune / pcg_tune_set); prints the median and min ms per variant")
@@ -118,6 +119,9 @@ def main():
         flops = 2.0 * B * g.OH * g.OW * Cout * k * k * Cin
         fns = {"fwd": lambda: ops.conv2d_fwd(g, x, w, None, out=y), "dgrad": lambda: ops.conv2d_dgrad(g, dy, w, None, out=dx),
                "wgrad": lambda: ops.conv2d_wgrad(g, x, dy, dw, False)}
+        if args.xf:      # the same launches with an input transform (folded BatchNorm + LeakyReLU) on the activation operand x
+            xf = ops.InputXform(torch.cat([torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.1]).contiguous(), ops.ACT_LRELU, 0.2)
+            fns = {"fwd": lambda: ops.conv2d_fwd(g, x, w, None, out=y, xf=xf), "wgrad": lambda: ops.conv2d_wgrad(g, x, dy, dw, False, xf_x=xf)}
         for op in args.only.split(","):
             fn = fns[op]
             if args.ab:
