@@ -340,6 +340,19 @@ int pcg_conv2d_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* dy, const f
                                 float* dgamma /*nullable*/, float* dbeta /*nullable*/, int accumulate, int32_t groups, void* workspace,
                                 size_t workspace_bytes, pcg_stream_t stream);
 
+/* ... and its INPUT never needs the BatchNorm-apply pass (r04): the same full-window layer's forward and weight gradient read the
+ * pre-BatchNorm output z of the layer below and evaluate act(bn(z)) in their loads, with that layer's batch statistics (mean / invstd
+ * [groups][Cin], group = sample / (B / groups)) and the one bn_fold expression every BatchNorm pass uses — the values
+ * pcg_bn_apply_act would have written.  Workspace of the weight gradient: pcg_conv2d_wgrad_workspace_bytes.
+ * Eligibility: Cout = 1, window = input map, 256 % (Cin / 4) == 0, B / groups a multiple of 16.                                     */
+int32_t pcg_conv2d_bnin_full_ok(const pcg_conv_geom* g, int32_t groups);
+int pcg_conv2d_fwd_bnin_full(const pcg_conv_geom* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, int in_act, float in_slope, int32_t groups, const float* w, const float* bias /*nullable*/,
+                             int act, float slope, float* y, pcg_stream_t stream);
+int pcg_conv2d_wgrad_bnin_full(const pcg_conv_geom* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, int in_act, float in_slope, int32_t groups, const float* dy, float* dw, int accumulate,
+                               void* workspace, size_t workspace_bytes, pcg_stream_t stream);
+
 /* ---- pointwise activations (layers without BatchNorm) ----------------------------------------
  * nn.LeakyReLU after D's first conv (mnist_dcgan.py:101), nn.Tanh (:89), nn.Sigmoid (:112).        */
 int pcg_act_fwd(const float* x, int64_t n, int act, float slope, float* y, pcg_stream_t stream);

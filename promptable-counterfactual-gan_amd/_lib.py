@@ -99,6 +99,9 @@ PROTOTYPES = {
     "pcg_conv2d_fwd_bnbwd_thin_ok": (_i32, [_gp]),
     "pcg_conv2d_fwd_bnbwd_thin_workspace_bytes": (_sz, [_gp]),
     "pcg_conv2d_fwd_bnbwd_thin": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "pcg_conv2d_bnin_full_ok": (_i32, [_gp, _i32]),
+    "pcg_conv2d_fwd_bnin_full": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i32, _vp, _vp, _i, _f, _vp, _vp]),
+    "pcg_conv2d_wgrad_bnin_full": (_i, [_gp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i32, _vp, _vp, _i, _vp, _sz, _vp]),
     "pcg_slab_defer_begin": (_i, [_vp]),
     "pcg_slab_defer_flush": (_i, [_vp]),
     "pcg_slab_defer_pending": (_i32, []),

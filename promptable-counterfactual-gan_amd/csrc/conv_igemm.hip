@@ -1709,6 +1709,34 @@ extern "C" int pcg_conv2d_dgrad_bnbwd_full(const pcg_conv_geom* g, const float* 
   return thin_conv_dgrad_bnbwd_full(g, dy, w, z_below, mean, invstd, gamma, beta, act, slope, dz, dgamma, dbeta, accumulate, groups, workspace,
                                     workspace_bytes, (hipStream_t)stream);
 }
+// The full-window layer reading the PRE-BatchNorm output of the layer below (forward and weight gradient): see thin_conv.hip FullXf.
+extern "C" int32_t pcg_conv2d_bnin_full_ok(const pcg_conv_geom* g, int32_t groups) {
+  return check_geom(g) == PCG_OK && thin_conv_bnin_full_ok(g, groups) ? 1 : 0;
+}
+static int bnin_args(const char* who, const pcg_conv_geom* g, const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     int in_act, int32_t groups) {
+  if (int e = check_geom(g)) return e;
+  PCG_REQUIRE(z && mean && invstd && gamma && beta, "%s: null pointer", who);
+  PCG_REQUIRE(in_act == PCG_ACT_NONE || in_act == PCG_ACT_RELU || in_act == PCG_ACT_LRELU, "%s: input activation %d is not none / ReLU / LeakyReLU", who, in_act);
+  PCG_REQUIRE(pcg_conv2d_bnin_full_ok(g, groups), "%s: geometry / batch not eligible (pcg_conv2d_bnin_full_ok)", who);
+  return PCG_OK;
+}
+extern "C" int pcg_conv2d_fwd_bnin_full(const pcg_conv_geom* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, int in_act, float in_slope, int32_t groups, const float* w, const float* bias, int act,
+                                        float slope, float* y, pcg_stream_t stream) {
+  if (int e = bnin_args("pcg_conv2d_fwd_bnin_full", g, z, mean, invstd, gamma, beta, in_act, groups)) return e;
+  PCG_REQUIRE(w && y && act >= PCG_ACT_NONE && act <= PCG_ACT_SIGMOID, "pcg_conv2d_fwd_bnin_full: bad arguments");
+  const ThinBnIn bi{mean, invstd, gamma, beta, in_act, in_slope, groups};
+  return thin_conv_fwd(g, z, w, bias, y, nullptr, 0, (hipStream_t)stream, act, slope, &bi);
+}
+extern "C" int pcg_conv2d_wgrad_bnin_full(const pcg_conv_geom* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, int in_act, float in_slope, int32_t groups, const float* dy, float* dw, int accumulate,
+                                          void* workspace, size_t workspace_bytes, pcg_stream_t stream) {
+  if (int e = bnin_args("pcg_conv2d_wgrad_bnin_full", g, z, mean, invstd, gamma, beta, in_act, groups)) return e;
+  PCG_REQUIRE(dy && dw, "pcg_conv2d_wgrad_bnin_full: null pointer");
+  const ThinBnIn bi{mean, invstd, gamma, beta, in_act, in_slope, groups};
+  return thin_conv_wgrad(g, z, dy, dw, accumulate, workspace, workspace_bytes, (hipStream_t)stream, nullptr, &bi);
+}
 extern "C" int32_t pcg_conv2d_fwd_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? fwd_stat_rows(g) : 0; }
 extern "C" int32_t pcg_conv2d_dgrad_bn_partial_rows(const pcg_conv_geom* g) { return check_geom(g) == PCG_OK ? dgrad_stat_rows(g) : 0; }
 

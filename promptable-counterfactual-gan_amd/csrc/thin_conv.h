@@ -8,8 +8,12 @@ namespace pcg {
 inline bool thin_is_cin(const pcg_conv_geom* g) { return g->Cin <= 3; }
 inline bool thin_is_cout(const pcg_conv_geom* g) { return g->Cout <= 3 && !thin_is_cin(g); }
 
+// x of a full-window Cout = 1 layer given as the PRE-BatchNorm output of the layer below plus that layer's batch statistics (r04):
+// mean / invstd [groups][Cin]; the kernels read act(bn(x))
+struct ThinBnIn { const float* mean; const float* invstd; const float* gamma; const float* beta; int act; float slope; int groups; };
+bool thin_conv_bnin_full_ok(const pcg_conv_geom* g, int groups);
 int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
-                  size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f);
+                  size_t ws_bytes, hipStream_t s, int act = PCG_ACT_NONE, float slope = 0.f, const ThinBnIn* bnin = nullptr);
 // input transform on the WIDE operand of a Cin-thin layer (r04): it is a pre-BatchNorm tensor read as act(z * scale[c] + shift[c]) — a
 // one-channel ConvTranspose2d behind BatchNorm + ReLU (DCGAN's G5 behind G4) then needs no BatchNorm-apply pass and no activated copy
 struct ThinXf { const float* scale; const float* shift; float neg; };
@@ -20,7 +24,7 @@ size_t thin_conv_fwd_workspace_bytes(const pcg_conv_geom* g);   // optional scra
 size_t thin_conv_dgrad_workspace_bytes(const pcg_conv_geom* g);
 size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g);
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                    size_t ws_bytes, hipStream_t s, const ThinXf* xf = nullptr);
+                    size_t ws_bytes, hipStream_t s, const ThinXf* xf = nullptr, const ThinBnIn* bnin = nullptr);
 
 // Cin-thin forward fused with the BatchNorm + ReLU / LeakyReLU backward of the layer whose activated output it is a gradient of (r04)
 bool thin_conv_fwd_bnbwd_ok(const pcg_conv_geom* g);

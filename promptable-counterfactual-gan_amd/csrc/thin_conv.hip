@@ -162,25 +162,52 @@ bool full_window(const pcg_conv_geom* g) {
          (int64_t)g->B * L < (1ll << 31);
 }
 
+// x as the PRE-BatchNorm output z of the layer below (r04): the kernels evaluate act(bn(z)) on their loads with that layer's batch
+// statistics (mean / invstd [G][C], group = sample / Bg) — the BatchNorm-apply pass and the activated copy of D4's output disappear
+// (mnist_dcgan.py:108-110).  A thread's channel quad is fixed (256 % (C/4) == 0, rows are [hw][C]); same bn_fold expression as every
+// BatchNorm pass, so the values are the ones pcg_bn_apply_act would have written.
+struct FullXf { const float* mean; const float* invstd; const float* gamma; const float* beta; float neg; int C, Bg; };   // mean == nullptr: x is used as it is
+__device__ __forceinline__ void full_xf_coef(const FullXf& xf, int grp, int cq, float (&sc)[4], float (&sh)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * cq + e;
+    bn_fold(xf.gamma[c], xf.beta[c], xf.mean[grp * xf.C + c], xf.invstd[grp * xf.C + c], sc[e], sh[e]);
+  }
+}
+__device__ __forceinline__ float4 full_xf_apply(float4 v, const float (&sc)[4], const float (&sh)[4], float neg) {
+  return make_float4(act_neg_scale(fmaf(v.x, sc[0], sh[0]), neg), act_neg_scale(fmaf(v.y, sc[1], sh[1]), neg),
+                     act_neg_scale(fmaf(v.z, sc[2], sh[2]), neg), act_neg_scale(fmaf(v.w, sc[3], sh[3]), neg));
+}
 __global__ void __launch_bounds__(256) thin_full_dot_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ bias,
-                                                            float* __restrict__ y, int B, int L4, int act, float slope) {
+                                                            float* __restrict__ y, int B, int L4, int act, float slope, FullXf xf) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool has_xf = xf.mean != nullptr;
+  const int cq = has_xf ? threadIdx.x % (xf.C >> 2) : 0;
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  int last_grp = -1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const float4* xr = x + (size_t)b * L4;
+    if (has_xf && b / xf.Bg != last_grp) { last_grp = b / xf.Bg; full_xf_coef(xf, last_grp, cq, sc, sh); }   // (block-uniform)
     float a = 0.f;
     int i = threadIdx.x;
     for (; i + 7 * 256 < L4; i += 8 * 256) {   // 8 independent 16-byte loads of the row in flight
       float4 v[8], u[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { v[j] = xr[i + 256 * j]; u[j] = w[i + 256 * j]; }
+      if (has_xf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = full_xf_apply(v[j], sc, sh, xf.neg);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         a = fmaf(v[j].x, u[j].x, a); a = fmaf(v[j].y, u[j].y, a); a = fmaf(v[j].z, u[j].z, a); a = fmaf(v[j].w, u[j].w, a);
       }
     }
     for (; i < L4; i += 256) {
-      const float4 v = xr[i], u = w[i];
+      float4 v = xr[i];
+      const float4 u = w[i];
+      if (has_xf) v = full_xf_apply(v, sc, sh, xf.neg);
       a = fmaf(v.x, u.x, a); a = fmaf(v.y, u.y, a); a = fmaf(v.z, u.z, a); a = fmaf(v.w, u.w, a);
     }
 #pragma unroll
@@ -212,10 +239,13 @@ __global__ void __launch_bounds__(256) thin_full_outer_kernel(const float* __res
 
 // grid (ceil(L4/256), ceil(B/FULL_ROWS_DW)); slab row blockIdx.y holds the chunk's sums, samples added in order
 __global__ void __launch_bounds__(256) thin_full_wgrad_kernel(const float4* __restrict__ x, const float* __restrict__ dy, float4* __restrict__ slab, int B,
-                                                              int L4) {
+                                                              int L4, FullXf xf) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L4) return;
   const int b0 = blockIdx.y * FULL_ROWS_DW;
+  const bool has_xf = xf.mean != nullptr;       // (a chunk of FULL_ROWS_DW samples lies inside one group: checked on the host)
+  float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_xf) full_xf_coef(xf, b0 / xf.Bg, i % (xf.C >> 2), sc, sh);
   float4 v[FULL_ROWS_DW];
   float d[FULL_ROWS_DW];
 #pragma unroll
@@ -223,6 +253,7 @@ __global__ void __launch_bounds__(256) thin_full_wgrad_kernel(const float4* __re
     const int b = b0 + j;
     const bool ok = b < B;
     v[j] = ok ? x[(size_t)b * L4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_xf) v[j] = full_xf_apply(v[j], sc, sh, xf.neg);       // (a missing sample's dy is 0: its transformed value does not count)
     d[j] = ok ? dy[b] : 0.f;
   }
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -763,8 +794,21 @@ int launch_slab_reduce(const float* slab, float* dw, size_t n, size_t slab_strid
   return launch_status("slab_reduce_kernel");
 }
 
+// the BatchNorm-input form of the full-window kernels: x is the layer below's pre-BatchNorm output
+bool thin_conv_bnin_full_ok(const pcg_conv_geom* g, int groups) {
+  if (!full_window(g) || groups < 1 || groups > 8 || g->B % groups || g->Cin % 4) return false;
+  const int CQ = g->Cin / 4;
+  return CQ <= 256 && 256 % CQ == 0 && (g->B / groups) % FULL_ROWS_DW == 0;
+}
+static FullXf full_xf_of(const pcg_conv_geom* g, const ThinBnIn* bi) {
+  if (!bi || !bi->mean) return FullXf{nullptr, nullptr, nullptr, nullptr, 1.f, g->Cin, g->B};
+  return FullXf{bi->mean, bi->invstd, bi->gamma, bi->beta, act_neg_of(bi->act, bi->slope), g->Cin, g->B / bi->groups};
+}
+
 int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y, void* ws,
-                  size_t ws_bytes, hipStream_t s, int act, float slope) {
+                  size_t ws_bytes, hipStream_t s, int act, float slope, const ThinBnIn* bnin) {
+  PCG_REQUIRE(!(bnin && bnin->mean) || (thin_conv_bnin_full_ok(g, bnin->groups) && (((uintptr_t)x | (uintptr_t)w) & 15) == 0),
+              "thin conv forward: a BatchNorm input needs the full-window form (thin_conv_bnin_full_ok) and 16-byte aligned tensors");
   ThinP p{};
   p.act = act; p.slope = slope;
   const bool cin_thin = thin_is_cin(g);
@@ -781,7 +825,7 @@ int thin_conv_fwd(const pcg_conv_geom* g, const float* x, const float* w, const 
   if (full_window(g) && (((uintptr_t)x | (uintptr_t)w) & 15) == 0) {
     const int L4 = g->KH * g->KW * g->Cin / 4;
     hipLaunchKernelGGL(thin_full_dot_kernel, dim3((unsigned)(g->B < 4096 ? g->B : 4096)), dim3(256), 0, s, reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<const float4*>(w), bias, y, g->B, L4, act, slope);
+                       reinterpret_cast<const float4*>(w), bias, y, g->B, L4, act, slope, full_xf_of(g, bnin));
     return launch_status("thin_full_dot_kernel");
   }
   return launch_reduce(p, ws, ws_bytes, s);
@@ -954,9 +998,11 @@ size_t thin_conv_wgrad_workspace_bytes(const pcg_conv_geom* g) {
 }
 
 int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, float* dw, int accumulate, void* ws,
-                    size_t ws_bytes, hipStream_t s, const ThinXf* xf) {
+                    size_t ws_bytes, hipStream_t s, const ThinXf* xf, const ThinBnIn* bnin) {
   ThinP p{};
   const bool cin_thin = thin_is_cin(g);
+  PCG_REQUIRE(!(bnin && bnin->mean) || (thin_conv_bnin_full_ok(g, bnin->groups) && (((uintptr_t)x | (uintptr_t)ws) & 15) == 0),
+              "thin conv weight gradient: a BatchNorm input needs the full-window form (thin_conv_bnin_full_ok) and 16-byte aligned tensors");
   const bool has_xf = xf && xf->scale;
   PCG_REQUIRE(!has_xf || thin_conv_xf_ok(g), "thin conv weight gradient: this geometry takes no input transform (thin_conv_xf_ok)");
   if (has_xf) { p.xf_scale = xf->scale; p.xf_shift = xf->shift; p.xf_neg = xf->neg; }
@@ -968,7 +1014,7 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
       return PCG_ERR_WORKSPACE;
     }
     hipLaunchKernelGGL(thin_full_wgrad_kernel, dim3((unsigned)((L / 4 + 255) / 256), (unsigned)nslabs), dim3(256), 0, s, reinterpret_cast<const float4*>(x), dy,
-                       reinterpret_cast<float4*>(ws), g->B, L / 4);
+                       reinterpret_cast<float4*>(ws), g->B, L / 4, full_xf_of(g, bnin));
     if (int e = launch_status("thin_full_wgrad_kernel")) return e;
     return launch_slab_reduce((const float*)ws, dw, (size_t)L, (size_t)L, nslabs, accumulate, s, true);
   }

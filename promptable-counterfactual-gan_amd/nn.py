@@ -366,6 +366,18 @@ class SequentialConvNet(FlatModule):
             return self.fold_bn_apply
         return self.fold_bn_apply_thin and nxt.transposed and g.Cin == 1 and ops.xform_thin_ok(g)
 
+    def _next_reads_bn_input(self, idx, B, H, W, groups):
+        """Block idx + 1 is a full-window one-channel convolution that can read block idx's PRE-BatchNorm output (ops.BnInput): D's last
+        layer behind D4's BatchNorm + LeakyReLU.  B: samples in the launch (all groups)."""
+        if not self.fold_bn_apply_thin or idx + 1 >= len(self._blocks):
+            return False
+        b, nxt = self._blocks[idx], self._blocks[idx + 1]
+        if b.bn is None or not b.bn.training or b.act not in (ACT_NONE, ACT_RELU, ACT_LRELU) or nxt.transposed or nxt.bn is not None:
+            return False
+        if nxt.conv.out_channels != 1 or nxt.kh != H or nxt.kw != W or nxt.pad != 0:
+            return False
+        return ops.bnin_full_ok(ops.conv_geom(B, H, W, nxt.conv.in_channels, 1, nxt.kh, nxt.kw, nxt.stride, nxt.pad), groups)
+
     def _run_forward(self, x, keep=True):
         B, H, W, C = x.shape
         saved = []
@@ -419,7 +431,10 @@ class SequentialConvNet(FlatModule):
                 else:
                     z, mean, invstd = ops.conv_bn_train(g, a, w, bias, b.transposed, bn.eps, bn.momentum, bn.running_mean,
                                                         bn.running_var, bn.num_batches_tracked, xf=xf_in)
-                    y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
+                    if self._next_reads_bn_input(idx, B, OH, OW, 1):
+                        y, xf = None, ops.BnInput(mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)     # no apply pass, no activated copy
+                    else:
+                        y = ops.bn_apply_act(z, C, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope)
             elif b.bn is not None:
                 bn = b.bn
                 z = ops.conv2d_dgrad(g, a, w, bias, xf=xf_in) if b.transposed else ops.conv2d_fwd(g, a, w, bias, xf=xf_in)
@@ -496,11 +511,13 @@ class SequentialConvNet(FlatModule):
         B, H, W, C = xs[0].shape
         saved = []
         a = None
+        xf = None     # ops.BnInput pending on `a` (then the producer's PRE-BatchNorm output): see _next_reads_bn_input
         for idx, b in enumerate(self._blocks):
             c = b.conv
             w = _w_ohwi(c.weight.data)
             bias = c.bias.data if c.bias is not None else None
             mean = invstd = z = None
+            xf_in, xf = xf, None
             if idx == 0:
                 # the groups' inputs are separate tensors: the first layer runs once per group into its slice of ONE output
                 g = ops.conv_geom(B, H, W, c.in_channels, c.out_channels, b.kh, b.kw, b.stride, b.pad)
@@ -515,7 +532,10 @@ class SequentialConvNet(FlatModule):
                     bn = b.bn
                     z, mean, invstd = ops.conv_bn_train_g(g, a, w, bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
                                                           bn.num_batches_tracked, G)
-                    y = ops.bn_apply_act_g(z, c.out_channels, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, G)
+                    if self._next_reads_bn_input(idx, G * B, g.OH, g.OW, G):
+                        y, xf = None, ops.BnInput(mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, G)
+                    else:
+                        y = ops.bn_apply_act_g(z, c.out_channels, mean, invstd, bn.weight.data, bn.bias.data, b.act, b.slope, G)
                 elif b.bn is not None:
                     bn = b.bn
                     z = ops.conv2d_fwd(g, a, w, bias)
@@ -523,10 +543,12 @@ class SequentialConvNet(FlatModule):
                                          var_eps=bn.eps, out=z)
                     z = None
                 else:
-                    y = ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope)
+                    y = ops.conv2d_fwd(g, a, w, bias, act=b.act, slope=b.slope, xf=xf_in)
+            if xf_in is not None and (idx == 0 or b.bn is not None):
+                raise PcgError("grouped forward: a BatchNorm input reached a layer that cannot read it")     # (_next_reads_bn_input rules this out)
             if keep:
-                saved.append((g, a_in, z, mean, invstd, y, b.bn is not None and not b.bn.training))
-            a, H, W = y, g.OH, g.OW
+                saved.append((g, a_in, z, mean, invstd, y, b.bn is not None and not b.bn.training, xf_in))
+            a, H, W = (y if xf is None else z), g.OH, g.OW
         return a, (saved, G, B)
 
     def _run_backward_groups(self, saved_all, dy):
@@ -546,7 +568,7 @@ class SequentialConvNet(FlatModule):
     def _run_backward_groups_impl(self, saved, G, B, d, own, fused, defer):
         for idx in range(len(self._blocks) - 1, -1, -1):
             b = self._blocks[idx]
-            g, a, z, mean, invstd, y, bn_eval = saved[idx]
+            g, a, z, mean, invstd, y, bn_eval, xf_in = saved[idx]
             c = b.conv
             C = c.out_channels
             if defer is not None:
@@ -576,12 +598,12 @@ class SequentialConvNet(FlatModule):
                 gw, acc = self._grad_view(c.weight)
                 gw = _w_ohwi(gw)
 
-                def wgrad_job(idx=idx, g=g, a=a, dz=dz, gw=gw, acc=acc, c=c, C=C):
+                def wgrad_job(idx=idx, g=g, a=a, dz=dz, gw=gw, acc=acc, c=c, C=C, xf_in=xf_in):
                     if idx == 0:
                         for k, x in enumerate(a):       # per group: the inputs are separate tensors (.grad accumulation of :153,161)
                             ops.conv2d_wgrad(g, x, dz[k * B:(k + 1) * B], gw, acc or k > 0)
                     else:
-                        ops.conv2d_wgrad(g, a, dz, gw, acc)      # ONE sum over the pixels of all groups
+                        ops.conv2d_wgrad(g, a, dz, gw, acc, xf_x=xf_in)      # ONE sum over the pixels of all groups
                     if c.bias is not None and c.bias.requires_grad:
                         gb, accb = self._grad_view(c.bias)
                         ops.colsum(dz.numel() // C, C, dz, gb, accb)
@@ -596,7 +618,7 @@ class SequentialConvNet(FlatModule):
             if idx == 0:
                 return None
             lo = self._blocks[idx - 1]
-            _, _, zl, ml, il, yl, lo_eval = saved[idx - 1]
+            _, _, zl, ml, il, yl, lo_eval, _ = saved[idx - 1]
             w = _w_ohwi(c.weight.data)
             fused = None
             mfma = g.Cin > 3 and g.Cout > 3 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and g.stride <= 2

@@ -227,6 +227,20 @@ def xform_ok(g, operand):
     return g.Cin > 3 and g.Cout > 3 and g.Cin % 4 == 0 and g.Cout % 4 == 0 and g.stride <= 2
 
 
+class BnInput:
+    """An activation that exists only as (pre-BatchNorm tensor z, the producing layer's batch statistics mean / invstd [groups][C], its
+    gamma / beta, activation): a full-window one-channel convolution reads act(bn(z)) in its own loads (pcg_conv2d_*_bnin_full).  Accepted
+    where an InputXform is: conv2d_fwd(xf=), conv2d_wgrad(xf_x=)."""
+
+    def __init__(self, mean, invstd, gamma, beta, act, slope, groups=1):
+        self.mean, self.invstd, self.gamma, self.beta = mean, invstd, gamma, beta
+        self.act, self.slope, self.groups = int(act), float(slope), int(groups)
+
+
+def bnin_full_ok(g, groups=1):
+    return bool(_lib.load().pcg_conv2d_bnin_full_ok(ctypes.byref(g), int(groups)))
+
+
 def xform_thin_ok(g):
     """A Cin = 1 layer whose dy-side operand may carry an input transform (pcg_conv2d_xf_thin_ok): conv2d_dgrad(xf=) / conv2d_wgrad(xf_dy=)."""
     return bool(_lib.load().pcg_conv2d_xf_thin_ok(ctypes.byref(g)))
@@ -245,7 +259,10 @@ def conv2d_fwd(g, x, w, bias=None, out=None, act=0, slope=0.0, xf=None):
     need = lib.pcg_conv2d_fwd_workspace_bytes(ctypes.byref(g))
     ws = workspace(need, x.device) if need else None
     with _Timed(g, "fwd"):
-        if xf is not None:
+        if isinstance(xf, BnInput):
+            check(lib.pcg_conv2d_fwd_bnin_full(ctypes.byref(g), _p(x), _p(xf.mean), _p(xf.invstd), _p(xf.gamma), _p(xf.beta), xf.act, xf.slope,
+                                               xf.groups, _p(w), _p(bias), int(act), float(slope), _p(y), _stream()), "pcg_conv2d_fwd_bnin_full")
+        elif xf is not None:
             assert xf.C == g.Cin
             check(lib.pcg_conv2d_fwd_xf(ctypes.byref(g), _p(x), xf.ref(), _p(w), _p(bias), int(act), float(slope), _p(y), _p(ws),
                                         ws.numel() if need else 0, _stream()), "pcg_conv2d_fwd_xf")
@@ -488,7 +505,11 @@ def conv2d_wgrad(g, x, dy, dw, accumulate, xf_x=None, xf_dy=None):
     else:
         ws = workspace(need, x.device)
     with _Timed(g, "wgrad"):
-        if xf_x is None and xf_dy is None:
+        if isinstance(xf_x, BnInput):
+            check(lib.pcg_conv2d_wgrad_bnin_full(ctypes.byref(g), _p(x), _p(xf_x.mean), _p(xf_x.invstd), _p(xf_x.gamma), _p(xf_x.beta), xf_x.act,
+                                                 xf_x.slope, xf_x.groups, _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
+                  "pcg_conv2d_wgrad_bnin_full")
+        elif xf_x is None and xf_dy is None:
             check(lib.pcg_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), int(bool(accumulate)), _p(ws), ws.numel(), _stream()),
                   "pcg_conv2d_wgrad")
         else:

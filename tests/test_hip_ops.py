@@ -496,6 +496,31 @@ def test_input_transform_on_the_one_channel_transposed_layer(pcg, B, H, C, act, 
     assert torch.equal(dw1, dw2)
 
 
+@pytest.mark.parametrize("B,groups", [(32, 1), (64, 2), (48, 3)])
+@pytest.mark.parametrize("act,slope", [(O.ACT_LRELU, 0.2), (O.ACT_RELU, 0.0)])
+def test_full_window_layer_reads_the_pre_batchnorm_tensor(pcg, B, groups, act, slope):
+    """ops.BnInput: the full-window one-channel convolution's forward and weight gradient on (z, batch statistics per group) == the plain
+    calls on bn_apply_act(z) of every group: bit for bit."""
+    ops = pcg.ops
+    C, Bg = 512, B // groups
+    g = ops.conv_geom(B, 4, 4, C, 1, 4, 4, 1, 0)
+    assert ops.bnin_full_ok(g, groups) and not ops.bnin_full_ok(ops.conv_geom(B + 8, 4, 4, C, 1, 4, 4, 1, 0), 1)
+    gen = torch.Generator().manual_seed(9 + B)
+    z = (torch.randn(B, 4, 4, C, generator=gen) * 1.3 + 0.2).to(dev()); w = (torch.randn(1, 4, 4, C, generator=gen) * 0.05).to(dev())
+    bias = torch.randn(1, generator=gen).to(dev()); dy = torch.randn(B, 1, 1, 1, generator=gen).to(dev())
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=gen)).to(dev()), (0.1 * torch.randn(C, generator=gen)).to(dev())
+    zg = z.reshape(groups, Bg * 16, C)
+    mean = zg.mean(1).contiguous(); invstd = (1.0 / torch.sqrt(zg.var(1, unbiased=False) + 1e-5)).contiguous()
+    a = torch.cat([ops.bn_apply_act(z[k * Bg:(k + 1) * Bg].contiguous(), C, mean[k].contiguous(), invstd[k].contiguous(), gamma, beta, act, slope)
+                   for k in range(groups)])
+    bi = ops.BnInput(mean, invstd, gamma, beta, act, slope, groups)
+    assert torch.equal(ops.conv2d_fwd(g, z, w, bias, act=O.ACT_SIGMOID, xf=bi), ops.conv2d_fwd(g, a, w, bias, act=O.ACT_SIGMOID))
+    dw1, dw2 = torch.full((1, 4, 4, C), 0.5, device=dev()), torch.full((1, 4, 4, C), 0.5, device=dev())
+    ops.conv2d_wgrad(g, z, dy, dw1, True, xf_x=bi)
+    ops.conv2d_wgrad(g, a, dy, dw2, True)
+    assert torch.equal(dw1, dw2)
+
+
 def test_input_transform_rejected_on_thin_layers(pcg):
     ops = pcg.ops
     geom = ops.conv_geom(2, 8, 8, 64, 1, 4, 4, 2, 1)
