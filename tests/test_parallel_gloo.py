@@ -152,6 +152,27 @@ def _toy_step(rec, netG, netD, optD, optG, real, noise, dp):
     return netD.flat_grads
 
 
+def _toy_pair_step(rec, netG, netD, optD, optG, real, noise, dp):
+    """The exchange points of dcgan.train_step(pair=True) (r04): wait(G) leads the step — G's forward comes first and the real and fake
+    discriminator passes are one pass — then sync_now(D), Adam(D), the G step, sync_then(G, Adam).  Same arithmetic as _toy_step."""
+    L = rec.launch
+    if dp is not None:
+        dp.wait(netG)                                                         # previous Adam(G) done: G's forward leads
+    L(lambda: netD.flat_grads.zero_())
+    L(lambda: netD.flat_grads.add_(real.sum() * netD.flat_params).add_(noise.sum() * netG.flat_params[:netD.flat_params.numel()]))   # ONE 2B pass
+    L(lambda: netD.bn_running.add_(real.mean()))
+    if dp is not None:
+        dp.sync_now(netD)
+    optD.step()
+    L(lambda: netG.flat_grads.zero_())
+    L(lambda: netG.flat_grads.add_(noise.sum() * netG.flat_params).add_(netD.flat_params.sum()))
+    if dp is not None:
+        dp.sync_then(netG, optG.step)
+    else:
+        optG.step()
+    return netD.flat_grads
+
+
 def _toy_countergan_step(rec, netG, netD, optD, optG, real, noise, dp):
     """The exchange points of countergan.train_step (mnist/trainer.py:96-123) in its data-parallel order: D(real) forward hoisted
     above wait(G), generator forward, D update (bucket averaged in stream order), G update (bucket + Adam overlapped)."""
@@ -183,7 +204,7 @@ def _segment_worker(rank, world, port, q, toy="dcgan"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pcgan_amd.nn import GraphedStep
     from pcgan_amd.parallel import GradSync
-    _toy_step = globals()["_toy_step" if toy == "dcgan" else "_toy_countergan_step"]
+    _toy_step = globals()[{"dcgan": "_toy_step", "dcgan_pair": "_toy_pair_step"}.get(toy, "_toy_countergan_step")]
 
     def build():
         rec = _Recorder()
@@ -211,6 +232,7 @@ def _segment_worker(rank, world, port, q, toy="dcgan"):
     ok = torch.equal(gG.flat_params, before[0]) and torch.equal(gD.flat_params, before[1])      # building it did not train
     ok = ok and float(oD2.steps) == 0 and float(gD.bn_running.abs().sum()) == 0
     # wait(G) | sync_now(D) | sync_then(G, Adam) cut the step into 4 segments, with the three exchanges between them
+    # (the paired order starts with wait(G): its first segment holds no launch, the program keeps the same shape)
     ok = ok and len(gs.program) == 4 and [op is not None for _, op in gs.program] == [True, True, True, False]
     for _ in range(steps):
         gs.load(real=shards[rank][0], noise=shards[rank][1])
@@ -219,7 +241,7 @@ def _segment_worker(rank, world, port, q, toy="dcgan"):
     ok = ok and torch.equal(gG.flat_params, eG.flat_params) and torch.equal(gD.flat_params, eD.flat_params)
     ok = ok and torch.equal(gD.bn_running, eD.bn_running) and float(oG2.steps) == steps
 
-    if toy != "dcgan":      # the single-process closed form below is the DCGAN toy's; (a) == (b) and (d) cover this order
+    if toy not in ("dcgan", "dcgan_pair"):      # the single-process closed form below is the DCGAN toy's; (a) == (b) and (d) cover this order
         for t in (gG.flat_params, gD.flat_params):
             gathered = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(gathered, t)
@@ -252,7 +274,7 @@ def _segment_worker(rank, world, port, q, toy="dcgan"):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("toy", ["dcgan", "countergan"])
+@pytest.mark.parametrize("toy", ["dcgan", "dcgan_pair", "countergan"])
 def test_segment_program_world2_gloo(toy):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
