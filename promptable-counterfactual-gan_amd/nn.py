@@ -768,13 +768,17 @@ class SequentialConvNet(FlatModule):
             if not b.transposed:
                 lo = self._blocks[idx - 1] if not last else None
                 if (lo is not None and self.fuse_backward_epilogue and lo.bn is not None and lo.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
-                        and not saved[idx - 1][6] and saved[idx - 1][2] is not None and lo.bn.weight.requires_grad and need_p
+                        and not saved[idx - 1][6] and saved[idx - 1][2] is not None
                         and self.fuse_full_window_bn and ops.full_dgrad_bn_bwd_ok(g)):
                     # a full-window one-channel convolution above a BatchNorm layer (D5 above D4): its grad-input — one multiply per
-                    # element — goes through that BatchNorm's backward without being written
+                    # element — goes through that BatchNorm's backward without being written (with or without parameter gradients:
+                    # the G step's pass through D wants none)
                     _, _, zl, ml, il, _, _, _ = saved[idx - 1]
-                    dgl, accl = self._grad_view(lo.bn.weight)
-                    dbl, _ = self._grad_view(lo.bn.bias)
+                    dgl = dbl = None
+                    accl = False
+                    if need_p and lo.bn.weight.requires_grad:
+                        dgl, accl = self._grad_view(lo.bn.weight)
+                        dbl, _ = self._grad_view(lo.bn.bias)
                     d = ops.full_dgrad_bn_bwd(g, dz, _w_ohwi(c.weight.data), zl, ml, il, lo.bn.weight.data, lo.bn.bias.data, lo.act, lo.slope,
                                               dgl, dbl, accl)
                     fused = ("done",)

@@ -169,6 +169,7 @@ def test_full_window_grad_input_through_batchnorm_backward(pcg, B, groups, act, 
     assert (out - ref).abs().max().item() <= 2e-6 * scale
     np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * dg_ref.abs().max().item())
     np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=2e-5, atol=2e-6 * db_ref.abs().max().item())
+    assert torch.equal(ops.full_dgrad_bn_bwd(g, dy, w, z, mean, invstd, gamma, beta, act, slope, None, None, False, groups=groups), out)   # no parameter gradients wanted
     # accumulate: a second call adds into dgamma / dbeta
     ops.full_dgrad_bn_bwd(g, dy, w, z, mean, invstd, gamma, beta, act, slope, dg, db, True, groups=groups)
     np.testing.assert_allclose(dg.cpu().numpy(), 2 * dg_ref.cpu().numpy(), rtol=2e-5, atol=4e-6 * dg_ref.abs().max().item())
