@@ -43,7 +43,18 @@ __global__ void __launch_bounds__(256) embed_table_grad_kernel(const float* __re
   if (i < total) {
     const int k = i / HW, p = i - k * HW;
     const int chunk = (B + 15) / 16, b0 = g * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
-    for (int b = b0; b < b1; ++b)
+    // every row is loaded (the gradient is a few MB: cache-resident) and a non-matching one adds 0 — eight independent loads in flight
+    // instead of a chain of branches; same sum (s + 0 == s), same order (r04: 25.7 -> 7.3 us at batch 1024)
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+      bool m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = dinp[((size_t)(b + j) * HW + p) * C + ch]; m[j] = idx[b + j] == (int64_t)k; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += m[j] ? v[j] : 0.f;
+    }
+    for (; b < b1; ++b)
       if (idx[b] == (int64_t)k) s += dinp[((size_t)b * HW + p) * C + ch];
   }
   red[g][il] = s;
