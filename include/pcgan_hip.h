@@ -189,8 +189,9 @@ int pcg_conv2d_dgrad_add(const pcg_conv_geom* g, const float* dy, const float* w
  * (`x + 0.1*bn2(conv2(...))`, models/generator.py:18-20: the gradient arriving at block i-1's bn2 is the sum block i's backward just
  * formed): partial rows get sum(sum_scale*dx) and sum(sum_scale*dx*xhat) with xhat from z_next / mean / invstd of that BatchNorm;
  * dx itself is stored unscaled.  Finish with pcg_bn_bwd_partial_db(dm = dx, dm_scale = sum_scale).  partial: the buffer of
- * pcg_conv2d_dgrad_bn_workspace_bytes, pcg_conv2d_dgrad_bn_partial_rows rows. */
-int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend, const float* z_next,
+ * pcg_conv2d_dgrad_bn_workspace_bytes, pcg_conv2d_dgrad_bn_partial_rows rows.  addend == NULL (r04, both forms): the plain grad-input
+ * with the sums — the head of the chain, conv_mid's grad-input above the last block's bn2 (generator.py:49,78). */
+int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* dy, const float* w, const float* addend /*nullable*/, const float* z_next,
                                const float* mean, const float* invstd, float sum_scale, float* dx, void* partial, size_t partial_bytes,
                                pcg_stream_t stream);
 /* The `fwd` forms of the skip-add epilogues (a ConvTranspose2d's grad-input; or a stride-1 Conv2d's grad-input run as a forward

@@ -306,13 +306,14 @@ class ResidualGenerator(FlatModule):
         dc = ops.scale_mask_bwd(dr, dm, mr, self.residual_scaling, like=mr).view(g_out.B, g_out.OH, g_out.OW, 1)
         _conv_wgrad(self, self.conv_out, g_out, hm, dc, True)
         d = _dgrad_act(g_out, dc, ops.ohwi(self.conv_out.weight.data), hm, ACT_LRELU, slope)     # the mask rides in the thin expand kernel
-        dh = _conv_bwd(self, self.conv_mid, g_mid, h_last, d, True, True)
         order = list(zip(reversed(self.resblocks), reversed(blocks)))
         # adjoint weights of every stride-1 conv whose grad-input runs on the forward kernel: ONE launch for all of them (r04; was one
         # 6 us launch in front of each of the 12 grad-inputs)
         adjw = {}
         if FUSE_BACKWARD_EPILOGUE and S1_DGRAD_AS_FWD:
             convs = [c for blk, sv in order for c, g_ in ((blk.conv2, sv[6]), (blk.conv1, sv[0])) if g_.stride == 1 and ops.xform_ok(g_, "x")]
+            if FUSE_SKIP_BNSUM and order and g_mid.stride == 1 and ops.xform_ok(g_mid, "x"):
+                convs.append(self.conv_mid)
             shapes = {tuple(c.weight.shape) for c in convs}
             if convs and len(shapes) == 1 and len(convs) <= 16:
                 for c, wa in zip(convs, ops.conv_weight_adjoint_many([ops.ohwi(c.weight.data) for c in convs])):
@@ -322,6 +323,17 @@ class ResidualGenerator(FlatModule):
             wa = adjw.get(id(conv))
             return wa if wa is not None else ops.conv_weight_adjoint(ops.ohwi(conv.weight.data))
         pending = None      # (partial, nparts): bn2's backward sums of the gradient `dh`, left by the previous block's skip-add epilogue
+        # conv_mid's backward: weight / bias gradients, then its grad-input `dh` = the gradient of the last block's output — with the column
+        # sums that block's bn2 backward needs, out of the same epilogue (r04: the head of the chain takes the no-addend form)
+        _conv_wgrad(self, self.conv_mid, g_mid, h_last, d, True)
+        head = order[0][1] if order else None
+        adjm = FUSE_BACKWARD_EPILOGUE and S1_DGRAD_AS_FWD and FUSE_SKIP_BNSUM and head is not None and g_mid.stride == 1 and ops.xform_ok(g_mid, "x")
+        if adjm:
+            dh, part, nparts = ops.conv2d_dgrad_add(ops.adjoint_geom(g_mid), d, adjoint_of(self.conv_mid), None,
+                                                    bnsum=(head[7], head[8], head[9], 0.1), transposed=True)
+            pending = (part, nparts)
+        else:
+            dh = ops.conv2d_dgrad(g_mid, d, ops.ohwi(self.conv_mid.weight.data))
         h0_masked = False
         for bi, (blk, (g1, h, z1, a1, m1, s1, g2, z2, m2, s2)) in enumerate(order):
             C = blk.bn2.num_features

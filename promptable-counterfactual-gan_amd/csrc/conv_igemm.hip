@@ -1530,7 +1530,8 @@ extern "C" int pcg_conv2d_fwd_add_bnsum(const pcg_conv_geom* g, const float* x, 
   EpiAux e{};
   e.mode = EPI_ADDSUM;
   if (int rc = check_geom(g)) return rc;
-  if (int rc = epi_common("pcg_conv2d_fwd_add_bnsum", g, y, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  e.no_addend = addend == nullptr;          // (r04) nullable: the sums of the plain result
+  if (int rc = epi_common("pcg_conv2d_fwd_add_bnsum", g, y, addend ? addend : y, PCG_ACT_NONE, 0.f, &e)) return rc;
   const size_t need = pcg_conv2d_fwd_bn_workspace_bytes(g);
   PCG_REQUIRE(need > 0, "pcg_conv2d_fwd_add_bnsum: layer not eligible (MFMA layers, channel count %% 4 == 0)");
   PCG_REQUIRE(z_next && mean && invstd && (((uintptr_t)z_next | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0,
@@ -1599,7 +1600,8 @@ extern "C" int pcg_conv2d_dgrad_add_bnsum(const pcg_conv_geom* g, const float* d
   EpiAux e{};
   e.mode = EPI_ADDSUM;
   if (int rc = check_geom(g)) return rc;
-  if (int rc = epi_common("pcg_conv2d_dgrad_add_bnsum", g, dx, addend, PCG_ACT_NONE, 0.f, &e)) return rc;
+  e.no_addend = addend == nullptr;          // (r04) nullable: the sums of the plain result
+  if (int rc = epi_common("pcg_conv2d_dgrad_add_bnsum", g, dx, addend ? addend : dx, PCG_ACT_NONE, 0.f, &e)) return rc;
   const size_t need = pcg_conv2d_dgrad_bn_workspace_bytes(g);
   PCG_REQUIRE(need > 0, "pcg_conv2d_dgrad_add_bnsum: layer not eligible (MFMA layers, stride <= 2, channel count %% 4 == 0)");
   PCG_REQUIRE(z_next && mean && invstd && (((uintptr_t)z_next | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0,

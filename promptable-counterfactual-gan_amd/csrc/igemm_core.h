@@ -517,6 +517,8 @@ struct EpiAux {
   int64_t delta_bytes;      // (char*)aux - (char*)out
   int64_t delta2_bytes;     // EPI_ADDSUM: (char*)z_next - (char*)out
   const float* mean; const float* invstd; const float* gamma; const float* beta;   // EPI_BNBWD, per output column
+  int no_addend;            // EPI_ADDSUM without an addend (r04): the aux resource is empty, its loads return 0 — the column sums of a plain
+                            // grad-input for a BatchNorm whose gradient arrives scaled (CounteRGAN: conv_mid's grad-input above the last block's bn2)
   int group_rows;           // > 0: grouped launch (r04) — G independent batches side by side along M, `group_rows` rows each (per sub-pixel
                             // phase for a grad-input launch; a multiple of the tile height): mean / invstd are [G][N], the tile's group
                             // picks the row (the caller passes the offset to igemm_store_tile)
@@ -601,8 +603,8 @@ __device__ __forceinline__ void igemm_store_tile(f32x16 (&acc)[Cfg::TM][Cfg::TN]
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
       float* dst = row_base(wm * Cfg::WTM + r0 + RPI * (k0 + kk));
-      u[kk] = (dst && nok) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      u[kk] = (dst && nok && !epi->no_addend) ? *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dst + wn * Cfg::WTN + 4 * cq) + delta)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (emode == EPI_ADDSUM) {   // wave-uniform: its own loop (the second aux tensor is read next to each row's arithmetic)
       const int64_t delta2 = epi->delta2_bytes;
@@ -858,7 +860,7 @@ struct EpiBufs { rsrc_t out, aux, aux2; };
 __device__ __forceinline__ EpiBufs make_epi_bufs(float* out, uint32_t out_bytes, const EpiAux& e) {
   EpiBufs b;
   b.out = make_rsrc(out, out_bytes);
-  b.aux = make_rsrc(reinterpret_cast<const char*>(out) + e.delta_bytes, e.mode != EPI_NONE ? out_bytes : 0u);
+  b.aux = make_rsrc(reinterpret_cast<const char*>(out) + e.delta_bytes, (e.mode != EPI_NONE && !e.no_addend) ? out_bytes : 0u);
   b.aux2 = make_rsrc(reinterpret_cast<const char*>(out) + e.delta2_bytes, e.mode == EPI_ADDSUM ? out_bytes : 0u);
   return b;
 }

@@ -413,10 +413,14 @@ def conv2d_dgrad_add(g, dy, w, addend, out=None, bnsum=None, transposed=False):
     bnsum = (z_next, mean, invstd, scale): also leave the BatchNorm-backward column sums of scale*dx for the BatchNorm whose
     pre-normalisation output is z_next (the next one down the skip chain); returns (dx, partial, nparts) for bn_bwd_partial(dm_scale=scale).
     transposed=True: the forward-kernel form (g, w describe a forward convolution whose input is `dy`: ConvTranspose2d layers, or a
-    stride-1 layer through adjoint_geom / conv_weight_adjoint)."""
-    _chk(dy, "dy"); _chk(w, "w"); _chk(addend, "addend")
+    stride-1 layer through adjoint_geom / conv_weight_adjoint).  addend=None (with bnsum only): the plain grad-input and its sums."""
+    _chk(dy, "dy"); _chk(w, "w")
     shape = (g.B, g.OH, g.OW, g.Cout) if transposed else (g.B, g.IH, g.IW, g.Cin)
-    assert addend.numel() == shape[0] * shape[1] * shape[2] * shape[3]
+    if addend is None:
+        assert bnsum is not None, "conv2d_dgrad_add: addend=None only together with bnsum"
+    else:
+        _chk(addend, "addend")
+        assert addend.numel() == shape[0] * shape[1] * shape[2] * shape[3]
     dx = out if out is not None else torch.empty(shape, dtype=torch.float32, device=dy.device)
     lib = _lib.load()
     if bnsum is not None:

@@ -175,6 +175,30 @@ def test_full_window_grad_input_through_batchnorm_backward(pcg, B, groups, act, 
     np.testing.assert_allclose(dg.cpu().numpy(), 2 * dg_ref.cpu().numpy(), rtol=2e-5, atol=4e-6 * dg_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B", [4, 64])
+@pytest.mark.parametrize("transposed", [True, False])
+def test_bnsum_epilogue_without_an_addend(pcg, B, transposed):
+    """conv2d_dgrad_add(addend=None, bnsum=...) — the head of a skip chain: the plain grad-input with the next BatchNorm's backward
+    column sums — == the same call with an all-zero addend, bit for bit (result and partial rows), in both epilogue forms (small and
+    large launches take different kernels)."""
+    ops = pcg.ops
+    C, H = 64, 28
+    g = ops.conv_geom(B, H, H, C, C, 3, 3, 1, 1)
+    gen = torch.Generator().manual_seed(B)
+    dy = torch.randn(B, H, H, C, generator=gen).to(dev()); w = (torch.randn(C, 3, 3, C, generator=gen) * 0.05).to(dev())
+    z = (torch.randn(B, H, H, C, generator=gen) * 1.2 + 0.1).to(dev())
+    mean, invstd = ops.bn_train_stats(z, C, 1e-5, 0.1)
+    ga, wa = (ops.adjoint_geom(g), ops.conv_weight_adjoint(w)) if transposed else (g, w)
+    d0, p0, n0 = ops.conv2d_dgrad_add(ga, dy, wa, torch.zeros(B, H, H, C, device=dev()), bnsum=(z, mean, invstd, 0.1), transposed=transposed)
+    out = torch.full((B, H, H, C), float("nan"), device=dev())        # whatever the output buffer held must not leak into the result
+    d1, p1, n1 = ops.conv2d_dgrad_add(ga, dy, wa, None, out=out, bnsum=(z, mean, invstd, 0.1), transposed=transposed)
+    assert n0 == n1 and torch.equal(d0, d1)
+    rows = 2 * C * n0
+    assert torch.equal(p0.view(torch.float64)[:rows], p1.view(torch.float64)[:rows])
+    ref = ops.conv2d_dgrad(g, dy, w)
+    assert (d1 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_deferred_slab_reductions_are_bit_identical(pcg):
     """ops.slab_reductions_deferred(): the weight gradients of a sweep reduced in one launch == reduced per call, bit for bit; two sums
     into the same gradient stay in call order; a split-K FORWARD inside the block is not deferred."""
