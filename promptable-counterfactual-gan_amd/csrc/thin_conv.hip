@@ -626,6 +626,13 @@ int launch_expand(ThinP& p, hipStream_t s) {
     const size_t two = 2 * ((patch_bytes + 15) & ~(size_t)15), sm = smem > two ? smem : two;
     const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
     const unsigned blocks = rows_expand_blocks(rp.nunits);
+    static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch
+    if (mfma_on && p.Cs == 1 && p.C == 64 && !p.mask_src && (((uintptr_t)p.out) & 15) == 0) {     // one thin channel, 64 wide channels: the matrix-core form
+      const size_t sm2 = 2 * ((patch_bytes + 15) & ~(size_t)15);
+      if (k44) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<4, 4>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      else hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      return launch_status("thin_rows_expand_mfma_kernel");
+    }
 #define PCG_ROWS_EXPAND_CASE(KH_, KW_, CS_)                                                                                  \
     if (p.KH == KH_ && p.Cs == CS_) {                                                                                         \
       hipLaunchKernelGGL((thin_rows_expand_kernel<KH_, KW_, CS_>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes);      \
