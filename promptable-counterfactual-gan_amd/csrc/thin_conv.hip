@@ -873,7 +873,11 @@ int thin_conv_fwd_bnbwd(const pcg_conv_geom* g, const float* x, const float* w, 
   double* partial = (double*)ws;
   float* coef = reinterpret_cast<float*>(partial + (size_t)THIN_BN_BLOCKS * 2 * p.C);
   ThinBnBwd bn{z, mean, invstd, gamma, beta, coef, act_neg_of(act, slope), partial};
-  hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, false>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
+  static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch (with the forward's)
+  if (mfma_on && p.C == 64)       // the sums pass on the matrix cores
+    hipLaunchKernelGGL((thin_rows_expand_bn_sums_mfma_kernel<4, 4>), dim3(blocks), dim3(256), two, s, p, rp, thin_bytes, bn);
+  else
+    hipLaunchKernelGGL((thin_rows_expand_bn_kernel<4, 4, 1, false>), dim3(blocks), dim3(256), sm, s, p, rp, thin_bytes, bn);
   if (int e = launch_status("thin_rows_expand_bn_kernel(sums)")) return e;
   if (int e = launch_bn_bwd_finalize(partial, (int)blocks, (int64_t)g->B * g->OH * g->OW, p.C, gamma, invstd, coef, dgamma, dbeta, accumulate, s)) return e;
   const unsigned ablocks = rows_expand_blocks(rp.nunits);
