@@ -1050,6 +1050,14 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
   if (rows) {
     const int upb = (rp.nunits + nslabs - 1) / nslabs;
     const int nb = (rp.nunits + upb - 1) / upb;      // blocks that own at least one unit (<= nslabs)
+    static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch (with the expand forms')
+    if (mfma_on && p.Cs == 1 && p.C == 64 && (g->KH == 4 || g->KH == 3) && (((uintptr_t)p.wide) & 3) == 0) {      // the matrix-core form
+      const size_t sm2 = 2 * ((patch_bytes + 15) & ~(size_t)15);
+      if (g->KH == 4) hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<4, 4>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      else hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<3, 3>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      if (int e = launch_status("thin_rows_wgrad_mfma_kernel")) return e;
+      return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, nb, accumulate, s, true);
+    }
 #define PCG_ROWS_WGRAD_CASE(KH_, KW_, CS_)                                                                                       \
     if (g->KH == KH_ && p.Cs == CS_) {                                                                                            \
       hipLaunchKernelGGL((thin_rows_wgrad_kernel<KH_, KW_, CS_>), dim3(nb), dim3(256), 2 * ((patch_bytes + 15) & ~(size_t)15), s, p, rp, slab, wn, upb, \
