@@ -941,9 +941,9 @@ class _CutDP:
 class _HipGraphCapture:
     """Capture backend of GraphedStep: HIP graphs (torch.cuda.CUDAGraph), every segment in ONE memory pool."""
 
-    def __init__(self, device):
+    def __init__(self, device, tick=True):
         self._pool = None
-        self._tick = torch.zeros(1, device=device)
+        self._tick = torch.zeros(1, device=device) if tick else None     # tick=False: one segment holding the whole step, never empty
 
     def warmup(self, run, n, dp):
         side = torch.cuda.Stream()
@@ -970,7 +970,8 @@ class _HipGraphCapture:
         except BaseException:
             self._gc_restore()         # the capture never began: end() will not run, the collector must not stay off
             raise
-        self._tick.add_(1.0)       # no segment is ever empty (an empty capture cannot be instantiated)
+        if self._tick is not None:
+            self._tick.add_(1.0)   # no segment is ever empty (an empty capture cannot be instantiated)
 
     def _gc_restore(self):
         if getattr(self, "_gc_was_on", False):
@@ -1023,7 +1024,9 @@ class GraphedStep:
         osnap = [o.snapshot() for o in optimizers]
         run = step_fn if dp is None else (lambda: step_fn(dp))
         if capture is None:
-            capture = _HipGraphCapture(self.inputs[next(iter(self.inputs))].device if self.inputs else torch.device("cuda"))
+            # the segments of a data-parallel program may hold no launch (the paired step starts with wait(G)): they carry a one-element add;
+            # the single graph of a one-rank step does not need it (4.6 us per replay)
+            capture = _HipGraphCapture(self.inputs[next(iter(self.inputs))].device if self.inputs else torch.device("cuda"), tick=dp is not None)
         self._capture = capture
         capture.warmup(run, max(1, warmup), dp)
         self.program = []          # [(graph, eager operation after it or None)]
