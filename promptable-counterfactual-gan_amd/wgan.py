@@ -364,7 +364,7 @@ def critic_step_batched(critic, generator, critic_optimizer, hp, real_images, re
     B = real_images.shape[0]
     dev = real_images.device
     critic._ensure_flat()
-    critic_optimizer.zero_grad()                                                         # :136
+    critic.drop_grads()                                                                  # :136 — every critic parameter receives a gradient below: the first writer overwrites (no fill)
     with torch.no_grad():
         fake_image = generator(noise, real_class_labels)                                 # :142
         real_c, fake_c = real_images.contiguous(), fake_image.contiguous()
@@ -421,7 +421,7 @@ def critic_step(critic, generator, critic_optimizer, hp, real_images, real_class
 def generator_step(critic, generator, generator_optimizer, fake_class_labels, noise, dp=None, skip_dead_critic_wgrad=True):
     """:157-168 (labels :161 and noise :162 supplied).  skip_dead_critic_wgrad: the reference also accumulates the critic's
     weight gradients here and zeroes them at the next :136 without using them."""
-    generator_optimizer.zero_grad()                                                      # :159
+    generator.drop_grads()                                                               # :159 — every generator parameter receives a gradient in this backward
     if skip_dead_critic_wgrad:
         for p in critic.parameters():
             p.requires_grad_(False)
