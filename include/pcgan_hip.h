@@ -584,6 +584,9 @@ int pcg_instnorm_bwd_bwd_act(const float* r, const float* dy, const float* x, in
                              float* dgamma_partial, pcg_stream_t stream);
 /* nn.Flatten of an NCHW tensor (:96) from the NHWC activation, flat[b][c*HW + p] = act[b][p][c]; inverse != 0: the other way */
 int pcg_nhwc_to_nchw_flat(const float* src, float* dst, int32_t B, int32_t HW, int32_t C, int inverse, pcg_stream_t stream);
+/* x3 = [real | fake | alpha*real + (1-alpha)*fake] (3B samples): the input of the batched critic pass in one launch (r04) */
+int pcg_interpolate_stack(const float* alpha, const float* real, const float* fake, float* x3, int32_t B, int32_t per_sample,
+                          pcg_stream_t stream);
 /* interpolates = alpha*real + (1-alpha)*fake, alpha per sample (:147) */
 int pcg_interpolate(const float* alpha, const float* real, const float* fake, float* out, int32_t B, int32_t per_sample,
                     pcg_stream_t stream);

@@ -211,6 +211,7 @@ PROTOTYPES = {
     "pcg_rowsum3": (_i, [_i32, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i32, _i32, _vp]),
     "pcg_nhwc_to_nchw_flat": (_i, [_vp, _vp, _i32, _i32, _i32, _i, _vp]),
     "pcg_interpolate": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "pcg_interpolate_stack": (_i, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "pcg_gradient_penalty_fwd": (_i, [_vp, _i32, _i32, _f, _vp, _vp, _vp]),
     "pcg_gradient_penalty_bwd": (_i, [_vp, _vp, _vp, _i32, _i32, _f, _vp, _vp]),
     "pcg_rand_uniform": (_i, [_vp, _i64, _c.c_uint64, _c.c_uint64, _vp]),

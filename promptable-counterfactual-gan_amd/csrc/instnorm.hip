@@ -300,6 +300,17 @@ __global__ void __launch_bounds__(256) interpolate_kernel(const float* __restric
   }
 }
 
+// the batched critic pass's input in one launch (r04): x3 = [real | fake | alpha*real + (1-alpha)*fake], B samples each — the
+// interpolation and the two staging copies of torch.cat
+__global__ void __launch_bounds__(256) interpolate_stack_kernel(const float* __restrict__ alpha, const float* __restrict__ real,
+                                                                const float* __restrict__ fake, float* __restrict__ x3, int per_sample,
+                                                                size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float a = alpha[i / per_sample], r = real[i], f = fake[i];
+    x3[i] = r; x3[n + i] = f; x3[2 * n + i] = a * r + (1.f - a) * f;
+  }
+}
+
 // gradient penalty (:150): pen = lambda * mean_b (||g_b|| - 1)^2; one block per sample computes the norm; dpen/dg_b =
 // grad_out * 2*lambda/B * (||g_b|| - 1) * g_b / ||g_b||
 __global__ void __launch_bounds__(256) row_norm_kernel(const float* __restrict__ g, int per_sample, float* __restrict__ norms) {
@@ -709,6 +720,13 @@ extern "C" int pcg_nhwc_to_nchw_flat(const float* src, float* dst, int32_t B, in
   return launch_status("nhwc_to_nchw_flat_kernel");
 }
 
+extern "C" int pcg_interpolate_stack(const float* alpha, const float* real, const float* fake, float* x3, int32_t B, int32_t per_sample,
+                                     pcg_stream_t stream) {
+  PCG_REQUIRE(alpha && real && fake && x3 && B > 0 && per_sample > 0, "pcg_interpolate_stack: bad arguments");
+  const size_t n = (size_t)B * per_sample;
+  hipLaunchKernelGGL(interpolate_stack_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, alpha, real, fake, x3, per_sample, n);
+  return launch_status("interpolate_stack_kernel");
+}
 extern "C" int pcg_interpolate(const float* alpha, const float* real, const float* fake, float* out, int32_t B, int32_t per_sample,
                                pcg_stream_t stream) {
   PCG_REQUIRE(alpha && real && fake && out && B > 0 && per_sample > 0, "pcg_interpolate: bad arguments");

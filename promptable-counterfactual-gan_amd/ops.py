@@ -1367,6 +1367,16 @@ def interpolate(alpha, real, fake):
     return out
 
 
+def interpolate_stack(alpha, real, fake):
+    """[real | fake | alpha*real + (1-alpha)*fake] as one [3B, ...] tensor, one launch (the batched critic pass's input)."""
+    _chk(alpha, "alpha"); _chk(real, "real"); _chk(fake, "fake")
+    B = alpha.numel()
+    assert real.shape == fake.shape and real.shape[0] == B
+    x3 = torch.empty((3 * B,) + tuple(real.shape[1:]), dtype=torch.float32, device=real.device)
+    check(_lib.load().pcg_interpolate_stack(_p(alpha), _p(real), _p(fake), _p(x3), B, real.numel() // B, _stream()), "pcg_interpolate_stack")
+    return x3
+
+
 def gradient_penalty_fwd(grads, B, lam):
     _chk(grads, "grads")
     norms = torch.empty(B, dtype=torch.float32, device=grads.device)

@@ -368,8 +368,7 @@ def critic_step_batched(critic, generator, critic_optimizer, hp, real_images, re
     with torch.no_grad():
         fake_image = generator(noise, real_class_labels)                                 # :142
         real_c, fake_c = real_images.contiguous(), fake_image.contiguous()
-        interpolates = ops.interpolate(alpha.contiguous(), real_c, fake_c)               # :147
-        x3 = torch.cat([real_c, fake_c, interpolates], 0)                                # batch-major staging copies (2.4 MB at B=256)
+        x3 = ops.interpolate_stack(alpha.contiguous(), real_c, fake_c)                   # :147 and the batch-major staging of the three passes, one launch
         c3 = torch.cat([real_class_labels] * 3, 0).contiguous()
         out3, saved = critic._run_forward(x3, c3, keep=True)                             # :138, :143, :148 in one pass
         loss_real, loss_fake = ops.mean_fwd(out3[:B].contiguous()), ops.mean_fwd(out3[B:2 * B].contiguous())   # :139, :144
