@@ -690,16 +690,18 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     q.npix = p.B * p.WH * p.WW;  // stage 1 walks the wide tensor
     unsigned blocks = (unsigned)((q.npix + 15) / 16);
     if (blocks > 8192) blocks = 8192;
+    uint32_t plane = 0;      // tap-major T (planes of q.npix floats) behind the matrix-core form, pixel-major rows behind the vector kernels
     if (p.C == 64 && (((uintptr_t)p.wide) & 15) == 0) {   // the matrix-core form: two 16-output column blocks
       unsigned mb = (unsigned)((q.npix + 127) / 128);
       if (mb > 4096) mb = 4096;
       hipLaunchKernelGGL((thin_tapdot64_mfma_kernel<2, false>), dim3(mb), dim3(256), 0, s, q, T);
+      plane = (uint32_t)q.npix;
     } else if (p.Cs == 2) hipLaunchKernelGGL(thin_tapdot32_kernel<18>, dim3(blocks), dim3(256), smem, s, q, T);
     else hipLaunchKernelGGL(thin_tapdot32_kernel<27>, dim3(blocks), dim3(256), smem, s, q, T);
     if (int e = launch_status("thin_tapdot32_kernel")) return e;
     unsigned b2 = (unsigned)(((int64_t)p.npix * p.Cs + 255) / 256);
     if (b2 > 8192) b2 = 8192;
-    hipLaunchKernelGGL(thin_col2im32_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need);
+    hipLaunchKernelGGL(thin_col2im32_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need, plane);
     return launch_status("thin_col2im32_kernel");
   }
   if (need && ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0) {
@@ -710,6 +712,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     if (blocks > 8192) blocks = 8192;
     const int nt = p.KH * p.KW;
     const bool mfma1 = p.C == 64, mfmaN = p.C % 64 == 0 && p.C > 64 && p.C <= TD64_MAX_C;
+    uint32_t plane = 0;
     PCG_REQUIRE(!p.xf_scale || ((mfma1 || mfmaN) && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0), "thin conv: an input transform needs the matrix-core tap-dot form");
     if ((mfma1 || mfmaN) && nt <= 16 && (((uintptr_t)p.wide) & 15) == 0) {
       unsigned mb = (unsigned)((q.npix + 127) / 128);
@@ -719,6 +722,7 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
         if (mb > 1024) mb = 1024;     // (every block stages the filter image once)
         hipLaunchKernelGGL((thin_tapdot64_mfma_kernel<1, true>), dim3(mb), dim3(256), (size_t)16 * (p.C + 4) * sizeof(float), s, q, T);
       }
+      plane = (uint32_t)q.npix;
     } else if (nt == 16) hipLaunchKernelGGL(thin_tapdot_kernel<16>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 9) hipLaunchKernelGGL(thin_tapdot_kernel<9>, dim3(blocks), dim3(256), smem, s, q, T);
     else if (nt == 1) hipLaunchKernelGGL(thin_tapdot_kernel<1>, dim3(blocks), dim3(256), smem, s, q, T);
@@ -727,12 +731,12 @@ int launch_reduce(ThinP& p, void* ws, size_t ws_bytes, hipStream_t s) {
     if (p.transposed && p.stride == 2 && p.KH == 4 && p.KW == 4 && p.IW_ % 4 == 0 && (((uintptr_t)p.out) & 15) == 0) {
       unsigned b4 = (unsigned)((p.npix / 4 + 255) / 256);
       if (b4 > 8192) b4 = 8192;
-      hipLaunchKernelGGL(thin_col2im_s2k4_kernel, dim3(b4), dim3(256), 0, s, p, (const float*)T, (uint32_t)need);
+      hipLaunchKernelGGL(thin_col2im_s2k4_kernel, dim3(b4), dim3(256), 0, s, p, (const float*)T, (uint32_t)need, plane);
       return launch_status("thin_col2im_s2k4_kernel");
     }
     unsigned b2 = (unsigned)((p.npix + 255) / 256);
     if (b2 > 8192) b2 = 8192;
-    hipLaunchKernelGGL(thin_col2im_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need);
+    hipLaunchKernelGGL(thin_col2im_kernel, dim3(b2), dim3(256), 0, s, p, (const float*)T, (uint32_t)need, plane);
     return launch_status("thin_col2im_kernel");
   }
 generic:
