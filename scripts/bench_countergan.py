@@ -70,6 +70,9 @@ def main(argv=None):
         return gs.replay()
 
     sampled_now = set()
+    if gs is not None and args.warmup > 0:
+        eager(0)       # untimed: the event-sampled timed step runs eagerly on THIS stream — its activations come out of the caching allocator's
+                       # pool of this stream, which only an eager step fills (r04: a cold pool cost one timed step +10 ms of hipMalloc)
     for i in range(args.warmup):
         step(i)
     sampled_now = sampled

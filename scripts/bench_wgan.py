@@ -55,6 +55,8 @@ def main(argv=None):
         return gs.generator_step(fake, noise)
 
     def measure(fn):
+        if gs is not None and args.warmup > 0:
+            fn(0, eager=True)       # untimed: fills this stream's allocator pool for the event-sampled eager update (see bench_countergan.py)
         for i in range(args.warmup):
             fn(i)
         mid = args.steps // 2
