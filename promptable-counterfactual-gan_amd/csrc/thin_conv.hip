@@ -627,10 +627,12 @@ int launch_expand(ThinP& p, hipStream_t s) {
     const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
     const unsigned blocks = rows_expand_blocks(rp.nunits);
     static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch
-    if (mfma_on && p.Cs == 1 && p.C == 64 && !p.mask_src && (((uintptr_t)p.out) & 15) == 0) {     // one thin channel, 64 wide channels: the matrix-core form
+    if (mfma_on && p.C == 64 && !p.mask_src && (((uintptr_t)p.out) & 15) == 0) {     // 64 wide channels, at most 32 (tap, thin channel) pairs: the matrix-core form
       const size_t sm2 = 2 * ((patch_bytes + 15) & ~(size_t)15);
-      if (k44) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<4, 4>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
-      else hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      if (k44) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<4, 4, 1>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      else if (p.Cs == 1) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3, 1>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      else if (p.Cs == 2) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3, 2>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
+      else hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3, 3>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
       return launch_status("thin_rows_expand_mfma_kernel");
     }
 #define PCG_ROWS_EXPAND_CASE(KH_, KW_, CS_)                                                                                  \
@@ -1055,10 +1057,12 @@ int thin_conv_wgrad(const pcg_conv_geom* g, const float* x, const float* dy, flo
     const int upb = (rp.nunits + nslabs - 1) / nslabs;
     const int nb = (rp.nunits + upb - 1) / upb;      // blocks that own at least one unit (<= nslabs)
     static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch (with the expand forms')
-    if (mfma_on && p.Cs == 1 && p.C == 64 && (g->KH == 4 || g->KH == 3) && (((uintptr_t)p.wide) & 3) == 0) {      // the matrix-core form
+    if (mfma_on && p.C == 64 && ((g->KH == 4 && p.Cs == 1) || g->KH == 3) && (((uintptr_t)p.wide) & 3) == 0) {      // the matrix-core form
       const size_t sm2 = 2 * ((patch_bytes + 15) & ~(size_t)15);
-      if (g->KH == 4) hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<4, 4>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
-      else hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<3, 3>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      if (g->KH == 4) hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<4, 4, 1>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      else if (p.Cs == 1) hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<3, 3, 1>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      else if (p.Cs == 2) hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<3, 3, 2>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
+      else hipLaunchKernelGGL((thin_rows_wgrad_mfma_kernel<3, 3, 3>), dim3(nb), dim3(256), sm2, s, p, rp, slab, wn, upb, thin_bytes);
       if (int e = launch_status("thin_rows_wgrad_mfma_kernel")) return e;
       return launch_slab_reduce(slab, dw, (size_t)wn, (size_t)wn, nb, accumulate, s, true);
     }
