@@ -627,7 +627,7 @@ int launch_expand(ThinP& p, hipStream_t s) {
     const uint32_t thin_bytes = (uint32_t)((int64_t)p.B * p.TH * p.TW * p.Cs * 4);
     const unsigned blocks = rows_expand_blocks(rp.nunits);
     static const int mfma_on = [] { const char* e = getenv("PCG_EXPAND_MFMA"); return e ? atoi(e) : 1; }();      // A/B switch
-    if (mfma_on && p.C == 64 && !p.mask_src && (((uintptr_t)p.out) & 15) == 0) {     // 64 wide channels, at most 32 (tap, thin channel) pairs: the matrix-core form
+    if (mfma_on && p.C == 64 && (((uintptr_t)p.out | (uintptr_t)p.mask_src) & 15) == 0) {     // 64 wide channels, at most 32 (tap, thin channel) pairs: the matrix-core form
       const size_t sm2 = 2 * ((patch_bytes + 15) & ~(size_t)15);
       if (k44) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<4, 4, 1>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
       else if (p.Cs == 1) hipLaunchKernelGGL((thin_rows_expand_mfma_kernel<3, 3, 1>), dim3(blocks), dim3(256), sm2, s, p, rp, thin_bytes);
